@@ -1,0 +1,171 @@
+"""Device activation handle and the precision / allocation context.
+
+The reference's modules are single-sample functions `(C,H,W) -> ...` batched by the caller with
+`jax.vmap` (reference README.md:37-40).  Here the batch axis is physical from the start: an `Act`
+carries a torch device tensor whose leading axis is the batch (1 when the caller did not vmap)
+plus the *logical single-sample* view the reference code would see.
+
+Physical layouts in HBM:
+  kind "img": raw user images, NCHW [B,C,H,W], fp32 or bf16 (only at the network entry)
+  kind "map": feature maps, NHWC [B,H,W,C]  -- channel-contiguous so that the K axis of every
+              implicit GEMM is contiguous for 16-byte MFMA fragments
+  kind "seq": token / row matrices [B,N,D]
+  kind "vec": feature vectors [B,D]
+torch is used for device memory and streams only; every computation goes through the C ABI.
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_state = {"dtype": "bf16", "arena": None, "keep": None}
+
+DT = {"bf16": _lib.BF16, "fp32": _lib.F32}
+TORCH_DT = {"bf16": torch.bfloat16, "fp32": torch.float32}
+
+
+def compute_dtype() -> str:
+    return _state["dtype"]
+
+
+def set_compute_dtype(name: str):
+    """'bf16' (bf16 storage, fp32 accumulate/epilogue -- the MI355X headline path) or 'fp32'."""
+    if name not in DT:
+        raise ValueError(f"compute dtype must be 'bf16' or 'fp32', got {name!r}")
+    _state["dtype"] = name
+
+
+@contextlib.contextmanager
+def precision(name: str):
+    old = _state["dtype"]
+    set_compute_dtype(name)
+    try:
+        yield
+    finally:
+        _state["dtype"] = old
+
+
+def device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.MVError("eqxvision_amd needs an MI355X (no HIP device visible); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Arena:
+    """Bump allocator over one torch buffer: used while a forward is captured into a hipGraph so
+    that every intermediate has a stable address owned by the compiled function."""
+
+    def __init__(self, nbytes: int):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device())
+        self.off = 0
+        self.peak = 0
+
+    def alloc(self, shape, dtype: torch.dtype) -> torch.Tensor:
+        n = int(np.prod(shape)) if len(shape) else 1
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        start = (self.off + 255) & ~255
+        if start + nbytes > self.buf.numel():
+            raise _lib.MVError(f"capture arena exhausted ({self.buf.numel()} B); raise arena_bytes")
+        self.off = start + nbytes
+        self.peak = max(self.peak, self.off)
+        return self.buf[start:start + nbytes].view(dtype).view(*shape)
+
+
+def empty(shape, dtype: torch.dtype) -> torch.Tensor:
+    a = _state["arena"]
+    if a is not None:
+        return a.alloc(tuple(shape), dtype)
+    t = torch.empty(tuple(shape), dtype=dtype, device=device())
+    k = _state["keep"]
+    if k is not None:          # a recording owns every intermediate so replayed pointers stay valid
+        k.append(t)
+    return t
+
+
+@contextlib.contextmanager
+def keep_alive(lst):
+    old = _state["keep"]
+    _state["keep"] = lst
+    try:
+        yield
+    finally:
+        _state["keep"] = old
+
+
+@contextlib.contextmanager
+def use_arena(arena: Optional[Arena]):
+    old = _state["arena"]
+    _state["arena"] = arena
+    try:
+        yield
+    finally:
+        _state["arena"] = old
+
+
+class Act:
+    __slots__ = ("t", "kind", "batched")
+
+    def __init__(self, t: torch.Tensor, kind: str, batched: bool):
+        self.t = t
+        self.kind = kind
+        self.batched = batched
+
+    @property
+    def B(self) -> int:
+        return self.t.shape[0]
+
+    @property
+    def shape(self) -> Tuple[int, ...]:
+        """Logical single-sample shape, as the reference module code would see it."""
+        s = tuple(self.t.shape[1:])
+        if self.kind == "map":      # physical (H,W,C) -> logical (C,H,W)
+            return (s[2], s[0], s[1])
+        return s
+
+    @property
+    def dt(self) -> int:
+        return _lib.BF16 if self.t.dtype == torch.bfloat16 else _lib.F32
+
+    def __repr__(self):
+        return f"Act({self.kind}, logical={self.shape}, B={self.B}, {self.t.dtype}, batched={self.batched})"
+
+
+def _to_device_f32(x) -> torch.Tensor:
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.to(torch.float32)
+    return t.to(device(), non_blocking=True).contiguous()
+
+
+def wrap(x, batched: bool) -> Act:
+    """User array -> Act.  Rank (without the batch axis) picks the kind: 3 = image (C,H,W),
+    2 = rows (N,D), 1 = vector (D,)."""
+    if isinstance(x, Act):
+        return x
+    t = _to_device_f32(x)
+    if not batched:
+        t = t.unsqueeze(0)
+    r = t.dim() - 1
+    if r == 3:
+        return Act(t, "img", batched)
+    if r == 2:
+        return Act(t, "seq", batched)
+    if r == 1:
+        return Act(t, "vec", batched)
+    raise ValueError(f"unsupported input rank {r} (shape {tuple(t.shape)})")
+
+
+def is_act(x) -> bool:
+    return isinstance(x, Act)

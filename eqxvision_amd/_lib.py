@@ -1,0 +1,124 @@
+"""ctypes binding of the C ABI declared in `include/eqxvision_amd.h`.
+
+The shared library is built in-tree by `eqxvision_amd.build.build()` (hipcc, gfx950) into
+`eqxvision_amd/csrc/libeqxvision_amd.so`.  There is NO fallback: if the library is missing or
+a call fails, a `RuntimeError` is raised -- the product never computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libeqxvision_amd.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU_TANH = 0, 1, 2
+ABI_VERSION = 1
+
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+PROTOTYPES = {
+    "mv_abi_version": [],
+    "mv_last_error": [],
+    "mv_last_kernel": [],
+    "mv_set_flag": [C.c_char_p, _i],
+    "mv_get_flag": [C.c_char_p],
+    "mv_conv2d_nhwc_fwd": [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 14 + [_i, _i, _i, _vp],
+    "mv_conv2d_nchw_fwd": [_vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_i, _i, _i, _i, _i, _vp, _vp],
+    "mv_linear_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
+    "mv_maxpool2d_nhwc_fwd": [_vp, _vp] + [_i] * 10 + [_i, _vp],
+    "mv_adaptive_avgpool2d_nhwc_fwd": [_vp, _vp] + [_i] * 6 + [_i, _i, _vp],
+    "mv_layernorm_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp],
+    "mv_mha_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "mv_swin_window_attn_fwd": [_vp, _vp, _vp] + [_i] * 9 + [_i, _vp],
+    "mv_patch_merge_gather_nhwc": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mv_vit_cls_pos_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mv_eltwise_fwd": [_vp, _vp, _i64, _i, _i, _vp],
+    "mv_add_fwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
+    "mv_channel_affine_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "mv_nchw_to_nhwc": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "mv_nhwc_to_nchw": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "mv_cast": [_vp, _vp, _i64, _i, _i, _vp],
+    "mv_graph_begin_capture": [_vp],
+    "mv_graph_end_capture": [_vp, C.POINTER(_vp)],
+    "mv_graph_launch": [_vp, _vp],
+    "mv_graph_destroy": [_vp],
+    "mv_event_create": [C.POINTER(_vp)],
+    "mv_event_record": [_vp, _vp],
+    "mv_event_elapsed_ms": [_vp, _vp, C.POINTER(_f)],
+    "mv_event_destroy": [_vp],
+}
+_RESTYPES = {"mv_last_error": C.c_char_p, "mv_last_kernel": C.c_char_p}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class MVError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type the library.  Raises RuntimeError if it was never built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise MVError(
+                f"eqxvision_amd HIP library not built: {LIB_PATH} is missing. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError here == ABI mismatch, loud by design
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, _i)
+        if lib.mv_abi_version() != ABI_VERSION:
+            raise MVError(f"ABI mismatch: library {lib.mv_abi_version()} != binding {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+# When a forward is being recorded by `eqxvision_amd.filter_jit`, every kernel-enqueueing call is
+# appended here as (bound C function, argument tuple) so it can be replayed / graph-captured.
+_recording = None
+_NOT_RECORDED = ("mv_set_flag", "mv_graph_", "mv_event_")
+
+
+def set_recording(rec):
+    global _recording
+    old = _recording
+    _recording = rec
+    return old
+
+
+def call(name, *args):
+    lib = load()
+    fn = getattr(lib, name)
+    rc = fn(*args)
+    if rc != 0:
+        msg = lib.mv_last_error()
+        raise MVError(f"{name} failed (rc={rc}): {msg.decode() if msg else ''}")
+    if _recording is not None and not name.startswith(_NOT_RECORDED):
+        _recording.append((fn, args, name))
+    return rc
+
+
+def last_kernel() -> str:
+    s = load().mv_last_kernel()
+    return s.decode() if s else ""
+
+
+def set_flag(name: str, value: int):
+    call("mv_set_flag", name.encode(), int(value))
+
+
+def get_flag(name: str) -> int:
+    return load().mv_get_flag(name.encode())

@@ -1,0 +1,189 @@
+"""Minimal `eqx.Module` work-alike: dataclass-style pytrees without jax.
+
+The reference builds every layer/model as a frozen-dataclass `eqx.Module` whose
+pytree flatten order is the class-annotation order, depth first.  That order is
+the *contract* of `load_torch_weights` (reference `eqxvision/utils.py:172-199`),
+so this base class reproduces exactly that: fields = annotations in MRO order,
+`tree_flatten` walks them in declaration order, descending into Modules / lists /
+tuples / dicts.  Array leaves are host `numpy` arrays (the fp32 master copy);
+device-side copies (bf16, re-laid-out, BN-folded) are built lazily by
+`eqxvision_amd.ops` and cached on the module instance.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Any, Callable, List, Tuple
+
+import numpy as np
+
+
+class StateIndex:
+    """Stand-in for `eqx.experimental.StateIndex`: a mutable slot holding BatchNorm running
+    statistics outside the parameter leaves (reference utils.py:203-218)."""
+
+    __slots__ = ("value",)
+
+    def __init__(self, value=None):
+        self.value = value
+
+    def __repr__(self):
+        return f"StateIndex({'set' if self.value is not None else 'unset'})"
+
+
+class _ModuleMeta(type):
+    def __new__(mcls, name, bases, ns):
+        cls = super().__new__(mcls, name, bases, ns)
+        fields: List[str] = []
+        for klass in reversed(cls.__mro__):
+            for f in klass.__dict__.get("__annotations__", {}):
+                if f not in fields:
+                    fields.append(f)
+        cls.__fields__ = tuple(fields)
+        return cls
+
+
+class Module(metaclass=_ModuleMeta):
+    """Base class.  Sub-classes declare fields as class annotations and assign them in
+    `__init__`, like `eqx.Module`."""
+
+    __fields__: Tuple[str, ...] = ()
+
+    def __repr__(self):
+        inner = ", ".join(f"{f}={_short(getattr(self, f, None))}" for f in self.__fields__)
+        return f"{type(self).__name__}({inner})"
+
+    # a per-instance cache for device-side prepared weights (NOT a pytree field)
+    def _cache(self) -> dict:
+        c = self.__dict__.get("_dev_cache")
+        if c is None:
+            c = {}
+            object.__setattr__(self, "_dev_cache", c)
+        return c
+
+
+def _short(v):
+    if isinstance(v, np.ndarray):
+        return f"f{v.dtype.itemsize * 8}{list(v.shape)}"
+    if isinstance(v, (list, tuple)) and len(v) > 4:
+        return f"[{len(v)} items]"
+    return repr(v)
+
+
+def is_array(x) -> bool:
+    return isinstance(x, np.ndarray)
+
+
+def _children(node) -> List[Tuple[Any, Any]]:
+    """(key, child) pairs in flatten order for container nodes; None for leaves."""
+    if isinstance(node, Module):
+        return [(f, getattr(node, f)) for f in node.__fields__ if hasattr(node, f)]
+    if isinstance(node, (list, tuple)):
+        return list(enumerate(node))
+    if isinstance(node, dict):
+        return list(node.items())
+    return None
+
+
+def tree_leaves(tree) -> list:
+    """All leaves, depth-first in declaration order (== `jax.tree_util.tree_leaves` on the
+    reference's dataclass pytrees; `None` is not a leaf, like in jax)."""
+    out = []
+
+    def rec(n):
+        ch = _children(n)
+        if ch is None:
+            if n is not None:
+                out.append(n)
+            return
+        for _, c in ch:
+            rec(c)
+
+    rec(tree)
+    return out
+
+
+def _rebuild(n: "Module", rec: Callable, override: Callable = None) -> "Module":
+    """New instance of type(n): pytree fields rebuilt IN DECLARATION ORDER (the flatten order that
+    `load_torch_weights` relies on -- __init__ may assign them in any order), other attributes shared."""
+    new = object.__new__(type(n))
+    d = n.__dict__
+    for k in n.__fields__:
+        if k in d:
+            v = d[k]
+            object.__setattr__(new, k, override(k, v) if override is not None else rec(v))
+    for k, v in d.items():
+        if k not in n.__fields__ and k != "_dev_cache":
+            object.__setattr__(new, k, v)
+    return new
+
+
+def tree_map(fn: Callable, tree):
+    """Rebuild `tree` with `fn` applied to every leaf (new Module objects, caches dropped)."""
+
+    def rec(n):
+        if isinstance(n, Module):
+            return _rebuild(n, rec)
+        if isinstance(n, list):
+            return [rec(c) for c in n]
+        if isinstance(n, tuple):
+            return tuple(rec(c) for c in n)
+        if isinstance(n, dict):
+            return {k: rec(c) for k, c in n.items()}
+        if n is None:
+            return None
+        return fn(n)
+
+    return rec(tree)
+
+
+def tree_replace_leaves(tree, new_leaves: list):
+    it = iter(new_leaves)
+    out = tree_map(lambda _: next(it), tree)
+    return out
+
+
+def tree_inference(tree, value: bool = True):
+    """`eqx.tree_inference`: returns a copy with every field named `inference` set to `value`
+    (reference usage: tests/test_models/test_resnet.py:20, README.md:64)."""
+
+    def rec(n):
+        if isinstance(n, Module):
+            return _rebuild(n, rec, lambda k, v: value if k == "inference" else rec(v))
+        if isinstance(n, list):
+            return [rec(c) for c in n]
+        if isinstance(n, tuple):
+            return tuple(rec(c) for c in n)
+        if isinstance(n, dict):
+            return {k: rec(c) for k, c in n.items()}
+        return n      # leaves (arrays, StateIndex, callables, scalars) are shared, like in eqx
+
+    return rec(tree)
+
+
+def tree_at(where: Callable, tree, replace):
+    """Tiny `eqx.tree_at`: `where(tree)` must return one node (or a tuple of nodes); the
+    returned tree has them replaced.  Implemented by identity search on a deep structural copy."""
+    targets = where(tree)
+    single = not isinstance(targets, tuple)
+    targets = (targets,) if single else targets
+    repl = (replace,) if single else tuple(replace)
+    ids = {id(t): r for t, r in zip(targets, repl)}
+
+    def rec(n):
+        if id(n) in ids:
+            return ids[id(n)]
+        if isinstance(n, Module):
+            return _rebuild(n, rec)
+        if isinstance(n, list):
+            return [rec(c) for c in n]
+        if isinstance(n, tuple):
+            return tuple(rec(c) for c in n)
+        if isinstance(n, dict):
+            return {k: rec(c) for k, c in n.items()}
+        return n
+
+    return rec(tree)
+
+
+def clone(tree):
+    return tree_map(lambda x: copy.copy(x) if isinstance(x, StateIndex) else x, tree)

@@ -1,0 +1,105 @@
+// Shared device/host helpers for the gfx950 kernels.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/eqxvision_amd.h"
+
+namespace mv {
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even fp32 -> bf16 (NaN stays NaN)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T> struct io;
+template <> struct io<float> {
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct io<bf16_t> {
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    // jax.nn.gelu(approximate=True): 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    // tanh(u) = 1 - 2/(exp(2u)+1); stable for large |u|
+    float e = __expf(2.0f * u);
+    float t = 1.0f - 2.0f / (e + 1.0f);
+    return 0.5f * x * (1.0f + t);
+}
+
+template <int ACT> __device__ __forceinline__ float apply_act(float v) {
+    if (ACT == MV_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == MV_ACT_GELU_TANH) return gelu_tanh_f(v);
+    return v;
+}
+__device__ __forceinline__ float apply_act_rt(float v, int act) {
+    if (act == MV_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == MV_ACT_GELU_TANH) return gelu_tanh_f(v);
+    return v;
+}
+
+// ---- host side ------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+void set_kernel_name(const char* name);
+int get_flag(const char* name);
+const void* zero_page(hipStream_t stream);  // >= 4 KiB of device zeros for the current device
+
+inline size_t dsize(int dt) { return dt == MV_BF16 ? 2 : 4; }
+
+#define MV_CHECK_ARG(cond, ...)                      \
+    do {                                             \
+        if (!(cond)) {                               \
+            mv::set_error(__VA_ARGS__);              \
+            return MV_E_INVALID;                     \
+        }                                            \
+    } while (0)
+
+#define MV_LAUNCH_CHECK()                                                            \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            mv::set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return (int)e__;                                                         \
+        }                                                                            \
+    } while (0)
+
+#define MV_HIP(call)                                                                 \
+    do {                                                                             \
+        hipError_t e__ = (call);                                                     \
+        if (e__ != hipSuccess) {                                                     \
+            mv::set_error("%s:%d %s: %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return (int)e__;                                                         \
+        }                                                                            \
+    } while (0)
+
+// dispatch helpers implemented in the kernel translation units
+int igemm_supported(int C, int K, int R, int S, int groups, int in_dtype, int out_dtype);
+int igemm_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
+                 void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
+                 int dh, int dw, int act, int in_dtype, int out_dtype, hipStream_t stream);
+int stem_supported(int C, int K, int R, int S, int x_dtype, int out_dtype);
+int stem_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
+                int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act, int x_dtype,
+                int out_dtype, int tok_stride, int tok_offset, const float* pos, hipStream_t stream);
+int mha_mfma_supported(int N, int dh, int dtype);
+int mha_mfma_launch(const void* qkv, void* out, float* probs, int B, int N, int H, int dh, float scale,
+                    hipStream_t stream);
+
+}  // namespace mv

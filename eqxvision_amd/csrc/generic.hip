@@ -1,0 +1,828 @@
+// Shape-agnostic VALU kernels (any size, f32 or bf16) + the memory-bound ops (pooling,
+// LayerNorm, layout converters) + the C-ABI entry points that dispatch between these and the
+// MFMA kernels in igemm.hip / stem.hip / attn.hip.
+//
+// The contraction kernels here are the "any shape" path (odd channel counts such as the
+// MlpProjection(20,5,10) of the reference's tests/test_layers.py:25-40) and the on-device
+// cross-check for the MFMA kernels (flag "force_generic").  They are NOT the fast path.
+#include "common.h"
+
+namespace mv {
+
+// ------------------------------------------------------------------------------------------
+// direct convolution, one thread per (output row, output channel); x/w addressed by strides so
+// the same kernel serves NHWC activations + KRSC weights and NCHW images + OIHW weights.
+// ------------------------------------------------------------------------------------------
+struct ConvP {
+    int N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw, groups;
+    long long sxn, sxc, sxh, sxw;  // x strides (elements)
+    long long swk, swc, swr, sws;  // w strides (elements)
+    int act, tok_stride, tok_offset;
+};
+
+template <typename TX, typename TW, typename TY>
+__global__ void conv_generic_kernel(const TX* __restrict__ x, const TW* __restrict__ w,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const TY* __restrict__ residual, TY* __restrict__ y,
+                                    const float* __restrict__ pos, ConvP p) {
+    const int k = blockIdx.y * blockDim.x + threadIdx.x;
+    const long long m = (long long)blockIdx.x * blockDim.y + threadIdx.y;
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    if (k >= p.K || m >= M) return;
+    const int wo = (int)(m % p.Wo);
+    const int ho = (int)((m / p.Wo) % p.Ho);
+    const int n = (int)(m / ((long long)p.Wo * p.Ho));
+    const int Cg = p.C / p.groups, Kg = p.K / p.groups;
+    const int g = k / Kg;
+    float acc = 0.f;
+    for (int r = 0; r < p.R; ++r) {
+        const int hi = ho * p.sh - p.ph + r * p.dh;
+        if (hi < 0 || hi >= p.H) continue;
+        for (int s = 0; s < p.S; ++s) {
+            const int wi = wo * p.sw - p.pw + s * p.dw;
+            if (wi < 0 || wi >= p.W) continue;
+            const TX* xp = x + n * p.sxn + hi * p.sxh + wi * p.sxw + (long long)(g * Cg) * p.sxc;
+            const TW* wp = w + k * p.swk + r * p.swr + s * p.sws;
+            for (int c = 0; c < Cg; ++c) acc = fmaf(io<TX>::ld(xp + c * p.sxc), io<TW>::ld(wp + c * p.swc), acc);
+        }
+    }
+    float v = acc;
+    if (scale) v *= scale[k];
+    if (shift) v += shift[k];
+    long long row = m;
+    if (p.tok_stride > 0) {
+        const int pix = ho * p.Wo + wo;
+        row = (long long)n * p.tok_stride + p.tok_offset + pix;
+        if (pos) v += pos[(long long)(p.tok_offset + pix) * p.K + k];
+    }
+    if (residual) v += io<TY>::ld(residual + row * p.K + k);
+    v = apply_act_rt(v, p.act);
+    io<TY>::st(y + row * p.K + k, v);
+}
+
+template <typename TX, typename TW, typename TY>
+static int conv_generic_launch(const void* x, const void* w, const float* scale, const float* shift,
+                               const void* residual, void* y, const float* pos, const ConvP& p, hipStream_t st) {
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    dim3 block(64, 4);
+    dim3 grid((unsigned)((M + 3) / 4), (p.K + 63) / 64);
+    hipLaunchKernelGGL((conv_generic_kernel<TX, TW, TY>), grid, block, 0, st, (const TX*)x, (const TW*)w, scale, shift,
+                       (const TY*)residual, (TY*)y, pos, p);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+static int conv_generic_dispatch(const void* x, const void* w, const float* scale, const float* shift,
+                                 const void* residual, void* y, const float* pos, const ConvP& p, int x_dtype,
+                                 int w_dtype, int y_dtype, hipStream_t st) {
+    set_kernel_name("conv_generic");
+#define GO(TX, TW, TY) return conv_generic_launch<TX, TW, TY>(x, w, scale, shift, residual, y, pos, p, st)
+    if (x_dtype == MV_F32 && w_dtype == MV_F32 && y_dtype == MV_F32) GO(float, float, float);
+    if (x_dtype == MV_BF16 && w_dtype == MV_BF16 && y_dtype == MV_BF16) GO(bf16_t, bf16_t, bf16_t);
+    if (x_dtype == MV_BF16 && w_dtype == MV_BF16 && y_dtype == MV_F32) GO(bf16_t, bf16_t, float);
+    if (x_dtype == MV_F32 && w_dtype == MV_BF16 && y_dtype == MV_BF16) GO(float, bf16_t, bf16_t);
+    if (x_dtype == MV_F32 && w_dtype == MV_F32 && y_dtype == MV_BF16) GO(float, float, bf16_t);
+#undef GO
+    set_error("conv: unsupported dtype combination x=%d w=%d y=%d", x_dtype, w_dtype, y_dtype);
+    return MV_E_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------
+// attention, one wave per (b, h, query)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <typename T>
+__global__ void mha_generic_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ probs, int B,
+                                   int N, int H, int dh, float scale) {
+    extern __shared__ float sm[];  // [N] scores + [dh] q
+    float* sc = sm;
+    float* qs = sm + N;
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x;
+    const long long rs = 3LL * H * dh;  // row stride of qkv
+    const T* qrow = qkv + ((long long)b * N + i) * rs + h * dh;
+    for (int d = lane; d < dh; d += 64) qs[d] = io<T>::ld(qrow + d);
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = lane; j < N; j += 64) {
+        const T* krow = qkv + ((long long)b * N + j) * rs + (long long)H * dh + h * dh;
+        float s = 0.f;
+        for (int d = 0; d < dh; ++d) s = fmaf(qs[d], io<T>::ld(krow + d), s);
+        s *= scale;
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < N; j += 64) {
+        float e = __expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    const float inv = 1.f / sum;
+    if (probs) {
+        float* pr = probs + (((long long)b * H + h) * N + i) * N;
+        for (int j = lane; j < N; j += 64) pr[j] = sc[j] * inv;
+    }
+    for (int d = lane; d < dh; d += 64) {
+        float o = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const T* vrow = qkv + ((long long)b * N + j) * rs + 2LL * H * dh + h * dh;
+            o = fmaf(sc[j], io<T>::ld(vrow + d), o);
+        }
+        io<T>::st(out + ((long long)b * N + i) * H * dh + h * dh + d, o * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Swin shifted-window attention core (swin.py:123-250), one wave per (query token, head)
+// qkv NHWC [B,Hf,Wf,3C] with channel order [q|k|v][head][dh]; roll / partition / reverse / mask
+// are index arithmetic.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void swin_attn_generic_kernel(const T* __restrict__ qkv, const float* __restrict__ bias,
+                                         T* __restrict__ out, int B, int Hf, int Wf, int C, int heads, int wsh,
+                                         int wsw, int shh, int shw) {
+    extern __shared__ float sm[];  // [n] probs + [dh] q
+    const int n = wsh * wsw;
+    const int dh = C / heads;
+    float* sc = sm;
+    float* qs = sm + n;
+    const int nWw = Wf / wsw, nWh = Hf / wsh;
+    int t = blockIdx.x;                  // token index within window-major order
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x;
+    const int win = t / n, ti = t % n;
+    const int wy = win / nWw, wx = win % nWw;
+    (void)nWh;
+    // rolled coordinates of the query
+    const int qy = wy * wsh + ti / wsw, qx = wx * wsw + ti % wsw;
+    const int oy = (qy + shh) % Hf, ox = (qx + shw) % Wf;  // np.roll(x,-s)[i] = x[(i+s)%n]
+    const long long rs = 3LL * C;
+    const T* qrow = qkv + (((long long)b * Hf + oy) * Wf + ox) * rs + h * dh;
+    const float qscale = rsqrtf((float)dh);
+    for (int d = lane; d < dh; d += 64) qs[d] = io<T>::ld(qrow + d) * qscale;
+    __syncthreads();
+    const bool shifted = (shh + shw) > 0;
+    auto region = [&](int y, int x) {
+        int rh = (y < Hf - wsh) ? 0 : (y < Hf - shh ? 1 : 2);
+        int rw = (x < Wf - wsw) ? 0 : (x < Wf - shw ? 1 : 2);
+        return rh * 3 + rw;
+    };
+    const int qreg = region(qy, qx);
+    float mx = -INFINITY;
+    for (int j = lane; j < n; j += 64) {
+        const int ky = wy * wsh + j / wsw, kx = wx * wsw + j % wsw;
+        const int yy = (ky + shh) % Hf, xx = (kx + shw) % Wf;
+        const T* krow = qkv + (((long long)b * Hf + yy) * Wf + xx) * rs + C + h * dh;
+        float s = 0.f;
+        for (int d = 0; d < dh; ++d) s = fmaf(qs[d], io<T>::ld(krow + d), s);
+        s += bias[((long long)h * n + ti) * n + j];
+        if (shifted && region(ky, kx) != qreg) s += -100.0f;
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < n; j += 64) {
+        float e = __expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    const float inv = 1.f / sum;
+    for (int d = lane; d < dh; d += 64) {
+        float o = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const int ky = wy * wsh + j / wsw, kx = wx * wsw + j % wsw;
+            const int yy = (ky + shh) % Hf, xx = (kx + shw) % Wf;
+            const T* vrow = qkv + (((long long)b * Hf + yy) * Wf + xx) * rs + 2 * C + h * dh;
+            o = fmaf(sc[j], io<T>::ld(vrow + d), o);
+        }
+        io<T>::st(out + (((long long)b * Hf + oy) * Wf + ox) * C + h * dh + d, o * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// memory-bound ops
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int Ho,
+                                    int Wo, int kh, int kw, int sh, int sw, int ph, int pw) {
+    const long long total = (long long)N * Ho * Wo * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long m = i / C;
+        const int wo = (int)(m % Wo);
+        m /= Wo;
+        const int ho = (int)(m % Ho);
+        const int n = (int)(m / Ho);
+        float best = -INFINITY;
+        for (int r = 0; r < kh; ++r) {
+            const int hi = ho * sh - ph + r;
+            if (hi < 0 || hi >= H) continue;
+            for (int s = 0; s < kw; ++s) {
+                const int wi = wo * sw - pw + s;
+                if (wi < 0 || wi >= W) continue;
+                best = fmaxf(best, io<T>::ld(x + (((long long)n * H + hi) * W + wi) * C + c));
+            }
+        }
+        io<T>::st(y + i, best);
+    }
+}
+
+// 8 bf16 channels per thread (16-byte loads/stores), C % 8 == 0
+__global__ void maxpool_nhwc_bf16x8_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, int H, int W,
+                                           int C8, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw) {
+    const long long total = (long long)N * Ho * Wo * C8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        long long m = i / C8;
+        const int wo = (int)(m % Wo);
+        m /= Wo;
+        const int ho = (int)(m % Ho);
+        const int n = (int)(m / Ho);
+        float best[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+        for (int r = 0; r < kh; ++r) {
+            const int hi = ho * sh - ph + r;
+            if (hi < 0 || hi >= H) continue;
+            for (int s = 0; s < kw; ++s) {
+                const int wi = wo * sw - pw + s;
+                if (wi < 0 || wi >= W) continue;
+                const uint4 v = x[(((long long)n * H + hi) * W + wi) * C8 + c];
+                const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    best[2 * e] = fmaxf(best[2 * e], __uint_as_float(u[e] << 16));
+                    best[2 * e + 1] = fmaxf(best[2 * e + 1], __uint_as_float(u[e] & 0xffff0000u));
+                }
+            }
+        }
+        uint4 o;
+        // inputs are exact bf16 values, max is exact: truncation == rounding
+        o.x = (__float_as_uint(best[0]) >> 16) | (__float_as_uint(best[1]) & 0xffff0000u);
+        o.y = (__float_as_uint(best[2]) >> 16) | (__float_as_uint(best[3]) & 0xffff0000u);
+        o.z = (__float_as_uint(best[4]) >> 16) | (__float_as_uint(best[5]) & 0xffff0000u);
+        o.w = (__float_as_uint(best[6]) >> 16) | (__float_as_uint(best[7]) & 0xffff0000u);
+        y[i] = o;
+    }
+}
+
+__device__ __forceinline__ void adaptive_bounds(int n, int t, int i, int& lo, int& hi) {
+    // equinox AdaptiveAvgPool rule
+    if (n % t == 0) {
+        const int k = n / t;
+        lo = i * k;
+        hi = lo + k;
+    } else {
+        const int big = n % t, k = n / t;
+        if (i < big) {
+            lo = i * (k + 1);
+            hi = lo + k + 1;
+        } else {
+            lo = big * (k + 1) + (i - big) * k;
+            hi = lo + k;
+        }
+    }
+}
+
+template <typename TI, typename TO>
+__global__ void adaptive_avgpool_nhwc_kernel(const TI* __restrict__ x, TO* __restrict__ y, int N, int H, int W,
+                                             int C, int oh, int ow) {
+    const long long total = (long long)N * oh * ow * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long m = i / C;
+        const int j = (int)(m % ow);
+        m /= ow;
+        const int ii = (int)(m % oh);
+        const int n = (int)(m / oh);
+        int h0, h1, w0, w1;
+        adaptive_bounds(H, oh, ii, h0, h1);
+        adaptive_bounds(W, ow, j, w0, w1);
+        float s = 0.f;
+        for (int hh = h0; hh < h1; ++hh)
+            for (int ww = w0; ww < w1; ++ww) s += io<TI>::ld(x + (((long long)n * H + hh) * W + ww) * C + c);
+        io<TO>::st(y + i, s / (float)((h1 - h0) * (w1 - w0)));
+    }
+}
+
+// LayerNorm: one wave per row, two-pass in registers/LDS-free (row re-read from L1/L2).
+template <typename TI, typename TO>
+__global__ void layernorm_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, TO* __restrict__ y, long long M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const TI* xr = x + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += io<TI>::ld(xr + c);
+    const float mean = wave_sum(s) / (float)C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = io<TI>::ld(xr + c) - mean;
+        v += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
+    TO* yr = y + row * C;
+    for (int c = lane; c < C; c += 64) {
+        float o = (io<TI>::ld(xr + c) - mean) * rstd;
+        if (gamma) o *= gamma[c];
+        if (beta) o += beta[c];
+        io<TO>::st(yr + c, o);
+    }
+}
+
+// bf16 rows with C % 8 == 0 and C <= 64*8*4: whole row held in registers, 16-byte accesses.
+template <int CHUNKS>
+__global__ void layernorm_bf16x8_kernel(const uint4* __restrict__ x, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, uint4* __restrict__ y, long long M, int C8,
+                                        float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const uint4* xr = x + row * C8;
+    float v[CHUNKS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CHUNKS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C8) {
+            const uint4 u = xr[c];
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[i][2 * e] = __uint_as_float(w[e] << 16);
+                v[i][2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+                s += v[i][2 * e] + v[i][2 * e + 1];
+            }
+        }
+    }
+    const float C = (float)(C8 * 8);
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CHUNKS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    uint4* yr = y + row * C8;
+#pragma unroll
+    for (int i = 0; i < CHUNKS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C8) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = (v[i][e] - mean) * rstd;
+                if (gamma) o[e] *= gamma[c * 8 + e];
+                if (beta) o[e] += beta[c * 8 + e];
+            }
+            uint4 r;
+            r.x = pack_bf2(o[0], o[1]);
+            r.y = pack_bf2(o[2], o[3]);
+            r.z = pack_bf2(o[4], o[5]);
+            r.w = pack_bf2(o[6], o[7]);
+            yr[c] = r;
+        }
+    }
+}
+
+template <typename T>
+__global__ void eltwise_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, int act) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        io<T>::st(y + i, apply_act_rt(io<T>::ld(x + i), act));
+}
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long long n,
+                           int act) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        io<T>::st(y + i, apply_act_rt(io<T>::ld(a + i) + io<T>::ld(b + i), act));
+}
+template <typename T>
+__global__ void channel_affine_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, T* __restrict__ y, long long rows, int C,
+                                      int act) {
+    const long long n = rows * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        float v = io<T>::ld(x + i);
+        if (scale) v *= scale[c];
+        if (shift) v += shift[c];
+        io<T>::st(y + i, apply_act_rt(v, act));
+    }
+}
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        io<TO>::st(y + i, io<TI>::ld(x + i));
+}
+
+// NCHW <-> NHWC through a 32x33 LDS tile over (C, HW) so both sides stay coalesced.
+template <typename TI, typename TO, bool TO_NHWC>
+__global__ void layout_kernel(const TI* __restrict__ x, TO* __restrict__ y, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
+    const TI* xs = x + (long long)n * C * HW;
+    TO* ys = y + (long long)n * C * HW;
+    if (TO_NHWC) {  // read [c][p] rows (p contiguous), write [p][c] rows (c contiguous)
+        for (int j = ty; j < 32; j += 8) {
+            const int c = c0 + j, p = p0 + tx;
+            if (c < C && p < HW) tile[j][tx] = io<TI>::ld(xs + (long long)c * HW + p);
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int p = p0 + j, c = c0 + tx;
+            if (c < C && p < HW) io<TO>::st(ys + (long long)p * C + c, tile[tx][j]);
+        }
+    } else {
+        for (int j = ty; j < 32; j += 8) {
+            const int p = p0 + j, c = c0 + tx;
+            if (c < C && p < HW) tile[j][tx] = io<TI>::ld(xs + (long long)p * C + c);
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int c = c0 + j, p = p0 + tx;
+            if (c < C && p < HW) io<TO>::st(ys + (long long)c * HW + p, tile[tx][j]);
+        }
+    }
+}
+
+template <typename T>
+__global__ void cls_pos_kernel(const float* __restrict__ cls, const float* __restrict__ pos, T* __restrict__ tok,
+                               int B, int tok_stride, int D) {
+    const long long n = (long long)B * D;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int b = (int)(i / D);
+        io<T>::st(tok + (long long)b * tok_stride * D + d, cls[d] + pos[d]);
+    }
+}
+
+template <typename T>
+__global__ void patch_merge_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long n = (long long)B * Ho * Wo * 4 * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (4 * C));
+        long long m = i / (4 * C);
+        const int wo = (int)(m % Wo);
+        m /= Wo;
+        const int ho = (int)(m % Ho);
+        const int b = (int)(m / Ho);
+        const int q = c4 / C, c = c4 % C;
+        // block order [ (0::2,0::2) | (1::2,0::2) | (0::2,1::2) | (1::2,1::2) ]  (swin.py:26-30)
+        const int hi = 2 * ho + (q & 1), wi = 2 * wo + (q >> 1);
+        float v = 0.f;
+        if (hi < H && wi < W) v = io<T>::ld(x + (((long long)b * H + hi) * W + wi) * C + c);
+        io<T>::st(y + i, v);
+    }
+}
+
+static inline int grid_for(long long n, int block = 256) {
+    long long g = (n + block - 1) / block;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace mv
+
+using namespace mv;
+
+extern "C" {
+
+int mv_conv2d_nhwc_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
+                       void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
+                       int dh, int dw, int groups, int act, int in_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && w && y, "conv2d_nhwc: NULL pointer");
+    MV_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0, "conv2d_nhwc: non-positive dims");
+    MV_CHECK_ARG(sh > 0 && sw > 0 && dh > 0 && dw > 0 && ph >= 0 && pw >= 0, "conv2d_nhwc: bad stride/dilation/pad");
+    MV_CHECK_ARG(groups > 0 && C % groups == 0 && K % groups == 0, "conv2d_nhwc: C=%d K=%d not divisible by groups=%d",
+                 C, K, groups);
+    const int Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1;
+    const int Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
+    MV_CHECK_ARG(Ho > 0 && Wo > 0, "conv2d_nhwc: empty output (%d x %d)", Ho, Wo);
+    hipStream_t st = (hipStream_t)stream;
+    if (!get_flag("force_generic") && igemm_supported(C, K, R, S, groups, in_dtype, out_dtype))
+        return igemm_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, in_dtype,
+                            out_dtype, st);
+    ConvP p;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S; p.Ho = Ho; p.Wo = Wo;
+    p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw; p.groups = groups;
+    p.sxn = (long long)H * W * C; p.sxh = (long long)W * C; p.sxw = C; p.sxc = 1;
+    const int Cg = C / groups;
+    p.swk = (long long)R * S * Cg; p.swr = (long long)S * Cg; p.sws = Cg; p.swc = 1;
+    p.act = act; p.tok_stride = 0; p.tok_offset = 0;
+    return conv_generic_dispatch(x, w, scale, shift, residual, y, nullptr, p, in_dtype, in_dtype, out_dtype, st);
+}
+
+int mv_conv2d_nchw_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
+                       int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act, int x_dtype,
+                       int out_dtype, int tok_stride, int tok_offset, const float* pos, mv_stream_t stream) {
+    MV_CHECK_ARG(x && w && y, "conv2d_nchw: NULL pointer");
+    MV_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0, "conv2d_nchw: non-positive dims");
+    MV_CHECK_ARG(sh > 0 && sw > 0 && ph >= 0 && pw >= 0, "conv2d_nchw: bad stride/pad");
+    const int Ho = (H + 2 * ph - (R - 1) - 1) / sh + 1;
+    const int Wo = (W + 2 * pw - (S - 1) - 1) / sw + 1;
+    MV_CHECK_ARG(Ho > 0 && Wo > 0, "conv2d_nchw: empty output");
+    MV_CHECK_ARG(tok_stride == 0 || tok_stride >= tok_offset + Ho * Wo, "conv2d_nchw: tok_stride too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (!get_flag("force_generic") && stem_supported(C, K, R, S, x_dtype, out_dtype))
+        return stem_launch(x, w, scale, shift, y, N, C, H, W, K, R, S, sh, sw, ph, pw, act, x_dtype, out_dtype,
+                           tok_stride, tok_offset, pos, st);
+    ConvP p;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S; p.Ho = Ho; p.Wo = Wo;
+    p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = 1; p.dw = 1; p.groups = 1;
+    p.sxn = (long long)C * H * W; p.sxc = (long long)H * W; p.sxh = W; p.sxw = 1;
+    p.swk = (long long)C * R * S; p.swc = (long long)R * S; p.swr = S; p.sws = 1;
+    p.act = act; p.tok_stride = tok_stride; p.tok_offset = tok_offset;
+    return conv_generic_dispatch(x, w, scale, shift, nullptr, y, pos, p, x_dtype, out_dtype, out_dtype, st);
+}
+
+int mv_linear_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
+                  void* y, int64_t M, int N, int K, int act, int in_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && w && y, "linear: NULL pointer");
+    MV_CHECK_ARG(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear: bad dims M=%lld N=%d K=%d", (long long)M, N, K);
+    // a Linear over M rows is a 1x1 convolution over an M x 1 image
+    return mv_conv2d_nhwc_fwd(x, w, scale, shift, residual, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, 1, act,
+                              in_dtype, out_dtype, stream);
+}
+
+int mv_maxpool2d_nhwc_fwd(const void* x, void* y, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph,
+                          int pw, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0, "maxpool: bad args");
+    MV_CHECK_ARG(2 * ph <= kh && 2 * pw <= kw, "maxpool: padding larger than half the window");
+    const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+    MV_CHECK_ARG(Ho > 0 && Wo > 0, "maxpool: empty output");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MV_BF16 && C % 8 == 0) {
+        set_kernel_name("maxpool_nhwc_bf16x8");
+        const long long total = (long long)N * Ho * Wo * (C / 8);
+        hipLaunchKernelGGL(maxpool_nhwc_bf16x8_kernel, dim3(grid_for(total)), dim3(256), 0, st, (const uint4*)x,
+                           (uint4*)y, N, H, W, C / 8, Ho, Wo, kh, kw, sh, sw, ph, pw);
+    } else {
+        set_kernel_name("maxpool_nhwc");
+        const long long total = (long long)N * Ho * Wo * C;
+        if (dtype == MV_BF16)
+            hipLaunchKernelGGL(maxpool_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)x,
+                               (bf16_t*)y, N, H, W, C, Ho, Wo, kh, kw, sh, sw, ph, pw);
+        else
+            hipLaunchKernelGGL(maxpool_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x,
+                               (float*)y, N, H, W, C, Ho, Wo, kh, kw, sh, sw, ph, pw);
+    }
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_adaptive_avgpool2d_nhwc_fwd(const void* x, void* y, int N, int H, int W, int C, int oh, int ow, int in_dtype,
+                                   int out_dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && oh > 0 && ow > 0 && oh <= H && ow <= W, "avgpool: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)N * oh * ow * C;
+    set_kernel_name("adaptive_avgpool_nhwc");
+#define GO(TI, TO)                                                                                              \
+    hipLaunchKernelGGL((adaptive_avgpool_nhwc_kernel<TI, TO>), dim3(grid_for(total)), dim3(256), 0, st, (const TI*)x, \
+                       (TO*)y, N, H, W, C, oh, ow)
+    if (in_dtype == MV_BF16 && out_dtype == MV_BF16) GO(bf16_t, bf16_t);
+    else if (in_dtype == MV_BF16 && out_dtype == MV_F32) GO(bf16_t, float);
+    else if (in_dtype == MV_F32 && out_dtype == MV_F32) GO(float, float);
+    else if (in_dtype == MV_F32 && out_dtype == MV_BF16) GO(float, bf16_t);
+#undef GO
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, int64_t M, int C, float eps,
+                     int in_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && y && M > 0 && C > 0, "layernorm: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows_per_block = 4;
+    dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block)), block(64 * rows_per_block);
+    if (in_dtype == MV_BF16 && out_dtype == MV_BF16 && C % 8 == 0 && C <= 64 * 8 * 4 && !get_flag("force_generic")) {
+        set_kernel_name("layernorm_bf16x8");
+        const int C8 = C / 8;
+        if (C8 <= 64)
+            hipLaunchKernelGGL(layernorm_bf16x8_kernel<1>, grid, block, 0, st, (const uint4*)x, gamma, beta, (uint4*)y,
+                               (long long)M, C8, eps);
+        else if (C8 <= 128)
+            hipLaunchKernelGGL(layernorm_bf16x8_kernel<2>, grid, block, 0, st, (const uint4*)x, gamma, beta, (uint4*)y,
+                               (long long)M, C8, eps);
+        else
+            hipLaunchKernelGGL(layernorm_bf16x8_kernel<4>, grid, block, 0, st, (const uint4*)x, gamma, beta, (uint4*)y,
+                               (long long)M, C8, eps);
+    } else {
+        set_kernel_name("layernorm");
+#define GO(TI, TO)                                                                                         \
+    hipLaunchKernelGGL((layernorm_kernel<TI, TO>), grid, block, 0, st, (const TI*)x, gamma, beta, (TO*)y, \
+                       (long long)M, C, eps)
+        if (in_dtype == MV_BF16 && out_dtype == MV_BF16) GO(bf16_t, bf16_t);
+        else if (in_dtype == MV_BF16 && out_dtype == MV_F32) GO(bf16_t, float);
+        else if (in_dtype == MV_F32 && out_dtype == MV_F32) GO(float, float);
+        else if (in_dtype == MV_F32 && out_dtype == MV_BF16) GO(float, bf16_t);
+#undef GO
+    }
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_mha_fwd(const void* qkv, void* out, float* probs, int B, int N, int H, int dh, float scale, int dtype,
+               mv_stream_t stream) {
+    MV_CHECK_ARG(qkv && out && B > 0 && N > 0 && H > 0 && dh > 0, "mha: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (!get_flag("force_generic") && dtype == MV_BF16 && mha_mfma_supported(N, dh, dtype))
+        return mha_mfma_launch(qkv, out, probs, B, N, H, dh, scale, st);
+    MV_CHECK_ARG(H <= 65535 && B <= 65535, "mha: H/B too large for the generic kernel");
+    const size_t smem = (size_t)(N + dh) * sizeof(float);
+    MV_CHECK_ARG(smem <= 64 * 1024, "mha: sequence too long for the generic kernel (N=%d)", N);
+    set_kernel_name("mha_generic");
+    if (dtype == MV_BF16)
+        hipLaunchKernelGGL(mha_generic_kernel<bf16_t>, dim3(N, H, B), dim3(64), smem, st, (const bf16_t*)qkv,
+                           (bf16_t*)out, probs, B, N, H, dh, scale);
+    else
+        hipLaunchKernelGGL(mha_generic_kernel<float>, dim3(N, H, B), dim3(64), smem, st, (const float*)qkv,
+                           (float*)out, probs, B, N, H, dh, scale);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_swin_window_attn_fwd(const void* qkv, const float* bias, void* out, int B, int Hf, int Wf, int C, int heads,
+                            int ws_h, int ws_w, int shift_h, int shift_w, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(qkv && bias && out && B > 0 && Hf > 0 && Wf > 0 && C > 0 && heads > 0, "swin_attn: bad args");
+    MV_CHECK_ARG(C % heads == 0, "swin_attn: C %% heads != 0");
+    MV_CHECK_ARG(ws_h > 0 && ws_w > 0 && Hf % ws_h == 0 && Wf % ws_w == 0,
+                 "swin_attn: feature map %dx%d is not a multiple of the window %dx%d (reference swin.py:782-790)", Hf,
+                 Wf, ws_h, ws_w);
+    MV_CHECK_ARG(shift_h >= 0 && shift_w >= 0 && shift_h < ws_h && shift_w < ws_w, "swin_attn: bad shift");
+    if (ws_h >= Hf) shift_h = 0;  // swin.py:116-120
+    if (ws_w >= Wf) shift_w = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = ws_h * ws_w, dh = C / heads;
+    const int tokens = Hf * Wf;
+    MV_CHECK_ARG(heads <= 65535 && B <= 65535, "swin_attn: grid too large");
+    const size_t smem = (size_t)(n + dh) * sizeof(float);
+    set_kernel_name("swin_attn_generic");
+    if (dtype == MV_BF16)
+        hipLaunchKernelGGL(swin_attn_generic_kernel<bf16_t>, dim3(tokens, heads, B), dim3(64), smem, st,
+                           (const bf16_t*)qkv, bias, (bf16_t*)out, B, Hf, Wf, C, heads, ws_h, ws_w, shift_h, shift_w);
+    else
+        hipLaunchKernelGGL(swin_attn_generic_kernel<float>, dim3(tokens, heads, B), dim3(64), smem, st,
+                           (const float*)qkv, bias, (float*)out, B, Hf, Wf, C, heads, ws_h, ws_w, shift_h, shift_w);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_patch_merge_gather_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0, "patch_merge: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * 4 * C;
+    set_kernel_name("patch_merge_gather");
+    if (dtype == MV_BF16)
+        hipLaunchKernelGGL(patch_merge_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)x,
+                           (bf16_t*)y, B, H, W, C);
+    else
+        hipLaunchKernelGGL(patch_merge_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, (float*)y,
+                           B, H, W, C);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_vit_cls_pos_fwd(const float* cls, const float* pos, void* tokens, int B, int tok_stride, int D, int dtype,
+                       mv_stream_t stream) {
+    MV_CHECK_ARG(cls && pos && tokens && B > 0 && tok_stride > 0 && D > 0, "cls_pos: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)B * D;
+    set_kernel_name("vit_cls_pos");
+    if (dtype == MV_BF16)
+        hipLaunchKernelGGL(cls_pos_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, cls, pos, (bf16_t*)tokens, B,
+                           tok_stride, D);
+    else
+        hipLaunchKernelGGL(cls_pos_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, cls, pos, (float*)tokens, B,
+                           tok_stride, D);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_eltwise_fwd(const void* x, void* y, int64_t n, int act, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && y && n > 0, "eltwise: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    set_kernel_name("eltwise");
+    if (dtype == MV_BF16)
+        hipLaunchKernelGGL(eltwise_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
+                           (long long)n, act);
+    else
+        hipLaunchKernelGGL(eltwise_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, (float*)y,
+                           (long long)n, act);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_add_fwd(const void* a, const void* b, void* y, int64_t n, int act, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(a && b && y && n > 0, "add: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    set_kernel_name("add");
+    if (dtype == MV_BF16)
+        hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b,
+                           (bf16_t*)y, (long long)n, act);
+    else
+        hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a, (const float*)b,
+                           (float*)y, (long long)n, act);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_channel_affine_fwd(const void* x, const float* scale, const float* shift, void* y, int64_t rows, int C,
+                          int act, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && y && rows > 0 && C > 0, "channel_affine: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    set_kernel_name("channel_affine");
+    const long long n = (long long)rows * C;
+    if (dtype == MV_BF16)
+        hipLaunchKernelGGL(channel_affine_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)x, scale,
+                           shift, (bf16_t*)y, (long long)rows, C, act);
+    else
+        hipLaunchKernelGGL(channel_affine_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, scale,
+                           shift, (float*)y, (long long)rows, C, act);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+static int layout_launch(const void* x, void* y, int N, int C, int H, int W, int in_dtype, int out_dtype, bool to_nhwc,
+                         hipStream_t st) {
+    const int HW = H * W;
+    dim3 block(32, 8), grid((HW + 31) / 32, (C + 31) / 32, N);
+#define GO(TI, TO)                                                                                                   \
+    do {                                                                                                             \
+        if (to_nhwc)                                                                                                 \
+            hipLaunchKernelGGL((layout_kernel<TI, TO, true>), grid, block, 0, st, (const TI*)x, (TO*)y, C, HW);       \
+        else                                                                                                         \
+            hipLaunchKernelGGL((layout_kernel<TI, TO, false>), grid, block, 0, st, (const TI*)x, (TO*)y, C, HW);      \
+    } while (0)
+    if (in_dtype == MV_F32 && out_dtype == MV_F32) GO(float, float);
+    else if (in_dtype == MV_F32 && out_dtype == MV_BF16) GO(float, bf16_t);
+    else if (in_dtype == MV_BF16 && out_dtype == MV_F32) GO(bf16_t, float);
+    else GO(bf16_t, bf16_t);
+#undef GO
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_nchw_to_nhwc(const void* x, void* y, int N, int C, int H, int W, int in_dtype, int out_dtype,
+                    mv_stream_t stream) {
+    MV_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535, "nchw_to_nhwc: bad args");
+    set_kernel_name("nchw_to_nhwc");
+    return layout_launch(x, y, N, C, H, W, in_dtype, out_dtype, true, (hipStream_t)stream);
+}
+int mv_nhwc_to_nchw(const void* x, void* y, int N, int C, int H, int W, int in_dtype, int out_dtype,
+                    mv_stream_t stream) {
+    MV_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0 && N <= 65535, "nhwc_to_nchw: bad args");
+    set_kernel_name("nhwc_to_nchw");
+    return layout_launch(x, y, N, C, H, W, in_dtype, out_dtype, false, (hipStream_t)stream);
+}
+
+int mv_cast(const void* x, void* y, int64_t n, int in_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && y && n > 0, "cast: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    set_kernel_name("cast");
+#define GO(TI, TO) \
+    hipLaunchKernelGGL((cast_kernel<TI, TO>), dim3(grid_for(n)), dim3(256), 0, st, (const TI*)x, (TO*)y, (long long)n)
+    if (in_dtype == MV_F32 && out_dtype == MV_BF16) GO(float, bf16_t);
+    else if (in_dtype == MV_BF16 && out_dtype == MV_F32) GO(bf16_t, float);
+    else if (in_dtype == MV_F32) GO(float, float);
+    else GO(bf16_t, bf16_t);
+#undef GO
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+// Runtime plumbing behind the C ABI: thread-local error text, flags, the per-device zero page,
+// hipGraph capture and HIP-event timing.  No compute here.
+#include <stdarg.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "common.h"
+
+namespace mv {
+
+static thread_local char g_err[512] = "";
+static thread_local char g_kernel[128] = "";
+static std::mutex g_mu;
+static std::map<std::string, int> g_flags;
+static std::map<int, void*> g_zero;
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+void set_kernel_name(const char* name) {
+    strncpy(g_kernel, name, sizeof(g_kernel) - 1);
+    g_kernel[sizeof(g_kernel) - 1] = 0;
+}
+int get_flag(const char* name) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_flags.find(name);
+    return it == g_flags.end() ? 0 : it->second;
+}
+
+// 4 KiB of zeros per device: the source every out-of-image / out-of-range LDS-DMA lane reads.
+const void* zero_page(hipStream_t) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_zero.find(dev);
+    if (it != g_zero.end()) return it->second;
+    void* p = nullptr;
+    if (hipMalloc(&p, 4096) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 4096) != hipSuccess) return nullptr;  // synchronous, outside any capture
+    g_zero[dev] = p;
+    return p;
+}
+
+}  // namespace mv
+
+extern "C" {
+
+int mv_abi_version(void) { return MV_ABI_VERSION; }
+const char* mv_last_error(void) { return mv::g_err; }
+const char* mv_last_kernel(void) { return mv::g_kernel; }
+
+int mv_set_flag(const char* name, int value) {
+    if (!name) return MV_E_INVALID;
+    std::lock_guard<std::mutex> lk(mv::g_mu);
+    mv::g_flags[name] = value;
+    return MV_OK;
+}
+int mv_get_flag(const char* name) { return name ? mv::get_flag(name) : 0; }
+
+int mv_graph_begin_capture(mv_stream_t stream) {
+    if (!mv::zero_page((hipStream_t)stream)) {  // must exist before capture (hipMalloc is illegal inside)
+        mv::set_error("zero page allocation failed");
+        return MV_E_OOM;
+    }
+    MV_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return MV_OK;
+}
+int mv_graph_end_capture(mv_stream_t stream, void** graph_exec) {
+    MV_CHECK_ARG(graph_exec, "graph_exec is NULL");
+    hipGraph_t g = nullptr;
+    MV_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) {
+        mv::set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    *graph_exec = (void*)ex;
+    return MV_OK;
+}
+int mv_graph_launch(void* graph_exec, mv_stream_t stream) {
+    MV_CHECK_ARG(graph_exec, "graph_exec is NULL");
+    MV_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+    return MV_OK;
+}
+int mv_graph_destroy(void* graph_exec) {
+    if (graph_exec) MV_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return MV_OK;
+}
+
+int mv_event_create(void** ev) {
+    MV_CHECK_ARG(ev, "ev is NULL");
+    hipEvent_t e;
+    MV_HIP(hipEventCreate(&e));
+    *ev = (void*)e;
+    return MV_OK;
+}
+int mv_event_record(void* ev, mv_stream_t stream) {
+    MV_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return MV_OK;
+}
+int mv_event_elapsed_ms(void* start, void* stop, float* ms) {
+    MV_CHECK_ARG(ms, "ms is NULL");
+    MV_HIP(hipEventSynchronize((hipEvent_t)stop));
+    MV_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return MV_OK;
+}
+int mv_event_destroy(void* ev) {
+    if (ev) MV_HIP(hipEventDestroy((hipEvent_t)ev));
+    return MV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+"""Transformer MLP (reference layers/mlps.py:12-66): fc1 -> act -> drop -> fc2 -> drop.
+
+On the device this is two GEMM launches: bias + activation are fused into fc1's epilogue, bias
+(+ the caller's residual, see `_forward`) into fc2's."""
+from __future__ import annotations
+
+from typing import Callable, Tuple, Union
+
+from .. import nn, ops
+from .. import random as jr
+from .._module import Module
+from ..nn import boundary
+
+
+class MlpProjection(Module):
+    fc1: Module
+    act: Callable
+    drop1: nn.Dropout
+    fc2: Module
+    drop2: nn.Dropout
+
+    def __init__(self, in_features: int, hidden_features: int = None, out_features: int = None,
+                 lin_layer=nn.Linear, act_layer: Callable = None, drop: Union[float, Tuple[float]] = 0.0,
+                 *, key=None):
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        drop_probs = drop if isinstance(drop, tuple) else (drop, drop)
+        keys = jr.split(key if key is not None else jr.PRNGKey(0), 2)
+        self.fc1 = lin_layer(in_features, hidden_features, key=keys[0])
+        self.act = act_layer
+        self.drop1 = nn.Dropout(drop_probs[0])
+        self.fc2 = lin_layer(hidden_features, out_features, key=keys[1])
+        self.drop2 = nn.Dropout(drop_probs[1])
+
+    def _forward(self, x, residual=None):
+        if x.kind in ("img", "map"):
+            x = ops.as_map(x)
+        name = nn.act_name(self.act)
+        if name is not None:
+            h = ops.linear(x, self.fc1, act=name)
+        else:
+            h = ops.linear(x, self.fc1)
+            h = self.act(h) if self.act is not None else h
+        h = self.drop1(h)
+        y = ops.linear(h, self.fc2, residual=residual)
+        return self.drop2(y)
+
+    @boundary
+    def __call__(self, x, *, key=None):
+        return self._forward(x)

@@ -1,0 +1,53 @@
+"""Image -> patch tokens (reference layers/patch_embed.py:11-84).
+
+The reference runs Conv2d(k = s = patch), ravels each channel and moves the channel axis last.  Here
+the same contraction is one implicit-GEMM launch that reads the NCHW image directly (no im2col
+buffer) and writes token rows [P, D] -- the layout every following Linear wants."""
+from __future__ import annotations
+
+from typing import Optional, Tuple, Union
+
+from .. import nn, ops
+from .. import random as jr
+from .._module import Module
+from ..nn import boundary
+
+
+class PatchEmbed(Module):
+    img_size: Tuple[int]
+    patch_size: Tuple[int]
+    grid_size: Tuple[int]
+    num_patches: int
+    flatten: bool
+    proj: nn.Conv2d
+    norm: Module
+
+    def __init__(self, img_size: Union[int, Tuple[int]] = 224, patch_size: Union[int, Tuple[int]] = 16,
+                 in_chans: int = 3, embed_dim: int = 768, norm_layer=None, flatten: bool = True, *, key=None):
+        self.img_size = img_size if isinstance(img_size, tuple) else (img_size, img_size)
+        self.patch_size = patch_size if isinstance(patch_size, tuple) else (patch_size, patch_size)
+        self.grid_size = (self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1])
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.flatten = flatten
+        if key is None:
+            key = jr.PRNGKey(0)
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, key=key)
+        self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
+
+    def _check(self, x):
+        C, H, W = x.shape
+        if H != self.img_size[0] or W != self.img_size[1]:           # reference :74-77
+            raise ValueError(f"Input image height ({H},{W}) doesn't match model ({self.img_size}).")
+
+    @boundary
+    def __call__(self, x, *, key=None):
+        self._check(x)
+        if self.flatten and x.kind == "img":
+            t = ops.patch_embed_tokens(x, self.proj, None, None, 0)
+        else:
+            t = ops.conv2d(x, self.proj)
+            if self.flatten:                                          # map [B,gh,gw,D] == rows [B,P,D]
+                from .._act import Act
+                B, gh, gw, D = t.t.shape
+                t = Act(t.t.reshape(B, gh * gw, D), "seq", t.batched)
+        return self.norm(t)

@@ -1,0 +1,24 @@
+"""Flat model namespace (reference eqxvision/models/__init__.py:1-105) for the hot-path families."""
+from .classification.alexnet import AlexNet, alexnet
+from .classification.resnet import (
+    ResNet,
+    resnet18,
+    resnet34,
+    resnet50,
+    resnet101,
+    resnet152,
+    resnext50_32x4d,
+    resnext101_32x8d,
+    wide_resnet50_2,
+    wide_resnet101_2,
+)
+from .classification.swin import SwinTransformer, swin_b, swin_s, swin_t
+from .classification.vit import (
+    _VitAttention,
+    _VitBlock,
+    VisionTransformer,
+    vit_b_16,
+    vit_base,
+    vit_small,
+    vit_tiny,
+)

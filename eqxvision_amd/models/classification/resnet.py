@@ -1,0 +1,240 @@
+"""ResNet family (reference models/classification/resnet.py:37-511).
+
+Field order mirrors the reference (= torchvision registration order, the `load_torch_weights`
+contract).  Every residual block lowers to fused launches only:
+  conv+BN+relu, conv+BN+relu, [downsample conv+BN], conv+BN + identity + relu
+with the BatchNorm folded into the fp32 epilogue of the implicit-GEMM kernel."""
+from __future__ import annotations
+
+from typing import Any, Callable, List, Optional, Sequence, Type, Union
+
+from ... import nn, ops
+from ... import random as jr
+from ..._module import Module
+from ...nn import boundary
+from ...utils import load_torch_weights
+
+
+def _conv3x3(in_planes, out_planes, stride=1, groups=1, dilation=1, key=None):
+    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=dilation, groups=groups,
+                     use_bias=False, dilation=dilation, key=key)
+
+
+def _conv1x1(in_planes, out_planes, stride=1, key=None):
+    return nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, use_bias=False, key=key)
+
+
+def _shortcut(block, x):
+    """identity = self.downsample(x): a [conv1x1(stride), BN] Sequential or nn.Identity."""
+    return block.downsample(x)
+
+
+class _ResNetBasicBlock(Module):
+    expansion: int
+    conv1: Module
+    bn1: Module
+    relu: Callable
+    conv2: Module
+    bn2: Module
+    downsample: Module
+    stride: int
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1,
+                 norm_layer=None, key=None):
+        if norm_layer is None:
+            norm_layer = nn.BatchNorm
+        if groups != 1 or base_width != 64:
+            raise ValueError("BasicBlock only supports groups=1 and base_width=64")
+        if dilation > 1:
+            raise NotImplementedError("Dilation > 1 not supported in BasicBlock")
+        keys = jr.split(key, 2)
+        self.expansion = 1
+        self.conv1 = _conv3x3(inplanes, planes, stride, key=keys[0])
+        self.bn1 = norm_layer(planes, axis_name="batch")
+        self.relu = nn.relu
+        self.conv2 = _conv3x3(planes, planes, key=keys[1])
+        self.bn2 = norm_layer(planes, axis_name="batch")
+        self.downsample = downsample if downsample else nn.Identity()
+        self.stride = stride
+
+    @boundary
+    def __call__(self, x, *, key=None):                       # reference :80-92
+        out = ops.conv2d(x, self.conv1, self.bn1, "relu")
+        identity = _shortcut(self, x)
+        return ops.conv2d(out, self.conv2, self.bn2, "relu", residual=identity)
+
+
+class _ResNetBottleneck(Module):
+    # stride sits on the 3x3 (ResNet v1.5), like torchvision / the reference (:96-100)
+    expansion: int
+    conv1: Module
+    bn1: Module
+    conv2: Module
+    bn2: Module
+    conv3: Module
+    bn3: Module
+    relu: Callable
+    downsample: Module
+    stride: int
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1,
+                 norm_layer=None, key=None):
+        if norm_layer is None:
+            norm_layer = nn.BatchNorm
+        self.expansion = 4
+        keys = jr.split(key, 3)
+        width = int(planes * (base_width / 64.0)) * groups
+        self.conv1 = _conv1x1(inplanes, width, key=keys[0])
+        self.bn1 = norm_layer(width, axis_name="batch")
+        self.conv2 = _conv3x3(width, width, stride, groups, dilation, key=keys[1])
+        self.bn2 = norm_layer(width, axis_name="batch")
+        self.conv3 = _conv1x1(width, planes * self.expansion, key=keys[2])
+        self.bn3 = norm_layer(planes * self.expansion, axis_name="batch")
+        self.relu = nn.relu
+        self.downsample = downsample if downsample else nn.Identity()
+        self.stride = stride
+
+    @boundary
+    def __call__(self, x, *, key=None):                       # reference :144-162
+        x = ops.as_map(x)
+        out = ops.conv2d(x, self.conv1, self.bn1, "relu")
+        out = ops.conv2d(out, self.conv2, self.bn2, "relu")
+        identity = _shortcut(self, x)
+        return ops.conv2d(out, self.conv3, self.bn3, "relu", residual=identity)
+
+
+EXPANSIONS = {_ResNetBasicBlock: 1, _ResNetBottleneck: 4}
+
+
+class ResNet(Module):
+    inplanes: int
+    dilation: int
+    groups: Sequence[int]
+    base_width: int
+    conv1: Module
+    bn1: Module
+    relu: Callable
+    maxpool: Module
+    layer1: Module
+    layer2: Module
+    layer3: Module
+    layer4: Module
+    avgpool: Module
+    fc: Module
+
+    def __init__(self, block: Type[Union[_ResNetBasicBlock, _ResNetBottleneck]], layers: List[int],
+                 num_classes: int = 1000, groups: int = 1, width_per_group: int = 64,
+                 replace_stride_with_dilation: List[bool] = None, norm_layer: Any = None, *, key=None):
+        if not norm_layer:
+            norm_layer = nn.BatchNorm
+        if norm_layer is not nn.BatchNorm:                    # reference :222-225
+            raise NotImplementedError(f"{type(norm_layer)} is not currently supported. Use `nn.BatchNorm` instead.")
+        if key is None:
+            key = jr.PRNGKey(0)
+        keys = jr.split(key, 6)
+        self.inplanes = 64
+        self.dilation = 1
+        if replace_stride_with_dilation is None:
+            replace_stride_with_dilation = [False, False, False]
+        if len(replace_stride_with_dilation) != 3:
+            raise ValueError("replace_stride_with_dilation should be None or a 3-element tuple, got {}".format(
+                replace_stride_with_dilation))
+        self.groups = groups
+        self.base_width = width_per_group
+        self.conv1 = nn.Conv2d(3, self.inplanes, kernel_size=7, stride=2, padding=3, use_bias=False, key=keys[0])
+        self.bn1 = norm_layer(input_size=self.inplanes, axis_name="batch")
+        self.relu = nn.relu
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0], norm_layer, key=keys[1])
+        self.layer2 = self._make_layer(block, 128, layers[1], norm_layer, stride=2,
+                                       dilate=replace_stride_with_dilation[0], key=keys[2])
+        self.layer3 = self._make_layer(block, 256, layers[2], norm_layer, stride=2,
+                                       dilate=replace_stride_with_dilation[1], key=keys[3])
+        self.layer4 = self._make_layer(block, 512, layers[3], norm_layer, stride=2,
+                                       dilate=replace_stride_with_dilation[2], key=keys[4])
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * EXPANSIONS[block], num_classes, key=keys[5])
+
+    def _make_layer(self, block, planes, blocks, norm_layer, stride=1, dilate=False, key=None):
+        keys = jr.split(key, blocks + 1)
+        downsample = None
+        previous_dilation = self.dilation
+        if dilate:
+            self.dilation *= stride
+            stride = 1
+        if stride != 1 or self.inplanes != planes * EXPANSIONS[block]:        # reference :295-303
+            downsample = nn.Sequential([
+                _conv1x1(self.inplanes, planes * EXPANSIONS[block], stride, key=keys[0]),
+                norm_layer(planes * EXPANSIONS[block], axis_name="batch"),
+            ])
+        stack = [block(self.inplanes, planes, stride, downsample, self.groups, self.base_width, previous_dilation,
+                       norm_layer, key=keys[1])]
+        self.inplanes = planes * EXPANSIONS[block]
+        for i in range(1, blocks):
+            stack.append(block(self.inplanes, planes, groups=self.groups, base_width=self.base_width,
+                               dilation=self.dilation, norm_layer=norm_layer, key=keys[i + 1]))
+        return nn.Sequential(stack)
+
+    @boundary
+    def __call__(self, x, *, key):                            # reference :335-358
+        if key is None:
+            raise RuntimeError("The model requires a PRNGKey.")
+        x = ops.conv2d(x, self.conv1, self.bn1, "relu")       # stem straight from the NCHW image
+        x = self.maxpool(x)
+        x = self.layer1(x)
+        x = self.layer2(x)
+        x = self.layer3(x)
+        x = self.layer4(x)
+        x = self.avgpool(x)
+        x = ops.flatten(x)
+        return ops.linear(x, self.fc, out_fp32=True)
+
+
+def _resnet(block, layers, torch_weights=None, **kwargs):
+    model = ResNet(block, layers, **kwargs)
+    if torch_weights:
+        model = load_torch_weights(model, torch_weights=torch_weights)
+    return model
+
+
+def resnet18(torch_weights=None, **kwargs) -> ResNet:
+    return _resnet(_ResNetBasicBlock, [2, 2, 2, 2], torch_weights, **kwargs)
+
+
+def resnet34(torch_weights=None, **kwargs) -> ResNet:
+    return _resnet(_ResNetBasicBlock, [3, 4, 6, 3], torch_weights, **kwargs)
+
+
+def resnet50(torch_weights=None, **kwargs) -> ResNet:
+    """ResNet-50 v1.5 (reference :395-407): 53 convolutions, 4.09 GMAC per 224x224 image."""
+    return _resnet(_ResNetBottleneck, [3, 4, 6, 3], torch_weights, **kwargs)
+
+
+def resnet101(torch_weights=None, **kwargs) -> ResNet:
+    return _resnet(_ResNetBottleneck, [3, 4, 23, 3], torch_weights, **kwargs)
+
+
+def resnet152(torch_weights=None, **kwargs) -> ResNet:
+    return _resnet(_ResNetBottleneck, [3, 8, 36, 3], torch_weights, **kwargs)
+
+
+def resnext50_32x4d(torch_weights=None, **kwargs) -> ResNet:
+    kwargs["groups"] = 32
+    kwargs["width_per_group"] = 4
+    return _resnet(_ResNetBottleneck, [3, 4, 6, 3], torch_weights, **kwargs)
+
+
+def resnext101_32x8d(torch_weights=None, **kwargs) -> ResNet:
+    kwargs["groups"] = 32
+    kwargs["width_per_group"] = 8
+    return _resnet(_ResNetBottleneck, [3, 4, 23, 3], torch_weights, **kwargs)
+
+
+def wide_resnet50_2(torch_weights=None, **kwargs) -> ResNet:
+    kwargs["width_per_group"] = 64 * 2
+    return _resnet(_ResNetBottleneck, [3, 4, 6, 3], torch_weights, **kwargs)
+
+
+def wide_resnet101_2(torch_weights=None, **kwargs) -> ResNet:
+    kwargs["width_per_group"] = 64 * 2
+    return _resnet(_ResNetBottleneck, [3, 4, 23, 3], torch_weights, **kwargs)

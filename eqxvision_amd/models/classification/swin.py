@@ -1,0 +1,225 @@
+"""Swin Transformer V1 (reference models/classification/swin.py:23-66, 90-366, 526-578, 640-830).
+
+Same fields / constructors.  V2 (cosine attention + cpb_mlp) is out of scope.
+Device lowering of one block (reference :572-578):
+  LayerNorm2d rows | qkv GEMM(+bias) | window attention (roll / partition / bias / mask / softmax / PV /
+  reverse folded into addressing) | proj GEMM(+bias,+residual) | LayerNorm2d | fc1 GEMM(+gelu) |
+  fc2 GEMM(+residual)
+Feature maps stay NHWC, which is exactly the (H,W,C) view `_shifted_window_attention` transposes to
+(reference :106), so no transposes exist on the device.
+"""
+from __future__ import annotations
+
+import warnings
+from functools import partial
+from typing import Any, Callable, List, Optional
+
+import numpy as np
+
+from ... import nn, ops
+from ... import random as jr
+from ..._act import Act
+from ..._module import Module
+from ...layers import DropPath, LayerNorm2d, Linear2d, MlpProjection
+from ...nn import boundary
+from ...utils import load_torch_weights
+
+
+def _get_relative_position_bias(table: np.ndarray, index: np.ndarray, window_size: List[int]) -> np.ndarray:
+    """table[index] -> (heads, N, N)  (reference :34-43); negative indices wrap like jnp indexing."""
+    n = window_size[0] * window_size[1]
+    idx = np.asarray(index).reshape(-1).astype(np.int64)
+    b = np.asarray(table, np.float32)[idx]
+    return np.ascontiguousarray(b.reshape(n, n, -1).transpose(2, 0, 1))
+
+
+class _PatchMerging(Module):
+    reduction: Linear2d
+    norm: Callable
+
+    def __init__(self, dim: int, norm_layer: Callable = LayerNorm2d, *, key=None):
+        self.norm = norm_layer(4 * dim)
+        self.reduction = Linear2d(4 * dim, 2 * dim, use_bias=False, key=key)
+
+    @boundary
+    def __call__(self, x, *, key=None):                                # reference :61-65
+        x = ops.patch_merge_gather(x)                                  # _patch_merging_pad (:23-31)
+        x = self.norm(x)
+        return self.reduction(x)
+
+
+class _ShiftedWindowAttention(Module):
+    window_size: List[int]
+    shift_size: List[int]
+    num_heads: int
+    attention_dropout: float
+    dropout: float
+    relative_position_bias_table: np.ndarray
+    relative_position_index: np.ndarray
+    qkv: nn.Linear
+    proj: nn.Linear
+
+    def __init__(self, dim: int, window_size: List[int], shift_size: List[int], num_heads: int, qkv_bias: bool = True,
+                 proj_bias: bool = True, attention_dropout: float = 0.0, dropout: float = 0.0, *, key=None):
+        if len(window_size) != 2 or len(shift_size) != 2:
+            raise ValueError("window_size and shift_size must be of length 2")
+        keys = jr.split(key if key is not None else jr.PRNGKey(0), 3)
+        self.window_size = list(window_size)
+        self.shift_size = list(shift_size)
+        self.num_heads = num_heads
+        self.attention_dropout = attention_dropout
+        self.dropout = dropout
+        self.qkv = Linear2d(dim, dim * 3, use_bias=qkv_bias, key=keys[0])
+        self.proj = Linear2d(dim, dim, use_bias=proj_bias, key=keys[1])
+        self.relative_position_bias_table = self.define_relative_position_bias_table(key=keys[2])
+        self.relative_position_index = self.define_relative_position_index()
+
+    def define_relative_position_bias_table(self, key):
+        # reference :303-312: truncated_normal(lower=2, upper=2) -> the constant 2.0 (softmax-invariant)
+        n = (2 * self.window_size[0] - 1) * (2 * self.window_size[1] - 1)
+        return jr.truncated_normal(key, 2, 2, (n, self.num_heads))
+
+    def define_relative_position_index(self):
+        # reference :314-335 quirk: the torchvision-style index is built and DISCARDED;
+        # what is returned is relative_coords.sum(-1) in [-(Wh+Ww-2), Wh+Ww-2].  Reproduced as data; a
+        # pretrained checkpoint overwrites it with torchvision's index (Appendix C-1).
+        ch, cw = np.arange(self.window_size[0]), np.arange(self.window_size[1])
+        coords = np.stack(np.meshgrid(ch, cw, indexing="ij")).reshape(2, -1)
+        rel = coords[:, :, None] - coords[:, None, :]
+        return rel.transpose(1, 2, 0).sum(-1).reshape(-1).astype(np.int32)
+
+    def get_relative_position_bias(self) -> np.ndarray:
+        return _get_relative_position_bias(self.relative_position_bias_table, self.relative_position_index,
+                                           self.window_size)
+
+    def _bias_dev(self):
+        cache = self._cache()
+        b = cache.get("bias")
+        if b is None:
+            b = ops._dev(self.get_relative_position_bias(), __import__("torch").float32)
+            cache["bias"] = b
+        return b
+
+    def _forward(self, x: Act, residual: Optional[Act] = None) -> Act:
+        x = ops.as_map(x)
+        B, Hf, Wf, C = x.t.shape
+        if Hf % self.window_size[0] or Wf % self.window_size[1]:
+            raise ValueError(f"feature map {Hf}x{Wf} is not a multiple of the window {self.window_size} "
+                             "(the reference does not pad either, swin.py:782-790)")
+        qkv = ops.linear(x, self.qkv)                                  # reference :151-153
+        a = ops.swin_window_attention(qkv, self._bias_dev(), self.num_heads, self.window_size, self.shift_size)
+        return ops.linear(a, self.proj, residual=residual)             # reference :232 (+ the block's residual)
+
+    @boundary
+    def __call__(self, x, *, key=None):
+        return self._forward(x)
+
+
+class _SwinTransformerBlock(Module):
+    norm1: Callable
+    attn: Module
+    stochastic_depth: DropPath
+    norm2: Callable
+    mlp: MlpProjection
+
+    def __init__(self, dim: int, num_heads: int, window_size: List[int], shift_size: List[int], mlp_ratio: float = 4.0,
+                 dropout: float = 0.0, attention_dropout: float = 0.0, stochastic_depth_prob: float = 0.0,
+                 norm_layer: Callable[..., Module] = LayerNorm2d,
+                 attn_layer: Callable[..., Module] = _ShiftedWindowAttention, *, key=None):
+        keys = jr.split(key if key is not None else jr.PRNGKey(0), 2)
+        self.norm1 = norm_layer(dim)
+        self.attn = attn_layer(dim, window_size, shift_size, num_heads, attention_dropout=attention_dropout,
+                               dropout=dropout, key=keys[0])
+        self.stochastic_depth = DropPath(stochastic_depth_prob, mode="local")
+        self.norm2 = norm_layer(dim)
+        self.mlp = MlpProjection(dim, int(dim * mlp_ratio), dim, lin_layer=Linear2d, act_layer=nn.gelu, drop=dropout,
+                                 key=keys[1])
+
+    @boundary
+    def __call__(self, x, *, key=None):                                # reference :572-578
+        x = ops.as_map(x)
+        sd = self.stochastic_depth
+        if sd.inference or sd.p == 0.0:
+            x = self.attn._forward(self.norm1(x), residual=x)
+            return self.mlp._forward(self.norm2(x), residual=x)
+        x = ops.add(x, sd(self.attn._forward(self.norm1(x)), key=key))
+        return ops.add(x, sd(self.mlp._forward(self.norm2(x)), key=key))
+
+
+class SwinTransformer(Module):
+    features: nn.Sequential
+    norm: Callable
+    avgpool: nn.AdaptiveAvgPool2d
+    head: nn.Linear
+
+    def __init__(self, patch_size: List[int], embed_dim: int, depths: List[int], num_heads: List[int],
+                 window_size: List[int], mlp_ratio: float = 4.0, dropout: float = 0.0, attention_dropout: float = 0.0,
+                 stochastic_depth_prob: float = 0.1, num_classes: int = 1000, norm_layer: Callable = None,
+                 block: Module = None, downsample_layer: Module = None, *, key=None):
+        if key is None:
+            key = jr.PRNGKey(0)
+        keys = jr.split(key, 2)
+        if block is None:
+            block = _SwinTransformerBlock
+        if norm_layer is None:
+            norm_layer = partial(LayerNorm2d, eps=1e-5)
+        if downsample_layer is None:
+            downsample_layer = _PatchMerging
+        stack: List[Module] = [nn.Sequential([
+            nn.Conv2d(3, embed_dim, kernel_size=(patch_size[0], patch_size[1]),
+                      stride=(patch_size[0], patch_size[1]), key=keys[0]),
+            norm_layer(embed_dim),
+        ])]
+        total = sum(depths)
+        bid = 0
+        for i_stage in range(len(depths)):
+            stage: List[Module] = []
+            dim = embed_dim * 2 ** i_stage
+            for i_layer in range(depths[i_stage]):
+                keys = jr.split(keys[1], 2)
+                sd_prob = stochastic_depth_prob * float(bid) / (total - 1)
+                stage.append(block(dim, num_heads[i_stage], window_size=window_size,
+                                   shift_size=[0 if i_layer % 2 == 0 else w // 2 for w in window_size],
+                                   mlp_ratio=mlp_ratio, dropout=dropout, attention_dropout=attention_dropout,
+                                   stochastic_depth_prob=sd_prob, norm_layer=norm_layer, key=keys[0]))
+                bid += 1
+            stack.append(nn.Sequential(stage))
+            if i_stage < len(depths) - 1:
+                keys = jr.split(keys[1], 2)
+                stack.append(downsample_layer(dim, norm_layer, key=keys[0]))
+        self.features = nn.Sequential(stack)
+        num_features = embed_dim * 2 ** (len(depths) - 1)
+        self.norm = norm_layer(num_features)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.head = nn.Linear(num_features, num_classes, key=keys[1])
+
+    @boundary
+    def __call__(self, x, *, key=None):                                # reference :760-772
+        x = self.features(x)
+        x = self.norm(x)
+        x = self.avgpool(x)
+        x = ops.flatten(x)
+        return ops.linear(x, self.head, out_fp32=True)
+
+
+def _swin_transformer(arch, patch_size, embed_dim, depths, num_heads, window_size, stochastic_depth_prob,
+                      torch_weights, **kwargs: Any) -> SwinTransformer:
+    warnings.warn("Currently, dynamic padding of the input is not supported! "
+                  "Please make sure that the input is a multiple of window_size.")
+    model = SwinTransformer(patch_size=patch_size, embed_dim=embed_dim, depths=depths, num_heads=num_heads,
+                            window_size=window_size, stochastic_depth_prob=stochastic_depth_prob, **kwargs)
+    if torch_weights:
+        model = load_torch_weights(model, torch_weights=torch_weights)
+    return model
+
+
+def swin_t(torch_weights: str = None, **kwargs: Any) -> SwinTransformer:
+    return _swin_transformer("swin_t", [4, 4], 96, [2, 2, 6, 2], [3, 6, 12, 24], [7, 7], 0.2, torch_weights, **kwargs)
+
+
+def swin_s(torch_weights: str = None, **kwargs: Any) -> SwinTransformer:
+    return _swin_transformer("swin_s", [4, 4], 96, [2, 2, 18, 2], [3, 6, 12, 24], [7, 7], 0.3, torch_weights, **kwargs)
+
+
+def swin_b(torch_weights: str = None, **kwargs: Any) -> SwinTransformer:
+    return _swin_transformer("swin_b", [4, 4], 128, [2, 2, 18, 2], [4, 8, 16, 32], [7, 7], 0.5, torch_weights, **kwargs)

@@ -1,0 +1,196 @@
+"""Vision Transformer (reference models/classification/vit.py:15-404; DINO port).
+
+Same classes / fields / constructors / `__call__` signatures.  Device lowering of one block
+(`_VitBlock.__call__`, reference :139-157) = 7 launches:
+  LayerNorm | qkv GEMM(+bias) | fused attention (QK^T, softmax, PV) | proj GEMM(+bias,+residual)
+  LayerNorm | fc1 GEMM(+bias,+gelu) | fc2 GEMM(+bias,+residual)
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from ... import nn, ops
+from ... import random as jr
+from ..._act import Act
+from ..._module import Module
+from ...layers import DropPath, MlpProjection, PatchEmbed
+from ...nn import boundary
+from ...utils import load_torch_weights
+
+
+class _VitAttention(Module):
+    num_heads: int
+    scale: float
+    qkv: nn.Linear
+    attn_drop: nn.Dropout
+    proj: nn.Linear
+    proj_drop: nn.Dropout
+
+    def __init__(self, dim: int, num_heads: int = 8, qkv_bias: bool = False, qk_scale=None, attn_drop: float = 0.0,
+                 proj_drop: float = 0.0, *, key=None):
+        keys = jr.split(key if key is not None else jr.PRNGKey(0), 2)
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, use_bias=qkv_bias, key=keys[0])
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim, key=keys[1])
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def _forward(self, x: Act, residual: Optional[Act] = None, need_probs: bool = True):
+        x = ops.as_rows(x)
+        if x.kind != "seq":
+            raise ValueError(f"_VitAttention expects (tokens, dim), got {x.shape}")
+        qkv = ops.linear(x, self.qkv)                                  # reference :64
+        y, probs = ops.mha(qkv, self.num_heads, self.scale, need_probs)  # reference :65-73
+        self.attn_drop(y)                                              # identity (or a loud error) -- reference :71
+        y = ops.linear(y, self.proj, residual=residual)                # reference :74 (+ the block's residual)
+        y = self.proj_drop(y)
+        attn = None
+        if probs is not None:                                          # reference returns (1, heads, N, N) per sample
+            B, H, N, _ = probs.shape
+            attn = Act(probs.reshape(B, 1, H, N, N), "raw", x.batched)
+        return y, attn
+
+    @boundary
+    def __call__(self, x, *, key=None):
+        return self._forward(x)
+
+
+class _VitBlock(Module):
+    norm1: Module
+    attn: _VitAttention
+    drop_path: DropPath
+    norm2: Module
+    mlp: MlpProjection
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0,
+                 drop_path=0.0, act_layer=nn.gelu, norm_layer=nn.LayerNorm, *, key):
+        keys = jr.split(key, 2)
+        self.norm1 = norm_layer(dim)
+        self.attn = _VitAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                  attn_drop=attn_drop, proj_drop=drop, key=keys[0])
+        self.drop_path = DropPath(float(drop_path)) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = MlpProjection(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer,
+                                 drop=drop, key=keys[1])
+
+    def _residual_ok(self) -> bool:
+        dp = self.drop_path
+        return isinstance(dp, nn.Identity) or dp.inference or dp.p == 0.0
+
+    @boundary
+    def __call__(self, x, return_attention=False, *, key=None):        # reference :139-157
+        x = ops.as_rows(x)
+        y = self.norm1(x)
+        if return_attention:
+            _, attn = self.attn._forward(y, need_probs=True)
+            return attn
+        if self._residual_ok():            # x + Identity(y): fold the add into the GEMM epilogues
+            x, _ = self.attn._forward(y, residual=x, need_probs=False)
+            return self.mlp._forward(self.norm2(x), residual=x)
+        y, _ = self.attn._forward(y, need_probs=False)
+        x = ops.add(x, self.drop_path(y, key=key))
+        y = self.mlp._forward(self.norm2(x))
+        return ops.add(x, self.drop_path(y, key=key))
+
+
+class VisionTransformer(Module):
+    num_features: int
+    cls_token: np.ndarray
+    pos_embed: np.ndarray
+    patch_embed: PatchEmbed
+    pos_drop: nn.Dropout
+    blocks: Sequence[_VitBlock]
+    norm: Module
+    fc: nn.Linear
+    inference: bool
+
+    def __init__(self, img_size: Union[int, Tuple[int]] = 224, patch_size: Union[int, Tuple[int]] = 16,
+                 in_chans: int = 3, num_classes: int = 0, embed_dim: int = 768, depth: int = 12, num_heads: int = 12,
+                 mlp_ratio: float = 4.0, qkv_bias: bool = True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
+                 drop_path_rate=0.0, norm_layer=nn.LayerNorm, *, key=None):
+        if key is None:
+            key = jr.PRNGKey(0)
+        keys = jr.split(key, depth + 3)
+        self.inference = False
+        self.num_features = embed_dim
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        # unit-scale truncated normals, no 0.02 factor (reference :229-234)
+        self.cls_token = jr.truncated_normal(keys[0], -2, 2, (1, embed_dim))
+        self.pos_embed = jr.truncated_normal(keys[1], -2, 2, (num_patches + 1, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [float(v) for v in np.linspace(0, drop_path_rate, depth)]
+        self.blocks = [
+            _VitBlock(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                      drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer,
+                      key=keys[i + 1])
+            for i in range(depth)
+        ]
+        self.norm = norm_layer(embed_dim)
+        self.fc = nn.Identity() if num_classes == 0 else nn.Linear(embed_dim, num_classes, key=keys[-1])
+
+    def _tokens(self, x: Act) -> Act:
+        """patch_embed -> concat(cls, x) + pos_embed (reference :268-269) in one implicit-GEMM launch
+        (+ a B x D kernel for the cls row)."""
+        pe = self.patch_embed
+        if x.kind == "img" and pe.flatten and isinstance(pe.norm, nn.Identity):
+            pe._check(x)
+            cls = ops.prep_f32(self, "cls_token", self.cls_token.reshape(-1))
+            pos = ops.prep_f32(self, "pos_embed", self.pos_embed)
+            return ops.patch_embed_tokens(x, pe.proj, cls, pos, 1)
+        raise NotImplementedError("VisionTransformer expects a raw (C,H,W) image and the default PatchEmbed")
+
+    def _head(self, x: Act) -> Act:
+        x = self.norm(x)                                               # reference :272
+        B, N, D = x.t.shape
+        cls = Act(x.t[:, 0, :], "vec", x.batched)                      # x[0] (strided view: rows of D, stride N*D)
+        if isinstance(self.fc, nn.Identity):
+            return Act(cls.t.contiguous(), "vec", x.batched)
+        return ops.linear(Act(cls.t.contiguous(), "vec", x.batched), self.fc, out_fp32=True)
+
+    @boundary
+    def __call__(self, x, *, key=None):                                # reference :261-273
+        x = self._tokens(x)
+        for blk in self.blocks:
+            x = blk(x)
+        return self._head(x)
+
+    @boundary
+    def get_last_self_attention(self, x, *, key=None):                 # reference :275-292
+        if not self.inference:
+            raise ValueError("Model being evaluated outside inference mode. Try in inference mode.")
+        x = self._tokens(x)
+        for blk in self.blocks[:-1]:
+            x = blk(x)
+        return self.blocks[-1](x, return_attention=True)
+
+
+def _vit(patch_size, embed_dim, depth, num_heads, mlp_ratio, torch_weights, key, kwargs):
+    model = VisionTransformer(patch_size=patch_size, embed_dim=embed_dim, depth=depth, num_heads=num_heads,
+                              mlp_ratio=mlp_ratio, key=key, **kwargs)
+    if torch_weights:
+        model = load_torch_weights(model, torch_weights=torch_weights)
+    return model
+
+
+def vit_tiny(patch_size=16, embed_dim=192, depth=12, num_heads=3, mlp_ratio=4, torch_weights: str = None, *,
+             key=None, **kwargs):
+    return _vit(patch_size, embed_dim, depth, num_heads, mlp_ratio, torch_weights, key, kwargs)
+
+
+def vit_small(patch_size=16, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4, torch_weights: str = None, *,
+              key=None, **kwargs):
+    return _vit(patch_size, embed_dim, depth, num_heads, mlp_ratio, torch_weights, key, kwargs)
+
+
+def vit_base(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, torch_weights: str = None, *,
+             key=None, **kwargs):
+    """ViT-B/16 (reference :370-404): 12 blocks, 768-d, 12 heads, 17.6 GMAC per 224x224 image."""
+    return _vit(patch_size, embed_dim, depth, num_heads, mlp_ratio, torch_weights, key, kwargs)
+
+
+vit_b_16 = vit_base   # the north star's name for vit_base(patch_size=16)

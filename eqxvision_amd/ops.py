@@ -1,0 +1,353 @@
+"""Host-side operator layer: Python wrappers that marshal `Act`s into the C ABI
+(`include/eqxvision_amd.h`).  One function per fused op of the hot path; weight preparation
+(BN folding, KRSC re-layout, bf16 conversion) happens once per module and is cached on it.
+
+Everything here enqueues HIP kernels on torch's current stream; nothing computes on the host.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._act import Act, DT, TORCH_DT, compute_dtype, device, empty, stream_ptr
+
+ACT = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "gelu": _lib.ACT_GELU_TANH}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _dev(a: np.ndarray, dtype: torch.dtype) -> torch.Tensor:
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if t.dtype != dtype:
+        t = t.to(dtype)            # host-side RNE conversion of constants (weights)
+    return t.to(device())
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+# ------------------------------------------------------------------ weight preparation (cached)
+def bn_fold(bn) -> Tuple[np.ndarray, np.ndarray]:
+    """BatchNorm inference as per-channel scale/shift:  (x-mean)/sqrt(var+eps)*w+b."""
+    st = bn.state_index.value
+    if st is None:
+        raise RuntimeError(
+            "BatchNorm has no running statistics (the reference's unloaded eqx.experimental.BatchNorm "
+            "cannot run inference either); load weights or set them via load_torch_weights")
+    mean, var = st
+    inv = 1.0 / np.sqrt(np.asarray(var, np.float32) + np.float32(bn.eps))
+    g = np.asarray(bn.weight, np.float32) if bn.weight is not None else np.ones_like(inv)
+    b = np.asarray(bn.bias, np.float32) if bn.bias is not None else np.zeros_like(inv)
+    scale = (g * inv).astype(np.float32)
+    shift = (b - np.asarray(mean, np.float32) * scale).astype(np.float32)
+    return scale, shift
+
+
+def _check_bn(bn):
+    if bn is not None and not bn.inference:
+        raise NotImplementedError(
+            "BatchNorm in training mode (batch statistics + pmean over axis_name) is outside the inference "
+            "hot path; call eqxvision_amd.tree_inference(model, True) first")
+
+
+def prep_conv(conv, bn, layout: str, dtype: str):
+    key = ("conv", layout, dtype, id(bn))
+    cache = conv._cache()
+    hit = cache.get(key)
+    if hit is not None:
+        return hit
+    w = np.asarray(conv.weight, np.float32)                      # (O, I/g, kh, kw)
+    if layout == "krsc":
+        w = np.ascontiguousarray(w.transpose(0, 2, 3, 1))
+    bias = None if conv.bias is None else np.asarray(conv.bias, np.float32).reshape(-1)
+    scale = shift = None
+    if bn is not None:
+        scale, shift = bn_fold(bn)
+        if bias is not None:
+            shift = shift + bias * scale
+    elif bias is not None:
+        shift = bias
+    out = (_dev(w, TORCH_DT[dtype]),
+           None if scale is None else _dev(scale, torch.float32),
+           None if shift is None else _dev(shift, torch.float32))
+    cache[key] = out
+    return out
+
+
+def prep_linear(lin, dtype: str):
+    key = ("lin", dtype)
+    cache = lin._cache()
+    hit = cache.get(key)
+    if hit is not None:
+        return hit
+    w = _dev(np.asarray(lin.weight, np.float32), TORCH_DT[dtype])
+    b = None if lin.bias is None else _dev(np.asarray(lin.bias, np.float32).reshape(-1), torch.float32)
+    cache[key] = (w, b)
+    return w, b
+
+
+def prep_f32(mod, name: str, arr) -> Optional[torch.Tensor]:
+    if arr is None:
+        return None
+    cache = mod._cache()
+    key = ("f32", name)
+    hit = cache.get(key)
+    if hit is None:
+        hit = _dev(np.asarray(arr, np.float32), torch.float32)
+        cache[key] = hit
+    return hit
+
+
+# ------------------------------------------------------------------ layout plumbing
+def as_map(x: Act) -> Act:
+    """img (NCHW, user dtype) -> map (NHWC, compute dtype)."""
+    if x.kind == "map":
+        return x
+    if x.kind != "img":
+        raise ValueError(f"expected an image / feature map, got {x}")
+    B, C, H, W = x.t.shape
+    dt = compute_dtype()
+    y = empty((B, H, W, C), TORCH_DT[dt])
+    _lib.call("mv_nchw_to_nhwc", _ptr(x.t), _ptr(y), B, C, H, W, x.dt, DT[dt], stream_ptr())
+    return Act(y, "map", x.batched)
+
+
+def as_rows(x: Act) -> Act:
+    """seq / vec in the compute dtype."""
+    dt = compute_dtype()
+    if x.t.dtype == TORCH_DT[dt]:
+        return x
+    y = empty(tuple(x.t.shape), TORCH_DT[dt])
+    _lib.call("mv_cast", _ptr(x.t), _ptr(y), x.t.numel(), x.dt, DT[dt], stream_ptr())
+    return Act(y, x.kind, x.batched)
+
+
+def to_user(x: Act) -> torch.Tensor:
+    """Act -> fp32 torch tensor in the reference's logical layout (batch axis kept iff batched)."""
+    if x.kind == "map":
+        B, H, W, C = x.t.shape
+        y = empty((B, C, H, W), torch.float32)
+        _lib.call("mv_nhwc_to_nchw", _ptr(x.t), _ptr(y), B, C, H, W, x.dt, _lib.F32, stream_ptr())
+    elif x.t.dtype == torch.float32:
+        y = x.t
+    else:
+        y = empty(tuple(x.t.shape), torch.float32)
+        _lib.call("mv_cast", _ptr(x.t), _ptr(y), x.t.numel(), x.dt, _lib.F32, stream_ptr())
+    return y if x.batched else y[0]
+
+
+def flatten(x: Act) -> Act:
+    """jnp.ravel of the logical (C,H,W) sample -> vec, CHW order (alexnet.py:83, resnet.py:355)."""
+    if x.kind == "vec":
+        return x
+    if x.kind == "seq":
+        B = x.B
+        return Act(x.t.reshape(B, -1), "vec", x.batched)
+    x = as_map(x)
+    B, H, W, C = x.t.shape
+    if H * W == 1:
+        return Act(x.t.reshape(B, C), "vec", x.batched)
+    y = empty((B, C, H, W), x.t.dtype)
+    _lib.call("mv_nhwc_to_nchw", _ptr(x.t), _ptr(y), B, C, H, W, x.dt, x.dt, stream_ptr())
+    return Act(y.reshape(B, C * H * W), "vec", x.batched)
+
+
+# ------------------------------------------------------------------ contractions
+STEM_MAX_CIN = 4
+
+
+def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> Act:
+    """Conv2d [+ BatchNorm(inference)] [+ residual] [+ relu/gelu], one launch."""
+    _check_bn(bn)
+    dt = compute_dtype()
+    kh, kw = conv.kernel_size
+    sh, sw = conv.stride
+    ph, pw = conv.padding
+    dh, dw = conv.dilation
+    K, Cin = conv.out_channels, conv.in_channels
+    if x.kind == "img" and Cin <= STEM_MAX_CIN and conv.groups == 1 and dh == 1 and dw == 1 and residual is None:
+        B, C, H, W = x.t.shape
+        if C != Cin:
+            raise ValueError(f"Conv2d expected {Cin} input channels, got {C}")
+        w, scale, shift = prep_conv(conv, bn, "oihw", dt)
+        Ho = (H + 2 * ph - (kh - 1) - 1) // sh + 1
+        Wo = (W + 2 * pw - (kw - 1) - 1) // sw + 1
+        y = empty((B, Ho, Wo, K), TORCH_DT[dt])
+        _lib.call("mv_conv2d_nchw_fwd", _ptr(x.t), _ptr(w), _ptr(scale), _ptr(shift), _ptr(y),
+                  B, C, H, W, K, kh, kw, sh, sw, ph, pw, ACT[act], x.dt, DT[dt], 0, 0, None, stream_ptr())
+        return Act(y, "map", x.batched)
+    x = as_map(x)
+    B, H, W, C = x.t.shape
+    if C != Cin:
+        raise ValueError(f"Conv2d expected {Cin} input channels, got {C}")
+    if x.t.dtype != TORCH_DT[dt]:
+        raise ValueError(f"activation dtype {x.t.dtype} does not match compute dtype {dt}")
+    w, scale, shift = prep_conv(conv, bn, "krsc", dt)
+    Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    y = empty((B, Ho, Wo, K), TORCH_DT[dt])
+    res = None
+    if residual is not None:
+        residual = as_map(residual)
+        if tuple(residual.t.shape) != (B, Ho, Wo, K):
+            raise ValueError(f"residual shape {tuple(residual.t.shape)} != conv output {(B, Ho, Wo, K)}")
+        res = residual.t
+    _lib.call("mv_conv2d_nhwc_fwd", _ptr(x.t), _ptr(w), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y),
+              B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, conv.groups, ACT[act], DT[dt], DT[dt], stream_ptr())
+    return Act(y, "map", x.batched)
+
+
+def linear(x: Act, lin, act=None, residual: Optional[Act] = None, out_fp32: bool = False) -> Act:
+    """Linear over the last (feature) axis of rows: seq [B,N,D], vec [B,D] or map (Linear2d)."""
+    dt = compute_dtype()
+    x = as_map(x) if x.kind in ("img", "map") else as_rows(x)
+    w, b = prep_linear(lin, dt)
+    N, K = lin.out_features, lin.in_features
+    if x.t.shape[-1] != K:
+        raise ValueError(f"Linear expected {K} input features, got {x.t.shape[-1]}")
+    M = x.t.numel() // K
+    odt = torch.float32 if out_fp32 else TORCH_DT[dt]
+    y = empty(tuple(x.t.shape[:-1]) + (N,), odt)
+    res = None
+    if residual is not None:
+        if tuple(residual.t.shape) != tuple(y.shape) or residual.t.dtype != odt:
+            raise ValueError("residual shape/dtype mismatch in linear")
+        res = residual.t
+    _lib.call("mv_linear_fwd", _ptr(x.t), _ptr(w), None, _ptr(b), _ptr(res), _ptr(y), M, N, K, ACT[act],
+              DT[dt], _lib.F32 if out_fp32 else DT[dt], stream_ptr())
+    return Act(y, x.kind, x.batched)
+
+
+def patch_embed_tokens(x: Act, conv, cls: Optional[torch.Tensor], pos: Optional[torch.Tensor], n_extra: int) -> Act:
+    """PatchEmbed conv (k = s = patch) straight from the NCHW image into token rows
+    [B, n_extra + P, D]; with `pos` the position embedding is added in the epilogue and row 0 gets
+    cls + pos[0] (vit.py:268-269)."""
+    dt = compute_dtype()
+    if x.kind != "img":
+        raise ValueError("patch_embed expects a raw (C,H,W) image")
+    B, C, H, W = x.t.shape
+    kh, kw = conv.kernel_size
+    sh, sw = conv.stride
+    ph, pw = conv.padding
+    K = conv.out_channels
+    w, scale, shift = prep_conv(conv, None, "oihw", dt)
+    Ho = (H + 2 * ph - kh) // sh + 1
+    Wo = (W + 2 * pw - kw) // sw + 1
+    T = n_extra + Ho * Wo
+    y = empty((B, T, K), TORCH_DT[dt])
+    _lib.call("mv_conv2d_nchw_fwd", _ptr(x.t), _ptr(w), _ptr(scale), _ptr(shift), _ptr(y),
+              B, C, H, W, K, kh, kw, sh, sw, ph, pw, _lib.ACT_NONE, x.dt, DT[dt], T, n_extra, _ptr(pos), stream_ptr())
+    if n_extra:
+        _lib.call("mv_vit_cls_pos_fwd", _ptr(cls), _ptr(pos), _ptr(y), B, T, K, DT[dt], stream_ptr())
+    return Act(y, "seq", x.batched)
+
+
+# ------------------------------------------------------------------ normalisation / pooling
+def layernorm(x: Act, ln) -> Act:
+    x = as_map(x) if x.kind in ("img", "map") else as_rows(x)
+    C = x.t.shape[-1]
+    if int(np.prod(ln.shape)) != C:
+        raise ValueError(f"LayerNorm over {ln.shape} applied to rows of {C}")
+    g = prep_f32(ln, "weight", ln.weight)
+    b = prep_f32(ln, "bias", ln.bias)
+    y = empty(tuple(x.t.shape), x.t.dtype)
+    _lib.call("mv_layernorm_fwd", _ptr(x.t), _ptr(g), _ptr(b), _ptr(y), x.t.numel() // C, C, float(ln.eps),
+              x.dt, x.dt, stream_ptr())
+    return Act(y, x.kind, x.batched)
+
+
+def batchnorm(x: Act, bn, act=None) -> Act:
+    """Stand-alone BatchNorm inference (unfused call sites): per-channel affine."""
+    _check_bn(bn)
+    x = as_map(x) if x.kind in ("img", "map") else as_rows(x)
+    cache = bn._cache()
+    hit = cache.get("fold")
+    if hit is None:
+        s, h = bn_fold(bn)
+        hit = (_dev(s, torch.float32), _dev(h, torch.float32))
+        cache["fold"] = hit
+    C = x.t.shape[-1]
+    y = empty(tuple(x.t.shape), x.t.dtype)
+    _lib.call("mv_channel_affine_fwd", _ptr(x.t), _ptr(hit[0]), _ptr(hit[1]), _ptr(y), x.t.numel() // C, C,
+              ACT[act], x.dt, stream_ptr())
+    return Act(y, x.kind, x.batched)
+
+
+def maxpool2d(x: Act, kernel_size, stride, padding) -> Act:
+    x = as_map(x)
+    B, H, W, C = x.t.shape
+    kh, kw = _pair(kernel_size)
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    Ho = (H + 2 * ph - kh) // sh + 1
+    Wo = (W + 2 * pw - kw) // sw + 1
+    y = empty((B, Ho, Wo, C), x.t.dtype)
+    _lib.call("mv_maxpool2d_nhwc_fwd", _ptr(x.t), _ptr(y), B, H, W, C, kh, kw, sh, sw, ph, pw, x.dt, stream_ptr())
+    return Act(y, "map", x.batched)
+
+
+def adaptive_avgpool2d(x: Act, target) -> Act:
+    x = as_map(x)
+    B, H, W, C = x.t.shape
+    oh, ow = _pair(target)
+    if oh == H and ow == W:
+        return x
+    y = empty((B, oh, ow, C), x.t.dtype)
+    _lib.call("mv_adaptive_avgpool2d_nhwc_fwd", _ptr(x.t), _ptr(y), B, H, W, C, oh, ow, x.dt, x.dt, stream_ptr())
+    return Act(y, "map", x.batched)
+
+
+# ------------------------------------------------------------------ attention
+def mha(qkv: Act, heads: int, scale: float, need_probs: bool):
+    """qkv rows [B,N,3D] -> ([B,N,D], probs fp32 [B,heads,N,N] or None)   (vit.py:65-73)."""
+    B, N, D3 = qkv.t.shape
+    D = D3 // 3
+    dh = D // heads
+    out = empty((B, N, D), qkv.t.dtype)
+    probs = empty((B, heads, N, N), torch.float32) if need_probs else None
+    _lib.call("mv_mha_fwd", _ptr(qkv.t), _ptr(out), _ptr(probs), B, N, heads, dh, float(scale), qkv.dt, stream_ptr())
+    return Act(out, "seq", qkv.batched), probs
+
+
+def swin_window_attention(qkv: Act, bias: torch.Tensor, heads: int, window, shift) -> Act:
+    B, Hf, Wf, C3 = qkv.t.shape
+    C = C3 // 3
+    out = empty((B, Hf, Wf, C), qkv.t.dtype)
+    _lib.call("mv_swin_window_attn_fwd", _ptr(qkv.t), _ptr(bias), _ptr(out), B, Hf, Wf, C, heads,
+              int(window[0]), int(window[1]), int(shift[0]), int(shift[1]), qkv.dt, stream_ptr())
+    return Act(out, "map", qkv.batched)
+
+
+def patch_merge_gather(x: Act) -> Act:
+    x = as_map(x)
+    B, H, W, C = x.t.shape
+    y = empty((B, (H + 1) // 2, (W + 1) // 2, 4 * C), x.t.dtype)
+    _lib.call("mv_patch_merge_gather_nhwc", _ptr(x.t), _ptr(y), B, H, W, C, x.dt, stream_ptr())
+    return Act(y, "map", x.batched)
+
+
+# ------------------------------------------------------------------ element-wise (unfused call sites)
+def _canon(x: Act) -> Act:
+    return as_map(x) if x.kind == "img" else (x if x.kind == "map" else as_rows(x))
+
+
+def eltwise(x: Act, act: str) -> Act:
+    x = _canon(x)
+    y = empty(tuple(x.t.shape), x.t.dtype)
+    _lib.call("mv_eltwise_fwd", _ptr(x.t), _ptr(y), x.t.numel(), ACT[act], x.dt, stream_ptr())
+    return Act(y, x.kind, x.batched)
+
+
+def add(a: Act, b: Act, act=None) -> Act:
+    a, b = _canon(a), _canon(b)
+    if tuple(a.t.shape) != tuple(b.t.shape) or a.t.dtype != b.t.dtype:
+        raise ValueError(f"add: mismatched operands {a} vs {b}")
+    y = empty(tuple(a.t.shape), a.t.dtype)
+    _lib.call("mv_add_fwd", _ptr(a.t), _ptr(b.t), _ptr(y), a.t.numel(), ACT[act], a.dt, stream_ptr())
+    return Act(y, a.kind, a.batched)

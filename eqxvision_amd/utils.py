@@ -1,0 +1,106 @@
+"""`eqxvision.utils` for the hot path: the ordered torch-checkpoint loader and the URL table.
+
+`load_torch_weights` reproduces the reference's contract (eqxvision/utils.py:120-219, SURVEY
+Appendix C): iterate the torch `state_dict` in file order, skip keys containing "running" /
+"num_batches", and hand the remaining tensors one-per-array-leaf to the model in pytree-flatten
+order (reshaped to the leaf's shape); BatchNorm running statistics are consumed in the same file
+order by the `StateIndex` leaves.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Optional
+
+import numpy as np
+
+from ._module import Module, StateIndex, tree_leaves, tree_map
+
+_TEMP_DIR = "/tmp/.eqx"          # same cache dir as the reference (utils.py:17)
+
+_PT = "https://download.pytorch.org/models/"
+_DINO = "https://dl.fbaipublicfiles.com/dino/"
+# key -> checkpoint file stem; keys are the reference's (including its "sim_b" typo, utils.py:79)
+_STEMS = {
+    "alexnet": "alexnet-owt-7be5be79",
+    "resnet18": "resnet18-5c106cde", "resnet34": "resnet34-333f7ec4", "resnet50": "resnet50-19c8e357",
+    "resnet101": "resnet101-5d3b4d8f", "resnet152": "resnet152-b121ed2d",
+    "resnext50_32x4d": "resnext50_32x4d-7cdf4587", "resnext101_32x8d": "resnext101_32x8d-8ba56ff5",
+    "wide_resnet50_2": "wide_resnet50_2-95faca4d", "wide_resnet101_2": "wide_resnet101_2-32ee1156",
+    "swin_t": "swin_t-704ceda3", "swin_s": "swin_s-5e29d889", "sim_b": "swin_b-68c6b09e",
+}
+CLASSIFICATION_URLS = {k: f"{_PT}{v}.pth" for k, v in _STEMS.items()}
+for _arch, _dir in (("small", "deitsmall"), ("base", "vitbase")):
+    for _p in (16, 8):
+        CLASSIFICATION_URLS[f"vit_{_arch}_patch{_p}_224_dino"] = (
+            f"{_DINO}dino_{_dir}{_p}_pretrain/dino_{_dir}{_p}_pretrain.pth")
+
+
+def _resolve(torch_weights: str) -> str:
+    if os.path.exists(torch_weights):
+        return torch_weights
+    cached = os.path.join(_TEMP_DIR, os.path.basename(torch_weights))
+    if os.path.exists(cached):
+        logging.info(f"Downloaded file exists at {cached}. Using the cached file!")
+        return cached
+    import torch
+    os.makedirs(_TEMP_DIR, exist_ok=True)
+    torch.hub.download_url_to_file(torch_weights, cached)     # network boundary (reference :159-170)
+    return cached
+
+
+def _is_param_leaf(leaf) -> bool:
+    # reference :192-199: every array leaf that is not a size-1 bool takes the next checkpoint tensor
+    return isinstance(leaf, np.ndarray) and not (leaf.size == 1 and leaf.dtype == np.bool_)
+
+
+def load_torch_weights(model: Module, torch_weights: Optional[str] = None) -> Module:
+    """Return a copy of `model` whose array leaves are replaced, in order, by the tensors of a
+    PyTorch checkpoint (path or URL)."""
+    try:
+        import torch
+    except ImportError as e:  # pragma: no cover
+        raise RuntimeError(" Torch package not found! Pretrained is only supported with the torch package.") from e
+    if torch_weights is None:
+        raise ValueError("torch_weights parameter cannot be empty!")
+    saved = torch.load(_resolve(torch_weights), map_location="cpu")
+    params, stats = [], []
+    for name, w in saved.items():
+        arr = w.detach().cpu().numpy() if hasattr(w, "detach") else np.asarray(w)
+        if "running_mean" in name:
+            stats.append([arr.astype(np.float32), None])
+        elif "running_var" in name:
+            stats[-1][1] = arr.astype(np.float32)
+        elif "num_batches" not in name:
+            params.append((name, arr))
+    it_p = iter(params)
+    it_s = iter(stats)
+    n_state = [0]
+
+    def replace(leaf):
+        if _is_param_leaf(leaf):
+            try:
+                name, arr = next(it_p)
+            except StopIteration:
+                raise ValueError("checkpoint has fewer tensors than the model has array leaves") from None
+            if arr.size != leaf.size:
+                raise ValueError(f"checkpoint tensor {name} {arr.shape} cannot fill a leaf of shape {leaf.shape}")
+            dt = leaf.dtype if np.issubdtype(leaf.dtype, np.integer) else np.float32
+            return np.ascontiguousarray(arr.reshape(leaf.shape).astype(dt))
+        if isinstance(leaf, StateIndex):
+            # leaves come in pairs per BatchNorm: first_time_index <- False, state_index <- (mean, var)
+            n_state[0] += 1
+            if n_state[0] % 2 == 1:
+                return StateIndex(False)
+            try:
+                mean, var = next(it_s)
+            except StopIteration:
+                raise ValueError("checkpoint has fewer BatchNorm statistics than the model has BatchNorm layers") from None
+            return StateIndex((mean, var))
+        return leaf
+
+    new = tree_map(replace, model)
+    leftover = sum(1 for _ in it_p)
+    if leftover:
+        raise ValueError(f"checkpoint has {leftover} more tensors than the model has array leaves")
+    return new

@@ -1,0 +1,136 @@
+/* eqxvision_amd -- C ABI of the MI355X (gfx950) forward-pass engine.
+ *
+ * The reference (paganpasta/eqxvision) has NO native/FFI interface: its hot path is
+ * `jax.vmap(net, axis_name="batch")(images, key=keys)` (README.md:37-40) over
+ * `eqx.Module.__call__`s that bottom out in equinox/jax ops.  This header is the boundary the
+ * replacement sits behind; each entry point names the reference op(s) it replaces.  The Python
+ * host (`eqxvision_amd/_lib.py`) binds it with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch .data_ptr()), dense, caller-owned;
+ *   - activations are NHWC ("pixel-major, channel-contiguous") or row-major [rows][features];
+ *     the only NCHW tensors are user images entering `mv_conv2d_nchw_fwd` and the layout
+ *     converters;
+ *   - dtype codes: MV_F32 / MV_BF16.  bf16 = bf16 storage, fp32 accumulate, fp32 epilogue;
+ *   - all work is enqueued on `stream` (a hipStream_t; NULL = default stream), asynchronous;
+ *   - return 0 on success, negative MV_E_* on argument errors, positive = hipError_t;
+ *     `mv_last_error()` gives a thread-local message.  Nothing aborts or throws across the ABI.
+ */
+#ifndef EQXVISION_AMD_H
+#define EQXVISION_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MV_ABI_VERSION 1
+
+typedef void* mv_stream_t; /* hipStream_t */
+
+enum { MV_F32 = 0, MV_BF16 = 1 };
+enum { MV_ACT_NONE = 0, MV_ACT_RELU = 1, MV_ACT_GELU_TANH = 2 };
+enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
+/* mv_set_flag names: "force_generic" (1 = route every op to the simple VALU kernels, used by
+ * tests to cross-check the MFMA kernels), "igemm_tile" (override tile heuristic, 0 = auto). */
+
+int mv_abi_version(void);
+const char* mv_last_error(void);
+int mv_set_flag(const char* name, int value);
+int mv_get_flag(const char* name);
+/* name of the kernel variant the last call on this thread dispatched to (for tests/bench) */
+const char* mv_last_kernel(void);
+
+/* eqx.nn.Conv2d (+ eqx.experimental.BatchNorm inference + relu + residual add), reference call
+ * sites resnet.py:144-162, conv_norm_activation.py:60-85, alexnet.py:44-55.
+ *   y[n,ho,wo,k] = act( scale[k] * sum_{r,s,c} x[n, ho*sh-ph+r*dh, wo*sw-pw+s*dw, c] * w[k,r,s,c]
+ *                       + shift[k] + residual[n,ho,wo,k] )
+ * x NHWC [N,H,W,C]; w KRSC [K][R][S][C/groups] (same dtype as x); scale/shift fp32 [K] or NULL
+ * (=1 / =0); residual (out_dtype, NHWC like y) or NULL. */
+int mv_conv2d_nhwc_fwd(const void* x, const void* w, const float* scale, const float* shift,
+                       const void* residual, void* y,
+                       int N, int H, int W, int C, int K, int R, int S,
+                       int sh, int sw, int ph, int pw, int dh, int dw, int groups,
+                       int act, int in_dtype, int out_dtype, mv_stream_t stream);
+
+/* Same contraction for a raw NCHW image batch (the network entry: resnet.py:243-251 stem,
+ * alexnet.py:44 conv1, patch_embed.py:60-62/79-82, swin.py:705-711).  x NCHW [N,C,H,W] of
+ * x_dtype; w OIHW [K][C][R][S] of out_dtype; y NHWC rows of out_dtype.
+ * Token mode (ViT): if tok_stride > 0 the output row of pixel p of image n is
+ * n*tok_stride + tok_offset + p and `pos` (fp32 [tok_stride][K]) row tok_offset+p is added
+ * (vit.py:269: concat(cls, x) + pos_embed).  Otherwise tok_stride = tok_offset = 0, pos NULL. */
+int mv_conv2d_nchw_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y,
+                       int N, int C, int H, int W, int K, int R, int S,
+                       int sh, int sw, int ph, int pw, int act, int x_dtype, int out_dtype,
+                       int tok_stride, int tok_offset, const float* pos, mv_stream_t stream);
+
+/* eqx.nn.Linear under vmap / Linear2d (vit.py:64,74; mlps.py:60-64; resnet.py:356;
+ * extensions_2d.py:31-50):  y[M,N] = act(scale[n]*(x[M,K] . w[N,K]^T) + shift[n] + residual[M,N]) */
+int mv_linear_fwd(const void* x, const void* w, const float* scale, const float* shift,
+                  const void* residual, void* y, int64_t M, int N, int K,
+                  int act, int in_dtype, int out_dtype, mv_stream_t stream);
+
+/* eqx.nn.MaxPool2d (resnet.py:254, alexnet.py:46,49,56): -inf padding, floor output size. */
+int mv_maxpool2d_nhwc_fwd(const void* x, void* y, int N, int H, int W, int C,
+                          int kh, int kw, int sh, int sw, int ph, int pw, int dtype, mv_stream_t stream);
+
+/* eqx.nn.AdaptiveAvgPool2d (resnet.py:283, alexnet.py:59, swin.py:757), equinox chunking rule. */
+int mv_adaptive_avgpool2d_nhwc_fwd(const void* x, void* y, int N, int H, int W, int C, int oh, int ow,
+                                   int in_dtype, int out_dtype, mv_stream_t stream);
+
+/* eqx.nn.LayerNorm under vmap / LayerNorm2d (vit.py:149,154,272; extensions_2d.py:9-28):
+ * rows of C, biased variance, gamma/beta fp32 [C] or NULL. */
+int mv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                     int64_t M, int C, float eps, int in_dtype, int out_dtype, mv_stream_t stream);
+
+/* _VitAttention core (vit.py:65-73): qkv [B,N,3,H,dh] (the qkv Linear output, channel order
+ * [q|k|v][head][dh]) -> out [B,N,H*dh] = merge_heads(softmax(q k^T * scale) v);
+ * probs (fp32 [B,H,N,N]) optional (NULL) -- the `attn` the reference returns. */
+int mv_mha_fwd(const void* qkv, void* out, float* probs, int B, int N, int H, int dh, float scale,
+               int dtype, mv_stream_t stream);
+
+/* _shifted_window_attention core (swin.py:123-250) on the qkv Linear2d output:
+ * qkv NHWC [B,Hf,Wf,3*C] -> out NHWC [B,Hf,Wf,C]; cyclic shift, window partition/reverse and
+ * the shift mask are folded into addressing; bias fp32 [heads][ws*ws][ws*ws] (table[index]). */
+int mv_swin_window_attn_fwd(const void* qkv, const float* bias, void* out, int B, int Hf, int Wf, int C,
+                            int heads, int ws_h, int ws_w, int shift_h, int shift_w,
+                            int dtype, mv_stream_t stream);
+
+/* _patch_merging_pad (swin.py:23-31): NHWC [B,H,W,C] -> [B,H/2,W/2,4C], channel blocks
+ * [x(0::2,0::2) | x(1::2,0::2) | x(0::2,1::2) | x(1::2,1::2)], zero pad odd H/W. */
+int mv_patch_merge_gather_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, mv_stream_t stream);
+
+/* vit.py:269 row 0 of every image: tokens[b,0,:] = cls[:] + pos[0,:] (fp32 inputs). */
+int mv_vit_cls_pos_fwd(const float* cls, const float* pos, void* tokens, int B, int tok_stride, int D,
+                       int dtype, mv_stream_t stream);
+
+/* jax.nn.relu / jax.nn.gelu (tanh form) / residual add as standalone ops (unfused call sites) */
+int mv_eltwise_fwd(const void* x, void* y, int64_t n, int act, int dtype, mv_stream_t stream);
+int mv_add_fwd(const void* a, const void* b, void* y, int64_t n, int act, int dtype, mv_stream_t stream);
+/* per-channel affine y = act(x*scale[c] + shift[c]) over rows of C (stand-alone BatchNorm inference) */
+int mv_channel_affine_fwd(const void* x, const float* scale, const float* shift, void* y,
+                          int64_t rows, int C, int act, int dtype, mv_stream_t stream);
+
+/* layout / dtype plumbing at the user boundary */
+int mv_nchw_to_nhwc(const void* x, void* y, int N, int C, int H, int W, int in_dtype, int out_dtype, mv_stream_t stream);
+int mv_nhwc_to_nchw(const void* x, void* y, int N, int C, int H, int W, int in_dtype, int out_dtype, mv_stream_t stream);
+int mv_cast(const void* x, void* y, int64_t n, int in_dtype, int out_dtype, mv_stream_t stream);
+
+/* hipGraph capture of a whole forward (replaces the reference's eqx.filter_jit executable) */
+int mv_graph_begin_capture(mv_stream_t stream);
+int mv_graph_end_capture(mv_stream_t stream, void** graph_exec);
+int mv_graph_launch(void* graph_exec, mv_stream_t stream);
+int mv_graph_destroy(void* graph_exec);
+
+/* HIP-event timing helpers on the caller's stream (bench.py's live roofline measurement) */
+int mv_event_create(void** ev);
+int mv_event_record(void* ev, mv_stream_t stream);
+int mv_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+int mv_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EQXVISION_AMD_H */

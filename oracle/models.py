@@ -1,0 +1,193 @@
+"""CPU ORACLE (test infrastructure): numpy restatement of the four hot-path models of
+paganpasta/eqxvision, single-sample like the reference, keyed by torch-style
+`state_dict` names (see oracle/state.py).  PARITY UNPINNED -- see oracle/np_ops.py.
+
+Each function cites the reference lines it follows.  `bf16=True` emulates the
+product's storage precision (weights and inter-layer activations rounded to
+bf16, fp32 accumulation, fp32 epilogues) so that kernel bugs are separated from
+expected bf16 rounding.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import np_ops as O
+
+F32 = np.float32
+
+
+class _Q:
+    """Optional bf16 storage emulation."""
+
+    def __init__(self, bf16):
+        self.on = bf16
+
+    def __call__(self, x):
+        return O.bf16_round(x) if self.on else np.asarray(x, F32)
+
+
+def _bn_fold(sd, name, eps=1e-5):
+    inv = 1.0 / np.sqrt(sd[name + ".running_var"].astype(F32) + F32(eps))
+    scale = sd[name + ".weight"].astype(F32) * inv
+    shift = sd[name + ".bias"].astype(F32) - sd[name + ".running_mean"].astype(F32) * scale
+    return scale.astype(F32), shift.astype(F32)
+
+
+def _conv_bn(sd, q, x, conv, bn, stride=1, padding=0, dilation=1, groups=1, relu=False, residual=None):
+    """conv -> BN(inference) [-> + residual] [-> relu]; rounding only at the layer output."""
+    y = O.conv2d(x, q(sd[conv + ".weight"]), None, stride, padding, dilation, groups)
+    if bn is not None:
+        if q.on:       # product folds BN into an fp32 scale/shift epilogue
+            sc, sh = _bn_fold(sd, bn)
+            y = y * sc[:, None, None] + sh[:, None, None]
+        else:          # literal reference order: (x-mean)/sqrt(var+eps)*w+b
+            y = O.batchnorm_inference(y, sd[bn + ".weight"], sd[bn + ".bias"],
+                                      sd[bn + ".running_mean"], sd[bn + ".running_var"])
+    if residual is not None:
+        y = y + residual
+    if relu:
+        y = O.relu(y)
+    return q(y)
+
+
+# ---------------------------------------------------------------- alexnet.py:41-85
+def alexnet_features(sd, x, bf16=False):
+    q = _Q(bf16)
+    x = q(x)
+
+    def cr(x, name, stride, pad):
+        y = O.conv2d(x, q(sd[name + ".weight"]), sd[name + ".bias"], stride, pad)
+        return q(O.relu(y))
+
+    x = cr(x, "features.0", 4, 2)
+    x = O.maxpool2d(x, 3, 2)
+    x = cr(x, "features.3", 1, 2)
+    x = O.maxpool2d(x, 3, 2)
+    x = cr(x, "features.6", 1, 1)
+    x = cr(x, "features.8", 1, 1)
+    x = cr(x, "features.10", 1, 1)
+    x = O.maxpool2d(x, 3, 2)
+    return x
+
+
+def alexnet_forward(sd, x, bf16=False):
+    q = _Q(bf16)
+    x = alexnet_features(sd, x, bf16)
+    x = q(O.adaptive_avgpool2d(x, (6, 6)))                     # alexnet.py:82
+    x = np.ravel(x)                                            # alexnet.py:83
+    x = q(O.relu(O.linear(x, q(sd["classifier.1.weight"]), sd["classifier.1.bias"])))
+    x = q(O.relu(O.linear(x, q(sd["classifier.4.weight"]), sd["classifier.4.bias"])))
+    return O.linear(x, q(sd["classifier.6.weight"]), sd["classifier.6.bias"])
+
+
+# ---------------------------------------------------------------- resnet.py:144-162, 335-358
+def resnet_forward(sd, x, block="bottleneck", layers=(3, 4, 6, 3), bf16=False, groups=1):
+    q = _Q(bf16)
+    x = q(x)
+    x = _conv_bn(sd, q, x, "conv1", "bn1", stride=2, padding=3, relu=True)         # resnet.py:344-346
+    x = O.maxpool2d(x, 3, 2, 1)                                                      # resnet.py:347
+    for li, nblk in enumerate(layers):
+        stride = 1 if li == 0 else 2
+        for bi in range(nblk):
+            p = f"layer{li + 1}.{bi}"
+            s = stride if bi == 0 else 1
+            if (p + ".downsample.0.weight") in sd:                                   # resnet.py:295-303
+                identity = _conv_bn(sd, q, x, p + ".downsample.0", p + ".downsample.1", stride=s)
+            else:
+                identity = x
+            if block == "bottleneck":                                                # resnet.py:144-162
+                out = _conv_bn(sd, q, x, p + ".conv1", p + ".bn1", relu=True)
+                out = _conv_bn(sd, q, out, p + ".conv2", p + ".bn2", stride=s, padding=1, groups=groups, relu=True)
+                x = _conv_bn(sd, q, out, p + ".conv3", p + ".bn3", relu=True, residual=identity)
+            else:                                                                    # resnet.py:80-92
+                out = _conv_bn(sd, q, x, p + ".conv1", p + ".bn1", stride=s, padding=1, relu=True)
+                x = _conv_bn(sd, q, out, p + ".conv2", p + ".bn2", padding=1, relu=True, residual=identity)
+    x = q(O.adaptive_avgpool2d(x, (1, 1)))                                           # resnet.py:354
+    x = np.ravel(x)
+    return O.linear(x, q(sd["fc.weight"]), sd["fc.bias"])                            # resnet.py:356
+
+
+# ---------------------------------------------------------------- vit.py:139-157, 261-273
+def vit_block(sd, q, x, p, num_heads, return_attention=False):
+    y = q(O.layernorm_rows(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"]))       # vit.py:149
+    N, C = y.shape
+    dh = C // num_heads
+    qkv = y @ q(sd[p + ".attn.qkv.weight"]).T
+    if (p + ".attn.qkv.bias") in sd:
+        qkv = qkv + sd[p + ".attn.qkv.bias"]
+    qkv = q(qkv).reshape(N, 3, num_heads, dh).transpose(1, 2, 0, 3)                   # vit.py:65-66
+    qq, kk, vv = qkv[0], qkv[1], qkv[2]
+    attn = (qq @ np.transpose(kk, (0, 2, 1))) * F32(dh ** -0.5)                      # vit.py:69
+    attn = O.softmax(attn, -1)                                                       # vit.py:70
+    if return_attention:
+        return attn[None]                                                            # (1, heads, N, N)
+    a = q(np.transpose(q(attn) @ vv if q.on else attn @ vv, (1, 0, 2)).reshape(N, C))  # vit.py:73
+    y = a @ q(sd[p + ".attn.proj.weight"]).T + sd[p + ".attn.proj.bias"]             # vit.py:74
+    x = q(x + y)                                                                     # vit.py:153
+    y = q(O.layernorm_rows(x, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"]))       # vit.py:154
+    h = q(O.gelu_tanh(y @ q(sd[p + ".mlp.fc1.weight"]).T + sd[p + ".mlp.fc1.bias"]))  # mlps.py:61-62
+    y = h @ q(sd[p + ".mlp.fc2.weight"]).T + sd[p + ".mlp.fc2.bias"]                 # mlps.py:64
+    return q(x + y)                                                                  # vit.py:156
+
+
+def vit_tokens(sd, q, x, patch):
+    x = q(x)
+    t = O.patch_embed(x, q(sd["patch_embed.proj.weight"]), sd["patch_embed.proj.bias"], patch)  # vit.py:268
+    D = t.shape[1]
+    cls = sd["cls_token"].reshape(1, D)
+    pos = sd["pos_embed"].reshape(-1, D)
+    return q(np.concatenate([cls, t], 0) + pos)                                      # vit.py:269
+
+
+def vit_forward(sd, x, patch=16, num_heads=12, depth=12, bf16=False):
+    q = _Q(bf16)
+    x = vit_tokens(sd, q, x, patch)
+    for i in range(depth):
+        x = vit_block(sd, q, x, f"blocks.{i}", num_heads)
+    x = q(O.layernorm_rows(x, sd["norm.weight"], sd["norm.bias"]))                   # vit.py:272
+    if "fc.weight" in sd:
+        return O.linear(x[0], q(sd["fc.weight"]), sd["fc.bias"])                     # vit.py:273
+    return x[0]
+
+
+def vit_last_self_attention(sd, x, patch=16, num_heads=12, depth=12, bf16=False):
+    """vit.py:275-292"""
+    q = _Q(bf16)
+    x = vit_tokens(sd, q, x, patch)
+    for i in range(depth - 1):
+        x = vit_block(sd, q, x, f"blocks.{i}", num_heads)
+    return vit_block(sd, q, x, f"blocks.{depth - 1}", num_heads, return_attention=True)
+
+
+# ---------------------------------------------------------------- swin.py:572-578, 760-772
+def swin_block(sd, q, x, p, num_heads, window, shift):
+    y = q(O.layernorm2d(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"]))
+    bias = O.relative_position_bias(sd[p + ".attn.relative_position_bias_table"],
+                                    sd[p + ".attn.relative_position_index"], window)
+    y = O.shifted_window_attention(y, q(sd[p + ".attn.qkv.weight"]), q(sd[p + ".attn.proj.weight"]), bias,
+                                   window, num_heads, shift, sd[p + ".attn.qkv.bias"], sd[p + ".attn.proj.bias"])
+    x = q(x + y)
+    y = q(O.layernorm2d(x, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"]))
+    h = q(O.gelu_tanh(O.linear2d(y, q(sd[p + ".mlp.0.weight"]), sd[p + ".mlp.0.bias"])))
+    y = O.linear2d(h, q(sd[p + ".mlp.3.weight"]), sd[p + ".mlp.3.bias"])
+    return q(x + y)
+
+
+def swin_forward(sd, x, patch=(4, 4), depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window=(7, 7), bf16=False):
+    q = _Q(bf16)
+    x = q(x)
+    x = O.conv2d(x, q(sd["features.0.0.weight"]), sd["features.0.0.bias"], stride=tuple(patch))   # swin.py:705-711
+    x = q(O.layernorm2d(q(x), sd["features.0.2.weight"], sd["features.0.2.bias"]))
+    fi = 1
+    for si, depth in enumerate(depths):
+        for bi in range(depth):
+            shift = [0 if bi % 2 == 0 else w // 2 for w in window]                    # swin.py:736-738
+            x = swin_block(sd, q, x, f"features.{fi}.{bi}", num_heads[si], list(window), shift)
+        fi += 1
+        if si < len(depths) - 1:
+            p = f"features.{fi}"
+            x = q(O.patch_merging(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"], q(sd[p + ".reduction.weight"])))
+            fi += 1
+    x = q(O.layernorm2d(x, sd["norm.weight"], sd["norm.bias"]))                      # swin.py:768
+    x = q(O.adaptive_avgpool2d(x, (1, 1)))                                           # swin.py:769
+    return O.linear(np.ravel(x), q(sd["head.weight"]), sd["head.bias"])              # swin.py:771

@@ -1,0 +1,194 @@
+"""CPU ORACLE support (test infrastructure): synthetic torch-style `state_dict`s.
+
+The reference loads weights by ORDER from a torchvision / DINO `state_dict`
+(`eqxvision/utils.py:172-199`), so the synthetic checkpoints below follow the
+torchvision registration order and key names.  The same dict is fed (a) to the
+product through `load_torch_weights` and (b) to the oracle models in
+`oracle/models.py`, which is how both sides see identical weights.
+
+Distributions follow SURVEY.md section 8(d): Conv/Linear U(+-1/sqrt(fan_in)) (equinox default
+init), BN gamma~U[0.5,1.5], beta~N(0,0.1), mean~N(0,0.1), var~U[0.5,1.5].
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+F32 = np.float32
+
+
+def _u(rng, shape, fan_in):
+    lim = 1.0 / np.sqrt(fan_in)
+    return rng.uniform(-lim, lim, size=shape).astype(F32)
+
+
+def _conv(sd, rng, name, cin, cout, k, bias, groups=1):
+    kh, kw = (k, k) if isinstance(k, int) else k
+    fan = cin // groups * kh * kw
+    sd[name + ".weight"] = _u(rng, (cout, cin // groups, kh, kw), fan)
+    if bias:
+        sd[name + ".bias"] = _u(rng, (cout,), fan)
+
+
+def _linear(sd, rng, name, fin, fout, bias=True):
+    sd[name + ".weight"] = _u(rng, (fout, fin), fin)
+    if bias:
+        sd[name + ".bias"] = _u(rng, (fout,), fin)
+
+
+def _bn(sd, rng, name, c):
+    sd[name + ".weight"] = rng.uniform(0.5, 1.5, c).astype(F32)
+    sd[name + ".bias"] = (0.1 * rng.standard_normal(c)).astype(F32)
+    sd[name + ".running_mean"] = (0.1 * rng.standard_normal(c)).astype(F32)
+    sd[name + ".running_var"] = rng.uniform(0.5, 1.5, c).astype(F32)
+    sd[name + ".num_batches_tracked"] = np.asarray(1, np.int64)
+
+
+def _ln(sd, rng, name, c, randomize=True):
+    if randomize:
+        sd[name + ".weight"] = rng.uniform(0.5, 1.5, c).astype(F32)
+        sd[name + ".bias"] = (0.1 * rng.standard_normal(c)).astype(F32)
+    else:
+        sd[name + ".weight"] = np.ones(c, F32)
+        sd[name + ".bias"] = np.zeros(c, F32)
+
+
+def alexnet_state(seed=1, num_classes=1000):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    _conv(sd, rng, "features.0", 3, 64, 11, True)
+    _conv(sd, rng, "features.3", 64, 192, 5, True)
+    _conv(sd, rng, "features.6", 192, 384, 3, True)
+    _conv(sd, rng, "features.8", 384, 256, 3, True)
+    _conv(sd, rng, "features.10", 256, 256, 3, True)
+    _linear(sd, rng, "classifier.1", 256 * 6 * 6, 4096)
+    _linear(sd, rng, "classifier.4", 4096, 4096)
+    _linear(sd, rng, "classifier.6", 4096, num_classes)
+    return sd
+
+
+def resnet_state(seed=1, block="bottleneck", layers=(3, 4, 6, 3), num_classes=1000,
+                 width_per_group=64, groups=1, stem=64):
+    """torchvision ResNet registration order (mirrored by resnet.py:101-110,171-184)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    exp = 4 if block == "bottleneck" else 1
+    _conv(sd, rng, "conv1", 3, stem, 7, False)
+    _bn(sd, rng, "bn1", stem)
+    inplanes = stem
+    for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), layers)):
+        stride = 1 if li == 0 else 2
+        for bi in range(nblk):
+            p = f"layer{li + 1}.{bi}"
+            s = stride if bi == 0 else 1
+            if block == "bottleneck":
+                width = int(planes * (width_per_group / 64.0)) * groups
+                _conv(sd, rng, p + ".conv1", inplanes, width, 1, False)
+                _bn(sd, rng, p + ".bn1", width)
+                _conv(sd, rng, p + ".conv2", width, width, 3, False, groups)
+                _bn(sd, rng, p + ".bn2", width)
+                _conv(sd, rng, p + ".conv3", width, planes * 4, 1, False)
+                _bn(sd, rng, p + ".bn3", planes * 4)
+            else:
+                _conv(sd, rng, p + ".conv1", inplanes, planes, 3, False)
+                _bn(sd, rng, p + ".bn1", planes)
+                _conv(sd, rng, p + ".conv2", planes, planes, 3, False)
+                _bn(sd, rng, p + ".bn2", planes)
+            if bi == 0 and (s != 1 or inplanes != planes * exp):
+                _conv(sd, rng, p + ".downsample.0", inplanes, planes * exp, 1, False)
+                _bn(sd, rng, p + ".downsample.1", planes * exp)
+            inplanes = planes * exp
+    _linear(sd, rng, "fc", 512 * exp, num_classes)
+    return sd
+
+
+def _trunc_normal(rng, shape):
+    x = rng.standard_normal(shape)
+    bad = np.abs(x) > 2
+    while bad.any():
+        x[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(x) > 2
+    return x.astype(F32)
+
+
+def vit_state(seed=1, img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12,
+              mlp_ratio=4, num_classes=1000, in_chans=3, qkv_bias=True, randomize_ln=True):
+    """DINO/timm ViT state_dict order (vit.py:163-171 field order)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    n = (img_size // patch_size) ** 2
+    sd["cls_token"] = _trunc_normal(rng, (1, 1, embed_dim))         # vit.py:229-231 (unit scale)
+    sd["pos_embed"] = _trunc_normal(rng, (1, n + 1, embed_dim))     # vit.py:232-234
+    _conv(sd, rng, "patch_embed.proj", in_chans, embed_dim, patch_size, True)
+    hidden = int(embed_dim * mlp_ratio)
+    for i in range(depth):
+        p = f"blocks.{i}"
+        _ln(sd, rng, p + ".norm1", embed_dim, randomize_ln)
+        _linear(sd, rng, p + ".attn.qkv", embed_dim, 3 * embed_dim, qkv_bias)
+        _linear(sd, rng, p + ".attn.proj", embed_dim, embed_dim)
+        _ln(sd, rng, p + ".norm2", embed_dim, randomize_ln)
+        _linear(sd, rng, p + ".mlp.fc1", embed_dim, hidden)
+        _linear(sd, rng, p + ".mlp.fc2", hidden, embed_dim)
+    _ln(sd, rng, "norm", embed_dim, randomize_ln)
+    if num_classes:
+        _linear(sd, rng, "fc", embed_dim, num_classes)
+    return sd
+
+
+def swin_relative_position_index(ws):
+    """torchvision's index (what pretrained checkpoints carry and overwrite the reference's
+    own buggy init with -- SURVEY Appendix C-1 / D)."""
+    ch, cw = np.arange(ws[0]), np.arange(ws[1])
+    coords = np.stack(np.meshgrid(ch, cw, indexing="ij")).reshape(2, -1)
+    rel = (coords[:, :, None] - coords[:, None, :]).transpose(1, 2, 0).copy()
+    rel[:, :, 0] += ws[0] - 1
+    rel[:, :, 1] += ws[1] - 1
+    rel[:, :, 0] *= 2 * ws[1] - 1
+    return rel.sum(-1).reshape(-1).astype(np.int64)
+
+
+def swin_state(seed=1, patch_size=(4, 4), embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24),
+               window_size=(7, 7), mlp_ratio=4.0, num_classes=1000, randomize_ln=True):
+    """torchvision swin_t registration order (swin.py:260-268,526-530,47-48)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    _conv(sd, rng, "features.0.0", 3, embed_dim, tuple(patch_size), True)
+    _ln(sd, rng, "features.0.2", embed_dim, randomize_ln)
+    fi = 1
+    for si, depth in enumerate(depths):
+        dim = embed_dim * 2 ** si
+        for bi in range(depth):
+            p = f"features.{fi}.{bi}"
+            _ln(sd, rng, p + ".norm1", dim, randomize_ln)
+            sd[p + ".attn.relative_position_bias_table"] = (
+                0.02 * rng.standard_normal(((2 * window_size[0] - 1) * (2 * window_size[1] - 1), num_heads[si]))
+            ).astype(F32)
+            sd[p + ".attn.relative_position_index"] = swin_relative_position_index(window_size)
+            _linear(sd, rng, p + ".attn.qkv", dim, 3 * dim)
+            _linear(sd, rng, p + ".attn.proj", dim, dim)
+            _ln(sd, rng, p + ".norm2", dim, randomize_ln)
+            _linear(sd, rng, p + ".mlp.0", dim, int(dim * mlp_ratio))
+            _linear(sd, rng, p + ".mlp.3", int(dim * mlp_ratio), dim)
+        fi += 1
+        if si < len(depths) - 1:
+            p = f"features.{fi}"
+            _linear(sd, rng, p + ".reduction", 4 * dim, 2 * dim, bias=False)
+            _ln(sd, rng, p + ".norm", 4 * dim, randomize_ln)
+            fi += 1
+    nf = embed_dim * 2 ** (len(depths) - 1)
+    _ln(sd, rng, "norm", nf, randomize_ln)
+    _linear(sd, rng, "head", nf, num_classes)
+    return sd
+
+
+def save_pth(sd, path):
+    """Write the dict as a real torch checkpoint so `load_torch_weights` exercises torch.load."""
+    import torch
+    torch.save(OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v))) for k, v in sd.items()), path)
+
+
+def synthetic_images(batch, size=224, seed=0, chans=3):
+    """U[0,1) fp32 NCHW images, PCG64(seed)  (reference README.md:45 uses jr.uniform)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.random((batch, chans, size, size), dtype=F32)

@@ -1,0 +1,194 @@
+"""CPU ORACLE (test infrastructure): an INDEPENDENT batched fp32 restatement of the same four
+models on `torch.nn.functional` (CPU).  Two jobs:
+
+  1. cross-check of `oracle/models.py` (numpy): the two must agree to <=1e-4 relative;
+     torchvision semantics are what the reference's own tests use as ground truth
+     (`/root/reference/tests/test_models/test_resnet.py:24`).
+  2. the `cpu_baseline` leg of bench.py ("port": CPU restatement, not JAX -- jax/equinox are
+     not installed on the box), timed on all host cores.
+
+PARITY UNPINNED -- see oracle/np_ops.py.  Never imported by the product.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _t(sd):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v for k, v in sd.items()}
+
+
+def _bn(sd, x, name):
+    return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"],
+                        sd[name + ".weight"], sd[name + ".bias"], False, 0.0, 1e-5)
+
+
+@torch.no_grad()
+def alexnet_features(sd, x):
+    sd = _t(sd)
+    x = torch.as_tensor(x)
+    x = F.relu(F.conv2d(x, sd["features.0.weight"], sd["features.0.bias"], 4, 2))
+    x = F.max_pool2d(x, 3, 2)
+    x = F.relu(F.conv2d(x, sd["features.3.weight"], sd["features.3.bias"], 1, 2))
+    x = F.max_pool2d(x, 3, 2)
+    x = F.relu(F.conv2d(x, sd["features.6.weight"], sd["features.6.bias"], 1, 1))
+    x = F.relu(F.conv2d(x, sd["features.8.weight"], sd["features.8.bias"], 1, 1))
+    x = F.relu(F.conv2d(x, sd["features.10.weight"], sd["features.10.bias"], 1, 1))
+    return F.max_pool2d(x, 3, 2)
+
+
+@torch.no_grad()
+def alexnet_forward(sd, x):
+    t = _t(sd)
+    x = alexnet_features(sd, x)
+    x = F.adaptive_avg_pool2d(x, (6, 6)).flatten(1)
+    x = F.relu(F.linear(x, t["classifier.1.weight"], t["classifier.1.bias"]))
+    x = F.relu(F.linear(x, t["classifier.4.weight"], t["classifier.4.bias"]))
+    return F.linear(x, t["classifier.6.weight"], t["classifier.6.bias"])
+
+
+@torch.no_grad()
+def resnet_forward(sd, x, block="bottleneck", layers=(3, 4, 6, 3), groups=1):
+    sd = _t(sd)
+    x = torch.as_tensor(x)
+    x = F.relu(_bn(sd, F.conv2d(x, sd["conv1.weight"], None, 2, 3), "bn1"))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, nblk in enumerate(layers):
+        stride = 1 if li == 0 else 2
+        for bi in range(nblk):
+            p = f"layer{li + 1}.{bi}"
+            s = stride if bi == 0 else 1
+            idt = x
+            if (p + ".downsample.0.weight") in sd:
+                idt = _bn(sd, F.conv2d(x, sd[p + ".downsample.0.weight"], None, s), p + ".downsample.1")
+            if block == "bottleneck":
+                o = F.relu(_bn(sd, F.conv2d(x, sd[p + ".conv1.weight"]), p + ".bn1"))
+                o = F.relu(_bn(sd, F.conv2d(o, sd[p + ".conv2.weight"], None, s, 1, 1, groups), p + ".bn2"))
+                o = _bn(sd, F.conv2d(o, sd[p + ".conv3.weight"]), p + ".bn3")
+            else:
+                o = F.relu(_bn(sd, F.conv2d(x, sd[p + ".conv1.weight"], None, s, 1), p + ".bn1"))
+                o = _bn(sd, F.conv2d(o, sd[p + ".conv2.weight"], None, 1, 1), p + ".bn2")
+            x = F.relu(o + idt)
+    x = F.adaptive_avg_pool2d(x, 1).flatten(1)
+    return F.linear(x, sd["fc.weight"], sd["fc.bias"])
+
+
+def _vit_tokens(sd, x, patch):
+    x = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], patch)
+    x = x.flatten(2).transpose(1, 2)
+    D = x.shape[-1]
+    cls = sd["cls_token"].reshape(1, 1, D).expand(x.shape[0], -1, -1)
+    return torch.cat([cls, x], 1) + sd["pos_embed"].reshape(1, -1, D)
+
+
+def _vit_block(sd, x, p, H, return_attention=False):
+    B, N, C = x.shape
+    y = F.layer_norm(x, (C,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5)
+    qkv = F.linear(y, sd[p + ".attn.qkv.weight"], sd.get(p + ".attn.qkv.bias"))
+    qkv = qkv.reshape(B, N, 3, H, C // H).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = ((q @ k.transpose(-2, -1)) * (C // H) ** -0.5).softmax(-1)
+    if return_attention:
+        return attn[:, None]
+    y = (attn @ v).transpose(1, 2).reshape(B, N, C)
+    x = x + F.linear(y, sd[p + ".attn.proj.weight"], sd[p + ".attn.proj.bias"])
+    y = F.layer_norm(x, (C,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+    y = F.gelu(F.linear(y, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"]), approximate="tanh")
+    return x + F.linear(y, sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
+
+
+@torch.no_grad()
+def vit_forward(sd, x, patch=16, num_heads=12, depth=12):
+    sd = _t(sd)
+    x = _vit_tokens(sd, torch.as_tensor(x), patch)
+    for i in range(depth):
+        x = _vit_block(sd, x, f"blocks.{i}", num_heads)
+    x = F.layer_norm(x, (x.shape[-1],), sd["norm.weight"], sd["norm.bias"], 1e-5)[:, 0]
+    if "fc.weight" in sd:
+        x = F.linear(x, sd["fc.weight"], sd["fc.bias"])
+    return x
+
+
+@torch.no_grad()
+def vit_last_self_attention(sd, x, patch=16, num_heads=12, depth=12):
+    sd = _t(sd)
+    x = _vit_tokens(sd, torch.as_tensor(x), patch)
+    for i in range(depth - 1):
+        x = _vit_block(sd, x, f"blocks.{i}", num_heads)
+    return _vit_block(sd, x, f"blocks.{depth - 1}", num_heads, return_attention=True)
+
+
+def _swin_attn(sd, x, p, H, ws, shift):
+    """torchvision-style shifted_window_attention on NHWC (independent of the numpy oracle)."""
+    B, Hh, Ww, C = x.shape
+    shift = list(shift)
+    if ws[0] >= Hh:
+        shift[0] = 0
+    if ws[1] >= Ww:
+        shift[1] = 0
+    if sum(shift) > 0:
+        x = torch.roll(x, (-shift[0], -shift[1]), (1, 2))
+    nW = (Hh // ws[0]) * (Ww // ws[1])
+    n = ws[0] * ws[1]
+    x = x.view(B, Hh // ws[0], ws[0], Ww // ws[1], ws[1], C).permute(0, 1, 3, 2, 4, 5).reshape(B * nW, n, C)
+    qkv = F.linear(x, sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"])
+    qkv = qkv.reshape(B * nW, n, 3, H, C // H).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * (C // H) ** -0.5, qkv[1], qkv[2]
+    attn = q @ k.transpose(-2, -1)
+    table = sd[p + ".attn.relative_position_bias_table"]
+    idx = sd[p + ".attn.relative_position_index"].long().view(-1)
+    bias = table[idx].view(n, n, -1).permute(2, 0, 1)
+    attn = attn + bias[None]
+    if sum(shift) > 0:
+        m = x.new_zeros((Hh, Ww))
+        hs = ((0, -ws[0]), (-ws[0], -shift[0]), (-shift[0], None))
+        wsl = ((0, -ws[1]), (-ws[1], -shift[1]), (-shift[1], None))
+        c = 0
+        for h in hs:
+            for w in wsl:
+                m[h[0]:h[1], w[0]:w[1]] = c
+                c += 1
+        m = m.view(Hh // ws[0], ws[0], Ww // ws[1], ws[1]).permute(0, 2, 1, 3).reshape(nW, n)
+        m = m.unsqueeze(1) - m.unsqueeze(2)
+        m = m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
+        attn = attn.view(B, nW, H, n, n) + m[None, :, None]
+        attn = attn.view(-1, H, n, n)
+    attn = attn.softmax(-1)
+    y = (attn @ v).transpose(1, 2).reshape(B * nW, n, C)
+    y = F.linear(y, sd[p + ".attn.proj.weight"], sd[p + ".attn.proj.bias"])
+    y = y.view(B, Hh // ws[0], Ww // ws[1], ws[0], ws[1], C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hh, Ww, C)
+    if sum(shift) > 0:
+        y = torch.roll(y, (shift[0], shift[1]), (1, 2))
+    return y
+
+
+@torch.no_grad()
+def swin_forward(sd, x, patch=(4, 4), depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window=(7, 7)):
+    sd = _t(sd)
+    x = torch.as_tensor(x)
+    x = F.conv2d(x, sd["features.0.0.weight"], sd["features.0.0.bias"], tuple(patch)).permute(0, 2, 3, 1)
+    x = F.layer_norm(x, (x.shape[-1],), sd["features.0.2.weight"], sd["features.0.2.bias"], 1e-5)
+    fi = 1
+    for si, depth in enumerate(depths):
+        for bi in range(depth):
+            p = f"features.{fi}.{bi}"
+            C = x.shape[-1]
+            shift = [0 if bi % 2 == 0 else w // 2 for w in window]
+            y = F.layer_norm(x, (C,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5)
+            x = x + _swin_attn(sd, y, p, num_heads[si], list(window), shift)
+            y = F.layer_norm(x, (C,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+            y = F.gelu(F.linear(y, sd[p + ".mlp.0.weight"], sd[p + ".mlp.0.bias"]), approximate="tanh")
+            x = x + F.linear(y, sd[p + ".mlp.3.weight"], sd[p + ".mlp.3.bias"])
+        fi += 1
+        if si < len(depths) - 1:
+            p = f"features.{fi}"
+            x0, x1, x2, x3 = x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]
+            x = torch.cat([x0, x1, x2, x3], -1)
+            x = F.layer_norm(x, (x.shape[-1],), sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-5)
+            x = F.linear(x, sd[p + ".reduction.weight"])
+            fi += 1
+    x = F.layer_norm(x, (x.shape[-1],), sd["norm.weight"], sd["norm.bias"], 1e-5)
+    x = x.mean((1, 2))
+    return F.linear(x, sd["head.weight"], sd["head.bias"])
