@@ -31,7 +31,7 @@ PROTOTYPES = {
     "mv_linear_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
     "mv_maxpool2d_nhwc_fwd": [_vp, _vp] + [_i] * 10 + [_i, _vp],
     "mv_adaptive_avgpool2d_nhwc_fwd": [_vp, _vp] + [_i] * 6 + [_i, _i, _vp],
-    "mv_layernorm_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp],
+    "mv_layernorm_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _i64, _f, _i, _i, _vp],
     "mv_mha_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "mv_swin_window_attn_fwd": [_vp, _vp, _vp] + [_i] * 9 + [_i, _vp],
     "mv_patch_merge_gather_nhwc": [_vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -328,11 +328,12 @@ __global__ void adaptive_avgpool_nhwc_kernel(const TI* __restrict__ x, TO* __res
 // LayerNorm: one wave per row, two-pass in registers/LDS-free (row re-read from L1/L2).
 template <typename TI, typename TO>
 __global__ void layernorm_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, TO* __restrict__ y, long long M, int C, float eps) {
+                                 const float* __restrict__ beta, TO* __restrict__ y, long long M, int C,
+                                 long long xs, float eps) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
-    const TI* xr = x + row * C;
+    const TI* xr = x + row * xs;
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += io<TI>::ld(xr + c);
     const float mean = wave_sum(s) / (float)C;
@@ -355,11 +356,11 @@ __global__ void layernorm_kernel(const TI* __restrict__ x, const float* __restri
 template <int CHUNKS>
 __global__ void layernorm_bf16x8_kernel(const uint4* __restrict__ x, const float* __restrict__ gamma,
                                         const float* __restrict__ beta, uint4* __restrict__ y, long long M, int C8,
-                                        float eps) {
+                                        long long xs8, float eps) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
-    const uint4* xr = x + row * C8;
+    const uint4* xr = x + row * xs8;
     float v[CHUNKS][8];
     float s = 0.f;
 #pragma unroll
@@ -623,29 +624,32 @@ int mv_adaptive_avgpool2d_nhwc_fwd(const void* x, void* y, int N, int H, int W, 
     return MV_OK;
 }
 
-int mv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, int64_t M, int C, float eps,
-                     int in_dtype, int out_dtype, mv_stream_t stream) {
+int mv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, int64_t M, int C,
+                     int64_t x_row_stride, float eps, int in_dtype, int out_dtype, mv_stream_t stream) {
     MV_CHECK_ARG(x && y && M > 0 && C > 0, "layernorm: bad args");
+    const long long xs = x_row_stride ? (long long)x_row_stride : (long long)C;
+    MV_CHECK_ARG(xs >= C, "layernorm: row stride %lld < C=%d", xs, C);
     hipStream_t st = (hipStream_t)stream;
     const int rows_per_block = 4;
     dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block)), block(64 * rows_per_block);
-    if (in_dtype == MV_BF16 && out_dtype == MV_BF16 && C % 8 == 0 && C <= 64 * 8 * 4 && !get_flag("force_generic")) {
+    if (in_dtype == MV_BF16 && out_dtype == MV_BF16 && C % 8 == 0 && xs % 8 == 0 && C <= 64 * 8 * 4 &&
+        !get_flag("force_generic")) {
         set_kernel_name("layernorm_bf16x8");
         const int C8 = C / 8;
         if (C8 <= 64)
             hipLaunchKernelGGL(layernorm_bf16x8_kernel<1>, grid, block, 0, st, (const uint4*)x, gamma, beta, (uint4*)y,
-                               (long long)M, C8, eps);
+                               (long long)M, C8, xs / 8, eps);
         else if (C8 <= 128)
             hipLaunchKernelGGL(layernorm_bf16x8_kernel<2>, grid, block, 0, st, (const uint4*)x, gamma, beta, (uint4*)y,
-                               (long long)M, C8, eps);
+                               (long long)M, C8, xs / 8, eps);
         else
             hipLaunchKernelGGL(layernorm_bf16x8_kernel<4>, grid, block, 0, st, (const uint4*)x, gamma, beta, (uint4*)y,
-                               (long long)M, C8, eps);
+                               (long long)M, C8, xs / 8, eps);
     } else {
         set_kernel_name("layernorm");
 #define GO(TI, TO)                                                                                         \
     hipLaunchKernelGGL((layernorm_kernel<TI, TO>), grid, block, 0, st, (const TI*)x, gamma, beta, (TO*)y, \
-                       (long long)M, C, eps)
+                       (long long)M, C, xs, eps)
         if (in_dtype == MV_BF16 && out_dtype == MV_BF16) GO(bf16_t, bf16_t);
         else if (in_dtype == MV_BF16 && out_dtype == MV_F32) GO(bf16_t, float);
         else if (in_dtype == MV_F32 && out_dtype == MV_F32) GO(float, float);

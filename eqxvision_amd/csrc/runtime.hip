@@ -76,7 +76,7 @@ int mv_graph_end_capture(mv_stream_t stream, void** graph_exec) {
     MV_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
     hipGraphExec_t ex = nullptr;
     hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     if (e != hipSuccess) {
         mv::set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
         return (int)e;

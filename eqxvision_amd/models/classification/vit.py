@@ -145,12 +145,16 @@ class VisionTransformer(Module):
         raise NotImplementedError("VisionTransformer expects a raw (C,H,W) image and the default PatchEmbed")
 
     def _head(self, x: Act) -> Act:
-        x = self.norm(x)                                               # reference :272
-        B, N, D = x.t.shape
-        cls = Act(x.t[:, 0, :], "vec", x.batched)                      # x[0] (strided view: rows of D, stride N*D)
+        # reference :272-273 normalises every token and keeps x[0]; only the cls row is needed
+        if type(self.norm) is nn.LayerNorm:
+            cls = ops.layernorm_first_row(x, self.norm)
+        else:
+            x = self.norm(x)
+            B, N, D = x.t.shape
+            cls = ops.first_row(x)
         if isinstance(self.fc, nn.Identity):
-            return Act(cls.t.contiguous(), "vec", x.batched)
-        return ops.linear(Act(cls.t.contiguous(), "vec", x.batched), self.fc, out_fp32=True)
+            return cls
+        return ops.linear(cls, self.fc, out_fp32=True)
 
     @boundary
     def __call__(self, x, *, key=None):                                # reference :261-273

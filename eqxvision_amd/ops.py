@@ -257,9 +257,22 @@ def layernorm(x: Act, ln) -> Act:
     g = prep_f32(ln, "weight", ln.weight)
     b = prep_f32(ln, "bias", ln.bias)
     y = empty(tuple(x.t.shape), x.t.dtype)
-    _lib.call("mv_layernorm_fwd", _ptr(x.t), _ptr(g), _ptr(b), _ptr(y), x.t.numel() // C, C, float(ln.eps),
+    _lib.call("mv_layernorm_fwd", _ptr(x.t), _ptr(g), _ptr(b), _ptr(y), x.t.numel() // C, C, 0, float(ln.eps),
               x.dt, x.dt, stream_ptr())
     return Act(y, x.kind, x.batched)
+
+
+def layernorm_first_row(x: Act, ln) -> Act:
+    """LayerNorm of row 0 of every sample of a seq [B,N,D] -> vec [B,D] (vit.py:272-273: only
+    `x[0]` of the normalised tokens is used), via the kernel's row-stride argument."""
+    x = as_rows(x)
+    B, N, D = x.t.shape
+    g = prep_f32(ln, "weight", ln.weight)
+    b = prep_f32(ln, "bias", ln.bias)
+    y = empty((B, D), x.t.dtype)
+    _lib.call("mv_layernorm_fwd", _ptr(x.t), _ptr(g), _ptr(b), _ptr(y), B, D, N * D, float(ln.eps),
+              x.dt, x.dt, stream_ptr())
+    return Act(y, "vec", x.batched)
 
 
 def batchnorm(x: Act, bn, act=None) -> Act:
@@ -351,3 +364,12 @@ def add(a: Act, b: Act, act=None) -> Act:
     y = empty(tuple(a.t.shape), a.t.dtype)
     _lib.call("mv_add_fwd", _ptr(a.t), _ptr(b.t), _ptr(y), a.t.numel(), ACT[act], a.dt, stream_ptr())
     return Act(y, a.kind, a.batched)
+
+
+def first_row(x: Act) -> Act:
+    """x[0] of a seq [B,N,D] -> vec [B,D] (a strided gather done by the cast kernel per image)."""
+    B, N, D = x.t.shape
+    y = empty((B, D), x.t.dtype)
+    for b in range(B):
+        _lib.call("mv_cast", x.t[b].data_ptr(), y[b].data_ptr(), D, x.dt, x.dt, stream_ptr())
+    return Act(y, "vec", x.batched)

@@ -81,9 +81,12 @@ int mv_adaptive_avgpool2d_nhwc_fwd(const void* x, void* y, int N, int H, int W, 
                                    int in_dtype, int out_dtype, mv_stream_t stream);
 
 /* eqx.nn.LayerNorm under vmap / LayerNorm2d (vit.py:149,154,272; extensions_2d.py:9-28):
- * rows of C, biased variance, gamma/beta fp32 [C] or NULL. */
+ * M rows of C, biased variance, gamma/beta fp32 [C] or NULL.  Row i of x starts at element
+ * i*x_row_stride (0 = dense = C), so e.g. only the cls row of every image can be normalised
+ * (vit.py:272-273 uses x[0] only); y is dense [M][C]. */
 int mv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
-                     int64_t M, int C, float eps, int in_dtype, int out_dtype, mv_stream_t stream);
+                     int64_t M, int C, int64_t x_row_stride, float eps, int in_dtype, int out_dtype,
+                     mv_stream_t stream);
 
 /* _VitAttention core (vit.py:65-73): qkv [B,N,3,H,dh] (the qkv Linear output, channel order
  * [q|k|v][head][dh]) -> out [B,N,H*dh] = merge_heads(softmax(q k^T * scale) v);

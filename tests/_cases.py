@@ -1,0 +1,503 @@
+"""GPU parity cases: each returns {"ok": bool, "err": ..., ...}.  HIP path (through the C ABI) vs the
+CPU oracle (`oracle/np_ops.py`) on the same seeded inputs.
+
+bf16 cases feed the oracle the SAME bf16-rounded inputs, so the only differences are fp32
+accumulation order and the rounding of the stored output:
+    bf16 output:  max|got-ref| <= 1e-2 * max(1, max|ref|)     (north-star bf16 tolerance)
+    fp32 output:  max|got-ref| <= 1e-3 * max(1, max|ref|)     (north-star fp32 tolerance)
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import np_ops as O
+
+TOL_BF16 = 1e-2
+TOL_F32 = 1e-3
+
+
+def _lib():
+    from eqxvision_amd import _lib as L
+    return L
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def bf(a):
+    return O.bf16_round(np.asarray(a, np.float32))
+
+
+def dev(a, dtype):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype == "bf16":
+        t = t.to(torch.bfloat16)
+    return t.cuda()
+
+
+def host(t):
+    return t.float().cpu().numpy()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _cmp(got, ref, tol):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    if got.shape != ref.shape:
+        return {"ok": False, "err": f"shape {got.shape} vs {ref.shape}"}
+    if not np.isfinite(got).all():
+        return {"ok": False, "err": "non-finite output", "nan": int((~np.isfinite(got)).sum())}
+    d = np.abs(got - ref).max()
+    lim = tol * max(1.0, np.abs(ref).max())
+    return {"ok": bool(d <= lim), "err": float(d), "lim": float(lim), "refmax": float(np.abs(ref).max())}
+
+
+DT = {"bf16": 1, "fp32": 0}
+
+
+# --------------------------------------------------------------------------------------------
+def conv_nhwc_case(N, H, W, C, K, R, S, stride=1, pad=0, dil=1, groups=1, act=0, res=False, scale=True,
+                   dtype="bf16", out="same", generic=False, seed=0, tile=0):
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        q = bf if dtype == "bf16" else (lambda a: np.asarray(a, np.float32))
+        x = q(rng.standard_normal((N, C, H, W)))
+        w = q(rng.standard_normal((K, C // groups, R, S)) / np.sqrt(C // groups * R * S))
+        sc = rng.uniform(0.5, 1.5, K).astype(np.float32) if scale else None
+        sf = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
+        odt = dtype if out == "same" else out
+        qo = bf if odt == "bf16" else (lambda a: np.asarray(a, np.float32))
+        r = qo(rng.standard_normal((N, K, Ho, Wo))) if res else None
+        ref = np.stack([O.conv2d(x[i], w, None, stride, pad, dil, groups) for i in range(N)])
+        if sc is not None:
+            ref = ref * sc[None, :, None, None]
+        ref = ref + sf[None, :, None, None]
+        if r is not None:
+            ref = ref + r
+        if act == 1:
+            ref = O.relu(ref)
+        elif act == 2:
+            ref = O.gelu_tanh(ref)
+        xd = dev(x.transpose(0, 2, 3, 1), dtype)
+        wd = dev(w.transpose(0, 2, 3, 1), dtype)
+        scd = None if sc is None else dev(sc, "fp32")
+        sfd = dev(sf, "fp32")
+        rd = None if r is None else dev(r.transpose(0, 2, 3, 1), odt)
+        y = torch.empty((N, Ho, Wo, K), dtype=torch.bfloat16 if odt == "bf16" else torch.float32, device="cuda")
+        L.set_flag("force_generic", 1 if generic else 0)
+        L.set_flag("igemm_tile", tile)
+        try:
+            L.call("mv_conv2d_nhwc_fwd", xd.data_ptr(), wd.data_ptr(), None if scd is None else scd.data_ptr(),
+                   sfd.data_ptr(), None if rd is None else rd.data_ptr(), y.data_ptr(),
+                   N, H, W, C, K, R, S, stride, stride, pad, pad, dil, dil, groups, act, DT[dtype], DT[odt], _stream())
+            kern = L.last_kernel()
+        finally:
+            L.set_flag("force_generic", 0)
+            L.set_flag("igemm_tile", 0)
+        torch.cuda.synchronize()
+        got = host(y).transpose(0, 3, 1, 2)
+        info = _cmp(got, ref, TOL_BF16 if odt == "bf16" else TOL_F32)
+        info["kernel"] = kern
+        return info
+    return run
+
+
+def conv_nchw_case(N, C, H, W, K, R, S, stride, pad, act=0, xdtype="fp32", tokens=False, generic=False, seed=0):
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        x = rng.random((N, C, H, W), dtype=np.float32)
+        if xdtype == "bf16":
+            x = bf(x)
+        w = bf(rng.standard_normal((K, C, R, S)) / np.sqrt(C * R * S))
+        sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        sf = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        Ho = (H + 2 * pad - R) // stride + 1
+        Wo = (W + 2 * pad - S) // stride + 1
+        P = Ho * Wo
+        xr = bf(x)   # the kernel rounds the image operand to bf16 for the MFMA
+        ref = np.stack([O.conv2d(xr[i], w, None, stride, pad) for i in range(N)]) * sc[None, :, None, None] \
+            + sf[None, :, None, None]
+        if act == 1:
+            ref = O.relu(ref)
+        ref = ref.reshape(N, K, P).transpose(0, 2, 1)          # rows [N, P, K]
+        xd = dev(x, xdtype)
+        wd = dev(w, "bf16")
+        scd, sfd = dev(sc, "fp32"), dev(sf, "fp32")
+        if tokens:
+            T = P + 1
+            pos = rng.standard_normal((T, K)).astype(np.float32)
+            posd = dev(pos, "fp32")
+            y = torch.zeros((N, T, K), dtype=torch.bfloat16, device="cuda")
+            ref = np.concatenate([np.zeros((N, 1, K), np.float32), ref + pos[None, 1:]], 1)
+            targs = (T, 1, posd.data_ptr())
+        else:
+            y = torch.empty((N, P, K), dtype=torch.bfloat16, device="cuda")
+            targs = (0, 0, None)
+        L.set_flag("force_generic", 1 if generic else 0)
+        try:
+            L.call("mv_conv2d_nchw_fwd", xd.data_ptr(), wd.data_ptr(), scd.data_ptr(), sfd.data_ptr(), y.data_ptr(),
+                   N, C, H, W, K, R, S, stride, stride, pad, pad, act, DT[xdtype], 1, *targs, _stream())
+            kern = L.last_kernel()
+        finally:
+            L.set_flag("force_generic", 0)
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, TOL_BF16)
+        info["kernel"] = kern
+        return info
+    return run
+
+
+def linear_case(M, K, N, act=0, res=False, dtype="bf16", out="same", generic=False, seed=0, tile=0):
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        q = bf if dtype == "bf16" else (lambda a: np.asarray(a, np.float32))
+        x = q(rng.standard_normal((M, K)))
+        w = q(rng.standard_normal((N, K)) / np.sqrt(K))
+        b = (0.1 * rng.standard_normal(N)).astype(np.float32)
+        odt = dtype if out == "same" else out
+        qo = bf if odt == "bf16" else (lambda a: np.asarray(a, np.float32))
+        r = qo(rng.standard_normal((M, N))) if res else None
+        ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+        if r is not None:
+            ref = ref + r
+        if act == 1:
+            ref = O.relu(ref)
+        elif act == 2:
+            ref = O.gelu_tanh(ref)
+        xd, wd, bd = dev(x, dtype), dev(w, dtype), dev(b, "fp32")
+        rd = None if r is None else dev(r, odt)
+        y = torch.empty((M, N), dtype=torch.bfloat16 if odt == "bf16" else torch.float32, device="cuda")
+        L.set_flag("force_generic", 1 if generic else 0)
+        L.set_flag("igemm_tile", tile)
+        try:
+            L.call("mv_linear_fwd", xd.data_ptr(), wd.data_ptr(), None, bd.data_ptr(),
+                   None if rd is None else rd.data_ptr(), y.data_ptr(), M, N, K, act, DT[dtype], DT[odt], _stream())
+            kern = L.last_kernel()
+        finally:
+            L.set_flag("force_generic", 0)
+            L.set_flag("igemm_tile", 0)
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, TOL_BF16 if odt == "bf16" else TOL_F32)
+        info["kernel"] = kern
+        return info
+    return run
+
+
+def maxpool_case(N, H, W, C, k, s, p, dtype="bf16", seed=0):
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        if dtype == "bf16":
+            x = bf(x)
+        ref = np.stack([O.maxpool2d(x[i], k, s, p) for i in range(N)])
+        Ho, Wo = ref.shape[2:]
+        xd = dev(x.transpose(0, 2, 3, 1), dtype)
+        y = torch.empty((N, Ho, Wo, C), dtype=xd.dtype, device="cuda")
+        L.call("mv_maxpool2d_nhwc_fwd", xd.data_ptr(), y.data_ptr(), N, H, W, C, k, k, s, s, p, p, DT[dtype], _stream())
+        torch.cuda.synchronize()
+        info = _cmp(host(y).transpose(0, 3, 1, 2), ref, 1e-6)
+        info["kernel"] = L.last_kernel()
+        return info
+    return run
+
+
+def avgpool_case(N, H, W, C, oh, ow, dtype="bf16", seed=0):
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        if dtype == "bf16":
+            x = bf(x)
+        ref = np.stack([O.adaptive_avgpool2d(x[i], (oh, ow)) for i in range(N)])
+        xd = dev(x.transpose(0, 2, 3, 1), dtype)
+        y = torch.empty((N, oh, ow, C), dtype=torch.float32, device="cuda")
+        L.call("mv_adaptive_avgpool2d_nhwc_fwd", xd.data_ptr(), y.data_ptr(), N, H, W, C, oh, ow, DT[dtype], 0, _stream())
+        torch.cuda.synchronize()
+        return _cmp(host(y).transpose(0, 3, 1, 2), ref, 1e-5)
+    return run
+
+
+def layernorm_case(M, C, dtype="bf16", generic=False, stride=None, seed=0):
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        rs = C if stride is None else stride
+        xfull = (rng.standard_normal((M, rs)) * 2 + 0.5).astype(np.float32)
+        if dtype == "bf16":
+            xfull = bf(xfull)
+        x = xfull[:, :C]
+        g = rng.uniform(0.5, 1.5, C).astype(np.float32)
+        b = (0.1 * rng.standard_normal(C)).astype(np.float32)
+        ref = O.layernorm_rows(x, g, b, 1e-5)
+        xd = dev(xfull, dtype)
+        y = torch.empty((M, C), dtype=xd.dtype, device="cuda")
+        gd, bd = dev(g, "fp32"), dev(b, "fp32")
+        L.set_flag("force_generic", 1 if generic else 0)
+        try:
+            L.call("mv_layernorm_fwd", xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), y.data_ptr(), M, C, rs, 1e-5,
+                   DT[dtype], DT[dtype], _stream())
+            kern = L.last_kernel()
+        finally:
+            L.set_flag("force_generic", 0)
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, TOL_BF16 if dtype == "bf16" else 1e-4)
+        info["kernel"] = kern
+        return info
+    return run
+
+
+def mha_case(B, N, H, dh, dtype="bf16", probs=True, generic=False, seed=0, spike=False):
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        D = H * dh
+        qkv = rng.standard_normal((B, N, 3 * D)).astype(np.float32)
+        if spike:   # one huge logit per row: exercises the max-subtraction
+            qkv[:, :, :D] *= 6.0
+        if dtype == "bf16":
+            qkv = bf(qkv)
+        scale = dh ** -0.5
+        t = qkv.reshape(B, N, 3, H, dh).transpose(2, 0, 3, 1, 4).astype(np.float64)
+        q, k, v = t[0], t[1], t[2]
+        a = O.softmax((q @ k.transpose(0, 1, 3, 2)) * scale, -1).astype(np.float64)
+        ref = (a @ v).transpose(0, 2, 1, 3).reshape(B, N, D)
+        qd = dev(qkv, dtype)
+        y = torch.empty((B, N, D), dtype=qd.dtype, device="cuda")
+        pr = torch.empty((B, H, N, N), dtype=torch.float32, device="cuda") if probs else None
+        L.set_flag("force_generic", 1 if generic else 0)
+        try:
+            L.call("mv_mha_fwd", qd.data_ptr(), y.data_ptr(), None if pr is None else pr.data_ptr(), B, N, H, dh,
+                   float(scale), DT[dtype], _stream())
+            kern = L.last_kernel()
+        finally:
+            L.set_flag("force_generic", 0)
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, TOL_BF16 if dtype == "bf16" else TOL_F32)
+        info["kernel"] = kern
+        if probs:
+            pi = _cmp(host(pr), a, 2e-3)
+            info["probs_err"] = pi.get("err")
+            info["ok"] = info["ok"] and pi["ok"]
+        return info
+    return run
+
+
+def swin_attn_case(B, Hf, C, heads, ws, shift, dtype="bf16", seed=0):
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        n = ws * ws
+        qkv = rng.standard_normal((B, 3 * C, Hf, Hf)).astype(np.float32)
+        if dtype == "bf16":
+            qkv = bf(qkv)
+        bias = (0.5 * rng.standard_normal((heads, n, n))).astype(np.float32)
+        # oracle: shifted_window_attention with identity qkv / proj so that it consumes qkv directly
+        eye3 = np.eye(3 * C, dtype=np.float32)
+        refs = []
+        for i in range(B):
+            # feed x = qkv (3C channels) through a fake "qkv_weight" = identity on a 3C-dim input is not
+            # shape-compatible with the C-dim API, so restate the core here from the oracle's pieces:
+            refs.append(_swin_core_ref(qkv[i], bias, ws, heads, shift, C))
+        ref = np.stack(refs)
+        qd = dev(qkv.transpose(0, 2, 3, 1), dtype)
+        bd = dev(bias, "fp32")
+        y = torch.empty((B, Hf, Hf, C), dtype=qd.dtype, device="cuda")
+        L.call("mv_swin_window_attn_fwd", qd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, Hf, Hf, C, heads, ws, ws,
+               shift, shift, DT[dtype], _stream())
+        torch.cuda.synchronize()
+        info = _cmp(host(y).transpose(0, 3, 1, 2), ref, TOL_BF16 if dtype == "bf16" else TOL_F32)
+        info["kernel"] = L.last_kernel()
+        return info
+    return run
+
+
+def _swin_core_ref(qkv_chw, bias, ws, heads, shift, C):
+    """oracle.shifted_window_attention with the qkv projection already applied: call it with
+    x = qkv viewed as a 3C-channel map and identity weights of matching size, then undo proj."""
+    # Use the oracle function on a widened problem: x has 3C channels, qkv_weight maps 3C -> 3*(3C)?  Too
+    # wasteful; instead call the oracle with C' = C by passing weights that SELECT q,k,v from a
+    # concatenated input is impossible (input must be C-dim).  So: run the oracle three-in-one by
+    # temporarily treating the projection as identity via linear algebra: x' = q part, and patch k,v
+    # through the bias-free path below (same code as oracle lines, restated for pre-projected qkv).
+    H = qkv_chw.shape[1]
+    x = np.transpose(qkv_chw, (1, 2, 0))
+    sh = [shift, shift]
+    if ws >= H:
+        sh = [0, 0]
+    if sum(sh) > 0:
+        x = np.roll(x, (-sh[0], -sh[1]), axis=(0, 1))
+    nW = (H // ws) ** 2
+    n = ws * ws
+    x = x.reshape(H // ws, ws, H // ws, ws, 3 * C).transpose(0, 2, 1, 3, 4).reshape(nW, n, 3 * C)
+    dh = C // heads
+    t = x.reshape(nW, n, 3, heads, dh).transpose(2, 0, 3, 1, 4).astype(np.float64)
+    q, k, v = t[0] * dh ** -0.5, t[1], t[2]
+    attn = q @ k.transpose(0, 1, 3, 2) + bias[None]
+    if sum(sh) > 0:
+        m = np.zeros((H, H))
+        sl = ((0, H - ws), (H - ws, H - sh[0]), (H - sh[0], H))
+        c = 0
+        for a in sl:
+            for b in sl:
+                m[a[0]:a[1], b[0]:b[1]] = c
+                c += 1
+        m = m.reshape(H // ws, ws, H // ws, ws).transpose(0, 2, 1, 3).reshape(nW, n)
+        am = np.where((m[:, None, :] - m[:, :, None]) != 0, -100.0, 0.0)
+        attn = attn + am[:, None]
+    attn = O.softmax(attn, -1).astype(np.float64)
+    y = (attn @ v).transpose(0, 2, 1, 3).reshape(nW, n, C)
+    y = y.reshape(H // ws, H // ws, ws, ws, C).transpose(0, 2, 1, 3, 4).reshape(H, H, C)
+    if sum(sh) > 0:
+        y = np.roll(y, (sh[0], sh[1]), axis=(0, 1))
+    return np.transpose(y, (2, 0, 1)).astype(np.float32)
+
+
+def misc_case(kind, dtype="bf16", seed=0):
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        q = bf if dtype == "bf16" else (lambda a: np.asarray(a, np.float32))
+        tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        if kind == "patch_merge":
+            B, H, W, C = 2, 7, 6, 16
+            x = q(rng.standard_normal((B, C, H, W)))
+            xp = np.pad(x, ((0, 0), (0, 0), (0, H % 2), (0, W % 2)))
+            ref = np.concatenate([xp[:, :, 0::2, 0::2], xp[:, :, 1::2, 0::2], xp[:, :, 0::2, 1::2], xp[:, :, 1::2, 1::2]], 1)
+            xd = dev(x.transpose(0, 2, 3, 1), dtype)
+            y = torch.empty((B, (H + 1) // 2, (W + 1) // 2, 4 * C), dtype=tdt, device="cuda")
+            L.call("mv_patch_merge_gather_nhwc", xd.data_ptr(), y.data_ptr(), B, H, W, C, DT[dtype], _stream())
+            torch.cuda.synchronize()
+            return _cmp(host(y).transpose(0, 3, 1, 2), ref, 1e-6)
+        if kind == "layout":
+            N, C, H, W = 3, 37, 9, 11
+            x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+            xd = dev(x, "fp32")
+            y = torch.empty((N, H, W, C), dtype=tdt, device="cuda")
+            L.call("mv_nchw_to_nhwc", xd.data_ptr(), y.data_ptr(), N, C, H, W, 0, DT[dtype], _stream())
+            z = torch.empty((N, C, H, W), dtype=torch.float32, device="cuda")
+            L.call("mv_nhwc_to_nchw", y.data_ptr(), z.data_ptr(), N, C, H, W, DT[dtype], 0, _stream())
+            torch.cuda.synchronize()
+            a = _cmp(host(y), q(x).transpose(0, 2, 3, 1), 1e-6)
+            b = _cmp(host(z), q(x), 1e-6)
+            a["ok"] = a["ok"] and b["ok"]
+            return a
+        if kind == "eltwise":
+            n = 100003
+            x = q(rng.standard_normal(n) * 3)
+            y2 = q(rng.standard_normal(n))
+            xd, yd = dev(x, dtype), dev(y2, dtype)
+            o1 = torch.empty(n, dtype=tdt, device="cuda")
+            o2 = torch.empty(n, dtype=tdt, device="cuda")
+            o3 = torch.empty(n, dtype=tdt, device="cuda")
+            L.call("mv_eltwise_fwd", xd.data_ptr(), o1.data_ptr(), n, 2, DT[dtype], _stream())
+            L.call("mv_eltwise_fwd", xd.data_ptr(), o2.data_ptr(), n, 1, DT[dtype], _stream())
+            L.call("mv_add_fwd", xd.data_ptr(), yd.data_ptr(), o3.data_ptr(), n, 1, DT[dtype], _stream())
+            torch.cuda.synchronize()
+            tol = TOL_BF16 if dtype == "bf16" else 1e-5
+            a = _cmp(host(o1), O.gelu_tanh(x), tol)
+            b = _cmp(host(o2), O.relu(x), tol)
+            c = _cmp(host(o3), O.relu(x + y2), tol)
+            a["ok"] = a["ok"] and b["ok"] and c["ok"]
+            a["err"] = max(a.get("err", 9), b.get("err", 9), c.get("err", 9))
+            return a
+        if kind == "affine_cls":
+            rows, C = 50, 24
+            x = q(rng.standard_normal((rows, C)))
+            sc = rng.uniform(0.5, 1.5, C).astype(np.float32)
+            sf = rng.standard_normal(C).astype(np.float32)
+            xd = dev(x, dtype)
+            o = torch.empty((rows, C), dtype=tdt, device="cuda")
+            L.call("mv_channel_affine_fwd", xd.data_ptr(), dev(sc, "fp32").data_ptr(), dev(sf, "fp32").data_ptr(),
+                   o.data_ptr(), rows, C, 1, DT[dtype], _stream())
+            B, T, D = 3, 5, 16
+            cls = rng.standard_normal(D).astype(np.float32)
+            pos = rng.standard_normal((T, D)).astype(np.float32)
+            tok = torch.zeros((B, T, D), dtype=tdt, device="cuda")
+            L.call("mv_vit_cls_pos_fwd", dev(cls, "fp32").data_ptr(), dev(pos, "fp32").data_ptr(), tok.data_ptr(), B, T, D,
+                   DT[dtype], _stream())
+            torch.cuda.synchronize()
+            a = _cmp(host(o), O.relu(x * sc + sf), TOL_BF16 if dtype == "bf16" else 1e-5)
+            ref = np.zeros((B, T, D), np.float32)
+            ref[:, 0] = cls + pos[0]
+            b = _cmp(host(tok), ref, TOL_BF16 if dtype == "bf16" else 1e-6)
+            a["ok"] = a["ok"] and b["ok"]
+            return a
+        raise ValueError(kind)
+    return run
+
+
+def all_cases():
+    c = []
+    # ---- implicit-GEMM conv (MFMA) : ResNet-50 shapes at reduced spatial size + edge cases
+    c += [("igemm/1x1_64_64", conv_nhwc_case(2, 14, 14, 64, 64, 1, 1, act=1)),
+          ("igemm/1x1_64_256_res", conv_nhwc_case(2, 14, 14, 64, 256, 1, 1, act=1, res=True)),
+          ("igemm/3x3_64_64", conv_nhwc_case(2, 14, 14, 64, 64, 3, 3, pad=1, act=1)),
+          ("igemm/3x3_128_s2", conv_nhwc_case(2, 14, 14, 128, 128, 3, 3, stride=2, pad=1, act=1)),
+          ("igemm/1x1_256_512_s2", conv_nhwc_case(2, 14, 14, 256, 512, 1, 1, stride=2)),
+          ("igemm/3x3_512_7x7", conv_nhwc_case(3, 7, 7, 512, 512, 3, 3, pad=1, act=1, res=True)),
+          ("igemm/3x3_dil2", conv_nhwc_case(1, 13, 11, 64, 128, 3, 3, pad=2, dil=2)),
+          ("igemm/5x5_192", conv_nhwc_case(1, 13, 13, 64, 192, 5, 5, pad=2, act=1, scale=False)),
+          ("igemm/1x1_tile128_K64", conv_nhwc_case(2, 9, 9, 128, 64, 1, 1, tile=1)),
+          ("igemm/3x3_tile64_K256", conv_nhwc_case(2, 9, 9, 64, 256, 3, 3, pad=1, tile=2)),
+          ("igemm/1x1_M1", conv_nhwc_case(1, 1, 1, 2048, 1000, 1, 1, out="fp32")),
+          ("igemm/gelu", conv_nhwc_case(1, 8, 8, 128, 128, 1, 1, act=2)),
+          ("igemm/big_M", conv_nhwc_case(8, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=3))]
+    c += [("linear/vit_qkv", linear_case(197 * 2, 768, 2304)),
+          ("linear/vit_fc1_gelu", linear_case(197 * 2, 768, 3072, act=2)),
+          ("linear/vit_fc2_res", linear_case(197 * 2, 3072, 768, res=True)),
+          ("linear/fc_f32out", linear_case(256, 2048, 1000, out="fp32")),
+          ("linear/alex_fc", linear_case(4, 9216, 4096, act=1)),
+          ("linear/odd_generic", linear_case(10, 20, 5, act=2)),
+          ("linear/f32_generic", linear_case(33, 70, 18, dtype="fp32", res=True)),
+          ("linear/generic_vs_oracle_768", linear_case(70, 768, 96, generic=True))]
+    c += [("conv_generic/groups", conv_nhwc_case(2, 9, 9, 32, 64, 3, 3, pad=1, groups=4, act=1)),
+          ("conv_generic/f32", conv_nhwc_case(1, 10, 10, 12, 20, 3, 3, stride=2, pad=1, dtype="fp32", res=True)),
+          ("conv_generic/same_as_igemm", conv_nhwc_case(1, 14, 14, 64, 64, 3, 3, pad=1, generic=True))]
+    # ---- network-entry conv from NCHW images
+    c += [("stem/resnet7x7", conv_nchw_case(2, 3, 64, 64, 64, 7, 7, 2, 3, act=1)),
+          ("stem/resnet7x7_bf16in", conv_nchw_case(2, 3, 64, 64, 64, 7, 7, 2, 3, act=1, xdtype="bf16")),
+          ("stem/alexnet11x11", conv_nchw_case(2, 3, 67, 67, 64, 11, 11, 4, 2, act=1)),
+          ("stem/vit_patch16_tokens", conv_nchw_case(2, 3, 64, 64, 768, 16, 16, 16, 0, tokens=True)),
+          ("stem/swin_patch4", conv_nchw_case(2, 3, 56, 56, 96, 4, 4, 4, 0)),
+          ("stem/generic_tokens", conv_nchw_case(1, 3, 32, 32, 64, 8, 8, 8, 0, tokens=True, generic=True)),
+          ("stem/full224", conv_nchw_case(2, 3, 224, 224, 64, 7, 7, 2, 3, act=1, seed=5))]
+    c += [("maxpool/3_2_1", maxpool_case(2, 112, 112, 64, 3, 2, 1)),
+          ("maxpool/3_2_0", maxpool_case(2, 55, 55, 64, 3, 2, 0)),
+          ("maxpool/f32_oddC", maxpool_case(1, 13, 13, 5, 3, 2, 0, dtype="fp32")),
+          ("avgpool/global", avgpool_case(2, 7, 7, 2048, 1, 1)),
+          ("avgpool/13to6", avgpool_case(1, 13, 13, 16, 6, 6)),
+          ("layernorm/768", layernorm_case(394, 768)),
+          ("layernorm/96", layernorm_case(100, 96)),
+          ("layernorm/768_generic", layernorm_case(50, 768, generic=True)),
+          ("layernorm/strided", layernorm_case(8, 768, stride=768 * 5)),
+          ("layernorm/odd_f32", layernorm_case(7, 20, dtype="fp32"))]
+    c += [("mha/vit_197_64", mha_case(2, 197, 12, 64)),
+          ("mha/vit_197_64_noprobs", mha_case(1, 197, 3, 64, probs=False)),
+          ("mha/spike", mha_case(1, 197, 2, 64, spike=True)),
+          ("mha/17_32", mha_case(2, 17, 4, 32)),
+          ("mha/256_32", mha_case(1, 256, 2, 32)),
+          ("mha/generic_8_8", mha_case(1, 8, 4, 8)),
+          ("mha/generic_f32", mha_case(1, 50, 2, 16, dtype="fp32")),
+          ("mha/generic_vs_oracle_197", mha_case(1, 197, 2, 64, generic=True))]
+    c += [("swin/shift3", swin_attn_case(2, 14, 96, 3, 7, 3)),
+          ("swin/noshift", swin_attn_case(2, 14, 96, 3, 7, 0)),
+          ("swin/window_ge_map", swin_attn_case(1, 7, 192, 6, 7, 3)),
+          ("swin/f32", swin_attn_case(1, 14, 32, 2, 7, 3, dtype="fp32"))]
+    c += [("misc/patch_merge", misc_case("patch_merge")),
+          ("misc/layout", misc_case("layout")),
+          ("misc/layout_f32", misc_case("layout", "fp32")),
+          ("misc/eltwise", misc_case("eltwise")),
+          ("misc/eltwise_f32", misc_case("eltwise", "fp32")),
+          ("misc/affine_cls", misc_case("affine_cls"))]
+    return c

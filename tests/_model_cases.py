@@ -1,0 +1,193 @@
+"""Model-level GPU parity cases: product (eqxvision_amd, HIP through the C ABI) vs CPU oracle on
+the same synthetic checkpoint (loaded through `load_torch_weights`) and the same seeded images.
+Tolerance (north star): logits within 1e-2*max(1,max|ref|) in bf16, 1e-3*max(1,max|ref|) in fp32."""
+from __future__ import annotations
+
+import os
+import tempfile
+
+import numpy as np
+import torch
+
+from oracle import models as OM
+from oracle import np_ops as O
+from oracle import state as S
+from oracle import torch_ref as TR
+
+
+def _cmp(got, ref, tol, extra=None):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    if got.shape != ref.shape:
+        return {"ok": False, "err": f"shape {got.shape} vs {ref.shape}"}
+    if not np.isfinite(got).all():
+        return {"ok": False, "err": "non-finite output"}
+    d = float(np.abs(got - ref).max())
+    lim = tol * max(1.0, float(np.abs(ref).max()))
+    out = {"ok": d <= lim, "err": d, "lim": lim, "refmax": float(np.abs(ref).max()),
+           "argmax_match": bool((got.reshape(got.shape[0], -1).argmax(-1) == ref.reshape(ref.shape[0], -1).argmax(-1)).all())}
+    if extra:
+        out.update(extra)
+    return out
+
+
+def _load(factory, sd, **kw):
+    import eqxvision_amd as eqv
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "w.pth")
+        S.save_pth(sd, p)
+        net = factory(torch_weights=p, **kw)
+    return eqv.tree_inference(net, True)
+
+
+def _keys(B):
+    import eqxvision_amd as eqv
+    return eqv.random.split(eqv.random.PRNGKey(0), B)
+
+
+def _run(net, x, dtype, jit=False):
+    import eqxvision_amd as eqv
+    with eqv.precision(dtype):
+        if jit:
+            fwd = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k))
+            return fwd, fwd(net, x, _keys(x.shape[0]))
+        out = eqv.vmap(net, axis_name="batch")(x, key=_keys(x.shape[0]))
+    torch.cuda.synchronize()
+    return out
+
+
+def resnet_case(block, layers, size, B, classes=10, dtype="bf16", full_ref="numpy"):
+    def run():
+        import eqxvision_amd as eqv
+        sd = S.resnet_state(1, block, layers, classes)
+        x = S.synthetic_images(B, size, seed=0)
+        fac = {("bottleneck", (3, 4, 6, 3)): eqv.models.resnet50, ("basic", (2, 2, 2, 2)): eqv.models.resnet18}.get(
+            (block, tuple(layers)))
+        if fac is None:
+            blk = eqv.models.classification.resnet._ResNetBottleneck if block == "bottleneck" else \
+                eqv.models.classification.resnet._ResNetBasicBlock
+            fac = lambda torch_weights=None, **kw: eqv.models.classification.resnet._resnet(blk, list(layers), torch_weights, **kw)
+        net = _load(fac, sd, num_classes=classes)
+        got = _run(net, x, dtype).cpu().numpy()
+        if full_ref == "torch":
+            ref = TR.resnet_forward(sd, x, block, layers).numpy()
+            emu = None
+        else:
+            ref = O.vmap(lambda im: OM.resnet_forward(sd, im, block, layers))(x)
+            emu = O.vmap(lambda im: OM.resnet_forward(sd, im, block, layers, bf16=True))(x) if dtype == "bf16" else None
+        extra = {}
+        if emu is not None:
+            extra["err_vs_bf16_emulation"] = float(np.abs(got - emu).max())
+        return _cmp(got, ref, 1e-2 if dtype == "bf16" else 1e-3, extra)
+    return run
+
+
+def alexnet_case(B, dtype="bf16", features_only=False):
+    def run():
+        import eqxvision_amd as eqv
+        sd = S.alexnet_state(1, 1000)
+        x = S.synthetic_images(B, 224, seed=0)
+        net = _load(eqv.models.alexnet, sd)
+        if features_only:      # what the reference's own test pins (tests/test_models/test_alexnet.py:18-25)
+            with eqv.precision(dtype):
+                got = eqv.vmap(net.features, axis_name="batch")(x, key=_keys(B)).cpu().numpy()
+            ref = TR.alexnet_features(sd, x).numpy()
+        else:
+            got = _run(net, x, dtype).cpu().numpy()
+            ref = TR.alexnet_forward(sd, x).numpy()
+        return _cmp(got, ref, 1e-2 if dtype == "bf16" else 1e-3)
+    return run
+
+
+def vit_case(img, patch, dim, depth, heads, B, classes=10, dtype="bf16", attn=False, full_ref="numpy"):
+    def run():
+        import eqxvision_amd as eqv
+        sd = S.vit_state(1, img, patch, dim, depth, heads, 4, classes)
+        x = S.synthetic_images(B, img, seed=0)
+        fac = lambda torch_weights=None, **kw: eqv.models.VisionTransformer(**kw) if torch_weights is None else \
+            eqv.utils.load_torch_weights(eqv.models.VisionTransformer(**kw), torch_weights)
+        net = _load(fac, sd, img_size=img, patch_size=patch, embed_dim=dim, depth=depth, num_heads=heads,
+                    num_classes=classes)
+        if attn:
+            with eqv.precision(dtype):
+                got = eqv.vmap(net.get_last_self_attention)(x, key=_keys(B)).cpu().numpy()
+            ref = TR.vit_last_self_attention(sd, x, patch, heads, depth).numpy()
+            return _cmp(got, ref, 1e-2 if dtype == "bf16" else 1e-3)
+        got = _run(net, x, dtype).cpu().numpy()
+        if full_ref == "torch":
+            ref = TR.vit_forward(sd, x, patch, heads, depth).numpy()
+            extra = {}
+        else:
+            ref = O.vmap(lambda im: OM.vit_forward(sd, im, patch, heads, depth))(x)
+            extra = {}
+            if dtype == "bf16":
+                emu = O.vmap(lambda im: OM.vit_forward(sd, im, patch, heads, depth, bf16=True))(x)
+                extra["err_vs_bf16_emulation"] = float(np.abs(got - emu).max())
+        return _cmp(got, ref, 1e-2 if dtype == "bf16" else 1e-3, extra)
+    return run
+
+
+def swin_case(size, embed, depths, heads, B, classes=10, dtype="bf16", full_ref="numpy"):
+    def run():
+        import warnings
+        import eqxvision_amd as eqv
+        sd = S.swin_state(1, (4, 4), embed, depths, heads, (7, 7), 4.0, classes)
+        x = S.synthetic_images(B, size, seed=0)
+        fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(eqv.models.SwinTransformer(**kw), torch_weights)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            net = _load(fac, sd, patch_size=[4, 4], embed_dim=embed, depths=list(depths), num_heads=list(heads),
+                        window_size=[7, 7], num_classes=classes)
+        got = _run(net, x, dtype).cpu().numpy()
+        if full_ref == "torch":
+            ref = TR.swin_forward(sd, x, (4, 4), depths, heads, (7, 7)).numpy()
+        else:
+            ref = O.vmap(lambda im: OM.swin_forward(sd, im, (4, 4), depths, heads, (7, 7)))(x)
+        return _cmp(got, ref, 1e-2 if dtype == "bf16" else 1e-3)
+    return run
+
+
+def jit_case():
+    """filter_jit: the Python body runs once; replays (call 2 = hipGraph capture, call 3 = graph launch)
+    with NEW inputs must equal eager results (reference semantics: tests/test_models/test_vit.py:35)."""
+    def run():
+        import eqxvision_amd as eqv
+        sd = S.resnet_state(1, "bottleneck", (1, 1, 1, 1), 10)
+        blk = eqv.models.classification.resnet._ResNetBottleneck
+        fac = lambda torch_weights=None, **kw: eqv.models.classification.resnet._resnet(blk, [1, 1, 1, 1], torch_weights, **kw)
+        net = _load(fac, sd, num_classes=10)
+        count = [0]
+
+        def body(n, im, k):
+            count[0] += 1
+            return eqv.vmap(n, axis_name="batch")(im, key=k)
+
+        fwd = eqv.filter_jit(body)
+        errs = []
+        for seed in (0, 1, 2, 3):
+            x = S.synthetic_images(4, 64, seed=seed)
+            got = fwd(net, x, _keys(4)).cpu().numpy()
+            ref = eqv.vmap(net, axis_name="batch")(x, key=_keys(4)).cpu().numpy()
+            errs.append(float(np.abs(got - ref).max()))
+        return {"ok": max(errs) == 0.0 and count[0] == 1, "errs": errs, "traces": count[0]}
+    return run
+
+
+def all_cases(full=True):
+    c = [("model/resnet_tiny_bottleneck", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2)),
+         ("model/resnet18_64px", resnet_case("basic", (2, 2, 2, 2), 64, 2)),
+         ("model/resnet_tiny_fp32", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2, dtype="fp32")),
+         ("model/vit_tiny", vit_case(32, 8, 64, 2, 2, 3)),
+         ("model/vit_tiny_fp32", vit_case(32, 8, 64, 2, 2, 2, dtype="fp32")),
+         ("model/vit_tiny_last_attn", vit_case(32, 8, 64, 2, 2, 2, attn=True)),
+         ("model/swin_tiny", swin_case(56, 32, (2, 2), (2, 4), 2)),
+         ("model/swin_tiny_fp32", swin_case(56, 32, (2, 2), (2, 4), 1, dtype="fp32")),
+         ("model/filter_jit_replay", jit_case())]
+    if full:
+        c += [("model/alexnet_features_B2", alexnet_case(2, features_only=True)),
+              ("model/alexnet_B4_bf16", alexnet_case(4)),
+              ("model/alexnet_B4_fp32", alexnet_case(4, dtype="fp32")),
+              ("model/resnet50_B2", resnet_case("bottleneck", (3, 4, 6, 3), 224, 2, classes=1000, full_ref="torch")),
+              ("model/vit_base_B2", vit_case(224, 16, 768, 12, 12, 2, classes=1000, full_ref="torch")),
+              ("model/swin_t_B1", swin_case(224, 96, (2, 2, 6, 2), (3, 6, 12, 24), 1, classes=1000, full_ref="torch"))]
+    return c

@@ -1,0 +1,58 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the batch sharding + logits all-gather
+(`eqxvision_amd.dist`), with a stand-in forward (the HIP forward itself needs a GPU)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, batch, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from eqxvision_amd import dist as D
+    r, w, _ = D.init_from_env("gloo")
+    imgs = torch.arange(batch * 3 * 4 * 4, dtype=torch.float32).reshape(batch, 3, 4, 4)
+
+    def forward(x):      # deterministic per-sample "logits"
+        return torch.stack([x.sum((1, 2, 3)), x.mean((1, 2, 3)), x.amax((1, 2, 3))], 1)
+
+    out = D.sharded_forward(forward, imgs)
+    q.put((rank, out.numpy()))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [8, 7])
+def test_sharded_forward_gloo(batch):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, batch, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = dict(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in ps]
+    imgs = torch.arange(batch * 3 * 4 * 4, dtype=torch.float32).reshape(batch, 3, 4, 4)
+    ref = torch.stack([imgs.sum((1, 2, 3)), imgs.mean((1, 2, 3)), imgs.amax((1, 2, 3))], 1).numpy()
+    for r in range(world):
+        assert res[r].shape == ref.shape
+        np.testing.assert_array_equal(res[r], ref)
+
+
+def test_shard_bounds_cover_batch():
+    from eqxvision_amd.dist import shard_bounds
+    for B in (1, 7, 8, 2048):
+        for W in (1, 2, 4, 8):
+            spans = [shard_bounds(B, r, W) for r in range(W)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

@@ -1,0 +1,26 @@
+"""`-m gpu`: HIP path (through the C ABI) vs the CPU oracle, op level and model level."""
+import pytest
+import torch
+
+from tests import _cases, _model_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from eqxvision_amd import _lib
+    _lib.load()     # fails loudly if the HIP library was not built / shipped
+
+
+@pytest.mark.parametrize("name,fn", _cases.all_cases(), ids=[n for n, _ in _cases.all_cases()])
+def test_op(name, fn):
+    info = fn()
+    assert info["ok"], f"{name}: {info}"
+
+
+@pytest.mark.parametrize("name,fn", _model_cases.all_cases(), ids=[n for n, _ in _model_cases.all_cases()])
+def test_model(name, fn):
+    info = fn()
+    assert info["ok"], f"{name}: {info}"
