@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/s of the vmap'd inference forward (BASELINE.json configs[1]:
+resnet50 bf16 forward, batch 256 per MI355X; `--model vit_base` = configs[2]).
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched through
+`torch.distributed.run` (one rank per GPU, RCCL).  A step = one forward of the per-GPU batch through the
+HIP path (hipGraph replay of the recorded launch list) + the all-gather of the fp32 logits; images are
+already resident in HBM.  W untimed warm-up steps, then exactly K timed steps bracketed by
+barrier + synchronize; MAX over ranks; rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     algorithmic FLOPs of one forward launch (8.178 GFLOP/img resnet50,
+               35.13 GFLOP/img vit_base) / the launch's average duration measured with HIP events on the
+               launch stream over the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s).
+  cpu_baseline the CPU restatement (oracle/torch_ref.py, fp32, all host cores -- NOT JAX, which is not
+               installed) timed on a bounded sample of the same workload, rank 0 at N=1 only.
+`--layers FILE` additionally replays the recorded launch list kernel by kernel with HIP events and
+writes a per-launch table (kernel, shape, us, TFLOP/s, GB/s) -- the tuning worksheet, outside the timing.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+GFLOP_PER_IMG = {"resnet50": 8.178, "vit_base": 35.13, "swin_t": 8.98, "alexnet": 1.428}
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def build_model(name: str, seed: int = 1):
+    import warnings
+
+    import eqxvision_amd as eqv
+    key = eqv.random.PRNGKey(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if name == "resnet50":
+            net = eqv.utils.randomize_batchnorm(eqv.models.resnet50(key=key), seed)
+        elif name == "vit_base":
+            net = eqv.models.vit_base(num_classes=1000, key=key)
+        elif name == "swin_t":
+            net = eqv.models.swin_t(key=key)
+        elif name == "alexnet":
+            net = eqv.models.alexnet(key=key)
+        else:
+            raise SystemExit(f"unknown model {name}")
+    return eqv.tree_inference(net, True)
+
+
+def _ev():
+    from eqxvision_amd import _lib
+    e = ctypes.c_void_p()
+    _lib.call("mv_event_create", ctypes.byref(e))
+    return e
+
+
+def layer_table(compiled, path, steps=5):
+    """Replay the recorded launch list call by call with HIP events -> per-launch worksheet."""
+    from eqxvision_amd import _lib
+    from eqxvision_amd._act import stream_ptr
+    s = stream_ptr()
+    rows = []
+    e0, e1 = _ev(), _ev()
+    for cfn, args, name in compiled.calls:
+        cfn(*args[:-1], s)
+        kern = _lib.last_kernel()
+        ts = []
+        for _ in range(steps):
+            _lib.call("mv_event_record", e0, s)
+            cfn(*args[:-1], s)
+            _lib.call("mv_event_record", e1, s)
+            ms = ctypes.c_float()
+            _lib.call("mv_event_elapsed_ms", e0, e1, ctypes.byref(ms))
+            ts.append(ms.value)
+        us = 1e3 * float(np.median(ts))
+        flops = byts = 0.0
+        shape = ""
+        if name == "mv_conv2d_nhwc_fwd":
+            N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, g = args[6:20]
+            Ho = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1
+            Wo = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
+            flops = 2.0 * N * Ho * Wo * K * R * S * C / g
+            byts = 2.0 * (N * H * W * C + K * R * S * C / g + N * Ho * Wo * K * (2 if args[4] else 1))
+            shape = f"N{N} {H}x{W}x{C}->{Ho}x{Wo}x{K} k{R}s{sh}"
+        elif name == "mv_linear_fwd":
+            M, N, K = args[6:9]
+            flops = 2.0 * M * N * K
+            byts = 2.0 * (M * K + N * K + M * N * (2 if args[4] else 1))
+            shape = f"M{M} K{K} N{N}"
+        elif name == "mv_conv2d_nchw_fwd":
+            N, C, H, W, K, R, S, sh, sw, ph, pw = args[5:16]
+            Ho = (H + 2 * ph - R) // sh + 1
+            Wo = (W + 2 * pw - S) // sw + 1
+            flops = 2.0 * N * Ho * Wo * K * R * S * C
+            byts = 4.0 * N * C * H * W + 2.0 * N * Ho * Wo * K
+            shape = f"N{N} {C}x{H}x{W}->{Ho}x{Wo}x{K} k{R}s{sh}"
+        elif name == "mv_mha_fwd":
+            B, N, H, dh = args[3:7]
+            flops = 4.0 * B * H * N * N * dh
+            byts = 2.0 * B * N * H * dh * 4
+            shape = f"B{B} N{N} H{H} dh{dh}"
+        elif name == "mv_maxpool2d_nhwc_fwd":
+            N, H, W, C, kh, kw, sh, sw, ph, pw = args[2:12]
+            Ho = (H + 2 * ph - kh) // sh + 1
+            byts = 2.0 * N * C * (H * W + Ho * Ho)
+            shape = f"N{N} {H}x{W}x{C}"
+        elif name == "mv_layernorm_fwd":
+            M, C = args[4:6]
+            byts = 4.0 * M * C
+            shape = f"M{M} C{C}"
+        rows.append({"call": name, "kernel": kern, "shape": shape, "us": round(us, 2),
+                     "tflops": round(flops / us / 1e6, 1) if us else 0, "gbs": round(byts / us / 1e3, 1) if us else 0,
+                     "gflop": round(flops / 1e9, 3), "mb": round(byts / 1e6, 2)})
+    tot = sum(r["us"] for r in rows)
+    with open(path, "w") as f:
+        f.write(f"# per-launch replay, {len(rows)} launches, sum {tot:.1f} us\n")
+        f.write(f"{'kernel':34s} {'shape':38s} {'us':>9s} {'TFLOP/s':>8s} {'GB/s':>8s} {'GFLOP':>8s} {'MB':>8s} {'%':>5s}\n")
+        for r in rows:
+            f.write(f"{r['kernel']:34s} {r['shape']:38s} {r['us']:9.2f} {r['tflops']:8.1f} {r['gbs']:8.1f} "
+                    f"{r['gflop']:8.3f} {r['mb']:8.2f} {100 * r['us'] / tot:5.1f}\n")
+    return rows
+
+
+def cpu_baseline(model_name, net, threads):
+    """CPU restatement (port) of the same forward on the host cores; bounded sample."""
+    import eqxvision_amd as eqv
+    from oracle import torch_ref as TR
+    sd = eqv.utils.state_dict(net)
+    B = 32 if model_name != "vit_base" else 16
+    reps = 4 if model_name != "vit_base" else 3
+    x = np.random.Generator(np.random.PCG64(0)).random((B, 3, 224, 224), dtype=np.float32)
+    fwd = {"resnet50": lambda: TR.resnet_forward(sd, x), "vit_base": lambda: TR.vit_forward(sd, x),
+           "alexnet": lambda: TR.alexnet_forward(sd, x)}.get(model_name)
+    if fwd is None:
+        return None
+    torch.set_num_threads(threads)
+    fwd()                                   # warm-up
+    best = 1e30
+    t_all = time.time()
+    for _ in range(reps):
+        t = time.time()
+        fwd()
+        best = min(best, time.time() - t)
+    return {"value": round(B / best, 2), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{model_name} fp32 forward (torch-CPU restatement oracle/torch_ref.py, NOT JAX), batch {B}, "
+                      f"best of {reps} after 1 warm-up ({time.time() - t_all:.1f}s of CPU work)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="resnet50")
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--layers", default=None, help="write a per-launch worksheet to this file")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    a = ap.parse_args()
+
+    import eqxvision_amd as eqv
+    from eqxvision_amd import _lib, dist as D
+    from eqxvision_amd._act import stream_ptr
+    import torch.distributed as td
+
+    rank, world, local = D.init_from_env()
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    eqv.set_compute_dtype(a.dtype)
+    net = build_model(a.model)
+    B = a.batch
+    # synthetic images, generated once, resident in HBM (fp32 NCHW like the reference's inputs)
+    g = torch.Generator(device="cpu").manual_seed(rank)
+    images = torch.rand((B, 3, 224, 224), generator=g, dtype=torch.float32).cuda()
+    keys = eqv.random.split(eqv.random.PRNGKey(0), B)
+
+    fwd = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k),
+                         use_graph=not a.no_graph, clone_outputs=False)
+
+    def step():
+        logits = fwd(net, images, keys)
+        if world > 1:
+            logits = D.all_gather_rows(logits, B * world)
+        return logits
+
+    for _ in range(max(a.warmup, 3)):        # call 1 records, call 2 captures the hipGraph, call 3+ replays
+        out = step()
+    torch.cuda.synchronize()
+    assert out.shape == (B * world, 1000) and bool(torch.isfinite(out).all())
+
+    e0, e1 = _ev(), _ev()
+    if world > 1:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _lib.call("mv_event_record", e0, stream_ptr())
+    for _ in range(a.steps):
+        step()
+    _lib.call("mv_event_record", e1, stream_ptr())
+    torch.cuda.synchronize()
+    if world > 1:
+        td.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = ctypes.c_float()
+    _lib.call("mv_event_elapsed_ms", e0, e1, ctypes.byref(ms))
+    dev_ms_per_step = ms.value / a.steps
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    compiled = next(iter(fwd._cache.values()))
+    if a.layers and rank == 0:
+        layer_table(compiled, a.layers)
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / a.steps
+        value = B * world * a.steps / dt
+        flop_per_launch = GFLOP_PER_IMG[a.model] * 1e9 * B
+        achieved = flop_per_launch / (dev_ms_per_step * 1e-3) / 1e12
+        line = {
+            "metric": "images/sec", "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"{a.model} {a.dtype} forward, batch={B}/GPU, 3x224x224, 1000 classes",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "launches_per_step": len(compiled.calls),
+                       "graph": compiled.graph is not None},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "whole-forward hipGraph launch (dominant kernels: igemm_bf16_*)",
+                         "launch_ms": round(dev_ms_per_step, 4),
+                         "flop_per_launch": flop_per_launch},
+        }
+        if world == 1 and not a.no_cpu:
+            try:
+                line["cpu_baseline"] = cpu_baseline(a.model, net, torch.get_num_threads())
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,7 @@ inline size_t dsize(int dt) { return dt == MV_BF16 ? 2 : 4; }
     do {                                                                             \
         hipError_t e__ = (call);                                                     \
         if (e__ != hipSuccess) {                                                     \
+            (void)hipGetLastError(); /* clear the sticky error so later launches are not blamed */ \
             mv::set_error("%s:%d %s: %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
             return (int)e__;                                                         \
         }                                                                            \

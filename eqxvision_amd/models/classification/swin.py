@@ -18,7 +18,7 @@ import numpy as np
 
 from ... import nn, ops
 from ... import random as jr
-from ..._act import Act
+from ..._act import Act, residual_fp32
 from ..._module import Module
 from ...layers import DropPath, LayerNorm2d, Linear2d, MlpProjection
 from ...nn import boundary
@@ -45,6 +45,8 @@ class _PatchMerging(Module):
     def __call__(self, x, *, key=None):                                # reference :61-65
         x = ops.patch_merge_gather(x)                                  # _patch_merging_pad (:23-31)
         x = self.norm(x)
+        if type(self.reduction) is Linear2d:
+            return ops.linear(ops.as_map(x), self.reduction, out_fp32=residual_fp32())
         return self.reduction(x)
 
 
@@ -193,9 +195,22 @@ class SwinTransformer(Module):
         self.avgpool = nn.AdaptiveAvgPool2d(1)
         self.head = nn.Linear(num_features, num_classes, key=keys[1])
 
+    def _features(self, x):
+        """self.features(x); the patch-embed LayerNorm2d starts the fp32 residual stream when enabled."""
+        L = self.features.layers
+        first = L[0]
+        if (residual_fp32() and isinstance(first, nn.Sequential) and len(first) == 2
+                and type(first.layers[0]) is nn.Conv2d and isinstance(first.layers[1], nn.LayerNorm)):
+            x = ops.conv2d(x, first.layers[0])
+            x = ops.layernorm(x, first.layers[1], out_fp32=True)
+            for layer in L[1:]:
+                x = layer(x)
+            return x
+        return self.features(x)
+
     @boundary
     def __call__(self, x, *, key=None):                                # reference :760-772
-        x = self.features(x)
+        x = self._features(x)
         x = self.norm(x)
         x = self.avgpool(x)
         x = ops.flatten(x)

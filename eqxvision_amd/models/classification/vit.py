@@ -13,7 +13,7 @@ import numpy as np
 
 from ... import nn, ops
 from ... import random as jr
-from ..._act import Act
+from ..._act import Act, residual_fp32
 from ..._module import Module
 from ...layers import DropPath, MlpProjection, PatchEmbed
 from ...nn import boundary
@@ -40,7 +40,7 @@ class _VitAttention(Module):
         self.proj_drop = nn.Dropout(proj_drop)
 
     def _forward(self, x: Act, residual: Optional[Act] = None, need_probs: bool = True):
-        x = ops.as_rows(x)
+        x = ops.as_rows(x)          # GEMM operand: compute dtype
         if x.kind != "seq":
             raise ValueError(f"_VitAttention expects (tokens, dim), got {x.shape}")
         qkv = ops.linear(x, self.qkv)                                  # reference :64
@@ -83,7 +83,7 @@ class _VitBlock(Module):
 
     @boundary
     def __call__(self, x, return_attention=False, *, key=None):        # reference :139-157
-        x = ops.as_rows(x)
+        x = ops.as_rows(x, keep_fp32=True)      # the residual stream may be fp32 (see _act.residual_fp32)
         y = self.norm1(x)
         if return_attention:
             _, attn = self.attn._forward(y, need_probs=True)
@@ -141,7 +141,8 @@ class VisionTransformer(Module):
             pe._check(x)
             cls = ops.prep_f32(self, "cls_token", self.cls_token.reshape(-1))
             pos = ops.prep_f32(self, "pos_embed", self.pos_embed)
-            return ops.patch_embed_tokens(x, pe.proj, cls, pos, 1)
+            t = ops.patch_embed_tokens(x, pe.proj, cls, pos, 1)
+            return ops.cast(t, "fp32") if residual_fp32() else t
         raise NotImplementedError("VisionTransformer expects a raw (C,H,W) image and the default PatchEmbed")
 
     def _head(self, x: Act) -> Act:

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._act import Act, DT, TORCH_DT, compute_dtype, device, empty, stream_ptr
+from ._act import Act, DT, TORCH_DT, compute_dtype, device, empty, residual_fp32, stream_ptr
 
 ACT = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "gelu": _lib.ACT_GELU_TANH}
 
@@ -118,10 +118,10 @@ def as_map(x: Act) -> Act:
     return Act(y, "map", x.batched)
 
 
-def as_rows(x: Act) -> Act:
-    """seq / vec in the compute dtype."""
+def as_rows(x: Act, keep_fp32: bool = False) -> Act:
+    """seq / vec in the compute dtype (fp32 rows pass through when `keep_fp32`: residual streams)."""
     dt = compute_dtype()
-    if x.t.dtype == TORCH_DT[dt]:
+    if x.t.dtype == TORCH_DT[dt] or (keep_fp32 and x.t.dtype == torch.float32):
         return x
     y = empty(tuple(x.t.shape), TORCH_DT[dt])
     _lib.call("mv_cast", _ptr(x.t), _ptr(y), x.t.numel(), x.dt, DT[dt], stream_ptr())
@@ -207,17 +207,21 @@ def linear(x: Act, lin, act=None, residual: Optional[Act] = None, out_fp32: bool
     """Linear over the last (feature) axis of rows: seq [B,N,D], vec [B,D] or map (Linear2d)."""
     dt = compute_dtype()
     x = as_map(x) if x.kind in ("img", "map") else as_rows(x)
+    if x.t.dtype != TORCH_DT[dt]:
+        x = cast(x, dt)
     w, b = prep_linear(lin, dt)
     N, K = lin.out_features, lin.in_features
     if x.t.shape[-1] != K:
         raise ValueError(f"Linear expected {K} input features, got {x.t.shape[-1]}")
     M = x.t.numel() // K
+    if residual is not None and residual.t.dtype == torch.float32:
+        out_fp32 = True                 # fp32 residual stream: add and store in fp32
     odt = torch.float32 if out_fp32 else TORCH_DT[dt]
     y = empty(tuple(x.t.shape[:-1]) + (N,), odt)
     res = None
     if residual is not None:
         if tuple(residual.t.shape) != tuple(y.shape) or residual.t.dtype != odt:
-            raise ValueError("residual shape/dtype mismatch in linear")
+            raise ValueError(f"residual shape/dtype mismatch in linear: {residual} vs {tuple(y.shape)} {odt}")
         res = residual.t
     _lib.call("mv_linear_fwd", _ptr(x.t), _ptr(w), None, _ptr(b), _ptr(res), _ptr(y), M, N, K, ACT[act],
               DT[dt], _lib.F32 if out_fp32 else DT[dt], stream_ptr())
@@ -249,29 +253,42 @@ def patch_embed_tokens(x: Act, conv, cls: Optional[torch.Tensor], pos: Optional[
 
 
 # ------------------------------------------------------------------ normalisation / pooling
-def layernorm(x: Act, ln) -> Act:
-    x = as_map(x) if x.kind in ("img", "map") else as_rows(x)
+def layernorm(x: Act, ln, out_fp32: bool = False) -> Act:
+    """Rows of the last axis; reads the input in its own dtype (bf16, or the fp32 residual stream) and
+    writes the compute dtype (what the next GEMM consumes) unless `out_fp32`."""
+    if x.kind == "img":
+        x = as_map(x)
+    dt = compute_dtype()
     C = x.t.shape[-1]
     if int(np.prod(ln.shape)) != C:
         raise ValueError(f"LayerNorm over {ln.shape} applied to rows of {C}")
     g = prep_f32(ln, "weight", ln.weight)
     b = prep_f32(ln, "bias", ln.bias)
-    y = empty(tuple(x.t.shape), x.t.dtype)
+    odt = torch.float32 if out_fp32 else TORCH_DT[dt]
+    y = empty(tuple(x.t.shape), odt)
     _lib.call("mv_layernorm_fwd", _ptr(x.t), _ptr(g), _ptr(b), _ptr(y), x.t.numel() // C, C, 0, float(ln.eps),
-              x.dt, x.dt, stream_ptr())
+              x.dt, _lib.F32 if out_fp32 else DT[dt], stream_ptr())
+    return Act(y, x.kind, x.batched)
+
+
+def cast(x: Act, dtype: str) -> Act:
+    if x.t.dtype == TORCH_DT[dtype]:
+        return x
+    y = empty(tuple(x.t.shape), TORCH_DT[dtype])
+    _lib.call("mv_cast", _ptr(x.t), _ptr(y), x.t.numel(), x.dt, DT[dtype], stream_ptr())
     return Act(y, x.kind, x.batched)
 
 
 def layernorm_first_row(x: Act, ln) -> Act:
     """LayerNorm of row 0 of every sample of a seq [B,N,D] -> vec [B,D] (vit.py:272-273: only
     `x[0]` of the normalised tokens is used), via the kernel's row-stride argument."""
-    x = as_rows(x)
+    dt = compute_dtype()
     B, N, D = x.t.shape
     g = prep_f32(ln, "weight", ln.weight)
     b = prep_f32(ln, "bias", ln.bias)
-    y = empty((B, D), x.t.dtype)
+    y = empty((B, D), TORCH_DT[dt])
     _lib.call("mv_layernorm_fwd", _ptr(x.t), _ptr(g), _ptr(b), _ptr(y), B, D, N * D, float(ln.eps),
-              x.dt, x.dt, stream_ptr())
+              x.dt, DT[dt], stream_ptr())
     return Act(y, "vec", x.batched)
 
 
@@ -319,6 +336,7 @@ def adaptive_avgpool2d(x: Act, target) -> Act:
 # ------------------------------------------------------------------ attention
 def mha(qkv: Act, heads: int, scale: float, need_probs: bool):
     """qkv rows [B,N,3D] -> ([B,N,D], probs fp32 [B,heads,N,N] or None)   (vit.py:65-73)."""
+    qkv = cast(qkv, compute_dtype())
     B, N, D3 = qkv.t.shape
     D = D3 // 3
     dh = D // heads

@@ -70,8 +70,25 @@ class _Compiled:
         self.refs = None
 
 
+def _is_key_array(x) -> bool:
+    """PRNG keys (uint32 arrays): dead values in inference, never shipped to the device."""
+    if isinstance(x, np.ndarray):
+        return x.dtype == np.uint32
+    return isinstance(x, torch.Tensor) and x.dtype in (torch.uint32, torch.int32, torch.int64) and not x.is_cuda
+
+
+def _is_resident(x) -> bool:
+    """A device tensor the kernels can read in place (no staging copy)."""
+    return (isinstance(x, torch.Tensor) and x.is_cuda and x.is_contiguous()
+            and x.dtype in (torch.float32, torch.bfloat16))
+
+
 def _sig(x):
     if _is_array(x):
+        if _is_key_array(x):
+            return ("key", tuple(x.shape))
+        if _is_resident(x):            # read in place: the buffer address is part of the signature
+            return ("dev", tuple(x.shape), str(x.dtype), x.data_ptr())
         return ("arr", tuple(x.shape), str(x.dtype))
     if isinstance(x, Module) or callable(x):
         return ("obj", id(x))
@@ -112,20 +129,24 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
     def jitted(*args, **kwargs):
         key = (compute_dtype(), tuple(_sig(a) for a in args), tuple((k, _sig(v)) for k, v in sorted(kwargs.items())))
         c = cache.get(key)
-        flat_arrays = [a for a in args if _is_array(a)] + [v for _, v in sorted(kwargs.items()) if _is_array(v)]
+
+        def staged(v):
+            return _is_array(v) and not _is_key_array(v) and not _is_resident(v)
+
+        flat_arrays = [a for a in args if staged(a)] + [v for _, v in sorted(kwargs.items()) if staged(v)]
         if c is None:
             c = _Compiled()
-            c.refs = (args, kwargs)            # keep static objects (modules) alive: ids are in the key
+            c.refs = (args, kwargs)            # keep static objects (modules, resident inputs) alive
             new_args, new_kwargs = [], {}
             for a in args:
-                if _is_array(a):
+                if staged(a):                  # host array: owned device staging buffer, refreshed per call
                     t = _to_device_f32(a).clone()
                     c.static_in.append(t)
                     new_args.append(t)
                 else:
                     new_args.append(a)
             for k, v in sorted(kwargs.items()):
-                if _is_array(v):
+                if staged(v):
                     t = _to_device_f32(v).clone()
                     c.static_in.append(t)
                     new_kwargs[k] = t
@@ -144,13 +165,19 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
             dst.copy_(src if isinstance(src, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(src)),
                       non_blocking=True)
         if use_graph and c.graph is None and c.calls:
-            _lib.call("mv_graph_begin_capture", stream_ptr())
-            try:
-                _replay(c)
-            finally:
-                import ctypes
+            # capture on a private stream (the legacy default stream cannot be captured); it first waits
+            # for everything already queued on the caller's stream
+            import ctypes
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                _lib.call("mv_graph_begin_capture", stream_ptr())
                 g = ctypes.c_void_p()
-                _lib.call("mv_graph_end_capture", stream_ptr(), ctypes.byref(g))
+                try:
+                    _replay(c)
+                finally:
+                    _lib.call("mv_graph_end_capture", stream_ptr(), ctypes.byref(g))
             c.graph = g
         if c.graph is not None:
             _lib.call("mv_graph_launch", c.graph, stream_ptr())

@@ -104,3 +104,74 @@ def load_torch_weights(model: Module, torch_weights: Optional[str] = None) -> Mo
     if leftover:
         raise ValueError(f"checkpoint has {leftover} more tensors than the model has array leaves")
     return new
+
+
+def state_dict(model: Module) -> "OrderedDict[str, np.ndarray]":
+    """Export a torch-style ordered `state_dict` from a model tree: names are attribute paths with
+    `nn.Sequential.layers[i]` / list entries flattened to their index ("layer1.0.conv1.weight"), which
+    is torchvision's naming for the ported families; BatchNorm running statistics are emitted as
+    `running_mean` / `running_var`.  The inverse of `load_torch_weights` (same order)."""
+    from collections import OrderedDict
+
+    from . import nn
+    out = OrderedDict()
+
+    def rec(node, prefix):
+        if isinstance(node, nn.BatchNorm):
+            if node.weight is not None:
+                out[prefix + "weight"] = node.weight
+                out[prefix + "bias"] = node.bias
+            st = node.state_index.value
+            if st is not None:
+                out[prefix + "running_mean"], out[prefix + "running_var"] = st
+            return
+        if isinstance(node, Module):
+            for f in node.__fields__:
+                if not hasattr(node, f):
+                    continue
+                v = getattr(node, f)
+                if isinstance(node, nn.Sequential) and f == "layers":
+                    rec(v, prefix)
+                else:
+                    rec(v, prefix + f + ".")
+            return
+        if isinstance(node, (list, tuple)):
+            for i, v in enumerate(node):
+                rec(v, prefix + f"{i}.")
+            return
+        if isinstance(node, np.ndarray):
+            out[prefix[:-1]] = node
+
+    rec(model, "")
+    return out
+
+
+def randomize_batchnorm(model: Module, seed: int = 1) -> Module:
+    """Give every BatchNorm non-trivial affine parameters and running statistics
+    (gamma~U[0.5,1.5], beta~N(0,0.1), mean~N(0,0.1), var~U[0.5,1.5]) so that a randomly initialised
+    model can run inference (the reference's unloaded BatchNorm has no state at all) and the BN
+    folding is exercised.  Used for synthetic benchmarks."""
+    from . import nn
+    rng = np.random.Generator(np.random.PCG64(seed))
+
+    def rec(n):
+        if isinstance(n, nn.BatchNorm):
+            c = n.input_size
+            new = object.__new__(type(n))
+            new.__dict__.update({k: v for k, v in n.__dict__.items() if k != "_dev_cache"})
+            object.__setattr__(new, "weight", rng.uniform(0.5, 1.5, c).astype(np.float32))
+            object.__setattr__(new, "bias", (0.1 * rng.standard_normal(c)).astype(np.float32))
+            object.__setattr__(new, "first_time_index", StateIndex(False))
+            object.__setattr__(new, "state_index", StateIndex(((0.1 * rng.standard_normal(c)).astype(np.float32),
+                                                                rng.uniform(0.5, 1.5, c).astype(np.float32))))
+            return new
+        if isinstance(n, Module):
+            from ._module import _rebuild
+            return _rebuild(n, rec)
+        if isinstance(n, list):
+            return [rec(c) for c in n]
+        if isinstance(n, tuple):
+            return tuple(rec(c) for c in n)
+        return n
+
+    return rec(model)

@@ -418,13 +418,15 @@ def misc_case(kind, dtype="bf16", seed=0):
             sf = rng.standard_normal(C).astype(np.float32)
             xd = dev(x, dtype)
             o = torch.empty((rows, C), dtype=tdt, device="cuda")
-            L.call("mv_channel_affine_fwd", xd.data_ptr(), dev(sc, "fp32").data_ptr(), dev(sf, "fp32").data_ptr(),
+            scd, sfd = dev(sc, "fp32"), dev(sf, "fp32")     # keep the device tensors alive across the launch
+            L.call("mv_channel_affine_fwd", xd.data_ptr(), scd.data_ptr(), sfd.data_ptr(),
                    o.data_ptr(), rows, C, 1, DT[dtype], _stream())
             B, T, D = 3, 5, 16
             cls = rng.standard_normal(D).astype(np.float32)
             pos = rng.standard_normal((T, D)).astype(np.float32)
             tok = torch.zeros((B, T, D), dtype=tdt, device="cuda")
-            L.call("mv_vit_cls_pos_fwd", dev(cls, "fp32").data_ptr(), dev(pos, "fp32").data_ptr(), tok.data_ptr(), B, T, D,
+            clsd, posd = dev(cls, "fp32"), dev(pos, "fp32")
+            L.call("mv_vit_cls_pos_fwd", clsd.data_ptr(), posd.data_ptr(), tok.data_ptr(), B, T, D,
                    DT[dtype], _stream())
             torch.cuda.synchronize()
             a = _cmp(host(o), O.relu(x * sc + sf), TOL_BF16 if dtype == "bf16" else 1e-5)
