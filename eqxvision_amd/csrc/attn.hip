@@ -40,28 +40,56 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const bf16_t* __restrict_
     const bf16_t* kbase = qbase + (long long)H * DH;
     const bf16_t* vbase = qbase + 2LL * H * DH;
 
-    // ---- stage K: [key][d], 16-byte chunks ----------------------------------------------------
+    // ---- stage K: [key][d], 16-byte chunks; loads are batched (4 in flight per thread) and unconditional
+    //      (clamped row, zeroed afterwards) so their latencies overlap instead of chaining ------------------
     constexpr int CH = DH / 8;
-    for (int i = tid; i < NP * CH; i += 256) {
-        const int key = i / CH, ch = i - key * CH;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (key < N) v = *(const uint4*)(kbase + (long long)key * rs + ch * 8);
-        *(uint4*)(kl + key * KPITCH + ch * 16) = v;
-    }
-    // ---- stage V^T: [d][key]; each thread transposes a 2-key x 8-d patch into 8 dword stores --
-    for (int i = tid; i < (NP / 2) * CH; i += 256) {
-        const int ch = i / (NP / 2), kp = i - ch * (NP / 2);          // consecutive lanes -> consecutive key pairs
-        const int key = 2 * kp;
-        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
-        if (key < N) v0 = *(const uint4*)(vbase + (long long)key * rs + ch * 8);
-        if (key + 1 < N) v1 = *(const uint4*)(vbase + (long long)(key + 1) * rs + ch * 8);
-        const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, c[4] = {v1.x, v1.y, v1.z, v1.w};
+    constexpr int KITEMS = NP * CH;
+    for (int base = 0; base < KITEMS; base += 256 * 4) {
+        uint4 v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint32_t lo = (a[e] & 0xffffu) | (c[e] << 16);          // d = 8ch+2e   : (key, key+1)
-            const uint32_t hi = (a[e] >> 16) | (c[e] & 0xffff0000u);      // d = 8ch+2e+1
-            *(uint32_t*)(vl + (ch * 8 + 2 * e) * VPITCH + key * 2) = lo;
-            *(uint32_t*)(vl + (ch * 8 + 2 * e + 1) * VPITCH + key * 2) = hi;
+        for (int j = 0; j < 4; ++j) {
+            const int i = base + j * 256 + tid;
+            const int key = i / CH, ch = i - key * CH;
+            const int kc = key < N ? key : N - 1;
+            v[j] = *(const uint4*)(kbase + (long long)kc * rs + ch * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = base + j * 256 + tid;
+            const int key = i / CH, ch = i - key * CH;
+            if (i < KITEMS) *(uint4*)(kl + key * KPITCH + ch * 16) = key < N ? v[j] : make_uint4(0, 0, 0, 0);
+        }
+    }
+    // ---- stage V^T: [d][key]; each thread transposes a 2-key x 8-d patch into 8 dword stores --------------
+    constexpr int VITEMS = (NP / 2) * CH;
+    for (int base = 0; base < VITEMS; base += 256 * 2) {
+        uint4 v0[2], v1[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = base + j * 256 + tid;
+            const int ch = i / (NP / 2), kp = i - ch * (NP / 2);      // consecutive lanes -> consecutive key pairs
+            const int key = 2 * kp;
+            const int k0 = key < N ? key : N - 1, k1 = key + 1 < N ? key + 1 : N - 1;
+            const int chc = ch < CH ? ch : CH - 1;
+            v0[j] = *(const uint4*)(vbase + (long long)k0 * rs + chc * 8);
+            v1[j] = *(const uint4*)(vbase + (long long)k1 * rs + chc * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = base + j * 256 + tid;
+            if (i >= VITEMS) continue;
+            const int ch = i / (NP / 2), kp = i - ch * (NP / 2);
+            const int key = 2 * kp;
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            const uint4 w0 = key < N ? v0[j] : z, w1 = key + 1 < N ? v1[j] : z;
+            const uint32_t a[4] = {w0.x, w0.y, w0.z, w0.w}, c[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t lo = (a[e] & 0xffffu) | (c[e] << 16);          // d = 8ch+2e   : (key, key+1)
+                const uint32_t hi = (a[e] >> 16) | (c[e] & 0xffff0000u);      // d = 8ch+2e+1
+                *(uint32_t*)(vl + (ch * 8 + 2 * e) * VPITCH + key * 2) = lo;
+                *(uint32_t*)(vl + (ch * 8 + 2 * e + 1) * VPITCH + key * 2) = hi;
+            }
         }
     }
     __syncthreads();

@@ -352,64 +352,98 @@ __global__ void layernorm_kernel(const TI* __restrict__ x, const float* __restri
     }
 }
 
-// bf16 rows with C % 8 == 0 and C <= 64*8*4: whole row held in registers, 16-byte accesses.
-template <int CHUNKS>
-__global__ void layernorm_bf16x8_kernel(const uint4* __restrict__ x, const float* __restrict__ gamma,
-                                        const float* __restrict__ beta, uint4* __restrict__ y, long long M, int C8,
-                                        long long xs8, float eps) {
+// Vectorised LayerNorm: one wave per row, the whole row held in registers, 16-byte loads.
+// TI = bf16 (8 elements per 16-byte chunk) or fp32 (4 elements per chunk, the fp32 residual stream);
+// TO = bf16 or fp32.  CHUNKS = 16-byte chunks per lane (row length <= 64 * CHUNKS chunks).
+template <typename T> struct Vec16;
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void ld(const bf16_t* p, float* v) {
+        const uint4 u = *(const uint4*)p;
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = __uint_as_float(w[e] << 16);
+            v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+        }
+    }
+};
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    __device__ static __forceinline__ void ld(const float* p, float* v) {
+        const float4 u = *(const float4*)p;
+        v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+    }
+};
+template <typename TO, int N> struct StN;
+template <> struct StN<bf16_t, 8> {
+    __device__ static __forceinline__ void st(bf16_t* p, const float* o) {
+        *(uint4*)p = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+    }
+};
+template <> struct StN<bf16_t, 4> {
+    __device__ static __forceinline__ void st(bf16_t* p, const float* o) {
+        *(uint2*)p = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+    }
+};
+template <> struct StN<float, 8> {
+    __device__ static __forceinline__ void st(float* p, const float* o) {
+        *(float4*)p = make_float4(o[0], o[1], o[2], o[3]);
+        *(float4*)(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+};
+template <> struct StN<float, 4> {
+    __device__ static __forceinline__ void st(float* p, const float* o) { *(float4*)p = make_float4(o[0], o[1], o[2], o[3]); }
+};
+
+template <typename TI, typename TO, int CHUNKS>
+__global__ void layernorm_vec_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, TO* __restrict__ y, long long M, int C,
+                                     long long xs, float eps) {
+    constexpr int N = Vec16<TI>::N;
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
-    const uint4* xr = x + row * xs8;
-    float v[CHUNKS][8];
+    const int nch = C / N;
+    const TI* xr = x + row * xs;
+    float v[CHUNKS][N];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < CHUNKS; ++i) {
         const int c = lane + 64 * i;
-        if (c < C8) {
-            const uint4 u = xr[c];
-            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+        if (c < nch) {
+            Vec16<TI>::ld(xr + c * N, v[i]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[i][2 * e] = __uint_as_float(w[e] << 16);
-                v[i][2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
-                s += v[i][2 * e] + v[i][2 * e + 1];
-            }
+            for (int e = 0; e < N; ++e) s += v[i][e];
         }
     }
-    const float C = (float)(C8 * 8);
-    const float mean = wave_sum(s) / C;
+    const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < CHUNKS; ++i) {
         const int c = lane + 64 * i;
-        if (c < C8) {
+        if (c < nch) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < N; ++e) {
                 const float d = v[i][e] - mean;
                 q += d * d;
             }
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / C + eps);
-    uint4* yr = y + row * C8;
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    TO* yr = y + row * C;
 #pragma unroll
     for (int i = 0; i < CHUNKS; ++i) {
         const int c = lane + 64 * i;
-        if (c < C8) {
-            float o[8];
+        if (c < nch) {
+            float o[N];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < N; ++e) {
                 o[e] = (v[i][e] - mean) * rstd;
-                if (gamma) o[e] *= gamma[c * 8 + e];
-                if (beta) o[e] += beta[c * 8 + e];
+                if (gamma) o[e] *= gamma[c * N + e];
+                if (beta) o[e] += beta[c * N + e];
             }
-            uint4 r;
-            r.x = pack_bf2(o[0], o[1]);
-            r.y = pack_bf2(o[2], o[3]);
-            r.z = pack_bf2(o[4], o[5]);
-            r.w = pack_bf2(o[6], o[7]);
-            yr[c] = r;
+            StN<TO, N>::st(yr + c * N, o);
         }
     }
 }
@@ -632,19 +666,27 @@ int mv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void*
     hipStream_t st = (hipStream_t)stream;
     const int rows_per_block = 4;
     dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block)), block(64 * rows_per_block);
-    if (in_dtype == MV_BF16 && out_dtype == MV_BF16 && C % 8 == 0 && xs % 8 == 0 && C <= 64 * 8 * 4 &&
-        !get_flag("force_generic")) {
-        set_kernel_name("layernorm_bf16x8");
-        const int C8 = C / 8;
-        if (C8 <= 64)
-            hipLaunchKernelGGL(layernorm_bf16x8_kernel<1>, grid, block, 0, st, (const uint4*)x, gamma, beta, (uint4*)y,
-                               (long long)M, C8, xs / 8, eps);
-        else if (C8 <= 128)
-            hipLaunchKernelGGL(layernorm_bf16x8_kernel<2>, grid, block, 0, st, (const uint4*)x, gamma, beta, (uint4*)y,
-                               (long long)M, C8, xs / 8, eps);
-        else
-            hipLaunchKernelGGL(layernorm_bf16x8_kernel<4>, grid, block, 0, st, (const uint4*)x, gamma, beta, (uint4*)y,
-                               (long long)M, C8, xs / 8, eps);
+    const int epc = in_dtype == MV_BF16 ? 8 : 4;          // elements per 16-byte chunk of the input
+    const int nch = C / epc;
+    if (C % epc == 0 && xs % epc == 0 && nch <= 64 * 8 && !get_flag("force_generic")) {
+        set_kernel_name("layernorm_vec");
+#define GO3(TI, TO, CH) \
+    hipLaunchKernelGGL((layernorm_vec_kernel<TI, TO, CH>), grid, block, 0, st, (const TI*)x, gamma, beta, (TO*)y, \
+                       (long long)M, C, xs, eps)
+#define GO2(TI, TO)                         \
+    do {                                    \
+        if (nch <= 64) GO3(TI, TO, 1);      \
+        else if (nch <= 128) GO3(TI, TO, 2);\
+        else if (nch <= 192) GO3(TI, TO, 3);\
+        else if (nch <= 256) GO3(TI, TO, 4);\
+        else GO3(TI, TO, 8);                \
+    } while (0)
+        if (in_dtype == MV_BF16 && out_dtype == MV_BF16) GO2(bf16_t, bf16_t);
+        else if (in_dtype == MV_BF16 && out_dtype == MV_F32) GO2(bf16_t, float);
+        else if (in_dtype == MV_F32 && out_dtype == MV_F32) GO2(float, float);
+        else GO2(float, bf16_t);
+#undef GO2
+#undef GO3
     } else {
         set_kernel_name("layernorm");
 #define GO(TI, TO)                                                                                         \

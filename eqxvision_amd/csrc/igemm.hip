@@ -22,12 +22,9 @@
 //    tile t+1 is issued before the MFMAs of tile t.
 //  * blockIdx -> tile mapping is XCD-aware: the 8 XCDs (private L2s) each take a contiguous chunk of
 //    the tile list, n-tiles fastest, so every n-tile of one pixel tile hits the same L2.
-#include "common.h"
+#include "mfma_common.h"
 
 namespace mv {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct IgemmP {
     const bf16_t* x;
@@ -41,35 +38,26 @@ struct IgemmP {
     int M, tiles_m, tiles_n, act;
 };
 
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    // blocks are dispatched round-robin over the 8 XCDs; give each XCD a contiguous tile range
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-template <typename OutT> struct Out4;
-template <> struct Out4<bf16_t> {
-    __device__ static __forceinline__ float4 ld(const void* p) {
-        const uint2 u = *(const uint2*)p;
-        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-    }
-    __device__ static __forceinline__ void st(void* p, float4 v) {
-        uint2 u;
-        u.x = pack_bf2(v.x, v.y);
-        u.y = pack_bf2(v.z, v.w);
-        *(uint2*)p = u;
+// 8 consecutive residual values of one output row, fetched as raw bits early, decoded in the epilogue
+template <typename OutT> struct Res8;
+template <> struct Res8<bf16_t> {
+    uint4 u;
+    __device__ __forceinline__ void load(const bf16_t* p) { u = *(const uint4*)p; }
+    __device__ __forceinline__ void add_to(float* v) const {
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] += __uint_as_float(w[e] << 16);
+            v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+        }
     }
 };
-template <> struct Out4<float> {
-    __device__ static __forceinline__ float4 ld(const void* p) { return *(const float4*)p; }
-    __device__ static __forceinline__ void st(void* p, float4 v) { *(float4*)p = v; }
+template <> struct Res8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *(const float4*)p; b = *(const float4*)(p + 4); }
+    __device__ __forceinline__ void add_to(float* v) const {
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
 };
 
 template <int BM, int BN, int WM, int WN, typename OutT, bool DENSE>
@@ -158,6 +146,25 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
     const int fr = lane & 31, fh = lane >> 5, swz = (fr >> 1) & 7;
     const int xrow0 = wm * (BM / WM), wrow0 = wn * (BN / WN);
 
+    // ---------------- residual prefetch ------------------------------------------------------------
+    // The epilogue re-reads the tile row-major: in pass q of channel chunk c this lane owns pixel row
+    // 8q + lane/8 and channels 64c + 8*(lane%8) .. +7.  Its residual values are fetched NOW, unconditionally
+    // (clamped address), so that their HBM latency overlaps the whole main loop instead of forming a chain
+    // of 8 dependent round trips at the end.
+    const OutT* res = (const OutT*)p.residual;
+    Res8<OutT> rres[TN / 2][4];
+    if (res) {
+#pragma unroll
+        for (int c = 0; c < TN / 2; ++c)
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = m0 + xrow0 + pass * 8 + (lane >> 3);
+                const int n = n0 + c * 64 + (lane & 7) * 8;
+                const bool ok = m < p.M && n < p.K;
+                rres[c][pass].load(res + (ok ? (long long)m * p.K + n : 0));
+            }
+    }
+
     // ---------------- main loop ---------------------------------------------------------------
     int r = 0, s = 0, c0 = 0;   // position of the NEXT tile to stage
     stage(0, r, s, c0);
@@ -203,41 +210,65 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
                                                                         acc[a][b], 0, 0, 0);
     }
 
-    // ---------------- epilogue: D[row = channel][col = pixel] ------------------------------------
-    // lane: pixel = fr, channels 8*g + 4*fh + {0..3} for g = 0..3  <-  acc[4*g + {0..3}]
+    // ---------------- epilogue -------------------------------------------------------------------
+    // MFMA result D[row = channel][col = pixel]: a lane holds pixel `fr` and, per accumulator quad g,
+    // channels 8g + 4fh + {0..3}.  Storing that directly touches 32 different 128-byte lines with 16 bytes
+    // each per instruction (measured: ~2 TB/s on the memory-bound 1x1 layers).  Instead every wave
+    // transposes its 32-pixel x 64-channel chunk through its own LDS patch (fp32, scale/shift already
+    // applied) and re-reads it row-major: 8 lanes own one pixel's 64 channels = ONE full 128-byte line of
+    // the NHWC output, so the residual read and the store are 16 bytes per lane, fully coalesced.
+    constexpr int EPITCH = 64 * 4 + 16;          // bytes per staged pixel row (+16: conflict-free b128 writes)
+    static_assert(WN == 1 && TM == 1 && (TN % 2) == 0, "epilogue assumes one 32-pixel tile x BN channels per wave");
+    static_assert(4 * 32 * EPITCH <= 2 * STAGE, "epilogue patch must fit the staging buffers");
+    __syncthreads();                             // every wave is done reading the last k-tile
+    char* ep = smem + wave * (32 * EPITCH);
     OutT* y = (OutT*)p.y;
-    const OutT* res = (const OutT*)p.residual;
+    const int mrow0 = m0 + xrow0;                // first pixel of this wave
 #pragma unroll
-    for (int b = 0; b < TM; ++b) {
-        const int m = m0 + xrow0 + b * 32 + fr;
-        if (m >= p.M) continue;
+    for (int c = 0; c < TN / 2; ++c) {
 #pragma unroll
-        for (int a = 0; a < TN; ++a) {
+        for (int a2 = 0; a2 < 2; ++a2) {
+            const int a = 2 * c + a2;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wrow0 + a * 32 + 8 * g + 4 * fh;
-                if (n >= p.K) continue;
-                float4 v = make_float4(acc[a][b][4 * g + 0], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2],
-                                       acc[a][b][4 * g + 3]);
-                if (p.scale) {
-                    const float4 sc = *(const float4*)(p.scale + n);
-                    v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+                const int nl = a2 * 32 + 8 * g + 4 * fh;
+                const int n = n0 + c * 64 + nl;
+                float4 v = make_float4(acc[a][0][4 * g + 0], acc[a][0][4 * g + 1], acc[a][0][4 * g + 2],
+                                       acc[a][0][4 * g + 3]);
+                if (n < p.K) {
+                    if (p.scale) {
+                        const float4 sc = *(const float4*)(p.scale + n);
+                        v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+                    }
+                    if (p.shift) {
+                        const float4 sf = *(const float4*)(p.shift + n);
+                        v.x += sf.x; v.y += sf.y; v.z += sf.z; v.w += sf.w;
+                    }
                 }
-                if (p.shift) {
-                    const float4 sf = *(const float4*)(p.shift + n);
-                    v.x += sf.x; v.y += sf.y; v.z += sf.z; v.w += sf.w;
-                }
+                *(float4*)(ep + fr * EPITCH + nl * 4) = v;
+            }
+        }
+        // LDS is in-order per wave: the reads below see the writes above (no barrier needed, the patch
+        // is private to the wave)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + (lane >> 3), c8 = lane & 7;
+            const int m = mrow0 + row;
+            const int n = n0 + c * 64 + c8 * 8;
+            const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
+            const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
+            if (m < p.M && n < p.K) {
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 const long long o = (long long)m * p.K + n;
-                if (res) {
-                    const float4 rv = Out4<OutT>::ld(res + o);
-                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                }
+                if (res) rres[c][pass].add_to(v);
                 if (p.act == MV_ACT_RELU) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 } else if (p.act == MV_ACT_GELU_TANH) {
-                    v.x = gelu_tanh_f(v.x); v.y = gelu_tanh_f(v.y); v.z = gelu_tanh_f(v.z); v.w = gelu_tanh_f(v.w);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
                 }
-                Out4<OutT>::st(y + o, v);
+                Out8<OutT>::st(y + o, v);
             }
         }
     }
@@ -247,7 +278,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
 int igemm_supported(int C, int K, int R, int S, int groups, int in_dtype, int out_dtype) {
     (void)R; (void)S;
     return in_dtype == MV_BF16 && (out_dtype == MV_BF16 || out_dtype == MV_F32) && groups == 1 && C % 64 == 0 &&
-           K % 4 == 0;
+           K % 8 == 0;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -297,7 +328,7 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
         return launch_tile<128, 64, 4, 1>(p, dense, out_f32, st);
     }
     set_kernel_name(dense ? "igemm_bf16_128x128_dense" : "igemm_bf16_128x128_conv");
-    return launch_tile<128, 128, 2, 2>(p, dense, out_f32, st);
+    return launch_tile<128, 128, 4, 1>(p, dense, out_f32, st);
 }
 
 }  // namespace mv

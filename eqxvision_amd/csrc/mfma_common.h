@@ -1,0 +1,57 @@
+// Device helpers shared by the MFMA kernels (igemm.hip, stem.hip): LDS-DMA, XCD-aware tile remap,
+// vector output packing.  gfx950 only.
+#pragma once
+#include "common.h"
+
+namespace mv {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    // blocks are dispatched round-robin over the 8 XCDs; give each XCD a contiguous tile range
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <typename OutT> struct Out4;
+template <> struct Out4<bf16_t> {
+    __device__ static __forceinline__ float4 ld(const void* p) {
+        const uint2 u = *(const uint2*)p;
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    }
+    __device__ static __forceinline__ void st(void* p, float4 v) {
+        uint2 u;
+        u.x = pack_bf2(v.x, v.y);
+        u.y = pack_bf2(v.z, v.w);
+        *(uint2*)p = u;
+    }
+};
+template <> struct Out4<float> {
+    __device__ static __forceinline__ float4 ld(const void* p) { return *(const float4*)p; }
+    __device__ static __forceinline__ void st(void* p, float4 v) { *(float4*)p = v; }
+};
+
+template <typename OutT> struct Out8;
+template <> struct Out8<bf16_t> {
+    __device__ static __forceinline__ void st(bf16_t* p, const float* v) {
+        uint4 u;
+        u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+        *(uint4*)p = u;
+    }
+};
+template <> struct Out8<float> {
+    __device__ static __forceinline__ void st(float* p, const float* v) {
+        *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+
+}  // namespace mv

@@ -34,7 +34,8 @@ enum { MV_F32 = 0, MV_BF16 = 1 };
 enum { MV_ACT_NONE = 0, MV_ACT_RELU = 1, MV_ACT_GELU_TANH = 2 };
 enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
 /* mv_set_flag names: "force_generic" (1 = route every op to the simple VALU kernels, used by
- * tests to cross-check the MFMA kernels), "igemm_tile" (override tile heuristic, 0 = auto). */
+ * tests to cross-check the MFMA kernels), "igemm_tile" (override tile heuristic, 0 = auto),
+ * "stem_v0" (1 = use the table-gather entry-conv kernel instead of the patch/GEMM variants). */
 
 int mv_abi_version(void);
 const char* mv_last_error(void);

@@ -110,7 +110,8 @@ def conv_nhwc_case(N, H, W, C, K, R, S, stride=1, pad=0, dil=1, groups=1, act=0,
     return run
 
 
-def conv_nchw_case(N, C, H, W, K, R, S, stride, pad, act=0, xdtype="fp32", tokens=False, generic=False, seed=0):
+def conv_nchw_case(N, C, H, W, K, R, S, stride, pad, act=0, xdtype="fp32", tokens=False, generic=False, seed=0,
+                   v0=False):
     def run():
         L = _lib()
         rng = _rng(seed)
@@ -143,12 +144,14 @@ def conv_nchw_case(N, C, H, W, K, R, S, stride, pad, act=0, xdtype="fp32", token
             y = torch.empty((N, P, K), dtype=torch.bfloat16, device="cuda")
             targs = (0, 0, None)
         L.set_flag("force_generic", 1 if generic else 0)
+        L.set_flag("stem_v0", 1 if v0 else 0)
         try:
             L.call("mv_conv2d_nchw_fwd", xd.data_ptr(), wd.data_ptr(), scd.data_ptr(), sfd.data_ptr(), y.data_ptr(),
                    N, C, H, W, K, R, S, stride, stride, pad, pad, act, DT[xdtype], 1, *targs, _stream())
             kern = L.last_kernel()
         finally:
             L.set_flag("force_generic", 0)
+            L.set_flag("stem_v0", 0)
         torch.cuda.synchronize()
         info = _cmp(host(y), ref, TOL_BF16)
         info["kernel"] = kern
@@ -473,7 +476,13 @@ def all_cases():
           ("stem/vit_patch16_tokens", conv_nchw_case(2, 3, 64, 64, 768, 16, 16, 16, 0, tokens=True)),
           ("stem/swin_patch4", conv_nchw_case(2, 3, 56, 56, 96, 4, 4, 4, 0)),
           ("stem/generic_tokens", conv_nchw_case(1, 3, 32, 32, 64, 8, 8, 8, 0, tokens=True, generic=True)),
-          ("stem/full224", conv_nchw_case(2, 3, 224, 224, 64, 7, 7, 2, 3, act=1, seed=5))]
+          ("stem/full224", conv_nchw_case(2, 3, 224, 224, 64, 7, 7, 2, 3, act=1, seed=5)),
+          ("stem/resnet7x7_tablekernel", conv_nchw_case(2, 3, 64, 64, 64, 7, 7, 2, 3, act=1, v0=True)),
+          ("stem/vit_tokens_tablekernel", conv_nchw_case(1, 3, 64, 64, 768, 16, 16, 16, 0, tokens=True, v0=True)),
+          ("stem/alexnet_224", conv_nchw_case(1, 3, 224, 224, 64, 11, 11, 4, 2, act=1, seed=2)),
+          ("stem/vit_224_bf16in", conv_nchw_case(2, 3, 224, 224, 768, 16, 16, 16, 0, tokens=True, xdtype="bf16")),
+          ("stem/patch8_notokens", conv_nchw_case(3, 3, 40, 48, 192, 8, 8, 8, 0)),
+          ("stem/odd_size_7x7", conv_nchw_case(1, 3, 61, 75, 32, 7, 7, 2, 3, act=1))]
     c += [("maxpool/3_2_1", maxpool_case(2, 112, 112, 64, 3, 2, 1)),
           ("maxpool/3_2_0", maxpool_case(2, 55, 55, 64, 3, 2, 0)),
           ("maxpool/f32_oddC", maxpool_case(1, 13, 13, 5, 3, 2, 0, dtype="fp32")),
@@ -483,7 +492,10 @@ def all_cases():
           ("layernorm/96", layernorm_case(100, 96)),
           ("layernorm/768_generic", layernorm_case(50, 768, generic=True)),
           ("layernorm/strided", layernorm_case(8, 768, stride=768 * 5)),
-          ("layernorm/odd_f32", layernorm_case(7, 20, dtype="fp32"))]
+          ("layernorm/odd_f32", layernorm_case(7, 20, dtype="fp32")),
+          ("layernorm/768_f32", layernorm_case(64, 768, dtype="fp32")),
+          ("layernorm/1536", layernorm_case(50, 1536)),
+          ("layernorm/3072_f32", layernorm_case(9, 3072, dtype="fp32"))]
     c += [("mha/vit_197_64", mha_case(2, 197, 12, 64)),
           ("mha/vit_197_64_noprobs", mha_case(1, 197, 3, 64, probs=False)),
           ("mha/spike", mha_case(1, 197, 2, 64, spike=True)),
