@@ -152,6 +152,9 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
     // (clamped address), so that their HBM latency overlaps the whole main loop instead of forming a chain
     // of 8 dependent round trips at the end.
     const OutT* res = (const OutT*)p.residual;
+    ScaleShift8 ss[TN / 2];
+#pragma unroll
+    for (int c = 0; c < TN / 2; ++c) ss[c].load(p.scale, p.shift, n0 + c * 64 + (lane & 7) * 8, p.K);
     Res8<OutT> rres[TN / 2][4];
     if (res) {
 #pragma unroll
@@ -232,19 +235,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nl = a2 * 32 + 8 * g + 4 * fh;
-                const int n = n0 + c * 64 + nl;
                 float4 v = make_float4(acc[a][0][4 * g + 0], acc[a][0][4 * g + 1], acc[a][0][4 * g + 2],
                                        acc[a][0][4 * g + 3]);
-                if (n < p.K) {
-                    if (p.scale) {
-                        const float4 sc = *(const float4*)(p.scale + n);
-                        v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
-                    }
-                    if (p.shift) {
-                        const float4 sf = *(const float4*)(p.shift + n);
-                        v.x += sf.x; v.y += sf.y; v.z += sf.z; v.w += sf.w;
-                    }
-                }
                 *(float4*)(ep + fr * EPITCH + nl * 4) = v;
             }
         }
@@ -260,6 +252,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
             if (m < p.M && n < p.K) {
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 const long long o = (long long)m * p.K + n;
+                ss[c].apply(v);
                 if (res) rres[c][pass].add_to(v);
                 if (p.act == MV_ACT_RELU) {
 #pragma unroll
@@ -321,6 +314,8 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
     p.act = act;
     const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
     const bool out_f32 = out_dtype == MV_F32;
+    if (dense && !get_flag("no_stream") && !get_flag("igemm_tile") && stream1x1_supported(C, K, in_dtype, out_dtype, M))
+        return stream1x1_launch(x, w, scale, shift, residual, y, M, C, K, act, out_dtype, st);
     int tile = get_flag("igemm_tile");
     if (tile == 0) tile = (K <= 64) ? 2 : 1;
     if (tile == 2) {

@@ -54,4 +54,24 @@ template <> struct Out8<float> {
     }
 };
 
+// Per-lane epilogue constants for the row-major read-back phase: in every pass the lane owns channels
+// n .. n+7 (n = n0 + 64*chunk + 8*(lane%8)), so scale/shift for them are loaded ONCE, unconditionally
+// (clamped index), before the main loop -- never inside the per-tile epilogue, where hipcc would wrap each
+// conditional load in a branch + s_waitcnt vmcnt(0) (measured: ~16 serialised L2 round trips per tile).
+struct ScaleShift8 {
+    float sc[8], sh[8];
+    __device__ __forceinline__ void load(const float* scale, const float* shift, int n, int N) {
+        const int nn = (n + 8 <= N) ? n : 0;
+        float4 a = make_float4(1.f, 1.f, 1.f, 1.f), b = a, c = make_float4(0.f, 0.f, 0.f, 0.f), d = c;
+        if (scale) { a = *(const float4*)(scale + nn); b = *(const float4*)(scale + nn + 4); }
+        if (shift) { c = *(const float4*)(shift + nn); d = *(const float4*)(shift + nn + 4); }
+        sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+        sh[0] = c.x; sh[1] = c.y; sh[2] = c.z; sh[3] = c.w; sh[4] = d.x; sh[5] = d.y; sh[6] = d.z; sh[7] = d.w;
+    }
+    __device__ __forceinline__ void apply(float* v) const {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+    }
+};
+
 }  // namespace mv

@@ -235,6 +235,8 @@ __global__ __launch_bounds__(256) void stem_patch_kernel(const StemV1P p) {
     const int lbase = (py * p.sh) * p.PWp + px * p.sw;         // patch element offset of my window origin
     const TX* xg = (const TX*)p.x;
     const int HW = p.H * p.W;
+    ScaleShift8 ss;
+    ss.load(p.scale, p.shift, n0 + (lane & 7) * 8, p.K);
 
     for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
         const int tx = tile % p.tiles_x;
@@ -290,18 +292,7 @@ __global__ __launch_bounds__(256) void stem_patch_kernel(const StemV1P p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nl = a * 32 + 8 * g + 4 * fh;
-                const int n = n0 + nl;
                 float4 v = make_float4(acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3]);
-                if (n < p.K) {
-                    if (p.scale) {
-                        const float4 sc = *(const float4*)(p.scale + n);
-                        v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
-                    }
-                    if (p.shift) {
-                        const float4 sf = *(const float4*)(p.shift + n);
-                        v.x += sf.x; v.y += sf.y; v.z += sf.z; v.w += sf.w;
-                    }
-                }
                 *(float4*)(ep + fr * EPITCH + nl * 4) = v;
             }
 #pragma unroll
@@ -313,6 +304,7 @@ __global__ __launch_bounds__(256) void stem_patch_kernel(const StemV1P p) {
             const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
             if (oy < p.Ho && ox < p.Wo && n < p.K) {
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                ss.apply(v);
                 if (p.act == MV_ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -468,6 +460,10 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const PatchP p) {
         return c * HW + r * p.W + s0;
     };
 
+    ScaleShift8 ss[TN / 2];
+#pragma unroll
+    for (int c = 0; c < TN / 2; ++c) ss[c].load(p.scale, p.shift, n0 + c * 64 + (lane & 7) * 8, p.K);
+
     f32x16 acc[TN];
 #pragma unroll
     for (int a = 0; a < TN; ++a)
@@ -521,18 +517,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const PatchP p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nl = a2 * 32 + 8 * g + 4 * fh;
-                const int n = n0 + c * 64 + nl;
                 float4 v = make_float4(acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3]);
-                if (n < p.K) {
-                    if (p.scale) {
-                        const float4 sc = *(const float4*)(p.scale + n);
-                        v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
-                    }
-                    if (p.shift) {
-                        const float4 sf = *(const float4*)(p.shift + n);
-                        v.x += sf.x; v.y += sf.y; v.z += sf.z; v.w += sf.w;
-                    }
-                }
                 *(float4*)(ep + fr * EPITCH + nl * 4) = v;
             }
         }
@@ -545,6 +530,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const PatchP p) {
             const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
             if (mr < p.M && n < p.K) {
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                ss[c].apply(v);
                 long long orow = mr;
                 if (p.tok_stride > 0) {
                     const int pb = mr / P, pp = mr - pb * P;

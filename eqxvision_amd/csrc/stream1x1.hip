@@ -1,0 +1,235 @@
+// Weight-stationary streaming kernel for the memory-bound pointwise layers (1x1 stride-1 Conv2d and
+// Linear with a short reduction: K <= 256), gfx950.
+//
+//   y[m, n] = act( scale[n] * sum_k x[m, k] * w[n, k] + shift[n] + res[m, n] ),   k contiguous in x and w
+//
+// These layers (ResNet-50: 64->256, 256->64, 128->512, 256->1024 ... at 56x56 .. 14x14) move >100 bytes
+// per kFLOP: they are HBM-bound and were latency-starved in the tiled igemm kernel (2-3 TB/s): one k-tile
+// per block means load -> compute -> store phases in series with nothing else in flight.  Here
+//   * the block's weight slab W[BN][K] (<= 64 KB) is loaded into LDS ONCE and stays there;
+//   * every wave owns whole 32-pixel tiles: its x operand is needed by no other wave, so it never
+//     goes through LDS -- each lane loads its MFMA B-fragments (16 bytes) straight from HBM into VGPRs,
+//     double buffered one tile ahead; the residual row chunks of the tile are fetched before its MFMAs;
+//   * there is NO block barrier in the steady state: 8 waves per CU free-run over a grid-stride list of
+//     pixel tiles, so loads, MFMAs and stores of different waves overlap continuously;
+//   * the epilogue is the igemm one: fp32 scale/shift in the accumulator layout, transpose through a
+//     wave-private LDS patch, then 16-byte-per-lane full-line NHWC stores.
+#include "mfma_common.h"
+
+namespace mv {
+
+struct StreamP {
+    const bf16_t* x;
+    const bf16_t* w;
+    const float* scale;
+    const float* shift;
+    const void* residual;
+    void* y;
+    int M, K, N;          // rows, reduction, output channels
+    int tiles_m, act, wpitch;
+};
+
+template <typename OutT> struct SRes8;
+template <> struct SRes8<bf16_t> {
+    uint4 u;
+    __device__ __forceinline__ void load(const bf16_t* p) { u = *(const uint4*)p; }
+    __device__ __forceinline__ void add_to(float* v) const {
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] += __uint_as_float(w[e] << 16);
+            v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+        }
+    }
+};
+template <> struct SRes8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *(const float4*)p; b = *(const float4*)(p + 4); }
+    __device__ __forceinline__ void add_to(float* v) const {
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+};
+
+// TN = 32-channel MFMA tiles per wave (BN = 32*TN), KC = K/16 MFMA k-steps, WAVES per block.
+template <int TN, int KC, int WAVES, typename OutT>
+__global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) {
+    constexpr int BN = 32 * TN;
+    constexpr int EPITCH = 64 * 4 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wl = smem;                                            // [BN][wpitch]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* ep = smem + BN * p.wpitch + wave * (32 * EPITCH);     // wave-private epilogue patch
+    const int n0 = blockIdx.y * BN;
+    const int K = KC * 16;
+
+    // ---- weight slab -> LDS (once).  16-byte chunks, zero rows past N.
+    {
+        constexpr int CH = KC * 2;                              // 16-byte chunks per row
+        for (int base = 0; base < BN * CH; base += WAVES * 64 * 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = base + j * WAVES * 64 + tid;
+                const int row = i / CH, ch = i - row * CH;
+                const int n = n0 + row;
+                const bool ok = i < BN * CH && n < p.N;
+                v[j] = *(const uint4*)(p.w + (ok ? (long long)n * K + ch * 8 : 0));
+                if (!ok) v[j] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = base + j * WAVES * 64 + tid;
+                const int row = i / CH, ch = i - row * CH;
+                if (i < BN * CH) *(uint4*)(wl + row * p.wpitch + ch * 16) = v[j];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
+    OutT* y = (OutT*)p.y;
+    const OutT* res = (const OutT*)p.residual;
+    const char* wfrag = wl + fr * p.wpitch + fh * 16;           // + a*32*wpitch + kk*32
+
+    auto load_x = [&](uint4* xf, int tile) {
+        int m = tile * 32 + fr;
+        m = m < p.M ? m : p.M - 1;                              // clamp: rows past the end are never stored
+        const bf16_t* src = p.x + (long long)m * K + fh * 8;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) xf[kk] = *(const uint4*)(src + kk * 16);
+    };
+
+    ScaleShift8 ss[TN / 2];
+#pragma unroll
+    for (int c = 0; c < TN / 2; ++c) ss[c].load(p.scale, p.shift, n0 + c * 64 + (lane & 7) * 8, p.N);
+
+    auto load_res = [&](SRes8<OutT> (*rr)[4], int tile) {
+#pragma unroll
+        for (int c = 0; c < TN / 2; ++c)
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = tile * 32 + pass * 8 + (lane >> 3);
+                const int n = n0 + c * 64 + (lane & 7) * 8;
+                const bool ok = m < p.M && n < p.N;
+                rr[c][pass].load(res + (ok ? (long long)m * p.N + n : 0));
+            }
+    };
+
+    // ONE register set for the x fragments and ONE for the residual rows, each refilled for the next tile
+    // immediately after its last use: the x refill flies during the epilogue, the residual refill during
+    // the next tile's MFMAs.  (A second buffer would cost 64-128 VGPRs at K = 256 and halve the occupancy.)
+    uint4 xa[KC];
+    SRes8<OutT> rr[TN / 2][4];
+    int tile = gw;
+    if (tile < p.tiles_m) {
+        load_x(xa, tile);
+        if (res) load_res(rr, tile);
+    }
+    for (; tile < p.tiles_m; tile += nw) {
+        const int nxt = tile + nw;
+        f32x16 acc[TN];
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const uint4 av = *(const uint4*)(wfrag + a * 32 * p.wpitch + kk * 32);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                 __builtin_bit_cast(bf16x8, xa[kk]), acc[a], 0, 0, 0);
+            }
+        }
+        if (nxt < p.tiles_m) load_x(xa, nxt);                  // refill right after the last MFMA read them
+        // epilogue: accumulator layout -> LDS patch -> row-major full lines
+#pragma unroll
+        for (int c = 0; c < TN / 2; ++c) {
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2) {
+                const int a = 2 * c + a2;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = a2 * 32 + 8 * g + 4 * fh;
+                    float4 v = make_float4(acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3]);
+                    *(float4*)(ep + fr * EPITCH + nl * 4) = v;
+                }
+            }
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = pass * 8 + (lane >> 3), c8 = lane & 7;
+                const int m = tile * 32 + row;
+                const int n = n0 + c * 64 + c8 * 8;
+                const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
+                const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
+                if (m < p.M && n < p.N) {
+                    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    ss[c].apply(v);
+                    if (res) rr[c][pass].add_to(v);
+                    if (p.act == MV_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    } else if (p.act == MV_ACT_GELU_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                    }
+                    Out8<OutT>::st(y + (long long)m * p.N + n, v);
+                }
+            }
+        }
+        if (res && nxt < p.tiles_m) load_res(rr, nxt);
+    }
+}
+
+int stream1x1_supported(int C, int K, int in_dtype, int out_dtype, long long M) {
+    // C = reduction length, K = output channels (igemm naming)
+    return in_dtype == MV_BF16 && (out_dtype == MV_BF16 || out_dtype == MV_F32) && (C == 64 || C == 128 || C == 256) &&
+           K % 8 == 0 && M >= 8192;
+}
+
+template <int TN, int KC, typename OutT>
+static int stream_go(const StreamP& p, int tiles_n, hipStream_t st) {
+    constexpr int WAVES = 8;
+    const size_t smem = (size_t)32 * TN * p.wpitch + (size_t)WAVES * 32 * (64 * 4 + 16);
+    int gx = 256 / tiles_n;                                   // ~one block per CU in total
+    if (gx < 1) gx = 1;
+    const int need = (p.tiles_m + WAVES - 1) / WAVES;
+    if (gx > need) gx = need;
+    dim3 grid(gx, tiles_n), block(WAVES * 64);
+    auto kern = stream1x1_kernel<TN, KC, WAVES, OutT>;
+    if (smem > 48 * 1024)
+        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, grid, block, smem, st, p);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int stream1x1_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
+                     void* y, long long M, int C, int K, int act, int out_dtype, hipStream_t st) {
+    StreamP p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.M = (int)M; p.K = C; p.N = K;
+    p.tiles_m = (int)((M + 31) / 32);
+    p.act = act;
+    p.wpitch = C * 2 + 16;                                     // odd number of 16-byte slots: conflict-free fragments
+    const bool f32o = out_dtype == MV_F32;
+    const int bn = (K <= 64) ? 64 : 128;
+    const int tiles_n = (K + bn - 1) / bn;
+    char name[64];
+    snprintf(name, sizeof(name), "stream1x1_bf16_bn%d_k%d", bn, C);
+    set_kernel_name(name);
+#define GO(TN_, KC_)                                                              \
+    return f32o ? stream_go<TN_, KC_, float>(p, tiles_n, st) : stream_go<TN_, KC_, bf16_t>(p, tiles_n, st)
+    if (bn == 64) {
+        if (C == 64) GO(2, 4);
+        if (C == 128) GO(2, 8);
+        GO(2, 16);
+    }
+    if (C == 64) GO(4, 4);
+    if (C == 128) GO(4, 8);
+    GO(4, 16);
+#undef GO
+}
+
+}  // namespace mv

@@ -458,7 +458,14 @@ def all_cases():
           ("igemm/1x1_M1", conv_nhwc_case(1, 1, 1, 2048, 1000, 1, 1, out="fp32")),
           ("igemm/gelu", conv_nhwc_case(1, 8, 8, 128, 128, 1, 1, act=2)),
           ("igemm/big_M", conv_nhwc_case(8, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=3))]
-    c += [("linear/vit_qkv", linear_case(197 * 2, 768, 2304)),
+    c += [("stream/64_256_res", conv_nhwc_case(4, 56, 56, 64, 256, 1, 1, act=1, res=True)),
+          ("stream/256_64", conv_nhwc_case(4, 56, 56, 256, 64, 1, 1, act=1)),
+          ("stream/128_512_res", conv_nhwc_case(16, 28, 28, 128, 512, 1, 1, act=1, res=True, seed=2)),
+          ("stream/256_1024_oddM", conv_nhwc_case(47, 14, 14, 256, 1024, 1, 1, act=1, res=True, seed=3)),
+          ("stream/64_64_noscale", conv_nhwc_case(3, 56, 56, 64, 64, 1, 1, scale=False)),
+          ("stream/linear_f32out_res", linear_case(9000, 128, 200, res=True, out="fp32")),
+          ("stream/gelu_N72", linear_case(8200, 64, 72, act=2)),
+          ("linear/vit_qkv", linear_case(197 * 2, 768, 2304)),
           ("linear/vit_fc1_gelu", linear_case(197 * 2, 768, 3072, act=2)),
           ("linear/vit_fc2_res", linear_case(197 * 2, 3072, 768, res=True)),
           ("linear/fc_f32out", linear_case(256, 2048, 1000, out="fp32")),
