@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+    int tile_m, tile_n;
+    tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---------------- staging constants -------------------------------------------------------
@@ -316,6 +317,12 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
     const bool out_f32 = out_dtype == MV_F32;
     if (dense && !get_flag("no_stream") && !get_flag("igemm_tile") && stream1x1_supported(C, K, in_dtype, out_dtype, M))
         return stream1x1_launch(x, w, scale, shift, residual, y, M, C, K, act, out_dtype, st);
+    // deep-pipelined 8-wave kernel: every real convolution (taps or stride) and the big Linears; the
+    // short dense 1x1 layers late in the network (M <= 50k) measured the same or faster on the 128^2 kernel
+    const bool want2 = igemm2_wanted(M, C, K, R, S) && (!dense || M >= 32768 || get_flag("igemm2_tile"));
+    if (!get_flag("no_igemm2") && !get_flag("igemm_tile") && want2)
+        return igemm2_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act,
+                             out_dtype, st);
     int tile = get_flag("igemm_tile");
     if (tile == 0) tile = (K <= 64) ? 2 : 1;
     if (tile == 2) {

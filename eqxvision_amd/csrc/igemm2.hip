@@ -1,0 +1,384 @@
+// Deep-pipelined implicit GEMM for the compute-bound layers (3x3 convolutions, ViT / Swin Linears),
+// gfx950.  Same math, operand layouts and epilogue as igemm.hip; what changes is the pipeline:
+//
+//  * 512 threads = 8 waves (2 per SIMD), block tile 256 pixels x 128 (or 64) channels, k-tile 64.
+//  * an S = 3 stage LDS ring filled by LDS-DMA (`global_load_lds_dwordx4`): the DMA for k-tile t+2 is
+//    issued while tile t is being multiplied, so ~2 tile-times (~2000 cycles) of HBM/L2 latency are
+//    covered.  The 128^2 kernel prefetched ONE tile ahead (~500 cycles): measured 25% MFMA utilisation.
+//  * hipcc cannot express this: it makes every ds_read that follows an LDS-DMA wait for vmcnt(0) and
+//    drains the queue at __syncthreads().  So the steady state uses
+//        - `s_waitcnt vmcnt(N)` with a COUNTED N (inline asm): only the oldest tile has to have landed,
+//        - raw `s_barrier`,
+//        - inline-asm `ds_read_b128` for the MFMA fragments (invisible to the compiler's LDS-DMA alias
+//          check) with hand-counted `lgkmcnt`, software-pipelined one k16-step ahead of the MFMAs;
+//          every wait names the fragment registers it guards as "+v" operands so no MFMA can be
+//          scheduled above it (cdna_hip_programming.md section 5.7).
+//  * vmcnt counts in issue order, so the residual / scale / shift prefetch issued before the ring is
+//    always older than any DMA and never disturbs the counts; there are no stores before the epilogue.
+#include "mfma_common.h"
+
+namespace mv {
+
+struct Igemm2P {
+    const bf16_t* x;
+    const bf16_t* w;
+    const float* scale;
+    const float* shift;
+    const void* residual;
+    void* y;
+    const bf16_t* zero;
+    int N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw;
+    int M, tiles_m, tiles_n, act;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int IMM> __device__ __forceinline__ void lds_read16(u32x4& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename OutT> struct R8;
+template <> struct R8<bf16_t> {
+    uint4 u;
+    __device__ __forceinline__ void load(const bf16_t* p) { u = *(const uint4*)p; }
+    __device__ __forceinline__ void add_to(float* v) const {
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] += __uint_as_float(w[e] << 16);
+            v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+        }
+    }
+};
+template <> struct R8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *(const float4*)p; b = *(const float4*)(p + 4); }
+    __device__ __forceinline__ void add_to(float* v) const {
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+};
+
+// WM x WN waves (= 8), each TM x TN tiles of 32x32.  BM = 32*TM*WM pixels, BN = 32*TN*WN channels (TN*32 = 64).
+// NST = LDS ring depth (3 for the 256x128 / 256x64 tiles, 2 for 256x256 whose k-tile alone lasts ~2000
+// cycles); RESPF = prefetch the residual rows before the main loop (needs TM*4 16-byte registers).
+template <int WM, int WN, int TM, int TN, int NST, bool RESPF, typename OutT>
+__global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int ROWB = 128;
+    constexpr int XI = BM / 64, WI = BN / 64;            // DMA instructions per thread per k-tile (8 waves x 8 rows)
+    constexpr int L = XI + WI;
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int EPITCH = 64 * 4 + 16;
+    static_assert(WM * WN == 8 && TN == 2, "8 waves; a wave covers 64 channels (one 128-byte output line)");
+    static_assert(8 * 32 * EPITCH <= NST * STAGE, "epilogue patches must fit");
+    static_assert((NST - 1) * L <= 63, "vmcnt immediate");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    int tile_m, tile_n;
+    tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---------------- DMA addressing -------------------------------------------------------------------
+    // Per staged row: ONE 64-bit element offset of the tap-(0,0), channel-0 source and a bit mask of the
+    // filter taps that fall inside the image, both computed once.  Per k-tile the source of a lane is
+    // then `valid_bit ? x + base + tapdelta : zero_page` with a wave-uniform tapdelta: ~7 VALU per DMA
+    // instead of re-deriving (hi, wi), two range checks and a 64-bit multiply chain every k-tile.
+    const int srow = lane >> 3;
+    const int chunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+    const int cpt = p.C >> 6;
+    const int nk = p.R * p.S * cpt;
+    const long long wrow_stride = (long long)p.R * p.S * p.C;
+    long long xbase[XI];
+    unsigned vlo[XI], vhi[XI];
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+        const int m = m0 + 8 * (wave + 8 * j) + srow;
+        const bool valid = m < p.M;
+        const int wo = m % p.Wo;
+        const int tt = m / p.Wo;
+        const int ho = tt % p.Ho;
+        const int b = tt / p.Ho;
+        const int hi0 = ho * p.sh - p.ph, wi0 = wo * p.sw - p.pw;
+        xbase[j] = (((long long)b * p.H + hi0) * p.W + wi0) * p.C + chunk * 8;
+        unsigned long long mask = 0;
+        if (valid) {
+            for (int r = 0; r < p.R; ++r) {
+                const int hi = hi0 + r * p.dh;
+                if ((unsigned)hi >= (unsigned)p.H) continue;
+                for (int s = 0; s < p.S; ++s) {
+                    const int wi = wi0 + s * p.dw;
+                    if ((unsigned)wi < (unsigned)p.W) mask |= 1ull << (r * p.S + s);
+                }
+            }
+        }
+        vlo[j] = (unsigned)mask;
+        vhi[j] = (unsigned)(mask >> 32);
+    }
+    long long woff[WI];
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+        const int n = n0 + 8 * (wave + 8 * j) + srow;
+        woff[j] = n < p.K ? (long long)n * wrow_stride + chunk * 8 : -1;
+    }
+    auto stage = [&](int buf, int r, int s, int c0) {
+        char* xs = smem + buf * STAGE;
+        char* ws = xs + BM * ROWB;
+        const int tp = r * p.S + s;                                          // wave-uniform
+        const long long tapdelta = ((long long)(r * p.dh) * p.W + s * p.dw) * p.C + c0;
+        const int tapoff = tp * p.C + c0;
+        const bf16_t* xt = p.x + tapdelta;
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            const unsigned bits = tp < 32 ? vlo[j] : vhi[j];
+            const bool ok = (bits >> (tp & 31)) & 1u;
+            const bf16_t* src = ok ? xt + xbase[j] : p.zero;
+            glds16(src, xs + 8 * (wave + 8 * j) * ROWB);
+        }
+#pragma unroll
+        for (int j = 0; j < WI; ++j) {
+            const bf16_t* src = woff[j] >= 0 ? p.w + woff[j] + tapoff : p.zero;
+            glds16(src, ws + 8 * (wave + 8 * j) * ROWB);
+        }
+    };
+
+    // ---------------- fragment addressing ------------------------------------------------------------
+    const int wm = wave % WM, wn = wave / WM;
+    const int fr = lane & 31, fh = lane >> 5, swz = (fr >> 1) & 7;
+    const int xrow0 = wm * (32 * TM), wrow0 = wn * (32 * TN);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned xaddr[4], waddr[4];     // per k16-step: byte address of my 16-byte fragment in stage 0
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const unsigned ko = (unsigned)(((2 * kk + fh) ^ swz) << 4);
+        xaddr[kk] = lds0 + (xrow0 + fr) * ROWB + ko;
+        waddr[kk] = lds0 + BM * ROWB + (wrow0 + fr) * ROWB + ko;
+    }
+
+    // ---------------- epilogue constants + residual prefetch (older than every DMA) --------------------
+    const OutT* res = (const OutT*)p.residual;
+    ScaleShift8 ss;
+    ss.load(p.scale, p.shift, n0 + wrow0 + (lane & 7) * 8, p.K);
+    R8<OutT> rres[RESPF ? TM : 1][4];
+    if (RESPF && res) {
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = m0 + xrow0 + b * 32 + pass * 8 + (lane >> 3);
+                const int n = n0 + wrow0 + (lane & 7) * 8;
+                const bool ok = m < p.M && n < p.K;
+                rres[b][pass].load(res + (ok ? (long long)m * p.K + n : 0));
+            }
+    }
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    // ---------------- ring prologue: tiles 0 .. NST-2 ----------------------------------------------------
+    int r = 0, s = 0, c0 = 0;
+    auto advance = [&]() {
+        c0 += 64;
+        if (c0 == p.C) {
+            c0 = 0;
+            if (++s == p.S) {
+                s = 0;
+                ++r;
+            }
+        }
+    };
+    int issued = 0;
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) {
+        if (issued < nk) {
+            stage(i, r, s, c0);
+            advance();
+            ++issued;
+        }
+    }
+
+    // ---------------- main loop ---------------------------------------------------------------------------
+    int cur = 0;
+    for (int it = 0; it < nk; ++it) {
+        // tile `it` must have landed; younger tiles (at most NST-2) may stay in flight
+        const int younger = issued - it - 1;
+        if (NST > 2 && younger >= NST - 2) wait_vm<(NST > 2 ? (NST - 2) * L : 0)>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        // Refill the stage everyone just left with tile it+NST-1.  The two waves of a SIMD run this
+        // (VALU/SALU address work + DMA issue) at OPPOSITE ends of the iteration: waves 0-3 before their
+        // MFMAs, waves 4-7 after, so one wave's address phase overlaps its partner's MFMA phase instead of
+        // both idling the matrix pipe together right after the barrier.  vmcnt accounting is unchanged
+        // (the refill is still the newest L operations when the next iteration's wait executes).
+        const bool refill = issued < nk;
+        int rbuf = cur + NST - 1;
+        if (rbuf >= NST) rbuf -= NST;
+        if (refill && wave < 4) stage(rbuf, r, s, c0);
+        const unsigned sb = (unsigned)(cur * STAGE);
+        u32x4 af[2][TN], bfm[2][TM];
+        auto read_step = [&](int set, int kk) {
+            lds_read16<0>(af[set][0], waddr[kk] + sb);
+            lds_read16<32 * ROWB>(af[set][1], waddr[kk] + sb);
+            lds_read16<0>(bfm[set][0], xaddr[kk] + sb);
+            if constexpr (TM >= 2) lds_read16<32 * ROWB>(bfm[set][1], xaddr[kk] + sb);
+            if constexpr (TM >= 3) lds_read16<64 * ROWB>(bfm[set][2], xaddr[kk] + sb);
+            if constexpr (TM >= 4) lds_read16<96 * ROWB>(bfm[set][3], xaddr[kk] + sb);
+        };
+        auto wait_step = [&](int set, bool last) {
+            // the TN+TM reads of this step are done once at most TN+TM younger ones remain in flight;
+            // naming the fragments as "+v" operands pins every consumer MFMA below the wait
+            if constexpr (TM == 1) {
+                if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[set][0]), "+v"(af[set][1]), "+v"(bfm[set][0]));
+                else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(af[set][0]), "+v"(af[set][1]), "+v"(bfm[set][0]));
+            } else if constexpr (TM == 2) {
+                if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[set][0]), "+v"(af[set][1]), "+v"(bfm[set][0]), "+v"(bfm[set][1]));
+                else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[set][0]), "+v"(af[set][1]), "+v"(bfm[set][0]), "+v"(bfm[set][1]));
+            } else {
+                static_assert(TM == 4, "TM in {1,2,4}");
+                if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[set][0]), "+v"(af[set][1]), "+v"(bfm[set][0]), "+v"(bfm[set][1]), "+v"(bfm[set][2]), "+v"(bfm[set][3]));
+                else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[set][0]), "+v"(af[set][1]), "+v"(bfm[set][0]), "+v"(bfm[set][1]), "+v"(bfm[set][2]), "+v"(bfm[set][3]));
+            }
+        };
+        read_step(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int cs = kk & 1, ns = cs ^ 1;
+            if (kk < 3) read_step(ns, kk + 1);
+            wait_step(cs, kk == 3);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[cs][a]),
+                                                                        __builtin_bit_cast(bf16x8, bfm[cs][b]),
+                                                                        acc[a][b], 0, 0, 0);
+        }
+        if (refill && wave >= 4) stage(rbuf, r, s, c0);
+        if (refill) {
+            advance();
+            ++issued;
+        }
+        if (++cur == NST) cur = 0;
+    }
+
+    // ---------------- epilogue (as igemm.hip: LDS transpose, full-line stores) ------------------------------
+    __syncthreads();
+    char* ep = smem + wave * (32 * EPITCH);
+    OutT* y = (OutT*)p.y;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        R8<OutT> late[4];                 // no prefetch: fetch this pixel tile's 4 residual rows together
+        if (!RESPF && res) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = m0 + xrow0 + b * 32 + pass * 8 + (lane >> 3);
+                const int n = n0 + wrow0 + (lane & 7) * 8;
+                const bool ok = m < p.M && n < p.K;
+                late[pass].load(res + (ok ? (long long)m * p.K + n : 0));
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = a * 32 + 8 * g + 4 * fh;
+                *(float4*)(ep + fr * EPITCH + nl * 4) = make_float4(acc[a][b][4 * g + 0], acc[a][b][4 * g + 1],
+                                                                     acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
+            }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + (lane >> 3), c8 = lane & 7;
+            const int m = m0 + xrow0 + b * 32 + row;
+            const int n = n0 + wrow0 + c8 * 8;
+            const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
+            const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
+            if (m < p.M && n < p.K) {
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                ss.apply(v);
+                if (res) {
+                    if constexpr (RESPF) rres[b][pass].add_to(v);
+                    else late[pass].add_to(v);
+                }
+                if (p.act == MV_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (p.act == MV_ACT_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                }
+                Out8<OutT>::st(y + (long long)m * p.K + n, v);
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int NST, bool RESPF>
+static int launch2(Igemm2P& p, bool out_f32, hipStream_t st) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int SMEM = NST * (BM + BN) * 128;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.K + BN - 1) / BN;
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(512);
+#define GO(OT)                                                                                                   \
+    do {                                                                                                         \
+        auto kern = igemm2_kernel<WM, WN, TM, TN, NST, RESPF, OT>;                                               \
+        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));        \
+        hipLaunchKernelGGL(kern, grid, block, SMEM, st, p);                                                      \
+    } while (0)
+    if (out_f32) GO(float); else GO(bf16_t);
+#undef GO
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int igemm2_wanted(long long M, int C, int K, int R, int S) {
+    // worth it once there is enough work to fill the chip with 256-row tiles and a reduction of >= 4 k-tiles
+    const long long ktiles = (long long)R * S * (C / 64);
+    (void)K;
+    return M >= 4096 && ktiles >= 4 && R * S <= 64;
+}
+
+int igemm2_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y,
+                  int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
+                  int act, int out_dtype, hipStream_t st) {
+    Igemm2P p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.zero = (const bf16_t*)zero_page(st);
+    if (!p.zero) {
+        set_error("igemm2: zero page allocation failed");
+        return MV_E_OOM;
+    }
+    p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S;
+    p.Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1;
+    p.Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
+    p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw;
+    p.M = (int)((long long)N * p.Ho * p.Wo);
+    p.act = act;
+    const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
+    const bool out_f32 = out_dtype == MV_F32;
+    int tile = get_flag("igemm2_tile");          // 0 auto, 1 = 256x64, 2 = 256x128, 3 = 256x256
+    if (tile == 0) {
+        const long long big_tiles = ((p.M + 255) / 256) * (long long)((K + 255) / 256);
+        tile = K <= 64 ? 1 : ((K >= 1024 && big_tiles >= 512) ? 3 : 2);
+    }
+    if (tile == 1) {
+        set_kernel_name(dense ? "igemm2_bf16_256x64_dense" : "igemm2_bf16_256x64_conv");
+        return launch2<8, 1, 1, 2, 3, true>(p, out_f32, st);
+    }
+    if (tile == 3) {
+        set_kernel_name(dense ? "igemm2_bf16_256x256_dense" : "igemm2_bf16_256x256_conv");
+        return launch2<2, 4, 4, 2, 2, false>(p, out_f32, st);
+    }
+    set_kernel_name(dense ? "igemm2_bf16_256x128_dense" : "igemm2_bf16_256x128_conv");
+    return launch2<4, 2, 2, 2, 3, true>(p, out_f32, st);
+}
+
+}  // namespace mv

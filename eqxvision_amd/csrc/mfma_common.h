@@ -20,6 +20,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// tile-list order inside an XCD: groups of GM pixel tiles; inside a group the channel tile is the
+// slow index.  The ~32 blocks an XCD runs concurrently then form a (GM pixel tiles) x (32/GM channel
+// tiles) patch: every x tile is shared by 32/GM blocks and every weight tile by GM blocks out of the
+// XCD's 4 MB L2, instead of streaming all weight tiles through it for every pixel tile.
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+    constexpr int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int group = t / per_group, r = t - group * per_group;
+    const int gm0 = group * GM;
+    const int gsize = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
+    tile_n = r / gsize;
+    tile_m = gm0 + (r - tile_n * gsize);
+}
+
 template <typename OutT> struct Out4;
 template <> struct Out4<bf16_t> {
     __device__ static __forceinline__ float4 ld(const void* p) {

@@ -423,7 +423,8 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const PatchP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+    int tile_m, tile_n;
+    tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n);
     const int m0 = tile_m * 128, n0 = tile_n * BN;
     const int fr = lane & 31, fh = lane >> 5, swz = (fr >> 1) & 7;
 

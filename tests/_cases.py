@@ -62,7 +62,7 @@ DT = {"bf16": 1, "fp32": 0}
 
 # --------------------------------------------------------------------------------------------
 def conv_nhwc_case(N, H, W, C, K, R, S, stride=1, pad=0, dil=1, groups=1, act=0, res=False, scale=True,
-                   dtype="bf16", out="same", generic=False, seed=0, tile=0):
+                   dtype="bf16", out="same", generic=False, seed=0, tile=0, flags=()):
     def run():
         L = _lib()
         rng = _rng(seed)
@@ -94,6 +94,8 @@ def conv_nhwc_case(N, H, W, C, K, R, S, stride=1, pad=0, dil=1, groups=1, act=0,
         y = torch.empty((N, Ho, Wo, K), dtype=torch.bfloat16 if odt == "bf16" else torch.float32, device="cuda")
         L.set_flag("force_generic", 1 if generic else 0)
         L.set_flag("igemm_tile", tile)
+        for f in flags:
+            L.set_flag(f.split("=")[0], int(f.split("=")[1]) if "=" in f else 1)
         try:
             L.call("mv_conv2d_nhwc_fwd", xd.data_ptr(), wd.data_ptr(), None if scd is None else scd.data_ptr(),
                    sfd.data_ptr(), None if rd is None else rd.data_ptr(), y.data_ptr(),
@@ -102,6 +104,8 @@ def conv_nhwc_case(N, H, W, C, K, R, S, stride=1, pad=0, dil=1, groups=1, act=0,
         finally:
             L.set_flag("force_generic", 0)
             L.set_flag("igemm_tile", 0)
+            for f in flags:
+                L.set_flag(f.split("=")[0], 0)
         torch.cuda.synchronize()
         got = host(y).transpose(0, 3, 1, 2)
         info = _cmp(got, ref, TOL_BF16 if odt == "bf16" else TOL_F32)
@@ -458,7 +462,23 @@ def all_cases():
           ("igemm/1x1_M1", conv_nhwc_case(1, 1, 1, 2048, 1000, 1, 1, out="fp32")),
           ("igemm/gelu", conv_nhwc_case(1, 8, 8, 128, 128, 1, 1, act=2)),
           ("igemm/big_M", conv_nhwc_case(8, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=3))]
-    c += [("stream/64_256_res", conv_nhwc_case(4, 56, 56, 64, 256, 1, 1, act=1, res=True)),
+    c += [("igemm2/3x3_128_28", conv_nhwc_case(8, 28, 28, 128, 128, 3, 3, pad=1, act=1, seed=11)),
+          ("igemm2/3x3_64_56_bn64", conv_nhwc_case(2, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=12)),
+          ("igemm2/3x3_256_s2", conv_nhwc_case(24, 28, 28, 256, 256, 3, 3, stride=2, pad=1, act=1, seed=13)),
+          ("igemm2/1x1_512_128", conv_nhwc_case(8, 28, 28, 512, 128, 1, 1, act=1, seed=14)),
+          ("igemm2/1x1_256_512_s2", conv_nhwc_case(8, 56, 56, 256, 512, 1, 1, stride=2, seed=15)),
+          ("igemm2/1x1_1024_256_res", conv_nhwc_case(24, 14, 14, 1024, 256, 1, 1, act=1, res=True, seed=16)),
+          ("igemm2/3x3_K192_tail", conv_nhwc_case(5, 29, 31, 64, 192, 3, 3, pad=1, act=1, seed=17)),
+          ("igemm2/3x3_dil2_oddM", conv_nhwc_case(3, 37, 41, 128, 128, 3, 3, pad=2, dil=2, seed=18)),
+          ("igemm2/5x5", conv_nhwc_case(6, 27, 27, 64, 192, 5, 5, pad=2, act=1, scale=False, seed=19)),
+          ("igemm2/t256_3x3_256", conv_nhwc_case(40, 14, 14, 256, 256, 3, 3, pad=1, act=1, res=True, seed=31, flags=("igemm2_tile=3",))),
+          ("igemm2/t256_1x1_768_512_tail", conv_nhwc_case(3, 41, 43, 768, 512, 1, 1, act=2, seed=32, flags=("igemm2_tile=3",))),
+          ("igemm2/t256_3x3_s2_K320", conv_nhwc_case(9, 33, 35, 128, 320, 3, 3, stride=2, pad=1, seed=33, flags=("igemm2_tile=3",))),
+          ("igemm2/t256_f32out_res", conv_nhwc_case(30, 14, 14, 512, 256, 1, 1, res=True, out="fp32", seed=34, flags=("igemm2_tile=3",))),
+          ("igemm2/t64_forced_K128", conv_nhwc_case(6, 28, 28, 128, 128, 3, 3, pad=1, seed=35, flags=("igemm2_tile=1",))),
+          ("igemm/old_kernel_3x3_128_28", conv_nhwc_case(8, 28, 28, 128, 128, 3, 3, pad=1, act=1, seed=11, flags=("no_igemm2",))),
+          ("igemm/old_kernel_1x1_64_256", conv_nhwc_case(4, 56, 56, 64, 256, 1, 1, act=1, res=True, flags=("no_stream",))),
+          ("stream/64_256_res", conv_nhwc_case(4, 56, 56, 64, 256, 1, 1, act=1, res=True)),
           ("stream/256_64", conv_nhwc_case(4, 56, 56, 256, 64, 1, 1, act=1)),
           ("stream/128_512_res", conv_nhwc_case(16, 28, 28, 128, 512, 1, 1, act=1, res=True, seed=2)),
           ("stream/256_1024_oddM", conv_nhwc_case(47, 14, 14, 256, 1024, 1, 1, act=1, res=True, seed=3)),
