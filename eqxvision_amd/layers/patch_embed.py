@@ -35,13 +35,19 @@ class PatchEmbed(Module):
         self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
 
     def _check(self, x):
-        C, H, W = x.shape
+        shp = tuple(x.shape)
+        if len(shp) != 3:
+            raise ValueError(f"PatchEmbed expects (in_chans, H, W), got {shp}")
+        C, H, W = shp
         if H != self.img_size[0] or W != self.img_size[1]:           # reference :74-77
             raise ValueError(f"Input image height ({H},{W}) doesn't match model ({self.img_size}).")
 
-    @boundary
     def __call__(self, x, *, key=None):
-        self._check(x)
+        self._check(x)            # shape error first, like the reference (:74-77) -- no device needed
+        return self._forward(x)
+
+    @boundary
+    def _forward(self, x):
         if self.flatten and x.kind == "img":
             t = ops.patch_embed_tokens(x, self.proj, None, None, 0)
         else:

@@ -47,10 +47,13 @@ class AlexNet(Module):
             nn.Linear(4096, num_classes, key=k[7]),
         ])
 
-    @boundary
     def __call__(self, x, *, key):
         if key is None:                                  # reference :78-79
             raise RuntimeError("The model requires a PRNGKey.")
+        return self._forward(x)
+
+    @boundary
+    def _forward(self, x):
         x = self.features(x)
         x = self.avgpool(x)
         x = ops.flatten(x)                               # jnp.ravel in CHW order (reference :83)

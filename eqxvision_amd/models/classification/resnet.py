@@ -175,10 +175,13 @@ class ResNet(Module):
                                dilation=self.dilation, norm_layer=norm_layer, key=keys[i + 1]))
         return nn.Sequential(stack)
 
-    @boundary
     def __call__(self, x, *, key):                            # reference :335-358
         if key is None:
             raise RuntimeError("The model requires a PRNGKey.")
+        return self._forward(x)
+
+    @boundary
+    def _forward(self, x):
         x = ops.conv2d(x, self.conv1, self.bn1, "relu")       # stem straight from the NCHW image
         x = self.maxpool(x)
         x = self.layer1(x)

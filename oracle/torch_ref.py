@@ -17,7 +17,13 @@ import torch.nn.functional as F
 
 
 def _t(sd):
-    return {k: torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v for k, v in sd.items()}
+    out = {}
+    for k, v in sd.items():
+        t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
+        if isinstance(t, torch.Tensor) and t.dim() == 3 and tuple(t.shape[1:]) == (1, 1):
+            t = t.reshape(-1)            # equinox stores conv biases as (C,1,1); torch wants (C,)
+        out[k] = t
+    return out
 
 
 def _bn(sd, x, name):

@@ -1,0 +1,155 @@
+"""CPU: host-side mirror of the reference's module surface -- pytree order (the load_torch_weights
+contract), constructors, mode switches and error behaviour.  No GPU needed."""
+import os
+import tempfile
+import warnings
+from functools import partial
+
+import numpy as np
+import pytest
+
+import eqxvision_amd as eqv
+from eqxvision_amd import nn
+from oracle import state as S
+
+
+def _keys(sd):
+    return [k for k in sd.keys() if "num_batches" not in k]
+
+
+@pytest.mark.parametrize("factory,state", [
+    (lambda: eqv.models.alexnet(), lambda: S.alexnet_state(1)),
+    (lambda: eqv.models.resnet50(), lambda: S.resnet_state(1)),
+    (lambda: eqv.models.resnet18(), lambda: S.resnet_state(1, "basic", (2, 2, 2, 2))),
+    (lambda: eqv.models.vit_base(num_classes=1000), lambda: S.vit_state(1)),
+    (lambda: eqv.models.vit_small(), lambda: S.vit_state(1, embed_dim=384, num_heads=6, num_classes=0)),
+])
+def test_pytree_order_is_torchvision_registration_order(factory, state):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = factory()
+    sd = state()
+    # a model exported with utils.state_dict lists its leaves in flatten order: must equal the checkpoint order
+    model = eqv.utils.randomize_batchnorm(model)
+    mine = eqv.utils.state_dict(model)
+    assert list(mine.keys()) == _keys(sd)
+    for k in mine:
+        assert mine[k].size == np.asarray(sd[k]).size, k
+
+
+def test_load_torch_weights_roundtrip_and_bn_state():
+    sd = S.resnet_state(3, "bottleneck", (1, 1, 1, 1), 7)
+    blk = eqv.models.classification.resnet._ResNetBottleneck
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "w.pth")
+        S.save_pth(sd, p)
+        net = eqv.models.classification.resnet._resnet(blk, [1, 1, 1, 1], p, num_classes=7)
+    out = eqv.utils.state_dict(net)
+    for k in _keys(sd):
+        np.testing.assert_array_equal(out[k].reshape(-1), np.asarray(sd[k]).reshape(-1))
+    assert net.conv1.bias is None and net.bn1.first_time_index.value is False
+    assert net.layer1.layers[0].downsample.layers[1].state_index.value[0].shape == (256,)
+    with pytest.raises(ValueError):
+        eqv.utils.load_torch_weights(net, None)
+    # too few tensors in the checkpoint -> loud error, not silent truncation
+    short = dict(list(sd.items())[:5])
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "s.pth")
+        S.save_pth(short, p)
+        with pytest.raises(ValueError):
+            eqv.utils.load_torch_weights(eqv.models.resnet18(), p)
+
+
+def test_swin_checkpoint_overwrites_relative_position_index():
+    sd = S.swin_state(1, (4, 4), 32, (2, 2), (2, 4), (7, 7), 4.0, 10)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net = eqv.models.SwinTransformer(patch_size=[4, 4], embed_dim=32, depths=[2, 2], num_heads=[2, 4],
+                                         window_size=[7, 7], num_classes=10)
+    attn = net.features.layers[1].layers[0].attn
+    # reference quirk (swin.py:314-335): random-init index is relative_coords.sum(-1) in [-12, 12]
+    assert attn.relative_position_index.min() == -12 and attn.relative_position_index.max() == 12
+    assert np.all(attn.relative_position_bias_table == 2.0)          # truncated_normal(2, 2) quirk
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "w.pth")
+        S.save_pth(sd, p)
+        net2 = eqv.utils.load_torch_weights(net, p)
+    idx = net2.features.layers[1].layers[0].attn.relative_position_index
+    assert idx.min() == 0 and idx.max() == 168
+    b = net2.features.layers[1].layers[0].attn.get_relative_position_bias()
+    assert b.shape == (2, 49, 49)
+    red = net2.features.layers[2]
+    assert type(red).__name__ == "_PatchMerging" and red.reduction.weight.shape == (64, 128) and red.reduction.bias is None
+
+
+def test_tree_inference_flips_every_inference_field_and_copies():
+    v = eqv.models.vit_tiny(num_classes=10, drop_path_rate=0.1)
+    assert v.inference is False and v.blocks[3].drop_path.inference is False
+    vi = eqv.tree_inference(v, True)
+    assert vi.inference and vi.blocks[3].drop_path.inference and vi.blocks[0].attn.attn_drop.inference
+    assert v.inference is False                                        # original untouched (immutable pytrees)
+    assert vi.blocks[0].attn.qkv.weight is v.blocks[0].attn.qkv.weight  # leaves shared
+    r = eqv.tree_inference(eqv.models.resnet18(), True)
+    assert r.bn1.inference and r.layer2.layers[0].downsample.layers[1].inference
+    assert isinstance(v.blocks[0].drop_path, nn.Identity) and isinstance(v.blocks[5].drop_path.p, float)
+
+
+def test_reference_error_behaviour_without_gpu():
+    x = np.zeros((3, 64, 64), np.float32)
+    with pytest.raises(RuntimeError, match="PRNGKey"):
+        eqv.models.resnet18()(x, key=None)                             # resnet.py:341-342
+    with pytest.raises(RuntimeError, match="PRNGKey"):
+        eqv.models.alexnet()(x, key=None)                              # alexnet.py:78-79
+    with pytest.raises(ValueError, match="doesn't match model"):
+        eqv.layers.PatchEmbed()(x)                                     # patch_embed.py:74-77
+    with pytest.raises(NotImplementedError):
+        eqv.models.ResNet(eqv.models.classification.resnet._ResNetBottleneck, [1, 1, 1, 1], norm_layer=nn.LayerNorm)
+    with pytest.raises(ValueError):
+        eqv.models.ResNet(eqv.models.classification.resnet._ResNetBottleneck, [1, 1, 1, 1],
+                          replace_stride_with_dilation=[True])
+    with pytest.raises(ValueError):
+        eqv.models.classification.resnet._ResNetBasicBlock(64, 64, groups=2, key=eqv.random.PRNGKey(0))
+    with pytest.raises(RuntimeError, match="DropPath requires a key"):
+        eqv.layers.DropPath(0.5)(x, key=None)
+    with pytest.raises(ValueError):
+        eqv.models.classification.swin._ShiftedWindowAttention(32, [7], [0, 0], 2)
+
+
+def test_conv_norm_activation_structure():
+    c = eqv.layers.ConvNormActivation(3, 4, key=eqv.random.PRNGKey(1))
+    assert [type(l).__name__ for l in c.layers] == ["Conv2d", "BatchNorm", "Lambda"] and c.out_channels == 4
+    assert c.layers[0].padding == (1, 1) and c.layers[0].bias is None and c.layers[1].axis_name == "batch"
+    c = eqv.layers.ConvNormActivation(3, 4, kernel_size=5, dilation=2, norm_layer=None, activation_layer=None)
+    assert len(c.layers) == 1 and c.layers[0].padding == (4, 4) and c.layers[0].bias.shape == (4, 1, 1)
+    c = eqv.layers.ConvNormActivation(3, 4, norm_layer=partial(nn.BatchNorm, eps=1e-3))
+    assert c.layers[1].eps == 1e-3 and c.layers[1].axis_name == "batch"
+    c = eqv.layers.ConvNormActivation(3, 4, norm_layer=eqv.layers.LayerNorm2d, activation_layer=nn.gelu)
+    assert type(c.layers[1]).__name__ == "LayerNorm2d" and c.layers[2].fn is nn.gelu
+
+
+def test_resnet_variants_shapes_and_dilation():
+    r = eqv.models.resnext50_32x4d()
+    assert r.layer1.layers[0].conv2.groups == 32 and r.layer1.layers[0].conv2.weight.shape == (128, 4, 3, 3)
+    w = eqv.models.wide_resnet50_2()
+    assert w.layer1.layers[0].conv1.weight.shape == (128, 64, 1, 1)
+    d = eqv.models.resnet50(replace_stride_with_dilation=[False, True, True])
+    assert d.layer3.layers[1].conv2.dilation == (2, 2) and d.layer4.layers[1].conv2.dilation == (4, 4)
+    assert d.layer4.layers[0].conv2.stride == (1, 1)
+    assert eqv.models.vit_b_16 is eqv.models.vit_base
+
+
+def test_urls_and_keys_mirror_the_reference():
+    u = eqv.utils.CLASSIFICATION_URLS
+    assert u["resnet50"].endswith("resnet50-19c8e357.pth") and u["alexnet"].endswith("alexnet-owt-7be5be79.pth")
+    assert "sim_b" in u and u["vit_small_patch16_224_dino"].endswith("dino_deitsmall16_pretrain.pth")
+    k = eqv.random.split(eqv.random.PRNGKey(3), 5)
+    assert k.shape == (5, 2) and k.dtype == np.uint32 and len({tuple(r) for r in k}) == 5
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from eqxvision_amd._lib import MVError
+    with pytest.raises(MVError, match="no CPU fallback"):
+        eqv.vmap(eqv.models.resnet18())(np.zeros((1, 3, 64, 64), np.float32), key=eqv.random.split(eqv.random.PRNGKey(0), 1))

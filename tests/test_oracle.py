@@ -1,0 +1,153 @@
+"""CPU: the numpy oracle (`oracle/np_ops.py`, `oracle/models.py`) against (a) torch.nn.functional -- the
+ground truth the reference's own tests use (tests/test_models/test_resnet.py:24) -- and (b) the committed
+golden vectors.  The reference itself cannot be imported here (no jax / equinox): parity is otherwise unpinned."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import models as OM
+from oracle import np_ops as O
+from oracle import state as S
+from oracle import torch_ref as TR
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "hotpath_small.npz"))
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(1e-12, np.abs(b).max())
+
+
+def rng(seed=0):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(C=3, K=8, R=7, S=7, stride=2, pad=3, H=23, W=19),
+    dict(C=16, K=12, R=3, S=3, stride=1, pad=1, H=9, W=9),
+    dict(C=16, K=12, R=3, S=3, stride=2, pad=2, dil=2, H=11, W=13),
+    dict(C=8, K=8, R=3, S=3, stride=1, pad=1, groups=4, H=7, W=7),
+    dict(C=6, K=10, R=1, S=1, stride=2, pad=0, H=8, W=8),
+    dict(C=3, K=5, R=11, S=11, stride=4, pad=2, H=35, W=35),
+])
+def test_conv2d_matches_torch(cfg):
+    r = rng(1)
+    g = cfg.get("groups", 1)
+    x = r.standard_normal((cfg["C"], cfg["H"], cfg["W"])).astype(np.float32)
+    w = r.standard_normal((cfg["K"], cfg["C"] // g, cfg["R"], cfg["S"])).astype(np.float32)
+    b = r.standard_normal((cfg["K"], 1, 1)).astype(np.float32)
+    got = O.conv2d(x, w, b, cfg["stride"], cfg["pad"], cfg.get("dil", 1), g)
+    ref = F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), torch.from_numpy(b.reshape(-1)), cfg["stride"],
+                   cfg["pad"], cfg.get("dil", 1), g)[0].numpy()
+    assert got.shape == ref.shape and rel(got, ref) < 1e-5
+
+
+def test_pool_norm_activation_match_torch():
+    r = rng(2)
+    x = r.standard_normal((5, 13, 12)).astype(np.float32)
+    t = torch.from_numpy(x)[None]
+    assert rel(O.maxpool2d(x, 3, 2, 1), F.max_pool2d(t, 3, 2, 1)[0].numpy()) == 0
+    assert rel(O.maxpool2d(x, 3, 2, 0), F.max_pool2d(t, 3, 2, 0)[0].numpy()) == 0
+    x2 = r.standard_normal((4, 12, 6)).astype(np.float32)
+    assert rel(O.adaptive_avgpool2d(x2, (6, 6)), F.adaptive_avg_pool2d(torch.from_numpy(x2)[None], (6, 6))[0].numpy()) < 1e-6
+    assert rel(O.adaptive_avgpool2d(x2, (1, 1)), x2.mean((1, 2), keepdims=True)) < 1e-6
+    rows = r.standard_normal((7, 20)).astype(np.float32)
+    g_, b_ = r.uniform(0.5, 1.5, 20).astype(np.float32), r.standard_normal(20).astype(np.float32)
+    ref = F.layer_norm(torch.from_numpy(rows), (20,), torch.from_numpy(g_), torch.from_numpy(b_), 1e-5).numpy()
+    assert rel(O.layernorm_rows(rows, g_, b_), ref) < 1e-5
+    assert rel(O.layernorm(rows[0], g_, b_), ref[0]) < 1e-5
+    v = (3 * r.standard_normal(1000)).astype(np.float32)
+    assert rel(O.gelu_tanh(v), F.gelu(torch.from_numpy(v), approximate="tanh").numpy()) < 1e-6
+    assert np.abs(O.gelu_tanh(v) - F.gelu(torch.from_numpy(v)).numpy()).max() > 1e-4      # NOT the erf form
+    assert rel(O.softmax(rows), torch.from_numpy(rows).softmax(-1).numpy()) < 1e-6
+    m, var = r.standard_normal(5).astype(np.float32), r.uniform(0.5, 1.5, 5).astype(np.float32)
+    gb, bb = r.uniform(0.5, 1.5, 5).astype(np.float32), r.standard_normal(5).astype(np.float32)
+    ref = F.batch_norm(t, torch.from_numpy(m), torch.from_numpy(var), torch.from_numpy(gb), torch.from_numpy(bb), False, 0., 1e-5)[0].numpy()
+    assert rel(O.batchnorm_inference(x, gb, bb, m, var), ref) < 1e-5
+
+
+def test_adaptive_avgpool_equinox_rule_when_not_divisible():
+    # first n%t outputs use chunks of n//t+1, the rest n//t (differs from torch)
+    x = np.arange(7, dtype=np.float32).reshape(1, 7, 1)
+    out = O.adaptive_avgpool2d(x, (3, 1)).reshape(-1)
+    np.testing.assert_allclose(out, [np.mean([0, 1, 2]), np.mean([3, 4]), np.mean([5, 6])])
+
+
+def test_patch_embed_is_a_gemm_and_attention_matches_sdpa():
+    r = rng(3)
+    img = r.standard_normal((3, 32, 32)).astype(np.float32)
+    w = r.standard_normal((24, 3, 8, 8)).astype(np.float32)
+    b = r.standard_normal((24, 1, 1)).astype(np.float32)
+    tok = O.patch_embed(img, w, b, 8)
+    gemm = img.reshape(3, 4, 8, 4, 8).transpose(1, 3, 0, 2, 4).reshape(16, 192) @ w.reshape(24, 192).T + b.reshape(-1)
+    assert tok.shape == (16, 24) and rel(tok, gemm) < 1e-5
+    x = r.standard_normal((9, 32)).astype(np.float32)
+    wq, bq = r.standard_normal((96, 32)).astype(np.float32) / 6, r.standard_normal(96).astype(np.float32)
+    wp, bp = r.standard_normal((32, 32)).astype(np.float32) / 6, r.standard_normal(32).astype(np.float32)
+    y, attn = O.vit_attention(x, wq, bq, wp, bp, 4)
+    assert y.shape == (9, 32) and attn.shape == (1, 4, 9, 9)
+    qkv = torch.from_numpy(x @ wq.T + bq).reshape(9, 3, 4, 8).permute(1, 2, 0, 3)
+    ref = F.scaled_dot_product_attention(qkv[0][None], qkv[1][None], qkv[2][None])[0].permute(1, 0, 2).reshape(9, 32)
+    assert rel(y, ref.numpy() @ wp.T + bp) < 1e-5
+
+
+def test_bf16_round_matches_torch():
+    v = (rng(4).standard_normal(10000) * 100).astype(np.float32)
+    ref = torch.from_numpy(v).to(torch.bfloat16).float().numpy()
+    np.testing.assert_array_equal(O.bf16_round(v), ref)
+
+
+def test_models_numpy_vs_torch_and_golden():
+    x = S.synthetic_images(2, 64, seed=0)
+    sd = S.resnet_state(1, "bottleneck", (1, 1, 1, 1), 10)
+    a = O.vmap(lambda im: OM.resnet_forward(sd, im, "bottleneck", (1, 1, 1, 1)))(x)
+    assert rel(a, TR.resnet_forward(sd, x, "bottleneck", (1, 1, 1, 1)).numpy()) < 1e-5
+    assert rel(a, GOLD["resnet_bottleneck_1111_64px"]) < 1e-5
+    sd = S.resnet_state(1, "basic", (2, 2, 2, 2), 10)
+    a = O.vmap(lambda im: OM.resnet_forward(sd, im, "basic", (2, 2, 2, 2)))(x)
+    assert rel(a, GOLD["resnet18_64px"]) < 1e-5
+    x32 = S.synthetic_images(3, 32, seed=0)
+    sd = S.vit_state(1, 32, 8, 64, 2, 2, 4, 10)
+    a = O.vmap(lambda im: OM.vit_forward(sd, im, 8, 2, 2))(x32)
+    assert rel(a, GOLD["vit_32px_p8_d64_h2_depth2"]) < 1e-5
+    a = O.vmap(lambda im: OM.vit_last_self_attention(sd, im, 8, 2, 2))(x32[:2])
+    assert a.shape == (2, 1, 2, 17, 17) and rel(a, GOLD["vit_32px_last_attn"]) < 1e-5
+    x56 = S.synthetic_images(2, 56, seed=0)
+    sd = S.swin_state(1, (4, 4), 32, (2, 2), (2, 4), (7, 7), 4.0, 10)
+    a = O.vmap(lambda im: OM.swin_forward(sd, im, (4, 4), (2, 2), (2, 4), (7, 7)))(x56)
+    assert rel(a, GOLD["swin_56px_e32_d22"]) < 1e-5
+    assert rel(a, TR.swin_forward(sd, x56, (4, 4), (2, 2), (2, 4), (7, 7)).numpy()) < 1e-5
+
+
+def test_alexnet_golden_and_bf16_emulation_is_close():
+    x = S.synthetic_images(2, 224, seed=0)
+    sd = S.alexnet_state(1, 1000)
+    lg = O.vmap(lambda im: OM.alexnet_forward(sd, im))(x)
+    assert rel(lg[:, :16], GOLD["alexnet_224_logits_head16"]) < 1e-4
+    assert rel(np.linalg.norm(lg, axis=1), GOLD["alexnet_224_logits_l2"]) < 1e-5
+    emu = O.vmap(lambda im: OM.alexnet_forward(sd, im, bf16=True))(x[:1])
+    assert np.abs(emu - lg[:1]).max() <= 1e-2 * max(1.0, np.abs(lg).max())
+
+
+def test_swin_shift_mask_and_window_edge_cases():
+    r = rng(5)
+    C, H, heads = 16, 14, 2
+    x = r.standard_normal((C, H, H)).astype(np.float32)
+    wq, wp = r.standard_normal((3 * C, C)).astype(np.float32) / 4, r.standard_normal((C, C)).astype(np.float32) / 4
+    bq, bp = r.standard_normal(3 * C).astype(np.float32), r.standard_normal(C).astype(np.float32)
+    bias = r.standard_normal((heads, 49, 49)).astype(np.float32)
+    sd = {"p.attn.qkv.weight": torch.from_numpy(wq), "p.attn.qkv.bias": torch.from_numpy(bq),
+          "p.attn.proj.weight": torch.from_numpy(wp), "p.attn.proj.bias": torch.from_numpy(bp)}
+    for shift in ([3, 3], [0, 0]):
+        got = O.shifted_window_attention(x, wq, wp, bias, [7, 7], heads, shift, bq, bp)
+        # independent torch restatement with an explicit (heads, n, n) bias through a fake table
+        table = torch.from_numpy(bias.transpose(1, 2, 0).reshape(49 * 49, heads).copy())
+        sd2 = dict(sd, **{"p.attn.relative_position_bias_table": table,
+                          "p.attn.relative_position_index": torch.arange(49 * 49)})
+        ref = TR._swin_attn(sd2, torch.from_numpy(x).permute(1, 2, 0)[None], "p", heads, [7, 7], shift)[0].permute(2, 0, 1).numpy()
+        assert rel(got, ref) < 1e-5
+    with pytest.raises(ValueError):
+        O.shifted_window_attention(x[:, :13], wq, wp, bias, [7, 7], heads, [0, 0], bq, bp)
