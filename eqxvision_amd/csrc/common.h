@@ -102,10 +102,15 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
 int stream1x1_supported(int C, int K, int in_dtype, int out_dtype, long long M);
 int stream1x1_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                      void* y, long long M, int C, int K, int act, int out_dtype, hipStream_t stream);
+int conv3x3c64_supported(int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int in_dtype,
+                         int out_dtype, const void* residual, long long M);
+int conv3x3c64_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H,
+                      int W, int act, hipStream_t stream);
 int igemm2_wanted(long long M, int C, int K, int R, int S);
 int igemm2_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                   void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
-                  int dh, int dw, int act, int out_dtype, hipStream_t stream);
+                  int dh, int dw, int act, int out_dtype, int m_end, hipStream_t stream);
+int igemm2_tile_shape(long long M, int K, int* bm, int* bn);
 int stem_supported(int C, int K, int R, int S, int x_dtype, int out_dtype);
 int stem_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
                 int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act, int x_dtype,

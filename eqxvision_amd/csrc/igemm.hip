@@ -36,6 +36,7 @@ struct IgemmP {
     const bf16_t* zero;
     int N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw;
     int M, tiles_m, tiles_n, act;
+    int m_off;   // first output row this launch covers (rows m_off .. M-1)
 };
 
 // 8 consecutive residual values of one output row, fetched as raw bits early, decoded in the epilogue
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
     const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     int tile_m, tile_n;
     tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = p.m_off + tile_m * BM, n0 = tile_n * BN;
 
     // ---------------- staging constants -------------------------------------------------------
     const int srow = lane >> 3;                                    // row inside the 8-row DMA group
@@ -277,7 +278,7 @@ int igemm_supported(int C, int K, int R, int S, int groups, int in_dtype, int ou
 
 template <int BM, int BN, int WM, int WN>
 static int launch_tile(IgemmP& p, bool dense, bool out_f32, hipStream_t st) {
-    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_m = (p.M - p.m_off + BM - 1) / BM;
     p.tiles_n = (p.K + BN - 1) / BN;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
 #define GO(OT, DN) hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, OT, DN>), grid, block, 0, st, p)
@@ -312,17 +313,40 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
         return MV_E_UNSUPPORTED;
     }
     p.M = (int)M;
+    p.m_off = 0;
     p.act = act;
     const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
     const bool out_f32 = out_dtype == MV_F32;
+    if (!get_flag("no_stream") && !get_flag("igemm_tile") && !get_flag("igemm2_tile") &&
+        conv3x3c64_supported(C, K, R, S, sh, sw, ph, pw, dh, dw, in_dtype, out_dtype, residual, M))
+        return conv3x3c64_launch(x, w, scale, shift, y, N, H, W, act, st);
     if (dense && !get_flag("no_stream") && !get_flag("igemm_tile") && stream1x1_supported(C, K, in_dtype, out_dtype, M))
         return stream1x1_launch(x, w, scale, shift, residual, y, M, C, K, act, out_dtype, st);
     // deep-pipelined 8-wave kernel: every real convolution (taps or stride) and the big Linears; the
     // short dense 1x1 layers late in the network (M <= 50k) measured the same or faster on the 128^2 kernel
     const bool want2 = igemm2_wanted(M, C, K, R, S) && (!dense || M >= 32768 || get_flag("igemm2_tile"));
-    if (!get_flag("no_igemm2") && !get_flag("igemm_tile") && want2)
-        return igemm2_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act,
-                             out_dtype, st);
+    int m_off = 0;
+    if (!get_flag("no_igemm2") && !get_flag("igemm_tile") && want2) {
+        // Main + tail: 256-row tiles fill whole rounds of the 256 CUs; a last, mostly empty round (e.g. 392
+        // tiles = 1.53 rounds) would cost a full tile time with a third of the chip idle (measured 67% wave
+        // occupancy on the ResNet 3x3 layers).  So the deep-pipelined kernel takes the rows that fill complete
+        // rounds and the 128-row kernel below (two blocks per CU) finishes the remaining rows in one short round.
+        int bm, bn;
+        igemm2_tile_shape(M, K, &bm, &bn);
+        const long long tm = (M + bm - 1) / bm, tn = (K + bn - 1) / bn;
+        const long long blocks = tm * tn, rounds = blocks / 256, rem = blocks - rounds * 256;
+        long long main_mt = tm;
+        // measured on ResNet-50 (profiles/r01): the tail's 128-row blocks need two rounds of their own for the
+        // common 392- and 784-tile layers, so the split LOSES ~8%; kept behind a flag for shapes where it pays
+        if (get_flag("tail_split") && rounds >= 1 && rem > 0 && rem <= 128) main_mt = (rounds * 256) / tn;
+        if (main_mt <= 0) main_mt = tm;
+        const int m_end = main_mt < tm ? (int)(main_mt * bm) : 0;
+        const int rc = igemm2_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act,
+                                     out_dtype, m_end, st);
+        if (rc != MV_OK || m_end == 0) return rc;
+        m_off = m_end;
+    }
+    p.m_off = m_off;
     int tile = get_flag("igemm_tile");
     if (tile == 0) tile = (K <= 64) ? 2 : 1;
     if (tile == 2) {

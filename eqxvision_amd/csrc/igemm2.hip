@@ -28,7 +28,7 @@ struct Igemm2P {
     void* y;
     const bf16_t* zero;
     int N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw;
-    int M, tiles_m, tiles_n, act;
+    int M, tiles_m, tiles_n, act;   // M = rows covered by THIS launch (rows 0 .. M-1)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -124,25 +124,27 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
         const int n = n0 + 8 * (wave + 8 * j) + srow;
         woff[j] = n < p.K ? (long long)n * wrow_stride + chunk * 8 : -1;
     }
-    auto stage = [&](int buf, int r, int s, int c0) {
+    // one DMA piece: piece q < XI stages 8 pixel rows of the x tile, q >= XI stages 8 weight rows
+    auto stage_piece = [&](int q, int buf, int r, int s, int c0) {
         char* xs = smem + buf * STAGE;
         char* ws = xs + BM * ROWB;
         const int tp = r * p.S + s;                                          // wave-uniform
-        const long long tapdelta = ((long long)(r * p.dh) * p.W + s * p.dw) * p.C + c0;
-        const int tapoff = tp * p.C + c0;
-        const bf16_t* xt = p.x + tapdelta;
-#pragma unroll
-        for (int j = 0; j < XI; ++j) {
-            const unsigned bits = tp < 32 ? vlo[j] : vhi[j];
+        if (q < XI) {
+            const long long tapdelta = ((long long)(r * p.dh) * p.W + s * p.dw) * p.C + c0;
+            const unsigned bits = tp < 32 ? vlo[q] : vhi[q];
             const bool ok = (bits >> (tp & 31)) & 1u;
-            const bf16_t* src = ok ? xt + xbase[j] : p.zero;
-            glds16(src, xs + 8 * (wave + 8 * j) * ROWB);
-        }
-#pragma unroll
-        for (int j = 0; j < WI; ++j) {
+            const bf16_t* src = ok ? p.x + tapdelta + xbase[q] : p.zero;
+            glds16(src, xs + 8 * (wave + 8 * q) * ROWB);
+        } else {
+            const int j = q - XI;
+            const int tapoff = tp * p.C + c0;
             const bf16_t* src = woff[j] >= 0 ? p.w + woff[j] + tapoff : p.zero;
             glds16(src, ws + 8 * (wave + 8 * j) * ROWB);
         }
+    };
+    auto stage = [&](int buf, int r, int s, int c0) {
+#pragma unroll
+        for (int q = 0; q < L; ++q) stage_piece(q, buf, r, s, c0);
     };
 
     // ---------------- fragment addressing ------------------------------------------------------------
@@ -213,15 +215,13 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
         if (NST > 2 && younger >= NST - 2) wait_vm<(NST > 2 ? (NST - 2) * L : 0)>();
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
-        // Refill the stage everyone just left with tile it+NST-1.  The two waves of a SIMD run this
-        // (VALU/SALU address work + DMA issue) at OPPOSITE ends of the iteration: waves 0-3 before their
-        // MFMAs, waves 4-7 after, so one wave's address phase overlaps its partner's MFMA phase instead of
-        // both idling the matrix pipe together right after the barrier.  vmcnt accounting is unchanged
-        // (the refill is still the newest L operations when the next iteration's wait executes).
+        // Refill the stage everyone just left with tile it+NST-1.  The L DMA pieces are spread over the four
+        // k16-steps below (a quarter per step, between the fragment reads and the MFMAs) so their address
+        // VALU/SALU work hides under MFMA execution instead of forming a block of its own after the barrier.
+        // vmcnt accounting is unchanged: they are still the newest L operations at the next iteration's wait.
         const bool refill = issued < nk;
         int rbuf = cur + NST - 1;
         if (rbuf >= NST) rbuf -= NST;
-        if (refill && wave < 4) stage(rbuf, r, s, c0);
         const unsigned sb = (unsigned)(cur * STAGE);
         u32x4 af[2][TN], bfm[2][TM];
         auto read_step = [&](int set, int kk) {
@@ -252,6 +252,11 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
         for (int kk = 0; kk < 4; ++kk) {
             const int cs = kk & 1, ns = cs ^ 1;
             if (kk < 3) read_step(ns, kk + 1);
+            // a quarter of the refill DMA (address VALU + issue) rides in the shadow of this step's MFMAs
+            if (refill) {
+#pragma unroll
+                for (int q = (kk * L) / 4; q < ((kk + 1) * L) / 4; ++q) stage_piece(q, rbuf, r, s, c0);
+            }
             wait_step(cs, kk == 3);
 #pragma unroll
             for (int a = 0; a < TN; ++a)
@@ -261,7 +266,6 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
                                                                         __builtin_bit_cast(bf16x8, bfm[cs][b]),
                                                                         acc[a][b], 0, 0, 0);
         }
-        if (refill && wave >= 4) stage(rbuf, r, s, c0);
         if (refill) {
             advance();
             ++issued;
@@ -346,9 +350,21 @@ int igemm2_wanted(long long M, int C, int K, int R, int S) {
     return M >= 4096 && ktiles >= 4 && R * S <= 64;
 }
 
+// block tile igemm2_launch will pick for (M rows, K output channels)
+int igemm2_tile_shape(long long M, int K, int* bm, int* bn) {
+    int tile = get_flag("igemm2_tile");
+    if (tile == 0) {
+        const long long big_tiles = ((M + 255) / 256) * (long long)((K + 255) / 256);
+        tile = K <= 64 ? 1 : ((K >= 1024 && big_tiles >= 512) ? 3 : 2);
+    }
+    *bm = 256;
+    *bn = tile == 1 ? 64 : (tile == 3 ? 256 : 128);
+    return tile;
+}
+
 int igemm2_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y,
                   int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
-                  int act, int out_dtype, hipStream_t st) {
+                  int act, int out_dtype, int m_end, hipStream_t st) {
     Igemm2P p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.zero = (const bf16_t*)zero_page(st);
@@ -361,14 +377,12 @@ int igemm2_launch(const void* x, const void* w, const float* scale, const float*
     p.Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
     p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw;
     p.M = (int)((long long)N * p.Ho * p.Wo);
+    if (m_end > 0 && m_end < p.M) p.M = m_end;      // this launch covers output rows [0, m_end) only
     p.act = act;
     const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
     const bool out_f32 = out_dtype == MV_F32;
-    int tile = get_flag("igemm2_tile");          // 0 auto, 1 = 256x64, 2 = 256x128, 3 = 256x256
-    if (tile == 0) {
-        const long long big_tiles = ((p.M + 255) / 256) * (long long)((K + 255) / 256);
-        tile = K <= 64 ? 1 : ((K >= 1024 && big_tiles >= 512) ? 3 : 2);
-    }
+    int bm_, bn_;
+    const int tile = igemm2_tile_shape((long long)N * p.Ho * p.Wo, K, &bm_, &bn_);   // 1 = 256x64, 2 = 256x128, 3 = 256x256
     if (tile == 1) {
         set_kernel_name(dense ? "igemm2_bf16_256x64_dense" : "igemm2_bf16_256x64_conv");
         return launch2<8, 1, 1, 2, 3, true>(p, out_f32, st);

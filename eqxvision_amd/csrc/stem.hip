@@ -191,7 +191,11 @@ struct StemV1P {
     int off_patch, off_ftab, off_ep;   // LDS byte offsets
 };
 
-template <typename TX>
+// NE > 0: every thread owns NE fixed patch elements and keeps the NEXT tile's values in registers
+// (software prefetch issued right after the LDS image of the current tile is written), so the HBM latency of
+// the patch gather overlaps the MFMA + epilogue phase instead of stalling each tile twice (~4 us per tile
+// measured).  NE = 0: patches too large for that (AlexNet 11x11/4): batched loads inside the tile.
+template <typename TX, int NE>
 __global__ __launch_bounds__(256) void stem_patch_kernel(const StemV1P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wl = smem;                                   // [64][wpitch]
@@ -238,36 +242,77 @@ __global__ __launch_bounds__(256) void stem_patch_kernel(const StemV1P p) {
     ScaleShift8 ss;
     ss.load(p.scale, p.shift, n0 + (lane & 7) * 8, p.K);
 
-    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+    // prefetch path: per-thread element coordinates are tile independent
+    int eoff[NE > 0 ? NE : 1], eyy[NE > 0 ? NE : 1], exx[NE > 0 ? NE : 1];
+    float pv[NE > 0 ? NE : 1];
+    auto tile_origin = [&](int tile, int& b, int& oy0, int& ox0) {
         const int tx = tile % p.tiles_x;
         const int ty = (tile / p.tiles_x) % p.tiles_y;
-        const int b = tile / (p.tiles_x * p.tiles_y);
-        const int oy0 = ty * 8, ox0 = tx * 16;
+        b = tile / (p.tiles_x * p.tiles_y);
+        oy0 = ty * 8;
+        ox0 = tx * 16;
+    };
+    auto prefetch = [&](int tile) {
+        int b, oy0, ox0;
+        tile_origin(tile, b, oy0, ox0);
+        const int hi0 = oy0 * p.sh - p.ph, wi0 = ox0 * p.sw - p.pw;
+        const TX* xb = xg + (long long)b * p.C * HW;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int hi = hi0 + eyy[j], wi = wi0 + exx[j];
+            const bool ok = eoff[j] >= 0 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const float t = ldx<TX>(xb + (ok ? (long long)eoff[j] + (long long)hi * p.W + wi : 0));
+            pv[j] = ok ? t : 0.f;
+        }
+    };
+    if (NE > 0) {
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int i = j * 256 + tid;
+            const int xx = i % p.PWp;
+            const int t2 = i / p.PWp;
+            exx[j] = xx;
+            eyy[j] = t2 % p.PH;
+            eoff[j] = i < p.patch_elems ? (t2 / p.PH) * HW : -1;
+        }
+        if ((int)blockIdx.x < p.tiles) prefetch(blockIdx.x);
+    }
+
+    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        int b, oy0, ox0;
+        tile_origin(tile, b, oy0, ox0);
         const int hi0 = oy0 * p.sh - p.ph, wi0 = ox0 * p.sw - p.pw;
         __syncthreads();                      // previous tile's MFMAs are done with the patch (and tables are ready)
-        // patch staging: issue 8 independent loads per thread, THEN convert + write (a conditional load per
-        // loop trip would serialise ~patch_elems/256 HBM round trips per tile)
-        const TX* xb = xg + (long long)b * p.C * HW;
-        for (int base = 0; base < p.patch_elems; base += 256 * 8) {
-            float v[8];
+        if (NE > 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = base + j * 256 + tid;
-                const int xx = i % p.PWp;
-                const int t2 = i / p.PWp;
-                const int yy = t2 % p.PH, c = t2 / p.PH;
-                const int hi = hi0 + yy, wi = wi0 + xx;
-                const bool ok = i < p.patch_elems && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                const float t = ldx<TX>(xb + (ok ? (long long)c * HW + (long long)hi * p.W + wi : 0));
-                v[j] = ok ? t : 0.f;
+            for (int j = 0; j < NE; ++j) {
+                const int i = j * 256 + tid;
+                if (i < p.patch_elems) patch[i] = f2bf(pv[j]);
             }
+        } else {
+            const TX* xb = xg + (long long)b * p.C * HW;
+            for (int base = 0; base < p.patch_elems; base += 256 * 8) {
+                float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = base + j * 256 + tid;
-                if (i < p.patch_elems) patch[i] = f2bf(v[j]);
+                for (int j = 0; j < 8; ++j) {
+                    const int i = base + j * 256 + tid;
+                    const int xx = i % p.PWp;
+                    const int t2 = i / p.PWp;
+                    const int yy = t2 % p.PH, c = t2 / p.PH;
+                    const int hi = hi0 + yy, wi = wi0 + xx;
+                    const bool ok = i < p.patch_elems && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                    const float t = ldx<TX>(xb + (ok ? (long long)c * HW + (long long)hi * p.W + wi : 0));
+                    v[j] = ok ? t : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = base + j * 256 + tid;
+                    if (i < p.patch_elems) patch[i] = f2bf(v[j]);
+                }
             }
         }
         __syncthreads();
+        if (NE > 0 && tile + (int)gridDim.x < p.tiles) prefetch(tile + gridDim.x);   // flies under the MFMAs below
 
         f32x16 acc[2];
 #pragma unroll
@@ -361,17 +406,20 @@ static int stem_v1_launch(const void* x, const void* w, const float* scale, cons
     if (gx > cap) gx = cap;
     dim3 grid(gx, tiles_n), block(256);
     set_kernel_name(x_dtype == MV_F32 ? "stem_patch_mfma_f32in" : "stem_patch_mfma_bf16in");
+    const int ne = (p.patch_elems + 255) / 256;
+#define GO(TX_, NE_)                                                                                             \
+    do {                                                                                                         \
+        auto kern = stem_patch_kernel<TX_, NE_>;                                                                 \
+        if (smem > 48 * 1024)                                                                                    \
+            MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL(kern, grid, block, smem, st, p);                                                      \
+    } while (0)
     if (x_dtype == MV_F32) {
-        if (smem > 48 * 1024)
-            MV_HIP(hipFuncSetAttribute((const void*)stem_patch_kernel<float>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(stem_patch_kernel<float>, grid, block, smem, st, p);
+        if (ne <= 10) GO(float, 10); else GO(float, 0);
     } else {
-        if (smem > 48 * 1024)
-            MV_HIP(hipFuncSetAttribute((const void*)stem_patch_kernel<bf16_t>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(stem_patch_kernel<bf16_t>, grid, block, smem, st, p);
+        if (ne <= 10) GO(bf16_t, 10); else GO(bf16_t, 0);
     }
+#undef GO
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

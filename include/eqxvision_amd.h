@@ -37,7 +37,8 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  * tests to cross-check the MFMA kernels), "igemm_tile" (override tile heuristic, 0 = auto),
  * "stem_v0" (1 = use the table-gather entry-conv kernel instead of the patch/GEMM variants),
  * "no_stream" / "no_igemm2" (1 = do not dispatch to the streaming 1x1 / deep-pipelined kernels),
- * "igemm2_tile" (0 auto, 1 = 256x64, 2 = 256x128, 3 = 256x256 block tile). */
+ * "igemm2_tile" (0 auto, 1 = 256x64, 2 = 256x128, 3 = 256x256 block tile), "tail_split" (1 = hand the
+ * rows of a small partial last round of 256-row tiles to the 128-row kernel). */
 
 int mv_abi_version(void);
 const char* mv_last_error(void);

@@ -462,8 +462,11 @@ def all_cases():
           ("igemm/1x1_M1", conv_nhwc_case(1, 1, 1, 2048, 1000, 1, 1, out="fp32")),
           ("igemm/gelu", conv_nhwc_case(1, 8, 8, 128, 128, 1, 1, act=2)),
           ("igemm/big_M", conv_nhwc_case(8, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=3))]
-    c += [("igemm2/3x3_128_28", conv_nhwc_case(8, 28, 28, 128, 128, 3, 3, pad=1, act=1, seed=11)),
-          ("igemm2/3x3_64_56_bn64", conv_nhwc_case(2, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=12)),
+    c += [("c3x3c64/56", conv_nhwc_case(4, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=41)),
+          ("c3x3c64/odd_37x29_noact", conv_nhwc_case(9, 37, 29, 64, 64, 3, 3, pad=1, scale=False, seed=42)),
+          ("c3x3c64/tiny_rows", conv_nhwc_case(70, 12, 10, 64, 64, 3, 3, pad=1, act=1, seed=43)),
+          ("igemm2/3x3_128_28", conv_nhwc_case(8, 28, 28, 128, 128, 3, 3, pad=1, act=1, seed=11)),
+          ("igemm2/3x3_64_56_bn64", conv_nhwc_case(2, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=12, flags=("no_stream",))),
           ("igemm2/3x3_256_s2", conv_nhwc_case(24, 28, 28, 256, 256, 3, 3, stride=2, pad=1, act=1, seed=13)),
           ("igemm2/1x1_512_128", conv_nhwc_case(8, 28, 28, 512, 128, 1, 1, act=1, seed=14)),
           ("igemm2/1x1_256_512_s2", conv_nhwc_case(8, 56, 56, 256, 512, 1, 1, stride=2, seed=15)),
@@ -476,6 +479,8 @@ def all_cases():
           ("igemm2/t256_3x3_s2_K320", conv_nhwc_case(9, 33, 35, 128, 320, 3, 3, stride=2, pad=1, seed=33, flags=("igemm2_tile=3",))),
           ("igemm2/t256_f32out_res", conv_nhwc_case(30, 14, 14, 512, 256, 1, 1, res=True, out="fp32", seed=34, flags=("igemm2_tile=3",))),
           ("igemm2/t64_forced_K128", conv_nhwc_case(6, 28, 28, 128, 128, 3, 3, pad=1, seed=35, flags=("igemm2_tile=1",))),
+          ("igemm2/split_main_tail_3x3", conv_nhwc_case(70, 28, 28, 128, 256, 3, 3, pad=1, act=1, res=True, seed=51, flags=("tail_split",))),
+          ("igemm2/split_main_tail_dense", conv_nhwc_case(86, 28, 28, 512, 128, 1, 1, act=1, seed=52, flags=("tail_split",))),
           ("igemm/old_kernel_3x3_128_28", conv_nhwc_case(8, 28, 28, 128, 128, 3, 3, pad=1, act=1, seed=11, flags=("no_igemm2",))),
           ("igemm/old_kernel_1x1_64_256", conv_nhwc_case(4, 56, 56, 64, 256, 1, 1, act=1, res=True, flags=("no_stream",))),
           ("stream/64_256_res", conv_nhwc_case(4, 56, 56, 64, 256, 1, 1, act=1, res=True)),
