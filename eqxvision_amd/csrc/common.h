@@ -115,6 +115,9 @@ int stem_supported(int C, int K, int R, int S, int x_dtype, int out_dtype);
 int stem_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
                 int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act, int x_dtype,
                 int out_dtype, int tok_stride, int tok_offset, const float* pos, hipStream_t stream);
+int swin_mfma_supported(int C, int heads, int ws_h, int ws_w, int dtype);
+int swin_mfma_launch(const void* qkv, const float* bias, void* out, int B, int Hf, int Wf, int C, int heads, int ws_h,
+                     int ws_w, int shift_h, int shift_w, hipStream_t stream);
 int mha_mfma_supported(int N, int dh, int dtype);
 int mha_mfma_launch(const void* qkv, void* out, float* probs, int B, int N, int H, int dh, float scale,
                     hipStream_t stream);

@@ -569,6 +569,13 @@ int mv_conv2d_nhwc_fwd(const void* x, const void* w, const float* scale, const f
     const int Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
     MV_CHECK_ARG(Ho > 0 && Wo > 0, "conv2d_nhwc: empty output (%d x %d)", Ho, Wo);
     hipStream_t st = (hipStream_t)stream;
+    {   // pointwise layers whose reduction is not a multiple of 64 (Swin C = 96) still fit the streaming kernel
+        const long long M = (long long)N * Ho * Wo;
+        const bool dense1x1 = R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && groups == 1;
+        if (!get_flag("force_generic") && !get_flag("no_stream") && !get_flag("igemm_tile") && dense1x1 && C % 64 != 0 &&
+            stream1x1_supported(C, K, in_dtype, out_dtype, M))
+            return stream1x1_launch(x, w, scale, shift, residual, y, M, C, K, act, out_dtype, st);
+    }
     if (!get_flag("force_generic") && igemm_supported(C, K, R, S, groups, in_dtype, out_dtype))
         return igemm_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, in_dtype,
                             out_dtype, st);
@@ -733,6 +740,8 @@ int mv_swin_window_attn_fwd(const void* qkv, const float* bias, void* out, int B
     if (ws_h >= Hf) shift_h = 0;  // swin.py:116-120
     if (ws_w >= Wf) shift_w = 0;
     hipStream_t st = (hipStream_t)stream;
+    if (!get_flag("force_generic") && swin_mfma_supported(C, heads, ws_h, ws_w, dtype))
+        return swin_mfma_launch(qkv, bias, out, B, Hf, Wf, C, heads, ws_h, ws_w, shift_h, shift_w, st);
     const int n = ws_h * ws_w, dh = C / heads;
     const int tokens = Hf * Wf;
     MV_CHECK_ARG(heads <= 65535 && B <= 65535, "swin_attn: grid too large");

@@ -184,8 +184,8 @@ __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) 
 
 int stream1x1_supported(int C, int K, int in_dtype, int out_dtype, long long M) {
     // C = reduction length, K = output channels (igemm naming)
-    return in_dtype == MV_BF16 && (out_dtype == MV_BF16 || out_dtype == MV_F32) && (C == 64 || C == 128 || C == 256) &&
-           K % 8 == 0 && M >= 8192;
+    return in_dtype == MV_BF16 && (out_dtype == MV_BF16 || out_dtype == MV_F32) &&
+           (C == 64 || C == 96 || C == 128 || C == 192 || C == 256) && K % 8 == 0 && M >= 8192;
 }
 
 template <int TN, int KC, typename OutT>
@@ -223,11 +223,15 @@ int stream1x1_launch(const void* x, const void* w, const float* scale, const flo
     return f32o ? stream_go<TN_, KC_, float>(p, tiles_n, st) : stream_go<TN_, KC_, bf16_t>(p, tiles_n, st)
     if (bn == 64) {
         if (C == 64) GO(2, 4);
+        if (C == 96) GO(2, 6);
         if (C == 128) GO(2, 8);
+        if (C == 192) GO(2, 12);
         GO(2, 16);
     }
     if (C == 64) GO(4, 4);
+    if (C == 96) GO(4, 6);
     if (C == 128) GO(4, 8);
+    if (C == 192) GO(4, 12);
     GO(4, 16);
 #undef GO
 }

@@ -300,7 +300,7 @@ def mha_case(B, N, H, dh, dtype="bf16", probs=True, generic=False, seed=0, spike
     return run
 
 
-def swin_attn_case(B, Hf, C, heads, ws, shift, dtype="bf16", seed=0):
+def swin_attn_case(B, Hf, C, heads, ws, shift, dtype="bf16", seed=0, generic=False):
     def run():
         L = _lib()
         rng = _rng(seed)
@@ -320,8 +320,12 @@ def swin_attn_case(B, Hf, C, heads, ws, shift, dtype="bf16", seed=0):
         qd = dev(qkv.transpose(0, 2, 3, 1), dtype)
         bd = dev(bias, "fp32")
         y = torch.empty((B, Hf, Hf, C), dtype=qd.dtype, device="cuda")
-        L.call("mv_swin_window_attn_fwd", qd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, Hf, Hf, C, heads, ws, ws,
-               shift, shift, DT[dtype], _stream())
+        L.set_flag("force_generic", 1 if generic else 0)
+        try:
+            L.call("mv_swin_window_attn_fwd", qd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, Hf, Hf, C, heads, ws, ws,
+                   shift, shift, DT[dtype], _stream())
+        finally:
+            L.set_flag("force_generic", 0)
         torch.cuda.synchronize()
         info = _cmp(host(y).transpose(0, 3, 1, 2), ref, TOL_BF16 if dtype == "bf16" else TOL_F32)
         info["kernel"] = L.last_kernel()
@@ -490,6 +494,10 @@ def all_cases():
           ("stream/64_64_noscale", conv_nhwc_case(3, 56, 56, 64, 64, 1, 1, scale=False)),
           ("stream/linear_f32out_res", linear_case(9000, 128, 200, res=True, out="fp32")),
           ("stream/gelu_N72", linear_case(8200, 64, 72, act=2)),
+          ("stream/swin_qkv_96_288", linear_case(12544, 96, 288, seed=61)),
+          ("stream/swin_fc1_96_384_gelu", linear_case(12544, 96, 384, act=2, seed=62)),
+          ("stream/swin_proj_96_f32res", linear_case(9000, 96, 96, res=True, out="fp32", seed=63)),
+          ("stream/swin_192_576", linear_case(8300, 192, 576, seed=64)),
           ("linear/vit_qkv", linear_case(197 * 2, 768, 2304)),
           ("linear/vit_fc1_gelu", linear_case(197 * 2, 768, 3072, act=2)),
           ("linear/vit_fc2_res", linear_case(197 * 2, 3072, 768, res=True)),
@@ -539,7 +547,13 @@ def all_cases():
     c += [("swin/shift3", swin_attn_case(2, 14, 96, 3, 7, 3)),
           ("swin/noshift", swin_attn_case(2, 14, 96, 3, 7, 0)),
           ("swin/window_ge_map", swin_attn_case(1, 7, 192, 6, 7, 3)),
-          ("swin/f32", swin_attn_case(1, 14, 32, 2, 7, 3, dtype="fp32"))]
+          ("swin/f32", swin_attn_case(1, 14, 32, 2, 7, 3, dtype="fp32")),
+          ("swin/generic_shift3", swin_attn_case(2, 14, 96, 3, 7, 3, generic=True)),
+          ("swin/stage0_56_shift", swin_attn_case(3, 56, 96, 3, 7, 3, seed=7)),
+          ("swin/stage2_14_12heads", swin_attn_case(5, 14, 384, 12, 7, 3, seed=8)),
+          ("swin/stage3_7_24heads", swin_attn_case(9, 7, 768, 24, 7, 3, seed=9)),
+          ("swin/window8_64tokens", swin_attn_case(2, 16, 64, 2, 8, 4, seed=10)),
+          ("swin/window4", swin_attn_case(2, 12, 64, 2, 4, 2, seed=11))]
     c += [("misc/patch_merge", misc_case("patch_merge")),
           ("misc/layout", misc_case("layout")),
           ("misc/layout_f32", misc_case("layout", "fp32")),
