@@ -117,7 +117,7 @@ def layer_table(compiled, path, steps=5):
             shape = f"N{N} {H}x{W}x{C}"
         elif name == "mv_layernorm_fwd":
             M, C = args[4:6]
-            byts = 4.0 * M * C
+            byts = float(M) * C * sum(4 if d == 2 else 2 for d in args[8:10])
             shape = f"M{M} C{C}"
         rows.append({"call": name, "kernel": kern, "shape": shape, "us": round(us, 2),
                      "tflops": round(flops / us / 1e6, 1) if us else 0, "gbs": round(byts / us / 1e3, 1) if us else 0,
@@ -247,7 +247,7 @@ def main():
             d["us"] += r_["us"]; d["gflop"] += r_["gflop"]; d["mb"] += r_["mb"]; d["n"] += 1
         dom = max(fam.items(), key=lambda kv: kv[1]["us"]) if fam else ("n/a", {"us": 1, "gflop": 0, "mb": 0, "n": 1})
         dk, dv = dom
-        dom_tflops = dv["gflop"] / dv["us"] * 1e-3 if dv["us"] else 0.0
+        dom_tflops = dv["gflop"] / dv["us"] * 1e3 if dv["us"] else 0.0   # GFLOP/us = PFLOP/s
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per launch, if collected
         if os.path.exists(tj):

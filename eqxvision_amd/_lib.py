@@ -33,6 +33,9 @@ PROTOTYPES = {
     "mv_adaptive_avgpool2d_nhwc_fwd": [_vp, _vp] + [_i] * 6 + [_i, _i, _vp],
     "mv_layernorm_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _i64, _f, _i, _i, _vp],
     "mv_mha_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "mv_linear_heads_supported": [_i64, _i, _i, _i, _i, _i],
+    "mv_linear_heads_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
+    "mv_mha_heads_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "mv_swin_window_attn_fwd": [_vp, _vp, _vp] + [_i] * 9 + [_i, _vp],
     "mv_patch_merge_gather_nhwc": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mv_vit_cls_pos_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -109,7 +109,7 @@ int conv3x3c64_launch(const void* x, const void* w, const float* scale, const fl
 int igemm2_wanted(long long M, int C, int K, int R, int S);
 int igemm2_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                   void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
-                  int dh, int dw, int act, int out_dtype, int m_end, hipStream_t stream);
+                  int dh, int dw, int act, int out_dtype, int m_end, int tok, hipStream_t stream);
 int igemm2_tile_shape(long long M, int K, int* bm, int* bn);
 int stem_supported(int C, int K, int R, int S, int x_dtype, int out_dtype);
 int stem_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
@@ -119,7 +119,7 @@ int swin_mfma_supported(int C, int heads, int ws_h, int ws_w, int dtype);
 int swin_mfma_launch(const void* qkv, const float* bias, void* out, int B, int Hf, int Wf, int C, int heads, int ws_h,
                      int ws_w, int shift_h, int shift_w, hipStream_t stream);
 int mha_mfma_supported(int N, int dh, int dtype);
-int mha_mfma_launch(const void* qkv, void* out, float* probs, int B, int N, int H, int dh, float scale,
+int mha_mfma_launch(const void* qkv, int head_major, void* out, float* probs, int B, int N, int H, int dh, float scale,
                     hipStream_t stream);
 
 }  // namespace mv

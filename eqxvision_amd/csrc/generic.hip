@@ -396,55 +396,98 @@ template <> struct StN<float, 4> {
     __device__ static __forceinline__ void st(float* p, const float* o) { *(float4*)p = make_float4(o[0], o[1], o[2], o[3]); }
 };
 
-template <typename TI, typename TO, int CHUNKS>
-__global__ void layernorm_vec_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
-                                     const float* __restrict__ beta, TO* __restrict__ y, long long M, int C,
-                                     long long xs, float eps) {
+// WIDTH lanes cooperate on one row (64 / WIDTH rows per wave per step); every wave walks a grid-stride list of
+// row groups and issues the NEXT group's loads before reducing the current one, so the row latency is hidden
+// by the wave itself (the one-row-per-short-lived-wave version ran at 2.5 TB/s on [50432 x 768] fp32).
+template <int WIDTH> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <typename TI, typename TO, int CHUNKS, int WIDTH>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, TO* __restrict__ y, long long M,
+                                                            int C, long long xs, float eps) {
     constexpr int N = Vec16<TI>::N;
+    constexpr int RPW = 64 / WIDTH;                      // rows per wave per step
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const int sub = lane / WIDTH, sl = lane % WIDTH;     // which row of the group, lane within the row
+    const long long gw = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
     const int nch = C / N;
-    const TI* xr = x + row * xs;
-    float v[CHUNKS][N];
-    float s = 0.f;
+    const float invC = 1.0f / (float)C;
+
+    // gamma / beta live in registers for the whole kernel (per-row re-loads through null checks were compiled
+    // into 8 serialized scalar loads per chunk); chunk indices are clamped so every load is unconditional.
+    float gm[CHUNKS][N], bt[CHUNKS][N];
+    int cc[CHUNKS];
 #pragma unroll
     for (int i = 0; i < CHUNKS; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
-            Vec16<TI>::ld(xr + c * N, v[i]);
+        const int c = sl + WIDTH * i;
+        cc[i] = c < nch ? c : nch - 1;
 #pragma unroll
-            for (int e = 0; e < N; ++e) s += v[i][e];
+        for (int e = 0; e < N; e += 4) {
+            float4 gv = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gamma) gv = *(const float4*)(gamma + cc[i] * N + e);
+            if (beta) bv = *(const float4*)(beta + cc[i] * N + e);
+            gm[i][e] = gv.x; gm[i][e + 1] = gv.y; gm[i][e + 2] = gv.z; gm[i][e + 3] = gv.w;
+            bt[i][e] = bv.x; bt[i][e + 1] = bv.y; bt[i][e + 2] = bv.z; bt[i][e + 3] = bv.w;
         }
     }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
+
+    float cur[CHUNKS][N], nxt[CHUNKS][N];
+    const long long groups = (M + RPW - 1) / RPW;
+    auto load = [&](float (*v)[N], long long group) {
+        if (group >= groups) group = groups - 1;          // clamped re-read instead of a conditional load
+        long long row = group * RPW + sub;
+        if (row >= M) row = M - 1;
+        const TI* xr = x + row * xs;
 #pragma unroll
-    for (int i = 0; i < CHUNKS; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
+        for (int i = 0; i < CHUNKS; ++i) Vec16<TI>::ld(xr + cc[i] * N, v[i]);
+    };
+    // One step: issue the loads of the group after `gg` into `b`, then reduce / normalise / store `a`.  The
+    // two register sets swap roles every step (loop unrolled by two) so nothing is copied and the wave only
+    // ever waits for the OLDER of two row groups in flight.
+    auto step = [&](float (*a)[N], float (*b)[N], long long gg) {
+        load(b, gg + nw);
+        asm volatile("" : "+v"(a[0][0]) : : "memory");  // keep the prefetch ahead of the arithmetic on `a`
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) {
+            const bool on = sl + WIDTH * i < nch;
+#pragma unroll
+            for (int e = 0; e < N; ++e) s += on ? a[i][e] : 0.f;
+        }
+        const float mean = group_sum<WIDTH>(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) {
+            const bool on = sl + WIDTH * i < nch;
 #pragma unroll
             for (int e = 0; e < N; ++e) {
-                const float d = v[i][e] - mean;
-                q += d * d;
+                const float d = a[i][e] - mean;
+                q += on ? d * d : 0.f;
             }
         }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-    TO* yr = y + row * C;
+        const float rstd = rsqrtf(group_sum<WIDTH>(q) * invC + eps);
+        const long long row = gg * RPW + sub;
+        const bool live = gg < groups && row < M;
+        TO* yr = y + row * C;
 #pragma unroll
-    for (int i = 0; i < CHUNKS; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
+        for (int i = 0; i < CHUNKS; ++i) {
             float o[N];
 #pragma unroll
-            for (int e = 0; e < N; ++e) {
-                o[e] = (v[i][e] - mean) * rstd;
-                if (gamma) o[e] *= gamma[c * N + e];
-                if (beta) o[e] += beta[c * N + e];
-            }
-            StN<TO, N>::st(yr + c * N, o);
+            for (int e = 0; e < N; ++e) o[e] = (a[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
+            if (live && sl + WIDTH * i < nch) StN<TO, N>::st(yr + cc[i] * N, o);
         }
+    };
+    long long g = gw;
+    if (g >= groups) return;
+    load(cur, g);
+    for (; g < groups; g += 2 * nw) {
+        step(cur, nxt, g);
+        step(nxt, cur, g + nw);
     }
 }
 
@@ -677,23 +720,32 @@ int mv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void*
     const int nch = C / epc;
     if (C % epc == 0 && xs % epc == 0 && nch <= 64 * 8 && !get_flag("force_generic")) {
         set_kernel_name("layernorm_vec");
-#define GO3(TI, TO, CH) \
-    hipLaunchKernelGGL((layernorm_vec_kernel<TI, TO, CH>), grid, block, 0, st, (const TI*)x, gamma, beta, (TO*)y, \
+        const int width = nch <= 16 ? 16 : (nch <= 32 ? 32 : 64);
+        const int rpw = 64 / width;
+        const long long groups = (M + rpw - 1) / rpw;
+        long long nb = (groups + 3) / 4;
+        if (nb > 256 * 8) nb = 256 * 8;
+        dim3 vgrid((unsigned)nb), vblock(256);
+#define GO4(TI, TO, CH, WD) \
+    hipLaunchKernelGGL((layernorm_vec_kernel<TI, TO, CH, WD>), vgrid, vblock, 0, st, (const TI*)x, gamma, beta, (TO*)y, \
                        (long long)M, C, xs, eps)
-#define GO2(TI, TO)                         \
-    do {                                    \
-        if (nch <= 64) GO3(TI, TO, 1);      \
-        else if (nch <= 128) GO3(TI, TO, 2);\
-        else if (nch <= 192) GO3(TI, TO, 3);\
-        else if (nch <= 256) GO3(TI, TO, 4);\
-        else GO3(TI, TO, 8);                \
+#define GO2(TI, TO)                                   \
+    do {                                              \
+        if (width == 16) GO4(TI, TO, 1, 16);          \
+        else if (width == 32) GO4(TI, TO, 1, 32);     \
+        else if (nch <= 64) GO4(TI, TO, 1, 64);       \
+        else if (nch <= 128) GO4(TI, TO, 2, 64);      \
+        else if (nch <= 192) GO4(TI, TO, 3, 64);      \
+        else if (nch <= 256) GO4(TI, TO, 4, 64);      \
+        else if (nch <= 384) GO4(TI, TO, 6, 64);      \
+        else GO4(TI, TO, 8, 64);                      \
     } while (0)
         if (in_dtype == MV_BF16 && out_dtype == MV_BF16) GO2(bf16_t, bf16_t);
         else if (in_dtype == MV_BF16 && out_dtype == MV_F32) GO2(bf16_t, float);
         else if (in_dtype == MV_F32 && out_dtype == MV_F32) GO2(float, float);
         else GO2(float, bf16_t);
 #undef GO2
-#undef GO3
+#undef GO4
     } else {
         set_kernel_name("layernorm");
 #define GO(TI, TO)                                                                                         \
@@ -714,7 +766,7 @@ int mv_mha_fwd(const void* qkv, void* out, float* probs, int B, int N, int H, in
     MV_CHECK_ARG(qkv && out && B > 0 && N > 0 && H > 0 && dh > 0, "mha: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (!get_flag("force_generic") && dtype == MV_BF16 && mha_mfma_supported(N, dh, dtype))
-        return mha_mfma_launch(qkv, out, probs, B, N, H, dh, scale, st);
+        return mha_mfma_launch(qkv, 0, out, probs, B, N, H, dh, scale, st);
     MV_CHECK_ARG(H <= 65535 && B <= 65535, "mha: H/B too large for the generic kernel");
     const size_t smem = (size_t)(N + dh) * sizeof(float);
     MV_CHECK_ARG(smem <= 64 * 1024, "mha: sequence too long for the generic kernel (N=%d)", N);
@@ -727,6 +779,34 @@ int mv_mha_fwd(const void* qkv, void* out, float* probs, int B, int N, int H, in
                            (float*)out, probs, B, N, H, dh, scale);
     MV_LAUNCH_CHECK();
     return MV_OK;
+}
+
+int mv_linear_heads_supported(int64_t M, int N, int K, int tokens, int dh, int dtype) {
+    return dtype == MV_BF16 && dh == 64 && N % 64 == 0 && K % 64 == 0 && tokens > 0 && M > 0 && M % tokens == 0 &&
+           M < (1LL << 31) - 256 && igemm2_wanted(M, K, N, 1, 1) && !get_flag("force_generic") && !get_flag("no_igemm2") &&
+           mha_mfma_supported(tokens, dh, dtype);
+}
+
+int mv_linear_heads_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y, int64_t M, int N,
+                        int K, int tokens, int dh, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && w && y, "linear_heads: NULL pointer");
+    if (!mv_linear_heads_supported(M, N, K, tokens, dh, dtype)) {
+        set_error("linear_heads: unsupported shape M=%lld N=%d K=%d tokens=%d dh=%d (ask mv_linear_heads_supported first)",
+                  (long long)M, N, K, tokens, dh);
+        return MV_E_UNSUPPORTED;
+    }
+    return igemm2_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE, MV_BF16, 0,
+                         tokens, (hipStream_t)stream);
+}
+
+int mv_mha_heads_fwd(const void* qkv, void* out, float* probs, int B, int N, int H, int dh, float scale, int dtype,
+                     mv_stream_t stream) {
+    MV_CHECK_ARG(qkv && out && B > 0 && N > 0 && H > 0 && dh > 0, "mha_heads: bad args");
+    if (dtype != MV_BF16 || !mha_mfma_supported(N, dh, dtype)) {
+        set_error("mha_heads: unsupported N=%d dh=%d dtype=%d", N, dh, dtype);
+        return MV_E_UNSUPPORTED;
+    }
+    return mha_mfma_launch(qkv, 1, out, probs, B, N, H, dh, scale, (hipStream_t)stream);
 }
 
 int mv_swin_window_attn_fwd(const void* qkv, const float* bias, void* out, int B, int Hf, int Wf, int C, int heads,

@@ -324,7 +324,8 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
         return stream1x1_launch(x, w, scale, shift, residual, y, M, C, K, act, out_dtype, st);
     // deep-pipelined 8-wave kernel: every real convolution (taps or stride) and the big Linears; the
     // short dense 1x1 layers late in the network (M <= 50k) measured the same or faster on the 128^2 kernel
-    const bool want2 = igemm2_wanted(M, C, K, R, S) && (!dense || M >= 32768 || get_flag("igemm2_tile"));
+    // (measured, tools/swin_sweep.py: with an fp32 residual epilogue the 256-row kernel wins from M = 6272 up)
+    const bool want2 = igemm2_wanted(M, C, K, R, S) && (!dense || M >= 32768 || out_f32 || get_flag("igemm2_tile"));
     int m_off = 0;
     if (!get_flag("no_igemm2") && !get_flag("igemm_tile") && want2) {
         // Main + tail: 256-row tiles fill whole rounds of the 256 CUs; a last, mostly empty round (e.g. 392
@@ -342,7 +343,7 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
         if (main_mt <= 0) main_mt = tm;
         const int m_end = main_mt < tm ? (int)(main_mt * bm) : 0;
         const int rc = igemm2_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act,
-                                     out_dtype, m_end, st);
+                                     out_dtype, m_end, 0, st);
         if (rc != MV_OK || m_end == 0) return rc;
         m_off = m_end;
     }

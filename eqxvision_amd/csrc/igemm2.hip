@@ -29,6 +29,7 @@ struct Igemm2P {
     const bf16_t* zero;
     int N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw;
     int M, tiles_m, tiles_n, act;   // M = rows covered by THIS launch (rows 0 .. M-1)
+    int tok;                        // > 0: head-major output y[b][n/64][t][n%64], rows m = b*tok + t (qkv projection)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -318,7 +319,12 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
                 }
-                Out8<OutT>::st(y + (long long)m * p.K + n, v);
+                long long off = (long long)m * p.K + n;
+                if (p.tok > 0) {          // 64 channels = one head = one 128-byte line: same store width, new home
+                    const int bi = m / p.tok, ti = m - bi * p.tok;
+                    off = (((long long)bi * (p.K >> 6) + (n >> 6)) * p.tok + ti) * 64 + (n & 63);
+                }
+                Out8<OutT>::st(y + off, v);
             }
         }
     }
@@ -364,8 +370,9 @@ int igemm2_tile_shape(long long M, int K, int* bm, int* bn) {
 
 int igemm2_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y,
                   int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
-                  int act, int out_dtype, int m_end, hipStream_t st) {
+                  int act, int out_dtype, int m_end, int tok, hipStream_t st) {
     Igemm2P p;
+    p.tok = tok;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.zero = (const bf16_t*)zero_page(st);
     if (!p.zero) {

@@ -43,8 +43,7 @@ class _VitAttention(Module):
         x = ops.as_rows(x)          # GEMM operand: compute dtype
         if x.kind != "seq":
             raise ValueError(f"_VitAttention expects (tokens, dim), got {x.shape}")
-        qkv = ops.linear(x, self.qkv)                                  # reference :64
-        y, probs = ops.mha(qkv, self.num_heads, self.scale, need_probs)  # reference :65-73
+        y, probs = ops.qkv_attention(x, self.qkv, self.num_heads, self.scale, need_probs)   # reference :64-73
         self.attn_drop(y)                                              # identity (or a loud error) -- reference :71
         y = ops.linear(y, self.proj, residual=residual)                # reference :74 (+ the block's residual)
         y = self.proj_drop(y)

@@ -346,6 +346,31 @@ def mha(qkv: Act, heads: int, scale: float, need_probs: bool):
     return Act(out, "seq", qkv.batched), probs
 
 
+def qkv_attention(x: Act, lin, heads: int, scale: float, need_probs: bool):
+    """qkv Linear + attention core of `_VitAttention` (vit.py:64-73): rows [B,N,D] -> ([B,N,D], probs or None).
+    When the library has the path for this shape the projection writes q/k/v head-major
+    ([B, 3*heads, N, dh]: what the reference's reshape + transpose produce) and the attention kernel reads
+    contiguous heads; otherwise Linear -> [B,N,3D] -> strided attention.  Both are the HIP path."""
+    dt = compute_dtype()
+    x = as_rows(x)
+    if x.t.dtype != TORCH_DT[dt]:
+        x = cast(x, dt)
+    B, N, D = x.t.shape
+    if lin.in_features != D or lin.out_features != 3 * D or D % heads:
+        raise ValueError(f"qkv projection {lin.in_features}->{lin.out_features} does not fit rows of {D} / {heads} heads")
+    dh = D // heads
+    if not _lib.load().mv_linear_heads_supported(B * N, 3 * D, D, N, dh, DT[dt]):
+        return mha(linear(x, lin), heads, scale, need_probs)
+    w, b = prep_linear(lin, dt)
+    qkv = empty((B, 3 * heads, N, dh), TORCH_DT[dt])
+    _lib.call("mv_linear_heads_fwd", _ptr(x.t), _ptr(w), None, _ptr(b), _ptr(qkv), B * N, 3 * D, D, N, dh, DT[dt],
+              stream_ptr())
+    out = empty((B, N, D), TORCH_DT[dt])
+    probs = empty((B, heads, N, N), torch.float32) if need_probs else None
+    _lib.call("mv_mha_heads_fwd", _ptr(qkv), _ptr(out), _ptr(probs), B, N, heads, dh, float(scale), DT[dt], stream_ptr())
+    return Act(out, "seq", x.batched), probs
+
+
 def swin_window_attention(qkv: Act, bias: torch.Tensor, heads: int, window, shift) -> Act:
     B, Hf, Wf, C3 = qkv.t.shape
     C = C3 // 3

@@ -98,6 +98,19 @@ int mv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void*
 int mv_mha_fwd(const void* qkv, void* out, float* probs, int B, int N, int H, int dh, float scale,
                int dtype, mv_stream_t stream);
 
+/* The same two reference lines (vit.py:64 qkv = self.qkv(x); vit.py:65-66 reshape + transpose to
+ * [3, H, N, dh]) with the transposed layout produced by the projection itself: the GEMM epilogue writes
+ * y HEAD-MAJOR [B][3*H][tokens][dh] (rows m = b*tokens + t, column n -> group n/dh), so that every head's
+ * q/k/v block is contiguous for mv_mha_heads_fwd (128-byte pieces at a 3*H*dh stride are served by HBM
+ * at about half rate -- tools/ubench/stride_read.hip).  mv_linear_heads_supported() says whether this
+ * shape has the path (bf16, dh = 64, M a multiple of tokens, large enough for the 256-row GEMM);
+ * otherwise use mv_linear_fwd + mv_mha_fwd. */
+int mv_linear_heads_supported(int64_t M, int N, int K, int tokens, int dh, int dtype);
+int mv_linear_heads_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y,
+                        int64_t M, int N, int K, int tokens, int dh, int dtype, mv_stream_t stream);
+int mv_mha_heads_fwd(const void* qkv_head_major, void* out, float* probs, int B, int N, int H, int dh,
+                     float scale, int dtype, mv_stream_t stream);
+
 /* _shifted_window_attention core (swin.py:123-250) on the qkv Linear2d output:
  * qkv NHWC [B,Hf,Wf,3*C] -> out NHWC [B,Hf,Wf,C]; cyclic shift, window partition/reverse and
  * the shift mask are folded into addressing; bias fp32 [heads][ws*ws][ws*ws] (table[index]). */

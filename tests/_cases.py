@@ -235,7 +235,7 @@ def avgpool_case(N, H, W, C, oh, ow, dtype="bf16", seed=0):
     return run
 
 
-def layernorm_case(M, C, dtype="bf16", generic=False, stride=None, seed=0):
+def layernorm_case(M, C, dtype="bf16", generic=False, stride=None, seed=0, out=None):
     def run():
         L = _lib()
         rng = _rng(seed)
@@ -248,17 +248,18 @@ def layernorm_case(M, C, dtype="bf16", generic=False, stride=None, seed=0):
         b = (0.1 * rng.standard_normal(C)).astype(np.float32)
         ref = O.layernorm_rows(x, g, b, 1e-5)
         xd = dev(xfull, dtype)
-        y = torch.empty((M, C), dtype=xd.dtype, device="cuda")
+        odt = out or dtype
+        y = torch.empty((M, C), dtype=torch.bfloat16 if odt == "bf16" else torch.float32, device="cuda")
         gd, bd = dev(g, "fp32"), dev(b, "fp32")
         L.set_flag("force_generic", 1 if generic else 0)
         try:
             L.call("mv_layernorm_fwd", xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), y.data_ptr(), M, C, rs, 1e-5,
-                   DT[dtype], DT[dtype], _stream())
+                   DT[dtype], DT[odt], _stream())
             kern = L.last_kernel()
         finally:
             L.set_flag("force_generic", 0)
         torch.cuda.synchronize()
-        info = _cmp(host(y), ref, TOL_BF16 if dtype == "bf16" else 1e-4)
+        info = _cmp(host(y), ref, TOL_BF16 if "bf16" in (dtype, odt) else 1e-4)
         info["kernel"] = kern
         return info
     return run
@@ -294,6 +295,48 @@ def mha_case(B, N, H, dh, dtype="bf16", probs=True, generic=False, seed=0, spike
         info["kernel"] = kern
         if probs:
             pi = _cmp(host(pr), a, 2e-3)
+            info["probs_err"] = pi.get("err")
+            info["ok"] = info["ok"] and pi["ok"]
+        return info
+    return run
+
+
+def qkv_heads_case(B, N, H, dh, seed=0, probs=False):
+    """mv_linear_heads_fwd (head-major qkv projection) + mv_mha_heads_fwd vs the oracle's
+    Linear -> reshape/transpose -> attention (reference vit.py:64-73)."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        D = H * dh
+        x = bf(rng.standard_normal((B, N, D)).astype(np.float32))
+        w = bf((rng.standard_normal((3 * D, D)) / np.sqrt(D)).astype(np.float32))
+        b = (0.1 * rng.standard_normal(3 * D)).astype(np.float32)
+        if not L.load().mv_linear_heads_supported(B * N, 3 * D, D, N, dh, DT["bf16"]):
+            return {"ok": False, "err": "mv_linear_heads_supported says no"}
+        qkv_ref = bf(x.reshape(B * N, D).astype(np.float64) @ w.T.astype(np.float64) + b)          # [M, 3D] bf16-rounded
+        t = qkv_ref.reshape(B, N, 3, H, dh).transpose(2, 0, 3, 1, 4).astype(np.float64)      # [3, B, H, N, dh]
+        hm_ref = t.transpose(1, 0, 2, 3, 4).reshape(B, 3 * H, N, dh)
+        scale = dh ** -0.5
+        a = O.softmax((t[0] @ t[1].transpose(0, 1, 3, 2)) * scale, -1).astype(np.float64)
+        ref = (a @ t[2]).transpose(0, 2, 1, 3).reshape(B, N, D)
+        xd, wd, bd = dev(x, "bf16"), dev(w, "bf16"), dev(b, "fp32")
+        qkv = torch.empty((B, 3 * H, N, dh), dtype=torch.bfloat16, device="cuda")
+        y = torch.empty((B, N, D), dtype=torch.bfloat16, device="cuda")
+        pr = torch.empty((B, H, N, N), dtype=torch.float32, device="cuda") if probs else None
+        L.call("mv_linear_heads_fwd", xd.data_ptr(), wd.data_ptr(), None, bd.data_ptr(), qkv.data_ptr(), B * N, 3 * D, D,
+               N, dh, DT["bf16"], _stream())
+        k1 = L.last_kernel()
+        L.call("mv_mha_heads_fwd", qkv.data_ptr(), y.data_ptr(), None if pr is None else pr.data_ptr(), B, N, H, dh,
+               float(scale), DT["bf16"], _stream())
+        k2 = L.last_kernel()
+        torch.cuda.synchronize()
+        i1 = _cmp(host(qkv), hm_ref, TOL_BF16)
+        info = _cmp(host(y), ref, 2 * TOL_BF16)      # attention on a bf16-rounded qkv that may differ by one ulp
+        info["qkv_err"] = i1.get("err")
+        info["ok"] = info["ok"] and i1["ok"]
+        info["kernel"] = k1 + "+" + k2
+        if probs:
+            pi = _cmp(host(pr), a, 4e-3)
             info["probs_err"] = pi.get("err")
             info["ok"] = info["ok"] and pi["ok"]
         return info
@@ -535,7 +578,17 @@ def all_cases():
           ("layernorm/odd_f32", layernorm_case(7, 20, dtype="fp32")),
           ("layernorm/768_f32", layernorm_case(64, 768, dtype="fp32")),
           ("layernorm/1536", layernorm_case(50, 1536)),
-          ("layernorm/3072_f32", layernorm_case(9, 3072, dtype="fp32"))]
+          ("layernorm/3072_f32", layernorm_case(9, 3072, dtype="fp32")),
+          ("layernorm/96_f32_to_bf16_long", layernorm_case(40001, 96, dtype="fp32", out="bf16")),
+          ("layernorm/96_bf16_long", layernorm_case(70001, 96)),
+          ("layernorm/192_bf16_long", layernorm_case(33333, 192)),
+          ("layernorm/384_f32_to_bf16", layernorm_case(9001, 384, dtype="fp32", out="bf16")),
+          ("layernorm/768_f32_to_bf16_long", layernorm_case(20003, 768, dtype="fp32", out="bf16")),
+          ("layernorm/768_bf16_to_f32", layernorm_case(515, 768, out="fp32")),
+          ("layernorm/1_row", layernorm_case(1, 96)),
+          ("layernorm/1536_f32_to_bf16", layernorm_case(6272, 1536, dtype="fp32", out="bf16")),
+          ("layernorm/2048_f32", layernorm_case(33, 2048, dtype="fp32")),
+          ("layernorm/4096_bf16", layernorm_case(17, 4096))]
     c += [("mha/vit_197_64", mha_case(2, 197, 12, 64)),
           ("mha/vit_197_64_noprobs", mha_case(1, 197, 3, 64, probs=False)),
           ("mha/spike", mha_case(1, 197, 2, 64, spike=True)),
@@ -543,7 +596,13 @@ def all_cases():
           ("mha/256_32", mha_case(1, 256, 2, 32)),
           ("mha/generic_8_8", mha_case(1, 8, 4, 8)),
           ("mha/generic_f32", mha_case(1, 50, 2, 16, dtype="fp32")),
-          ("mha/generic_vs_oracle_197", mha_case(1, 197, 2, 64, generic=True))]
+          ("mha/generic_vs_oracle_197", mha_case(1, 197, 2, 64, generic=True)),
+          ("mha/qkv_heads_vit_base", qkv_heads_case(32, 197, 12, 64)),
+          ("mha/qkv_heads_probs_small", qkv_heads_case(24, 197, 4, 64, probs=True, seed=1)),
+          ("mha/qkv_heads_50tok", qkv_heads_case(100, 50, 4, 64, seed=2)),
+          ("mha/many_pairs_persistent", mha_case(70, 197, 12, 64, probs=False, seed=3)),
+          ("mha/many_pairs_225", mha_case(40, 225, 8, 32, probs=True, seed=4)),
+          ("mha/one_pair", mha_case(1, 33, 1, 64, seed=5))]
     c += [("swin/shift3", swin_attn_case(2, 14, 96, 3, 7, 3)),
           ("swin/noshift", swin_attn_case(2, 14, 96, 3, 7, 0)),
           ("swin/window_ge_map", swin_attn_case(1, 7, 192, 6, 7, 3)),
