@@ -111,6 +111,10 @@ int igemm2_launch(const void* x, const void* w, const float* scale, const float*
                   void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
                   int dh, int dw, int act, int out_dtype, int m_end, int tok, hipStream_t stream);
 int igemm2_tile_shape(long long M, int K, int* bm, int* bn);
+int igemm3_wanted(long long M, int C, int K, int R, int S);
+int igemm3_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
+                  void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
+                  int dh, int dw, int act, int out_dtype, int tok, hipStream_t stream);
 int stem_supported(int C, int K, int R, int S, int x_dtype, int out_dtype);
 int stem_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
                 int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act, int x_dtype,

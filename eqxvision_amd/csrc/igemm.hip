@@ -317,6 +317,9 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
     p.act = act;
     const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
     const bool out_f32 = out_dtype == MV_F32;
+    if (get_flag("igemm3") == 2 && igemm3_wanted(M, C, K, R, S))          // forced (tests)
+        return igemm3_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
+                             st);
     if (!get_flag("no_stream") && !get_flag("igemm_tile") && !get_flag("igemm2_tile") &&
         conv3x3c64_supported(C, K, R, S, sh, sw, ph, pw, dh, dw, in_dtype, out_dtype, residual, M))
         return conv3x3c64_launch(x, w, scale, shift, y, N, H, W, act, st);
@@ -326,6 +329,10 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
     // short dense 1x1 layers late in the network (M <= 50k) measured the same or faster on the 128^2 kernel
     // (measured, tools/swin_sweep.py: with an fp32 residual epilogue the 256-row kernel wins from M = 6272 up)
     const bool want2 = igemm2_wanted(M, C, K, R, S) && (!dense || M >= 32768 || out_f32 || get_flag("igemm2_tile"));
+    // phase-alternating 256x256 kernel (igemm3.hip): opt-in while it is being measured (flag igemm3 = 1)
+    if (get_flag("igemm3") >= 1 && !get_flag("igemm_tile") && !get_flag("igemm2_tile") && igemm3_wanted(M, C, K, R, S))
+        return igemm3_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
+                             st);
     int m_off = 0;
     if (!get_flag("no_igemm2") && !get_flag("igemm_tile") && want2) {
         // Main + tail: 256-row tiles fill whole rounds of the 256 CUs; a last, mostly empty round (e.g. 392

@@ -15,50 +15,9 @@
 //          scheduled above it (cdna_hip_programming.md section 5.7).
 //  * vmcnt counts in issue order, so the residual / scale / shift prefetch issued before the ring is
 //    always older than any DMA and never disturbs the counts; there are no stores before the epilogue.
-#include "mfma_common.h"
+#include "igemm_pipe.h"
 
 namespace mv {
-
-struct Igemm2P {
-    const bf16_t* x;
-    const bf16_t* w;
-    const float* scale;
-    const float* shift;
-    const void* residual;
-    void* y;
-    const bf16_t* zero;
-    int N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw;
-    int M, tiles_m, tiles_n, act;   // M = rows covered by THIS launch (rows 0 .. M-1)
-    int tok;                        // > 0: head-major output y[b][n/64][t][n%64], rows m = b*tok + t (qkv projection)
-};
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-template <int IMM> __device__ __forceinline__ void lds_read16(u32x4& dst, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM) : "memory");
-}
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <typename OutT> struct R8;
-template <> struct R8<bf16_t> {
-    uint4 u;
-    __device__ __forceinline__ void load(const bf16_t* p) { u = *(const uint4*)p; }
-    __device__ __forceinline__ void add_to(float* v) const {
-        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[2 * e] += __uint_as_float(w[e] << 16);
-            v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
-        }
-    }
-};
-template <> struct R8<float> {
-    float4 a, b;
-    __device__ __forceinline__ void load(const float* p) { a = *(const float4*)p; b = *(const float4*)(p + 4); }
-    __device__ __forceinline__ void add_to(float* v) const {
-        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-    }
-};
 
 // WM x WN waves (= 8), each TM x TN tiles of 32x32.  BM = 32*TM*WM pixels, BN = 32*TN*WN channels (TN*32 = 64).
 // NST = LDS ring depth (3 for the 256x128 / 256x64 tiles, 2 for 256x256 whose k-tile alone lasts ~2000
@@ -373,6 +332,7 @@ int igemm2_launch(const void* x, const void* w, const float* scale, const float*
                   int act, int out_dtype, int m_end, int tok, hipStream_t st) {
     Igemm2P p;
     p.tok = tok;
+    p.dbg = 0;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.zero = (const bf16_t*)zero_page(st);
     if (!p.zero) {

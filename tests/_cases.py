@@ -528,6 +528,18 @@ def all_cases():
           ("igemm2/t64_forced_K128", conv_nhwc_case(6, 28, 28, 128, 128, 3, 3, pad=1, seed=35, flags=("igemm2_tile=1",))),
           ("igemm2/split_main_tail_3x3", conv_nhwc_case(70, 28, 28, 128, 256, 3, 3, pad=1, act=1, res=True, seed=51, flags=("tail_split",))),
           ("igemm2/split_main_tail_dense", conv_nhwc_case(86, 28, 28, 512, 128, 1, 1, act=1, seed=52, flags=("tail_split",))),
+          ("igemm3/1x1_512_256", conv_nhwc_case(8, 28, 28, 512, 256, 1, 1, act=1, seed=61, flags=("igemm3=2",))),
+          ("igemm3/3x3_128_256", conv_nhwc_case(8, 28, 28, 128, 256, 3, 3, pad=1, act=1, seed=62, flags=("igemm3=2",))),
+          ("igemm3/3x3_s2_C96_K320", conv_nhwc_case(9, 33, 35, 96, 320, 3, 3, stride=2, pad=1, seed=63, flags=("igemm3=2",))),
+          ("igemm3/3x3_dil2_oddM", conv_nhwc_case(3, 37, 41, 64, 192, 3, 3, pad=2, dil=2, seed=64, flags=("igemm3=2",))),
+          ("igemm3/f32out_res", conv_nhwc_case(30, 14, 14, 512, 256, 1, 1, res=True, out="fp32", seed=65, flags=("igemm3=2",))),
+          ("igemm3/bf16_res_relu", conv_nhwc_case(40, 14, 14, 256, 256, 3, 3, pad=1, act=1, res=True, seed=66, flags=("igemm3=2",))),
+          ("igemm3/gelu_tail", conv_nhwc_case(3, 41, 43, 768, 512, 1, 1, act=2, seed=67, flags=("igemm3=2",))),
+          ("igemm3/k32_single_tile", conv_nhwc_case(4, 20, 20, 32, 64, 1, 1, seed=68, flags=("igemm3=2",))),
+          ("igemm3/k64_two_tiles", conv_nhwc_case(4, 20, 20, 64, 96, 1, 1, act=1, seed=69, flags=("igemm3=2",))),
+          ("igemm3/k96_three_tiles", conv_nhwc_case(4, 20, 20, 96, 256, 1, 1, seed=70, flags=("igemm3=2",))),
+          ("igemm3/k128_four_tiles", conv_nhwc_case(4, 20, 20, 128, 256, 1, 1, seed=71, flags=("igemm3=2",))),
+          ("igemm3/5x5", conv_nhwc_case(6, 27, 27, 64, 192, 5, 5, pad=2, act=1, scale=False, seed=72, flags=("igemm3=2",))),
           ("igemm/old_kernel_3x3_128_28", conv_nhwc_case(8, 28, 28, 128, 128, 3, 3, pad=1, act=1, seed=11, flags=("no_igemm2",))),
           ("igemm/old_kernel_1x1_64_256", conv_nhwc_case(4, 56, 56, 64, 256, 1, 1, act=1, res=True, flags=("no_stream",))),
           ("stream/64_256_res", conv_nhwc_case(4, 56, 56, 64, 256, 1, 1, act=1, res=True)),

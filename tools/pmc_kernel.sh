@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes for ONE kernel family: usage tools/pmc_kernel.sh TAG MODEL KERNEL_SUBSTR [BATCH]
+# PMC passes for ONE kernel family: usage [CMD='python tools/one_gemm.py ...'] tools/pmc_kernel.sh TAG MODEL KERNEL_SUBSTR [BATCH]
 TAG=${1:-pk}; MODEL=${2:-vit_base}; KSUB=${3:-mha}; BATCH=${4:-256}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
@@ -10,7 +10,8 @@ P4="GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_IFETCH SQ_LDS_DATA_FIFO_FUL
 i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $O/p$i -o p$i -- python bench.py --model $MODEL --batch $BATCH --steps 1 --warmup 3 --no-cpu --no-graph > $O/p$i.log 2>&1
+  if [ -n "$CMD" ]; then RUN="$CMD"; else RUN="python bench.py --model $MODEL --batch $BATCH --steps 1 --warmup 3 --no-cpu --no-graph"; fi
+  timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $O/p$i -o p$i -- $RUN > $O/p$i.log 2>&1
 done
 find $O -name "*.db" -delete
 KSUB=$KSUB O=$O python - <<'PY'
