@@ -33,6 +33,8 @@ PROTOTYPES = {
     "mv_adaptive_avgpool2d_nhwc_fwd": [_vp, _vp] + [_i] * 6 + [_i, _i, _vp],
     "mv_layernorm_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _i64, _f, _i, _i, _vp],
     "mv_mha_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "mv_stem_conv_pool_supported": [_i] * 14 + [_i64],
+    "mv_stem_conv_pool_fwd": [_vp, _vp, _vp, _vp, _vp] + [_i] * 17 + [_vp],
     "mv_linear_heads_supported": [_i64, _i, _i, _i, _i, _i],
     "mv_linear_heads_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
     "mv_mha_heads_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],

@@ -655,6 +655,27 @@ int mv_conv2d_nchw_fwd(const void* x, const void* w, const float* scale, const f
     return conv_generic_dispatch(x, w, scale, shift, nullptr, y, pos, p, x_dtype, out_dtype, out_dtype, st);
 }
 
+int mv_stem_conv_pool_supported(int C, int K, int R, int S, int sh, int sw, int ph, int pw, int pool_k, int pool_s,
+                                int pool_p, int act, int x_dtype, int out_dtype, int64_t in_elems) {
+    return !get_flag("force_generic") && !get_flag("no_stem_pool") &&
+           stem_pool_supported(C, K, R, S, sh, sw, ph, pw, pool_k, pool_s, pool_p, act, x_dtype, out_dtype, in_elems);
+}
+
+int mv_stem_conv_pool_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
+                          int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int pool_k, int pool_s,
+                          int pool_p, int act, int x_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && w && y, "stem_conv_pool: NULL pointer");
+    MV_CHECK_ARG(N > 0 && H > 0 && W > 0, "stem_conv_pool: non-positive dims");
+    if (!mv_stem_conv_pool_supported(C, K, R, S, sh, sw, ph, pw, pool_k, pool_s, pool_p, act, x_dtype, out_dtype,
+                                     (int64_t)N * C * H * W)) {
+        set_error("stem_conv_pool: unsupported configuration (ask mv_stem_conv_pool_supported first)");
+        return MV_E_UNSUPPORTED;
+    }
+    const int Ho = (H + 2 * ph - R) / sh + 1, Wo = (W + 2 * pw - S) / sw + 1;
+    MV_CHECK_ARG(Ho >= pool_k - pool_p && Wo >= pool_k - pool_p, "stem_conv_pool: image too small");
+    return stem_pool_launch(x, w, scale, shift, y, N, H, W, x_dtype, (hipStream_t)stream);
+}
+
 int mv_linear_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                   void* y, int64_t M, int N, int K, int act, int in_dtype, int out_dtype, mv_stream_t stream) {
     MV_CHECK_ARG(x && w && y, "linear: NULL pointer");

@@ -182,8 +182,10 @@ class ResNet(Module):
 
     @boundary
     def _forward(self, x):
-        x = ops.conv2d(x, self.conv1, self.bn1, "relu")       # stem straight from the NCHW image
-        x = self.maxpool(x)
+        if isinstance(self.maxpool, nn.MaxPool2d):
+            x = ops.stem_conv_pool(x, self.conv1, self.bn1, "relu", self.maxpool)   # reference :243-254, one launch
+        else:
+            x = self.maxpool(ops.conv2d(x, self.conv1, self.bn1, "relu"))
         x = self.layer1(x)
         x = self.layer2(x)
         x = self.layer3(x)

@@ -203,6 +203,34 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
     return Act(y, "map", x.batched)
 
 
+def stem_conv_pool(x: Act, conv, bn, act, pool) -> Act:
+    """ResNet entry (resnet.py:243-254): conv1 + bn1 + relu + maxpool.  One launch when the library has the fused
+    path for this configuration (the 112x112x64 map then never reaches HBM), else conv2d followed by maxpool2d."""
+    _check_bn(bn)
+    dt = compute_dtype()
+    kh, kw = conv.kernel_size
+    sh, sw = conv.stride
+    ph, pw = conv.padding
+    pk, ps, pp = _pair(pool.kernel_size), _pair(pool.stride), _pair(pool.padding)
+    fused = (x.kind == "img" and conv.groups == 1 and tuple(conv.dilation) == (1, 1) and pk[0] == pk[1] and ps[0] == ps[1]
+             and pp[0] == pp[1] and x.t.dim() == 4 and x.t.shape[1] == conv.in_channels)
+    if fused:
+        B, C, H, W = x.t.shape
+        fused = bool(_lib.load().mv_stem_conv_pool_supported(C, conv.out_channels, kh, kw, sh, sw, ph, pw, pk[0], ps[0], pp[0],
+                                                              ACT[act], x.dt, DT[dt], B * C * H * W))
+    if not fused:
+        return maxpool2d(conv2d(x, conv, bn, act), pool.kernel_size, pool.stride, pool.padding)
+    w, scale, shift = prep_conv(conv, bn, "oihw", dt)
+    Ho = (H + 2 * ph - kh) // sh + 1
+    Wo = (W + 2 * pw - kw) // sw + 1
+    Po = (Ho + 2 * pp[0] - pk[0]) // ps[0] + 1
+    Qo = (Wo + 2 * pp[0] - pk[0]) // ps[0] + 1
+    y = empty((B, Po, Qo, conv.out_channels), TORCH_DT[dt])
+    _lib.call("mv_stem_conv_pool_fwd", _ptr(x.t), _ptr(w), _ptr(scale), _ptr(shift), _ptr(y), B, C, H, W, conv.out_channels,
+              kh, kw, sh, sw, ph, pw, pk[0], ps[0], pp[0], ACT[act], x.dt, DT[dt], stream_ptr())
+    return Act(y, "map", x.batched)
+
+
 def linear(x: Act, lin, act=None, residual: Optional[Act] = None, out_fp32: bool = False) -> Act:
     """Linear over the last (feature) axis of rows: seq [B,N,D], vec [B,D] or map (Linear2d)."""
     dt = compute_dtype()

@@ -70,6 +70,20 @@ int mv_conv2d_nchw_fwd(const void* x, const void* w, const float* scale, const f
                        int sh, int sw, int ph, int pw, int act, int x_dtype, int out_dtype,
                        int tok_stride, int tok_offset, const float* pos, mv_stream_t stream);
 
+/* The ResNet network entry in one launch (resnet.py:243-254: conv1 -> bn1 -> relu -> maxpool):
+ * x NCHW [N,C,H,W] of x_dtype, w OIHW, folded BN scale/shift, y NHWC [N][Po][Qo][K] with
+ * (Ho, Wo) the convolution's and (Po, Qo) the MaxPool2d(pool_k, pool_s, pool_p) output size.  The conv map
+ * never reaches HBM.  mv_stem_conv_pool_supported() says whether the configuration has the path
+ * (C=3, K=64, 7x7/2 pad 3, pool 3/2 pad 1, ReLU, bf16 out); otherwise mv_conv2d_nchw_fwd +
+ * mv_maxpool2d_nhwc_fwd. */
+int mv_stem_conv_pool_supported(int C, int K, int R, int S, int sh, int sw, int ph, int pw,
+                                int pool_k, int pool_s, int pool_p, int act, int x_dtype, int out_dtype,
+                                int64_t in_elems);
+int mv_stem_conv_pool_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y,
+                          int N, int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw,
+                          int pool_k, int pool_s, int pool_p, int act, int x_dtype, int out_dtype,
+                          mv_stream_t stream);
+
 /* eqx.nn.Linear under vmap / Linear2d (vit.py:64,74; mlps.py:60-64; resnet.py:356;
  * extensions_2d.py:31-50):  y[M,N] = act(scale[n]*(x[M,K] . w[N,K]^T) + shift[n] + residual[M,N]) */
 int mv_linear_fwd(const void* x, const void* w, const float* scale, const float* shift,

@@ -235,6 +235,42 @@ def avgpool_case(N, H, W, C, oh, ow, dtype="bf16", seed=0):
     return run
 
 
+def stem_pool_case(N, H, W, xdtype="fp32", seed=0, neg_scale=False):
+    """mv_stem_conv_pool_fwd (conv 7x7/2 + BN + ReLU + maxpool 3/2/1, one launch) vs the oracle chain
+    conv2d -> scale/shift -> relu -> (bf16 rounding) -> maxpool2d (reference resnet.py:243-254)."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        C, K, R = 3, 64, 7
+        x = rng.random((N, C, H, W), dtype=np.float32) * 2 - 0.7
+        if xdtype == "bf16":
+            x = bf(x)
+        w = bf(rng.standard_normal((K, C, R, R)) / np.sqrt(C * R * R))
+        sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        if neg_scale:
+            sc[::3] *= -1.0            # BN gamma may be negative: scale/shift must be applied BEFORE the max
+        sf = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        if not L.load().mv_stem_conv_pool_supported(C, K, R, R, 2, 2, 3, 3, 3, 2, 1, 1, DT[xdtype], 1, N * C * H * W):
+            return {"ok": False, "err": "mv_stem_conv_pool_supported says no"}
+        xr = bf(x)
+        conv = np.stack([O.conv2d(xr[i], w, None, 2, 3) for i in range(N)]) * sc[None, :, None, None] + sf[None, :, None, None]
+        conv = bf(O.relu(conv))
+        ref = np.stack([O.maxpool2d(conv[i], 3, 2, 1) for i in range(N)])          # [N, K, Po, Qo]
+        Po, Qo = ref.shape[2], ref.shape[3]
+        ref = ref.transpose(0, 2, 3, 1)
+        xd, wd = dev(x, xdtype), dev(w, "bf16")
+        scd, sfd = dev(sc, "fp32"), dev(sf, "fp32")
+        y = torch.full((N, Po, Qo, K), -7.0, dtype=torch.bfloat16, device="cuda")
+        L.call("mv_stem_conv_pool_fwd", xd.data_ptr(), wd.data_ptr(), scd.data_ptr(), sfd.data_ptr(), y.data_ptr(),
+               N, C, H, W, K, R, R, 2, 2, 3, 3, 3, 2, 1, 1, DT[xdtype], 1, _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, TOL_BF16)
+        info["kernel"] = kern
+        return info
+    return run
+
+
 def layernorm_case(M, C, dtype="bf16", generic=False, stride=None, seed=0, out=None):
     def run():
         L = _lib()
@@ -575,6 +611,11 @@ def all_cases():
           ("stem/resnet7x7_tablekernel", conv_nchw_case(2, 3, 64, 64, 64, 7, 7, 2, 3, act=1, v0=True)),
           ("stem/vit_tokens_tablekernel", conv_nchw_case(1, 3, 64, 64, 768, 16, 16, 16, 0, tokens=True, v0=True)),
           ("stem/alexnet_224", conv_nchw_case(1, 3, 224, 224, 64, 11, 11, 4, 2, act=1, seed=2)),
+          ("stem/pool_fused_224", stem_pool_case(3, 224, 224, seed=6)),
+          ("stem/pool_fused_64_bf16in", stem_pool_case(2, 64, 64, xdtype="bf16", seed=7)),
+          ("stem/pool_fused_odd_75x93", stem_pool_case(2, 75, 93, seed=8)),
+          ("stem/pool_fused_negative_gamma", stem_pool_case(2, 96, 96, seed=9, neg_scale=True)),
+          ("stem/pool_fused_many_tiles", stem_pool_case(40, 128, 128, seed=10)),
           ("stem/vit_224_bf16in", conv_nchw_case(2, 3, 224, 224, 768, 16, 16, 16, 0, tokens=True, xdtype="bf16")),
           ("stem/patch8_notokens", conv_nchw_case(3, 3, 40, 48, 192, 8, 8, 8, 0)),
           ("stem/odd_size_7x7", conv_nchw_case(1, 3, 61, 75, 32, 7, 7, 2, 3, act=1))]
