@@ -54,18 +54,12 @@ __global__ __launch_bounds__(320, 2) void stem_pool_kernel(const StemPoolP p) {
     char* wl = smem;
     bf16_t* patch = (bf16_t*)(smem + OFF_PATCH);
     char* ctile = smem + OFF_CTILE;
-    int* ftab = (int*)(smem + OFF_FTAB);
-    float* sct = (float*)(smem + OFF_FTAB + 96);
+    float* sct = (float*)(smem + OFF_FTAB);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
 
-    // fragment table + weight slab (k' = (c, r, s8) order, zero padded), once per block
-    if (tid < 2 * NK16) {
-        const int ff = tid < NFRAG ? tid : NFRAG - 1;       // the padding fragment: any in-bounds address (weights are 0)
-        const int r = ff % R, c = ff / R;
-        ftab[tid] = (c * PH + r) * PWp;
-    }
+    // weight slab (k' = (c, r, s8) order, zero padded), once per block
     for (int i = tid; i < K * 2 * NK16; i += NT) {
         const int row = i / (2 * NK16), f = i - row * (2 * NK16);
         uint32_t u[4] = {0, 0, 0, 0};
@@ -140,7 +134,11 @@ __global__ __launch_bounds__(320, 2) void stem_pool_kernel(const StemPoolP p) {
 #pragma unroll
             for (int kk = 0; kk < NK16; ++kk) {
                 const int f = 2 * kk + fh;
-                const uint32_t* src = (const uint32_t*)(patch + lbase + ftab[f]);   // 4-byte aligned
+                // fragment f = (c, r) starts at patch element (c*PH + r)*PWp: two compile-time constants selected by
+                // the lane half (an LDS table here put TWO dependent LDS round trips in front of every MFMA pair)
+                const int f0 = 2 * kk < NFRAG ? 2 * kk : NFRAG - 1, f1 = 2 * kk + 1 < NFRAG ? 2 * kk + 1 : NFRAG - 1;
+                const int o0 = ((f0 / R) * PH + f0 % R) * PWp, o1 = ((f1 / R) * PH + f1 % R) * PWp;
+                const uint32_t* src = (const uint32_t*)(patch + lbase + (fh ? o1 : o0));   // 4-byte aligned
                 const uint4 bv = make_uint4(src[0], src[1], src[2], src[3]);
                 const uint4 a0 = *(const uint4*)(wl + fr * WPITCH + f * 16);
                 const uint4 a1 = *(const uint4*)(wl + (32 + fr) * WPITCH + f * 16);
@@ -221,7 +219,7 @@ int stem_pool_launch(const void* x, const void* w, const float* scale, const flo
     p.tiles = (int)tiles;
     int gx = p.tiles < 512 ? p.tiles : 512;               // two persistent blocks per CU
     set_kernel_name(x_dtype == MV_F32 ? "stem_pool_mfma_f32in" : "stem_pool_mfma_bf16in");
-    constexpr int SMEM = 64 * 368 + 9360 + 289 * 144 + 96 + 128 * 4;
+    constexpr int SMEM = 64 * 368 + 9360 + 289 * 144 + 128 * 4;
 #define GO(TX_)                                                                                                  \
     do {                                                                                                         \
         auto kern = stem_pool_kernel<TX_>;                                                                       \
