@@ -13,7 +13,12 @@
 //   * there is NO block barrier in the steady state: 8 waves per CU free-run over a grid-stride list of
 //     pixel tiles, so loads, MFMAs and stores of different waves overlap continuously;
 //   * the epilogue is the igemm one: fp32 scale/shift in the accumulator layout, transpose through a
-//     wave-private LDS patch, then 16-byte-per-lane full-line NHWC stores.
+//     wave-private LDS patch, then 16-byte-per-lane full-line NHWC stores;
+//   * a block keeps as many 128-channel slabs of W as fit in LDS (`npass`) and runs them one after the other on
+//     the SAME x fragments, so x is read once per block row instead of once per channel tile (Swin C=96 ->
+//     288 / 384, ResNet 64 -> 256), and two pixel tiles are in flight per wave (two fragment sets, each refilled
+//     a whole tile before its next use): with one 6 KB tile per wave in flight the K=96 layers were
+//     latency-bound at 3.3 TB/s.
 #include "mfma_common.h"
 
 namespace mv {
@@ -27,6 +32,7 @@ struct StreamP {
     void* y;
     int M, K, N;          // rows, reduction, output channels
     int tiles_m, act, wpitch;
+    int npass;            // 128-channel slabs of W resident per block (channel tiles blockIdx.y*npass ...)
 };
 
 template <typename OutT> struct SRes8;
@@ -50,29 +56,31 @@ template <> struct SRes8<float> {
     }
 };
 
-// TN = 32-channel MFMA tiles per wave (BN = 32*TN), KC = K/16 MFMA k-steps, WAVES per block.
+// TN = 32-channel MFMA tiles per wave and pass (BN = 32*TN), KC = K/16 MFMA k-steps, WAVES per block.
 template <int TN, int KC, int WAVES, typename OutT>
 __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) {
     constexpr int BN = 32 * TN;
     constexpr int EPITCH = 64 * 4 + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* wl = smem;                                            // [BN][wpitch]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    char* ep = smem + BN * p.wpitch + wave * (32 * EPITCH);     // wave-private epilogue patch
-    const int n0 = blockIdx.y * BN;
+    const int rows = p.npass * BN;                              // weight rows resident in this block
+    char* wl = smem;                                            // [rows][wpitch]
+    float* sct = (float*)(smem + rows * p.wpitch);              // [2][rows]: scale, shift of the block's channels
+    char* ep = (char*)(sct + 2 * rows) + wave * (32 * EPITCH);  // wave-private epilogue patch
+    const int nb = blockIdx.y * rows;                           // first channel of the block
     const int K = KC * 16;
 
-    // ---- weight slab -> LDS (once).  16-byte chunks, zero rows past N.
+    // ---- weight slab + scale / shift -> LDS (once).  16-byte chunks, zero rows past N.
     {
         constexpr int CH = KC * 2;                              // 16-byte chunks per row
-        for (int base = 0; base < BN * CH; base += WAVES * 64 * 4) {
+        for (int base = 0; base < rows * CH; base += WAVES * 64 * 4) {
             uint4 v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = base + j * WAVES * 64 + tid;
                 const int row = i / CH, ch = i - row * CH;
-                const int n = n0 + row;
-                const bool ok = i < BN * CH && n < p.N;
+                const int n = nb + row;
+                const bool ok = i < rows * CH && n < p.N;
                 v[j] = *(const uint4*)(p.w + (ok ? (long long)n * K + ch * 8 : 0));
                 if (!ok) v[j] = make_uint4(0, 0, 0, 0);
             }
@@ -80,8 +88,13 @@ __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) 
             for (int j = 0; j < 4; ++j) {
                 const int i = base + j * WAVES * 64 + tid;
                 const int row = i / CH, ch = i - row * CH;
-                if (i < BN * CH) *(uint4*)(wl + row * p.wpitch + ch * 16) = v[j];
+                if (i < rows * CH) *(uint4*)(wl + row * p.wpitch + ch * 16) = v[j];
             }
+        }
+        for (int i = tid; i < rows; i += WAVES * 64) {
+            const int n = nb + i;
+            sct[i] = (p.scale && n < p.N) ? p.scale[n] : 1.f;
+            sct[rows + i] = (p.shift && n < p.N) ? p.shift[n] : 0.f;
         }
     }
     __syncthreads();
@@ -90,7 +103,7 @@ __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) 
     const int gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
     OutT* y = (OutT*)p.y;
     const OutT* res = (const OutT*)p.residual;
-    const char* wfrag = wl + fr * p.wpitch + fh * 16;           // + a*32*wpitch + kk*32
+    const char* wfrag = wl + fr * p.wpitch + fh * 16;           // + (pass*BN + a*32)*wpitch + kk*32
 
     auto load_x = [&](uint4* xf, int tile) {
         int m = tile * 32 + fr;
@@ -99,12 +112,7 @@ __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) 
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) xf[kk] = *(const uint4*)(src + kk * 16);
     };
-
-    ScaleShift8 ss[TN / 2];
-#pragma unroll
-    for (int c = 0; c < TN / 2; ++c) ss[c].load(p.scale, p.shift, n0 + c * 64 + (lane & 7) * 8, p.N);
-
-    auto load_res = [&](SRes8<OutT> (*rr)[4], int tile) {
+    auto load_res = [&](SRes8<OutT> (*rr)[4], int tile, int n0) {
 #pragma unroll
         for (int c = 0; c < TN / 2; ++c)
 #pragma unroll
@@ -116,69 +124,87 @@ __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) 
             }
     };
 
-    // ONE register set for the x fragments and ONE for the residual rows, each refilled for the next tile
-    // immediately after its last use: the x refill flies during the epilogue, the residual refill during
-    // the next tile's MFMAs.  (A second buffer would cost 64-128 VGPRs at K = 256 and halve the occupancy.)
-    uint4 xa[KC];
+    // One pixel tile: every resident channel slab on the same fragments, then the fragments are refilled for the
+    // tile two strides ahead (`refill`), a whole tile of work before they are needed again.
     SRes8<OutT> rr[TN / 2][4];
-    int tile = gw;
-    if (tile < p.tiles_m) {
-        load_x(xa, tile);
-        if (res) load_res(rr, tile);
-    }
-    for (; tile < p.tiles_m; tile += nw) {
-        const int nxt = tile + nw;
-        f32x16 acc[TN];
+    auto run_tile = [&](uint4* xf, int tile, int refill) {
+        for (int ps = 0; ps < p.npass; ++ps) {
+            const int n0 = nb + ps * BN;
+            if (n0 >= p.N) break;
+            if (res) load_res(rr, tile, n0);                   // flies under this slab's MFMAs
+            f32x16 acc[TN];
 #pragma unroll
-        for (int a = 0; a < TN; ++a)
+            for (int a = 0; a < TN; ++a)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+            const char* wf = wfrag + (size_t)ps * BN * p.wpitch;
 #pragma unroll
-        for (int kk = 0; kk < KC; ++kk) {
+            for (int kk = 0; kk < KC; ++kk) {
 #pragma unroll
-            for (int a = 0; a < TN; ++a) {
-                const uint4 av = *(const uint4*)(wfrag + a * 32 * p.wpitch + kk * 32);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
-                                                                 __builtin_bit_cast(bf16x8, xa[kk]), acc[a], 0, 0, 0);
-            }
-        }
-        if (nxt < p.tiles_m) load_x(xa, nxt);                  // refill right after the last MFMA read them
-        // epilogue: accumulator layout -> LDS patch -> row-major full lines
-#pragma unroll
-        for (int c = 0; c < TN / 2; ++c) {
-#pragma unroll
-            for (int a2 = 0; a2 < 2; ++a2) {
-                const int a = 2 * c + a2;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int nl = a2 * 32 + 8 * g + 4 * fh;
-                    float4 v = make_float4(acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3]);
-                    *(float4*)(ep + fr * EPITCH + nl * 4) = v;
+                for (int a = 0; a < TN; ++a) {
+                    const uint4 av = *(const uint4*)(wf + a * 32 * p.wpitch + kk * 32);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                     __builtin_bit_cast(bf16x8, xf[kk]), acc[a], 0, 0, 0);
                 }
             }
+            if ((ps == p.npass - 1 || n0 + BN >= p.N) && refill < p.tiles_m) load_x(xf, refill);
+            // epilogue: accumulator layout -> LDS patch -> row-major full lines
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int row = pass * 8 + (lane >> 3), c8 = lane & 7;
-                const int m = tile * 32 + row;
-                const int n = n0 + c * 64 + c8 * 8;
-                const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
-                const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
-                if (m < p.M && n < p.N) {
-                    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    ss[c].apply(v);
-                    if (res) rr[c][pass].add_to(v);
-                    if (p.act == MV_ACT_RELU) {
+            for (int c = 0; c < TN / 2; ++c) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                    } else if (p.act == MV_ACT_GELU_TANH) {
+                for (int a2 = 0; a2 < 2; ++a2) {
+                    const int a = 2 * c + a2;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                    for (int g = 0; g < 4; ++g) {
+                        const int nl = a2 * 32 + 8 * g + 4 * fh;
+                        float4 v = make_float4(acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3]);
+                        *(float4*)(ep + fr * EPITCH + nl * 4) = v;
                     }
-                    Out8<OutT>::st(y + (long long)m * p.N + n, v);
+                }
+                const int c8 = lane & 7;
+                const int nloc = ps * BN + c * 64 + c8 * 8;        // my 8 channels inside the block's slab set
+                const float4 s0 = *(const float4*)(sct + nloc), s1 = *(const float4*)(sct + nloc + 4);
+                const float4 h0 = *(const float4*)(sct + rows + nloc), h1 = *(const float4*)(sct + rows + nloc + 4);
+                const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int row = pass * 8 + (lane >> 3);
+                    const int m = tile * 32 + row;
+                    const int n = n0 + c * 64 + c8 * 8;
+                    const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
+                    const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
+                    if (m < p.M && n < p.N) {
+                        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], scv[e], shv[e]);
+                        if (res) rr[c][pass].add_to(v);
+                        if (p.act == MV_ACT_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                        } else if (p.act == MV_ACT_GELU_TANH) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                        }
+                        Out8<OutT>::st(y + (long long)m * p.N + n, v);
+                    }
                 }
             }
         }
-        if (res && nxt < p.tiles_m) load_res(rr, nxt);
+    };
+
+    constexpr bool X2 = KC <= 8;                                // two fragment sets: 2 x KC x 4 VGPRs (K = 256 would spill)
+    uint4 xa[KC], xb[X2 ? KC : 1];
+    int tile = gw;
+    if (tile < p.tiles_m) load_x(xa, tile);
+    if constexpr (X2) {
+        if (tile + nw < p.tiles_m) load_x(xb, tile + nw);
+        for (; tile < p.tiles_m; tile += 2 * nw) {
+            run_tile(xa, tile, tile + 2 * nw);
+            if (tile + nw < p.tiles_m) run_tile(xb, tile + nw, tile + 3 * nw);
+        }
+    } else {
+        for (; tile < p.tiles_m; tile += nw) run_tile(xa, tile, tile + nw);
     }
 }
 
@@ -189,14 +215,21 @@ int stream1x1_supported(int C, int K, int in_dtype, int out_dtype, long long M) 
 }
 
 template <int TN, int KC, typename OutT>
-static int stream_go(const StreamP& p, int tiles_n, hipStream_t st) {
+static int stream_go(StreamP& p, int tiles_n, hipStream_t st) {
     constexpr int WAVES = 8;
-    const size_t smem = (size_t)32 * TN * p.wpitch + (size_t)WAVES * 32 * (64 * 4 + 16);
-    int gx = 256 / tiles_n;                                   // ~one block per CU in total
+    // as many channel slabs per block as LDS holds next to the epilogue patches (160 KB per CU, one block per CU)
+    const size_t slab = (size_t)32 * TN * p.wpitch + (size_t)2 * 32 * TN * 4, patches = (size_t)WAVES * 32 * (64 * 4 + 16);
+    int npass = (int)((160 * 1024 - 1024 - patches) / slab);
+    if (npass > tiles_n) npass = tiles_n;
+    if (npass < 1 || get_flag("stream_npass1")) npass = 1;
+    p.npass = npass;
+    const int gy = (tiles_n + npass - 1) / npass;
+    const size_t smem = slab * npass + patches;
+    int gx = 256 / gy;                                        // ~one block per CU in total
     if (gx < 1) gx = 1;
     const int need = (p.tiles_m + WAVES - 1) / WAVES;
     if (gx > need) gx = need;
-    dim3 grid(gx, tiles_n), block(WAVES * 64);
+    dim3 grid(gx, gy), block(WAVES * 64);
     auto kern = stream1x1_kernel<TN, KC, WAVES, OutT>;
     if (smem > 48 * 1024)
         MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
