@@ -250,7 +250,7 @@ def main():
         dom_tflops = dv["gflop"] / dv["us"] * 1e3 if dv["us"] else 0.0   # GFLOP/us = PFLOP/s
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per launch, if collected
-        if os.path.exists(tj):
+        if os.path.exists(tj) and a.batch == 256 and world == 1:      # the counters were collected on the B=256, 1-GPU workload
             try:
                 traffic = json.load(open(tj)).get(a.model, {}).get(dk)
             except Exception:  # noqa: BLE001

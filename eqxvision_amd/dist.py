@@ -22,10 +22,15 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    # test hooks (a 1-GPU box cannot host two RCCL ranks): EQV_DIST_BACKEND=gloo, EQV_DIST_DEVICE=0 put every rank on
+    # one device with a host-staged collective so the multi-rank control flow of bench.py can be exercised
+    backend = backend or os.environ.get("EQV_DIST_BACKEND")
+    if "EQV_DIST_DEVICE" in os.environ:
+        local = int(os.environ["EQV_DIST_DEVICE"])
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if torch.cuda.is_available():
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
