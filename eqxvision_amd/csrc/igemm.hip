@@ -329,10 +329,22 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
     // short dense 1x1 layers late in the network (M <= 50k) measured the same or faster on the 128^2 kernel
     // (measured, tools/swin_sweep.py: with an fp32 residual epilogue the 256-row kernel wins from M = 6272 up)
     const bool want2 = igemm2_wanted(M, C, K, R, S) && (!dense || M >= 32768 || out_f32 || get_flag("igemm2_tile"));
-    // phase-alternating 256x256 kernel (igemm3.hip): opt-in while it is being measured (flag igemm3 = 1)
-    if (get_flag("igemm3") >= 1 && !get_flag("igemm_tile") && !get_flag("igemm2_tile") && igemm3_wanted(M, C, K, R, S))
-        return igemm3_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
-                             st);
+    // Phase-alternating 256x256 kernel (igemm3.hip) instead of igemm2's 256x128 tile when it saves rounds of CUs.
+    // Measured on ResNet-50 / ViT-B / Swin-T (profiles/r01): per unit of tile area igemm3 runs ~1.09x faster than
+    // igemm2 256x128, so it wins when 2 * rounds(256x256 tiles) / 1.09 < rounds(256x128 tiles) -- the layers where
+    // halving the tile count removes a mostly empty last round (14x14 3x3: 392 -> 196 tiles, 81 -> 75 us; strided
+    // 1x1 56x56x256 -> 28x28x512: 135 -> 122 us) -- and loses otherwise (ViT fc2 / proj: 3 rounds of 256x256 vs 5 of
+    // 256x128).  igemm2's own 256x256 tile (K >= 1024) stays: same tile count, 5% faster main loop there.
+    if (!get_flag("no_igemm3") && !get_flag("igemm_tile") && !get_flag("igemm2_tile") && want2 && C % 32 == 0 &&
+        (long long)R * S * (C / 32) >= 8) {
+        int bm, bn;
+        const int t2 = igemm2_tile_shape(M, K, &bm, &bn);
+        const long long tm = (M + 255) / 256;
+        const long long r2 = (tm * ((K + 127) / 128) + 255) / 256, r3 = (tm * ((K + 255) / 256) + 255) / 256;
+        if (get_flag("igemm3") == 1 || (t2 == 2 && 1.835 * (double)r3 < (double)r2))
+            return igemm3_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype,
+                                 0, st);
+    }
     int m_off = 0;
     if (!get_flag("no_igemm2") && !get_flag("igemm_tile") && want2) {
         // Main + tail: 256-row tiles fill whole rounds of the 256 CUs; a last, mostly empty round (e.g. 392
