@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--layers", default=None, help="write a per-launch worksheet to this file")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="sub-batches captured as parallel hipGraph branches (fills the last, partial round of CUs of "
+                         "one kernel with the other lane's next kernel); 1 = a single launch list")
     a = ap.parse_args()
 
     import eqxvision_amd as eqv
@@ -194,7 +197,7 @@ def main():
     keys = eqv.random.split(eqv.random.PRNGKey(0), B)
 
     fwd = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k),
-                         use_graph=not a.no_graph, clone_outputs=False)
+                         use_graph=not a.no_graph, clone_outputs=False, lanes=a.lanes)
 
     def step():
         logits = fwd(net, images, keys)
@@ -261,7 +264,8 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"{a.model} {a.dtype} forward, batch={B}/GPU, 3x224x224, 1000 classes",
                        "global_batch": B * world, "parallelism": f"dp{world}", "launches_per_step": len(compiled.calls),
-                       "graph": compiled.graph is not None},
+                       "graph": compiled.graph is not None,
+                       "lanes": len(compiled.lane_calls) if compiled.lane_calls else 1},
             "roofline": {"bound": "mfma", "achieved": round(dom_tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(dom_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel": dk, "launches_per_step": dv["n"],

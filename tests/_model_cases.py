@@ -173,6 +173,41 @@ def jit_case():
     return run
 
 
+def lanes_case(model="resnet", lanes=2, B=6):
+    """filter_jit(lanes=k): sub-batches captured as parallel graph branches must give exactly what the single-lane
+    path gives for the same sub-batch shapes, for fresh inputs on every replay; odd batches fall back to one lane."""
+    def run():
+        import eqxvision_amd as eqv
+        if model == "resnet":
+            sd = S.resnet_state(1, "bottleneck", (1, 1, 1, 1), 10)
+            blk = eqv.models.classification.resnet._ResNetBottleneck
+            fac = lambda torch_weights=None, **kw: eqv.models.classification.resnet._resnet(blk, [1, 1, 1, 1], torch_weights, **kw)
+            net = _load(fac, sd, num_classes=10)
+            size = 64
+        else:
+            sd = S.vit_state(1, 64, 8, 32, 2, 2, 10)
+            net = _load(lambda torch_weights=None, **kw: eqv.models.VisionTransformer(
+                img_size=64, patch_size=8, embed_dim=32, depth=2, num_heads=2, **kw), sd, num_classes=10)
+            size = 64
+        fwd = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k), lanes=lanes)
+        errs = []
+        step = B // lanes
+        for seed in (0, 1, 2, 3):
+            x = S.synthetic_images(B, size, seed=seed)
+            got = fwd(net, x, _keys(B)).cpu().numpy()
+            ref = np.concatenate([eqv.vmap(net, axis_name="batch")(x[l * step:(l + 1) * step], key=_keys(step)).cpu().numpy()
+                                  for l in range(lanes)])
+            errs.append(float(np.abs(got - ref).max()))
+        c = next(iter(fwd._cache.values()))
+        x = S.synthetic_images(B + 1, size, seed=9)          # B+1 not divisible: one lane, still correct
+        got = fwd(net, x, _keys(B + 1)).cpu().numpy()
+        ref = eqv.vmap(net, axis_name="batch")(x, key=_keys(B + 1)).cpu().numpy()
+        errs.append(float(np.abs(got - ref).max()))
+        return {"ok": max(errs) == 0.0 and c.lane_calls is not None and len(c.lane_calls) == lanes and c.graph is not None,
+                "errs": errs, "lanes": None if c.lane_calls is None else len(c.lane_calls)}
+    return run
+
+
 def all_cases(full=True):
     c = [("model/resnet_tiny_bottleneck", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2)),
          ("model/resnet18_64px", resnet_case("basic", (2, 2, 2, 2), 64, 2)),
@@ -182,7 +217,9 @@ def all_cases(full=True):
          ("model/vit_tiny_last_attn", vit_case(32, 8, 64, 2, 2, 2, attn=True)),
          ("model/swin_tiny", swin_case(56, 32, (2, 2), (2, 4), 2)),
          ("model/swin_tiny_fp32", swin_case(56, 32, (2, 2), (2, 4), 1, dtype="fp32")),
-         ("model/filter_jit_replay", jit_case())]
+         ("model/filter_jit_replay", jit_case()),
+         ("model/filter_jit_lanes2_resnet", lanes_case("resnet", 2, 6)),
+         ("model/filter_jit_lanes3_resnet", lanes_case("resnet", 3, 6))]
     if full:
         c += [("model/alexnet_features_B2", alexnet_case(2, features_only=True)),
               ("model/alexnet_B4_bf16", alexnet_case(4)),

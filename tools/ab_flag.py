@@ -15,8 +15,12 @@ images = torch.rand((B, 3, 224, 224), dtype=torch.float32).cuda()
 keys = eqv.random.split(eqv.random.PRNGKey(0), B)
 fw = {}
 for v in (0, 1):
-    _lib.set_flag(flag, v)
-    f = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k), use_graph=True, clone_outputs=False)
+    if flag.startswith("lanes"):
+        f = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k), use_graph=True, clone_outputs=False,
+                           lanes=1 if v == 0 else int(flag[5:] or 2))
+    else:
+        _lib.set_flag(flag, v)
+        f = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k), use_graph=True, clone_outputs=False)
     for _ in range(4): f(net, images, keys)
     fw[v] = f
 torch.cuda.synchronize()
@@ -27,4 +31,4 @@ for r in range(reps):
         for _ in range(20): fw[v](net, images, keys)
         e1.record(); torch.cuda.synchronize()
         print(f"{flag}={v}: {e0.elapsed_time(e1)/20:.4f} ms/step  {B/(e0.elapsed_time(e1)/20)*1e3:.0f} img/s", flush=True)
-_lib.set_flag(flag, 0)
+if not flag.startswith('lanes'): _lib.set_flag(flag, 0)
