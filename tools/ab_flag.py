@@ -20,7 +20,8 @@ for v in (0, 1):
                            lanes=1 if v == 0 else int(flag[5:] or 2))
     else:
         _lib.set_flag(flag, v)
-        f = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k), use_graph=True, clone_outputs=False)
+        f = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k), use_graph=True, clone_outputs=False,
+                           lanes=int(os.environ.get("LANES", "2")))
     for _ in range(4): f(net, images, keys)
     fw[v] = f
 torch.cuda.synchronize()

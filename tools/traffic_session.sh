@@ -6,7 +6,7 @@ TAG=${1:-tr}; MODEL=${2:-resnet50}; BATCH=${3:-256}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/$C -o t -- python bench.py --model $MODEL --batch $BATCH --steps 3 --warmup 3 --no-cpu --no-graph > $O/$C.log 2>&1
+  timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/$C -o t -- python bench.py --model $MODEL --batch $BATCH --steps 3 --warmup 3 --no-cpu > $O/$C.log 2>&1
 done
 find $O -name "*.db" -delete
 O=$O MODEL=$MODEL python - <<'PY'
