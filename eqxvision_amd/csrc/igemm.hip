@@ -326,9 +326,12 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
     if (dense && !get_flag("no_stream") && !get_flag("igemm_tile") && stream1x1_supported(C, K, in_dtype, out_dtype, M))
         return stream1x1_launch(x, w, scale, shift, residual, y, M, C, K, act, out_dtype, st);
     // deep-pipelined 8-wave kernel: every real convolution (taps or stride) and the big Linears; the
-    // short dense 1x1 layers late in the network (M <= 50k) measured the same or faster on the 128^2 kernel
+    // short dense 1x1 layers with a short reduction measured the same or faster on the 128^2 kernel
     // (measured, tools/swin_sweep.py: with an fp32 residual epilogue the 256-row kernel wins from M = 6272 up)
-    const bool want2 = igemm2_wanted(M, C, K, R, S) && (!dense || M >= 32768 || out_f32 || get_flag("igemm2_tile"));
+    // (measured with two graph lanes, i.e. half-batch launches: from M = 4096 up the deep pipeline also wins on dense
+    //  layers with a long reduction -- ResNet 7x7 / 14x14 1x1s, ViT fc1 at M = 25216 -- but not at C = 384, Swin stage 2)
+    const long long dense_m = get_flag("igemm2_dense_m") ? get_flag("igemm2_dense_m") : (C >= 512 ? 4096 : 32768);
+    const bool want2 = igemm2_wanted(M, C, K, R, S) && (!dense || M >= dense_m || out_f32 || get_flag("igemm2_tile"));
     // Phase-alternating 256x256 kernel (igemm3.hip) instead of igemm2's 256x128 tile when it saves rounds of CUs.
     // Measured on ResNet-50 / ViT-B / Swin-T (profiles/r01): per unit of tile area igemm3 runs ~1.09x faster than
     // igemm2 256x128, so it wins when 2 * rounds(256x256 tiles) / 1.09 < rounds(256x128 tiles) -- the layers where
