@@ -587,6 +587,26 @@ __global__ void patch_merge_kernel(const T* __restrict__ x, T* __restrict__ y, i
     }
 }
 
+// 16-byte chunks: c16 = chunks per source pixel (C * sizeof(T) / 16); y rows are [4 * c16] chunks
+__global__ void patch_merge_vec_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int B, int H, int W, int c16) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long n = (long long)B * Ho * Wo * 4 * c16;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (4 * c16));
+        long long m = i / (4 * c16);
+        const int wo = (int)(m % Wo);
+        m /= Wo;
+        const int ho = (int)(m % Ho);
+        const int b = (int)(m / Ho);
+        const int q = c4 / c16, c = c4 - q * c16;
+        const int hi = 2 * ho + (q & 1), wi = 2 * wo + (q >> 1);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (hi < H && wi < W) v = x[(((long long)b * H + hi) * W + wi) * c16 + c];
+        y[i] = v;
+    }
+}
+
 static inline int grid_for(long long n, int block = 256) {
     long long g = (n + block - 1) / block;
     if (g > 256 * 16) g = 256 * 16;
@@ -865,6 +885,16 @@ int mv_patch_merge_gather_nhwc(const void* x, void* y, int B, int H, int W, int 
     MV_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0, "patch_merge: bad args");
     hipStream_t st = (hipStream_t)stream;
     const long long n = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * 4 * C;
+    const int esz = dtype == MV_BF16 ? 2 : 4;
+    if ((C * esz) % 16 == 0 && !get_flag("force_generic")) {
+        set_kernel_name("patch_merge_gather_vec");
+        const int c16 = C * esz / 16;
+        const long long nv = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * 4 * c16;
+        hipLaunchKernelGGL(patch_merge_vec_kernel, dim3(grid_for(nv)), dim3(256), 0, st, (const uint4*)x, (uint4*)y, B, H, W,
+                           c16);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
     set_kernel_name("patch_merge_gather");
     if (dtype == MV_BF16)
         hipLaunchKernelGGL(patch_merge_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)x,

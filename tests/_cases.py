@@ -459,8 +459,8 @@ def misc_case(kind, dtype="bf16", seed=0):
         rng = _rng(seed)
         q = bf if dtype == "bf16" else (lambda a: np.asarray(a, np.float32))
         tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
-        if kind == "patch_merge":
-            B, H, W, C = 2, 7, 6, 16
+        if kind in ("patch_merge", "patch_merge_odd_c"):
+            B, H, W, C = (2, 7, 6, 16) if kind == "patch_merge" else (3, 9, 11, 6)     # vector / scalar kernel
             x = q(rng.standard_normal((B, C, H, W)))
             xp = np.pad(x, ((0, 0), (0, 0), (0, H % 2), (0, W % 2)))
             ref = np.concatenate([xp[:, :, 0::2, 0::2], xp[:, :, 1::2, 0::2], xp[:, :, 0::2, 1::2], xp[:, :, 1::2, 1::2]], 1)
@@ -667,6 +667,8 @@ def all_cases():
           ("swin/window8_64tokens", swin_attn_case(2, 16, 64, 2, 8, 4, seed=10)),
           ("swin/window4", swin_attn_case(2, 12, 64, 2, 4, 2, seed=11))]
     c += [("misc/patch_merge", misc_case("patch_merge")),
+          ("misc/patch_merge_f32", misc_case("patch_merge", dtype="fp32")),
+          ("misc/patch_merge_odd_c", misc_case("patch_merge_odd_c")),
           ("misc/layout", misc_case("layout")),
           ("misc/layout_f32", misc_case("layout", "fp32")),
           ("misc/eltwise", misc_case("eltwise")),
