@@ -322,7 +322,8 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
                              st);
     if (!get_flag("no_stream") && !get_flag("igemm_tile") && !get_flag("igemm2_tile") &&
         conv3x3c64_supported(C, K, R, S, sh, sw, ph, pw, dh, dw, in_dtype, out_dtype, residual, M))
-        return conv3x3c64_launch(x, w, scale, shift, y, N, H, W, act, st);
+        return get_flag("c3x3_v1") ? conv3x3c64_launch(x, w, scale, shift, y, N, H, W, act, st)
+                                   : conv3x3c64_v2_launch(x, w, scale, shift, y, N, H, W, act, st);
     if (dense && !get_flag("no_stream") && !get_flag("igemm_tile") && stream1x1_supported(C, K, in_dtype, out_dtype, M))
         return stream1x1_launch(x, w, scale, shift, residual, y, M, C, K, act, out_dtype, st);
     // deep-pipelined 8-wave kernel: every real convolution (taps or stride) and the big Linears; the

@@ -548,6 +548,10 @@ def all_cases():
     c += [("c3x3c64/56", conv_nhwc_case(4, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=41)),
           ("c3x3c64/odd_37x29_noact", conv_nhwc_case(9, 37, 29, 64, 64, 3, 3, pad=1, scale=False, seed=42)),
           ("c3x3c64/tiny_rows", conv_nhwc_case(70, 12, 10, 64, 64, 3, 3, pad=1, act=1, seed=43)),
+          ("c3x3c64/wide_112_two_col_tiles", conv_nhwc_case(3, 30, 112, 64, 64, 3, 3, pad=1, act=1, seed=44)),
+          ("c3x3c64/width_100_H_not_mult4", conv_nhwc_case(5, 27, 100, 64, 64, 3, 3, pad=1, act=2, seed=45)),
+          ("c3x3c64/many_tiles_persistent", conv_nhwc_case(40, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=46)),
+          ("c3x3c64/v1_kernel_56", conv_nhwc_case(4, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=41, flags=("c3x3_v1",))),
           ("igemm2/3x3_128_28", conv_nhwc_case(8, 28, 28, 128, 128, 3, 3, pad=1, act=1, seed=11)),
           ("igemm2/3x3_64_56_bn64", conv_nhwc_case(2, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=12, flags=("no_stream",))),
           ("igemm2/3x3_256_s2", conv_nhwc_case(24, 28, 28, 256, 256, 3, 3, stride=2, pad=1, act=1, seed=13)),
