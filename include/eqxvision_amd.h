@@ -38,7 +38,11 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  * "stem_v0" (1 = use the table-gather entry-conv kernel instead of the patch/GEMM variants),
  * "no_stream" / "no_igemm2" (1 = do not dispatch to the streaming 1x1 / deep-pipelined kernels),
  * "igemm2_tile" (0 auto, 1 = 256x64, 2 = 256x128, 3 = 256x256 block tile), "tail_split" (1 = hand the
- * rows of a small partial last round of 256-row tiles to the 128-row kernel). */
+ * rows of a small partial last round of 256-row tiles to the 128-row kernel), "igemm2_dense_m" (override
+ * the row count from which dense layers use the deep-pipelined kernels), "igemm3" (1 = prefer, 2 = force
+ * the phase-alternating 256x256 kernel) / "no_igemm3", "c3x3_v1" (first-generation 3x3 64->64 kernel),
+ * "no_stem_pool" (do not fuse the ResNet entry with its max-pool), "stream_npass1" (one channel slab
+ * per block in the streaming 1x1 kernel).  All are A/B and test switches; 0 is the tuned default. */
 
 int mv_abi_version(void);
 const char* mv_last_error(void);
