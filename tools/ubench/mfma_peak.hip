@@ -26,6 +26,26 @@ __global__ __launch_bounds__(1024) void mfma_loop(const uint4* in, float* out, i
     if (s == 12345.678f) out[0] = s;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NACC>
+__global__ __launch_bounds__(1024) void mfma_loop16(const uint4* in, float* out, int iters) {
+    uint4 a = in[threadIdx.x & 63], b = in[64 + (threadIdx.x & 63)];
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][3];
+    if (s == 12345.678f) out[0] = s;
+}
+
 int main() {
     uint4* d; float* o;
     hipMalloc(&d, 128 * 16); hipMalloc(&o, 4);
@@ -43,7 +63,15 @@ int main() {
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
             double flop = (double)blocks * (wpb / 64) * iters * 4 * 32768.0;
-            printf("%s operands, %d waves/SIMD: %.1f TFLOP/s (%.3f ms)\n", rnd ? "random" : "zero  ", wpb / 256, flop / ms / 1e9, ms);
+            printf("32x32x16 %s operands, %d waves/SIMD: %.1f TFLOP/s (%.3f ms)\n", rnd ? "random" : "zero  ", wpb / 256, flop / ms / 1e9, ms);
+            hipLaunchKernelGGL(mfma_loop16<8>, dim3(blocks), dim3(wpb), 0, 0, d, o, iters);
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(mfma_loop16<8>, dim3(blocks), dim3(wpb), 0, 0, d, o, iters);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+            flop = (double)blocks * (wpb / 64) * iters * 8 * 16384.0;
+            printf("16x16x32 %s operands, %d waves/SIMD: %.1f TFLOP/s (%.3f ms)\n", rnd ? "random" : "zero  ", wpb / 256, flop / ms / 1e9, ms);
         }
     }
     return 0;
