@@ -212,7 +212,10 @@ int swin_mfma_launch(const void* qkv, const float* bias, void* out, int B, int H
     }
     p.total_windows = (int)tw;
     int gx = (int)((tw + 3) / 4);
-    const int cap = (256 * 8) / heads > 0 ? (256 * 8) / heads : 1;
+    // persistent blocks: two per CU in total (register-limited residency), so the per-block bias staging (16 KB) is
+    // amortised over many windows (with 8 blocks per CU a wave saw ~1.5 windows: 66 -> 41 us on the 56x56 stage)
+    const int per_cu = get_flag("swin_blocks_per_cu") ? get_flag("swin_blocks_per_cu") : 2;
+    const int cap = (256 * per_cu) / heads > 0 ? (256 * per_cu) / heads : 1;
     if (gx > cap) gx = cap;
     set_kernel_name("swin_attn_mfma");
     hipLaunchKernelGGL(swin_attn_mfma_kernel, dim3(gx, heads), dim3(256), 0, st, p);
