@@ -124,6 +124,9 @@ int swin_mfma_launch(const void* qkv, const float* bias, void* out, int B, int H
                      int ws_w, int shift_h, int shift_w, hipStream_t stream);
 int conv3x3c64_v2_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H,
                          int W, int act, hipStream_t stream);
+int skinny_supported(long long M, int C, int K, int in_dtype, const void* residual);
+int skinny_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, long long M, int C, int K,
+                  int act, int out_dtype, hipStream_t stream);
 int stem_pool_supported(int C, int K, int R, int S, int sh, int sw, int ph, int pw, int pk, int ps, int pp, int act,
                         int x_dtype, int out_dtype, long long in_elems);
 int stem_pool_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H, int W,

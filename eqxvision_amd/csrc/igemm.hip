@@ -317,6 +317,9 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
     p.act = act;
     const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
     const bool out_f32 = out_dtype == MV_F32;
+    if (dense && !get_flag("no_skinny") && !get_flag("igemm_tile") && !get_flag("igemm2_tile") && get_flag("igemm3") != 2 &&
+        skinny_supported(M, C, K, in_dtype, residual))                   // classifier heads: one wave per 32 x 32 tile
+        return skinny_launch(x, w, scale, shift, y, M, C, K, act, out_dtype, st);
     if (get_flag("igemm3") == 2 && igemm3_wanted(M, C, K, R, S))          // forced (tests)
         return igemm3_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
                              st);

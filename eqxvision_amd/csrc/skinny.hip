@@ -1,0 +1,104 @@
+// Skinny Linear for the classifier heads (ResNet fc 2048 -> 1000, ViT / Swin heads 768 -> 1000, AlexNet classifier at
+// small batch): M <= 256 rows, gfx950.
+//
+// The tiled kernels give such a layer one row tile x a handful of channel tiles = 8 blocks on a 256-CU chip (25 us
+// for 4 MB of weights).  Here every 32 x 32 output tile is ONE WAVE in its own block, spread over the whole chip:
+// both MFMA fragments (16 bytes = 8 reduction elements of one weight row / one input row) come straight from global
+// memory, eight k16-steps in flight; no LDS, no barrier; fp32 or bf16 output written from the accumulator layout
+// (a lane holds 4 consecutive channels of one row: 16-byte stores for fp32).
+#include "mfma_common.h"
+
+namespace mv {
+
+struct SkinnyP {
+    const bf16_t* x;      // [M][K]
+    const bf16_t* w;      // [N][K]
+    const float* scale;
+    const float* shift;
+    void* y;              // [M][N]
+    int M, N, K, act, tiles_n;
+};
+
+template <typename OutT>
+__global__ __launch_bounds__(64) void skinny_linear_kernel(const SkinnyP p) {
+    constexpr int D = 8;                                   // k16-steps in flight
+    const int lane = threadIdx.x, fr = lane & 31, fh = lane >> 5;
+    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+    const int n0 = tn * 32, m0 = tm * 32;
+    const int nr = n0 + fr < p.N ? n0 + fr : p.N - 1;      // clamped rows: never stored
+    const int mr = m0 + fr < p.M ? m0 + fr : p.M - 1;
+    const bf16_t* wa = p.w + (long long)nr * p.K + fh * 8;
+    const bf16_t* xa = p.x + (long long)mr * p.K + fh * 8;
+    const int nk = p.K >> 4;
+    uint4 af[D], bf[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const int kk = i < nk ? i : nk - 1;
+        af[i] = *(const uint4*)(wa + kk * 16);
+        bf[i] = *(const uint4*)(xa + kk * 16);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k0 = 0; k0 < nk; k0 += D) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const uint4 a = af[i], b = bf[i];
+            const int kn = k0 + D + i < nk ? k0 + D + i : nk - 1;          // clamped refill (unconditional load)
+            af[i] = *(const uint4*)(wa + kn * 16);
+            bf[i] = *(const uint4*)(xa + kn * 16);
+            if (k0 + i < nk)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
+                                                              0, 0, 0);
+        }
+    }
+    // accumulator register e: row (channel) n0 + (e&3) + 8*(e>>2) + 4*fh, column (input row) m0 + fr
+    const int m = m0 + fr;
+    if (m >= p.M) return;
+    OutT* yr = (OutT*)p.y + (long long)m * p.N;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = n0 + 8 * g + 4 * fh;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ne = n + e < p.N ? n + e : p.N - 1;
+            const float sc = p.scale ? p.scale[ne] : 1.f, sh = p.shift ? p.shift[ne] : 0.f;
+            v[e] = fmaf(acc[4 * g + e], sc, sh);
+            if (p.act == MV_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+            else if (p.act == MV_ACT_GELU_TANH) v[e] = gelu_tanh_f(v[e]);
+        }
+        if (n + 3 < p.N && (p.N & 3) == 0) Out4<OutT>::st(yr + n, make_float4(v[0], v[1], v[2], v[3]));
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) {
+                    if constexpr (sizeof(OutT) == 4) ((float*)yr)[n + e] = v[e];
+                    else ((bf16_t*)yr)[n + e] = f2bf(v[e]);
+                }
+        }
+    }
+}
+
+int skinny_supported(long long M, int C, int K, int in_dtype, const void* residual) {
+    // C = reduction length, K = output channels (igemm naming)
+    return in_dtype == MV_BF16 && residual == nullptr && M >= 1 && M <= 256 && C % 16 == 0 && C >= 64 && K >= 8;
+}
+
+int skinny_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, long long M, int C, int K,
+                  int act, int out_dtype, hipStream_t st) {
+    SkinnyP p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.y = y;
+    p.M = (int)M; p.N = K; p.K = C; p.act = act;
+    p.tiles_n = (K + 31) / 32;
+    const int tiles_m = (int)((M + 31) / 32);
+    set_kernel_name("skinny_linear_mfma");
+    if (out_dtype == MV_F32)
+        hipLaunchKernelGGL(skinny_linear_kernel<float>, dim3(p.tiles_n * tiles_m), dim3(64), 0, st, p);
+    else
+        hipLaunchKernelGGL(skinny_linear_kernel<bf16_t>, dim3(p.tiles_n * tiles_m), dim3(64), 0, st, p);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+}  // namespace mv

@@ -600,7 +600,12 @@ def all_cases():
           ("linear/alex_fc", linear_case(4, 9216, 4096, act=1)),
           ("linear/odd_generic", linear_case(10, 20, 5, act=2)),
           ("linear/f32_generic", linear_case(33, 70, 18, dtype="fp32", res=True)),
-          ("linear/generic_vs_oracle_768", linear_case(70, 768, 96, generic=True))]
+          ("linear/generic_vs_oracle_768", linear_case(70, 768, 96, generic=True)),
+          ("linear/skinny_fc_128", linear_case(128, 2048, 1000, out="fp32", seed=3)),
+          ("linear/skinny_head_200x768", linear_case(200, 768, 1000, out="fp32", seed=4)),
+          ("linear/skinny_odd_N_bf16", linear_case(33, 64, 42, act=1, seed=5)),
+          ("linear/skinny_1_row", linear_case(1, 4096, 1000, act=2, seed=6)),
+          ("linear/skinny_K_not_mult_of_D", linear_case(17, 144, 64, seed=7))]
     c += [("conv_generic/groups", conv_nhwc_case(2, 9, 9, 32, 64, 3, 3, pad=1, groups=4, act=1)),
           ("conv_generic/f32", conv_nhwc_case(1, 10, 10, 12, 20, 3, 3, stride=2, pad=1, dtype="fp32", res=True)),
           ("conv_generic/same_as_igemm", conv_nhwc_case(1, 14, 14, 64, 64, 3, 3, pad=1, generic=True))]
