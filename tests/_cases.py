@@ -633,6 +633,9 @@ def all_cases():
           ("maxpool/f32_oddC", maxpool_case(1, 13, 13, 5, 3, 2, 0, dtype="fp32")),
           ("avgpool/global", avgpool_case(2, 7, 7, 2048, 1, 1)),
           ("avgpool/13to6", avgpool_case(1, 13, 13, 16, 6, 6)),
+          ("avgpool/global_swin_7x7x768", avgpool_case(5, 7, 7, 768, 1, 1, seed=2)),
+          ("avgpool/global_hw_not_mult4_c8", avgpool_case(3, 5, 3, 8, 1, 1, seed=3)),
+          ("avgpool/global_odd_c_scalar_path", avgpool_case(3, 5, 3, 12, 1, 1, seed=4)),
           ("layernorm/768", layernorm_case(394, 768)),
           ("layernorm/96", layernorm_case(100, 96)),
           ("layernorm/768_generic", layernorm_case(50, 768, generic=True)),
