@@ -2,7 +2,8 @@
 // small batch): M <= 256 rows, gfx950.
 //
 // The tiled kernels give such a layer one row tile x a handful of channel tiles = 8 blocks on a 256-CU chip (25 us
-// for 4 MB of weights).  Here every 32 x 32 output tile is ONE WAVE in its own block, spread over the whole chip:
+// for 4 MB of weights).  Here every 32 x 32 output tile is a block of four waves that split the reduction, spread
+// over the whole chip (partial sums meet in LDS):
 // both MFMA fragments (16 bytes = 8 reduction elements of one weight row / one input row) come straight from global
 // memory, eight k16-steps in flight; no LDS, no barrier; fp32 or bf16 output written from the accumulator layout
 // (a lane holds 4 consecutive channels of one row: 16-byte stores for fp32).
@@ -20,38 +21,53 @@ struct SkinnyP {
 };
 
 template <typename OutT>
-__global__ __launch_bounds__(64) void skinny_linear_kernel(const SkinnyP p) {
-    constexpr int D = 8;                                   // k16-steps in flight
-    const int lane = threadIdx.x, fr = lane & 31, fh = lane >> 5;
+__global__ __launch_bounds__(256) void skinny_linear_kernel(const SkinnyP p) {
+    constexpr int D = 8;                                   // k16-steps in flight per wave
+    __shared__ float red[3][16][64];                       // partial accumulators of waves 1..3
+    const int lane = threadIdx.x & 63, fr = lane & 31, fh = lane >> 5;
+    // wave-uniform on purpose: the k-range bounds below must live in SGPRs.  MFMA ignores EXEC, so a bound the
+    // compiler believes divergent would turn the tail predicate into a no-op and run the skipped steps anyway.
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
     const int n0 = tn * 32, m0 = tm * 32;
     const int nr = n0 + fr < p.N ? n0 + fr : p.N - 1;      // clamped rows: never stored
     const int mr = m0 + fr < p.M ? m0 + fr : p.M - 1;
     const bf16_t* wa = p.w + (long long)nr * p.K + fh * 8;
     const bf16_t* xa = p.x + (long long)mr * p.K + fh * 8;
+    // the four waves of the block split the reduction: wave w takes k16-steps [kb, ke)
     const int nk = p.K >> 4;
+    const int per = (nk + 3) >> 2;
+    const int kb = wave * per, ke = (kb + per) < nk ? (kb + per) : nk;
     uint4 af[D], bf[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-        const int kk = i < nk ? i : nk - 1;
+        const int kk = kb + i < nk ? kb + i : nk - 1;
         af[i] = *(const uint4*)(wa + kk * 16);
         bf[i] = *(const uint4*)(xa + kk * 16);
     }
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (int k0 = 0; k0 < nk; k0 += D) {
+    for (int k0 = kb; k0 < ke; k0 += D) {
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             const uint4 a = af[i], b = bf[i];
             const int kn = k0 + D + i < nk ? k0 + D + i : nk - 1;          // clamped refill (unconditional load)
             af[i] = *(const uint4*)(wa + kn * 16);
             bf[i] = *(const uint4*)(xa + kn * 16);
-            if (k0 + i < nk)
+            if (k0 + i < ke)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
                                                               0, 0, 0);
         }
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave - 1][e][lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += red[0][e][lane] + red[1][e][lane] + red[2][e][lane];
     // accumulator register e: row (channel) n0 + (e&3) + 8*(e>>2) + 4*fh, column (input row) m0 + fr
     const int m = m0 + fr;
     if (m >= p.M) return;
@@ -94,9 +110,9 @@ int skinny_launch(const void* x, const void* w, const float* scale, const float*
     const int tiles_m = (int)((M + 31) / 32);
     set_kernel_name("skinny_linear_mfma");
     if (out_dtype == MV_F32)
-        hipLaunchKernelGGL(skinny_linear_kernel<float>, dim3(p.tiles_n * tiles_m), dim3(64), 0, st, p);
+        hipLaunchKernelGGL(skinny_linear_kernel<float>, dim3(p.tiles_n * tiles_m), dim3(256), 0, st, p);
     else
-        hipLaunchKernelGGL(skinny_linear_kernel<bf16_t>, dim3(p.tiles_n * tiles_m), dim3(64), 0, st, p);
+        hipLaunchKernelGGL(skinny_linear_kernel<bf16_t>, dim3(p.tiles_n * tiles_m), dim3(256), 0, st, p);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

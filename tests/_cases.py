@@ -605,7 +605,9 @@ def all_cases():
           ("linear/skinny_head_200x768", linear_case(200, 768, 1000, out="fp32", seed=4)),
           ("linear/skinny_odd_N_bf16", linear_case(33, 64, 42, act=1, seed=5)),
           ("linear/skinny_1_row", linear_case(1, 4096, 1000, act=2, seed=6)),
-          ("linear/skinny_K_not_mult_of_D", linear_case(17, 144, 64, seed=7))]
+          ("linear/skinny_K_not_mult_of_D", linear_case(17, 144, 64, seed=7)),
+          ("linear/skinny_one_step_per_wave", linear_case(33, 64, 40, act=1, seed=8)),
+          ("linear/skinny_tail_3_steps", linear_case(70, 192, 104, out="fp32", seed=9))]
     c += [("conv_generic/groups", conv_nhwc_case(2, 9, 9, 32, 64, 3, 3, pad=1, groups=4, act=1)),
           ("conv_generic/f32", conv_nhwc_case(1, 10, 10, 12, 20, 3, 3, stride=2, pad=1, dtype="fp32", res=True)),
           ("conv_generic/same_as_igemm", conv_nhwc_case(1, 14, 14, 64, 64, 3, 3, pad=1, generic=True))]
