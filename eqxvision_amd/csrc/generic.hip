@@ -889,6 +889,9 @@ int mv_linear_heads_fwd(const void* x, const void* w, const float* scale, const 
                   (long long)M, N, K, tokens, dh);
         return MV_E_UNSUPPORTED;
     }
+    if (get_flag("igemm4") >= 1 && igemm4_wanted(M, K, N, 1, 1))
+        return igemm4_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE, MV_BF16,
+                             tokens, get_flag("igemm4") == 2 ? 3 : 2, (hipStream_t)stream);
     if (get_flag("igemm3") >= 1 && igemm3_wanted(M, K, N, 1, 1))   // (qkv: N = 2304 uses igemm2's 256x256 tile by default)
         return igemm3_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE, MV_BF16,
                              tokens, (hipStream_t)stream);

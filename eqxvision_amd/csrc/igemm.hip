@@ -318,8 +318,12 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
     const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
     const bool out_f32 = out_dtype == MV_F32;
     if (dense && !get_flag("no_skinny") && !get_flag("igemm_tile") && !get_flag("igemm2_tile") && get_flag("igemm3") != 2 &&
+        get_flag("igemm4") < 2 &&
         skinny_supported(M, C, K, in_dtype, residual))                   // classifier heads: one wave per 32 x 32 tile
         return skinny_launch(x, w, scale, shift, y, M, C, K, act, out_dtype, st);
+    if (get_flag("igemm4") >= 2 && igemm4_wanted(M, C, K, R, S))          // forced (tests): 2 = 256x256, 3 = 256x128
+        return igemm4_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
+                             get_flag("igemm4") == 2 ? 3 : 2, st);
     if (get_flag("igemm3") == 2 && igemm3_wanted(M, C, K, R, S))          // forced (tests)
         return igemm3_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
                              st);
@@ -348,7 +352,11 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
         const int t2 = igemm2_tile_shape(M, K, &bm, &bn);
         const long long tm = (M + 255) / 256;
         const long long r2 = (tm * ((K + 127) / 128) + 255) / 256, r3 = (tm * ((K + 255) / 256) + 255) / 256;
-        if (get_flag("igemm3") == 1 || (t2 == 2 && 1.835 * (double)r3 < (double)r2))
+        const bool big = get_flag("igemm3") == 1 || (t2 == 2 && 1.835 * (double)r3 < (double)r2);
+        if (get_flag("igemm4") == 1 && K > 64)           // opt-in (measured: +0.7% ViT-B, -1.2% ResNet-50, 0 Swin-T)
+            return igemm4_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype,
+                                 0, 2, st);
+        if (big)
             return igemm3_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype,
                                  0, st);
     }

@@ -37,6 +37,8 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long pt0 = 0, pt1 = 0, pt2 = 0;
+    if (p.prof) pt0 = wall_clock64();
     const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     int tile_m, tile_n;
     tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n);
@@ -124,8 +126,15 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
     const OutT* res = (const OutT*)p.residual;
     ScaleShift8 ss;
     ss.load(p.scale, p.shift, n0 + wrow0 + (lane & 7) * 8, p.K);
+    // Residual rows are fetched in the MIDDLE of the reduction (end of iteration `jres`), not before it: issued up
+    // front they are older than the first k-tile, whose counted wait then sits behind 64-128 KB of residual traffic
+    // per block (measured: 5.8 us of prologue instead of 1.8 on the ViT projections).  vmcnt retires in issue
+    // order, so for the NST-1 iterations that follow the issue the counted wait allows RL more operations in flight.
+    constexpr int RL = TM * 4 * (sizeof(OutT) == 4 ? 2 : 1);
+    static_assert(!RESPF || (NST - 2) * L + RL <= 63, "vmcnt immediate");
     R8<OutT> rres[RESPF ? TM : 1][4];
-    if (RESPF && res) {
+    auto fetch_residual = [&]() {
+        asm volatile("" ::: "memory");                     // keep the loads at this point of the issue order
 #pragma unroll
         for (int b = 0; b < TM; ++b)
 #pragma unroll
@@ -133,9 +142,10 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
                 const int m = m0 + xrow0 + b * 32 + pass * 8 + (lane >> 3);
                 const int n = n0 + wrow0 + (lane & 7) * 8;
                 const bool ok = m < p.M && n < p.K;
-                rres[b][pass].load(res + (ok ? (long long)m * p.K + n : 0));
+                rres[RESPF ? b : 0][pass].load(res + (ok ? (long long)m * p.K + n : 0));
             }
-    }
+        asm volatile("" ::: "memory");
+    };
 
     f32x16 acc[TN][TM];
 #pragma unroll
@@ -167,13 +177,22 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
         }
     }
 
+    if (p.prof) pt1 = wall_clock64();
     // ---------------- main loop ---------------------------------------------------------------------------
     int cur = 0;
+    int raised = 0;                                        // iterations left whose wait must let the residual rows fly
+    const int jres = p.dbg ? -1 : (nk - 1) >> 1;
+    if (RESPF && res && p.dbg) fetch_residual();          // A/B: the old up-front fetch
     for (int it = 0; it < nk; ++it) {
         // tile `it` must have landed; younger tiles (at most NST-2) may stay in flight
         const int younger = issued - it - 1;
-        if (NST > 2 && younger >= NST - 2) wait_vm<(NST > 2 ? (NST - 2) * L : 0)>();
-        else wait_vm<0>();
+        if (NST > 2 && younger >= NST - 2) {
+            if (RESPF && raised > 0) wait_vm<(NST > 2 ? (NST - 2) * L + (RESPF ? RL : 0) : 0)>();
+            else wait_vm<(NST > 2 ? (NST - 2) * L : 0)>();
+        } else {
+            wait_vm<0>();
+        }
+        if (RESPF && raised > 0) --raised;
         __builtin_amdgcn_s_barrier();
         // Refill the stage everyone just left with tile it+NST-1.  The L DMA pieces are spread over the four
         // k16-steps below (a quarter per step, between the fragment reads and the MFMAs) so their address
@@ -230,11 +249,16 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
             advance();
             ++issued;
         }
+        if (RESPF && res && it == jres) {
+            fetch_residual();
+            raised = NST - 1;
+        }
         if (++cur == NST) cur = 0;
     }
 
     // ---------------- epilogue (as igemm.hip: LDS transpose, full-line stores) ------------------------------
     __syncthreads();
+    if (p.prof) pt2 = wall_clock64();
     char* ep = smem + wave * (32 * EPITCH);
     OutT* y = (OutT*)p.y;
 #pragma unroll
@@ -287,6 +311,10 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
             }
         }
     }
+    if (p.prof && tid == 0) {
+        long long* o = p.prof + 4ll * blockIdx.x;
+        o[0] = pt0; o[1] = pt1; o[2] = pt2; o[3] = wall_clock64();
+    }
 }
 
 template <int WM, int WN, int TM, int TN, int NST, bool RESPF>
@@ -332,7 +360,8 @@ int igemm2_launch(const void* x, const void* w, const float* scale, const float*
                   int act, int out_dtype, int m_end, int tok, hipStream_t st) {
     Igemm2P p;
     p.tok = tok;
-    p.dbg = 0;
+    p.dbg = get_flag("res_early");
+    p.prof = (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo"));
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.zero = (const bf16_t*)zero_page(st);
     if (!p.zero) {

@@ -324,6 +324,7 @@ int igemm3_launch(const void* x, const void* w, const float* scale, const float*
     Igemm2P p;
     p.tok = tok;
     p.dbg = 0;
+    p.prof = nullptr;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.zero = (const bf16_t*)zero_page(st);
     if (!p.zero) {

@@ -1,0 +1,405 @@
+// One wave per SIMD, 512 registers each: implicit GEMM, 256 pixels x 256 channels per block of FOUR waves, gfx950.
+//
+// igemm2 / igemm3 run eight waves (two per SIMD) with a 128 x 64 accumulator block each.  Phase stamps
+// (tools/phase_prof.py) put their main loops at 0.9-1.1 PFLOP/s: the two waves of a SIMD are barrier-locked into the
+// same phase, every k16-step re-reads 6 fragments for 8 MFMAs, and both pay their LDS-DMA issue separately.
+//
+// Here a wave owns 128 pixels x 128 channels: 16 accumulators = 256 registers (AGPRs), which only fits because the
+// block has ONE wave per SIMD (launch bound 256 threads -> 512 registers per lane).  Per k16-step a wave reads
+// 8 fragments for 16 MFMAs (LDS read traffic -33% per flop) and nobody shares its SIMD, so the overlap of fragment
+// reads / DMA issue with the matrix pipe is decided by the instruction order of ONE stream, fixed here with
+// sched_barrier fences: one ds_read or one LDS-DMA piece rides behind each MFMA.
+//
+//   k-tile 32 wide (64-byte rows), 4 LDS stages of 32 KB (igemm3's layout and source-side XOR swizzle).
+//   iteration `it` (tile it in stage cur, both fragment sets of a tile double-buffered in registers):
+//     step A: 16 MFMAs on set 0 (tile it, k 0..15)  | 8 reads -> set 1 (tile it, k 16..31), 4 DMA pieces of tile it+3
+//     step B: 16 MFMAs on set 1                     | 4 DMA pieces, counted vmcnt (tile it+1 landed), s_barrier,
+//                                                     8 reads -> set 0 (tile it+1, k 0..15)
+//   The stage refilled in iteration it held tile it-1: every wave's last read of it completed before the barrier of
+//   iteration it-1 (WAR).  vmcnt retires in issue order: 8 pieces per tile and wave, so tile it+1 has landed once at
+//   most 16 younger pieces are in flight.
+// Operands, accumulator layout and epilogue are igemm2's (A = weights, B = pixels; LDS transpose, 128-byte stores).
+#include <type_traits>
+
+#include "igemm_pipe.h"
+
+namespace mv {
+
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// TN = 4, NST = 4: 256 x 256 tile, one block per CU (512 registers per lane).
+// TN = 2, NST = 3: 256 x 128 tile, 72 KB of LDS and <= 256 registers: TWO independent blocks per CU, so one block's
+//                  prologue / epilogue runs under the other's main loop and the two waves of a SIMD are never
+//                  barrier-locked to each other.
+template <int TN, int NST, typename OutT>
+__global__ __launch_bounds__(256, TN == 2 ? 2 : 1) void igemm4_kernel(const Igemm2P p) {
+    constexpr int BM = 256, BN = 64 * TN, TM = 4;
+    constexpr int ROWB = 64;                              // bytes per staged row: 32 bf16
+    constexpr int STAGE = (BM + BN) * ROWB;               // 32 KB / 24 KB
+    constexpr int EPITCH = 64 * 4 + 16;
+    constexpr int NP = 4;                                 // x DMA pieces (16 rows x 64 B) per wave and k-tile
+    constexpr int NPW = BN / 64;                          // weight pieces per wave and k-tile
+    constexpr int L = NP + NPW;                           // vmcnt units per k-tile
+    constexpr int F = TN + TM;                            // fragments per k16-step
+    constexpr int NM = TN * TM;                           // MFMAs per k16-step
+    static_assert((TN == 4 && NST == 4) || (TN == 2 && NST == 3), "two configurations");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long pt0 = 0, pt1 = 0, pt2 = 0;
+    if (p.prof) pt0 = wall_clock64();
+    const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    int tile_m, tile_n;
+    tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---------------- DMA addressing: wave w stages rows 16 (w + 4 j) .. + 15, j = 0..3, of x and of w --------------
+    const int srow = lane >> 2;
+    const int chunk = (lane & 3) ^ ((lane >> 4) & 3);     // source chunk for LDS slot lane&3 of row srow
+    const int cpt = p.C >> 5;
+    const int nk = p.R * p.S * cpt;
+    const long long wrow_stride = (long long)p.R * p.S * p.C;
+    long long xbase[NP];
+    unsigned vlo[NP], vhi[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int m = m0 + 16 * (wave + 4 * j) + srow;
+        const bool valid = m < p.M;
+        const int wo = m % p.Wo;
+        const int tt = m / p.Wo;
+        const int ho = tt % p.Ho;
+        const int b = tt / p.Ho;
+        const int hi0 = ho * p.sh - p.ph, wi0 = wo * p.sw - p.pw;
+        xbase[j] = (((long long)b * p.H + hi0) * p.W + wi0) * p.C + chunk * 8;
+        unsigned long long mask = 0;
+        if (valid) {
+            for (int r = 0; r < p.R; ++r) {
+                const int hi = hi0 + r * p.dh;
+                if ((unsigned)hi >= (unsigned)p.H) continue;
+                for (int s = 0; s < p.S; ++s) {
+                    const int wi = wi0 + s * p.dw;
+                    if ((unsigned)wi < (unsigned)p.W) mask |= 1ull << (r * p.S + s);
+                }
+            }
+        }
+        vlo[j] = (unsigned)mask;
+        vhi[j] = (unsigned)(mask >> 32);
+    }
+    // per-lane source pointers of the k-tile being staged, bumped by 64 bytes per k-tile (0 on the zero page)
+    const char* xp[NP];
+    const char* wp[NPW];
+    unsigned xinc[NP], winc[NPW];
+    auto retap = [&](int r, int s) {
+        const int tp = r * p.S + s;                                          // wave-uniform
+        const long long tapdelta = ((long long)(r * p.dh) * p.W + s * p.dw) * p.C;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const unsigned bits = tp < 32 ? vlo[j] : vhi[j];
+            const bool ok = (bits >> (tp & 31)) & 1u;
+            xp[j] = ok ? (const char*)(p.x + tapdelta + xbase[j]) : (const char*)p.zero;
+            xinc[j] = ok ? 64u : 0u;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        const int n = n0 + 16 * (wave + 4 * j) + srow;
+        const bool ok = n < p.K;
+        wp[j] = ok ? (const char*)(p.w + (long long)n * wrow_stride + chunk * 8) : (const char*)p.zero;
+        winc[j] = ok ? 64u : 0u;
+    }
+    retap(0, 0);
+    // piece q: 0..3 = x rows, 4.. = weight rows
+    auto stage_piece = [&](int q, int buf) {
+        char* xs = smem + buf * STAGE;
+        char* ws = xs + BM * ROWB;
+        if (q < NP) glds16(xp[q], xs + 16 * (wave + 4 * q) * ROWB);
+        else glds16(wp[q - NP], ws + 16 * (wave + 4 * (q - NP)) * ROWB);
+    };
+    int r = 0, s = 0, c0 = 0;
+    auto advance = [&]() {            // to the next k-tile: 32 more channels of this tap, or the next tap
+        c0 += 32;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) wp[j] += winc[j];                      // KRSC rows: taps are contiguous
+        if (c0 == p.C) {
+            c0 = 0;
+            if (++s == p.S) {
+                s = 0;
+                ++r;
+            }
+            retap(r, s);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) xp[j] += xinc[j];
+        }
+    };
+
+    // ---------------- fragment addressing ----------------------------------------------------------------------------
+    const int wm = wave & 1, wn = wave >> 1;
+    const int fr = lane & 31, fh = lane >> 5, swz = (fr >> 2) & 3;
+    const int xrow0 = wm * 128, wrow0 = wn * (32 * TN);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned xaddr[2], waddr[2];     // per k16-step of a k-tile: byte address of my 16-byte fragment in stage 0
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const unsigned ko = (unsigned)(((2 * kk + fh) ^ swz) << 4);
+        xaddr[kk] = lds0 + (xrow0 + fr) * ROWB + ko;
+        waddr[kk] = lds0 + BM * ROWB + (wrow0 + fr) * ROWB + ko;
+    }
+
+    // epilogue constants: older than every DMA, never in the way of the counted waits
+    ScaleShift8 ss[TN / 2];
+#pragma unroll
+    for (int h = 0; h < TN / 2; ++h) ss[h].load(p.scale, p.shift, n0 + wrow0 + h * 64 + (lane & 7) * 8, p.K);
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    // ---------------- ring prologue: tiles 0 .. 2 ----------------------------------------------------------------------
+    int issued = 0;
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) {
+        if (issued < nk) {
+#pragma unroll
+            for (int q = 0; q < L; ++q) stage_piece(q, i);
+            advance();
+            ++issued;
+        }
+    }
+    if (issued >= 3) wait_vm<2 * L>();
+    else if (issued == 2) wait_vm<L>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+
+    // fragment i of a set: 0 .. TN-1 = weight rows 32 i .., TN .. = pixel rows 32 (i - TN) ..
+    u32x4 fw[2][TN], fx[2][TM];
+    auto read_frag = [&](auto idx, int set, int kk, unsigned sb) {
+        constexpr int I = decltype(idx)::value;
+        if constexpr (I < TN) lds_read16<I * 32 * ROWB>(fw[set][I], waddr[kk] + sb);
+        else lds_read16<(I - TN) * 32 * ROWB>(fx[set][I - TN], xaddr[kk] + sb);
+    };
+    auto wait_set = [&](int set) {   // every fragment register is named so that no MFMA can be scheduled above the wait
+        if constexpr (TN == 4)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fw[set][0]), "+v"(fw[set][1]), "+v"(fw[set][2]), "+v"(fw[set][3]), "+v"(fx[set][0]),
+                           "+v"(fx[set][1]), "+v"(fx[set][2]), "+v"(fx[set][3]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fw[set][0]), "+v"(fw[set][1]), "+v"(fx[set][0]), "+v"(fx[set][1]), "+v"(fx[set][2]),
+                           "+v"(fx[set][3]));
+    };
+    static_for<0, F>([&](auto i) { read_frag(i, 0, 0, 0u); });
+    if (p.prof) pt1 = wall_clock64();
+
+    // DMA pieces ride behind the MFMAs that have no fragment read behind them: LA of them in step A, the rest in the
+    // first PB slots of step B; then the counted wait + barrier, then the next tile's first fragment set.
+    constexpr int LA = TN == 4 ? 4 : 2;
+    constexpr int PB = TN == 4 ? 4 : 2;
+    constexpr int PER = (L - LA) / PB;                   // pieces per slot in step B
+    static_assert(LA + PB * PER == L && PB + F <= NM, "schedule");
+    int cur = 0;
+    for (int it = 0; it < nk; ++it) {
+        const unsigned sb = (unsigned)(cur * STAGE);
+        int rbuf = cur + NST - 1;
+        if (rbuf >= NST) rbuf -= NST;
+        int nbuf = cur + 1;
+        if (nbuf >= NST) nbuf = 0;
+        const bool refill = issued < nk;                  // wave-uniform
+        const bool more = it + 1 < nk;
+        // ---- step A: k 0..15 of tile it ------------------------------------------------------------------------
+        wait_set(0);
+        static_for<0, NM>([&](auto mi) {
+            constexpr int M = decltype(mi)::value, a = M >> 2, b = M & 3;
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[0][a]),
+                                                                __builtin_bit_cast(bf16x8, fx[0][b]), acc[a][b], 0, 0, 0);
+            if constexpr (M < F) read_frag(std::integral_constant<int, M>{}, 1, 1, sb);
+            else if constexpr (TN == 4) {
+                if constexpr (((M - F) & 1) == 0) {
+                    if (refill) stage_piece((M - F) >> 1, rbuf);
+                }
+            } else {
+                if (refill) stage_piece(M - F, rbuf);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---- step B: k 16..31 -----------------------------------------------------------------------------------
+        wait_set(1);
+        static_for<0, NM>([&](auto mi) {
+            constexpr int M = decltype(mi)::value, a = M >> 2, b = M & 3;
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[1][a]),
+                                                                __builtin_bit_cast(bf16x8, fx[1][b]), acc[a][b], 0, 0, 0);
+            if constexpr (M < PB) {
+                if (refill) {
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) stage_piece(LA + M * PER + q, rbuf);
+                }
+                if constexpr (M == PB - 1) {
+                    if (refill) {
+                        advance();
+                        ++issued;
+                    }
+                    // tile it+1 must be in LDS before anybody reads it: my pieces of it are older than those of the
+                    // (at most NST-2) younger tiles in flight; the barrier collects everybody's
+                    const int younger = issued - it - 2;
+                    if (NST == 4 && younger >= 2) wait_vm<2 * L>();
+                    else if (younger >= 1) wait_vm<L>();
+                    else wait_vm<0>();
+                    __builtin_amdgcn_s_barrier();
+                }
+            } else if constexpr (M < PB + F) {
+                if (more) read_frag(std::integral_constant<int, M - PB>{}, 0, 0, (unsigned)(nbuf * STAGE));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        cur = nbuf;
+    }
+
+    // ---------------- epilogue: LDS transpose + full-line stores, software-pipelined -----------------------------------
+    // One unit = a 32-pixel x 64-channel block of the wave's tile (NI units).  Only four waves share the CU's load /
+    // store path here, so a unit's latency chain (accumulators -> LDS patch -> transposed rows -> residual -> store)
+    // would be fully exposed if the units ran back to back (measured 8 us per 256 x 256 tile, 20 us with an fp32
+    // residual).  Two patches per wave: unit i+1's patch writes, transposed reads and residual loads are issued
+    // before unit i is finished and stored.
+    __syncthreads();
+    if (p.prof) pt2 = wall_clock64();
+    const OutT* res = (const OutT*)p.residual;
+    constexpr int PATCH = 32 * EPITCH;
+    static_assert(4 * 2 * PATCH <= NST * STAGE, "two epilogue patches per wave must fit");
+    char* ep0 = smem + wave * (2 * PATCH);
+    OutT* y = (OutT*)p.y;
+    constexpr int NI = TM * (TN / 2);
+    float4 rd[2][4][2];
+    R8<OutT> late[2][4];
+    auto stage_in = [&](auto ii) {
+        constexpr int I = decltype(ii)::value, h = I / TM, b = I % TM;
+        char* ep = ep0 + (I & 1) * PATCH;
+        if (res) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = m0 + xrow0 + b * 32 + pass * 8 + (lane >> 3);
+                const int n = n0 + wrow0 + h * 64 + (lane & 7) * 8;
+                const bool ok = m < p.M && n < p.K;
+                late[I & 1][pass].load(res + (ok ? (long long)m * p.K + n : 0));
+            }
+        }
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = a2 * 32 + 8 * g + 4 * fh;
+                *(float4*)(ep + fr * EPITCH + nl * 4) =
+                    make_float4(acc[2 * h + a2][b][4 * g + 0], acc[2 * h + a2][b][4 * g + 1], acc[2 * h + a2][b][4 * g + 2],
+                                acc[2 * h + a2][b][4 * g + 3]);
+            }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + (lane >> 3), c8 = lane & 7;
+            rd[I & 1][pass][0] = *(const float4*)(ep + row * EPITCH + c8 * 32);
+            rd[I & 1][pass][1] = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
+        }
+    };
+    auto finish = [&](auto ii) {
+        constexpr int I = decltype(ii)::value, h = I / TM, b = I % TM;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + (lane >> 3), c8 = lane & 7;
+            const int m = m0 + xrow0 + b * 32 + row;
+            const int n = n0 + wrow0 + h * 64 + c8 * 8;
+            const float4 lo = rd[I & 1][pass][0], hi = rd[I & 1][pass][1];
+            if (m < p.M && n < p.K) {
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                ss[h].apply(v);
+                if (res) late[I & 1][pass].add_to(v);
+                if (p.act == MV_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (p.act == MV_ACT_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                }
+                long long off = (long long)m * p.K + n;
+                if (p.tok > 0) {          // 64 channels = one head = one 128-byte line: same store width, new home
+                    const int bi = m / p.tok, ti = m - bi * p.tok;
+                    off = (((long long)bi * (p.K >> 6) + (n >> 6)) * p.tok + ti) * 64 + (n & 63);
+                }
+                Out8<OutT>::st(y + off, v);
+            }
+        }
+    };
+    stage_in(std::integral_constant<int, 0>{});
+    static_for<0, NI>([&](auto ii) {
+        constexpr int I = decltype(ii)::value;
+        if constexpr (I + 1 < NI) stage_in(std::integral_constant<int, I + 1>{});
+        finish(ii);
+    });
+    if (p.prof && tid == 0) {
+        long long* o = p.prof + 4ll * blockIdx.x;
+        o[0] = pt0; o[1] = pt1; o[2] = pt2; o[3] = wall_clock64();
+    }
+}
+
+int igemm4_wanted(long long M, int C, int K, int R, int S) {
+    const long long ktiles = (long long)R * S * (C / 32);
+    if (C % 32 != 0 || R * S > 64 || K % 8 != 0) return 0;
+    if (get_flag("igemm4") >= 2) return 1;                // forced (tests): any shape the kernel can express
+    (void)M;
+    return ktiles >= 8;
+}
+
+// tile: 2 = 256 x 128 (two blocks per CU), 3 = 256 x 256 (one block per CU)
+int igemm4_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y,
+                  int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
+                  int act, int out_dtype, int tok, int tile, hipStream_t st) {
+    Igemm2P p;
+    p.tok = tok;
+    p.dbg = 0;
+    p.prof = (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo"));
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.zero = (const bf16_t*)zero_page(st);
+    if (!p.zero) {
+        set_error("igemm4: zero page allocation failed");
+        return MV_E_OOM;
+    }
+    p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S;
+    p.Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1;
+    p.Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
+    p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw;
+    p.M = (int)((long long)N * p.Ho * p.Wo);
+    p.act = act;
+    const int bn = tile == 3 ? 256 : 128;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (K + bn - 1) / bn;
+    const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
+#define GO(TN_, NST_, OT)                                                                                       \
+    do {                                                                                                        \
+        constexpr int SMEM = NST_ * (256 + 64 * TN_) * 64;                                                      \
+        auto kern = igemm4_kernel<TN_, NST_, OT>;                                                               \
+        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));       \
+        hipLaunchKernelGGL(kern, grid, block, SMEM, st, p);                                                     \
+    } while (0)
+    if (tile == 3) {
+        set_kernel_name(dense ? "igemm4_bf16_256x256_dense" : "igemm4_bf16_256x256_conv");
+        if (out_dtype == MV_F32) GO(4, 4, float);
+        else GO(4, 4, bf16_t);
+    } else {
+        set_kernel_name(dense ? "igemm4_bf16_256x128_dense" : "igemm4_bf16_256x128_conv");
+        if (out_dtype == MV_F32) GO(2, 3, float);
+        else GO(2, 3, bf16_t);
+    }
+#undef GO
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+}  // namespace mv

@@ -16,6 +16,7 @@ struct Igemm2P {
     int N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw;
     int M, tiles_m, tiles_n, act;   // M = rows covered by THIS launch (rows 0 .. M-1)
     int dbg;                        // experiments only
+    long long* prof;                // experiments only: per-block phase stamps
     int tok;                        // > 0: head-major output y[b][n/64][t][n%64], rows m = b*tok + t (qkv projection)
 };
 

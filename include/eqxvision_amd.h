@@ -42,7 +42,11 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  * the row count from which dense layers use the deep-pipelined kernels), "igemm3" (1 = prefer, 2 = force
  * the phase-alternating 256x256 kernel) / "no_igemm3", "c3x3_v1" (first-generation 3x3 64->64 kernel),
  * "no_stem_pool" (do not fuse the ResNet entry with its max-pool), "stream_npass1" (one channel slab
- * per block in the streaming 1x1 kernel).  All are A/B and test switches; 0 is the tuned default. */
+ * per block in the streaming 1x1 kernel), "no_skinny" (classifier heads on the tiled kernels), "res_early"
+ * (igemm2: fetch residual rows before the reduction instead of in its middle), "igemm4" (four-wave kernels of
+ * igemm4.hip: 1 = 256x128 tiles / two blocks per CU wherever igemm2 would run, 2 = force 256x256, 3 = force
+ * 256x128), "prof_lo" / "prof_hi" (device pointer for per-block phase stamps, tools/phase_prof.py).
+ * All are A/B and test switches; 0 is the tuned default. */
 
 int mv_abi_version(void);
 const char* mv_last_error(void);
