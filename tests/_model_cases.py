@@ -208,6 +208,47 @@ def lanes_case(model="resnet", lanes=2, B=6):
     return run
 
 
+def full_batch_case(model, B, lanes=2):
+    """BASELINE.json's full configuration (resnet50 / vit_base B=256, swin_t B=128) on the bench path -- filter_jit, hipGraph
+    replay, graph lanes -- checked through a size-independent property: the batch is 8 distinct images tiled B/8 times, so
+    (a) rows 0..7 must match the fp32 torch restatement of the same 8 images within the bf16 tolerance and (b) every
+    row r must agree with row r % 8 (same image, different position in the batch / tile / lane)."""
+    def run():
+        import warnings
+        import eqxvision_amd as eqv
+        x8 = S.synthetic_images(8, 224, seed=3)
+        if model == "resnet50":
+            sd = S.resnet_state(1, "bottleneck", (3, 4, 6, 3), 1000)
+            net = _load(eqv.models.resnet50, sd, num_classes=1000)
+            ref = TR.resnet_forward(sd, x8, "bottleneck", (3, 4, 6, 3)).numpy()
+        elif model == "vit_base":
+            sd = S.vit_state(1, 224, 16, 768, 12, 12, 4, 1000)
+            fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(eqv.models.VisionTransformer(**kw), torch_weights)
+            net = _load(fac, sd, img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12, num_classes=1000)
+            ref = TR.vit_forward(sd, x8, 16, 12, 12).numpy()
+        else:
+            sd = S.swin_state(1, (4, 4), 96, (2, 2, 6, 2), (3, 6, 12, 24), (7, 7), 4.0, 1000)
+            fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(eqv.models.SwinTransformer(**kw), torch_weights)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                net = _load(fac, sd, patch_size=[4, 4], embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24],
+                            window_size=[7, 7], num_classes=1000)
+            ref = TR.swin_forward(sd, x8, (4, 4), (2, 2, 6, 2), (3, 6, 12, 24), (7, 7)).numpy()
+        x = torch.as_tensor(np.asarray(x8)).repeat(B // 8, 1, 1, 1).cuda()
+        with eqv.precision("bf16"):
+            fwd = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k), lanes=lanes)
+            for _ in range(3):                      # trace, capture, replay
+                got = fwd(net, x, _keys(B))
+        got = got.float().cpu().numpy()
+        out = _cmp(got[:8], ref, 1e-2)
+        rep = np.abs(got.reshape(B // 8, 8, -1) - got[None, :8]).max()
+        out["replica_max_diff"] = float(rep)
+        out["replicas_bit_identical"] = bool(rep == 0.0)
+        out["ok"] = bool(out["ok"] and rep <= out["lim"])
+        return out
+    return run
+
+
 def all_cases(full=True):
     c = [("model/resnet_tiny_bottleneck", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2)),
          ("model/resnet18_64px", resnet_case("basic", (2, 2, 2, 2), 64, 2)),
@@ -226,5 +267,8 @@ def all_cases(full=True):
               ("model/alexnet_B4_fp32", alexnet_case(4, dtype="fp32")),
               ("model/resnet50_B2", resnet_case("bottleneck", (3, 4, 6, 3), 224, 2, classes=1000, full_ref="torch")),
               ("model/vit_base_B2", vit_case(224, 16, 768, 12, 12, 2, classes=1000, full_ref="torch")),
-              ("model/swin_t_B1", swin_case(224, 96, (2, 2, 6, 2), (3, 6, 12, 24), 1, classes=1000, full_ref="torch"))]
+              ("model/swin_t_B1", swin_case(224, 96, (2, 2, 6, 2), (3, 6, 12, 24), 1, classes=1000, full_ref="torch")),
+              ("model/resnet50_B256_full_config", full_batch_case("resnet50", 256)),
+              ("model/vit_base_B256_full_config", full_batch_case("vit_base", 256)),
+              ("model/swin_t_B128_full_config", full_batch_case("swin_t", 128))]
     return c
