@@ -232,7 +232,7 @@ def main():
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = float(tt.item())
 
-    compiled = next(iter(fwd._cache.values()))
+    compiled = fwd._entries()[0]
     rows = layer_table(compiled, a.layers) if rank == 0 else []
 
     if rank == 0:

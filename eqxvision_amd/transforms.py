@@ -57,10 +57,14 @@ def vmap(fn: Callable, in_axes=0, out_axes=0, axis_name=None, **_ignored) -> Cal
     return batched
 
 
+MAX_INPLACE_VARIANTS = 2   # per signature: graphs that read resident device inputs in place (one per buffer address)
+
+
 class _Compiled:
-    __slots__ = ("static_in", "calls", "keep", "out", "graph", "replays", "refs", "lane_calls")
+    __slots__ = ("static_in", "calls", "keep", "out", "graph", "replays", "refs", "lane_calls", "own_resident")
 
     def __init__(self):
+        self.own_resident = False      # True: resident device inputs are copied into owned buffers before each replay
         self.static_in = []
         self.lane_calls = None         # lanes > 1: one launch list per sub-batch (c.calls = their concatenation)
         self.calls = []
@@ -88,8 +92,8 @@ def _sig(x):
     if _is_array(x):
         if _is_key_array(x):
             return ("key", tuple(x.shape))
-        if _is_resident(x):            # read in place: the buffer address is part of the signature
-            return ("dev", tuple(x.shape), str(x.dtype), x.data_ptr())
+        if _is_resident(x):            # read in place; the buffer address selects the variant (see `jitted`)
+            return ("dev", tuple(x.shape), str(x.dtype))
         return ("arr", tuple(x.shape), str(x.dtype))
     if isinstance(x, Module) or callable(x):
         return ("obj", id(x))
@@ -185,26 +189,44 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
     @functools.wraps(fn)
     def jitted(*args, **kwargs):
         key = (compute_dtype(), tuple(_sig(a) for a in args), tuple((k, _sig(v)) for k, v in sorted(kwargs.items())))
-        c = cache.get(key)
+        # A graph bakes buffer addresses in.  Resident device inputs are read in place -- no staging copy -- by a
+        # variant per address tuple, at most MAX_INPLACE_VARIANTS of them (a double-buffered loader stays zero-copy);
+        # beyond that ONE more variant owns its input buffers and takes a device-to-device copy per call, so a caller
+        # that passes a fresh tensor every step neither retraces nor pins a new set of intermediates each time.
+        flat_all = list(args) + [v for _, v in sorted(kwargs.items())]
+        ptrs = tuple(v.data_ptr() for v in flat_all if _is_array(v) and _is_resident(v))
+        grp = cache.get(key)
+        if grp is None:
+            grp = cache[key] = {"variants": {}, "owned": None}
+        c = grp["variants"].get(ptrs)
+        own = False
+        if c is None and ptrs and len(grp["variants"]) >= MAX_INPLACE_VARIANTS:
+            c, own = grp["owned"], True
+        elif c is not None:
+            own = c.own_resident
 
         def staged(v):
-            return _is_array(v) and not _is_key_array(v) and not _is_resident(v)
+            return _is_array(v) and not _is_key_array(v) and (own or not _is_resident(v))
+
+        def stage(v):
+            return v.clone() if _is_resident(v) else _to_device_f32(v).clone()
 
         flat_arrays = [a for a in args if staged(a)] + [v for _, v in sorted(kwargs.items()) if staged(v)]
         if c is None:
             c = _Compiled()
+            c.own_resident = own
             c.refs = (args, kwargs)            # keep static objects (modules, resident inputs) alive
             new_args, new_kwargs = [], {}
             for a in args:
-                if staged(a):                  # host array: owned device staging buffer, refreshed per call
-                    t = _to_device_f32(a).clone()
+                if staged(a):                  # owned device staging buffer, refreshed per call
+                    t = stage(a)
                     c.static_in.append(t)
                     new_args.append(t)
                 else:
                     new_args.append(a)
             for k, v in sorted(kwargs.items()):
                 if staged(v):
-                    t = _to_device_f32(v).clone()
+                    t = stage(v)
                     c.static_in.append(t)
                     new_kwargs[k] = t
                 else:
@@ -219,7 +241,10 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
                         c.out = fn(*new_args, **new_kwargs)
                 finally:
                     _lib.set_recording(old)
-            cache[key] = c
+            if own:
+                grp["owned"] = c
+            else:
+                grp["variants"][ptrs] = c
             return _outputs(c)
         # refresh the static input buffers, then replay
         for dst, src in zip(c.static_in, flat_arrays):
@@ -265,4 +290,6 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
         return _outputs(c)
 
     jitted._cache = cache
+    jitted._entries = lambda: [c for g in cache.values()
+                               for c in list(g["variants"].values()) + ([g["owned"]] if g["owned"] is not None else [])]
     return jitted

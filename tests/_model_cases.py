@@ -198,13 +198,52 @@ def lanes_case(model="resnet", lanes=2, B=6):
             ref = np.concatenate([eqv.vmap(net, axis_name="batch")(x[l * step:(l + 1) * step], key=_keys(step)).cpu().numpy()
                                   for l in range(lanes)])
             errs.append(float(np.abs(got - ref).max()))
-        c = next(iter(fwd._cache.values()))
+        c = fwd._entries()[0]
         x = S.synthetic_images(B + 1, size, seed=9)          # B+1 not divisible: one lane, still correct
         got = fwd(net, x, _keys(B + 1)).cpu().numpy()
         ref = eqv.vmap(net, axis_name="batch")(x, key=_keys(B + 1)).cpu().numpy()
         errs.append(float(np.abs(got - ref).max()))
         return {"ok": max(errs) == 0.0 and c.lane_calls is not None and len(c.lane_calls) == lanes and c.graph is not None,
                 "errs": errs, "lanes": None if c.lane_calls is None else len(c.lane_calls)}
+    return run
+
+
+def fresh_inputs_case():
+    """A caller that hands filter_jit a NEW resident device tensor every step (the usual data-loader pattern): the first
+    MAX_INPLACE_VARIANTS addresses get zero-copy graphs, every later one reuses ONE variant that owns its input buffer
+    (device-to-device copy per call) -- no retrace, no unbounded pinning -- and every result equals the eager one."""
+    def run():
+        import eqxvision_amd as eqv
+        from eqxvision_amd import transforms as T
+        sd = S.resnet_state(1, "bottleneck", (1, 1, 1, 1), 10)
+        blk = eqv.models.classification.resnet._ResNetBottleneck
+        fac = lambda torch_weights=None, **kw: eqv.models.classification.resnet._resnet(blk, [1, 1, 1, 1], torch_weights, **kw)
+        net = _load(fac, sd, num_classes=10)
+        count = [0]
+
+        def body(n, im, k):
+            count[0] += 1
+            return eqv.vmap(n, axis_name="batch")(im, key=k)
+
+        fwd = eqv.filter_jit(body, lanes=2)
+        errs, held = [], []
+        for seed in range(9):
+            x = torch.as_tensor(S.synthetic_images(4, 64, seed=seed)).cuda()
+            held.append(x)                                   # keep them all alive: nine distinct addresses
+            got = fwd(net, x, _keys(4)).cpu().numpy()
+            ref = eqv.vmap(net, axis_name="batch")(x, key=_keys(4)).cpu().numpy()
+            errs.append(float(np.abs(got - ref).max()))
+        for seed in (0, 1):                                  # the first two buffers again: their zero-copy graphs replay
+            x = held[seed]
+            x.copy_(torch.as_tensor(S.synthetic_images(4, 64, seed=20 + seed)))
+            got = fwd(net, x, _keys(4)).cpu().numpy()
+            ref = eqv.vmap(net, axis_name="batch")(x, key=_keys(4)).cpu().numpy()
+            errs.append(float(np.abs(got - ref).max()))
+        ent = fwd._entries()
+        owned = [c for c in ent if c.own_resident]
+        return {"ok": max(errs) == 0.0 and len(ent) == T.MAX_INPLACE_VARIANTS + 1 and len(owned) == 1 and
+                count[0] == 2 * (T.MAX_INPLACE_VARIANTS + 1) and owned[0].graph is not None,
+                "errs": errs, "entries": len(ent), "traces": count[0], "owned_replays": owned[0].replays if owned else -1}
     return run
 
 
@@ -260,7 +299,8 @@ def all_cases(full=True):
          ("model/swin_tiny_fp32", swin_case(56, 32, (2, 2), (2, 4), 1, dtype="fp32")),
          ("model/filter_jit_replay", jit_case()),
          ("model/filter_jit_lanes2_resnet", lanes_case("resnet", 2, 6)),
-         ("model/filter_jit_lanes3_resnet", lanes_case("resnet", 3, 6))]
+         ("model/filter_jit_lanes3_resnet", lanes_case("resnet", 3, 6)),
+         ("model/filter_jit_fresh_device_inputs", fresh_inputs_case())]
     if full:
         c += [("model/alexnet_features_B2", alexnet_case(2, features_only=True)),
               ("model/alexnet_B4_bf16", alexnet_case(4)),
