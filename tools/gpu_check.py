@@ -13,11 +13,11 @@ from tests import _cases, _model_cases  # noqa: E402
 
 
 def main():
-    only = sys.argv[1] if len(sys.argv) > 1 else None
+    only = sys.argv[1:]                       # substrings; a case runs if it contains any of them
     results = []
     nfail = 0
     for name, fn in _cases.all_cases() + _model_cases.all_cases():
-        if only and only not in name:
+        if only and not any(o in name for o in only):
             continue
         t = time.time()
         try:
