@@ -16,14 +16,14 @@ torch is used for device memory and streams only; every computation goes through
 from __future__ import annotations
 
 import contextlib
-from typing import Optional, Tuple
+from typing import Tuple
 
 import numpy as np
 import torch
 
 from . import _lib
 
-_state = {"dtype": "bf16", "arena": None, "keep": None, "residual_fp32": True}
+_state = {"dtype": "bf16", "keep": None, "residual_fp32": True}
 
 DT = {"bf16": _lib.BF16, "fp32": _lib.F32}
 TORCH_DT = {"bf16": torch.bfloat16, "fp32": torch.float32}
@@ -72,30 +72,7 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-class Arena:
-    """Bump allocator over one torch buffer: used while a forward is captured into a hipGraph so
-    that every intermediate has a stable address owned by the compiled function."""
-
-    def __init__(self, nbytes: int):
-        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device())
-        self.off = 0
-        self.peak = 0
-
-    def alloc(self, shape, dtype: torch.dtype) -> torch.Tensor:
-        n = int(np.prod(shape)) if len(shape) else 1
-        nbytes = n * torch.empty((), dtype=dtype).element_size()
-        start = (self.off + 255) & ~255
-        if start + nbytes > self.buf.numel():
-            raise _lib.MVError(f"capture arena exhausted ({self.buf.numel()} B); raise arena_bytes")
-        self.off = start + nbytes
-        self.peak = max(self.peak, self.off)
-        return self.buf[start:start + nbytes].view(dtype).view(*shape)
-
-
 def empty(shape, dtype: torch.dtype) -> torch.Tensor:
-    a = _state["arena"]
-    if a is not None:
-        return a.alloc(tuple(shape), dtype)
     t = torch.empty(tuple(shape), dtype=dtype, device=device())
     k = _state["keep"]
     if k is not None:          # a recording owns every intermediate so replayed pointers stay valid
@@ -111,16 +88,6 @@ def keep_alive(lst):
         yield
     finally:
         _state["keep"] = old
-
-
-@contextlib.contextmanager
-def use_arena(arena: Optional[Arena]):
-    old = _state["arena"]
-    _state["arena"] = arena
-    try:
-        yield
-    finally:
-        _state["arena"] = old
 
 
 class Act:
