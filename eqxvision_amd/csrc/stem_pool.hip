@@ -13,7 +13,10 @@
 //     is neutral for a max over post-ReLU values (every pool window holds at least one real pixel);
 //   * after a barrier every thread pools 8 channels of one output pixel: 9 x ds_read_b128 + packed int16 max
 //     (non-negative bf16 order like their bit patterns) and ONE 16-byte store, 8 lanes per 128-byte NHWC line;
-//   * the next tile's patch is prefetched into registers under the MFMAs (persistent blocks).
+//   * TWO blocks share a CU (<= 128 VGPRs: `amdgpu_waves_per_eu(4, 4)` -- with 154 registers and five waves per block
+//     the second block was never co-resident, measured with per-block time stamps), so one block's patch load and
+//     pooling run under the other's MFMAs; the patch is fetched as aligned 4-pixel chunks (columns 4 px0 - 8 ..),
+//     5 loads per thread instead of 15 scalar ones.
 #include "mfma_common.h"
 
 namespace mv {
@@ -34,23 +37,41 @@ template <> __device__ __forceinline__ float ld_img<bf16_t>(const bf16_t* p) { r
 
 typedef short i16x8 __attribute__((ext_vector_type(8)));   // post-ReLU bf16 orders like int16 (and -0.0 = 0x8000 never wins)
 
-template <typename TX>
-__global__ __launch_bounds__(320, 2) void stem_pool_kernel(const StemPoolP p) {
+template <typename TX> struct Img4;
+template <> struct Img4<float> {
+    static __device__ __forceinline__ void ld(const float* p, float* v) {
+        const float4 t = *(const float4*)p;
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+};
+template <> struct Img4<bf16_t> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* v) {
+        const uint2 t = *(const uint2*)p;
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    }
+};
+
+// VEC: W % 4 == 0 and a 16-byte aligned image base -- every 4-pixel chunk is one aligned load, entirely inside or
+// entirely outside the image; otherwise the chunk is assembled from four bounds-checked scalar loads.
+template <typename TX, bool VEC>
+__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(4, 4))) void stem_pool_kernel(const StemPoolP p) {
     constexpr int C = 3, R = 7, S = 7, K = 64;
     constexpr int CT = 17;                                  // conv tile edge (2 * 8 + 1)
     constexpr int NPIX = CT * CT;                           // 289
     constexpr int PH = 2 * (CT - 1) + R;                    // 39 patch rows
-    constexpr int PWp = 40;                                 // patch row pitch (elements, even)
-    constexpr int PATCH = C * PH * PWp;                     // 4680
+    constexpr int PWp = 48;                                 // patch row pitch (elements): image columns 4 px0 - 8 .. + 47
+    constexpr int PATCH = C * PH * PWp;                     // 5616
+    constexpr int NCHUNK = C * PH * (PWp / 4);              // 1404 chunks of 4 pixels
     constexpr int NFRAG = C * R;                            // 21 fragments of 8 (s padded 7 -> 8)
     constexpr int NK16 = (NFRAG + 1) / 2;                   // 11
     constexpr int WPITCH = ((2 * NK16) | 1) * 16;           // 368 bytes
     constexpr int CPITCH = 144;                             // conv tile row pitch (bytes): 64 bf16 + 16
-    constexpr int NT = 320, NE = (PATCH + NT - 1) / NT;     // 15 patch elements per thread
+    constexpr int NT = 320, NE = (NCHUNK + NT - 1) / NT;    // 5 chunks per thread
     constexpr int OFF_PATCH = K * WPITCH;                                  // 23552
-    constexpr int OFF_CTILE = OFF_PATCH + ((PATCH * 2 + 15) & ~15);         // + 9360
+    constexpr int OFF_CTILE = OFF_PATCH + ((PATCH * 2 + 15) & ~15);         // + 11232
     constexpr int OFF_FTAB = OFF_CTILE + NPIX * CPITCH;                     // + 41616
-    extern __shared__ __attribute__((aligned(16))) char smem[];             // 74.6 KB: two blocks per CU
+    extern __shared__ __attribute__((aligned(16))) char smem[];             // 76.9 KB: two blocks per CU
     char* wl = smem;
     bf16_t* patch = (bf16_t*)(smem + OFF_PATCH);
     char* ctile = smem + OFF_CTILE;
@@ -59,14 +80,15 @@ __global__ __launch_bounds__(320, 2) void stem_pool_kernel(const StemPoolP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
 
-    // weight slab (k' = (c, r, s8) order, zero padded), once per block
+    // weight slab (k' = (c, r, s8) order, s8 = [0, s0 .. s6]: a B fragment starts one pixel LEFT of the window so that
+    // it is 4-byte aligned in the patch), once per block
     for (int i = tid; i < K * 2 * NK16; i += NT) {
         const int row = i / (2 * NK16), f = i - row * (2 * NK16);
         uint32_t u[4] = {0, 0, 0, 0};
         if (f < NFRAG) {
             const bf16_t* src = p.w + ((long long)row * C * R + f) * S;
 #pragma unroll
-            for (int e = 0; e < S; ++e) u[e >> 1] |= (uint32_t)src[e] << ((e & 1) * 16);
+            for (int e = 0; e < S; ++e) u[(e + 1) >> 1] |= (uint32_t)src[e] << (((e + 1) & 1) * 16);   // slot 0 = pad
         }
         *(uint4*)(wl + row * WPITCH + f * 16) = make_uint4(u[0], u[1], u[2], u[3]);
     }
@@ -87,37 +109,45 @@ __global__ __launch_bounds__(320, 2) void stem_pool_kernel(const StemPoolP p) {
         py0 = ty * 8;
         px0 = tx * 8;
     };
-    // patch element i of thread: i = j * NT + tid -> (c, yy, xx); input pixel (4*py0 - 5 + yy, 4*px0 - 5 + xx)
-    float pv[NE];
-    auto prefetch = [&](int tile) {
-        int b, py0, px0;
-        origin(tile, b, py0, px0);
-        const int hi0 = 4 * py0 - 5, wi0 = 4 * px0 - 5;
-        const TX* xb = xg + (long long)b * C * HW;
-#pragma unroll
-        for (int j = 0; j < NE; ++j) {
-            const int i = j * NT + tid;
-            const int xx = i % PWp, t2 = i / PWp;
-            const int yy = t2 % PH, c = t2 / PH;
-            const int hi = hi0 + yy, wi = wi0 + xx;
-            const bool ok = i < PATCH && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const float t = ld_img<TX>(xb + (ok ? (long long)c * HW + (long long)hi * p.W + wi : 0));
-            pv[j] = ok ? t : 0.f;
-        }
-    };
-    if ((int)blockIdx.x < p.tiles) prefetch(blockIdx.x);
-
+    // chunk i of thread: i = j * NT + tid -> (c, yy, q): input row 4*py0 - 5 + yy, columns 4*px0 - 8 + 4q .. + 3
     for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
         int b, py0, px0;
         origin(tile, b, py0, px0);
+        const int hi0 = 4 * py0 - 5, wi0 = 4 * px0 - 8;
+        const TX* xb = xg + (long long)b * C * HW;
+        float pv[NE][4];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int i = j * NT + tid;
+            const int q = i % (PWp / 4), t2 = i / (PWp / 4);
+            const int yy = t2 % PH, c = t2 / PH;
+            const int hi = hi0 + yy, wi = wi0 + 4 * q;
+            const bool rowok = i < NCHUNK && (unsigned)hi < (unsigned)p.H;
+            if constexpr (VEC) {
+                const bool ok = rowok && (unsigned)wi < (unsigned)p.W;
+                Img4<TX>::ld(xb + (ok ? (long long)c * HW + (long long)hi * p.W + wi : 0), pv[j]);
+                if (!ok) pv[j][0] = pv[j][1] = pv[j][2] = pv[j][3] = 0.f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = rowok && (unsigned)(wi + e) < (unsigned)p.W;
+                    const float t = ld_img<TX>(xb + (ok ? (long long)c * HW + (long long)hi * p.W + wi + e : 0));
+                    pv[j][e] = ok ? t : 0.f;
+                }
+            }
+        }
         __syncthreads();                      // previous tile: MFMAs done with the patch, pooling done with ctile
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int i = j * NT + tid;
-            if (i < PATCH) patch[i] = f2bf(pv[j]);
+            if (i < NCHUNK) {
+                uint2 u;
+                u.x = pack_bf2(pv[j][0], pv[j][1]);
+                u.y = pack_bf2(pv[j][2], pv[j][3]);
+                *(uint2*)(patch + 4 * i) = u;
+            }
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < p.tiles) prefetch(tile + gridDim.x);   // flies under the MFMAs below
 
         // ---- convolution: 10 pixel tiles of 32 over the 17 x 17 conv region (conv origin 2*py0 - 1, 2*px0 - 1)
 #pragma unroll 1
@@ -125,7 +155,7 @@ __global__ __launch_bounds__(320, 2) void stem_pool_kernel(const StemPoolP p) {
             const int idx = t * 32 + fr;
             const int ic = idx < NPIX ? idx : NPIX - 1;
             const int cy = ic / CT, cx = ic - cy * CT;
-            const int lbase = (2 * cy) * PWp + 2 * cx;      // patch element offset of my window origin (even)
+            const int lbase = (2 * cy) * PWp + 2 * cx + 2;  // one pixel left of my window origin (column 3 + 2cx): even
             f32x16 acc[2];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -219,14 +249,16 @@ int stem_pool_launch(const void* x, const void* w, const float* scale, const flo
     p.tiles = (int)tiles;
     int gx = p.tiles < 512 ? p.tiles : 512;               // two persistent blocks per CU
     set_kernel_name(x_dtype == MV_F32 ? "stem_pool_mfma_f32in" : "stem_pool_mfma_bf16in");
-    constexpr int SMEM = 64 * 368 + 9360 + 289 * 144 + 128 * 4;
-#define GO(TX_)                                                                                                  \
+    constexpr int SMEM = 64 * 368 + 11232 + 289 * 144 + 128 * 4;
+    const bool vec = W % 4 == 0 && ((uintptr_t)x & 15) == 0;
+#define GO(TX_, V_)                                                                                              \
     do {                                                                                                         \
-        auto kern = stem_pool_kernel<TX_>;                                                                       \
+        auto kern = stem_pool_kernel<TX_, V_>;                                                                   \
         MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));        \
         hipLaunchKernelGGL(kern, dim3(gx), dim3(320), SMEM, st, p);                                              \
     } while (0)
-    if (x_dtype == MV_F32) GO(float); else GO(bf16_t);
+    if (x_dtype == MV_F32) { if (vec) GO(float, true); else GO(float, false); }
+    else { if (vec) GO(bf16_t, true); else GO(bf16_t, false); }
 #undef GO
     MV_LAUNCH_CHECK();
     return MV_OK;

@@ -653,6 +653,8 @@ def all_cases():
           ("stem/pool_fused_odd_75x93", stem_pool_case(2, 75, 93, seed=8)),
           ("stem/pool_fused_negative_gamma", stem_pool_case(2, 96, 96, seed=9, neg_scale=True)),
           ("stem/pool_fused_many_tiles", stem_pool_case(40, 128, 128, seed=10)),
+          ("stem/pool_fused_odd_bf16in_61x70", stem_pool_case(3, 61, 70, xdtype="bf16", seed=11)),
+          ("stem/pool_fused_w228_h30", stem_pool_case(2, 30, 228, seed=12)),
           ("stem/vit_224_bf16in", conv_nchw_case(2, 3, 224, 224, 768, 16, 16, 16, 0, tokens=True, xdtype="bf16")),
           ("stem/patch8_notokens", conv_nchw_case(3, 3, 40, 48, 192, 8, 8, 8, 0)),
           ("stem/odd_size_7x7", conv_nchw_case(1, 3, 61, 75, 32, 7, 7, 2, 3, act=1))]
