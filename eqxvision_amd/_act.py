@@ -91,12 +91,14 @@ def keep_alive(lst):
 
 
 class Act:
-    __slots__ = ("t", "kind", "batched")
+    __slots__ = ("t", "kind", "batched", "pre")
 
     def __init__(self, t: torch.Tensor, kind: str, batched: bool):
         self.t = t
         self.kind = kind
         self.batched = batched
+        self.pre = None     # (module, Act): the result of applying `module` (+ its norm + relu) to this activation was
+                            # already produced by the launch that produced it (ops.conv1x1_chain)
 
     @property
     def B(self) -> int:

@@ -1,0 +1,227 @@
+// Two pointwise layers in one streaming kernel (ResNet-50 layer1, 56x56): the last convolution of a bottleneck and
+// the first convolution of the NEXT one (reference resnet.py:144-162, blocks chained by nn.Sequential :330-333),
+//
+//   y [m, 0:256] = relu( scale3 * (W3  t2[m, 0:64]) + shift3 + res[m, 0:256] )        -> HBM (the next block's identity)
+//   t1[m, 0:64]  = relu( scale1 * (W1n y [m, 0:256]) + shift1 )                        -> HBM (the next block's conv2 input)
+//
+// Each of the two layers alone runs at the HBM roofline (stream1x1.hip, 5.3 TB/s); what is left to save is traffic:
+// un-fused the 256-channel map y is written once and read twice (as the next conv1's input and as the next residual).
+// Here the second GEMM consumes y while a wave still holds it: -411 MB per block boundary at batch 256.
+//
+// Structure = stream1x1.hip with both 128-channel slabs of W3 resident (weights in LDS, every wave free-runs over
+// 32-pixel tiles, x fragments straight from HBM into registers, no block barrier in the steady state), plus:
+//   * after a 64-channel chunk of y has been finished (scale / shift / residual / ReLU, rounded to bf16, stored), the
+//     same bf16 values are written back into the wave's LDS patch as [32 pixels][64 channels] -- exactly the B operand
+//     layout of the second GEMM -- and 8 MFMAs accumulate W1n[:, chunk] * y_chunk into two more accumulators;
+//   * after the fourth chunk the 32 x 64 result goes through the usual patch transpose and is stored as whole lines.
+// The second GEMM therefore sees y exactly as the next layer would read it from HBM (bf16-rounded): bit-identical to
+// the un-fused pair.
+#include "mfma_common.h"
+
+namespace mv {
+
+struct ChainP {
+    const bf16_t* x;        // t2 [M][64]
+    const bf16_t* w3;       // [256][64]
+    const float* scale3;
+    const float* shift3;
+    const bf16_t* residual; // [M][256]
+    bf16_t* y;              // [M][256]
+    const bf16_t* w1;       // [64][256]
+    const float* scale1;
+    const float* shift1;
+    bf16_t* t1;             // [M][64]
+    int M, tiles_m;
+};
+
+__global__ __launch_bounds__(512) void chain1x1_kernel(const ChainP p) {
+    constexpr int C = 64, K = 256, N2 = 64, WAVES = 8;
+    constexpr int KC = C / 16;                                  // 4 k16-steps of the first GEMM
+    constexpr int W3P = C * 2 + 16;                             // 144: odd number of 16-byte slots
+    constexpr int W1P = K * 2 + 16;                             // 528
+    constexpr int EPITCH = 64 * 4 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* w3l = smem;                                           // [256][W3P]
+    char* w1l = w3l + K * W3P;                                  // [64][W1P]
+    float* sct = (float*)(w1l + N2 * W1P);                      // scale3[256], shift3[256], scale1[64], shift1[64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* ep = (char*)(sct + 2 * K + 2 * N2) + wave * (32 * EPITCH);
+
+    for (int i = tid; i < K * (C / 8); i += WAVES * 64) {       // W3: 8 chunks of 16 bytes per row
+        const int row = i >> 3, ch = i & 7;
+        *(uint4*)(w3l + row * W3P + ch * 16) = *(const uint4*)(p.w3 + (long long)row * C + ch * 8);
+    }
+    for (int i = tid; i < N2 * (K / 8); i += WAVES * 64) {      // W1n: 32 chunks per row
+        const int row = i >> 5, ch = i & 31;
+        *(uint4*)(w1l + row * W1P + ch * 16) = *(const uint4*)(p.w1 + (long long)row * K + ch * 8);
+    }
+    for (int i = tid; i < K; i += WAVES * 64) {
+        sct[i] = p.scale3 ? p.scale3[i] : 1.f;
+        sct[K + i] = p.shift3 ? p.shift3[i] : 0.f;
+    }
+    if (tid < N2) {
+        sct[2 * K + tid] = p.scale1 ? p.scale1[tid] : 1.f;
+        sct[2 * K + N2 + tid] = p.shift1 ? p.shift1[tid] : 0.f;
+    }
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
+    const char* w3f = w3l + fr * W3P + fh * 16;                 // + (a*32)*W3P + kk*32
+    const char* w1f = w1l + fr * W1P + fh * 16;                 // + (a2*32)*W1P + (chunk*4 + kk2)*32
+
+    auto load_x = [&](uint4* xf, int tile) {
+        int m = tile * 32 + fr;
+        m = m < p.M ? m : p.M - 1;                              // clamp: rows past the end are never stored
+        const bf16_t* src = p.x + (long long)m * C + fh * 8;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) xf[kk] = *(const uint4*)(src + kk * 16);
+    };
+
+    auto run_tile = [&](uint4* xf, int tile, int refill) {
+        f32x16 acc2[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[a][e] = 0.f;
+#pragma unroll 1
+        for (int ps = 0; ps < 2; ++ps) {                        // 128-channel slab of y
+            uint4 rr[2][4];                                     // residual rows of the slab's two 64-channel chunks
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    int m = tile * 32 + pass * 8 + (lane >> 3);
+                    m = m < p.M ? m : p.M - 1;
+                    rr[c][pass] = *(const uint4*)(p.residual + (long long)m * K + ps * 128 + c * 64 + (lane & 7) * 8);
+                }
+            f32x16 acc[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+            const char* wf = w3f + (size_t)ps * 128 * W3P;
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const uint4 av = *(const uint4*)(wf + a * 32 * W3P + kk * 32);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                     __builtin_bit_cast(bf16x8, xf[kk]), acc[a], 0, 0, 0);
+                }
+            if (ps == 1 && refill < p.tiles_m) load_x(xf, refill);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int chunk = ps * 2 + c;                   // 64-channel chunk of y
+#pragma unroll
+                for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int a = 2 * c + a2;
+                        const int nl = a2 * 32 + 8 * g + 4 * fh;
+                        *(float4*)(ep + fr * EPITCH + nl * 4) =
+                            make_float4(acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3]);
+                    }
+                const int c8 = lane & 7;
+                const int nloc = chunk * 64 + c8 * 8;
+                const float4 s0 = *(const float4*)(sct + nloc), s1 = *(const float4*)(sct + nloc + 4);
+                const float4 h0 = *(const float4*)(sct + K + nloc), h1 = *(const float4*)(sct + K + nloc + 4);
+                const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int row = pass * 8 + (lane >> 3);
+                    const int m = tile * 32 + row;
+                    const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
+                    const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
+                    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    const uint32_t rw[4] = {rr[c][pass].x, rr[c][pass].y, rr[c][pass].z, rr[c][pass].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] = fmaf(v[2 * e], scv[2 * e], shv[2 * e]) + __uint_as_float(rw[e] << 16);
+                        v[2 * e + 1] = fmaf(v[2 * e + 1], scv[2 * e + 1], shv[2 * e + 1]) + __uint_as_float(rw[e] & 0xffff0000u);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    uint4 u;
+                    u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+                    if (m < p.M) *(uint4*)(p.y + (long long)m * K + nloc) = u;
+                    // the same bf16 values, row-major in the patch: the B operand of the second GEMM.  (This pass's
+                    // fp32 reads of these rows are older LDS operations of the same wave: in-order, no hazard.)
+                    *(uint4*)(ep + row * EPITCH + c8 * 16) = u;
+                }
+#pragma unroll
+                for (int kk2 = 0; kk2 < 4; ++kk2) {
+                    const uint4 bv = *(const uint4*)(ep + fr * EPITCH + (2 * kk2 + fh) * 16);
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2) {
+                        const uint4 av = *(const uint4*)(w1f + a2 * 32 * W1P + (chunk * 4 + kk2) * 32);
+                        acc2[a2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                           __builtin_bit_cast(bf16x8, bv), acc2[a2], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- second layer's epilogue: 32 pixels x 64 channels
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = a2 * 32 + 8 * g + 4 * fh;
+                *(float4*)(ep + fr * EPITCH + nl * 4) =
+                    make_float4(acc2[a2][4 * g], acc2[a2][4 * g + 1], acc2[a2][4 * g + 2], acc2[a2][4 * g + 3]);
+            }
+        const int c8 = lane & 7;
+        const float* s2 = sct + 2 * K + c8 * 8;
+        const float4 s0 = *(const float4*)s2, s1 = *(const float4*)(s2 + 4);
+        const float4 h0 = *(const float4*)(s2 + N2), h1 = *(const float4*)(s2 + N2 + 4);
+        const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + (lane >> 3);
+            const int m = tile * 32 + row;
+            const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
+            const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], scv[e], shv[e]), 0.f);
+            if (m < p.M) Out8<bf16_t>::st(p.t1 + (long long)m * N2 + c8 * 8, v);
+        }
+    };
+
+    uint4 xa[KC], xb[KC];                                       // two pixel tiles in flight per wave
+    int tile = gw;
+    if (tile < p.tiles_m) load_x(xa, tile);
+    if (tile + nw < p.tiles_m) load_x(xb, tile + nw);
+    for (; tile < p.tiles_m; tile += 2 * nw) {
+        run_tile(xa, tile, tile + 2 * nw);
+        if (tile + nw < p.tiles_m) run_tile(xb, tile + nw, tile + 3 * nw);
+    }
+}
+
+int chain1x1_supported(long long M, int C, int K, int N2, int dtype) {
+    return dtype == MV_BF16 && C == 64 && K == 256 && N2 == 64 && M >= 8192 && M < (1LL << 31) - 64 && !get_flag("no_chain");
+}
+
+int chain1x1_launch(const void* x, const void* w3, const float* scale3, const float* shift3, const void* residual, void* y,
+                    const void* w1, const float* scale1, const float* shift1, void* t1, long long M, hipStream_t st) {
+    ChainP p;
+    p.x = (const bf16_t*)x; p.w3 = (const bf16_t*)w3; p.scale3 = scale3; p.shift3 = shift3;
+    p.residual = (const bf16_t*)residual; p.y = (bf16_t*)y;
+    p.w1 = (const bf16_t*)w1; p.scale1 = scale1; p.shift1 = shift1; p.t1 = (bf16_t*)t1;
+    p.M = (int)M;
+    p.tiles_m = (int)((M + 31) / 32);
+    constexpr int SMEM = 256 * 144 + 64 * 528 + (2 * 256 + 2 * 64) * 4 + 8 * 32 * (64 * 4 + 16);
+    int gx = 256;
+    const int need = (p.tiles_m + 7) / 8;
+    if (gx > need) gx = need;
+    set_kernel_name("chain1x1_bf16_64_256_64");
+    auto kern = chain1x1_kernel;
+    MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(512), SMEM, st, p);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+}  // namespace mv

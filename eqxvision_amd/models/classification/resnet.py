@@ -96,10 +96,24 @@ class _ResNetBottleneck(Module):
 
     @boundary
     def __call__(self, x, *, key=None):                       # reference :144-162
+        return self.call_chained(x, None)
+
+    def call_chained(self, x, nxt):
+        """The block; `nxt` = the bottleneck that follows in the stage's nn.Sequential (or None).  When the library can,
+        this block's last convolution and `nxt`'s first one are ONE launch (ops.conv1x1_chain) and `nxt` finds its
+        conv1 output attached to its input."""
+        pre = x.pre if ops.is_act(x) else None
         x = ops.as_map(x)
-        out = ops.conv2d(x, self.conv1, self.bn1, "relu")
+        if pre is not None and pre[0] is self.conv1:
+            out = pre[1]
+        else:
+            out = ops.conv2d(x, self.conv1, self.bn1, "relu")
         out = ops.conv2d(out, self.conv2, self.bn2, "relu")
         identity = _shortcut(self, x)
+        if isinstance(nxt, _ResNetBottleneck):
+            y = ops.conv1x1_chain(out, self.conv3, self.bn3, identity, nxt.conv1, nxt.bn1)
+            if y is not None:
+                return y
         return ops.conv2d(out, self.conv3, self.bn3, "relu", residual=identity)
 
 

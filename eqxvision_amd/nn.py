@@ -311,6 +311,13 @@ class Sequential(Module):
                 x = ops.linear(x, layer, a)
                 i = j
                 continue
+            if hasattr(layer, "call_chained") and is_act(x):
+                # consecutive residual blocks (resnet.py:330-333): the block may fuse its tail with the next one's head
+                x = layer.call_chained(x, L[i + 1] if i + 1 < len(L) else None)
+                i += 1
+                continue
             x = layer(x, key=keys[i])
             i += 1
+        if is_act(x):
+            x.pre = None                     # a result attached for a block that is not in this Sequential is dropped
         return x

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._act import Act, DT, TORCH_DT, compute_dtype, device, empty, residual_fp32, stream_ptr
+from ._act import Act, is_act, DT, TORCH_DT, compute_dtype, device, empty, residual_fp32, stream_ptr
 
 ACT = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "gelu": _lib.ACT_GELU_TANH}
 
@@ -201,6 +201,40 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
     _lib.call("mv_conv2d_nhwc_fwd", _ptr(x.t), _ptr(w), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y),
               B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, conv.groups, ACT[act], DT[dt], DT[dt], stream_ptr())
     return Act(y, "map", x.batched)
+
+
+def _pointwise(conv) -> bool:
+    return (tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (0, 0)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1)
+
+
+def conv1x1_chain(x: Act, conv3, bn3, residual: Act, conv1n, bn1n) -> Optional[Act]:
+    """relu(bn3(conv3(x)) + residual), and in the same launch relu(bn1n(conv1n(.))) of that result: the tail of one
+    ResNet bottleneck and the head of the next (resnet.py:144-162).  Returns the first result with the second attached
+    as `.pre = (conv1n, Act)`, or None when the library has no fused path for the shapes (caller falls back to conv2d)."""
+    dt = compute_dtype()
+    if dt != "bf16" or not (_pointwise(conv3) and _pointwise(conv1n)) or conv3.out_channels != conv1n.in_channels:
+        return None
+    _check_bn(bn3)
+    _check_bn(bn1n)
+    x, residual = as_map(x), as_map(residual)
+    B, H, W, C = x.t.shape
+    K, N2 = conv3.out_channels, conv1n.out_channels
+    M = B * H * W
+    if C != conv3.in_channels or tuple(residual.t.shape) != (B, H, W, K) or x.t.dtype != torch.bfloat16 \
+            or residual.t.dtype != torch.bfloat16:
+        return None
+    if not _lib.load().mv_conv1x1_chain_supported(M, C, K, N2, DT[dt]):
+        return None
+    w3, s3, h3 = prep_conv(conv3, bn3, "krsc", dt)
+    w1, s1, h1 = prep_conv(conv1n, bn1n, "krsc", dt)
+    y = empty((B, H, W, K), torch.bfloat16)
+    t1 = empty((B, H, W, N2), torch.bfloat16)
+    _lib.call("mv_conv1x1_chain_fwd", _ptr(x.t), _ptr(w3), _ptr(s3), _ptr(h3), _ptr(residual.t), _ptr(y), _ptr(w1), _ptr(s1),
+              _ptr(h1), _ptr(t1), M, C, K, N2, DT[dt], stream_ptr())
+    out = Act(y, "map", x.batched)
+    out.pre = (conv1n, Act(t1, "map", x.batched))
+    return out
 
 
 def stem_conv_pool(x: Act, conv, bn, act, pool) -> Act:

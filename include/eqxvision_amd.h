@@ -42,7 +42,7 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  * the row count from which dense layers use the deep-pipelined kernels), "igemm3" (1 = prefer, 2 = force
  * the phase-alternating 256x256 kernel) / "no_igemm3", "c3x3_v1" (first-generation 3x3 64->64 kernel),
  * "no_stem_pool" (do not fuse the ResNet entry with its max-pool), "stream_npass1" (one channel slab
- * per block in the streaming 1x1 kernel), "no_skinny" (classifier heads on the tiled kernels), "res_early"
+ * per block in the streaming 1x1 kernel), "no_chain" (do not fuse conv3 with the next block's conv1), "no_skinny" (classifier heads on the tiled kernels), "res_early"
  * (igemm2: fetch residual rows before the reduction instead of in its middle), "igemm4" (four-wave kernels of
  * igemm4.hip: 1 = 256x128 tiles / two blocks per CU wherever igemm2 would run, 2 = force 256x256, 3 = force
  * 256x128), "prof_lo" / "prof_hi" (device pointer for per-block phase stamps, tools/phase_prof.py).
@@ -91,6 +91,19 @@ int mv_stem_conv_pool_fwd(const void* x, const void* w, const float* scale, cons
                           int N, int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw,
                           int pool_k, int pool_s, int pool_p, int act, int x_dtype, int out_dtype,
                           mv_stream_t stream);
+
+/* Two chained pointwise layers of consecutive ResNet bottlenecks in one launch (resnet.py:144-162: block i's
+ * conv3 -> bn3 -> + identity -> relu, then block i+1's conv1 -> bn1 -> relu; blocks chained by nn.Sequential, :330-333):
+ *   y [M,K]  = relu(scale3[k] * (x[M,C] . w3[K,C]^T) + shift3[k] + residual[M,K])
+ *   t1[M,N2] = relu(scale1[n] * (y[M,K] . w1[N2,K]^T) + shift1[n])
+ * All operands bf16, NHWC rows; y is rounded to bf16 before the second product, exactly as the un-fused pair
+ * (two mv_conv2d_nhwc_fwd calls) would see it.  mv_conv1x1_chain_supported() says whether the shape has the path
+ * (C=64, K=256, N2=64, M >= 8192). */
+int mv_conv1x1_chain_supported(int64_t M, int C, int K, int N2, int dtype);
+int mv_conv1x1_chain_fwd(const void* x, const void* w3, const float* scale3, const float* shift3,
+                         const void* residual, void* y, const void* w1, const float* scale1,
+                         const float* shift1, void* t1, int64_t M, int C, int K, int N2, int dtype,
+                         mv_stream_t stream);
 
 /* eqx.nn.Linear under vmap / Linear2d (vit.py:64,74; mlps.py:60-64; resnet.py:356;
  * extensions_2d.py:31-50):  y[M,N] = act(scale[n]*(x[M,K] . w[N,K]^T) + shift[n] + residual[M,N]) */

@@ -114,6 +114,51 @@ def conv_nhwc_case(N, H, W, C, K, R, S, stride=1, pad=0, dil=1, groups=1, act=0,
     return run
 
 
+def chain_case(M, seed=0):
+    """mv_conv1x1_chain_fwd (bottleneck tail + next bottleneck head in one launch, resnet.py:144-162) vs the oracle,
+    and bit-for-bit vs the library's own un-fused pair of 1x1 convolutions."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        C, K, N2 = 64, 256, 64
+        x = bf(rng.standard_normal((M, C)))
+        w3 = bf(rng.standard_normal((K, C)) / np.sqrt(C))
+        s3 = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        s3[::5] *= -1.0
+        h3 = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        r = bf(rng.standard_normal((M, K)))
+        w1 = bf(rng.standard_normal((N2, K)) / np.sqrt(K))
+        s1 = rng.uniform(0.5, 1.5, N2).astype(np.float32)
+        h1 = (0.1 * rng.standard_normal(N2)).astype(np.float32)
+        if not L.load().mv_conv1x1_chain_supported(M, C, K, N2, 1):
+            return {"ok": False, "err": "mv_conv1x1_chain_supported says no"}
+        yref = O.relu((x.astype(np.float64) @ w3.astype(np.float64).T) * s3 + h3 + r)
+        t1ref = O.relu((bf(yref).astype(np.float64) @ w1.astype(np.float64).T) * s1 + h1)
+        d = {k: dev(v, "bf16") for k, v in dict(x=x, w3=w3, r=r, w1=w1).items()}
+        f = {k: dev(v, "fp32") for k, v in dict(s3=s3, h3=h3, s1=s1, h1=h1).items()}
+        y = torch.full((M, K), -7.0, dtype=torch.bfloat16, device="cuda")
+        t1 = torch.full((M, N2), -7.0, dtype=torch.bfloat16, device="cuda")
+        L.call("mv_conv1x1_chain_fwd", d["x"].data_ptr(), d["w3"].data_ptr(), f["s3"].data_ptr(), f["h3"].data_ptr(),
+               d["r"].data_ptr(), y.data_ptr(), d["w1"].data_ptr(), f["s1"].data_ptr(), f["h1"].data_ptr(), t1.data_ptr(),
+               M, C, K, N2, 1, _stream())
+        kern = L.last_kernel()
+        y2 = torch.empty_like(y)
+        t2 = torch.empty_like(t1)
+        L.call("mv_linear_fwd", d["x"].data_ptr(), d["w3"].data_ptr(), f["s3"].data_ptr(), f["h3"].data_ptr(), d["r"].data_ptr(),
+               y2.data_ptr(), M, K, C, 1, 1, 1, _stream())
+        L.call("mv_linear_fwd", y2.data_ptr(), d["w1"].data_ptr(), f["s1"].data_ptr(), f["h1"].data_ptr(), None,
+               t2.data_ptr(), M, N2, K, 1, 1, 1, _stream())
+        torch.cuda.synchronize()
+        a = _cmp(host(y), yref, TOL_BF16)
+        b = _cmp(host(t1), t1ref, TOL_BF16)
+        same_y = bool(torch.equal(y, y2))
+        dt1 = float((t1.float() - t2.float()).abs().max())
+        return {"ok": a["ok"] and b["ok"] and same_y and dt1 <= b["lim"], "err": max(a["err"], b["err"]), "lim": a["lim"],
+                "y_bit_identical_to_unfused": same_y, "t1_bit_identical_to_unfused": dt1 == 0.0, "t1_vs_unfused": dt1,
+                "kernel": kern}
+    return run
+
+
 def conv_nchw_case(N, C, H, W, K, R, S, stride, pad, act=0, xdtype="fp32", tokens=False, generic=False, seed=0,
                    v0=False):
     def run():
@@ -606,6 +651,9 @@ def all_cases():
           ("igemm4/t128_k160_five_tiles", conv_nhwc_case(4, 20, 20, 160, 264, 1, 1, seed=193, flags=("igemm4=3",))),
           ("igemm4/5x5", conv_nhwc_case(6, 27, 27, 64, 192, 5, 5, pad=2, act=1, scale=False, seed=92, flags=("igemm4=2",))),
           ("igemm4/t128_5x5", conv_nhwc_case(6, 27, 27, 64, 192, 5, 5, pad=2, act=1, scale=False, seed=192, flags=("igemm4=3",))),
+          ("chain/56x56_B4", chain_case(4 * 56 * 56, seed=1)),
+          ("chain/ragged_M", chain_case(8192 + 37, seed=2)),
+          ("chain/many_tiles", chain_case(40 * 56 * 56 + 5, seed=3)),
           ("igemm/old_kernel_3x3_128_28", conv_nhwc_case(8, 28, 28, 128, 128, 3, 3, pad=1, act=1, seed=11, flags=("no_igemm2",))),
           ("igemm/old_kernel_1x1_64_256", conv_nhwc_case(4, 56, 56, 64, 256, 1, 1, act=1, res=True, flags=("no_stream",))),
           ("stream/64_256_res", conv_nhwc_case(4, 56, 56, 64, 256, 1, 1, act=1, res=True)),
