@@ -34,8 +34,12 @@ struct ChainP {
     int M, tiles_m;
 };
 
-__global__ __launch_bounds__(512) void chain1x1_kernel(const ChainP p) {
-    constexpr int C = 64, K = 256, N2 = 64, WAVES = 8;
+// N2 = 64: the next block of the same stage (8 waves).  N2 = 128: the first block of the next stage, whose conv1 is
+// still stride 1 on the 56x56 map (ResNet v1.5 strides the 3x3); its weights take 66 KB, so 6 waves' patches fit.
+template <int N2, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
+    constexpr int C = 64, K = 256;
+    constexpr int T2 = N2 / 32;                                 // 32-channel tiles of the second GEMM
     constexpr int KC = C / 16;                                  // 4 k16-steps of the first GEMM
     constexpr int W3P = C * 2 + 16;                             // 144: odd number of 16-byte slots
     constexpr int W1P = K * 2 + 16;                             // 528
@@ -59,7 +63,8 @@ __global__ __launch_bounds__(512) void chain1x1_kernel(const ChainP p) {
         sct[i] = p.scale3 ? p.scale3[i] : 1.f;
         sct[K + i] = p.shift3 ? p.shift3[i] : 0.f;
     }
-    if (tid < N2) {
+    for (int tid2 = tid; tid2 < N2; tid2 += WAVES * 64) {
+        const int tid = tid2;
         sct[2 * K + tid] = p.scale1 ? p.scale1[tid] : 1.f;
         sct[2 * K + N2 + tid] = p.shift1 ? p.shift1[tid] : 0.f;
     }
@@ -79,9 +84,9 @@ __global__ __launch_bounds__(512) void chain1x1_kernel(const ChainP p) {
     };
 
     auto run_tile = [&](uint4* xf, int tile, int refill) {
-        f32x16 acc2[2];
+        f32x16 acc2[T2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < T2; ++a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc2[a][e] = 0.f;
 #pragma unroll 1
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(512) void chain1x1_kernel(const ChainP p) {
                 for (int kk2 = 0; kk2 < 4; ++kk2) {
                     const uint4 bv = *(const uint4*)(ep + fr * EPITCH + (2 * kk2 + fh) * 16);
 #pragma unroll
-                    for (int a2 = 0; a2 < 2; ++a2) {
+                    for (int a2 = 0; a2 < T2; ++a2) {
                         const uint4 av = *(const uint4*)(w1f + a2 * 32 * W1P + (chunk * 4 + kk2) * 32);
                         acc2[a2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
                                                                            __builtin_bit_cast(bf16x8, bv), acc2[a2], 0, 0, 0);
@@ -162,31 +167,35 @@ __global__ __launch_bounds__(512) void chain1x1_kernel(const ChainP p) {
                 }
             }
         }
-        // ---- second layer's epilogue: 32 pixels x 64 channels
+        // ---- second layer's epilogue: 32 pixels x N2 channels, 64 at a time
 #pragma unroll
-        for (int a2 = 0; a2 < 2; ++a2)
+        for (int c2 = 0; c2 < N2 / 64; ++c2) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = a2 * 32 + 8 * g + 4 * fh;
-                *(float4*)(ep + fr * EPITCH + nl * 4) =
-                    make_float4(acc2[a2][4 * g], acc2[a2][4 * g + 1], acc2[a2][4 * g + 2], acc2[a2][4 * g + 3]);
+            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = a2 * 32 + 8 * g + 4 * fh;
+                    *(float4*)(ep + fr * EPITCH + nl * 4) =
+                        make_float4(acc2[2 * c2 + a2][4 * g], acc2[2 * c2 + a2][4 * g + 1], acc2[2 * c2 + a2][4 * g + 2],
+                                    acc2[2 * c2 + a2][4 * g + 3]);
+                }
+            const int c8 = lane & 7;
+            const float* s2 = sct + 2 * K + c2 * 64 + c8 * 8;
+            const float4 s0 = *(const float4*)s2, s1 = *(const float4*)(s2 + 4);
+            const float4 h0 = *(const float4*)(s2 + N2), h1 = *(const float4*)(s2 + N2 + 4);
+            const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = pass * 8 + (lane >> 3);
+                const int m = tile * 32 + row;
+                const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
+                const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], scv[e], shv[e]), 0.f);
+                if (m < p.M) Out8<bf16_t>::st(p.t1 + (long long)m * N2 + c2 * 64 + c8 * 8, v);
             }
-        const int c8 = lane & 7;
-        const float* s2 = sct + 2 * K + c8 * 8;
-        const float4 s0 = *(const float4*)s2, s1 = *(const float4*)(s2 + 4);
-        const float4 h0 = *(const float4*)(s2 + N2), h1 = *(const float4*)(s2 + N2 + 4);
-        const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int row = pass * 8 + (lane >> 3);
-            const int m = tile * 32 + row;
-            const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
-            const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
-            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], scv[e], shv[e]), 0.f);
-            if (m < p.M) Out8<bf16_t>::st(p.t1 + (long long)m * N2 + c8 * 8, v);
         }
     };
 
@@ -201,27 +210,38 @@ __global__ __launch_bounds__(512) void chain1x1_kernel(const ChainP p) {
 }
 
 int chain1x1_supported(long long M, int C, int K, int N2, int dtype) {
-    return dtype == MV_BF16 && C == 64 && K == 256 && N2 == 64 && M >= 8192 && M < (1LL << 31) - 64 && !get_flag("no_chain");
+    return dtype == MV_BF16 && C == 64 && K == 256 && (N2 == 64 || N2 == 128) && M >= 8192 && M < (1LL << 31) - 64 &&
+           !get_flag("no_chain");
+}
+
+template <int N2, int WAVES>
+static int chain_go(ChainP& p, hipStream_t st) {
+    constexpr int SMEM = 256 * 144 + N2 * 528 + (2 * 256 + 2 * N2) * 4 + WAVES * 32 * (64 * 4 + 16);
+    static_assert(SMEM <= 160 * 1024, "LDS");
+    int gx = 256;
+    const int need = (p.tiles_m + WAVES - 1) / WAVES;
+    if (gx > need) gx = need;
+    auto kern = chain1x1_kernel<N2, WAVES>;
+    MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(WAVES * 64), SMEM, st, p);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
 }
 
 int chain1x1_launch(const void* x, const void* w3, const float* scale3, const float* shift3, const void* residual, void* y,
-                    const void* w1, const float* scale1, const float* shift1, void* t1, long long M, hipStream_t st) {
+                    const void* w1, const float* scale1, const float* shift1, void* t1, long long M, int N2, hipStream_t st) {
     ChainP p;
     p.x = (const bf16_t*)x; p.w3 = (const bf16_t*)w3; p.scale3 = scale3; p.shift3 = shift3;
     p.residual = (const bf16_t*)residual; p.y = (bf16_t*)y;
     p.w1 = (const bf16_t*)w1; p.scale1 = scale1; p.shift1 = shift1; p.t1 = (bf16_t*)t1;
     p.M = (int)M;
     p.tiles_m = (int)((M + 31) / 32);
-    constexpr int SMEM = 256 * 144 + 64 * 528 + (2 * 256 + 2 * 64) * 4 + 8 * 32 * (64 * 4 + 16);
-    int gx = 256;
-    const int need = (p.tiles_m + 7) / 8;
-    if (gx > need) gx = need;
-    set_kernel_name("chain1x1_bf16_64_256_64");
-    auto kern = chain1x1_kernel;
-    MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    hipLaunchKernelGGL(kern, dim3(gx), dim3(512), SMEM, st, p);
-    MV_LAUNCH_CHECK();
-    return MV_OK;
+    if (N2 == 64) {
+        set_kernel_name("chain1x1_bf16_64_256_64");
+        return chain_go<64, 8>(p, st);
+    }
+    set_kernel_name("chain1x1_bf16_64_256_128");
+    return chain_go<128, 6>(p, st);
 }
 
 }  // namespace mv

@@ -113,7 +113,7 @@ int igemm2_launch(const void* x, const void* w, const float* scale, const float*
 int igemm2_tile_shape(long long M, int K, int* bm, int* bn);
 int chain1x1_supported(long long M, int C, int K, int N2, int dtype);
 int chain1x1_launch(const void* x, const void* w3, const float* scale3, const float* shift3, const void* residual, void* y,
-                    const void* w1, const float* scale1, const float* shift1, void* t1, long long M, hipStream_t st);
+                    const void* w1, const float* scale1, const float* shift1, void* t1, long long M, int N2, hipStream_t st);
 int igemm4_wanted(long long M, int C, int K, int R, int S);
 int igemm4_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                   void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh,

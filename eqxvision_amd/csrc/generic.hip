@@ -750,7 +750,7 @@ int mv_conv1x1_chain_fwd(const void* x, const void* w3, const float* scale3, con
                   (long long)M, C, K, N2);
         return MV_E_UNSUPPORTED;
     }
-    return chain1x1_launch(x, w3, scale3, shift3, residual, y, w1, scale1, shift1, t1, M, (hipStream_t)stream);
+    return chain1x1_launch(x, w3, scale3, shift3, residual, y, w1, scale1, shift1, t1, M, N2, (hipStream_t)stream);
 }
 
 int mv_linear_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* residual,

@@ -200,10 +200,12 @@ class ResNet(Module):
             x = ops.stem_conv_pool(x, self.conv1, self.bn1, "relu", self.maxpool)   # reference :243-254, one launch
         else:
             x = self.maxpool(ops.conv2d(x, self.conv1, self.bn1, "relu"))
-        x = self.layer1(x)
-        x = self.layer2(x)
-        x = self.layer3(x)
-        x = self.layer4(x)
+        stages = [self.layer1, self.layer2, self.layer3, self.layer4]
+        for i, stage in enumerate(stages):
+            # the last block of a stage may fuse its tail with the head of the next stage's first block
+            nxt = stages[i + 1][0] if i + 1 < len(stages) and isinstance(stages[i + 1], nn.Sequential) and \
+                len(stages[i + 1]) > 0 else None
+            x = stage.call_chained(x, nxt) if isinstance(stage, nn.Sequential) else stage(x)
         x = self.avgpool(x)
         x = ops.flatten(x)
         return ops.linear(x, self.fc, out_fp32=True)

@@ -284,6 +284,11 @@ class Sequential(Module):
 
     @boundary
     def __call__(self, x, *, key=None):
+        return self.call_chained(x, None, key=key)
+
+    def call_chained(self, x, nxt, *, key=None):
+        """`__call__`, with `nxt` = the module that will consume the result (or None): the last layer may then fuse
+        its tail with `nxt`'s head (see _ResNetBottleneck.call_chained) and attach that result as `.pre`."""
         L = self.layers
         keys = [None] * len(L) if key is None else list(jr.split(key, max(len(L), 1)))
         i = 0
@@ -313,11 +318,9 @@ class Sequential(Module):
                 continue
             if hasattr(layer, "call_chained") and is_act(x):
                 # consecutive residual blocks (resnet.py:330-333): the block may fuse its tail with the next one's head
-                x = layer.call_chained(x, L[i + 1] if i + 1 < len(L) else None)
+                x = layer.call_chained(x, L[i + 1] if i + 1 < len(L) else nxt)
                 i += 1
                 continue
             x = layer(x, key=keys[i])
             i += 1
-        if is_act(x):
-            x.pre = None                     # a result attached for a block that is not in this Sequential is dropped
         return x

@@ -98,7 +98,7 @@ int mv_stem_conv_pool_fwd(const void* x, const void* w, const float* scale, cons
  *   t1[M,N2] = relu(scale1[n] * (y[M,K] . w1[N2,K]^T) + shift1[n])
  * All operands bf16, NHWC rows; y is rounded to bf16 before the second product, exactly as the un-fused pair
  * (two mv_conv2d_nhwc_fwd calls) would see it.  mv_conv1x1_chain_supported() says whether the shape has the path
- * (C=64, K=256, N2=64, M >= 8192). */
+ * (C=64, K=256, N2=64 or 128, M >= 8192). */
 int mv_conv1x1_chain_supported(int64_t M, int C, int K, int N2, int dtype);
 int mv_conv1x1_chain_fwd(const void* x, const void* w3, const float* scale3, const float* shift3,
                          const void* residual, void* y, const void* w1, const float* scale1,

@@ -114,13 +114,13 @@ def conv_nhwc_case(N, H, W, C, K, R, S, stride=1, pad=0, dil=1, groups=1, act=0,
     return run
 
 
-def chain_case(M, seed=0):
+def chain_case(M, seed=0, N2=64):
     """mv_conv1x1_chain_fwd (bottleneck tail + next bottleneck head in one launch, resnet.py:144-162) vs the oracle,
     and bit-for-bit vs the library's own un-fused pair of 1x1 convolutions."""
     def run():
         L = _lib()
         rng = _rng(seed)
-        C, K, N2 = 64, 256, 64
+        C, K = 64, 256
         x = bf(rng.standard_normal((M, C)))
         w3 = bf(rng.standard_normal((K, C)) / np.sqrt(C))
         s3 = rng.uniform(0.5, 1.5, K).astype(np.float32)
@@ -654,6 +654,8 @@ def all_cases():
           ("chain/56x56_B4", chain_case(4 * 56 * 56, seed=1)),
           ("chain/ragged_M", chain_case(8192 + 37, seed=2)),
           ("chain/many_tiles", chain_case(40 * 56 * 56 + 5, seed=3)),
+          ("chain/n128_56x56_B4", chain_case(4 * 56 * 56, seed=4, N2=128)),
+          ("chain/n128_ragged_many", chain_case(33 * 56 * 56 + 21, seed=5, N2=128)),
           ("igemm/old_kernel_3x3_128_28", conv_nhwc_case(8, 28, 28, 128, 128, 3, 3, pad=1, act=1, seed=11, flags=("no_igemm2",))),
           ("igemm/old_kernel_1x1_64_256", conv_nhwc_case(4, 56, 56, 64, 256, 1, 1, act=1, res=True, flags=("no_stream",))),
           ("stream/64_256_res", conv_nhwc_case(4, 56, 56, 64, 256, 1, 1, act=1, res=True)),
