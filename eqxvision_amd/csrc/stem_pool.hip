@@ -110,7 +110,16 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         px0 = tx * 8;
     };
     // chunk i of thread: i = j * NT + tid -> (c, yy, q): input row 4*py0 - 5 + yy, columns 4*px0 - 8 + 4q .. + 3
-    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+    // XCD-aware tile order: blocks are dispatched round-robin over the 8 XCDs, each with its own L2.  XCD x owns the
+    // contiguous tile range [x T/8, (x+1) T/8) and its blocks stride through it together, so the overlapping halo
+    // columns / rows of neighbouring tiles are fetched from HBM once per XCD instead of once per tile (PMC: 224 MB
+    // fetched per 128 images for 77 MB of pixels with the plain grid-stride order).
+    const bool by_xcd = gridDim.x >= 8;
+    const int xcd = by_xcd ? (blockIdx.x & 7) : 0, jloc = by_xcd ? (blockIdx.x >> 3) : blockIdx.x;
+    const int per_x = by_xcd ? ((gridDim.x + 7 - xcd) >> 3) : gridDim.x;        // blocks that landed on my XCD
+    const int t_lo = by_xcd ? (int)(((long long)p.tiles * xcd) >> 3) : 0;
+    const int t_hi = by_xcd ? (int)(((long long)p.tiles * (xcd + 1)) >> 3) : p.tiles;
+    for (int tile = t_lo + jloc; tile < t_hi; tile += per_x) {
         int b, py0, px0;
         origin(tile, b, py0, px0);
         const int hi0 = 4 * py0 - 5, wi0 = 4 * px0 - 8;
