@@ -905,6 +905,20 @@ int mv_linear_heads_fwd(const void* x, const void* w, const float* scale, const 
                   (long long)M, N, K, tokens, dh);
         return MV_E_UNSUPPORTED;
     }
+    const int ov = (!get_flag("igemm2_tile") && !get_flag("igemm3") && !get_flag("igemm4")) ? tile_override("ovh", M, N, K, 1, 1, 1) : 0;
+    if ((ov == 2 || ov == 3) ) {
+        igemm2_force_tile(ov);
+        const int rc = igemm2_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE,
+                                     MV_BF16, 0, tokens, (hipStream_t)stream);
+        igemm2_force_tile(0);
+        return rc;
+    }
+    if (ov == 4 && igemm3_wanted(M, K, N, 1, 1))
+        return igemm3_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE, MV_BF16,
+                             tokens, (hipStream_t)stream);
+    if ((ov == 5 || ov == 6) && igemm4_wanted(M, K, N, 1, 1))
+        return igemm4_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE, MV_BF16,
+                             tokens, ov == 6 ? 3 : 2, (hipStream_t)stream);
     if (get_flag("igemm4") >= 1 && igemm4_wanted(M, K, N, 1, 1))
         return igemm4_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE, MV_BF16,
                              tokens, get_flag("igemm4") == 2 ? 3 : 2, (hipStream_t)stream);

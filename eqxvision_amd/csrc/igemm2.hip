@@ -344,8 +344,11 @@ int igemm2_wanted(long long M, int C, int K, int R, int S) {
 }
 
 // block tile igemm2_launch will pick for (M rows, K output channels)
+static thread_local int g_forced_tile = 0;          // set around one launch by the per-shape override (igemm.hip)
+void igemm2_force_tile(int tile) { g_forced_tile = tile; }
+
 int igemm2_tile_shape(long long M, int K, int* bm, int* bn) {
-    int tile = get_flag("igemm2_tile");
+    int tile = g_forced_tile ? g_forced_tile : get_flag("igemm2_tile");
     if (tile == 0) {
         const long long big_tiles = ((M + 255) / 256) * (long long)((K + 255) / 256);
         tile = K <= 64 ? 1 : ((K >= 1024 && big_tiles >= 512) ? 3 : 2);
