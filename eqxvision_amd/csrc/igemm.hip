@@ -292,16 +292,27 @@ static int launch_tile(IgemmP& p, bool dense, bool out_f32, hipStream_t st) {
     return MV_OK;
 }
 
-// Per-shape kernel choice for tools/tune_tiles.py: "ov:<M>:<C>:<K>:<R>:<S>:<stride>" flags (greedy search on whole-model
-// time).  Choices: 1/2/3 = igemm2 256x64 / 256x128 / 256x256, 4 = igemm3, 5 / 6 = igemm4 256x128 / 256x256, 7 / 8 =
-// 128x128 / 128x64 (this file), 9 = stream1x1; 0 = the rules below.  Round 1 result (resnet50 B=256, two lanes, 19
-// shapes x 8 candidates): four shapes improved by 0.4-0.6% each, +0.4% in total -- inside the run-to-run drift -- so
-// no table is compiled in: the rules stand.
+// Per-shape kernel choice: "ov:<M>:<C>:<K>:<R>:<S>:<stride>" flags (tools/tune_tiles.py sets them while it searches:
+// greedy, one shape at a time, judged on whole-model ms/step in one process) and the short table of shapes where the
+// search beat the rules below by more than its 0.4% threshold.  Choices: 1/2/3 = igemm2 256x64 / 256x128 / 256x256,
+// 4 = igemm3, 5 / 6 = igemm4 256x128 / 256x256, 7 / 8 = 128x128 / 128x64 (this file), 9 = stream1x1; 0 = the rules.
+// Round 1 (profiles/r01/*_tile_search.txt): resnet50 B=256 and swin_t B=128 -- nothing above the drift (+0.4% / -0.4%
+// in total), rules kept; vit_base B=256, two lanes -- three shapes, +3.5% together:
+struct TunedTile { const char* kind; int M, a, b, R, S, sh, choice; };
+static const TunedTile kTuned[] = {
+    {"ov", 25216, 3072, 768, 1, 1, 1, 3},     // ViT-B fc2 (+fp32 residual): igemm2 256x256, 13.73 -> 13.44 ms/step
+    {"ovh", 25216, 2304, 768, 1, 1, 1, 5},    // ViT-B qkv, head-major: igemm4 256x128 (two blocks per CU), 13.46 -> 13.36
+    {"ov", 25216, 768, 768, 1, 1, 1, 6},      // ViT-B attention projection: igemm4 256x256, 13.38 -> 13.27
+};
 int tile_override(const char* kind, long long M, int a, int b, int R, int S, int sh) {
     char key[96];
     snprintf(key, sizeof(key), "%s:%lld:%d:%d:%d:%d:%d", kind, M, a, b, R, S, sh);
     const int f = get_flag(key);
-    return f > 0 ? f : 0;
+    if (f) return f > 0 ? f : 0;                          // a negative flag = "the rules", whatever the table says
+    if (get_flag("no_tuned")) return 0;
+    for (const TunedTile& t : kTuned)
+        if (!strcmp(t.kind, kind) && t.M == M && t.a == a && t.b == b && t.R == R && t.S == S && t.sh == sh) return t.choice;
+    return 0;
 }
 
 int igemm_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y,

@@ -45,7 +45,8 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  * per block in the streaming 1x1 kernel), "no_chain" (do not fuse conv3 with the next block's conv1), "no_skinny" (classifier heads on the tiled kernels), "res_early"
  * (igemm2: fetch residual rows before the reduction instead of in its middle), "igemm4" (four-wave kernels of
  * igemm4.hip: 1 = 256x128 tiles / two blocks per CU wherever igemm2 would run, 2 = force 256x256, 3 = force
- * 256x128), "prof_lo" / "prof_hi" (device pointer for per-block phase stamps, tools/phase_prof.py).
+ * 256x128), "prof_lo" / "prof_hi" (device pointer for per-block phase stamps, tools/phase_prof.py), "no_tuned" (ignore the
+ * table of tuned shapes) and "ov:<M>:<C>:<K>:<R>:<S>:<stride>" / "ovh:..." (per-shape kernel choice, tools/tune_tiles.py).
  * All are A/B and test switches; 0 is the tuned default. */
 
 int mv_abi_version(void);
