@@ -574,6 +574,45 @@ def misc_case(kind, dtype="bf16", seed=0):
     return run
 
 
+def fuzz_cases(n, seed=0, mfma_only=False):
+    """`n` random convolution / linear shapes for the DEFAULT dispatch (tools/fuzz_ops.py and the `fuzz/` pytest cases):
+    any tap count / stride / padding / dilation / residual / activation / output dtype, sized so the oracle stays fast."""
+    rng = np.random.default_rng(seed)
+    ch = [64, 64, 128, 128, 192, 256, 256, 320, 384, 512, 768] if mfma_only else \
+        [8, 16, 24, 32, 48, 64, 96, 128, 160, 192, 256, 320, 384, 512, 768]
+    out = []
+    i = 0
+    while len(out) < n:
+        i += 1
+        if rng.random() < 0.66:
+            R = int(rng.choice([1, 1, 3, 3, 3, 5, 7]))
+            C, K = int(rng.choice(ch)), int(rng.choice(ch))
+            H, W = int(rng.integers(5, 60)), int(rng.integers(5, 60))
+            N = int(max(1, min(rng.integers(1, 300), 6e9 // (H * W * C * K * R * R))))
+            stride = int(rng.choice([1, 1, 2]))
+            dil = int(rng.choice([1, 1, 2])) if R > 1 else 1
+            pad = int(rng.choice([0, (R - 1) // 2 * dil, 1]))
+            if H + 2 * pad < dil * (R - 1) + 1 or W + 2 * pad < dil * (R - 1) + 1:
+                continue
+            act = int(rng.choice([0, 1, 2]))
+            res = bool(rng.random() < 0.4)
+            o = "fp32" if rng.random() < 0.25 else "same"
+            name = f"fuzz/s{seed}_conv_N{N}_{H}x{W}_C{C}_K{K}_{R}x{R}_s{stride}_p{pad}_d{dil}_a{act}_r{int(res)}_{o}"
+            out.append((name, conv_nhwc_case(N, H, W, C, K, R, R, stride=stride, pad=pad, dil=dil, act=act, res=res, out=o,
+                                             seed=1000 + i)))
+        else:
+            K = int(rng.choice(ch + [1024, 2048, 3072]))
+            Nn = int(rng.choice(ch + [1000, 1024, 2304]))
+            M = int(rng.choice([1, 7, 33, 128, 200, 257, 1000, 3136, 6272, 12544, 25000]))
+            M = int(max(1, min(M, 4e9 // (K * Nn))))
+            act = int(rng.choice([0, 1, 2]))
+            res = bool(rng.random() < 0.4)
+            o = "fp32" if rng.random() < 0.3 else "same"
+            name = f"fuzz/s{seed}_linear_M{M}_K{K}_N{Nn}_a{act}_r{int(res)}_{o}"
+            out.append((name, linear_case(M, K, Nn, act=act, res=res, out=o, seed=2000 + i)))
+    return out
+
+
 def all_cases():
     c = []
     # ---- implicit-GEMM conv (MFMA) : ResNet-50 shapes at reduced spatial size + edge cases
@@ -766,4 +805,5 @@ def all_cases():
           ("misc/eltwise", misc_case("eltwise")),
           ("misc/eltwise_f32", misc_case("eltwise", "fp32")),
           ("misc/affine_cls", misc_case("affine_cls"))]
+    c += fuzz_cases(24, seed=3) + fuzz_cases(16, seed=4, mfma_only=True)      # default dispatch, random shapes
     return c
