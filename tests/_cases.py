@@ -613,6 +613,54 @@ def fuzz_cases(n, seed=0, mfma_only=False):
     return out
 
 
+def fuzz_misc_cases(n, seed=0):
+    """Random shapes for the non-GEMM kernels: LayerNorm (row length / dtype / out dtype), attention (tokens, heads),
+    Swin window attention (map size, shift), pools, the fused ResNet entry and the chained 1x1 pair."""
+    rng = np.random.default_rng(seed)
+    out = []
+    i = 0
+    while len(out) < n:
+        i += 1
+        k = int(rng.integers(0, 7))
+        sd = 3000 + i
+        if k == 0:
+            C = int(rng.choice([32, 64, 96, 128, 192, 256, 384, 512, 768, 1024, 1536, 40, 100]))
+            M = int(rng.choice([1, 5, 63, 197, 1000, 3136, 12544, 50000]))
+            dt = str(rng.choice(["bf16", "fp32"]))
+            o = str(rng.choice(["bf16", "fp32"])) if dt == "fp32" or rng.random() < 0.5 else None
+            out.append((f"fuzzm/s{seed}_ln_M{M}_C{C}_{dt}_{o}", layernorm_case(M, C, dtype=dt, out=o, seed=sd)))
+        elif k == 1:
+            B, N = int(rng.integers(1, 40)), int(rng.choice([5, 17, 50, 64, 65, 128, 197, 200, 256]))
+            H, dh = int(rng.choice([1, 2, 3, 4, 6, 12])), int(rng.choice([32, 64]))
+            out.append((f"fuzzm/s{seed}_mha_B{B}_N{N}_H{H}_dh{dh}", mha_case(B, N, H, dh, probs=bool(rng.random() < 0.5), seed=sd)))
+        elif k == 2:
+            ws = 7
+            Hf = ws * int(rng.choice([1, 2, 3, 4, 8]))
+            heads = int(rng.choice([1, 2, 3, 6]))
+            shift = 0 if Hf == ws or rng.random() < 0.4 else 3
+            out.append((f"fuzzm/s{seed}_swin_B{3}_H{Hf}_h{heads}_sh{shift}",
+                        swin_attn_case(int(rng.integers(1, 5)), Hf, 32 * heads, heads, ws, shift, seed=sd)))
+        elif k == 3:
+            kk, st = (3, 2) if rng.random() < 0.6 else (2, 2)
+            pd = int(rng.choice([0, 1])) if kk == 3 else 0
+            out.append((f"fuzzm/s{seed}_maxpool_{i}", maxpool_case(int(rng.integers(1, 6)), int(rng.integers(7, 70)),
+                                                                  int(rng.integers(7, 70)), int(rng.choice([8, 64, 96, 192, 256])),
+                                                                  kk, st, pd, seed=sd)))
+        elif k == 4:
+            hw = int(rng.choice([6, 7, 12, 14]))
+            oh = int(rng.choice([1, hw]))
+            out.append((f"fuzzm/s{seed}_avgpool_{i}", avgpool_case(int(rng.integers(1, 9)), hw, hw, int(rng.choice([64, 256, 768, 2048])),
+                                                                  oh, oh, seed=sd)))
+        elif k == 5:
+            out.append((f"fuzzm/s{seed}_stem_pool_{i}", stem_pool_case(int(rng.integers(1, 5)), int(rng.integers(20, 130)),
+                                                                      int(rng.integers(20, 130)),
+                                                                      xdtype=str(rng.choice(["fp32", "bf16"])), seed=sd)))
+        else:
+            out.append((f"fuzzm/s{seed}_chain_{i}", chain_case(8192 + int(rng.integers(0, 30000)), seed=sd,
+                                                              N2=int(rng.choice([64, 128])))))
+    return out
+
+
 def all_cases():
     c = []
     # ---- implicit-GEMM conv (MFMA) : ResNet-50 shapes at reduced spatial size + edge cases
@@ -806,4 +854,5 @@ def all_cases():
           ("misc/eltwise_f32", misc_case("eltwise", "fp32")),
           ("misc/affine_cls", misc_case("affine_cls"))]
     c += fuzz_cases(24, seed=3) + fuzz_cases(16, seed=4, mfma_only=True)      # default dispatch, random shapes
+    c += fuzz_misc_cases(24, seed=5)
     return c

@@ -11,7 +11,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 fails = 0
 kernels = {}
-for name, fn in T.fuzz_cases(n, seed, mfma_only=bool(os.environ.get("MFMA_ONLY"))):
+cases = T.fuzz_misc_cases(n, seed) if os.environ.get("MISC") else T.fuzz_cases(n, seed, mfma_only=bool(os.environ.get("MFMA_ONLY")))
+for name, fn in cases:
     try:
         info = fn()
         ok = bool(info["ok"])
