@@ -54,12 +54,19 @@ __global__ __launch_bounds__(512) void igemm3_kernel(const Igemm2P p) {
     const int cpt = p.C >> 5;
     const int nk = p.R * p.S * cpt;
     const long long wrow_stride = (long long)p.R * p.S * p.C;
+    const bool dense1x1 = p.R == 1 && p.S == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0;   // block-uniform
     long long xbase[2];
     unsigned vlo[2], vhi[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = m0 + 16 * (wave + 8 * j) + srow;
         const bool valid = m < p.M;
+        if (dense1x1) {                                   // a Linear: row m is pixel m, one tap, no division chain
+            xbase[j] = (long long)m * p.C + chunk * 8;
+            vlo[j] = valid ? 1u : 0u;
+            vhi[j] = 0u;
+            continue;
+        }
         const int wo = m % p.Wo;
         const int tt = m / p.Wo;
         const int ho = tt % p.Ho;

@@ -67,10 +67,17 @@ __global__ __launch_bounds__(256, TN == 2 ? 2 : 1) void igemm4_kernel(const Igem
     const long long wrow_stride = (long long)p.R * p.S * p.C;
     long long xbase[NP];
     unsigned vlo[NP], vhi[NP];
+    const bool dense = p.R == 1 && p.S == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0;   // block-uniform
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int m = m0 + 16 * (wave + 4 * j) + srow;
         const bool valid = m < p.M;
+        if (dense) {                                      // a Linear: row m is pixel m, one tap, no division chain
+            xbase[j] = (long long)m * p.C + chunk * 8;
+            vlo[j] = valid ? 1u : 0u;
+            vhi[j] = 0u;
+            continue;
+        }
         const int wo = m % p.Wo;
         const int tt = m / p.Wo;
         const int ho = tt % p.Ho;
