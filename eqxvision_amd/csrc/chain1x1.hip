@@ -51,13 +51,38 @@ __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     char* ep = (char*)(sct + 2 * K + 2 * N2) + wave * (32 * EPITCH);
 
-    for (int i = tid; i < K * (C / 8); i += WAVES * 64) {       // W3: 8 chunks of 16 bytes per row
-        const int row = i >> 3, ch = i & 7;
-        *(uint4*)(w3l + row * W3P + ch * 16) = *(const uint4*)(p.w3 + (long long)row * C + ch * 8);
-    }
-    for (int i = tid; i < N2 * (K / 8); i += WAVES * 64) {      // W1n: 32 chunks per row
-        const int row = i >> 5, ch = i & 31;
-        *(uint4*)(w1l + row * W1P + ch * 16) = *(const uint4*)(p.w1 + (long long)row * K + ch * 8);
+    // both weight matrices -> LDS, 16-byte chunks, several loads in flight per thread (one load per loop trip made the
+    // prologue a chain of dependent L2 round trips)
+    {
+        constexpr int NT = WAVES * 64, N3 = K * (C / 8), N1 = N2 * (K / 8), U = 4;
+        for (int base = 0; base < N3; base += U * NT) {
+            uint4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * NT + tid;
+                const int ic = i < N3 ? i : N3 - 1;
+                v[u] = *(const uint4*)(p.w3 + (long long)(ic >> 3) * C + (ic & 7) * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * NT + tid;
+                if (i < N3) *(uint4*)(w3l + (i >> 3) * W3P + (i & 7) * 16) = v[u];
+            }
+        }
+        for (int base = 0; base < N1; base += U * NT) {
+            uint4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * NT + tid;
+                const int ic = i < N1 ? i : N1 - 1;
+                v[u] = *(const uint4*)(p.w1 + (long long)(ic >> 5) * K + (ic & 31) * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * NT + tid;
+                if (i < N1) *(uint4*)(w1l + (i >> 5) * W1P + (i & 31) * 16) = v[u];
+            }
+        }
     }
     for (int i = tid; i < K; i += WAVES * 64) {
         sct[i] = p.scale3 ? p.scale3[i] : 1.f;
