@@ -81,16 +81,42 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int fr = lane & 31, fh = lane >> 5;
 
     // weight slab (k' = (c, r, s8) order, s8 = [0, s0 .. s6]: a B fragment starts one pixel LEFT of the window so that
-    // it is 4-byte aligned in the patch), once per block
-    for (int i = tid; i < K * 2 * NK16; i += NT) {
-        const int row = i / (2 * NK16), f = i - row * (2 * NK16);
-        uint32_t u[4] = {0, 0, 0, 0};
-        if (f < NFRAG) {
-            const bf16_t* src = p.w + ((long long)row * C * R + f) * S;
+    // it is 4-byte aligned in the patch), once per block: the 18.8 KB of OIHW weights are copied to LDS as they are
+    // (coalesced 16-byte loads, all in flight; the conv tile area is idle) and re-laid out LDS -> LDS.  Seven dependent
+    // 2-byte global loads per fragment made this prologue ~5 us long.
+    {
+        constexpr int WELEMS = K * C * R * S;                  // 9408 bf16
+        constexpr int NCH16 = (WELEMS * 2 + 15) / 16;          // 1176 chunks
+        constexpr int U = (NCH16 + NT - 1) / NT;               // 4
+        bf16_t* wraw = (bf16_t*)ctile;
+        const bool al = ((uintptr_t)p.w & 15) == 0;
+        uint4 v[U];
 #pragma unroll
-            for (int e = 0; e < S; ++e) u[(e + 1) >> 1] |= (uint32_t)src[e] << (((e + 1) & 1) * 16);   // slot 0 = pad
+        for (int u = 0; u < U; ++u) {
+            const int i = u * NT + tid;
+            const int ic = i < NCH16 ? i : NCH16 - 1;
+            if (al) v[u] = *(const uint4*)(p.w + ic * 8);
         }
-        *(uint4*)(wl + row * WPITCH + f * 16) = make_uint4(u[0], u[1], u[2], u[3]);
+        if (al) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = u * NT + tid;
+                if (i < NCH16) *(uint4*)(wraw + i * 8) = v[u];
+            }
+        } else {
+            for (int i = tid; i < WELEMS; i += NT) wraw[i] = p.w[i];
+        }
+        __syncthreads();
+        for (int i = tid; i < K * 2 * NK16; i += NT) {
+            const int row = i / (2 * NK16), f = i - row * (2 * NK16);
+            uint32_t u[4] = {0, 0, 0, 0};
+            if (f < NFRAG) {
+                const bf16_t* src = wraw + (row * C * R + f) * S;
+#pragma unroll
+                for (int e = 0; e < S; ++e) u[(e + 1) >> 1] |= (uint32_t)src[e] << (((e + 1) & 1) * 16);   // slot 0 = pad
+            }
+            *(uint4*)(wl + row * WPITCH + f * 16) = make_uint4(u[0], u[1], u[2], u[3]);
+        }
     }
 
     // epilogue constants live in LDS (64 + 64 floats): as per-lane registers they cost 64 VGPRs and the second
