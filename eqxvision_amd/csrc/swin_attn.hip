@@ -34,9 +34,17 @@ __global__ __launch_bounds__(256) void swin_attn_mfma_kernel(const SwinP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y;
     const int n = p.n;
-    for (int i = tid; i < 64 * 64; i += 256) {
-        const int q = i >> 6, k = i & 63;
-        bias_l[i] = (q < n && k < n) ? p.bias[((long long)h * n + q) * n + k] : 0.f;
+    {   // 16 entries per thread, all loads in flight before the first LDS store (one dependent round trip, not 16)
+        float bv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = j * 256 + tid, q = i >> 6, k = i & 63;
+            const bool ok = q < n && k < n;
+            const float t = p.bias[ok ? ((long long)h * n + q) * n + k : 0];
+            bv[j] = ok ? t : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bias_l[j * 256 + tid] = bv[j];
     }
     __syncthreads();
 
