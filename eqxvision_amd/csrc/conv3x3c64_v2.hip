@@ -58,9 +58,13 @@ __global__ __launch_bounds__(512) void conv3x3c64_v2_kernel(const C3V2P p) {
         char* wst = smem + HBUF;                               // [64 rows][1152 + 16 bytes]
         constexpr int WROW = 576 * 2 + 16;
         static_assert(HBUF + 64 * WROW <= 2 * HBUF + 8 * 32 * EPITCH, "weight staging must stay below the sct table");
-        for (int i = tid; i < 64 * 72; i += 512) {             // 72 chunks of 16 bytes per row
-            const int row = i / 72, ch = i - row * 72;
-            *(uint4*)(wst + row * WROW + ch * 16) = *(const uint4*)(p.w + (long long)row * 576 + ch * 8);
+        uint4 wv[9];                                           // 64 rows x 72 chunks of 16 bytes = 9 per thread, all in flight
+#pragma unroll
+        for (int j = 0; j < 9; ++j) wv[j] = *(const uint4*)(p.w + (long long)(j * 512 + tid) * 8);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int i = j * 512 + tid, row = i / 72, ch = i - row * 72;
+            *(uint4*)(wst + row * WROW + ch * 16) = wv[j];
         }
         __syncthreads();
         const char* wr = wst + (half * 32 + fr) * WROW + fh * 16;
