@@ -22,7 +22,8 @@ namespace mv {
 
 struct ChainP {
     const bf16_t* x;        // t2 [M][64]
-    const bf16_t* w3;       // [256][64]
+    const bf16_t* x2;       // DUAL: the block input [M][64] (second K-source: the downsample branch)
+    const bf16_t* w3;       // [256][64]; DUAL: [256][128] = [scale3 * W3 | scale_d * W_d]
     const float* scale3;
     const float* shift3;
     const bf16_t* residual; // [M][256]
@@ -36,9 +37,13 @@ struct ChainP {
 
 // N2 = 64: the next block of the same stage (8 waves).  N2 = 128: the first block of the next stage, whose conv1 is
 // still stride 1 on the 56x56 map (ResNet v1.5 strides the 3x3); its weights take 66 KB, so 6 waves' patches fit.
-template <int N2, int WAVES>
+// DUAL: the first block of layer1, whose identity is itself a 1x1 convolution of the block input (downsample = conv + BN,
+// resnet.py:295-303).  conv3 and the downsample conv write the same output, so they are ONE GEMM over the concatenated
+// reduction [t2 | x] with the two BatchNorm scales folded into the bf16 weight rows (shifts summed): the 256-channel
+// identity map is neither written nor read (-411 MB at batch 256) and its launch disappears.
+template <int N2, int WAVES, bool DUAL>
 __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
-    constexpr int C = 64, K = 256;
+    constexpr int C = DUAL ? 128 : 64, K = 256;
     constexpr int T2 = N2 / 32;                                 // 32-channel tiles of the second GEMM
     constexpr int KC = C / 16;                                  // 4 k16-steps of the first GEMM
     constexpr int W3P = C * 2 + 16;                             // 144: odd number of 16-byte slots
@@ -61,12 +66,12 @@ __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
             for (int u = 0; u < U; ++u) {
                 const int i = base + u * NT + tid;
                 const int ic = i < N3 ? i : N3 - 1;
-                v[u] = *(const uint4*)(p.w3 + (long long)(ic >> 3) * C + (ic & 7) * 8);
+                v[u] = *(const uint4*)(p.w3 + (long long)ic * 8);           // rows are C = 8 * (C/8) elements: contiguous
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = base + u * NT + tid;
-                if (i < N3) *(uint4*)(w3l + (i >> 3) * W3P + (i & 7) * 16) = v[u];
+                if (i < N3) *(uint4*)(w3l + (i / (C / 8)) * W3P + (i % (C / 8)) * 16) = v[u];
             }
         }
         for (int base = 0; base < N1; base += U * NT) {
@@ -103,9 +108,14 @@ __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
     auto load_x = [&](uint4* xf, int tile) {
         int m = tile * 32 + fr;
         m = m < p.M ? m : p.M - 1;                              // clamp: rows past the end are never stored
-        const bf16_t* src = p.x + (long long)m * C + fh * 8;
+        const bf16_t* src = p.x + (long long)m * 64 + fh * 8;
 #pragma unroll
-        for (int kk = 0; kk < KC; ++kk) xf[kk] = *(const uint4*)(src + kk * 16);
+        for (int kk = 0; kk < 4; ++kk) xf[kk] = *(const uint4*)(src + kk * 16);
+        if constexpr (DUAL) {
+            const bf16_t* src2 = p.x2 + (long long)m * 64 + fh * 8;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) xf[4 + kk] = *(const uint4*)(src2 + kk * 16);
+        }
     };
 
     auto run_tile = [&](uint4* xf, int tile, int refill) {
@@ -116,15 +126,17 @@ __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
             for (int e = 0; e < 16; ++e) acc2[a][e] = 0.f;
 #pragma unroll 1
         for (int ps = 0; ps < 2; ++ps) {                        // 128-channel slab of y
-            uint4 rr[2][4];                                     // residual rows of the slab's two 64-channel chunks
+            uint4 rr[DUAL ? 1 : 2][4];                          // residual rows of the slab's two 64-channel chunks
+            if constexpr (!DUAL) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int pass = 0; pass < 4; ++pass) {
-                    int m = tile * 32 + pass * 8 + (lane >> 3);
-                    m = m < p.M ? m : p.M - 1;
-                    rr[c][pass] = *(const uint4*)(p.residual + (long long)m * K + ps * 128 + c * 64 + (lane & 7) * 8);
-                }
+                    for (int pass = 0; pass < 4; ++pass) {
+                        int m = tile * 32 + pass * 8 + (lane >> 3);
+                        m = m < p.M ? m : p.M - 1;
+                        rr[c][pass] = *(const uint4*)(p.residual + (long long)m * K + ps * 128 + c * 64 + (lane & 7) * 8);
+                    }
+            }
             f32x16 acc[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
@@ -165,11 +177,16 @@ __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
                     const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
                     const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
                     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    const uint32_t rw[4] = {rr[c][pass].x, rr[c][pass].y, rr[c][pass].z, rr[c][pass].w};
+                    if constexpr (DUAL) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] = fmaf(v[2 * e], scv[2 * e], shv[2 * e]) + __uint_as_float(rw[e] << 16);
-                        v[2 * e + 1] = fmaf(v[2 * e + 1], scv[2 * e + 1], shv[2 * e + 1]) + __uint_as_float(rw[e] & 0xffff0000u);
+                        for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], scv[e], shv[e]);
+                    } else {
+                        const uint32_t rw[4] = {rr[c][pass].x, rr[c][pass].y, rr[c][pass].z, rr[c][pass].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] = fmaf(v[2 * e], scv[2 * e], shv[2 * e]) + __uint_as_float(rw[e] << 16);
+                            v[2 * e + 1] = fmaf(v[2 * e + 1], scv[2 * e + 1], shv[2 * e + 1]) + __uint_as_float(rw[e] & 0xffff0000u);
+                        }
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -238,15 +255,19 @@ int chain1x1_supported(long long M, int C, int K, int N2, int dtype) {
     return dtype == MV_BF16 && C == 64 && K == 256 && (N2 == 64 || N2 == 128) && M >= 8192 && M < (1LL << 31) - 64 &&
            !get_flag("no_chain");
 }
+int chain1x1_dual_supported(long long M, int C1, int C2, int K, int N2, int dtype) {
+    return dtype == MV_BF16 && C1 == 64 && C2 == 64 && K == 256 && N2 == 64 && M >= 8192 && M < (1LL << 31) - 64 &&
+           !get_flag("no_chain") && !get_flag("no_dual_chain");
+}
 
-template <int N2, int WAVES>
+template <int N2, int WAVES, bool DUAL>
 static int chain_go(ChainP& p, hipStream_t st) {
-    constexpr int SMEM = 256 * 144 + N2 * 528 + (2 * 256 + 2 * N2) * 4 + WAVES * 32 * (64 * 4 + 16);
+    constexpr int SMEM = 256 * ((DUAL ? 128 : 64) * 2 + 16) + N2 * 528 + (2 * 256 + 2 * N2) * 4 + WAVES * 32 * (64 * 4 + 16);
     static_assert(SMEM <= 160 * 1024, "LDS");
     int gx = 256;
     const int need = (p.tiles_m + WAVES - 1) / WAVES;
     if (gx > need) gx = need;
-    auto kern = chain1x1_kernel<N2, WAVES>;
+    auto kern = chain1x1_kernel<N2, WAVES, DUAL>;
     MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     hipLaunchKernelGGL(kern, dim3(gx), dim3(WAVES * 64), SMEM, st, p);
     MV_LAUNCH_CHECK();
@@ -256,17 +277,31 @@ static int chain_go(ChainP& p, hipStream_t st) {
 int chain1x1_launch(const void* x, const void* w3, const float* scale3, const float* shift3, const void* residual, void* y,
                     const void* w1, const float* scale1, const float* shift1, void* t1, long long M, int N2, hipStream_t st) {
     ChainP p;
-    p.x = (const bf16_t*)x; p.w3 = (const bf16_t*)w3; p.scale3 = scale3; p.shift3 = shift3;
+    p.x = (const bf16_t*)x; p.x2 = nullptr; p.w3 = (const bf16_t*)w3; p.scale3 = scale3; p.shift3 = shift3;
     p.residual = (const bf16_t*)residual; p.y = (bf16_t*)y;
     p.w1 = (const bf16_t*)w1; p.scale1 = scale1; p.shift1 = shift1; p.t1 = (bf16_t*)t1;
     p.M = (int)M;
     p.tiles_m = (int)((M + 31) / 32);
     if (N2 == 64) {
         set_kernel_name("chain1x1_bf16_64_256_64");
-        return chain_go<64, 8>(p, st);
+        return chain_go<64, 8, false>(p, st);
     }
     set_kernel_name("chain1x1_bf16_64_256_128");
-    return chain_go<128, 6>(p, st);
+    return chain_go<128, 6, false>(p, st);
+}
+
+// x [M][64] and x2 [M][64] are the two K-sources, wcat [256][128] = [rows of W3 scaled | rows of W_d scaled], shift3 = the
+// sum of the two folded BatchNorm shifts (scale3 may be NULL = 1)
+int chain1x1_dual_launch(const void* x, const void* x2, const void* wcat, const float* scale3, const float* shift3, void* y,
+                         const void* w1, const float* scale1, const float* shift1, void* t1, long long M, hipStream_t st) {
+    ChainP p;
+    p.x = (const bf16_t*)x; p.x2 = (const bf16_t*)x2; p.w3 = (const bf16_t*)wcat; p.scale3 = scale3; p.shift3 = shift3;
+    p.residual = nullptr; p.y = (bf16_t*)y;
+    p.w1 = (const bf16_t*)w1; p.scale1 = scale1; p.shift1 = shift1; p.t1 = (bf16_t*)t1;
+    p.M = (int)M;
+    p.tiles_m = (int)((M + 31) / 32);
+    set_kernel_name("chain1x1_dual_bf16_64+64_256_64");
+    return chain_go<64, 6, true>(p, st);
 }
 
 }  // namespace mv

@@ -114,6 +114,9 @@ int igemm2_tile_shape(long long M, int K, int* bm, int* bn);
 void igemm2_force_tile(int tile);
 int tile_override(const char* kind, long long M, int a, int b, int R, int S, int sh);
 int chain1x1_supported(long long M, int C, int K, int N2, int dtype);
+int chain1x1_dual_supported(long long M, int C1, int C2, int K, int N2, int dtype);
+int chain1x1_dual_launch(const void* x, const void* x2, const void* wcat, const float* scale3, const float* shift3, void* y,
+                         const void* w1, const float* scale1, const float* shift1, void* t1, long long M, hipStream_t st);
 int chain1x1_launch(const void* x, const void* w3, const float* scale3, const float* shift3, const void* residual, void* y,
                     const void* w1, const float* scale1, const float* shift1, void* t1, long long M, int N2, hipStream_t st);
 int igemm4_wanted(long long M, int C, int K, int R, int S);

@@ -753,6 +753,22 @@ int mv_conv1x1_chain_fwd(const void* x, const void* w3, const float* scale3, con
     return chain1x1_launch(x, w3, scale3, shift3, residual, y, w1, scale1, shift1, t1, M, N2, (hipStream_t)stream);
 }
 
+int mv_conv1x1_dual_chain_supported(int64_t M, int C1, int C2, int K, int N2, int dtype) {
+    return !get_flag("force_generic") && !get_flag("no_stream") && chain1x1_dual_supported(M, C1, C2, K, N2, dtype);
+}
+
+int mv_conv1x1_dual_chain_fwd(const void* x, const void* x2, const void* wcat, const float* scale, const float* shift, void* y,
+                              const void* w1, const float* scale1, const float* shift1, void* t1, int64_t M, int C1, int C2,
+                              int K, int N2, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && x2 && wcat && y && w1 && t1, "conv1x1_dual_chain: NULL pointer");
+    if (!mv_conv1x1_dual_chain_supported(M, C1, C2, K, N2, dtype)) {
+        set_error("conv1x1_dual_chain: unsupported shape M=%lld C1=%d C2=%d K=%d N2=%d (ask mv_conv1x1_dual_chain_supported)",
+                  (long long)M, C1, C2, K, N2);
+        return MV_E_UNSUPPORTED;
+    }
+    return chain1x1_dual_launch(x, x2, wcat, scale, shift, y, w1, scale1, shift1, t1, M, (hipStream_t)stream);
+}
+
 int mv_linear_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                   void* y, int64_t M, int N, int K, int act, int in_dtype, int out_dtype, mv_stream_t stream) {
     MV_CHECK_ARG(x && w && y, "linear: NULL pointer");

@@ -109,11 +109,20 @@ class _ResNetBottleneck(Module):
         else:
             out = ops.conv2d(x, self.conv1, self.bn1, "relu")
         out = ops.conv2d(out, self.conv2, self.bn2, "relu")
-        identity = _shortcut(self, x)
         if isinstance(nxt, _ResNetBottleneck):
+            ds = self.downsample
+            if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d) and \
+                    isinstance(ds[1], nn.BatchNorm):
+                # identity = BN(conv1x1(x)): it and conv3 add into one output -> one GEMM over [out | x] (stride 1 only)
+                y = ops.conv1x1_dual_chain(out, self.conv3, self.bn3, x, ds[0], ds[1], nxt.conv1, nxt.bn1)
+                if y is not None:
+                    return y
+            identity = _shortcut(self, x)
             y = ops.conv1x1_chain(out, self.conv3, self.bn3, identity, nxt.conv1, nxt.bn1)
             if y is not None:
                 return y
+        else:
+            identity = _shortcut(self, x)
         return ops.conv2d(out, self.conv3, self.bn3, "relu", residual=identity)
 
 

@@ -237,6 +237,58 @@ def conv1x1_chain(x: Act, conv3, bn3, residual: Act, conv1n, bn1n) -> Optional[A
     return out
 
 
+def _scaled_rows(conv, bn) -> Tuple[np.ndarray, np.ndarray]:
+    """A pointwise conv + BatchNorm(inference) as (scale[k] * W[k, :], shift[k]) in fp32."""
+    w = np.asarray(conv.weight, np.float32).reshape(conv.out_channels, -1)
+    bias = None if conv.bias is None else np.asarray(conv.bias, np.float32).reshape(-1)
+    if bn is not None:
+        scale, shift = bn_fold(bn)
+        if bias is not None:
+            shift = shift + bias * scale
+        return w * scale[:, None], shift
+    return w, (np.zeros(conv.out_channels, np.float32) if bias is None else bias)
+
+
+def conv1x1_dual_chain(x: Act, conv3, bn3, xin: Act, ds_conv, ds_bn, conv1n, bn1n) -> Optional[Act]:
+    """relu(bn3(conv3(x)) + ds_bn(ds_conv(xin))) -- a bottleneck whose identity is a pointwise conv of the block input
+    (resnet.py:295-303) -- and relu(bn1n(conv1n(.))) of that result, in ONE launch: the two convolutions that add into
+    the same output run as one GEMM over the concatenated reduction [x | xin], the BatchNorm scales folded into the bf16
+    weight rows.  Returns the block output with the next conv1's result attached (`.pre`), or None if unsupported."""
+    dt = compute_dtype()
+    if dt != "bf16" or not (_pointwise(conv3) and _pointwise(ds_conv) and _pointwise(conv1n)):
+        return None
+    if conv3.out_channels != ds_conv.out_channels or conv3.out_channels != conv1n.in_channels:
+        return None
+    for b in (bn3, ds_bn, bn1n):
+        _check_bn(b)
+    x, xin = as_map(x), as_map(xin)
+    B, H, W, C1 = x.t.shape
+    C2, K, N2 = xin.t.shape[-1], conv3.out_channels, conv1n.out_channels
+    M = B * H * W
+    if tuple(xin.t.shape[:3]) != (B, H, W) or C1 != conv3.in_channels or C2 != ds_conv.in_channels \
+            or x.t.dtype != torch.bfloat16 or xin.t.dtype != torch.bfloat16:
+        return None
+    if not _lib.load().mv_conv1x1_dual_chain_supported(M, C1, C2, K, N2, DT[dt]):
+        return None
+    cache = conv3._cache()
+    key = ("dual", id(bn3), id(ds_conv), id(ds_bn))
+    hit = cache.get(key)
+    if hit is None:
+        w3, h3 = _scaled_rows(conv3, bn3)
+        wd, hd = _scaled_rows(ds_conv, ds_bn)
+        hit = (_dev(np.concatenate([w3, wd], axis=1), torch.bfloat16), _dev((h3 + hd).astype(np.float32), torch.float32))
+        cache[key] = hit
+    wcat, shift = hit
+    w1, s1, h1 = prep_conv(conv1n, bn1n, "krsc", dt)
+    y = empty((B, H, W, K), torch.bfloat16)
+    t1 = empty((B, H, W, N2), torch.bfloat16)
+    _lib.call("mv_conv1x1_dual_chain_fwd", _ptr(x.t), _ptr(xin.t), _ptr(wcat), None, _ptr(shift), _ptr(y), _ptr(w1), _ptr(s1),
+              _ptr(h1), _ptr(t1), M, C1, C2, K, N2, DT[dt], stream_ptr())
+    out = Act(y, "map", x.batched)
+    out.pre = (conv1n, Act(t1, "map", x.batched))
+    return out
+
+
 def stem_conv_pool(x: Act, conv, bn, act, pool) -> Act:
     """ResNet entry (resnet.py:243-254): conv1 + bn1 + relu + maxpool.  One launch when the library has the fused
     path for this configuration (the 112x112x64 map then never reaches HBM), else conv2d followed by maxpool2d."""

@@ -159,6 +159,48 @@ def chain_case(M, seed=0, N2=64):
     return run
 
 
+def dual_chain_case(M, seed=0):
+    """mv_conv1x1_dual_chain_fwd: conv3 + BN and the downsample conv + BN as one GEMM over [t2 | x] (scales folded into
+    the bf16 weight rows, as ops.conv1x1_dual_chain does), ReLU, then the next block's conv1 + BN + ReLU -- vs the oracle
+    with the un-folded fp32 scales (resnet.py:144-162, 295-303)."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        C, K, N2 = 64, 256, 64
+        x = bf(rng.standard_normal((M, C)))
+        x2 = bf(rng.standard_normal((M, C)))
+        w3 = bf(rng.standard_normal((K, C)) / np.sqrt(C))
+        wd = bf(rng.standard_normal((K, C)) / np.sqrt(C))
+        s3 = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        sd = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        sd[::7] *= -1.0
+        h3 = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        hd = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        w1 = bf(rng.standard_normal((N2, K)) / np.sqrt(K))
+        s1 = rng.uniform(0.5, 1.5, N2).astype(np.float32)
+        h1 = (0.1 * rng.standard_normal(N2)).astype(np.float32)
+        if not L.load().mv_conv1x1_dual_chain_supported(M, C, C, K, N2, 1):
+            return {"ok": False, "err": "mv_conv1x1_dual_chain_supported says no"}
+        f64 = np.float64
+        yref = O.relu((x.astype(f64) @ w3.astype(f64).T) * s3 + h3 + (x2.astype(f64) @ wd.astype(f64).T) * sd + hd)
+        t1ref = O.relu((bf(yref).astype(f64) @ w1.astype(f64).T) * s1 + h1)
+        wcat = np.concatenate([w3.astype(np.float32) * s3[:, None], wd.astype(np.float32) * sd[:, None]], axis=1)
+        d = {k: dev(v, "bf16") for k, v in dict(x=x, x2=x2, wcat=bf(wcat), w1=w1).items()}
+        f = {k: dev(v, "fp32") for k, v in dict(h=(h3 + hd).astype(np.float32), s1=s1, h1=h1).items()}
+        y = torch.full((M, K), -7.0, dtype=torch.bfloat16, device="cuda")
+        t1 = torch.full((M, N2), -7.0, dtype=torch.bfloat16, device="cuda")
+        L.call("mv_conv1x1_dual_chain_fwd", d["x"].data_ptr(), d["x2"].data_ptr(), d["wcat"].data_ptr(), None, f["h"].data_ptr(),
+               y.data_ptr(), d["w1"].data_ptr(), f["s1"].data_ptr(), f["h1"].data_ptr(), t1.data_ptr(), M, C, C, K, N2, 1,
+               _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        a = _cmp(host(y), yref, TOL_BF16)
+        b = _cmp(host(t1), t1ref, TOL_BF16)
+        return {"ok": a["ok"] and b["ok"], "err": max(a["err"], b["err"]), "lim": min(a["lim"], b["lim"]), "err_y": a["err"],
+                "err_t1": b["err"], "kernel": kern}
+    return run
+
+
 def conv_nchw_case(N, C, H, W, K, R, S, stride, pad, act=0, xdtype="fp32", tokens=False, generic=False, seed=0,
                    v0=False):
     def run():
@@ -741,6 +783,8 @@ def all_cases():
           ("chain/56x56_B4", chain_case(4 * 56 * 56, seed=1)),
           ("chain/ragged_M", chain_case(8192 + 37, seed=2)),
           ("chain/many_tiles", chain_case(40 * 56 * 56 + 5, seed=3)),
+          ("chain/dual_56x56_B4", dual_chain_case(4 * 56 * 56, seed=6)),
+          ("chain/dual_ragged_many", dual_chain_case(29 * 56 * 56 + 13, seed=7)),
           ("chain/n128_56x56_B4", chain_case(4 * 56 * 56, seed=4, N2=128)),
           ("chain/n128_ragged_many", chain_case(33 * 56 * 56 + 21, seed=5, N2=128)),
           ("igemm/old_kernel_3x3_128_28", conv_nhwc_case(8, 28, 28, 128, 128, 3, 3, pad=1, act=1, seed=11, flags=("no_igemm2",))),
