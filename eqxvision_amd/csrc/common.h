@@ -111,6 +111,9 @@ int igemm2_launch(const void* x, const void* w, const float* scale, const float*
                   void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
                   int dh, int dw, int act, int out_dtype, int m_end, int tok, hipStream_t stream);
 int igemm2_tile_shape(long long M, int K, int* bm, int* bn);
+int igemm2_dual_supported(long long M, int C1, int C2, int K, int dtype);
+int igemm2_dual_launch(const void* x, const void* x2, const void* w, const float* scale, const float* shift, void* y, int N,
+                       int Ho, int Wo, int C1, int H2, int W2, int C2, int s2, int K, int act, hipStream_t st);
 void igemm2_force_tile(int tile);
 int tile_override(const char* kind, long long M, int a, int b, int R, int S, int sh);
 int chain1x1_supported(long long M, int C, int K, int N2, int dtype);

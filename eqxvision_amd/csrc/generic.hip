@@ -753,6 +753,25 @@ int mv_conv1x1_chain_fwd(const void* x, const void* w3, const float* scale3, con
     return chain1x1_launch(x, w3, scale3, shift3, residual, y, w1, scale1, shift1, t1, M, N2, (hipStream_t)stream);
 }
 
+int mv_conv1x1_dual_supported(int64_t M, int C1, int C2, int K, int dtype) {
+    return !get_flag("force_generic") && !get_flag("no_igemm2") && igemm2_dual_supported(M, C1, C2, K, dtype);
+}
+
+int mv_conv1x1_dual_fwd(const void* x, const void* x2, const void* wcat, const float* scale, const float* shift, void* y,
+                        int N, int Ho, int Wo, int C1, int H2, int W2, int C2, int stride2, int K, int act, int dtype,
+                        mv_stream_t stream) {
+    MV_CHECK_ARG(x && x2 && wcat && y, "conv1x1_dual: NULL pointer");
+    MV_CHECK_ARG(N > 0 && Ho > 0 && Wo > 0 && stride2 >= 1 && (Ho - 1) * stride2 < H2 && (Wo - 1) * stride2 < W2,
+                 "conv1x1_dual: the strided source does not cover the output map");
+    const int64_t M = (int64_t)N * Ho * Wo;
+    if (!mv_conv1x1_dual_supported(M, C1, C2, K, dtype)) {
+        set_error("conv1x1_dual: unsupported shape M=%lld C1=%d C2=%d K=%d (ask mv_conv1x1_dual_supported first)", (long long)M,
+                  C1, C2, K);
+        return MV_E_UNSUPPORTED;
+    }
+    return igemm2_dual_launch(x, x2, wcat, scale, shift, y, N, Ho, Wo, C1, H2, W2, C2, stride2, K, act, (hipStream_t)stream);
+}
+
 int mv_conv1x1_dual_chain_supported(int64_t M, int C1, int C2, int K, int N2, int dtype) {
     return !get_flag("force_generic") && !get_flag("no_stream") && chain1x1_dual_supported(M, C1, C2, K, N2, dtype);
 }

@@ -22,7 +22,10 @@ namespace mv {
 // WM x WN waves (= 8), each TM x TN tiles of 32x32.  BM = 32*TM*WM pixels, BN = 32*TN*WN channels (TN*32 = 64).
 // NST = LDS ring depth (3 for the 256x128 / 256x64 tiles, 2 for 256x256 whose k-tile alone lasts ~2000
 // cycles); RESPF = prefetch the residual rows before the main loop (needs TM*4 16-byte registers).
-template <int WM, int WN, int TM, int TN, int NST, bool RESPF, typename OutT>
+// DUAL: two reduction sources that add into one output -- a dense pointwise layer on x (C channels) and a strided
+// pointwise layer on x2 (C2 channels at pixel stride s2): a ResNet stage's first bottleneck, conv3 + the downsample conv
+// (resnet.py:144-162, 295-303).  The k-tiles walk x's channels, then x2's; weight rows are [C | C2] long.
+template <int WM, int WN, int TM, int TN, int NST, bool RESPF, typename OutT, bool DUAL = false>
 __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int ROWB = 128;
@@ -52,8 +55,8 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
     const int srow = lane >> 3;
     const int chunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
     const int cpt = p.C >> 6;
-    const int nk = p.R * p.S * cpt;
-    const long long wrow_stride = (long long)p.R * p.S * p.C;
+    const int nk = DUAL ? ((p.C + p.C2) >> 6) : p.R * p.S * cpt;
+    const long long wrow_stride = DUAL ? (long long)(p.C + p.C2) : (long long)p.R * p.S * p.C;
     const bool dense1x1 = p.R == 1 && p.S == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0;   // block-uniform
     long long xbase[XI];
     unsigned vlo[XI], vhi[XI];
@@ -74,7 +77,9 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
         const int hi0 = ho * p.sh - p.ph, wi0 = wo * p.sw - p.pw;
         xbase[j] = (((long long)b * p.H + hi0) * p.W + wi0) * p.C + chunk * 8;
         unsigned long long mask = 0;
-        if (valid) {
+        if constexpr (DUAL) {
+            mask = valid ? 3ull : 0ull;                   // both sources exist for every output pixel
+        } else if (valid) {
             for (int r = 0; r < p.R; ++r) {
                 const int hi = hi0 + r * p.dh;
                 if ((unsigned)hi >= (unsigned)p.H) continue;
@@ -86,6 +91,18 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
         }
         vlo[j] = (unsigned)mask;
         vhi[j] = (unsigned)(mask >> 32);
+    }
+    long long xbase2[DUAL ? XI : 1];
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            const int m = m0 + 8 * (wave + 8 * j) + srow;
+            const int wo = m % p.Wo;
+            const int tt = m / p.Wo;
+            const int ho = tt % p.Ho;
+            const int b = tt / p.Ho;
+            xbase2[j] = (((long long)b * p.H2 + ho * p.s2) * p.W2 + wo * p.s2) * p.C2 + chunk * 8;
+        }
     }
     long long woff[WI];
 #pragma unroll
@@ -99,14 +116,19 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
         char* ws = xs + BM * ROWB;
         const int tp = r * p.S + s;                                          // wave-uniform
         if (q < XI) {
-            const long long tapdelta = ((long long)(r * p.dh) * p.W + s * p.dw) * p.C + c0;
             const unsigned bits = tp < 32 ? vlo[q] : vhi[q];
             const bool ok = (bits >> (tp & 31)) & 1u;
-            const bf16_t* src = ok ? p.x + tapdelta + xbase[q] : p.zero;
+            const bf16_t* src;
+            if constexpr (DUAL) {                          // "tap" s = the source: 0 = x (dense), 1 = x2 (strided)
+                src = ok ? (s == 0 ? p.x + xbase[q] + c0 : p.x2 + xbase2[q] + c0) : p.zero;
+            } else {
+                const long long tapdelta = ((long long)(r * p.dh) * p.W + s * p.dw) * p.C + c0;
+                src = ok ? p.x + tapdelta + xbase[q] : p.zero;
+            }
             glds16(src, xs + 8 * (wave + 8 * q) * ROWB);
         } else {
             const int j = q - XI;
-            const int tapoff = tp * p.C + c0;
+            const int tapoff = tp * p.C + c0;                // DUAL: tp = s in {0, 1}: source 1's weights start at column C
             const bf16_t* src = woff[j] >= 0 ? p.w + woff[j] + tapoff : p.zero;
             glds16(src, ws + 8 * (wave + 8 * j) * ROWB);
         }
@@ -166,7 +188,7 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
     int r = 0, s = 0, c0 = 0;
     auto advance = [&]() {
         c0 += 64;
-        if (c0 == p.C) {
+        if (c0 == ((DUAL && s == 1) ? p.C2 : p.C)) {
             c0 = 0;
             if (++s == p.S) {
                 s = 0;
@@ -343,6 +365,42 @@ static int launch2(Igemm2P& p, bool out_f32, hipStream_t st) {
     return MV_OK;
 }
 
+int igemm2_dual_supported(long long M, int C1, int C2, int K, int dtype) {
+    return dtype == MV_BF16 && C1 % 64 == 0 && C2 % 64 == 0 && C1 >= 64 && C2 >= 64 && K % 8 == 0 && M >= 4096 &&
+           M < (1LL << 31) - 256 && !get_flag("no_dual");
+}
+
+// y[N,Ho,Wo,K] = act(scale[k] * (x[N,Ho,Wo,C1] . w[k, 0:C1] + x2[N, s2*ho, s2*wo, C2] . w[k, C1:C1+C2]) + shift[k])
+int igemm2_dual_launch(const void* x, const void* x2, const void* w, const float* scale, const float* shift, void* y, int N,
+                       int Ho, int Wo, int C1, int H2, int W2, int C2, int s2, int K, int act, hipStream_t st) {
+    Igemm2P p;
+    p.tok = 0;
+    p.dbg = 0;
+    p.prof = nullptr;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = nullptr; p.y = y;
+    p.x2 = (const bf16_t*)x2; p.C2 = C2; p.H2 = H2; p.W2 = W2; p.s2 = s2;
+    p.zero = (const bf16_t*)zero_page(st);
+    if (!p.zero) {
+        set_error("igemm2: zero page allocation failed");
+        return MV_E_OOM;
+    }
+    p.N = N; p.H = Ho; p.W = Wo; p.C = C1; p.K = K; p.R = 1; p.S = 2;       // S = 2 "taps" = the two sources
+    p.Ho = Ho; p.Wo = Wo;
+    p.sh = 1; p.sw = 1; p.ph = 0; p.pw = 0; p.dh = 1; p.dw = 1;
+    p.M = (int)((long long)N * Ho * Wo);
+    p.act = act;
+    constexpr int BM = 256, BN = 128, NST = 3;
+    constexpr int SMEM = NST * (BM + BN) * 128;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (K + BN - 1) / BN;
+    set_kernel_name("igemm2_dual_bf16_256x128");
+    auto kern = igemm2_kernel<4, 2, 2, 2, 3, true, bf16_t, true>;
+    MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), SMEM, st, p);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
 int igemm2_wanted(long long M, int C, int K, int R, int S) {
     // worth it once there is enough work to fill the chip with 256-row tiles and a reduction of >= 4 k-tiles
     const long long ktiles = (long long)R * S * (C / 64);
@@ -370,6 +428,7 @@ int igemm2_launch(const void* x, const void* w, const float* scale, const float*
                   int act, int out_dtype, int m_end, int tok, hipStream_t st) {
     Igemm2P p;
     p.tok = tok;
+    p.x2 = nullptr; p.C2 = 0; p.H2 = 0; p.W2 = 0; p.s2 = 1;
     p.dbg = get_flag("res_early");
     p.prof = (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo"));
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;

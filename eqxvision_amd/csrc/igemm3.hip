@@ -330,6 +330,7 @@ int igemm3_launch(const void* x, const void* w, const float* scale, const float*
                   int act, int out_dtype, int tok, hipStream_t st) {
     Igemm2P p;
     p.tok = tok;
+    p.x2 = nullptr; p.C2 = 0; p.H2 = 0; p.W2 = 0; p.s2 = 1;
     p.dbg = 0;
     p.prof = nullptr;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;

@@ -369,6 +369,7 @@ int igemm4_launch(const void* x, const void* w, const float* scale, const float*
                   int act, int out_dtype, int tok, int tile, hipStream_t st) {
     Igemm2P p;
     p.tok = tok;
+    p.x2 = nullptr; p.C2 = 0; p.H2 = 0; p.W2 = 0; p.s2 = 1;
     p.dbg = 0;
     p.prof = (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo"));
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;

@@ -17,6 +17,8 @@ struct Igemm2P {
     int M, tiles_m, tiles_n, act;   // M = rows covered by THIS launch (rows 0 .. M-1)
     int dbg;                        // experiments only
     long long* prof;                // experiments only: per-block phase stamps
+    const bf16_t* x2;               // igemm2 DUAL: second reduction source, NHWC [N][H2][W2][C2], read at pixel stride s2
+    int C2, H2, W2, s2;
     int tok;                        // > 0: head-major output y[b][n/64][t][n%64], rows m = b*tok + t (qkv projection)
 };
 

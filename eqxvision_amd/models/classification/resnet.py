@@ -109,20 +109,24 @@ class _ResNetBottleneck(Module):
         else:
             out = ops.conv2d(x, self.conv1, self.bn1, "relu")
         out = ops.conv2d(out, self.conv2, self.bn2, "relu")
-        if isinstance(nxt, _ResNetBottleneck):
-            ds = self.downsample
-            if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d) and \
-                    isinstance(ds[1], nn.BatchNorm):
-                # identity = BN(conv1x1(x)): it and conv3 add into one output -> one GEMM over [out | x] (stride 1 only)
+        ds = self.downsample
+        conv_ds = isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d) and \
+            isinstance(ds[1], nn.BatchNorm)
+        if conv_ds:
+            # identity = BN(conv1x1(x)) (resnet.py:295-303): it and conv3 add into one output -> one GEMM over the
+            # concatenated reduction [out | x]; the identity map is never materialised
+            if isinstance(nxt, _ResNetBottleneck):
                 y = ops.conv1x1_dual_chain(out, self.conv3, self.bn3, x, ds[0], ds[1], nxt.conv1, nxt.bn1)
                 if y is not None:
                     return y
-            identity = _shortcut(self, x)
+            y = ops.conv1x1_dual(out, self.conv3, self.bn3, x, ds[0], ds[1], "relu")
+            if y is not None:
+                return y
+        identity = _shortcut(self, x)
+        if isinstance(nxt, _ResNetBottleneck):
             y = ops.conv1x1_chain(out, self.conv3, self.bn3, identity, nxt.conv1, nxt.bn1)
             if y is not None:
                 return y
-        else:
-            identity = _shortcut(self, x)
         return ops.conv2d(out, self.conv3, self.bn3, "relu", residual=identity)
 
 

@@ -249,6 +249,47 @@ def _scaled_rows(conv, bn) -> Tuple[np.ndarray, np.ndarray]:
     return w, (np.zeros(conv.out_channels, np.float32) if bias is None else bias)
 
 
+def _dual_weights(conv3, bn3, ds_conv, ds_bn):
+    """[scale3 * W3 | scale_d * W_d] as bf16 rows and shift3 + shift_d (cached on conv3)."""
+    cache = conv3._cache()
+    key = ("dual", id(bn3), id(ds_conv), id(ds_bn))
+    hit = cache.get(key)
+    if hit is None:
+        w3, h3 = _scaled_rows(conv3, bn3)
+        wd, hd = _scaled_rows(ds_conv, ds_bn)
+        hit = (_dev(np.concatenate([w3, wd], axis=1), torch.bfloat16), _dev((h3 + hd).astype(np.float32), torch.float32))
+        cache[key] = hit
+    return hit
+
+
+def conv1x1_dual(x: Act, conv3, bn3, xin: Act, ds_conv, ds_bn, act="relu") -> Optional[Act]:
+    """act(bn3(conv3(x)) + ds_bn(ds_conv(xin))): a bottleneck's last conv and its (possibly strided) pointwise downsample
+    branch as one GEMM over the concatenated reduction (resnet.py:144-162, 295-303).  None when unsupported."""
+    dt = compute_dtype()
+    if dt != "bf16" or not _pointwise(conv3):
+        return None
+    sd = tuple(ds_conv.stride)
+    if tuple(ds_conv.kernel_size) != (1, 1) or tuple(ds_conv.padding) != (0, 0) or tuple(ds_conv.dilation) != (1, 1) \
+            or ds_conv.groups != 1 or sd[0] != sd[1] or conv3.out_channels != ds_conv.out_channels:
+        return None
+    _check_bn(bn3)
+    _check_bn(ds_bn)
+    x, xin = as_map(x), as_map(xin)
+    B, Ho, Wo, C1 = x.t.shape
+    B2, H2, W2, C2 = xin.t.shape
+    K = conv3.out_channels
+    if B2 != B or (H2 - 1) // sd[0] + 1 != Ho or (W2 - 1) // sd[0] + 1 != Wo or C1 != conv3.in_channels \
+            or C2 != ds_conv.in_channels or x.t.dtype != torch.bfloat16 or xin.t.dtype != torch.bfloat16:
+        return None
+    if not _lib.load().mv_conv1x1_dual_supported(B * Ho * Wo, C1, C2, K, DT[dt]):
+        return None
+    wcat, shift = _dual_weights(conv3, bn3, ds_conv, ds_bn)
+    y = empty((B, Ho, Wo, K), torch.bfloat16)
+    _lib.call("mv_conv1x1_dual_fwd", _ptr(x.t), _ptr(xin.t), _ptr(wcat), None, _ptr(shift), _ptr(y), B, Ho, Wo, C1, H2, W2, C2,
+              sd[0], K, ACT[act], DT[dt], stream_ptr())
+    return Act(y, "map", x.batched)
+
+
 def conv1x1_dual_chain(x: Act, conv3, bn3, xin: Act, ds_conv, ds_bn, conv1n, bn1n) -> Optional[Act]:
     """relu(bn3(conv3(x)) + ds_bn(ds_conv(xin))) -- a bottleneck whose identity is a pointwise conv of the block input
     (resnet.py:295-303) -- and relu(bn1n(conv1n(.))) of that result, in ONE launch: the two convolutions that add into
@@ -270,15 +311,7 @@ def conv1x1_dual_chain(x: Act, conv3, bn3, xin: Act, ds_conv, ds_bn, conv1n, bn1
         return None
     if not _lib.load().mv_conv1x1_dual_chain_supported(M, C1, C2, K, N2, DT[dt]):
         return None
-    cache = conv3._cache()
-    key = ("dual", id(bn3), id(ds_conv), id(ds_bn))
-    hit = cache.get(key)
-    if hit is None:
-        w3, h3 = _scaled_rows(conv3, bn3)
-        wd, hd = _scaled_rows(ds_conv, ds_bn)
-        hit = (_dev(np.concatenate([w3, wd], axis=1), torch.bfloat16), _dev((h3 + hd).astype(np.float32), torch.float32))
-        cache[key] = hit
-    wcat, shift = hit
+    wcat, shift = _dual_weights(conv3, bn3, ds_conv, ds_bn)
     w1, s1, h1 = prep_conv(conv1n, bn1n, "krsc", dt)
     y = empty((B, H, W, K), torch.bfloat16)
     t1 = empty((B, H, W, N2), torch.bfloat16)

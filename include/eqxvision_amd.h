@@ -42,7 +42,7 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  * the row count from which dense layers use the deep-pipelined kernels), "igemm3" (1 = prefer, 2 = force
  * the phase-alternating 256x256 kernel) / "no_igemm3", "c3x3_v1" (first-generation 3x3 64->64 kernel),
  * "no_stem_pool" (do not fuse the ResNet entry with its max-pool), "stream_npass1" (one channel slab
- * per block in the streaming 1x1 kernel), "no_chain" / "no_dual_chain" (do not fuse conv3 with the next block's conv1 / with the downsample conv), "no_skinny" (classifier heads on the tiled kernels), "res_early"
+ * per block in the streaming 1x1 kernel), "no_dual" (conv3 and the downsample conv as separate launches), "no_chain" / "no_dual_chain" (do not fuse conv3 with the next block's conv1 / with the downsample conv), "no_skinny" (classifier heads on the tiled kernels), "res_early"
  * (igemm2: fetch residual rows before the reduction instead of in its middle), "igemm4" (four-wave kernels of
  * igemm4.hip: 1 = 256x128 tiles / two blocks per CU wherever igemm2 would run, 2 = force 256x256, 3 = force
  * 256x128), "prof_lo" / "prof_hi" (device pointer for per-block phase stamps, tools/phase_prof.py), "no_tuned" (ignore the
@@ -105,6 +105,16 @@ int mv_conv1x1_chain_fwd(const void* x, const void* w3, const float* scale3, con
                          const void* residual, void* y, const void* w1, const float* scale1,
                          const float* shift1, void* t1, int64_t M, int C, int K, int N2, int dtype,
                          mv_stream_t stream);
+
+/* conv3 + BN and the downsample conv + BN of a stage's first bottleneck (resnet.py:144-162, 295-303) as ONE GEMM over
+ * the concatenated reduction: both add into the same output, so
+ *   y[N,Ho,Wo,K] = act(scale[k] * (x[N,Ho,Wo,C1] . wcat[k, 0:C1] + x2[N, s*ho, s*wo, C2] . wcat[k, C1:C1+C2]) + shift[k])
+ * with x2 the block input read at pixel stride s (1 or 2) and the two BatchNorm scales folded into wcat's rows by the
+ * caller (scale = NULL, shift = shift3 + shift_d).  The identity map is neither written nor read.  C1, C2 % 64 == 0. */
+int mv_conv1x1_dual_supported(int64_t M, int C1, int C2, int K, int dtype);
+int mv_conv1x1_dual_fwd(const void* x, const void* x2, const void* wcat, const float* scale, const float* shift,
+                        void* y, int N, int Ho, int Wo, int C1, int H2, int W2, int C2, int stride2, int K,
+                        int act, int dtype, mv_stream_t stream);
 
 /* The same chain for the FIRST bottleneck of a stage whose identity is a 1x1 stride-1 convolution of the block input
  * (downsample = conv + BN, resnet.py:295-303; ResNet-50 layer1): conv3 and the downsample conv accumulate into one

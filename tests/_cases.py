@@ -201,6 +201,41 @@ def dual_chain_case(M, seed=0):
     return run
 
 
+def dual_case(N, Ho, Wo, C1, C2, K, stride, act=1, seed=0):
+    """mv_conv1x1_dual_fwd: a dense pointwise layer on x and a strided pointwise layer on x2 accumulated in one GEMM
+    (scales folded into the weight rows) vs the oracle's two convolutions with fp32 scales (resnet.py:144-162, 295-303)."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        H2, W2 = (Ho - 1) * stride + 1 + int(rng.integers(0, stride)), (Wo - 1) * stride + 1 + int(rng.integers(0, stride))
+        x = bf(rng.standard_normal((N, Ho, Wo, C1)))
+        x2 = bf(rng.standard_normal((N, H2, W2, C2)))
+        w3 = bf(rng.standard_normal((K, C1)) / np.sqrt(C1))
+        wd = bf(rng.standard_normal((K, C2)) / np.sqrt(C2))
+        s3 = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        sd = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        h = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        M = N * Ho * Wo
+        if not L.load().mv_conv1x1_dual_supported(M, C1, C2, K, 1):
+            return {"ok": False, "err": "mv_conv1x1_dual_supported says no"}
+        f64 = np.float64
+        xs = x2[:, ::stride, ::stride][:, :Ho, :Wo]
+        ref = (x.reshape(M, C1).astype(f64) @ w3.astype(f64).T) * s3 + (xs.reshape(M, C2).astype(f64) @ wd.astype(f64).T) * sd + h
+        if act == 1:
+            ref = O.relu(ref)
+        wcat = bf(np.concatenate([w3.astype(np.float32) * s3[:, None], wd.astype(np.float32) * sd[:, None]], axis=1))
+        xd, x2d, wd_, hd = dev(x, "bf16"), dev(x2, "bf16"), dev(wcat, "bf16"), dev(h, "fp32")
+        y = torch.full((M, K), -7.0, dtype=torch.bfloat16, device="cuda")
+        L.call("mv_conv1x1_dual_fwd", xd.data_ptr(), x2d.data_ptr(), wd_.data_ptr(), None, hd.data_ptr(), y.data_ptr(), N, Ho, Wo,
+               C1, H2, W2, C2, stride, K, act, 1, _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, TOL_BF16)
+        info["kernel"] = kern
+        return info
+    return run
+
+
 def conv_nchw_case(N, C, H, W, K, R, S, stride, pad, act=0, xdtype="fp32", tokens=False, generic=False, seed=0,
                    v0=False):
     def run():
@@ -783,6 +818,11 @@ def all_cases():
           ("chain/56x56_B4", chain_case(4 * 56 * 56, seed=1)),
           ("chain/ragged_M", chain_case(8192 + 37, seed=2)),
           ("chain/many_tiles", chain_case(40 * 56 * 56 + 5, seed=3)),
+          ("dual/layer2_entry_s2", dual_case(8, 28, 28, 128, 256, 512, 2, seed=1)),
+          ("dual/layer3_entry_s2", dual_case(24, 14, 14, 256, 512, 1024, 2, seed=2)),
+          ("dual/layer4_entry_s2_ragged", dual_case(86, 7, 7, 512, 1024, 2048, 2, seed=3)),
+          ("dual/s1_64_64_K200_noact", dual_case(3, 37, 41, 64, 64, 200, 1, act=0, seed=4)),
+          ("dual/s2_odd_input", dual_case(5, 31, 29, 192, 128, 320, 2, seed=5)),
           ("chain/dual_56x56_B4", dual_chain_case(4 * 56 * 56, seed=6)),
           ("chain/dual_ragged_many", dual_chain_case(29 * 56 * 56 + 13, seed=7)),
           ("chain/n128_56x56_B4", chain_case(4 * 56 * 56, seed=4, N2=128)),
