@@ -389,14 +389,28 @@ int igemm2_dual_launch(const void* x, const void* x2, const void* w, const float
     p.sh = 1; p.sw = 1; p.ph = 0; p.pw = 0; p.dh = 1; p.dw = 1;
     p.M = (int)((long long)N * Ho * Wo);
     p.act = act;
-    constexpr int BM = 256, BN = 128, NST = 3;
-    constexpr int SMEM = NST * (BM + BN) * 128;
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (K + BN - 1) / BN;
-    set_kernel_name("igemm2_dual_bf16_256x128");
-    auto kern = igemm2_kernel<4, 2, 2, 2, 3, true, bf16_t, true>;
-    MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), SMEM, st, p);
+    p.tiles_m = (p.M + 255) / 256;
+    // 256 x 256 tiles measured +2% on resnet50 B=256 over 256 x 128 (the reductions are short: 6-24 k-tiles, so fewer,
+    // larger tiles amortise prologue and epilogue); "dual_tile" = 2 / 3 forces, 4 = 256 x 256 only with >= 256 tiles
+    int tile = get_flag("dual_tile");
+    const long long big = (long long)p.tiles_m * ((K + 255) / 256);
+    if (tile == 4) tile = big >= 256 ? 3 : 2;
+    if (tile != 2 && tile != 3) tile = (K % 256 == 0) ? 3 : 2;
+    if (tile == 3) {
+        constexpr int SMEM = 2 * (256 + 256) * 128;
+        p.tiles_n = (K + 255) / 256;
+        set_kernel_name("igemm2_dual_bf16_256x256");
+        auto kern = igemm2_kernel<2, 4, 4, 2, 2, false, bf16_t, true>;
+        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), SMEM, st, p);
+    } else {
+        constexpr int SMEM = 3 * (256 + 128) * 128;
+        p.tiles_n = (K + 127) / 128;
+        set_kernel_name("igemm2_dual_bf16_256x128");
+        auto kern = igemm2_kernel<4, 2, 2, 2, 3, true, bf16_t, true>;
+        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), SMEM, st, p);
+    }
     MV_LAUNCH_CHECK();
     return MV_OK;
 }
