@@ -166,9 +166,22 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
             outs.append(o)
         full = torch.empty((B,) + tuple(outs[0].shape[1:]), dtype=outs[0].dtype, device=outs[0].device)
         c.keep.append(outs)
-        for l, o in enumerate(outs):                     # gather the lanes' rows with the library's copy kernel
+        for l, o in enumerate(outs):
             dst = full[l * step:(l + 1) * step]
-            dt = _lib.F32 if o.dtype == torch.float32 else _lib.BF16
+            # The lane's result is normally the output buffer of its LAST launch (the classifier head): point that
+            # launch at the lane's rows of the full result instead of copying them there afterwards.
+            cfn, cargs, cname = lane_calls[l][-1] if lane_calls[l] else (None, (), "")
+            hits = [i for i, a in enumerate(cargs) if isinstance(a, int) and a == o.data_ptr()]
+            earlier = any(isinstance(a, int) and a == o.data_ptr() for _, args_, _ in lane_calls[l][:-1] for a in args_)
+            if len(hits) == 1 and not earlier and o.data_ptr() != 0:
+                patched = list(cargs)
+                patched[hits[0]] = dst.data_ptr()
+                lane_calls[l][-1] = (cfn, tuple(patched), cname)
+                rc = cfn(*patched)                       # the trace ran eagerly: produce this call's rows in `full` too
+                if rc != 0:
+                    raise _lib.MVError(f"lane output redirect of {cname} failed (rc={rc})")
+                continue
+            dt = _lib.F32 if o.dtype == torch.float32 else _lib.BF16     # otherwise: the library's copy kernel
             old = _lib.set_recording(lane_calls[l])
             try:
                 _lib.call("mv_cast", o.data_ptr(), dst.data_ptr(), o.numel(), dt, dt, stream_ptr())
