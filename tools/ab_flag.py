@@ -17,7 +17,7 @@ fw = {}
 for v in (0, 1):
     if flag.startswith("lanes"):
         f = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k), use_graph=True, clone_outputs=False,
-                           lanes=1 if v == 0 else int(flag[5:] or 2))
+                           lanes=int(os.environ.get('BASE_LANES', '1')) if v == 0 else int(flag[5:] or 2))
     else:
         _lib.set_flag(flag, v * int(os.environ.get('FLAGVAL', '1')))
         f = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k), use_graph=True, clone_outputs=False,
