@@ -698,7 +698,7 @@ def fuzz_misc_cases(n, seed=0):
     i = 0
     while len(out) < n:
         i += 1
-        k = int(rng.integers(0, 7))
+        k = int(rng.integers(0, 9))
         sd = 3000 + i
         if k == 0:
             C = int(rng.choice([32, 64, 96, 128, 192, 256, 384, 512, 768, 1024, 1536, 40, 100]))
@@ -732,9 +732,19 @@ def fuzz_misc_cases(n, seed=0):
             out.append((f"fuzzm/s{seed}_stem_pool_{i}", stem_pool_case(int(rng.integers(1, 5)), int(rng.integers(20, 130)),
                                                                       int(rng.integers(20, 130)),
                                                                       xdtype=str(rng.choice(["fp32", "bf16"])), seed=sd)))
-        else:
+        elif k == 6:
             out.append((f"fuzzm/s{seed}_chain_{i}", chain_case(8192 + int(rng.integers(0, 30000)), seed=sd,
                                                               N2=int(rng.choice([64, 128])))))
+        elif k == 7:
+            out.append((f"fuzzm/s{seed}_dual_chain_{i}", dual_chain_case(8192 + int(rng.integers(0, 30000)), seed=sd)))
+        else:
+            st = int(rng.choice([1, 2]))
+            Ho, Wo = int(rng.integers(7, 40)), int(rng.integers(7, 40))
+            N = int(max(1, -(-4096 // (Ho * Wo)) + rng.integers(0, 6)))
+            out.append((f"fuzzm/s{seed}_dual_{i}", dual_case(N, Ho, Wo, int(rng.choice([64, 128, 192, 256])),
+                                                            int(rng.choice([64, 128, 256, 512])),
+                                                            int(rng.choice([64, 200, 256, 512, 1024])), st,
+                                                            act=int(rng.choice([0, 1])), seed=sd)))
     return out
 
 
