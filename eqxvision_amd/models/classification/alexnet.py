@@ -20,32 +20,24 @@ class AlexNet(Module):
     def __init__(self, num_classes: int = 1000, dropout: float = 0.5, *, key=None) -> None:
         if key is None:
             key = jr.PRNGKey(0)
-        k = jr.split(key, 8)
-        self.features = nn.Sequential([
-            nn.Conv2d(3, 64, kernel_size=11, stride=4, padding=2, key=k[0]),
-            nn.Lambda(nn.relu),
-            nn.MaxPool2d(kernel_size=3, stride=2),
-            nn.Conv2d(64, 192, kernel_size=5, padding=2, key=k[1]),
-            nn.Lambda(nn.relu),
-            nn.MaxPool2d(kernel_size=3, stride=2),
-            nn.Conv2d(192, 384, kernel_size=3, padding=1, key=k[2]),
-            nn.Lambda(nn.relu),
-            nn.Conv2d(384, 256, kernel_size=3, padding=1, key=k[3]),
-            nn.Lambda(nn.relu),
-            nn.Conv2d(256, 256, kernel_size=3, padding=1, key=k[4]),
-            nn.Lambda(nn.relu),
-            nn.MaxPool2d(kernel_size=3, stride=2),
-        ])
+        keys = iter(jr.split(key, 8))
+        # (out_channels, kernel, stride, padding, max-pool after?) -- torchvision's AlexNet; the layer ORDER is the
+        # load_torch_weights contract (ordered zip with the checkpoint)
+        plan = ((64, 11, 4, 2, True), (192, 5, 1, 2, True), (384, 3, 1, 1, False), (256, 3, 1, 1, False), (256, 3, 1, 1, True))
+        stack, cin = [], 3
+        for cout, ksz, st, pad, pool in plan:
+            stack += [nn.Conv2d(cin, cout, kernel_size=ksz, stride=st, padding=pad, key=next(keys)), nn.Lambda(nn.relu)]
+            if pool:
+                stack.append(nn.MaxPool2d(kernel_size=3, stride=2))
+            cin = cout
+        self.features = nn.Sequential(stack)
         self.avgpool = nn.AdaptiveAvgPool2d((6, 6))
-        self.classifier = nn.Sequential([
-            nn.Dropout(p=dropout),
-            nn.Linear(256 * 6 * 6, 4096, key=k[5]),
-            nn.Lambda(nn.relu),
-            nn.Dropout(p=dropout),
-            nn.Linear(4096, 4096, key=k[6]),
-            nn.Lambda(nn.relu),
-            nn.Linear(4096, num_classes, key=k[7]),
-        ])
+        head, width = [], cin * 6 * 6
+        for hidden in (4096, 4096):
+            head += [nn.Dropout(p=dropout), nn.Linear(width, hidden, key=next(keys)), nn.Lambda(nn.relu)]
+            width = hidden
+        head.append(nn.Linear(width, num_classes, key=next(keys)))
+        self.classifier = nn.Sequential(head)
 
     def __call__(self, x, *, key):
         if key is None:                                  # reference :78-79

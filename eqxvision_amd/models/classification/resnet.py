@@ -231,44 +231,33 @@ def _resnet(block, layers, torch_weights=None, **kwargs):
     return model
 
 
-def resnet18(torch_weights=None, **kwargs) -> ResNet:
-    return _resnet(_ResNetBasicBlock, [2, 2, 2, 2], torch_weights, **kwargs)
+# name -> (block, blocks per stage, constructor overrides); reference :361-511
+_VARIANTS = {
+    "resnet18": (_ResNetBasicBlock, (2, 2, 2, 2), {}),
+    "resnet34": (_ResNetBasicBlock, (3, 4, 6, 3), {}),
+    "resnet50": (_ResNetBottleneck, (3, 4, 6, 3), {}),      # v1.5: 53 convolutions, 4.09 GMAC per 224x224 image
+    "resnet101": (_ResNetBottleneck, (3, 4, 23, 3), {}),
+    "resnet152": (_ResNetBottleneck, (3, 8, 36, 3), {}),
+    "resnext50_32x4d": (_ResNetBottleneck, (3, 4, 6, 3), {"groups": 32, "width_per_group": 4}),
+    "resnext101_32x8d": (_ResNetBottleneck, (3, 4, 23, 3), {"groups": 32, "width_per_group": 8}),
+    "wide_resnet50_2": (_ResNetBottleneck, (3, 4, 6, 3), {"width_per_group": 128}),
+    "wide_resnet101_2": (_ResNetBottleneck, (3, 4, 23, 3), {"width_per_group": 128}),
+}
 
 
-def resnet34(torch_weights=None, **kwargs) -> ResNet:
-    return _resnet(_ResNetBasicBlock, [3, 4, 6, 3], torch_weights, **kwargs)
+def _variant(name):
+    block, depths, fixed = _VARIANTS[name]
+
+    def make(torch_weights=None, **kwargs) -> ResNet:
+        kwargs.update(fixed)
+        return _resnet(block, list(depths), torch_weights, **kwargs)
+
+    make.__name__ = make.__qualname__ = name
+    make.__doc__ = f"{name} (reference models/classification/resnet.py); `torch_weights`: torchvision checkpoint path / URL."
+    return make
 
 
-def resnet50(torch_weights=None, **kwargs) -> ResNet:
-    """ResNet-50 v1.5 (reference :395-407): 53 convolutions, 4.09 GMAC per 224x224 image."""
-    return _resnet(_ResNetBottleneck, [3, 4, 6, 3], torch_weights, **kwargs)
-
-
-def resnet101(torch_weights=None, **kwargs) -> ResNet:
-    return _resnet(_ResNetBottleneck, [3, 4, 23, 3], torch_weights, **kwargs)
-
-
-def resnet152(torch_weights=None, **kwargs) -> ResNet:
-    return _resnet(_ResNetBottleneck, [3, 8, 36, 3], torch_weights, **kwargs)
-
-
-def resnext50_32x4d(torch_weights=None, **kwargs) -> ResNet:
-    kwargs["groups"] = 32
-    kwargs["width_per_group"] = 4
-    return _resnet(_ResNetBottleneck, [3, 4, 6, 3], torch_weights, **kwargs)
-
-
-def resnext101_32x8d(torch_weights=None, **kwargs) -> ResNet:
-    kwargs["groups"] = 32
-    kwargs["width_per_group"] = 8
-    return _resnet(_ResNetBottleneck, [3, 4, 23, 3], torch_weights, **kwargs)
-
-
-def wide_resnet50_2(torch_weights=None, **kwargs) -> ResNet:
-    kwargs["width_per_group"] = 64 * 2
-    return _resnet(_ResNetBottleneck, [3, 4, 6, 3], torch_weights, **kwargs)
-
-
-def wide_resnet101_2(torch_weights=None, **kwargs) -> ResNet:
-    kwargs["width_per_group"] = 64 * 2
-    return _resnet(_ResNetBottleneck, [3, 4, 23, 3], torch_weights, **kwargs)
+resnet18, resnet34, resnet50, resnet101, resnet152 = (_variant(n) for n in ("resnet18", "resnet34", "resnet50", "resnet101",
+                                                                            "resnet152"))
+resnext50_32x4d, resnext101_32x8d = _variant("resnext50_32x4d"), _variant("resnext101_32x8d")
+wide_resnet50_2, wide_resnet101_2 = _variant("wide_resnet50_2"), _variant("wide_resnet101_2")
