@@ -419,7 +419,8 @@ int igemm2_wanted(long long M, int C, int K, int R, int S) {
     // worth it once there is enough work to fill the chip with 256-row tiles and a reduction of >= 4 k-tiles
     const long long ktiles = (long long)R * S * (C / 64);
     (void)K;
-    return M >= 4096 && ktiles >= 4 && R * S <= 64;
+    // (from M = 2048 when the reduction is long, >= 32 k-tiles: Swin stage-3 fc2 3072 -> 768 at M = 3136, +0.5% swin_t)
+    return (M >= 4096 || (M >= 2048 && ktiles >= 32)) && ktiles >= 4 && R * S <= 64;
 }
 
 // block tile igemm2_launch will pick for (M rows, K output channels)
