@@ -60,49 +60,69 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
     const bool dense1x1 = p.R == 1 && p.S == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0;   // block-uniform
     long long xbase[XI];
     unsigned vlo[XI], vhi[XI];
+    // Row m -> (image b, output row ho, output column wo).  The block's first row is decomposed once with integer
+    // divisions (block-uniform); every staged row is that plus an offset < 256 + Wo, small enough for an exact
+    // float-reciprocal division (one multiply + a +-1 correction).  Four full division chains per lane cost 2.4 us of
+    // prologue per tile on the 3x3 layers (phase stamps: 3.6 us against 1.2 us for a dense layer).
+    const int b0 = m0 / (p.Ho * p.Wo), rem0 = m0 - b0 * (p.Ho * p.Wo);
+    const int ho0 = rem0 / p.Wo, wo0 = rem0 - ho0 * p.Wo;
+    const float inv_wo = 1.0f / (float)p.Wo, inv_ho = 1.0f / (float)p.Ho;
+    auto small_div = [](int v, int d, float inv, int& q, int& r) {      // 0 <= v < 2^22
+        q = (int)((float)v * inv);
+        r = v - q * d;
+        if (r >= d) { ++q; r -= d; }
+        if (r < 0) { --q; r += d; }
+    };
+    long long xbase2[DUAL ? XI : 1];
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
-        const int m = m0 + 8 * (wave + 8 * j) + srow;
+        const int roff = 8 * (wave + 8 * j) + srow;
+        const int m = m0 + roff;
         const bool valid = m < p.M;
-        if (dense1x1) {                                   // a Linear: row m is pixel m, one tap, no division chain
+        if (dense1x1) {                                   // a Linear: row m is pixel m, one tap, no division at all
             xbase[j] = (long long)m * p.C + chunk * 8;
             vlo[j] = valid ? 1u : 0u;
             vhi[j] = 0u;
             continue;
         }
-        const int wo = m % p.Wo;
-        const int tt = m / p.Wo;
-        const int ho = tt % p.Ho;
-        const int b = tt / p.Ho;
+        int qw, wo, qh, ho;
+        small_div(wo0 + roff, p.Wo, inv_wo, qw, wo);
+        small_div(ho0 + qw, p.Ho, inv_ho, qh, ho);
+        const int b = b0 + qh;
         const int hi0 = ho * p.sh - p.ph, wi0 = wo * p.sw - p.pw;
-        xbase[j] = (((long long)b * p.H + hi0) * p.W + wi0) * p.C + chunk * 8;
+        xbase[j] = (long long)((b * p.H + hi0) * p.W + wi0) * p.C + chunk * 8;    // pixel index fits 32 bits (N*H*W < 2^31)
+        if constexpr (DUAL) xbase2[j] = (long long)((b * p.H2 + ho * p.s2) * p.W2 + wo * p.s2) * p.C2 + chunk * 8;
         unsigned long long mask = 0;
         if constexpr (DUAL) {
             mask = valid ? 3ull : 0ull;                   // both sources exist for every output pixel
         } else if (valid) {
-            for (int r = 0; r < p.R; ++r) {
-                const int hi = hi0 + r * p.dh;
-                if ((unsigned)hi >= (unsigned)p.H) continue;
-                for (int s = 0; s < p.S; ++s) {
-                    const int wi = wi0 + s * p.dw;
-                    if ((unsigned)wi < (unsigned)p.W) mask |= 1ull << (r * p.S + s);
+            if (p.R == 3 && p.S == 3) {                    // the common case, branch-free: 3 + 3 range checks
+                const unsigned W_ = (unsigned)p.W, H_ = (unsigned)p.H;
+                const unsigned cols = ((unsigned)wi0 < W_ ? 1u : 0u) | ((unsigned)(wi0 + p.dw) < W_ ? 2u : 0u) |
+                                      ((unsigned)(wi0 + 2 * p.dw) < W_ ? 4u : 0u);
+                mask = ((unsigned)hi0 < H_ ? cols : 0u) | ((unsigned)(hi0 + p.dh) < H_ ? cols << 3 : 0u) |
+                       ((unsigned)(hi0 + 2 * p.dh) < H_ ? cols << 6 : 0u);
+            } else if (p.R * p.S <= 32) {                  // rows and columns are independent: R + S range checks, not R * S
+                unsigned cols = 0;
+                for (int s = 0; s < p.S; ++s)
+                    if ((unsigned)(wi0 + s * p.dw) < (unsigned)p.W) cols |= 1u << s;
+                unsigned m32 = 0;
+                for (int r = 0; r < p.R; ++r)
+                    if ((unsigned)(hi0 + r * p.dh) < (unsigned)p.H) m32 |= cols << (r * p.S);
+                mask = m32;
+            } else {
+                for (int r = 0; r < p.R; ++r) {
+                    const int hi = hi0 + r * p.dh;
+                    if ((unsigned)hi >= (unsigned)p.H) continue;
+                    for (int s = 0; s < p.S; ++s) {
+                        const int wi = wi0 + s * p.dw;
+                        if ((unsigned)wi < (unsigned)p.W) mask |= 1ull << (r * p.S + s);
+                    }
                 }
             }
         }
         vlo[j] = (unsigned)mask;
         vhi[j] = (unsigned)(mask >> 32);
-    }
-    long long xbase2[DUAL ? XI : 1];
-    if constexpr (DUAL) {
-#pragma unroll
-        for (int j = 0; j < XI; ++j) {
-            const int m = m0 + 8 * (wave + 8 * j) + srow;
-            const int wo = m % p.Wo;
-            const int tt = m / p.Wo;
-            const int ho = tt % p.Ho;
-            const int b = tt / p.Ho;
-            xbase2[j] = (((long long)b * p.H2 + ho * p.s2) * p.W2 + wo * p.s2) * p.C2 + chunk * 8;
-        }
     }
     long long woff[WI];
 #pragma unroll
@@ -384,6 +404,10 @@ int igemm2_dual_launch(const void* x, const void* x2, const void* w, const float
         set_error("igemm2: zero page allocation failed");
         return MV_E_OOM;
     }
+    if ((long long)N * H2 * W2 >= (1LL << 31) - (1LL << 20)) {
+        set_error("igemm2 dual: %lld input pixels do not fit the 32-bit pixel index", (long long)N * H2 * W2);
+        return MV_E_UNSUPPORTED;
+    }
     p.N = N; p.H = Ho; p.W = Wo; p.C = C1; p.K = K; p.R = 1; p.S = 2;       // S = 2 "taps" = the two sources
     p.Ho = Ho; p.Wo = Wo;
     p.sh = 1; p.sw = 1; p.ph = 0; p.pw = 0; p.dh = 1; p.dw = 1;
@@ -451,6 +475,10 @@ int igemm2_launch(const void* x, const void* w, const float* scale, const float*
     if (!p.zero) {
         set_error("igemm2: zero page allocation failed");
         return MV_E_OOM;
+    }
+    if ((long long)N * H * W >= (1LL << 31) - (1LL << 20)) {          // the kernel indexes input pixels with 32 bits
+        set_error("igemm2: %lld input pixels do not fit the 32-bit pixel index", (long long)N * H * W);
+        return MV_E_UNSUPPORTED;
     }
     p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S;
     p.Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1;
