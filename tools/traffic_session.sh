@@ -12,11 +12,11 @@ find $O -name "*.db" -delete
 O=$O MODEL=$MODEL python - <<'PY'
 import csv, glob, collections, json, os, re
 O, MODEL = os.environ["O"], os.environ["MODEL"]
-FAM = [("igemm2_kernel<4, 2, 2, 2, 3", "igemm2_bf16_256x128"), ("igemm2_kernel<2, 4, 4, 2, 2", "igemm2_bf16_256x256"),
+FAM = [("unsigned short, true>", "igemm2_dual_bf16_256x256"), ("igemm2_kernel<4, 2, 2, 2, 3", "igemm2_bf16_256x128"), ("igemm2_kernel<2, 4, 4, 2, 2", "igemm2_bf16_256x256"),
        ("igemm2_kernel<8, 1, 1, 2, 3", "igemm2_bf16_256x64"), ("igemm3_kernel", "igemm3_bf16_256x256"),
        ("igemm_bf16_kernel<128, 128", "igemm_bf16_128x128"), ("igemm_bf16_kernel<128, 64", "igemm_bf16_128x64"),
        ("stream1x1_kernel", "stream1x1"), ("chain1x1_kernel<64, 8, false", "chain1x1_bf16_64_256_64"), ("chain1x1_kernel<128", "chain1x1_bf16_64_256_128"),
-       ("chain1x1_kernel<64, 6, true", "chain1x1_dual_bf16_64+64_256_64"), ("unsigned short, true>", "igemm2_dual_bf16_256x256"),
+       ("chain1x1_kernel<64, 6, true", "chain1x1_dual_bf16_64+64_256_64"),
        ("conv3x3c64_v2_kernel", "conv3x3c64_halo"), ("stem_pool_kernel", "stem_pool_mfma_f32in"), ("conv3x3c64_kernel", "conv3x3c64_stream"), ("stem_patch_kernel", "stem_patch_mfma_f32in"),
        ("mha_mfma_kernel", "mha_mfma_dh64_hm"), ("layernorm_vec_kernel", "layernorm_vec"), ("swin_attn_mfma", "swin_attn_mfma"),
        ("maxpool_nhwc_bf16x8", "maxpool_nhwc_bf16x8")]
