@@ -205,7 +205,9 @@ def main():
             logits = D.all_gather_rows(logits, B * world)
         return logits
 
-    for _ in range(max(a.warmup, 3)):        # call 1 records, call 2 captures the hipGraph, call 3+ replays
+    for _ in range(3):                       # "compile": call 1 records, call 2 captures the hipGraph, call 3 = first replay
+        out = step()
+    for _ in range(a.warmup):                # the W untimed warm-up steps proper (graph replays)
         out = step()
     torch.cuda.synchronize()
     assert out.shape == (B * world, 1000) and bool(torch.isfinite(out).all())
