@@ -1,8 +1,14 @@
-"""`eqxvision.layers` surface (reference eqxvision/layers/__init__.py:1-6) for the hot path."""
-from .conv_norm_activation import ConvNormActivation
-from .drop_path import DropPath
-from .extensions_2d import LayerNorm2d, Linear2d
-from .mlps import MlpProjection
-from .patch_embed import PatchEmbed
+"""`eqxvision.layers` surface for the hot path: the reference's public names (eqxvision/layers/__init__.py), each bound
+to this package's implementation module."""
+from . import conv_norm_activation as _cna
+from . import drop_path as _dp
+from . import extensions_2d as _e2d
+from . import mlps as _mlp
+from . import patch_embed as _pe
 
-__all__ = ["ConvNormActivation", "DropPath", "LayerNorm2d", "Linear2d", "MlpProjection", "PatchEmbed"]
+_EXPORTS = {
+    "ConvNormActivation": _cna, "DropPath": _dp, "LayerNorm2d": _e2d, "Linear2d": _e2d, "MlpProjection": _mlp,
+    "PatchEmbed": _pe,
+}
+globals().update({name: getattr(mod, name) for name, mod in _EXPORTS.items()})
+__all__ = sorted(_EXPORTS)
