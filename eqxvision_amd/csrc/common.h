@@ -126,6 +126,14 @@ int igemm4_wanted(long long M, int C, int K, int R, int S);
 int igemm4_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                   void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh,
                   int dw, int act, int out_dtype, int tok, int tile, hipStream_t st);
+int igemm8_supported(long long M, int C, int K, int R, int S, long long x_bytes, long long w_bytes);
+int igemm8_wanted(long long M, int C, int K, int R, int S);
+int igemm8_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y,
+                  int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
+                  int act, int out_dtype, int tok, int tile, hipStream_t st);   // tile: 1 = 256x256, 2 = 128x256, 3 = 256x128
+int igemm8_dual_launch(const void* x, const void* x2, const void* w, const float* scale, const float* shift,
+                       const void* residual, void* y, int N, int Ho, int Wo, int C1, int H2, int W2, int C2, int s2, int K,
+                       int act, int out_dtype, int tile, hipStream_t st);
 int igemm3_wanted(long long M, int C, int K, int R, int S);
 int igemm3_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                   void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,

@@ -769,6 +769,16 @@ int mv_conv1x1_dual_fwd(const void* x, const void* x2, const void* wcat, const f
                   C1, C2, K);
         return MV_E_UNSUPPORTED;
     }
+    const int ovd = tile_override("ovd", M, C1, C2, K, stride2, 1);          // 10 / 11 / 12 = igemm8 tiles, 3 = igemm2, 0 = the rule
+    {
+        int t8 = 0;
+        if (get_flag("igemm8") >= 2) t8 = get_flag("igemm8") - 1;
+        else if (ovd >= 10 && ovd <= 12) t8 = ovd - 9;
+        else if (ovd == 0) t8 = igemm8_wanted(M, C1 + C2, K, 1, 1);
+        if (t8)
+            return igemm8_dual_launch(x, x2, wcat, scale, shift, nullptr, y, N, Ho, Wo, C1, H2, W2, C2, stride2, K, act, MV_BF16, t8,
+                                      (hipStream_t)stream);
+    }
     return igemm2_dual_launch(x, x2, wcat, scale, shift, y, N, Ho, Wo, C1, H2, W2, C2, stride2, K, act, (hipStream_t)stream);
 }
 
@@ -939,6 +949,16 @@ int mv_linear_heads_fwd(const void* x, const void* w, const float* scale, const 
         set_error("linear_heads: unsupported shape M=%lld N=%d K=%d tokens=%d dh=%d (ask mv_linear_heads_supported first)",
                   (long long)M, N, K, tokens, dh);
         return MV_E_UNSUPPORTED;
+    }
+    const int ov8 = (!get_flag("igemm2_tile") && !get_flag("igemm3") && !get_flag("igemm4")) ? tile_override("ovh", M, N, K, 1, 1, 1) : -1;
+    {
+        int t8 = 0;
+        if (get_flag("igemm8") >= 2) t8 = get_flag("igemm8") - 1;
+        else if (ov8 >= 10 && ov8 <= 12) t8 = ov8 - 9;
+        else if (ov8 == 0) t8 = igemm8_wanted(M, K, N, 1, 1);
+        if (t8 && igemm8_supported(M, K, N, 1, 1, 2LL * M * K, 2LL * N * K))
+            return igemm8_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE, MV_BF16, tokens,
+                                 t8, (hipStream_t)stream);
     }
     const int ov = (!get_flag("igemm2_tile") && !get_flag("igemm3") && !get_flag("igemm4")) ? tile_override("ovh", M, N, K, 1, 1, 1) : 0;
     if ((ov == 2 || ov == 3) ) {

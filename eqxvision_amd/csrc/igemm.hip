@@ -295,14 +295,14 @@ static int launch_tile(IgemmP& p, bool dense, bool out_f32, hipStream_t st) {
 // Per-shape kernel choice: "ov:<M>:<C>:<K>:<R>:<S>:<stride>" flags (tools/tune_tiles.py sets them while it searches:
 // greedy, one shape at a time, judged on whole-model ms/step in one process) and the short table of shapes where the
 // search beat the rules below by more than its 0.4% threshold.  Choices: 1/2/3 = igemm2 256x64 / 256x128 / 256x256,
-// 4 = igemm3, 5 / 6 = igemm4 256x128 / 256x256, 7 / 8 = 128x128 / 128x64 (this file), 9 = stream1x1; 0 = the rules.
+// 4 = igemm3, 5 / 6 = igemm4 256x128 / 256x256, 7 / 8 = 128x128 / 128x64 (this file), 9 = stream1x1, 10 / 11 / 12 = igemm8 256x256 / 128x256 / 256x128;
+// 0 = the rules.  Kinds: "ov" conv / linear, "ovh" head-major qkv projection, "ovd" dual-source pointwise (3 = igemm2, 10 = igemm8).
 // Round 1 (profiles/r01/*_tile_search.txt): resnet50 B=256 and swin_t B=128 -- nothing above the drift (+0.4% / -0.4%
 // in total), rules kept; vit_base B=256, two lanes -- three shapes, +3.5% together:
 struct TunedTile { const char* kind; int M, a, b, R, S, sh, choice; };
+// Round 2: the three ViT-B rows of round 1 are gone -- igemm8 (choice 10, now the rule for those shapes) beats all of them.
 static const TunedTile kTuned[] = {
-    {"ov", 25216, 3072, 768, 1, 1, 1, 3},     // ViT-B fc2 (+fp32 residual): igemm2 256x256, 13.73 -> 13.44 ms/step
-    {"ovh", 25216, 2304, 768, 1, 1, 1, 5},    // ViT-B qkv, head-major: igemm4 256x128 (two blocks per CU), 13.46 -> 13.36
-    {"ov", 25216, 768, 768, 1, 1, 1, 6},      // ViT-B attention projection: igemm4 256x256, 13.38 -> 13.27
+    {"none", 0, 0, 0, 0, 0, 0, 0},
 };
 int tile_override(const char* kind, long long M, int a, int b, int R, int S, int sh) {
     char key[96];
@@ -344,6 +344,9 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
         get_flag("igemm4") < 2 &&
         skinny_supported(M, C, K, in_dtype, residual))                   // classifier heads: one wave per 32 x 32 tile
         return skinny_launch(x, w, scale, shift, y, M, C, K, act, out_dtype, st);
+    if (get_flag("igemm8") >= 2 && igemm8_supported(M, C, K, R, S, 2LL * N * H * W * C, 2LL * K * R * S * C))      // forced (tests)
+        return igemm8_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
+                             get_flag("igemm8") - 1, st);                  // 2 = 256x256, 3 = 128x256, 4 = 256x128
     const bool plain = !get_flag("igemm_tile") && !get_flag("igemm2_tile") && !get_flag("igemm3") && !get_flag("igemm4") &&
                        !get_flag("no_igemm2") && !get_flag("no_igemm3") && !get_flag("no_stream") && !get_flag("tail_split") &&
                        !get_flag("igemm2_dense_m");
@@ -361,6 +364,9 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
     if ((ov == 5 || ov == 6) && igemm4_wanted(M, C, K, R, S))
         return igemm4_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
                              ov == 6 ? 3 : 2, st);
+    if (ov >= 10 && ov <= 12 && igemm8_supported(M, C, K, R, S, 2LL * N * H * W * C, 2LL * K * R * S * C))
+        return igemm8_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
+                             ov - 9, st);
     if (ov == 9 && dense && stream1x1_supported(C, K, in_dtype, out_dtype, M))
         return stream1x1_launch(x, w, scale, shift, residual, y, M, C, K, act, out_dtype, st);
     if (ov == 7 || ov == 8) {
@@ -384,6 +390,15 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
                                    : conv3x3c64_v2_launch(x, w, scale, shift, y, N, H, W, act, st);
     if (dense && !get_flag("no_stream") && !get_flag("igemm_tile") && stream1x1_supported(C, K, in_dtype, out_dtype, M))
         return stream1x1_launch(x, w, scale, shift, residual, y, M, C, K, act, out_dtype, st);
+    // Ping-pong 256 x 256 kernel (igemm8.hip): ~1.35x igemm2's rate per tile, so it takes every layer with enough 256 x 256
+    // tiles to fill most of a round of CUs, >= 192 output channels (a 128-channel layer would waste half of every tile) and
+    // a reduction long enough (>= 8 k-tiles) to amortise the bigger tile's prologue / epilogue (tools/g8_bench.py, round 2).
+    const int t8 = igemm8_wanted(M, C, K, R, S);
+    if (t8 && !get_flag("igemm_tile") && !get_flag("igemm2_tile") && !get_flag("igemm3") &&
+        !get_flag("igemm4") && !get_flag("no_igemm2") && !get_flag("tail_split") && !get_flag("igemm2_dense_m") &&
+        igemm8_supported(M, C, K, R, S, 2LL * N * H * W * C, 2LL * K * R * S * C))
+        return igemm8_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0, t8,
+                             st);
     // deep-pipelined 8-wave kernel: every real convolution (taps or stride) and the big Linears; the
     // short dense 1x1 layers with a short reduction measured the same or faster on the 128^2 kernel
     // (measured, tools/swin_sweep.py: with an fp32 residual epilogue the 256-row kernel wins from M = 6272 up)

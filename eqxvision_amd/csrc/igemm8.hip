@@ -1,0 +1,717 @@
+// Ping-pong implicit GEMM with 512-cycle phases, 256 pixels x 256 channels x 64 (k) per step, gfx950.
+//
+// The matrix pipe of a SIMD is shared by the two waves a 512-thread block puts on it.  igemm2 lets both waves run
+// the same schedule (reads, DMA issue and MFMAs interleaved in each wave); here the two waves of a SIMD never do the
+// same thing at the same time:
+//
+//   * the 8 waves form two groups of four (group g = wave / 4 owns pixel rows 128 g .. 128 g + 127 of the tile, its
+//     four waves 64 channels each), one wave of each group per SIMD; a wave's accumulator is 128 x 64 (8 MFMA tiles
+//     of 32 x 32 = 128 registers);
+//   * a k-tile of 64 is TWO phases, each a LOAD half and an MFMA half separated by raw `s_barrier`s:
+//         phase 1  LOAD: 16 ds_read_b128 (weights 64 x 64, pixels 0..63 x 64)   MFMA: 16 x v_mfma_f32_32x32x16_bf16
+//         phase 2  LOAD:  8 ds_read_b128 (pixels 64..127 x 64)                  MFMA: 16 x ...
+//     so an MFMA half is 512 cycles of back-to-back matrix work (igemm3's phases are 256: twice the barriers per
+//     FLOP); group 1 runs one barrier behind group 0, so on every SIMD one wave is in its MFMA half while its partner
+//     is in its LOAD half;
+//   * LDS holds two k-tiles (2 x 64 KB), each as three DMA units that are re-staged as soon as their last reader is
+//     done, not when the whole tile is: W (256 x 64, read in phase 1), Xtop (the 2 x 64 phase-1 pixel rows) and Xbot
+//     (the phase-2 rows).  Per thread a k-tile is 8 LDS-DMA instructions (16 bytes per lane), spread 3 / 5 over the two
+//     LOAD halves so that both stay shorter than the partner's 512-cycle MFMA half.  Every wait is a counted
+//     `s_waitcnt vmcnt(8 | 7)`: one whole k-tile stays in flight across the barriers.
+//   * the DMA is `buffer_load_dwordx4 ... offen lds`: the per-lane part of an address (row base) is a 32-bit VGPR
+//     offset computed ONCE, the per-k-tile part (filter tap, channel block) is a scalar offset, and rows that fall in
+//     the zero padding / beyond M or K get an out-of-range offset -- the buffer unit then writes zeros, so there is
+//     no zero page, no 64-bit pointer select and ~3 VALU per piece instead of ~7 (igemm2);
+//   * LDS rows are 128 bytes, lane-linear for the DMA; the 16-byte chunk a lane fetches is XOR-swizzled on the
+//     SOURCE side (chunk ^ ((row >> 1) & 7)) and the fragment reads apply the same XOR (conflict-free ds_read_b128).
+//
+// Operands, accumulator layout and epilogue are igemm2's (A = weights, B = pixels: a lane ends with 4 consecutive
+// channels of one pixel; wave-private LDS transpose, full 128-byte line stores; scale/shift, residual, activation,
+// head-major token output).  DUAL: a second reduction source x2 (pointwise, pixel stride s2) appended to the
+// reduction -- ResNet conv3 + downsample conv (resnet.py:144-162, 295-303), or x2 = x with the low halves of split
+// bf16 weights for the precision-critical Linears.
+#include <type_traits>
+
+#include "igemm_pipe.h"
+
+namespace mv {
+
+namespace {
+
+constexpr unsigned OOB = 0x80000000u;          // >= num_records of every descriptor: the DMA writes zeros
+constexpr int LDS_W = 0, LDS_XT = 65536, LDS_XB = 98304;   // unit bases of buffer 0; buffer 1: W +32768, XT/XB +16384
+constexpr int LDS_TOTAL = 131072;
+
+template <int LOFF>
+__device__ __forceinline__ void dma16(unsigned ldsw, unsigned voff, const u32x4& rsrc, unsigned soff) {
+    asm volatile("s_add_u32 m0, %0, %4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(ldsw), "v"(voff), "s"(rsrc), "s"(soff), "n"(LOFF)
+                 : "memory", "scc");
+}
+
+__device__ __forceinline__ u32x4 make_rsrc(const void* base) {
+    const unsigned long long b = (unsigned long long)base;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);      // stride 0: raw buffer
+    r[2] = OOB;                                                                 // num_records (bytes)
+    r[3] = 0x00020000u;                                                         // gfx9 raw-buffer data format
+    return r;
+}
+
+template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+}  // namespace
+
+struct TapState {          // the k-tile a DMA unit is being staged for: scalar source offsets of both operands
+    int r, s, c0;          // filter tap and first channel
+    unsigned xoff;         // byte offset of (tap, c0) from the x descriptor base
+    unsigned woff;         // byte offset of the k-tile inside a weight row
+    unsigned bit;          // 1 << tap index (which bit of a row's tap mask decides valid / zero padding)
+};
+
+__device__ __forceinline__ TapState tap_first() {
+    TapState s;
+    s.r = 0; s.s = 0; s.c0 = 0; s.xoff = 0; s.woff = 0; s.bit = 1u;
+    return s;
+}
+
+// -> state of k-tile `tile` (called with consecutive tiles); nk1 = k-tiles of the first source
+template <bool DUAL> __device__ __forceinline__ void tap_next(const Igemm2P& p, TapState& s, int tile, int nk1) {
+    s.woff += 128u;
+    if (DUAL && tile >= nk1) {                   // second source: one "tap", channels (tile - nk1) * 64
+        s.xoff = 128u * (unsigned)(tile - nk1);
+        return;
+    }
+    s.c0 += 64;
+    if (s.c0 == p.C) {
+        s.c0 = 0;
+        if (++s.s == p.S) { s.s = 0; ++s.r; }
+        s.bit <<= 1;
+    }
+    s.xoff = 2u * (unsigned)(((s.r * p.dh) * p.W + s.s * p.dw) * p.C + s.c0);
+}
+
+// Per-lane DMA source of one staged pixel row: byte offset of its tap-(0,0) / channel-0 element (+ the lane's swizzled
+// 16-byte chunk) from the x descriptor base, the bit mask of the filter taps that fall inside the image, and (DUAL) the
+// offset of the same output pixel in the second, strided source.  Block-uniform part (b0, ho0, wo0) done once by the caller.
+struct RowBase {
+    int ho0, wo0, b0;
+    float inv_wo, inv_ho;
+    unsigned padb;
+    bool dense1x1;
+};
+__device__ __forceinline__ RowBase row_base(const Igemm2P& p, int m0) {
+    RowBase rb;
+    rb.b0 = m0 / (p.Ho * p.Wo);
+    const int rem0 = m0 - rb.b0 * (p.Ho * p.Wo);
+    rb.ho0 = rem0 / p.Wo;
+    rb.wo0 = rem0 - rb.ho0 * p.Wo;
+    rb.inv_wo = 1.0f / (float)p.Wo;
+    rb.inv_ho = 1.0f / (float)p.Ho;
+    rb.dense1x1 = p.R == 1 && p.S == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0;   // block-uniform
+    rb.padb = rb.dense1x1 ? 0u : 2u * (unsigned)((p.ph * p.W + p.pw) * p.C);                 // keeps every row base >= 0
+    return rb;
+}
+__device__ __forceinline__ void small_div(int v, int d, float inv, int& q, int& r) {      // 0 <= v < 2^22
+    q = (int)((float)v * inv);
+    r = v - q * d;
+    if (r >= d) { ++q; r -= d; }
+    if (r < 0) { --q; r += d; }
+}
+template <bool DUAL>
+__device__ __forceinline__ void row_setup(const Igemm2P& p, const RowBase& rb, int m0, int roff, int gch, unsigned& vo,
+                                          unsigned& mask, unsigned& vo2) {
+    const int m = m0 + roff;
+    const bool valid = m < p.M;
+    if (rb.dense1x1 && !DUAL) {
+        vo = valid ? 2u * (unsigned)(m * p.C + gch * 8) : OOB;
+        mask = valid ? 1u : 0u;
+        return;
+    }
+    int qw, wo, qh, ho;
+    small_div(rb.wo0 + roff, p.Wo, rb.inv_wo, qw, wo);
+    small_div(rb.ho0 + qw, p.Ho, rb.inv_ho, qh, ho);
+    const int b = rb.b0 + qh;
+    const int hi0 = ho * p.sh - p.ph, wi0 = wo * p.sw - p.pw;
+    vo = 2u * (unsigned)(((b * p.H + hi0) * p.W + wi0) * p.C + gch * 8) + rb.padb;
+    if constexpr (DUAL) vo2 = valid ? 2u * (unsigned)(((b * p.H2 + ho * p.s2) * p.W2 + wo * p.s2) * p.C2 + gch * 8) : OOB;
+    unsigned mk = 0;
+    if (valid) {
+        unsigned cols = 0;
+        for (int s = 0; s < p.S; ++s)
+            if ((unsigned)(wi0 + s * p.dw) < (unsigned)p.W) cols |= 1u << s;
+        for (int r = 0; r < p.R; ++r)
+            if ((unsigned)(hi0 + r * p.dh) < (unsigned)p.H) mk |= cols << (r * p.S);
+    }
+    mask = mk;
+}
+
+template <typename OutT, bool DUAL>
+__global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int ROWB = 128;
+    constexpr int EPITCH = 64 * 4 + 16;
+    static_assert(8 * 32 * EPITCH <= LDS_TOTAL, "epilogue patches must fit");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+    const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    int tile_m, tile_n;
+    tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---------------- DMA addressing ---------------------------------------------------------------------
+    // One DMA instruction = 512 lanes x 16 bytes = 64 rows of 128 bytes; wave w stages rows 8 w .. 8 w + 7 of it.
+    const int srow = lane >> 3;
+    const int gch = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);      // source chunk of LDS slot lane & 7 (swizzle)
+    const int nk1 = p.R * p.S * (p.C >> 6);
+    const int nk = DUAL ? nk1 + (p.C2 >> 6) : nk1;
+    const unsigned wrow_bytes = 2u * (unsigned)(p.R * p.S * p.C + (DUAL ? p.C2 : 0));
+    const RowBase rb = row_base(p, m0);
+    const u32x4 rx = make_rsrc((const char*)p.x - rb.padb);
+    const u32x4 rw = make_rsrc(p.w);
+    u32x4 rx2 = rx;
+    if constexpr (DUAL) rx2 = make_rsrc(p.x2);
+
+    // x rows: slot q = 0 / 1 -> Xtop rows of group 0 / 1, q = 2 / 3 -> Xbot rows of group 0 / 1
+    unsigned xvo[4], xmask[4];
+    unsigned xvo2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        xvo2[q] = OOB;
+        row_setup<DUAL>(p, rb, m0, 128 * (q & 1) + 64 * (q >> 1) + 8 * wave + srow, gch, xvo[q], xmask[q], xvo2[q]);
+    }
+    unsigned wvo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 64 * j + 8 * wave + srow;
+        wvo[j] = n < p.K ? (unsigned)n * wrow_bytes + 16u * (unsigned)gch : OOB;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * (8 * ROWB));
+
+    // the pieces of one k-tile: W x4, Xtop x2 (group 0 rows, group 1 rows), Xbot x2; BUF compile-time
+    auto x_piece = [&](int q, const TapState& s, int tile, auto loff) {
+        constexpr int LOFF = decltype(loff)::value;
+        if (DUAL && tile >= nk1) {
+            if constexpr (DUAL) dma16<LOFF>(ldsw, xvo2[q], rx2, s.xoff);
+        } else {
+            const unsigned vo = (xmask[q] & s.bit) ? xvo[q] : OOB;
+            dma16<LOFF>(ldsw, vo, rx, s.xoff);
+        }
+    };
+#define MV_I8_W(BUF, st)                                                           \
+    do {                                                                           \
+        dma16<LDS_W + (BUF) * 32768 + 0 * 8192>(ldsw, wvo[0], rw, (st).woff);      \
+        dma16<LDS_W + (BUF) * 32768 + 1 * 8192>(ldsw, wvo[1], rw, (st).woff);      \
+        dma16<LDS_W + (BUF) * 32768 + 2 * 8192>(ldsw, wvo[2], rw, (st).woff);      \
+        dma16<LDS_W + (BUF) * 32768 + 3 * 8192>(ldsw, wvo[3], rw, (st).woff);      \
+    } while (0)
+#define MV_I8_X(BUF, q, st, tile)                                                                                     \
+    x_piece(q, st, tile,                                                                                               \
+            std::integral_constant<int, ((q) < 2 ? LDS_XT : LDS_XB) + (BUF) * 16384 + ((q) & 1) * 8192>{})
+
+    // ---------------- fragment addressing ----------------------------------------------------------------
+    const int fr = lane & 31, fh = lane >> 5, swz = (fr >> 1) & 7;
+    unsigned waddr[4], xaddr[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const unsigned ko = (unsigned)(((2 * kk + fh) ^ swz) << 4);
+        waddr[kk] = lds0 + LDS_W + (64 * wc + fr) * ROWB + ko;
+        xaddr[kk] = lds0 + LDS_XT + (64 * grp + fr) * ROWB + ko;
+    }
+
+    // ---------------- epilogue constants (older than every DMA: vmcnt retires in order) ------------------
+    const OutT* res = (const OutT*)p.residual;
+    ScaleShift8 ss;
+    ss.load(p.scale, p.shift, n0 + 64 * wc + (lane & 7) * 8, p.K);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    // ---------------- prologue: all of k-tile 0, and the phase-2 share (W, Xtop rows of group 0) of k-tile 1 ----
+    TapState sa = tap_first();      // state of the tile whose W / Xtop(0) pieces are issued next (phase-2 issue)
+    TapState sb = tap_first();      // state of the tile whose Xtop(1) / Xbot pieces are issued next (phase-1 issue)
+    MV_I8_W(0, sa);
+    MV_I8_X(0, 0, sa, 0);
+    MV_I8_X(0, 1, sb, 0);
+    MV_I8_X(0, 2, sb, 0);
+    MV_I8_X(0, 3, sb, 0);
+    if (nk > 1) {
+        tap_next<DUAL>(p, sa, 1, nk1);
+        MV_I8_W(1, sa);
+        MV_I8_X(1, 0, sa, 1);
+        wait_vm<7>();
+    } else {
+        wait_vm<2>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind
+
+    u32x4 wf[2][4], xf[2][4];
+    auto mfma_half = [&](int half) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][2 * half + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, wf[a][kk]), __builtin_bit_cast(bf16x8, xf[b][kk]), acc[a][2 * half + b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto pin_frags = [&]() {        // every MFMA below depends on this point (the waits above it)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            asm volatile("" : "+v"(wf[0][kk]), "+v"(wf[1][kk]), "+v"(xf[0][kk]), "+v"(xf[1][kk]));
+    };
+
+    // one k-tile; BUF = it & 1 is a template value so that every LDS offset is an instruction immediate
+    auto ktile = [&](int it, auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+        // ---- phase 1 LOAD: weights + top pixel rows of tile `it`; issue Xtop(1) / Xbot of tile it+1 into the other buffer
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            lds_read16<BUF * 32768>(wf[0][kk], waddr[kk]);
+            lds_read16<BUF * 32768 + 32 * ROWB>(wf[1][kk], waddr[kk]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            lds_read16<BUF * 16384>(xf[0][kk], xaddr[kk]);
+            lds_read16<BUF * 16384 + 32 * ROWB>(xf[1][kk], xaddr[kk]);
+        }
+        if (it + 1 < nk) {
+            tap_next<DUAL>(p, sb, it + 1, nk1);
+            MV_I8_X(BUF ^ 1, 1, sb, it + 1);
+            MV_I8_X(BUF ^ 1, 2, sb, it + 1);
+            MV_I8_X(BUF ^ 1, 3, sb, it + 1);
+            wait_vm_lgkm0<8>();          // Xbot of tile `it` (issued a k-tile ago) has landed
+        } else {
+            wait_vm_lgkm0<0>();
+        }
+        pin_frags();
+        __builtin_amdgcn_s_barrier();
+        mfma_half(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2 LOAD: bottom pixel rows of tile `it`; issue W / Xtop(0) of tile it+2 into this buffer
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            lds_read16<(LDS_XB - LDS_XT) + BUF * 16384>(xf[0][kk], xaddr[kk]);
+            lds_read16<(LDS_XB - LDS_XT) + BUF * 16384 + 32 * ROWB>(xf[1][kk], xaddr[kk]);
+        }
+        if (it + 2 < nk) {
+            tap_next<DUAL>(p, sa, it + 2, nk1);
+            MV_I8_W(BUF, sa);
+            MV_I8_X(BUF, 0, sa, it + 2);
+            wait_vm_lgkm0<7>();          // W and both Xtop pieces of tile it+1 have landed
+        } else if (it + 1 < nk) {
+            wait_vm_lgkm0<2>();
+        } else {
+            wait_vm_lgkm0<0>();
+        }
+        pin_frags();
+        __builtin_amdgcn_s_barrier();
+        mfma_half(1);
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int it = 0; it < nk; it += 2) {
+        ktile(it, std::integral_constant<int, 0>{});
+        if (it + 1 < nk) ktile(it + 1, std::integral_constant<int, 1>{});
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();          // balance group 1's extra barrier: nobody reads LDS any more
+
+    // ---------------- epilogue (igemm2's: wave-private LDS transpose, full-line stores) --------------------
+    char* ep = smem + wave * (32 * EPITCH);
+    OutT* y = (OutT*)p.y;
+    const int xrow0 = 128 * grp, wrow0 = 64 * wc;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        R8<OutT> late[4];
+        if (res) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = m0 + xrow0 + b * 32 + pass * 8 + (lane >> 3);
+                const int n = n0 + wrow0 + (lane & 7) * 8;
+                const bool ok = m < p.M && n < p.K;
+                late[pass].load(res + (ok ? (long long)m * p.K + n : 0));
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = a * 32 + 8 * g + 4 * fh;
+                *(float4*)(ep + fr * EPITCH + nl * 4) = make_float4(acc[a][b][4 * g + 0], acc[a][b][4 * g + 1],
+                                                                     acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
+            }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + (lane >> 3), c8 = lane & 7;
+            const int m = m0 + xrow0 + b * 32 + row;
+            const int n = n0 + wrow0 + c8 * 8;
+            const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
+            const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
+            if (m < p.M && n < p.K) {
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                ss.apply(v);
+                if (res) late[pass].add_to(v);
+                if (p.act == MV_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (p.act == MV_ACT_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                }
+                long long off = (long long)m * p.K + n;
+                if (p.tok > 0) {
+                    const int bi = m / p.tok, ti = m - bi * p.tok;
+                    off = (((long long)bi * (p.K >> 6) + (n >> 6)) * p.tok + ti) * 64 + (n & 63);
+                }
+                Out8<OutT>::st(y + off, v);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#undef MV_I8_W
+#undef MV_I8_X
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same ping-pong for layers with too few 256 x 256 tiles: a wave owns 64 x 64 (4 MFMA tiles, 64 accumulator registers),
+// a k-tile of 64 is ONE phase (LOAD: 16 ds_read_b128 + the thread's 6 DMA pieces of the tile two ahead; MFMA: 16 MFMAs),
+// LDS is a ring of three 48 KB k-tiles (`vmcnt(6)`: one whole tile in flight across the barriers).
+//   ARR = 0: block = 128 pixels x 256 channels (group g: pixel rows 64 g ..; its four waves: 64 channels each) -- layers
+//            with few pixel rows (ResNet 14 x 14 / 7 x 7 maps at half batch, Swin stages 2-3);
+//   ARR = 1: block = 256 pixels x 128 channels (group g: pixel rows 128 g ..; its waves 2 (pixels) x 2 (channels)) -- layers
+//            with 128 output channels (ResNet layer2).
+// Per FLOP it stages 1.5x the bytes of the 256 x 256 tile, so it is the slower kernel wherever both fill the chip.
+template <typename OutT, int ARR, bool DUAL>
+__global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
+    constexpr int BM = ARR == 0 ? 128 : 256, BN = ARR == 0 ? 256 : 128;
+    constexpr int ROWB = 128;
+    constexpr int XI = BM / 64, WI = BN / 64;              // DMA pieces per thread per k-tile
+    constexpr int XBYTES = BM * ROWB;                       // the x unit comes first in a ring slot, then the w unit
+    constexpr int SLOT = (BM + BN) * ROWB;                  // 48 KB
+    constexpr int EPITCH = 64 * 4 + 16;
+    static_assert(XI + WI == 6 && 3 * SLOT <= 160 * 1024 && 8 * 32 * EPITCH <= 3 * SLOT, "ring layout");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int xrow0 = ARR == 0 ? 64 * grp : 128 * grp + 64 * (wave & 1);
+    const int wrow0 = ARR == 0 ? 64 * (wave & 3) : 64 * ((wave >> 1) & 1);
+    const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    int tile_m, tile_n;
+    tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int srow = lane >> 3;
+    const int gch = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+    const int nk1 = p.R * p.S * (p.C >> 6);
+    const int nk = DUAL ? nk1 + (p.C2 >> 6) : nk1;
+    const unsigned wrow_bytes = 2u * (unsigned)(p.R * p.S * p.C + (DUAL ? p.C2 : 0));
+    const RowBase rb = row_base(p, m0);
+    const u32x4 rx = make_rsrc((const char*)p.x - rb.padb);
+    const u32x4 rw = make_rsrc(p.w);
+    u32x4 rx2 = rx;
+    if constexpr (DUAL) rx2 = make_rsrc(p.x2);
+    unsigned xvo[XI], xmask[XI], xvo2[XI];
+#pragma unroll
+    for (int q = 0; q < XI; ++q) {
+        xvo2[q] = OOB;
+        row_setup<DUAL>(p, rb, m0, 64 * q + 8 * wave + srow, gch, xvo[q], xmask[q], xvo2[q]);
+    }
+    unsigned wvo[WI];
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+        const int n = n0 + 64 * j + 8 * wave + srow;
+        wvo[j] = n < p.K ? (unsigned)n * wrow_bytes + 16u * (unsigned)gch : OOB;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * (8 * ROWB));
+
+    auto stage = [&](const TapState& st, int tile, auto slotc) {
+        constexpr int BASE = decltype(slotc)::value * SLOT;
+        const bool second = DUAL && tile >= nk1;
+        if (second) {
+            if constexpr (DUAL) {
+                dma16<BASE + 0 * 8192>(ldsw, xvo2[0], rx2, st.xoff);
+                dma16<BASE + 1 * 8192>(ldsw, xvo2[1], rx2, st.xoff);
+                if constexpr (XI == 4) {
+                    dma16<BASE + 2 * 8192>(ldsw, xvo2[2], rx2, st.xoff);
+                    dma16<BASE + 3 * 8192>(ldsw, xvo2[3], rx2, st.xoff);
+                }
+            }
+        } else {
+            dma16<BASE + 0 * 8192>(ldsw, (xmask[0] & st.bit) ? xvo[0] : OOB, rx, st.xoff);
+            dma16<BASE + 1 * 8192>(ldsw, (xmask[1] & st.bit) ? xvo[1] : OOB, rx, st.xoff);
+            if constexpr (XI == 4) {
+                dma16<BASE + 2 * 8192>(ldsw, (xmask[2] & st.bit) ? xvo[2] : OOB, rx, st.xoff);
+                dma16<BASE + 3 * 8192>(ldsw, (xmask[3] & st.bit) ? xvo[3] : OOB, rx, st.xoff);
+            }
+        }
+        dma16<BASE + XBYTES + 0 * 8192>(ldsw, wvo[0], rw, st.woff);
+        dma16<BASE + XBYTES + 1 * 8192>(ldsw, wvo[1], rw, st.woff);
+        if constexpr (WI == 4) {
+            dma16<BASE + XBYTES + 2 * 8192>(ldsw, wvo[2], rw, st.woff);
+            dma16<BASE + XBYTES + 3 * 8192>(ldsw, wvo[3], rw, st.woff);
+        }
+    };
+
+    // fragment addresses: set A reaches ring slots 0 and 1 through the instruction offset, set B is slot 2
+    const int fr = lane & 31, fh = lane >> 5, swz = (fr >> 1) & 7;
+    unsigned waddr[4], xaddr[4], waddr2[4], xaddr2[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const unsigned ko = (unsigned)(((2 * kk + fh) ^ swz) << 4);
+        xaddr[kk] = lds0 + (xrow0 + fr) * ROWB + ko;
+        waddr[kk] = lds0 + XBYTES + (wrow0 + fr) * ROWB + ko;
+        xaddr2[kk] = xaddr[kk] + 2 * SLOT;
+        waddr2[kk] = waddr[kk] + 2 * SLOT;
+    }
+
+    const OutT* res = (const OutT*)p.residual;
+    ScaleShift8 ss;
+    ss.load(p.scale, p.shift, n0 + wrow0 + (lane & 7) * 8, p.K);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    TapState st = tap_first();
+    stage(st, 0, std::integral_constant<int, 0>{});
+    if (nk > 1) {
+        tap_next<DUAL>(p, st, 1, nk1);
+        stage(st, 1, std::integral_constant<int, 1>{});
+        wait_vm<6>();
+    } else {
+        wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind
+
+    u32x4 wf[2][4], xf[2][4];
+    auto ktile = [&](int it, auto slotc) {
+        constexpr int SL = decltype(slotc)::value;          // ring slot of tile `it`
+        constexpr int OFF = SL == 2 ? 0 : SL * SLOT;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            lds_read16<OFF>(wf[0][kk], SL == 2 ? waddr2[kk] : waddr[kk]);
+            lds_read16<OFF + 32 * ROWB>(wf[1][kk], SL == 2 ? waddr2[kk] : waddr[kk]);
+            lds_read16<OFF>(xf[0][kk], SL == 2 ? xaddr2[kk] : xaddr[kk]);
+            lds_read16<OFF + 32 * ROWB>(xf[1][kk], SL == 2 ? xaddr2[kk] : xaddr[kk]);
+        }
+        if (it + 2 < nk) {                                   // tile it+2 goes where tile it-1 was (last read a phase ago)
+            tap_next<DUAL>(p, st, it + 2, nk1);
+            stage(st, it + 2, std::integral_constant<int, (SL + 2) % 3>{});
+            wait_vm_lgkm0<6>();                              // tile it+1 has landed
+        } else {
+            wait_vm_lgkm0<0>();
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            asm volatile("" : "+v"(wf[0][kk]), "+v"(wf[1][kk]), "+v"(xf[0][kk]), "+v"(xf[1][kk]));
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[a][kk]),
+                                                                        __builtin_bit_cast(bf16x8, xf[b][kk]), acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int it = 0; it < nk; it += 3) {
+        ktile(it, std::integral_constant<int, 0>{});
+        if (it + 1 < nk) ktile(it + 1, std::integral_constant<int, 1>{});
+        if (it + 2 < nk) ktile(it + 2, std::integral_constant<int, 2>{});
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+
+    char* ep = smem + wave * (32 * EPITCH);
+    OutT* y = (OutT*)p.y;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        R8<OutT> late[4];
+        if (res) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = m0 + xrow0 + b * 32 + pass * 8 + (lane >> 3);
+                const int n = n0 + wrow0 + (lane & 7) * 8;
+                const bool ok = m < p.M && n < p.K;
+                late[pass].load(res + (ok ? (long long)m * p.K + n : 0));
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = a * 32 + 8 * g + 4 * fh;
+                *(float4*)(ep + fr * EPITCH + nl * 4) = make_float4(acc[a][b][4 * g + 0], acc[a][b][4 * g + 1],
+                                                                     acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
+            }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + (lane >> 3), c8 = lane & 7;
+            const int m = m0 + xrow0 + b * 32 + row;
+            const int n = n0 + wrow0 + c8 * 8;
+            const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
+            const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
+            if (m < p.M && n < p.K) {
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                ss.apply(v);
+                if (res) late[pass].add_to(v);
+                if (p.act == MV_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (p.act == MV_ACT_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                }
+                long long off = (long long)m * p.K + n;
+                if (p.tok > 0) {
+                    const int bi = m / p.tok, ti = m - bi * p.tok;
+                    off = (((long long)bi * (p.K >> 6) + (n >> 6)) * p.tok + ti) * 64 + (n & 63);
+                }
+                Out8<OutT>::st(y + off, v);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+int igemm8_supported(long long M, int C, int K, int R, int S, long long x_bytes, long long w_bytes) {
+    // 64-channel k-tiles; the tap mask is 32 bits; byte offsets are 31 bits (the out-of-range marker is bit 31)
+    return C % 64 == 0 && C >= 64 && K % 8 == 0 && R * S <= 32 && M < (1LL << 31) - 256 && x_bytes < (1LL << 31) - (1 << 22) &&
+           w_bytes < (1LL << 31);
+}
+
+// The dispatch rule (igemm.hip, generic.hip).  Returns the tile: 0 = not this kernel family, 1 = 256 x 256,
+// 2 = 128 pixels x 256 channels, 3 = 256 pixels x 128 channels.  Measured (tools/g8_bench.py, round 2): the 256 x 256 kernel
+// wins from ~0.7 of a round of CUs up when the reduction is >= 8 k-tiles; below that the half-size tiles fill the chip.
+int igemm8_wanted(long long M, int C, int K, int R, int S) {
+    if (get_flag("no_igemm8")) return 0;
+    const long long nk = (long long)R * S * (C / 64);
+    if (nk < 8 || K < 96) return 0;
+    const long long tm256 = (M + 255) / 256, tm128 = (M + 127) / 128;
+    if (K <= 128) return tm256 >= 176 ? 3 : 0;
+    const long long t256 = tm256 * ((K + 255) / 256);
+    if (t256 >= 176) return 1;
+    if (get_flag("no_igemm8s")) return 0;
+    return tm128 * ((K + 255) / 256) >= 96 ? 2 : 0;
+}
+
+static int igemm8_go(Igemm2P& p, bool dual, bool out_f32, int tile, hipStream_t st) {
+    const int bm = tile == 1 ? 128 : 256, bn = tile == 2 ? 128 : 256;
+    p.tiles_m = (p.M + bm - 1) / bm;
+    p.tiles_n = (p.K + bn - 1) / bn;
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(512);
+#define GO(KERN, SMEM)                                                                                            \
+    do {                                                                                                          \
+        auto kern = KERN;                                                                                         \
+        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));         \
+        hipLaunchKernelGGL(kern, grid, block, SMEM, st, p);                                                       \
+    } while (0)
+#define GO4(NAME, SMEM, ...)                                                  \
+    do {                                                                      \
+        if (dual) {                                                           \
+            if (out_f32) GO((NAME<float, ##__VA_ARGS__, true>), SMEM);        \
+            else GO((NAME<bf16_t, ##__VA_ARGS__, true>), SMEM);               \
+        } else {                                                              \
+            if (out_f32) GO((NAME<float, ##__VA_ARGS__, false>), SMEM);       \
+            else GO((NAME<bf16_t, ##__VA_ARGS__, false>), SMEM);              \
+        }                                                                     \
+    } while (0)
+    if (tile == 1) GO4(igemm8s_kernel, 3 * 384 * 128, 0);
+    else if (tile == 2) GO4(igemm8s_kernel, 3 * 384 * 128, 1);
+    else GO4(igemm8_kernel, LDS_TOTAL);
+#undef GO4
+#undef GO
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int igemm8_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y,
+                  int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
+                  int act, int out_dtype, int tok, int tile, hipStream_t st) {
+    Igemm2P p;
+    memset(&p, 0, sizeof(p));
+    p.tok = tok;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S;
+    p.Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1;
+    p.Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
+    p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw;
+    p.s2 = 1;
+    const long long M = (long long)N * p.Ho * p.Wo;
+    if (!igemm8_supported(M, C, K, R, S, 2LL * N * H * W * C, 2LL * K * R * S * C)) {
+        set_error("igemm8: unsupported shape M=%lld C=%d K=%d R=%d S=%d", M, C, K, R, S);
+        return MV_E_UNSUPPORTED;
+    }
+    p.M = (int)M;
+    p.act = act;
+    const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
+    if (tile == 2) set_kernel_name(dense ? "igemm8_bf16_128x256_dense" : "igemm8_bf16_128x256_conv");
+    else if (tile == 3) set_kernel_name(dense ? "igemm8_bf16_256x128_dense" : "igemm8_bf16_256x128_conv");
+    else set_kernel_name(dense ? "igemm8_bf16_256x256_dense" : "igemm8_bf16_256x256_conv");
+    return igemm8_go(p, false, out_dtype == MV_F32, tile - 1, st);
+}
+
+// y[N,Ho,Wo,K] = act(scale[k] * (x[N,Ho,Wo,C1] . w[k, 0:C1] + x2[N, s2*ho, s2*wo, C2] . w[k, C1:C1+C2]) + shift[k] + residual)
+int igemm8_dual_launch(const void* x, const void* x2, const void* w, const float* scale, const float* shift,
+                       const void* residual, void* y, int N, int Ho, int Wo, int C1, int H2, int W2, int C2, int s2, int K,
+                       int act, int out_dtype, int tile, hipStream_t st) {
+    Igemm2P p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.x2 = (const bf16_t*)x2; p.C2 = C2; p.H2 = H2; p.W2 = W2; p.s2 = s2;
+    p.N = N; p.H = Ho; p.W = Wo; p.C = C1; p.K = K; p.R = 1; p.S = 1;
+    p.Ho = Ho; p.Wo = Wo;
+    p.sh = 1; p.sw = 1; p.ph = 0; p.pw = 0; p.dh = 1; p.dw = 1;
+    const long long M = (long long)N * Ho * Wo;
+    if (!igemm8_supported(M, C1, K, 1, 1, 2LL * M * C1, 2LL * K * (C1 + C2)) || C2 % 64 || C2 < 64 ||
+        2LL * N * H2 * W2 * C2 >= (1LL << 31) - (1 << 22)) {
+        set_error("igemm8 dual: unsupported shape M=%lld C1=%d C2=%d K=%d", M, C1, C2, K);
+        return MV_E_UNSUPPORTED;
+    }
+    p.M = (int)M;
+    p.act = act;
+    set_kernel_name(tile == 2 ? "igemm8_dual_bf16_128x256" : (tile == 3 ? "igemm8_dual_bf16_256x128" : "igemm8_dual_bf16_256x256"));
+    return igemm8_go(p, true, out_dtype == MV_F32, tile - 1, st);
+}
+
+}  // namespace mv

@@ -201,7 +201,7 @@ def dual_chain_case(M, seed=0):
     return run
 
 
-def dual_case(N, Ho, Wo, C1, C2, K, stride, act=1, seed=0):
+def dual_case(N, Ho, Wo, C1, C2, K, stride, act=1, seed=0, flags=()):
     """mv_conv1x1_dual_fwd: a dense pointwise layer on x and a strided pointwise layer on x2 accumulated in one GEMM
     (scales folded into the weight rows) vs the oracle's two convolutions with fp32 scales (resnet.py:144-162, 295-303)."""
     def run():
@@ -226,9 +226,15 @@ def dual_case(N, Ho, Wo, C1, C2, K, stride, act=1, seed=0):
         wcat = bf(np.concatenate([w3.astype(np.float32) * s3[:, None], wd.astype(np.float32) * sd[:, None]], axis=1))
         xd, x2d, wd_, hd = dev(x, "bf16"), dev(x2, "bf16"), dev(wcat, "bf16"), dev(h, "fp32")
         y = torch.full((M, K), -7.0, dtype=torch.bfloat16, device="cuda")
-        L.call("mv_conv1x1_dual_fwd", xd.data_ptr(), x2d.data_ptr(), wd_.data_ptr(), None, hd.data_ptr(), y.data_ptr(), N, Ho, Wo,
-               C1, H2, W2, C2, stride, K, act, 1, _stream())
-        kern = L.last_kernel()
+        for f in flags:
+            L.set_flag(f.split("=")[0], int(f.split("=")[1]) if "=" in f else 1)
+        try:
+            L.call("mv_conv1x1_dual_fwd", xd.data_ptr(), x2d.data_ptr(), wd_.data_ptr(), None, hd.data_ptr(), y.data_ptr(), N, Ho,
+                   Wo, C1, H2, W2, C2, stride, K, act, 1, _stream())
+            kern = L.last_kernel()
+        finally:
+            for f in flags:
+                L.set_flag(f.split("=")[0], 0)
         torch.cuda.synchronize()
         info = _cmp(host(y), ref, TOL_BF16)
         info["kernel"] = kern
@@ -285,7 +291,7 @@ def conv_nchw_case(N, C, H, W, K, R, S, stride, pad, act=0, xdtype="fp32", token
     return run
 
 
-def linear_case(M, K, N, act=0, res=False, dtype="bf16", out="same", generic=False, seed=0, tile=0):
+def linear_case(M, K, N, act=0, res=False, dtype="bf16", out="same", generic=False, seed=0, tile=0, flags=()):
     def run():
         L = _lib()
         rng = _rng(seed)
@@ -308,6 +314,8 @@ def linear_case(M, K, N, act=0, res=False, dtype="bf16", out="same", generic=Fal
         y = torch.empty((M, N), dtype=torch.bfloat16 if odt == "bf16" else torch.float32, device="cuda")
         L.set_flag("force_generic", 1 if generic else 0)
         L.set_flag("igemm_tile", tile)
+        for f in flags:
+            L.set_flag(f.split("=")[0], int(f.split("=")[1]) if "=" in f else 1)
         try:
             L.call("mv_linear_fwd", xd.data_ptr(), wd.data_ptr(), None, bd.data_ptr(),
                    None if rd is None else rd.data_ptr(), y.data_ptr(), M, N, K, act, DT[dtype], DT[odt], _stream())
@@ -315,6 +323,8 @@ def linear_case(M, K, N, act=0, res=False, dtype="bf16", out="same", generic=Fal
         finally:
             L.set_flag("force_generic", 0)
             L.set_flag("igemm_tile", 0)
+            for f in flags:
+                L.set_flag(f.split("=")[0], 0)
         torch.cuda.synchronize()
         info = _cmp(host(y), ref, TOL_BF16 if odt == "bf16" else TOL_F32)
         info["kernel"] = kern
@@ -459,7 +469,7 @@ def mha_case(B, N, H, dh, dtype="bf16", probs=True, generic=False, seed=0, spike
     return run
 
 
-def qkv_heads_case(B, N, H, dh, seed=0, probs=False):
+def qkv_heads_case(B, N, H, dh, seed=0, probs=False, flags=()):
     """mv_linear_heads_fwd (head-major qkv projection) + mv_mha_heads_fwd vs the oracle's
     Linear -> reshape/transpose -> attention (reference vit.py:64-73)."""
     def run():
@@ -481,9 +491,15 @@ def qkv_heads_case(B, N, H, dh, seed=0, probs=False):
         qkv = torch.empty((B, 3 * H, N, dh), dtype=torch.bfloat16, device="cuda")
         y = torch.empty((B, N, D), dtype=torch.bfloat16, device="cuda")
         pr = torch.empty((B, H, N, N), dtype=torch.float32, device="cuda") if probs else None
-        L.call("mv_linear_heads_fwd", xd.data_ptr(), wd.data_ptr(), None, bd.data_ptr(), qkv.data_ptr(), B * N, 3 * D, D,
-               N, dh, DT["bf16"], _stream())
-        k1 = L.last_kernel()
+        for f in flags:
+            L.set_flag(f.split("=")[0], int(f.split("=")[1]) if "=" in f else 1)
+        try:
+            L.call("mv_linear_heads_fwd", xd.data_ptr(), wd.data_ptr(), None, bd.data_ptr(), qkv.data_ptr(), B * N, 3 * D, D,
+                   N, dh, DT["bf16"], _stream())
+            k1 = L.last_kernel()
+        finally:
+            for f in flags:
+                L.set_flag(f.split("=")[0], 0)
         L.call("mv_mha_heads_fwd", qkv.data_ptr(), y.data_ptr(), None if pr is None else pr.data_ptr(), B, N, H, dh,
                float(scale), DT["bf16"], _stream())
         k2 = L.last_kernel()
@@ -825,6 +841,45 @@ def all_cases():
           ("igemm4/t128_k160_five_tiles", conv_nhwc_case(4, 20, 20, 160, 264, 1, 1, seed=193, flags=("igemm4=3",))),
           ("igemm4/5x5", conv_nhwc_case(6, 27, 27, 64, 192, 5, 5, pad=2, act=1, scale=False, seed=92, flags=("igemm4=2",))),
           ("igemm4/t128_5x5", conv_nhwc_case(6, 27, 27, 64, 192, 5, 5, pad=2, act=1, scale=False, seed=192, flags=("igemm4=3",))),
+          ("igemm8/1x1_512_256", conv_nhwc_case(8, 28, 28, 512, 256, 1, 1, act=1, seed=261, flags=("igemm8=2",))),
+          ("igemm8/3x3_128_256", conv_nhwc_case(8, 28, 28, 128, 256, 3, 3, pad=1, act=1, seed=262, flags=("igemm8=2",))),
+          ("igemm8/3x3_s2_C128_K320", conv_nhwc_case(9, 33, 35, 128, 320, 3, 3, stride=2, pad=1, seed=263, flags=("igemm8=2",))),
+          ("igemm8/3x3_dil2_oddM", conv_nhwc_case(3, 37, 41, 64, 192, 3, 3, pad=2, dil=2, seed=264, flags=("igemm8=2",))),
+          ("igemm8/f32out_res", conv_nhwc_case(30, 14, 14, 512, 256, 1, 1, res=True, out="fp32", seed=265, flags=("igemm8=2",))),
+          ("igemm8/bf16_res_relu", conv_nhwc_case(40, 14, 14, 256, 256, 3, 3, pad=1, act=1, res=True, seed=266, flags=("igemm8=2",))),
+          ("igemm8/gelu_tail", conv_nhwc_case(3, 41, 43, 768, 512, 1, 1, act=2, seed=267, flags=("igemm8=2",))),
+          ("igemm8/k64_one_tile", conv_nhwc_case(4, 20, 20, 64, 96, 1, 1, act=1, seed=268, flags=("igemm8=2",))),
+          ("igemm8/k128_two_tiles", conv_nhwc_case(4, 20, 20, 128, 256, 1, 1, seed=269, flags=("igemm8=2",))),
+          ("igemm8/k192_three_tiles", conv_nhwc_case(4, 20, 20, 192, 264, 1, 1, seed=270, flags=("igemm8=2",))),
+          ("igemm8/5x5", conv_nhwc_case(6, 27, 27, 64, 192, 5, 5, pad=2, act=1, scale=False, seed=271, flags=("igemm8=2",))),
+          ("igemm8/3x3_7x7_512", conv_nhwc_case(11, 7, 7, 512, 512, 3, 3, pad=1, act=1, seed=272, flags=("igemm8=2",))),
+          ("igemm8/1x1_s2_256_512", conv_nhwc_case(5, 56, 56, 256, 512, 1, 1, stride=2, seed=273, flags=("igemm8=2",))),
+          ("igemm8/linear_vit_fc2_f32res", linear_case(197 * 24, 3072, 768, res=True, out="fp32", seed=274, flags=("igemm8=2",))),
+          ("igemm8/dual_layer2_entry_s2", dual_case(8, 28, 28, 128, 256, 512, 2, seed=275, flags=("igemm8=2",))),
+          ("igemm8/dual_layer4_entry_ragged", dual_case(86, 7, 7, 512, 1024, 2048, 2, seed=276, flags=("igemm8=2",))),
+          ("igemm8/dual_s1_64_64_K200_noact", dual_case(3, 37, 41, 64, 64, 200, 1, act=0, seed=277, flags=("igemm8=2",))),
+          ("igemm8/qkv_heads_vit_base", qkv_heads_case(32, 197, 12, 64, seed=278, flags=("igemm8=2",))),
+          ("igemm8s/128x256_1x1_512_256", conv_nhwc_case(8, 28, 28, 512, 256, 1, 1, act=1, seed=361, flags=("igemm8=3",))),
+          ("igemm8s/128x256_3x3_128_256", conv_nhwc_case(8, 28, 28, 128, 256, 3, 3, pad=1, act=1, seed=362, flags=("igemm8=3",))),
+          ("igemm8s/128x256_3x3_s2_K320", conv_nhwc_case(9, 33, 35, 128, 320, 3, 3, stride=2, pad=1, seed=363, flags=("igemm8=3",))),
+          ("igemm8s/128x256_dil2_oddM", conv_nhwc_case(3, 37, 41, 64, 192, 3, 3, pad=2, dil=2, seed=364, flags=("igemm8=3",))),
+          ("igemm8s/128x256_f32out_res", conv_nhwc_case(30, 14, 14, 512, 256, 1, 1, res=True, out="fp32", seed=365, flags=("igemm8=3",))),
+          ("igemm8s/128x256_k64_one_tile", conv_nhwc_case(4, 20, 20, 64, 96, 1, 1, act=1, seed=368, flags=("igemm8=3",))),
+          ("igemm8s/128x256_k128_two", conv_nhwc_case(4, 20, 20, 128, 256, 1, 1, seed=369, flags=("igemm8=3",))),
+          ("igemm8s/128x256_k256_four", conv_nhwc_case(4, 20, 20, 256, 264, 1, 1, seed=370, flags=("igemm8=3",))),
+          ("igemm8s/128x256_3x3_7x7_512", conv_nhwc_case(11, 7, 7, 512, 512, 3, 3, pad=1, act=1, res=True, seed=372, flags=("igemm8=3",))),
+          ("igemm8s/128x256_gelu_tail", conv_nhwc_case(3, 41, 43, 768, 512, 1, 1, act=2, seed=367, flags=("igemm8=3",))),
+          ("igemm8s/128x256_dual_layer4", dual_case(86, 7, 7, 512, 1024, 2048, 2, seed=376, flags=("igemm8=3",))),
+          ("igemm8s/128x256_qkv_heads", qkv_heads_case(32, 197, 12, 64, seed=378, flags=("igemm8=3",))),
+          ("igemm8s/256x128_1x1_512_128", conv_nhwc_case(8, 28, 28, 512, 128, 1, 1, act=1, seed=461, flags=("igemm8=4",))),
+          ("igemm8s/256x128_3x3_128_128", conv_nhwc_case(8, 28, 28, 128, 128, 3, 3, pad=1, act=1, seed=462, flags=("igemm8=4",))),
+          ("igemm8s/256x128_3x3_s2_K320", conv_nhwc_case(9, 33, 35, 128, 320, 3, 3, stride=2, pad=1, seed=463, flags=("igemm8=4",))),
+          ("igemm8s/256x128_dil2_oddM_K72", conv_nhwc_case(3, 37, 41, 64, 72, 3, 3, pad=2, dil=2, seed=464, flags=("igemm8=4",))),
+          ("igemm8s/256x128_f32out_res", conv_nhwc_case(30, 14, 14, 512, 128, 1, 1, res=True, out="fp32", seed=465, flags=("igemm8=4",))),
+          ("igemm8s/256x128_k64_one_tile", conv_nhwc_case(4, 20, 20, 64, 96, 1, 1, act=1, seed=468, flags=("igemm8=4",))),
+          ("igemm8s/256x128_k192_three", conv_nhwc_case(4, 20, 20, 192, 264, 1, 1, seed=470, flags=("igemm8=4",))),
+          ("igemm8s/256x128_5x5", conv_nhwc_case(6, 27, 27, 64, 192, 5, 5, pad=2, act=1, scale=False, seed=471, flags=("igemm8=4",))),
+          ("igemm8s/256x128_dual_s1", dual_case(3, 37, 41, 64, 64, 200, 1, act=0, seed=477, flags=("igemm8=4",))),
           ("chain/56x56_B4", chain_case(4 * 56 * 56, seed=1)),
           ("chain/ragged_M", chain_case(8192 + 37, seed=2)),
           ("chain/many_tiles", chain_case(40 * 56 * 56 + 5, seed=3)),

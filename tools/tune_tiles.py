@@ -17,7 +17,7 @@ LANES = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 THRESH = float(os.environ.get("THRESH", "0.004"))
 STEPS = int(os.environ.get("STEPS", "30"))
 NAMES = {1: "igemm2 256x64", 2: "igemm2 256x128", 3: "igemm2 256x256", 4: "igemm3 256x256", 5: "igemm4 256x128",
-         6: "igemm4 256x256", 7: "igemm 128x128", 8: "igemm 128x64", 9: "stream1x1"}
+         6: "igemm4 256x256", 7: "igemm 128x128", 8: "igemm 128x64", 9: "stream1x1", 10: "igemm8 256x256"}
 
 eqv.set_compute_dtype("bf16")
 net = build_model(model)
@@ -64,6 +64,9 @@ def shapes_of(f):
         elif name == "mv_linear_heads_fwd":
             M, N_, K_ = args[5:8]
             key = ("ovh", M, N_, K_, 1, 1, 1)
+        elif name == "mv_conv1x1_dual_fwd":
+            N, Ho, Wo, C1, H2, W2, C2, s2, K_ = args[6:15]
+            key = ("ovd", N * Ho * Wo, C1, C2, K_, s2, 1)
         else:
             continue
         e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
@@ -97,7 +100,12 @@ chosen = {}
 for key in order:
     kern, us, n = tunable[key]
     dense = key[0] == "ovh" or (key[4] == 1 and key[5] == 1 and key[6] == 1)
-    cands = [2, 3, 4, 5, 6] if key[0] == "ovh" else ([2, 3, 4, 5, 6, 7, 8, 9] if dense else [1, 2, 3, 4, 5, 6, 7, 8])
+    if key[0] == "ovd":
+        cands = [3, 10]
+    elif os.environ.get("CANDS"):
+        cands = [int(c) for c in os.environ["CANDS"].split(",")]
+    else:
+        cands = [2, 3, 4, 10] if key[0] == "ovh" else ([2, 3, 4, 7, 9, 10] if dense else [1, 2, 3, 4, 7, 10])
     cur = timeit(make())                      # the configuration so far, re-measured next to its challengers
     best_c, best_t = 0, cur
     log = []
