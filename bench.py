@@ -3,7 +3,9 @@
 resnet50 bf16 forward, batch 256 per MI355X; `--model vit_base` = configs[2]).
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched through
-`torch.distributed.run` (one rank per GPU, RCCL).  A step = one forward of the per-GPU batch through the
+`torch.distributed.run` (one rank per GPU, RCCL) -- or spawns those ranks itself when WORLD_SIZE is unset.
+At 1 GPU the same invocation also times vit_base (B=256, the other half of the headline metric) and swin_t (B=128)
+and reports them under "extra".  A step = one forward of the per-GPU batch through the
 HIP path (hipGraph replay of the recorded launch list) + the all-gather of the fp32 logits; images are
 already resident in HBM.  W untimed warm-up steps, then exactly K timed steps bracketed by
 barrier + synchronize; MAX over ranks; rank 0 prints ONE JSON line.
@@ -163,58 +165,43 @@ def cpu_baseline(model_name, net, threads):
                       f"best of {reps} after 1 warm-up ({time.time() - t_all:.1f}s of CPU work)"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--model", default="resnet50")
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
-    ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--layers", default=None, help="write a per-launch worksheet to this file")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--lanes", type=int, default=2,
-                    help="sub-batches captured as parallel hipGraph branches (fills the last, partial round of CUs of "
-                         "one kernel with the other lane's next kernel); 1 = a single launch list")
-    a = ap.parse_args()
-
+def run_model(a, name, B, rank, world, soak_s):
+    """Build `name`, trace + capture its forward, (soak), W warm-up steps, K timed steps -> result dict (rank 0) + net."""
     import eqxvision_amd as eqv
     from eqxvision_amd import _lib, dist as D
     from eqxvision_amd._act import stream_ptr
-    import torch.distributed as td
 
-    rank, world, local = D.init_from_env()
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
-    eqv.set_compute_dtype(a.dtype)
-    net = build_model(a.model)
-    B = a.batch
+    net = build_model(name)
     # synthetic images, generated once, resident in HBM (fp32 NCHW like the reference's inputs)
     g = torch.Generator(device="cpu").manual_seed(rank)
     images = torch.rand((B, 3, 224, 224), generator=g, dtype=torch.float32).cuda()
     keys = eqv.random.split(eqv.random.PRNGKey(0), B)
-
     fwd = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k),
                          use_graph=not a.no_graph, clone_outputs=False, lanes=a.lanes)
+    gathered = torch.empty((B * world, 1000), dtype=torch.float32, device="cuda") if world > 1 else None
 
     def step():
         logits = fwd(net, images, keys)
-        if world > 1:
-            logits = D.all_gather_rows(logits, B * world)
+        if world > 1:                        # ONE all-gather of the fp32 logits on the launch stream (mv_allgather / RCCL)
+            logits = D.all_gather_rows(logits, B * world, out=gathered)
         return logits
 
     for _ in range(3):                       # "compile": call 1 records, call 2 captures the hipGraph, call 3 = first replay
         out = step()
+    torch.cuda.synchronize()
+    if soak_s > 0:                           # untimed: bring clocks / thermals to the sustained state (and make the GPU
+        t_end = time.perf_counter() + soak_s  # phase of this short benchmark visible to coarse utilisation samplers)
+        while time.perf_counter() < t_end:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
     for _ in range(a.warmup):                # the W untimed warm-up steps proper (graph replays)
         out = step()
     torch.cuda.synchronize()
     assert out.shape == (B * world, 1000) and bool(torch.isfinite(out).all())
 
     e0, e1 = _ev(), _ev()
-    if world > 1:
-        td.barrier()
+    D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     _lib.call("mv_event_record", e0, stream_ptr())
@@ -222,71 +209,147 @@ def main():
         step()
     _lib.call("mv_event_record", e1, stream_ptr())
     torch.cuda.synchronize()
-    if world > 1:
-        td.barrier()
+    D.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms = ctypes.c_float()
     _lib.call("mv_event_elapsed_ms", e0, e1, ctypes.byref(ms))
     dev_ms_per_step = ms.value / a.steps
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        dt = float(tt.item())
-
+    dt = D.max_over_ranks(dt)
     compiled = fwd._entries()[0]
-    rows = layer_table(compiled, a.layers) if rank == 0 else []
+    rows = layer_table(compiled, a.layers if name == a.model else None) if rank == 0 else []
+    if rank != 0:
+        return None, net
+    flop_per_launch = GFLOP_PER_IMG[name] * 1e9 * B
+    achieved = flop_per_launch / (dev_ms_per_step * 1e-3) / 1e12
+    # dominant kernel = the kernel family with the largest summed duration in one forward.  `achieved` = its algorithmic
+    # FLOPs / its duration in the per-launch replay of the recorded launch list (every launch alone on the chip, HIP events
+    # on the launch stream).  Inside the graph two lanes overlap, so rocprofv3's in-situ AverageNs of the same kernel is
+    # longer: `rocprof` carries that figure from the committed profile of this command (profiles/).
+    fam = {}
+    for r_ in rows:
+        k = r_["kernel"].replace("_dense", "").replace("_conv", "")
+        d = fam.setdefault(k, {"us": 0.0, "gflop": 0.0, "mb": 0.0, "n": 0})
+        d["us"] += r_["us"]; d["gflop"] += r_["gflop"]; d["mb"] += r_["mb"]; d["n"] += 1
+    gemm = {k: v for k, v in fam.items() if v["gflop"] > 0}
+    dk, dv = max((gemm or fam or {"n/a": {"us": 1, "gflop": 0, "mb": 0, "n": 1}}).items(), key=lambda kv: kv[1]["us"])
+    dom_tflops = dv["gflop"] / dv["us"] * 1e3 if dv["us"] else 0.0   # GFLOP/us = PFLOP/s
+    traffic = ref = None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per launch + rocprof averages, if collected
+    if os.path.exists(tj) and world == 1:
+        try:
+            tjd = json.load(open(tj))
+            if tjd.get("_batch", {}).get(name) == B:
+                traffic = tjd.get(name, {}).get(dk)
+                ref = tjd.get("_rocprof", {}).get(name, {}).get(dk)
+        except Exception:  # noqa: BLE001
+            traffic = ref = None
+    roof = {"bound": "mfma", "achieved": round(dom_tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(dom_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "kernel": dk, "launches_per_step": dv["n"],
+            "avg_launch_us": round(dv["us"] / max(1, dv["n"]), 2),
+            "share_of_step": round(dv["us"] / max(1e-9, sum(r_["us"] for r_ in rows)), 3),
+            "flop_per_launch": round(dv["gflop"] * 1e9 / max(1, dv["n"])),
+            "kernel_hbm_gbs": round(dv["mb"] / dv["us"] * 1e3, 1) if dv["us"] else 0.0,
+            "whole_forward": {"achieved": round(achieved, 1), "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                              "graph_launch_ms": round(dev_ms_per_step, 4), "flop_per_launch": flop_per_launch,
+                              "hbm_layerwise_bound_frac": 0.418 if name == "resnet50" else None}}
+    if ref:                                   # {"avg_launch_us": in-situ rocprofv3 average, "file": ...}
+        roof["rocprof"] = dict(ref, frac=round(dv["gflop"] / max(1, dv["n"]) / ref["avg_launch_us"] * 1e3 / MFMA_PEAK_TFLOPS, 4))
+    res = {"value": round(B * world * a.steps / dt, 1), "ms_per_step": round(1e3 * dt / a.steps, 4),
+           "config": {"workload": f"{name} {a.dtype} forward, batch={B}/GPU, 3x224x224, 1000 classes",
+                      "global_batch": B * world, "parallelism": f"dp{world}", "launches_per_step": len(compiled.calls),
+                      "graph": compiled.graph is not None,
+                      "lanes": len(compiled.lane_calls) if compiled.lane_calls else 1,
+                      "collective": ("mv_allgather (RCCL)" if D._state["native"] else "torch.distributed") if world > 1 else None},
+           "roofline": roof}
+    return res, net
 
-    if rank == 0:
-        ms_per_step = 1e3 * dt / a.steps
-        value = B * world * a.steps / dt
-        flop_per_launch = GFLOP_PER_IMG[a.model] * 1e9 * B
-        achieved = flop_per_launch / (dev_ms_per_step * 1e-3) / 1e12
-        # dominant kernel = the kernel family with the largest summed duration in one forward (per-launch
-        # replay of the recorded launch list, HIP events on the launch stream); its achieved rate is its
-        # algorithmic FLOPs / its time, its avg launch is what rocprofv3 --stats reports as AverageNs
-        fam = {}
-        for r_ in rows:
-            k = r_["kernel"].replace("_dense", "").replace("_conv", "")
-            d = fam.setdefault(k, {"us": 0.0, "gflop": 0.0, "mb": 0.0, "n": 0})
-            d["us"] += r_["us"]; d["gflop"] += r_["gflop"]; d["mb"] += r_["mb"]; d["n"] += 1
-        dom = max(fam.items(), key=lambda kv: kv[1]["us"]) if fam else ("n/a", {"us": 1, "gflop": 0, "mb": 0, "n": 1})
-        dk, dv = dom
-        dom_tflops = dv["gflop"] / dv["us"] * 1e3 if dv["us"] else 0.0   # GFLOP/us = PFLOP/s
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per launch, if collected
-        if os.path.exists(tj) and a.batch == 256 and world == 1:      # the counters were collected on the B=256, 1-GPU workload
+
+def respawn(a):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", default="resnet50")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 256; 128 for swin_t)")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--layers", default=None, help="write a per-launch worksheet of --model to this file")
+    ap.add_argument("--extra", default=None,
+                    help="comma list of further models timed in the same invocation and reported under \"extra\" "
+                         "(default at 1 GPU for the headline model: vit_base,swin_t; 'none' = only --model)")
+    ap.add_argument("--soak", type=float, default=None, help="seconds of untimed graph replays before the warm-up steps "
+                                                             "(default 5 at 1 GPU, 2 otherwise)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="sub-batches captured as parallel hipGraph branches (fills the last, partial round of CUs of "
+                         "one kernel with the other lane's next kernel); 1 = a single launch list")
+    a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn(a))
+
+    import eqxvision_amd as eqv
+    from eqxvision_amd import dist as D
+
+    rank, world, local = D.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but {world} rank(s) joined (WORLD_SIZE={os.environ.get('WORLD_SIZE')}): "
+                         "launch through torch.distributed.run or let bench.py spawn the ranks itself")
+    if world > 1 and D._state["native"] and eqv._lib.load().mv_comm_size() != world:
+        raise SystemExit(f"RCCL communicator has {eqv._lib.load().mv_comm_size()} ranks, expected {world}")
+    torch.cuda.set_device(local)
+    eqv.set_compute_dtype(a.dtype)
+    default_batch = {"swin_t": 128}
+    extras = []
+    if world == 1 and a.extra != "none":
+        extras = [m for m in (a.extra.split(",") if a.extra else (["vit_base", "swin_t"] if a.model == "resnet50" else [])) if m]
+    soak = a.soak if a.soak is not None else (5.0 if world == 1 else 2.0)
+
+    # CPU baseline FIRST (rank 0, 1 GPU only), so that the GPU phase is the tail of the run
+    cpu = {}
+    if world == 1 and not a.no_cpu:
+        for m in [a.model] + [e for e in extras if e in ("vit_base",)]:
             try:
-                traffic = json.load(open(tj)).get(a.model, {}).get(dk)
-            except Exception:  # noqa: BLE001
-                traffic = None
-        line = {
-            "metric": "images/sec", "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"{a.model} {a.dtype} forward, batch={B}/GPU, 3x224x224, 1000 classes",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "launches_per_step": len(compiled.calls),
-                       "graph": compiled.graph is not None,
-                       "lanes": len(compiled.lane_calls) if compiled.lane_calls else 1},
-            "roofline": {"bound": "mfma", "achieved": round(dom_tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(dom_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "kernel": dk, "launches_per_step": dv["n"],
-                         "avg_launch_us": round(dv["us"] / max(1, dv["n"]), 2),
-                         "share_of_step": round(dv["us"] / max(1e-9, sum(r_["us"] for r_ in rows)), 3),
-                         "flop_per_launch": round(dv["gflop"] * 1e9 / max(1, dv["n"])),
-                         "kernel_hbm_gbs": round(dv["mb"] / dv["us"] * 1e3, 1) if dv["us"] else 0.0,
-                         "whole_forward": {"achieved": round(achieved, 1), "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                                           "graph_launch_ms": round(dev_ms_per_step, 4),
-                                           "flop_per_launch": flop_per_launch,
-                                           "hbm_layerwise_bound_frac": 0.418 if a.model == "resnet50" else None}},
-        }
-        if world == 1 and not a.no_cpu:
-            try:
-                line["cpu_baseline"] = cpu_baseline(a.model, net, torch.get_num_threads())
+                cpu[m] = cpu_baseline(m, build_model(m), torch.get_num_threads())
             except Exception as e:  # noqa: BLE001
-                line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+                cpu[m] = {"error": f"{type(e).__name__}: {e}"}
+
+    res, _ = run_model(a, a.model, a.batch or default_batch.get(a.model, 256), rank, world, soak)
+    extra_out = {}
+    for m in extras:
+        try:
+            r, _ = run_model(a, m, default_batch.get(m, 256), rank, world, min(soak, 3.0))
+            if m in cpu:
+                r["cpu_baseline"] = cpu[m]
+            extra_out[m] = r
+        except Exception as e:  # noqa: BLE001
+            extra_out[m] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        line = {"metric": "images/sec", "value": res["value"], "unit": "images/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic", "config": res["config"], "roofline": res["roofline"]}
+        if a.model in cpu:
+            line["cpu_baseline"] = cpu[a.model]
+        if extra_out:
+            line["extra"] = extra_out
         print(json.dumps(line), flush=True)
     if world > 1:
+        import torch.distributed as td
+        D.native_comm_destroy()
         td.destroy_process_group()
 
 

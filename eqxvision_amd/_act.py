@@ -23,7 +23,10 @@ import torch
 
 from . import _lib
 
-_state = {"dtype": "bf16", "keep": None, "residual_fp32": True}
+import threading
+
+_state = {"dtype": "bf16", "residual_fp32": True}      # process-wide numerics configuration
+_tls = threading.local()                                  # .keep: the allocation pin list of THIS thread's trace
 
 DT = {"bf16": _lib.BF16, "fp32": _lib.F32}
 TORCH_DT = {"bf16": torch.bfloat16, "fp32": torch.float32}
@@ -74,7 +77,7 @@ def stream_ptr() -> int:
 
 def empty(shape, dtype: torch.dtype) -> torch.Tensor:
     t = torch.empty(tuple(shape), dtype=dtype, device=device())
-    k = _state["keep"]
+    k = getattr(_tls, "keep", None)
     if k is not None:          # a recording owns every intermediate so replayed pointers stay valid
         k.append(t)
     return t
@@ -82,12 +85,12 @@ def empty(shape, dtype: torch.dtype) -> torch.Tensor:
 
 @contextlib.contextmanager
 def keep_alive(lst):
-    old = _state["keep"]
-    _state["keep"] = lst
+    old = getattr(_tls, "keep", None)
+    _tls.keep = lst
     try:
         yield
     finally:
-        _state["keep"] = old
+        _tls.keep = old
 
 
 class Act:

@@ -26,6 +26,13 @@ PROTOTYPES = {
     "mv_last_kernel": [],
     "mv_set_flag": [C.c_char_p, _i],
     "mv_get_flag": [C.c_char_p],
+    "mv_flags_epoch": [],
+    "mv_comm_unique_id": [_vp, C.c_size_t],
+    "mv_comm_init": [_i, _i, _vp],
+    "mv_comm_size": [],
+    "mv_comm_rank": [],
+    "mv_allgather": [_vp, _vp, C.c_size_t, _vp],
+    "mv_comm_destroy": [],
     "mv_conv2d_nhwc_fwd": [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 14 + [_i, _i, _i, _vp],
     "mv_conv2d_nchw_fwd": [_vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_i, _i, _i, _i, _i, _vp, _vp],
     "mv_linear_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
@@ -99,14 +106,14 @@ def load():
 
 # When a forward is being recorded by `eqxvision_amd.filter_jit`, every kernel-enqueueing call is
 # appended here as (bound C function, argument tuple) so it can be replayed / graph-captured.
-_recording = None
-_NOT_RECORDED = ("mv_set_flag", "mv_graph_", "mv_event_")
+_tls = threading.local()        # .rec: the launch list being recorded on THIS thread (one trace per thread at a time)
+_NOT_RECORDED = ("mv_set_flag", "mv_graph_", "mv_event_", "mv_comm_")
+COMM_ID_BYTES = 128
 
 
 def set_recording(rec):
-    global _recording
-    old = _recording
-    _recording = rec
+    old = getattr(_tls, "rec", None)
+    _tls.rec = rec
     return old
 
 
@@ -117,8 +124,9 @@ def call(name, *args):
     if rc != 0:
         msg = lib.mv_last_error()
         raise MVError(f"{name} failed (rc={rc}): {msg.decode() if msg else ''}")
-    if _recording is not None and not name.startswith(_NOT_RECORDED):
-        _recording.append((fn, args, name))
+    rec = getattr(_tls, "rec", None)
+    if rec is not None and not name.startswith(_NOT_RECORDED):
+        rec.append((fn, args, name))
     return rc
 
 

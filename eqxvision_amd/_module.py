@@ -112,7 +112,7 @@ def _rebuild(n: "Module", rec: Callable, override: Callable = None) -> "Module":
             v = d[k]
             object.__setattr__(new, k, override(k, v) if override is not None else rec(v))
     for k, v in d.items():
-        if k not in n.__fields__ and k != "_dev_cache":
+        if k not in n.__fields__ and k not in ("_dev_cache", "_sig_cache"):
             object.__setattr__(new, k, v)
     return new
 

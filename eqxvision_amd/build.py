@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             list(ex.map(cc, jobs))
     objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
     if jobs or not os.path.exists(LIB):
-        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB],
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")

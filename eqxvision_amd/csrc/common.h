@@ -104,8 +104,6 @@ int stream1x1_launch(const void* x, const void* w, const float* scale, const flo
                      void* y, long long M, int C, int K, int act, int out_dtype, hipStream_t stream);
 int conv3x3c64_supported(int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int in_dtype,
                          int out_dtype, const void* residual, long long M);
-int conv3x3c64_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H,
-                      int W, int act, hipStream_t stream);
 int igemm2_wanted(long long M, int C, int K, int R, int S);
 int igemm2_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                   void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
@@ -122,10 +120,6 @@ int chain1x1_dual_launch(const void* x, const void* x2, const void* wcat, const 
                          const void* w1, const float* scale1, const float* shift1, void* t1, long long M, hipStream_t st);
 int chain1x1_launch(const void* x, const void* w3, const float* scale3, const float* shift3, const void* residual, void* y,
                     const void* w1, const float* scale1, const float* shift1, void* t1, long long M, int N2, hipStream_t st);
-int igemm4_wanted(long long M, int C, int K, int R, int S);
-int igemm4_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
-                  void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh,
-                  int dw, int act, int out_dtype, int tok, int tile, hipStream_t st);
 int igemm8_supported(long long M, int C, int K, int R, int S, long long x_bytes, long long w_bytes);
 int igemm8_wanted(long long M, int C, int K, int R, int S);
 int igemm8_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y,
@@ -134,10 +128,6 @@ int igemm8_launch(const void* x, const void* w, const float* scale, const float*
 int igemm8_dual_launch(const void* x, const void* x2, const void* w, const float* scale, const float* shift,
                        const void* residual, void* y, int N, int Ho, int Wo, int C1, int H2, int W2, int C2, int s2, int K,
                        int act, int out_dtype, int tile, hipStream_t st);
-int igemm3_wanted(long long M, int C, int K, int R, int S);
-int igemm3_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
-                  void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
-                  int dh, int dw, int act, int out_dtype, int tok, hipStream_t stream);
 int stem_supported(int C, int K, int R, int S, int x_dtype, int out_dtype);
 int stem_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
                 int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act, int x_dtype,

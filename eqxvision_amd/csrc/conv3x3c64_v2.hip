@@ -208,6 +208,12 @@ __global__ __launch_bounds__(512) void conv3x3c64_v2_kernel(const C3V2P p) {
     }
 }
 
+int conv3x3c64_supported(int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int in_dtype,
+                         int out_dtype, const void* residual, long long M) {
+    return C == 64 && K == 64 && R == 3 && S == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 &&
+           in_dtype == MV_BF16 && out_dtype == MV_BF16 && residual == nullptr && M >= 8192;
+}
+
 int conv3x3c64_v2_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H, int W,
                          int act, hipStream_t st) {
     C3V2P p;

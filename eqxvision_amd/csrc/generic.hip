@@ -950,7 +950,7 @@ int mv_linear_heads_fwd(const void* x, const void* w, const float* scale, const 
                   (long long)M, N, K, tokens, dh);
         return MV_E_UNSUPPORTED;
     }
-    const int ov8 = (!get_flag("igemm2_tile") && !get_flag("igemm3") && !get_flag("igemm4")) ? tile_override("ovh", M, N, K, 1, 1, 1) : -1;
+    const int ov8 = !get_flag("igemm2_tile") ? tile_override("ovh", M, N, K, 1, 1, 1) : -1;
     {
         int t8 = 0;
         if (get_flag("igemm8") >= 2) t8 = get_flag("igemm8") - 1;
@@ -960,26 +960,13 @@ int mv_linear_heads_fwd(const void* x, const void* w, const float* scale, const 
             return igemm8_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE, MV_BF16, tokens,
                                  t8, (hipStream_t)stream);
     }
-    const int ov = (!get_flag("igemm2_tile") && !get_flag("igemm3") && !get_flag("igemm4")) ? tile_override("ovh", M, N, K, 1, 1, 1) : 0;
-    if ((ov == 2 || ov == 3) ) {
-        igemm2_force_tile(ov);
+    if (ov8 == 2 || ov8 == 3) {
+        igemm2_force_tile(ov8);
         const int rc = igemm2_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE,
                                      MV_BF16, 0, tokens, (hipStream_t)stream);
         igemm2_force_tile(0);
         return rc;
     }
-    if (ov == 4 && igemm3_wanted(M, K, N, 1, 1))
-        return igemm3_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE, MV_BF16,
-                             tokens, (hipStream_t)stream);
-    if ((ov == 5 || ov == 6) && igemm4_wanted(M, K, N, 1, 1))
-        return igemm4_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE, MV_BF16,
-                             tokens, ov == 6 ? 3 : 2, (hipStream_t)stream);
-    if (get_flag("igemm4") >= 1 && igemm4_wanted(M, K, N, 1, 1))
-        return igemm4_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE, MV_BF16,
-                             tokens, get_flag("igemm4") == 2 ? 3 : 2, (hipStream_t)stream);
-    if (get_flag("igemm3") >= 1 && igemm3_wanted(M, K, N, 1, 1))   // (qkv: N = 2304 uses igemm2's 256x256 tile by default)
-        return igemm3_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE, MV_BF16,
-                             tokens, (hipStream_t)stream);
     return igemm2_launch(x, w, scale, shift, nullptr, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, MV_ACT_NONE, MV_BF16, 0,
                          tokens, (hipStream_t)stream);
 }

@@ -295,7 +295,7 @@ static int launch_tile(IgemmP& p, bool dense, bool out_f32, hipStream_t st) {
 // Per-shape kernel choice: "ov:<M>:<C>:<K>:<R>:<S>:<stride>" flags (tools/tune_tiles.py sets them while it searches:
 // greedy, one shape at a time, judged on whole-model ms/step in one process) and the short table of shapes where the
 // search beat the rules below by more than its 0.4% threshold.  Choices: 1/2/3 = igemm2 256x64 / 256x128 / 256x256,
-// 4 = igemm3, 5 / 6 = igemm4 256x128 / 256x256, 7 / 8 = 128x128 / 128x64 (this file), 9 = stream1x1, 10 / 11 / 12 = igemm8 256x256 / 128x256 / 256x128;
+// 7 / 8 = 128x128 / 128x64 (this file), 9 = stream1x1, 10 / 11 / 12 = igemm8 256x256 / 128x256 / 256x128;
 // 0 = the rules.  Kinds: "ov" conv / linear, "ovh" head-major qkv projection, "ovd" dual-source pointwise (3 = igemm2, 10 = igemm8).
 // Round 1 (profiles/r01/*_tile_search.txt): resnet50 B=256 and swin_t B=128 -- nothing above the drift (+0.4% / -0.4%
 // in total), rules kept; vit_base B=256, two lanes -- three shapes, +3.5% together:
@@ -340,16 +340,15 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
     p.act = act;
     const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
     const bool out_f32 = out_dtype == MV_F32;
-    if (dense && !get_flag("no_skinny") && !get_flag("igemm_tile") && !get_flag("igemm2_tile") && get_flag("igemm3") != 2 &&
-        get_flag("igemm4") < 2 &&
+    const bool forced_old = get_flag("igemm_tile") || get_flag("igemm2_tile") || get_flag("no_igemm2") || get_flag("igemm2_dense_m");
+    if (dense && !get_flag("no_skinny") && !forced_old && get_flag("igemm8") < 2 &&
         skinny_supported(M, C, K, in_dtype, residual))                   // classifier heads: one wave per 32 x 32 tile
         return skinny_launch(x, w, scale, shift, y, M, C, K, act, out_dtype, st);
-    if (get_flag("igemm8") >= 2 && igemm8_supported(M, C, K, R, S, 2LL * N * H * W * C, 2LL * K * R * S * C))      // forced (tests)
+    const bool ok8 = igemm8_supported(M, C, K, R, S, 2LL * N * H * W * C, 2LL * K * R * S * C);
+    if (get_flag("igemm8") >= 2 && ok8)                                   // forced (tests): 2 = 256x256, 3 = 128x256, 4 = 256x128
         return igemm8_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
-                             get_flag("igemm8") - 1, st);                  // 2 = 256x256, 3 = 128x256, 4 = 256x128
-    const bool plain = !get_flag("igemm_tile") && !get_flag("igemm2_tile") && !get_flag("igemm3") && !get_flag("igemm4") &&
-                       !get_flag("no_igemm2") && !get_flag("no_igemm3") && !get_flag("no_stream") && !get_flag("tail_split") &&
-                       !get_flag("igemm2_dense_m");
+                             get_flag("igemm8") - 1, st);
+    const bool plain = !forced_old && !get_flag("no_stream");
     const int ov = plain && sh == sw ? tile_override("ov", M, C, K, R, S, sh) : 0;
     if (ov >= 1 && ov <= 3 && C % 64 == 0 && (long long)R * S * (C / 64) >= 1 && R * S <= 64) {
         igemm2_force_tile(ov);
@@ -358,13 +357,7 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
         igemm2_force_tile(0);
         return rc;
     }
-    if (ov == 4 && igemm3_wanted(M, C, K, R, S))
-        return igemm3_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
-                             st);
-    if ((ov == 5 || ov == 6) && igemm4_wanted(M, C, K, R, S))
-        return igemm4_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
-                             ov == 6 ? 3 : 2, st);
-    if (ov >= 10 && ov <= 12 && igemm8_supported(M, C, K, R, S, 2LL * N * H * W * C, 2LL * K * R * S * C))
+    if (ov >= 10 && ov <= 12 && ok8)
         return igemm8_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
                              ov - 9, st);
     if (ov == 9 && dense && stream1x1_supported(C, K, in_dtype, out_dtype, M))
@@ -378,76 +371,24 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
         set_kernel_name(dense ? "igemm_bf16_128x128_dense" : "igemm_bf16_128x128_conv");
         return launch_tile<128, 128, 4, 1>(p, dense, out_f32, st);
     }
-    if (get_flag("igemm4") >= 2 && igemm4_wanted(M, C, K, R, S))          // forced (tests): 2 = 256x256, 3 = 256x128
-        return igemm4_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
-                             get_flag("igemm4") == 2 ? 3 : 2, st);
-    if (get_flag("igemm3") == 2 && igemm3_wanted(M, C, K, R, S))          // forced (tests)
-        return igemm3_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
-                             st);
     if (!get_flag("no_stream") && !get_flag("igemm_tile") && !get_flag("igemm2_tile") &&
         conv3x3c64_supported(C, K, R, S, sh, sw, ph, pw, dh, dw, in_dtype, out_dtype, residual, M))
-        return get_flag("c3x3_v1") ? conv3x3c64_launch(x, w, scale, shift, y, N, H, W, act, st)
-                                   : conv3x3c64_v2_launch(x, w, scale, shift, y, N, H, W, act, st);
+        return conv3x3c64_v2_launch(x, w, scale, shift, y, N, H, W, act, st);
     if (dense && !get_flag("no_stream") && !get_flag("igemm_tile") && stream1x1_supported(C, K, in_dtype, out_dtype, M))
         return stream1x1_launch(x, w, scale, shift, residual, y, M, C, K, act, out_dtype, st);
-    // Ping-pong 256 x 256 kernel (igemm8.hip): ~1.35x igemm2's rate per tile, so it takes every layer with enough 256 x 256
-    // tiles to fill most of a round of CUs, >= 192 output channels (a 128-channel layer would waste half of every tile) and
-    // a reduction long enough (>= 8 k-tiles) to amortise the bigger tile's prologue / epilogue (tools/g8_bench.py, round 2).
-    const int t8 = igemm8_wanted(M, C, K, R, S);
-    if (t8 && !get_flag("igemm_tile") && !get_flag("igemm2_tile") && !get_flag("igemm3") &&
-        !get_flag("igemm4") && !get_flag("no_igemm2") && !get_flag("tail_split") && !get_flag("igemm2_dense_m") &&
-        igemm8_supported(M, C, K, R, S, 2LL * N * H * W * C, 2LL * K * R * S * C))
+    // The ping-pong kernels (igemm8.hip) are THE GEMM core: every layer its rule accepts (enough tiles of one of its three
+    // shapes, a reduction of >= 4 k-tiles).  What is left below -- igemm2's 256-row tiles for short reductions, this file's
+    // 128 x 128 tile for small / odd shapes -- is the long tail.
+    const int t8 = forced_old ? 0 : igemm8_wanted(M, C, K, R, S);
+    if (t8 && ok8)
         return igemm8_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0, t8,
                              st);
-    // deep-pipelined 8-wave kernel: every real convolution (taps or stride) and the big Linears; the
-    // short dense 1x1 layers with a short reduction measured the same or faster on the 128^2 kernel
-    // (measured, tools/swin_sweep.py: with an fp32 residual epilogue the 256-row kernel wins from M = 6272 up)
-    // (measured with two graph lanes, i.e. half-batch launches: from M = 4096 up the deep pipeline also wins on dense
-    //  layers with a long reduction -- ResNet 7x7 / 14x14 1x1s, ViT fc1 at M = 25216 -- but not at C = 384, Swin stage 2)
+    // deep-pipelined 8-wave kernel (igemm2.hip): real convolutions (taps or stride) and big Linears the rule above passed on
     const long long dense_m = get_flag("igemm2_dense_m") ? get_flag("igemm2_dense_m") : (C >= 512 ? 4096 : 32768);
     const bool want2 = igemm2_wanted(M, C, K, R, S) && (!dense || M >= dense_m || out_f32 || get_flag("igemm2_tile"));
-    // Phase-alternating 256x256 kernel (igemm3.hip) instead of igemm2's 256x128 tile when it saves rounds of CUs.
-    // Measured on ResNet-50 / ViT-B / Swin-T (profiles/r01): per unit of tile area igemm3 runs ~1.09x faster than
-    // igemm2 256x128, so it wins when 2 * rounds(256x256 tiles) / 1.09 < rounds(256x128 tiles) -- the layers where
-    // halving the tile count removes a mostly empty last round (14x14 3x3: 392 -> 196 tiles, 81 -> 75 us; strided
-    // 1x1 56x56x256 -> 28x28x512: 135 -> 122 us) -- and loses otherwise (ViT fc2 / proj: 3 rounds of 256x256 vs 5 of
-    // 256x128).  igemm2's own 256x256 tile (K >= 1024) stays: same tile count, 5% faster main loop there.
-    if (!get_flag("no_igemm3") && !get_flag("igemm_tile") && !get_flag("igemm2_tile") && want2 && C % 32 == 0 &&
-        (long long)R * S * (C / 32) >= 8) {
-        int bm, bn;
-        const int t2 = igemm2_tile_shape(M, K, &bm, &bn);
-        const long long tm = (M + 255) / 256;
-        const long long r2 = (tm * ((K + 127) / 128) + 255) / 256, r3 = (tm * ((K + 255) / 256) + 255) / 256;
-        const bool big = get_flag("igemm3") == 1 || (t2 == 2 && 1.835 * (double)r3 < (double)r2);
-        if (get_flag("igemm4") == 1 && K > 64)           // opt-in (measured: +0.7% ViT-B, -1.2% ResNet-50, 0 Swin-T)
-            return igemm4_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype,
-                                 0, 2, st);
-        if (big)
-            return igemm3_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype,
-                                 0, st);
-    }
-    int m_off = 0;
-    if (!get_flag("no_igemm2") && !get_flag("igemm_tile") && want2) {
-        // Main + tail: 256-row tiles fill whole rounds of the 256 CUs; a last, mostly empty round (e.g. 392
-        // tiles = 1.53 rounds) would cost a full tile time with a third of the chip idle (measured 67% wave
-        // occupancy on the ResNet 3x3 layers).  So the deep-pipelined kernel takes the rows that fill complete
-        // rounds and the 128-row kernel below (two blocks per CU) finishes the remaining rows in one short round.
-        int bm, bn;
-        igemm2_tile_shape(M, K, &bm, &bn);
-        const long long tm = (M + bm - 1) / bm, tn = (K + bn - 1) / bn;
-        const long long blocks = tm * tn, rounds = blocks / 256, rem = blocks - rounds * 256;
-        long long main_mt = tm;
-        // measured on ResNet-50 (profiles/r01): the tail's 128-row blocks need two rounds of their own for the
-        // common 392- and 784-tile layers, so the split LOSES ~8%; kept behind a flag for shapes where it pays
-        if (get_flag("tail_split") && rounds >= 1 && rem > 0 && rem <= 128) main_mt = (rounds * 256) / tn;
-        if (main_mt <= 0) main_mt = tm;
-        const int m_end = main_mt < tm ? (int)(main_mt * bm) : 0;
-        const int rc = igemm2_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act,
-                                     out_dtype, m_end, 0, st);
-        if (rc != MV_OK || m_end == 0) return rc;
-        m_off = m_end;
-    }
-    p.m_off = m_off;
+    if (!get_flag("no_igemm2") && !get_flag("igemm_tile") && want2)
+        return igemm2_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0, 0, st);
+    p.m_off = 0;
     int tile = get_flag("igemm_tile");
     if (tile == 0) tile = (K <= 64) ? 2 : 1;
     if (tile == 2) {

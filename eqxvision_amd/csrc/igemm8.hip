@@ -10,8 +10,8 @@
 //   * a k-tile of 64 is TWO phases, each a LOAD half and an MFMA half separated by raw `s_barrier`s:
 //         phase 1  LOAD: 16 ds_read_b128 (weights 64 x 64, pixels 0..63 x 64)   MFMA: 16 x v_mfma_f32_32x32x16_bf16
 //         phase 2  LOAD:  8 ds_read_b128 (pixels 64..127 x 64)                  MFMA: 16 x ...
-//     so an MFMA half is 512 cycles of back-to-back matrix work (igemm3's phases are 256: twice the barriers per
-//     FLOP); group 1 runs one barrier behind group 0, so on every SIMD one wave is in its MFMA half while its partner
+//     so an MFMA half is 512 cycles of back-to-back matrix work (round 1's ping-pong kernel had 256-cycle phases: twice the
+//     barriers per FLOP); group 1 runs one barrier behind group 0, so on every SIMD one wave is in its MFMA half while its partner
 //     is in its LOAD half;
 //   * LDS holds two k-tiles (2 x 64 KB), each as three DMA units that are re-staged as soon as their last reader is
 //     done, not when the whole tile is: W (256 x 64, read in phase 1), Xtop (the 2 x 64 phase-1 pixel rows) and Xbot
@@ -621,18 +621,18 @@ int igemm8_supported(long long M, int C, int K, int R, int S, long long x_bytes,
 }
 
 // The dispatch rule (igemm.hip, generic.hip).  Returns the tile: 0 = not this kernel family, 1 = 256 x 256,
-// 2 = 128 pixels x 256 channels, 3 = 256 pixels x 128 channels.  Measured (tools/g8_bench.py, round 2): the 256 x 256 kernel
-// wins from ~0.7 of a round of CUs up when the reduction is >= 8 k-tiles; below that the half-size tiles fill the chip.
+// 2 = 128 pixels x 256 channels, 3 = 256 pixels x 128 channels.  Measured (tools/g8_bench.py, round 2, ViT / Swin / ResNet
+// shapes at full and half batch): the 256 x 256 kernel wins from ~0.6 of a round of CUs up; below that the half-size tiles
+// fill the chip; layers with <= 128 output channels take the 256 x 128 tile; reductions shorter than 4 k-tiles stay on the
+// streaming / 128 x 128 kernels (prologue + epilogue of the big tiles dominate).
 int igemm8_wanted(long long M, int C, int K, int R, int S) {
     if (get_flag("no_igemm8")) return 0;
     const long long nk = (long long)R * S * (C / 64);
-    if (nk < 8 || K < 96) return 0;
+    if (nk < 4 || K < 96) return 0;
     const long long tm256 = (M + 255) / 256, tm128 = (M + 127) / 128;
-    if (K <= 128) return tm256 >= 176 ? 3 : 0;
-    const long long t256 = tm256 * ((K + 255) / 256);
-    if (t256 >= 176) return 1;
-    if (get_flag("no_igemm8s")) return 0;
-    return tm128 * ((K + 255) / 256) >= 96 ? 2 : 0;
+    if (K <= 128) return tm256 >= 90 ? 3 : 0;
+    if (tm256 * ((K + 255) / 256) >= 150) return 1;
+    return tm128 * ((K + 255) / 256) >= 40 ? 2 : 0;
 }
 
 static int igemm8_go(Igemm2P& p, bool dual, bool out_f32, int tile, hipStream_t st) {

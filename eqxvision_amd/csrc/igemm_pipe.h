@@ -1,4 +1,4 @@
-// Shared by the deep-pipelined implicit-GEMM kernels (igemm2.hip, igemm3.hip): launch parameters, inline-asm
+// Shared by the deep-pipelined implicit-GEMM kernels (igemm2.hip, igemm8.hip): launch parameters, inline-asm
 // LDS / waitcnt primitives (invisible to hipcc's LDS-DMA alias check) and the residual-row loader.  gfx950 only.
 #pragma once
 #include "mfma_common.h"

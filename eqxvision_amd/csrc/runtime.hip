@@ -13,7 +13,10 @@ namespace mv {
 static thread_local char g_err[512] = "";
 static thread_local char g_kernel[128] = "";
 static std::mutex g_mu;
-static std::map<std::string, int> g_flags;
+// A/B and test switches.  Thread-local like the error text: a thread that flips a switch cannot change what another
+// thread's launches dispatch to, and the hot path takes no lock to read them.
+static thread_local std::map<std::string, int> g_flags;
+static thread_local int g_flags_epoch = 0;
 static std::map<int, void*> g_zero;
 
 void set_error(const char* fmt, ...) {
@@ -27,7 +30,7 @@ void set_kernel_name(const char* name) {
     g_kernel[sizeof(g_kernel) - 1] = 0;
 }
 int get_flag(const char* name) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_flags.empty()) return 0;
     auto it = g_flags.find(name);
     return it == g_flags.end() ? 0 : it->second;
 }
@@ -56,10 +59,12 @@ const char* mv_last_kernel(void) { return mv::g_kernel; }
 
 int mv_set_flag(const char* name, int value) {
     if (!name) return MV_E_INVALID;
-    std::lock_guard<std::mutex> lk(mv::g_mu);
-    mv::g_flags[name] = value;
+    if (value == 0) mv::g_flags.erase(name);
+    else mv::g_flags[name] = value;
+    ++mv::g_flags_epoch;
     return MV_OK;
 }
+int mv_flags_epoch(void) { return mv::g_flags_epoch; }
 int mv_get_flag(const char* name) { return name ? mv::get_flag(name) : 0; }
 
 int mv_graph_begin_capture(mv_stream_t stream) {

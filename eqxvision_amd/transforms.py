@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._act import Act, _to_device_f32, compute_dtype, keep_alive, stream_ptr, wrap
+from ._act import Act, _to_device_f32, compute_dtype, keep_alive, residual_fp32, stream_ptr, wrap
 from ._module import Module
 from .nn import _unwrap
 
@@ -88,6 +88,33 @@ def _is_resident(x) -> bool:
             and x.dtype in (torch.float32, torch.bfloat16))
 
 
+def _module_sig(m: Module):
+    """Structural signature of a Module tree: types, field layout, identity of the (immutable, shared) leaf arrays and the
+    values of everything else.  Two trees with the same signature run the same launch list on the same weights -- e.g. a
+    fresh `tree_inference(net, True)` copy made inside the caller's loop (new Module objects, shared leaves) hits the cache
+    instead of retracing.  Cached on the instance: Modules are frozen by convention, like eqx.Module."""
+    hit = m.__dict__.get("_sig_cache")
+    if hit is not None:
+        return hit
+
+    def rec(n):
+        if isinstance(n, Module):
+            return (type(n).__qualname__,) + tuple((f, rec(getattr(n, f))) for f in n.__fields__ if hasattr(n, f))
+        if isinstance(n, (list, tuple)):
+            return (type(n).__name__,) + tuple(rec(c) for c in n)
+        if isinstance(n, dict):
+            return ("dict",) + tuple((k, rec(c)) for k, c in n.items())
+        if isinstance(n, np.ndarray):
+            return ("a", id(n), n.shape, str(n.dtype))
+        if n is None or isinstance(n, (bool, int, float, str)):
+            return n
+        return ("o", id(n))                    # StateIndex slots, callables, ...: shared by identity
+
+    sig = ("mod", hash(rec(m)), id(type(m)))
+    object.__setattr__(m, "_sig_cache", sig)
+    return sig
+
+
 def _sig(x):
     if _is_array(x):
         if _is_key_array(x):
@@ -95,7 +122,9 @@ def _sig(x):
         if _is_resident(x):            # read in place; the buffer address selects the variant (see `jitted`)
             return ("dev", tuple(x.shape), str(x.dtype))
         return ("arr", tuple(x.shape), str(x.dtype))
-    if isinstance(x, Module) or callable(x):
+    if isinstance(x, Module):
+        return _module_sig(x)
+    if callable(x):
         return ("obj", id(x))
     if isinstance(x, (list, tuple)):
         return (type(x).__name__,) + tuple(_sig(v) for v in x)
@@ -108,6 +137,23 @@ def _sig(x):
         return ("obj", id(x))
 
 
+MAX_CACHE_SIGNATURES = 8   # per jitted function: least-recently-used signatures beyond this are evicted (graph destroyed,
+                           # pinned intermediates and argument references dropped)
+
+
+def _release(c: "_Compiled"):
+    if c is None:
+        return
+    if c.graph is not None:
+        try:
+            torch.cuda.synchronize()           # nothing may still be replaying the graph / reading its buffers
+            _lib.call("mv_graph_destroy", c.graph)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+        c.graph = None
+    c.calls, c.lane_calls, c.keep, c.static_in, c.refs, c.out = [], None, [], [], None, None
+
+
 def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bool = True, lanes: int = 1) -> Callable:
     """`lanes` > 1 (an extension; the reference has no counterpart): the batch is cut into `lanes` contiguous
     sub-batches whose launch lists are captured as PARALLEL branches of the hipGraph (one stream each).  The
@@ -116,7 +162,8 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
     e.g. 784 / 392 / 196 tiles on 256 CUs for the ResNet-50 3x3 layers at batch 256)."""
     if fn is None:
         return functools.partial(filter_jit, use_graph=use_graph, clone_outputs=clone_outputs, lanes=lanes)
-    cache = {}
+    import collections
+    cache = collections.OrderedDict()
 
     def _replay(c: _Compiled):
         s = stream_ptr()
@@ -201,7 +248,8 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
 
     @functools.wraps(fn)
     def jitted(*args, **kwargs):
-        key = (compute_dtype(), tuple(_sig(a) for a in args), tuple((k, _sig(v)) for k, v in sorted(kwargs.items())))
+        key = (compute_dtype(), residual_fp32(), _lib.load().mv_flags_epoch(), tuple(_sig(a) for a in args),
+               tuple((k, _sig(v)) for k, v in sorted(kwargs.items())))
         # A graph bakes buffer addresses in.  Resident device inputs are read in place -- no staging copy -- by a
         # variant per address tuple, at most MAX_INPLACE_VARIANTS of them (a double-buffered loader stays zero-copy);
         # beyond that ONE more variant owns its input buffers and takes a device-to-device copy per call, so a caller
@@ -211,6 +259,12 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
         grp = cache.get(key)
         if grp is None:
             grp = cache[key] = {"variants": {}, "owned": None}
+            while len(cache) > MAX_CACHE_SIGNATURES:         # LRU eviction
+                _, old_grp = cache.popitem(last=False)
+                for oc in list(old_grp["variants"].values()) + [old_grp["owned"]]:
+                    _release(oc)
+        else:
+            cache.move_to_end(key)
         c = grp["variants"].get(ptrs)
         own = False
         if c is None and ptrs and len(grp["variants"]) >= MAX_INPLACE_VARIANTS:

@@ -33,26 +33,20 @@ typedef void* mv_stream_t; /* hipStream_t */
 enum { MV_F32 = 0, MV_BF16 = 1 };
 enum { MV_ACT_NONE = 0, MV_ACT_RELU = 1, MV_ACT_GELU_TANH = 2 };
 enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
-/* mv_set_flag names: "force_generic" (1 = route every op to the simple VALU kernels, used by
- * tests to cross-check the MFMA kernels), "igemm_tile" (override tile heuristic, 0 = auto),
- * "stem_v0" (1 = use the table-gather entry-conv kernel instead of the patch/GEMM variants),
- * "no_stream" / "no_igemm2" (1 = do not dispatch to the streaming 1x1 / deep-pipelined kernels),
- * "igemm2_tile" (0 auto, 1 = 256x64, 2 = 256x128, 3 = 256x256 block tile), "tail_split" (1 = hand the
- * rows of a small partial last round of 256-row tiles to the 128-row kernel), "igemm2_dense_m" (override
- * the row count from which dense layers use the deep-pipelined kernels), "igemm3" (1 = prefer, 2 = force
- * the phase-alternating 256x256 kernel) / "no_igemm3", "c3x3_v1" (first-generation 3x3 64->64 kernel),
- * "no_stem_pool" (do not fuse the ResNet entry with its max-pool), "stream_npass1" (one channel slab
- * per block in the streaming 1x1 kernel), "no_dual" (conv3 and the downsample conv as separate launches), "no_chain" / "no_dual_chain" (do not fuse conv3 with the next block's conv1 / with the downsample conv), "no_skinny" (classifier heads on the tiled kernels), "res_early"
- * (igemm2: fetch residual rows before the reduction instead of in its middle), "igemm4" (four-wave kernels of
- * igemm4.hip: 1 = 256x128 tiles / two blocks per CU wherever igemm2 would run, 2 = force 256x256, 3 = force
- * 256x128), "prof_lo" / "prof_hi" (device pointer for per-block phase stamps, tools/phase_prof.py), "no_tuned" (ignore the
- * table of tuned shapes) and "ov:<M>:<C>:<K>:<R>:<S>:<stride>" / "ovh:..." (per-shape kernel choice, tools/tune_tiles.py).
- * All are A/B and test switches; 0 is the tuned default. */
+/* mv_set_flag names (A/B and test switches, per calling thread; 0 = the tuned default):
+ * "force_generic" (route every op to the simple VALU kernels: on-device cross-check of the MFMA kernels),
+ * "igemm8" (2 / 3 / 4 = force the ping-pong GEMM with 256x256 / 128x256 / 256x128 tiles), "no_igemm8",
+ * "igemm2_tile" (1 / 2 / 3 = force igemm2 with 256x64 / 256x128 / 256x256 tiles), "no_igemm2", "igemm2_dense_m",
+ * "igemm_tile" (1 / 2 = force the 128x128 / 128x64 kernel), "res_early", "no_stream" (no streaming 1x1 / 3x3c64 kernels),
+ * "stream_npass1", "stem_v0", "no_stem_pool", "no_dual", "no_chain", "no_dual_chain", "no_skinny", "no_tuned", and the
+ * per-shape kernel choice "ov:<M>:<C>:<K>:<R>:<S>:<stride>" / "ovh:<M>:<N>:<K>:1:1:1" / "ovd:<M>:<C1>:<C2>:<K>:<stride>:1"
+ * (tools/tune_tiles.py; codes in csrc/igemm.hip). */
 
 int mv_abi_version(void);
 const char* mv_last_error(void);
-int mv_set_flag(const char* name, int value);
+int mv_set_flag(const char* name, int value);   /* flags are per calling THREAD, like mv_last_error */
 int mv_get_flag(const char* name);
+int mv_flags_epoch(void);                        /* bumped by every mv_set_flag on this thread (recorded launch lists key on it) */
 /* name of the kernel variant the last call on this thread dispatched to (for tests/bench) */
 const char* mv_last_kernel(void);
 
@@ -201,6 +195,21 @@ int mv_graph_begin_capture(mv_stream_t stream);
 int mv_graph_end_capture(mv_stream_t stream, void** graph_exec);
 int mv_graph_launch(void* graph_exec, mv_stream_t stream);
 int mv_graph_destroy(void* graph_exec);
+
+/* The path's one collective: the batch axis of `jax.vmap(net, axis_name="batch")(images)` (README.md:37-40)
+ * shards over the GPUs of a node, one process per GPU; rank r runs images[r*B/W:(r+1)*B/W] and ONE all-gather of the fp32 logits
+ * rebuilds the (B, classes) array the single-device vmap returns.  RCCL over xGMI (librccl is dlopen'ed by the first call;
+ * $EQV_RCCL_LIB overrides the search).  Bootstrap: rank 0 calls mv_comm_unique_id and ships the MV_COMM_ID_BYTES bytes to
+ * the other ranks out of band (the Python host uses a torch.distributed gloo store); every rank then calls mv_comm_init
+ * with its HIP device already selected.  mv_allgather is enqueued on `stream` like every other call: recv[r*bytes : (r+1)*bytes]
+ * = rank r's send buffer.  One communicator per process. */
+#define MV_COMM_ID_BYTES 128
+int mv_comm_unique_id(void* out, size_t out_bytes);
+int mv_comm_init(int rank, int nranks, const void* unique_id);
+int mv_comm_size(void); /* 0 = no communicator */
+int mv_comm_rank(void);
+int mv_allgather(const void* send, void* recv, size_t bytes_per_rank, mv_stream_t stream);
+int mv_comm_destroy(void);
 
 /* HIP-event timing helpers on the caller's stream (bench.py's live roofline measurement) */
 int mv_event_create(void** ev);

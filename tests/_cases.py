@@ -786,7 +786,6 @@ def all_cases():
           ("c3x3c64/wide_112_two_col_tiles", conv_nhwc_case(3, 30, 112, 64, 64, 3, 3, pad=1, act=1, seed=44)),
           ("c3x3c64/width_100_H_not_mult4", conv_nhwc_case(5, 27, 100, 64, 64, 3, 3, pad=1, act=2, seed=45)),
           ("c3x3c64/many_tiles_persistent", conv_nhwc_case(40, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=46)),
-          ("c3x3c64/v1_kernel_56", conv_nhwc_case(4, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=41, flags=("c3x3_v1",))),
           ("igemm2/3x3_128_28", conv_nhwc_case(8, 28, 28, 128, 128, 3, 3, pad=1, act=1, seed=11)),
           ("igemm2/3x3_64_56_bn64", conv_nhwc_case(2, 56, 56, 64, 64, 3, 3, pad=1, act=1, seed=12, flags=("no_stream",))),
           ("igemm2/3x3_256_s2", conv_nhwc_case(24, 28, 28, 256, 256, 3, 3, stride=2, pad=1, act=1, seed=13)),
@@ -801,46 +800,6 @@ def all_cases():
           ("igemm2/t256_3x3_s2_K320", conv_nhwc_case(9, 33, 35, 128, 320, 3, 3, stride=2, pad=1, seed=33, flags=("igemm2_tile=3",))),
           ("igemm2/t256_f32out_res", conv_nhwc_case(30, 14, 14, 512, 256, 1, 1, res=True, out="fp32", seed=34, flags=("igemm2_tile=3",))),
           ("igemm2/t64_forced_K128", conv_nhwc_case(6, 28, 28, 128, 128, 3, 3, pad=1, seed=35, flags=("igemm2_tile=1",))),
-          ("igemm2/split_main_tail_3x3", conv_nhwc_case(70, 28, 28, 128, 256, 3, 3, pad=1, act=1, res=True, seed=51, flags=("tail_split",))),
-          ("igemm2/split_main_tail_dense", conv_nhwc_case(86, 28, 28, 512, 128, 1, 1, act=1, seed=52, flags=("tail_split",))),
-          ("igemm3/1x1_512_256", conv_nhwc_case(8, 28, 28, 512, 256, 1, 1, act=1, seed=61, flags=("igemm3=2",))),
-          ("igemm3/3x3_128_256", conv_nhwc_case(8, 28, 28, 128, 256, 3, 3, pad=1, act=1, seed=62, flags=("igemm3=2",))),
-          ("igemm3/3x3_s2_C96_K320", conv_nhwc_case(9, 33, 35, 96, 320, 3, 3, stride=2, pad=1, seed=63, flags=("igemm3=2",))),
-          ("igemm3/3x3_dil2_oddM", conv_nhwc_case(3, 37, 41, 64, 192, 3, 3, pad=2, dil=2, seed=64, flags=("igemm3=2",))),
-          ("igemm3/f32out_res", conv_nhwc_case(30, 14, 14, 512, 256, 1, 1, res=True, out="fp32", seed=65, flags=("igemm3=2",))),
-          ("igemm3/bf16_res_relu", conv_nhwc_case(40, 14, 14, 256, 256, 3, 3, pad=1, act=1, res=True, seed=66, flags=("igemm3=2",))),
-          ("igemm3/gelu_tail", conv_nhwc_case(3, 41, 43, 768, 512, 1, 1, act=2, seed=67, flags=("igemm3=2",))),
-          ("igemm3/k32_single_tile", conv_nhwc_case(4, 20, 20, 32, 64, 1, 1, seed=68, flags=("igemm3=2",))),
-          ("igemm3/k64_two_tiles", conv_nhwc_case(4, 20, 20, 64, 96, 1, 1, act=1, seed=69, flags=("igemm3=2",))),
-          ("igemm3/k96_three_tiles", conv_nhwc_case(4, 20, 20, 96, 256, 1, 1, seed=70, flags=("igemm3=2",))),
-          ("igemm3/k128_four_tiles", conv_nhwc_case(4, 20, 20, 128, 256, 1, 1, seed=71, flags=("igemm3=2",))),
-          ("igemm3/5x5", conv_nhwc_case(6, 27, 27, 64, 192, 5, 5, pad=2, act=1, scale=False, seed=72, flags=("igemm3=2",))),
-          ("igemm4/1x1_512_256", conv_nhwc_case(8, 28, 28, 512, 256, 1, 1, act=1, seed=81, flags=("igemm4=2",))),
-          ("igemm4/t128_1x1_512_256", conv_nhwc_case(8, 28, 28, 512, 256, 1, 1, act=1, seed=181, flags=("igemm4=3",))),
-          ("igemm4/3x3_128_256", conv_nhwc_case(8, 28, 28, 128, 256, 3, 3, pad=1, act=1, seed=82, flags=("igemm4=2",))),
-          ("igemm4/t128_3x3_128_256", conv_nhwc_case(8, 28, 28, 128, 256, 3, 3, pad=1, act=1, seed=182, flags=("igemm4=3",))),
-          ("igemm4/3x3_s2_C96_K320", conv_nhwc_case(9, 33, 35, 96, 320, 3, 3, stride=2, pad=1, seed=83, flags=("igemm4=2",))),
-          ("igemm4/t128_3x3_s2_C96_K320", conv_nhwc_case(9, 33, 35, 96, 320, 3, 3, stride=2, pad=1, seed=183, flags=("igemm4=3",))),
-          ("igemm4/3x3_dil2_oddM", conv_nhwc_case(3, 37, 41, 64, 192, 3, 3, pad=2, dil=2, seed=84, flags=("igemm4=2",))),
-          ("igemm4/t128_3x3_dil2_oddM", conv_nhwc_case(3, 37, 41, 64, 192, 3, 3, pad=2, dil=2, seed=184, flags=("igemm4=3",))),
-          ("igemm4/f32out_res", conv_nhwc_case(30, 14, 14, 512, 256, 1, 1, res=True, out="fp32", seed=85, flags=("igemm4=2",))),
-          ("igemm4/t128_f32out_res", conv_nhwc_case(30, 14, 14, 512, 256, 1, 1, res=True, out="fp32", seed=185, flags=("igemm4=3",))),
-          ("igemm4/bf16_res_relu", conv_nhwc_case(40, 14, 14, 256, 256, 3, 3, pad=1, act=1, res=True, seed=86, flags=("igemm4=2",))),
-          ("igemm4/t128_bf16_res_relu", conv_nhwc_case(40, 14, 14, 256, 256, 3, 3, pad=1, act=1, res=True, seed=186, flags=("igemm4=3",))),
-          ("igemm4/gelu_tail", conv_nhwc_case(3, 41, 43, 768, 512, 1, 1, act=2, seed=87, flags=("igemm4=2",))),
-          ("igemm4/t128_gelu_tail", conv_nhwc_case(3, 41, 43, 768, 512, 1, 1, act=2, seed=187, flags=("igemm4=3",))),
-          ("igemm4/k32_single_tile", conv_nhwc_case(4, 20, 20, 32, 64, 1, 1, seed=88, flags=("igemm4=2",))),
-          ("igemm4/t128_k32_single_tile", conv_nhwc_case(4, 20, 20, 32, 64, 1, 1, seed=188, flags=("igemm4=3",))),
-          ("igemm4/k64_two_tiles", conv_nhwc_case(4, 20, 20, 64, 96, 1, 1, act=1, seed=89, flags=("igemm4=2",))),
-          ("igemm4/t128_k64_two_tiles", conv_nhwc_case(4, 20, 20, 64, 96, 1, 1, act=1, seed=189, flags=("igemm4=3",))),
-          ("igemm4/k96_three_tiles", conv_nhwc_case(4, 20, 20, 96, 256, 1, 1, seed=90, flags=("igemm4=2",))),
-          ("igemm4/t128_k96_three_tiles", conv_nhwc_case(4, 20, 20, 96, 256, 1, 1, seed=190, flags=("igemm4=3",))),
-          ("igemm4/k128_four_tiles", conv_nhwc_case(4, 20, 20, 128, 256, 1, 1, seed=91, flags=("igemm4=2",))),
-          ("igemm4/t128_k128_four_tiles", conv_nhwc_case(4, 20, 20, 128, 256, 1, 1, seed=191, flags=("igemm4=3",))),
-          ("igemm4/k160_five_tiles", conv_nhwc_case(4, 20, 20, 160, 264, 1, 1, seed=93, flags=("igemm4=2",))),
-          ("igemm4/t128_k160_five_tiles", conv_nhwc_case(4, 20, 20, 160, 264, 1, 1, seed=193, flags=("igemm4=3",))),
-          ("igemm4/5x5", conv_nhwc_case(6, 27, 27, 64, 192, 5, 5, pad=2, act=1, scale=False, seed=92, flags=("igemm4=2",))),
-          ("igemm4/t128_5x5", conv_nhwc_case(6, 27, 27, 64, 192, 5, 5, pad=2, act=1, scale=False, seed=192, flags=("igemm4=3",))),
           ("igemm8/1x1_512_256", conv_nhwc_case(8, 28, 28, 512, 256, 1, 1, act=1, seed=261, flags=("igemm8=2",))),
           ("igemm8/3x3_128_256", conv_nhwc_case(8, 28, 28, 128, 256, 3, 3, pad=1, act=1, seed=262, flags=("igemm8=2",))),
           ("igemm8/3x3_s2_C128_K320", conv_nhwc_case(9, 33, 35, 128, 320, 3, 3, stride=2, pad=1, seed=263, flags=("igemm8=2",))),

@@ -288,6 +288,61 @@ def full_batch_case(model, B, lanes=2):
     return run
 
 
+def conv_norm_act_case(cin, cout, hw, B, kernel=3, stride=1, dilation=1, norm="bn", act="relu", dtype="bf16", seed=0):
+    """`eqxvision.layers.ConvNormActivation` as a MODULE on the device (reference layers/conv_norm_activation.py:18-86): the
+    Sequential [Conv2d, BatchNorm, Lambda(relu)] runs as ONE fused launch (nn.Sequential peephole) and must match the oracle's
+    conv -> BatchNorm(inference) -> activation.  (cin, cout, hw) = (3, 4, 5) is the reference's own test
+    (tests/test_layers.py:83-92: output shape (4, 5, 5), every value >= 0)."""
+    def run():
+        import functools
+        import eqxvision_amd as eqv
+        from eqxvision_amd import nn
+        rng = np.random.Generator(np.random.PCG64(seed))
+        norm_layer = {"bn": nn.BatchNorm, "bn_partial": functools.partial(nn.BatchNorm, eps=1e-3), "none": None}[norm]
+        act_layer = {"relu": nn.relu, "gelu": nn.gelu, "none": None}[act]
+        m = eqv.layers.ConvNormActivation(cin, cout, kernel_size=kernel, stride=stride, dilation=dilation, norm_layer=norm_layer,
+                                          activation_layer=act_layer, key=eqv.random.PRNGKey(seed + 1))
+        conv = m.layers[0]
+        bn = m.layers[1] if norm != "none" else None
+        w = np.asarray(conv.weight, np.float32)
+        bias = None if conv.bias is None else np.asarray(conv.bias, np.float32).reshape(-1)
+        if bn is not None:                       # non-trivial running statistics + affine, set like load_torch_weights does
+            g = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+            g[::3] *= -1.0
+            b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+            mean = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+            var = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+            object.__setattr__(bn, "weight", g)
+            object.__setattr__(bn, "bias", b)
+            bn.state_index.value = (mean, var)
+        m = eqv.tree_inference(m, True)
+        x = rng.standard_normal((B, cin, hw, hw)).astype(np.float32)
+        with eqv.precision(dtype):
+            got = eqv.vmap(m, axis_name="batch")(x, key=_keys(B))
+        torch.cuda.synchronize()
+        from eqxvision_amd import _lib
+        kern = _lib.last_kernel()
+        got = got.cpu().numpy()
+        q = O.bf16_round if dtype == "bf16" else (lambda a_: np.asarray(a_, np.float32))
+        pad = (kernel - 1) // 2 * dilation
+        ref = np.stack([O.conv2d(q(x[i]), q(w), bias, stride, pad, dilation) for i in range(B)])
+        if bn is not None:
+            eps = bn.eps
+            ref = np.stack([O.batchnorm_inference(ref[i], g, b, mean, var, eps) for i in range(B)])
+        if act == "relu":
+            ref = O.relu(ref)
+        elif act == "gelu":
+            ref = O.gelu_tanh(ref)
+        info = _cmp(got, ref, 1e-2 if dtype == "bf16" else 1e-3)
+        info["kernel"] = kern
+        Ho = (hw + 2 * pad - dilation * (kernel - 1) - 1) // stride + 1
+        info["shape_ok"] = tuple(got.shape) == (B, cout, Ho, Ho) and m.out_channels == cout
+        info["nonneg"] = bool((got >= 0).all()) if act == "relu" else None
+        info["ok"] = bool(info["ok"] and info["shape_ok"] and (info["nonneg"] is not False))
+        return info
+    return run
+
+
 def all_cases(full=True):
     c = [("model/resnet_tiny_bottleneck", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2)),
          ("model/resnet18_64px", resnet_case("basic", (2, 2, 2, 2), 64, 2)),
@@ -297,6 +352,11 @@ def all_cases(full=True):
          ("model/vit_tiny_last_attn", vit_case(32, 8, 64, 2, 2, 2, attn=True)),
          ("model/swin_tiny", swin_case(56, 32, (2, 2), (2, 4), 2)),
          ("model/swin_tiny_fp32", swin_case(56, 32, (2, 2), (2, 4), 1, dtype="fp32")),
+         ("model/conv_norm_act_reference_3_4_5x5", conv_norm_act_case(3, 4, 5, 1)),
+         ("model/conv_norm_act_3_4_5x5_fp32", conv_norm_act_case(3, 4, 5, 2, dtype="fp32")),
+         ("model/conv_norm_act_64_128_28_mfma", conv_norm_act_case(64, 128, 28, 6, seed=3)),
+         ("model/conv_norm_act_128_256_s2_eps", conv_norm_act_case(128, 256, 28, 40, stride=2, norm="bn_partial", seed=4)),
+         ("model/conv_norm_act_dil2_gelu_nonorm", conv_norm_act_case(64, 96, 20, 3, dilation=2, norm="none", act="gelu", seed=5)),
          ("model/filter_jit_replay", jit_case()),
          ("model/filter_jit_lanes2_resnet", lanes_case("resnet", 2, 6)),
          ("model/filter_jit_lanes3_resnet", lanes_case("resnet", 3, 6)),

@@ -43,3 +43,13 @@ def test_argument_errors_do_not_need_a_gpu(built_lib):
     assert rc == -1 and b"NULL" in built_lib.mv_last_error()
     rc = built_lib.mv_swin_window_attn_fwd(1, 1, 1, 1, 13, 13, 32, 2, 7, 7, 0, 0, 1, None)
     assert rc == -1 and b"multiple of the window" in built_lib.mv_last_error()
+
+
+def test_comm_argument_errors_do_not_need_a_gpu(built_lib):
+    # no communicator yet: the collective refuses loudly instead of copying locally (and librccl is not even loaded)
+    assert built_lib.mv_comm_size() == 0 and built_lib.mv_comm_rank() == -1
+    rc = built_lib.mv_allgather(1, 1, 16, None)
+    assert rc == -1 and b"mv_comm_init" in built_lib.mv_last_error()
+    rc = built_lib.mv_comm_init(3, 2, 1)
+    assert rc == -1 and b"bad rank" in built_lib.mv_last_error()
+    assert built_lib.mv_comm_destroy() == 0

@@ -102,12 +102,11 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     variants = [("old", (("no_igemm8", 1),)), ("rule", ()), ("g8", (("igemm8", 2),)), ("s128x256", (("igemm8", 3),)),
                 ("s256x128", (("igemm8", 4),))]
-    extra = os.environ.get("G8_EXTRA")          # e.g. "i3:igemm3=2,i4:igemm4=2"
+    extra = os.environ.get("G8_EXTRA")          # e.g. "relax:flag=1+flag2=3,other:flag=2"
     if extra:
         for item in extra.split(","):
-            n, fv = item.split(":")
-            f, v = fv.split("=")
-            variants.append((n, ((f, int(v)),)))
+            n, fvs = item.split(":")
+            variants.append((n, tuple((fv.split("=")[0], int(fv.split("=")[1])) for fv in fvs.split("+"))))
     if what in ("lin", "all"):
         ab("8192^3", lambda: lin(8192, 8192, 8192), reps, variants)
         ab("4096^3", lambda: lin(4096, 4096, 4096), reps, variants)
@@ -117,9 +116,13 @@ def main():
             ab(f"vit proj f32res M{M}", lambda: lin(M, 768, 768, res=True, f32=True), reps, variants)
             ab(f"vit fc1 gelu M{M}", lambda: lin(M, 3072, 768, act=2), reps, variants)
             ab(f"vit fc2 f32res M{M}", lambda: lin(M, 768, 3072, res=True, f32=True), reps, variants)
-        for (Mm, Nn, Kk) in ((3136 * 128, 288, 96), (784 * 128, 576, 192), (196 * 128, 1152, 384), (196 * 128, 1536, 384),
-                             (196 * 128, 384, 1536), (49 * 128, 2304, 768), (49 * 128, 3072, 768), (49 * 128, 768, 3072)):
-            ab(f"swin M{Mm} N{Nn} K{Kk}", lambda: lin(Mm, Nn, Kk), reps, variants)
+    if what in ("swin", "all"):
+        for B in (128, 64):
+            for (tok, Nn, Kk, res) in ((3136, 96, 384, True), (784, 192, 384, False), (784, 192, 768, True), (196, 1152, 384, False),
+                                       (196, 384, 384, True), (196, 1536, 384, False), (196, 384, 1536, True), (49, 768, 1536, False),
+                                       (49, 2304, 768, False), (49, 768, 768, True), (49, 3072, 768, False), (49, 768, 3072, True)):
+                ab(f"swin M{tok * B} N{Nn} K{Kk}" + (" f32res" if res else ""), lambda: lin(tok * B, Nn, Kk, res=res, f32=res), reps,
+                   variants)
     if what in ("dual", "all"):
         dv = [("base", (("ovd:%d", 3),)), ("g8", (("igemm8", 2),))]
         for B in (256, 128):

@@ -16,8 +16,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 LANES = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 THRESH = float(os.environ.get("THRESH", "0.004"))
 STEPS = int(os.environ.get("STEPS", "30"))
-NAMES = {1: "igemm2 256x64", 2: "igemm2 256x128", 3: "igemm2 256x256", 4: "igemm3 256x256", 5: "igemm4 256x128",
-         6: "igemm4 256x256", 7: "igemm 128x128", 8: "igemm 128x64", 9: "stream1x1", 10: "igemm8 256x256"}
+NAMES = {1: "igemm2 256x64", 2: "igemm2 256x128", 3: "igemm2 256x256", 7: "igemm 128x128", 8: "igemm 128x64", 9: "stream1x1",
+         10: "igemm8 256x256", 11: "igemm8 128x256", 12: "igemm8 256x128"}
 
 eqv.set_compute_dtype("bf16")
 net = build_model(model)
@@ -101,11 +101,11 @@ for key in order:
     kern, us, n = tunable[key]
     dense = key[0] == "ovh" or (key[4] == 1 and key[5] == 1 and key[6] == 1)
     if key[0] == "ovd":
-        cands = [3, 10]
+        cands = [3, 10, 11]
     elif os.environ.get("CANDS"):
         cands = [int(c) for c in os.environ["CANDS"].split(",")]
     else:
-        cands = [2, 3, 4, 10] if key[0] == "ovh" else ([2, 3, 4, 7, 9, 10] if dense else [1, 2, 3, 4, 7, 10])
+        cands = [2, 3, 10, 11] if key[0] == "ovh" else ([2, 3, 7, 9, 10, 11, 12] if dense else [2, 3, 7, 10, 11, 12])
     cur = timeit(make())                      # the configuration so far, re-measured next to its challengers
     best_c, best_t = 0, cur
     log = []
