@@ -12,9 +12,10 @@ Everything below the module `__call__`s is hand-written HIP for gfx950 behind a 
 __version__ = "0.1.0"
 
 from . import layers, models, nn, random, utils
-from ._act import compute_dtype, precision, set_compute_dtype
+from ._act import (compute_dtype, precision, set_compute_dtype, set_head_fp32, set_residual_fp32, set_split_weights)
 from ._module import Module, tree_at, tree_inference, tree_leaves
 from .transforms import filter_jit, vmap
 
 __all__ = ["layers", "models", "nn", "random", "utils", "Module", "tree_at", "tree_inference", "tree_leaves",
-           "filter_jit", "vmap", "compute_dtype", "precision", "set_compute_dtype"]
+           "filter_jit", "vmap", "compute_dtype", "precision", "set_compute_dtype", "set_head_fp32", "set_residual_fp32",
+           "set_split_weights"]

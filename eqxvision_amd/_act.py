@@ -25,7 +25,7 @@ from . import _lib
 
 import threading
 
-_state = {"dtype": "bf16", "residual_fp32": True}      # process-wide numerics configuration
+_state = {"dtype": "bf16", "residual_fp32": True, "head_fp32": True, "split_weights": True}   # process-wide numerics configuration
 _tls = threading.local()                                  # .keep: the allocation pin list of THIS thread's trace
 
 DT = {"bf16": _lib.BF16, "fp32": _lib.F32}
@@ -53,6 +53,28 @@ def residual_fp32() -> bool:
 
 def set_residual_fp32(on: bool):
     _state["residual_fp32"] = bool(on)
+
+
+def head_fp32() -> bool:
+    """Classifier heads (pooled / cls features -> logits: resnet.py:354-356, vit.py:272-273, swin.py:768-771) run in fp32 on
+    the exact-fp32 MFMA while the rest of the network stays bf16: the logits are the tested quantity, and rounding the pooled
+    features + the head weights to bf16 alone costs 3-5e-3 of the 1e-2 budget.  ~0.3 GFLOP: free."""
+    return _state["head_fp32"] and _state["dtype"] == "bf16"
+
+
+def set_head_fp32(on: bool):
+    _state["head_fp32"] = bool(on)
+
+
+def split_weights() -> bool:
+    """Layers that PRODUCE the residual stream (Swin patch embedding and patch merging, swin.py:705-711 / 61-65) carry their
+    fp32 weights as two bf16 terms (hi + lo) and run two products: their weight rounding is not damped by a residual add and
+    dominates the bf16 logit error of swin_t (1.4e-2 -> 8e-3 with this and the fp32 head)."""
+    return _state["split_weights"] and _state["dtype"] == "bf16"
+
+
+def set_split_weights(on: bool):
+    _state["split_weights"] = bool(on)
 
 
 @contextlib.contextmanager

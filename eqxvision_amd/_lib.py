@@ -36,6 +36,9 @@ PROTOTYPES = {
     "mv_conv2d_nhwc_fwd": [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 14 + [_i, _i, _i, _vp],
     "mv_conv2d_nchw_fwd": [_vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_i, _i, _i, _i, _i, _vp, _vp],
     "mv_linear_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
+    "mv_linear_split_supported": [_i64, _i, _i, _i],
+    "mv_linear_split_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
+    "mv_conv2d_nchw_split_fwd": [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_i, _i, _i, _vp],
     "mv_maxpool2d_nhwc_fwd": [_vp, _vp] + [_i] * 10 + [_i, _vp],
     "mv_adaptive_avgpool2d_nhwc_fwd": [_vp, _vp] + [_i] * 6 + [_i, _i, _vp],
     "mv_layernorm_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _i64, _f, _i, _i, _vp],

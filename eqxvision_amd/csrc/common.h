@@ -131,7 +131,11 @@ int igemm8_dual_launch(const void* x, const void* x2, const void* w, const float
 int stem_supported(int C, int K, int R, int S, int x_dtype, int out_dtype);
 int stem_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
                 int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act, int x_dtype,
-                int out_dtype, int tok_stride, int tok_offset, const float* pos, hipStream_t stream);
+                int out_dtype, int tok_stride, int tok_offset, const float* pos, hipStream_t stream,
+                const void* w_lo = nullptr);   // w_lo: low halves of split-precision weights (generic kernel only)
+int skinny_f32_supported(long long M, int C, int K, int in_dtype, int out_dtype, const void* residual);
+int skinny_f32_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, long long M, int C, int K,
+                      int act, hipStream_t stream);
 int swin_mfma_supported(int C, int heads, int ws_h, int ws_w, int dtype);
 int swin_mfma_launch(const void* qkv, const float* bias, void* out, int B, int Hf, int Wf, int C, int heads, int ws_h,
                      int ws_w, int shift_h, int shift_w, hipStream_t stream);

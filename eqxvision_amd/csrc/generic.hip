@@ -802,9 +802,45 @@ int mv_linear_fwd(const void* x, const void* w, const float* scale, const float*
                   void* y, int64_t M, int N, int K, int act, int in_dtype, int out_dtype, mv_stream_t stream) {
     MV_CHECK_ARG(x && w && y, "linear: NULL pointer");
     MV_CHECK_ARG(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear: bad dims M=%lld N=%d K=%d", (long long)M, N, K);
+    if (skinny_f32_supported(M, K, N, in_dtype, out_dtype, residual))       // fp32 classifier heads (exact-fp32 MFMA)
+        return skinny_f32_launch(x, w, scale, shift, y, M, K, N, act, (hipStream_t)stream);
     // a Linear over M rows is a 1x1 convolution over an M x 1 image
     return mv_conv2d_nhwc_fwd(x, w, scale, shift, residual, y, 1, (int)M, 1, K, N, 1, 1, 1, 1, 0, 0, 1, 1, 1, act,
                               in_dtype, out_dtype, stream);
+}
+
+int mv_linear_split_supported(int64_t M, int N, int K, int dtype) {
+    return dtype == MV_BF16 && !get_flag("force_generic") && M < (1LL << 31) - 256 &&
+           igemm8_supported(M, K, N, 1, 1, 2LL * M * K, 4LL * N * K) && K % 64 == 0;
+}
+
+int mv_linear_split_fwd(const void* x, const void* w_hi_lo, const float* scale, const float* shift, const void* residual,
+                        void* y, int64_t M, int N, int K, int act, int in_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && w_hi_lo && y, "linear_split: NULL pointer");
+    if (!mv_linear_split_supported(M, N, K, in_dtype)) {
+        set_error("linear_split: unsupported shape M=%lld N=%d K=%d (ask mv_linear_split_supported first)", (long long)M, N, K);
+        return MV_E_UNSUPPORTED;
+    }
+    int tile = igemm8_wanted(M, 2 * K, N, 1, 1);
+    if (tile == 0) tile = N <= 128 ? 3 : 2;
+    // the second reduction source IS x: [x | x] . [w_hi | w_lo]^T = x . (w_hi + w_lo)^T, accumulated in fp32
+    return igemm8_dual_launch(x, x, w_hi_lo, scale, shift, residual, y, 1, (int)M, 1, K, (int)M, 1, K, 1, N, act, out_dtype, tile,
+                              (hipStream_t)stream);
+}
+
+int mv_conv2d_nchw_split_fwd(const void* x, const void* w_hi, const void* w_lo, const float* scale, const float* shift,
+                             void* y, int N, int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act,
+                             int x_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && w_hi && w_lo && y, "conv2d_nchw_split: NULL pointer");
+    MV_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0,
+                 "conv2d_nchw_split: bad dims");
+    MV_CHECK_ARG((H + 2 * ph - R) / sh + 1 > 0 && (W + 2 * pw - S) / sw + 1 > 0, "conv2d_nchw_split: empty output");
+    if (get_flag("force_generic") || !stem_supported(C, K, R, S, x_dtype, out_dtype)) {
+        set_error("conv2d_nchw_split: unsupported configuration C=%d K=%d %dx%d", C, K, R, S);
+        return MV_E_UNSUPPORTED;
+    }
+    return stem_launch(x, w_hi, scale, shift, y, N, C, H, W, K, R, S, sh, sw, ph, pw, act, x_dtype, out_dtype, 0, 0, nullptr,
+                       (hipStream_t)stream, w_lo);
 }
 
 int mv_maxpool2d_nhwc_fwd(const void* x, void* y, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph,

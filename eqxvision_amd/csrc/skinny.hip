@@ -96,6 +96,93 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const SkinnyP p) {
     }
 }
 
+// fp32 classifier head: x fp32 [M][K], w fp32 [N][K], y fp32 -- `v_mfma_f32_32x32x2_f32` is EXACT fp32 (an fmaf chain) at
+// the vector rate, plenty for a 0.2-0.5 GFLOP head.  Why: the logits are the tested quantity; rounding the pooled features and
+// the head weights to bf16 alone costs 3-5e-3 of logit error (Swin-T / ViT-B, synthetic weights) out of a 1e-2 budget.
+// A lane's 16-byte load holds 4 consecutive k of its row; MFMA step t of the load uses element t from both operands, so the
+// k order inside a load is (t, fh) instead of (fh, t) -- the same permutation on both operands, i.e. the same sum.
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void skinny_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ y, int M, int N, int K, int act, int tiles_n) {
+    constexpr int D = 4;                                   // 16-byte loads in flight per operand per wave
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, fr = lane & 31, fh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // k-range bounds must be SGPRs (MFMA ignores EXEC)
+    const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+    const int n0 = tn * 32, m0 = tm * 32;
+    const int nr = n0 + fr < N ? n0 + fr : N - 1;
+    const int mr = m0 + fr < M ? m0 + fr : M - 1;
+    const float* wa = w + (long long)nr * K + fh * 4;
+    const float* xa = x + (long long)mr * K + fh * 4;
+    const int nk = K >> 3;                                 // steps of 8 k (2 lanes halves x 4)
+    const int per = (nk + 3) >> 2;
+    const int kb = wave * per, ke = (kb + per) < nk ? (kb + per) : nk;
+    float4 af[D], bf[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const int kk = kb + i < nk ? kb + i : nk - 1;
+        af[i] = *(const float4*)(wa + kk * 8);
+        bf[i] = *(const float4*)(xa + kk * 8);
+    }
+    f32x16s acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k0 = kb; k0 < ke; k0 += D) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const float4 a = af[i], b = bf[i];
+            const int kn = k0 + D + i < nk ? k0 + D + i : nk - 1;
+            af[i] = *(const float4*)(wa + kn * 8);
+            bf[i] = *(const float4*)(xa + kn * 8);
+            if (k0 + i < ke) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave - 1][e][lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += red[0][e][lane] + red[1][e][lane] + red[2][e][lane];
+    const int m = m0 + fr;
+    if (m >= M) return;
+    float* yr = y + (long long)m * N;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = n0 + 8 * g + 4 * fh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (n + e >= N) continue;
+            float v = fmaf(acc[4 * g + e], scale ? scale[n + e] : 1.f, shift ? shift[n + e] : 0.f);
+            if (act == MV_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == MV_ACT_GELU_TANH) v = gelu_tanh_f(v);
+            yr[n + e] = v;
+        }
+    }
+}
+
+int skinny_f32_supported(long long M, int C, int K, int in_dtype, int out_dtype, const void* residual) {
+    return in_dtype == MV_F32 && out_dtype == MV_F32 && residual == nullptr && M >= 1 && M <= 1024 && C % 8 == 0 && C >= 64 &&
+           K >= 8 && !get_flag("force_generic");
+}
+
+int skinny_f32_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, long long M, int C, int K,
+                      int act, hipStream_t st) {
+    const int tiles_n = (K + 31) / 32, tiles_m = (int)((M + 31) / 32);
+    set_kernel_name("skinny_linear_f32_mfma");
+    hipLaunchKernelGGL(skinny_f32_kernel, dim3(tiles_n * tiles_m), dim3(256), 0, st, (const float*)x, (const float*)w, scale, shift,
+                       (float*)y, (int)M, K, C, act, tiles_n);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
 int skinny_supported(long long M, int C, int K, int in_dtype, const void* residual) {
     // C = reduction length, K = output channels (igemm naming)
     return in_dtype == MV_BF16 && residual == nullptr && M >= 1 && M <= 256 && C % 16 == 0 && C >= 64 && K >= 8;

@@ -20,6 +20,7 @@ namespace mv {
 struct StemP {
     const void* x;
     const bf16_t* w;
+    const bf16_t* w2;    // optional low halves of split-precision weights (w_true ~ w + w2): second product per k-step
     const float* scale;
     const float* shift;
     const float* pos;
@@ -36,9 +37,11 @@ template <> __device__ __forceinline__ float ldx<bf16_t>(const bf16_t* p) { retu
 template <typename TX>
 __global__ __launch_bounds__(256) void stem_kernel(const StemP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // layout: [64 rows x pitch] weights | [Kp] int2 tap table
+    // layout: [64 rows x pitch] weights (| the same for the low halves) | [Kp] int2 tap table
+    const bool split = p.w2 != nullptr;                    // block-uniform
     char* wl = smem;
-    int2* ktab = (int2*)(smem + 64 * p.pitch);
+    char* wl2 = smem + 64 * p.pitch;
+    int2* ktab = (int2*)(smem + (split ? 128 : 64) * p.pitch);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.y * 64;
@@ -76,6 +79,19 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemP p) {
                 }
             }
             *(uint4*)(wl + row * p.pitch + ch * 16) = make_uint4(u[0], u[1], u[2], u[3]);
+            if (split) {
+                uint32_t u2[4] = {0, 0, 0, 0};
+                if (n < p.K) {
+                    const bf16_t* src = p.w2 + (long long)n * p.CRS + ch * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = ch * 8 + e;
+                        const uint32_t v = k < p.CRS ? (uint32_t)src[e] : 0u;
+                        u2[e >> 1] |= v << ((e & 1) * 16);
+                    }
+                }
+                *(uint4*)(wl2 + row * p.pitch + ch * 16) = make_uint4(u2[0], u2[1], u2[2], u2[3]);
+            }
         }
     }
     __syncthreads();
@@ -127,6 +143,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemP p) {
                                                              __builtin_bit_cast(bf16x8, bv), acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1),
                                                              __builtin_bit_cast(bf16x8, bv), acc[1], 0, 0, 0);
+            if (split) {                                   // scalar branch (MFMA ignores EXEC: never a lane mask)
+                const uint4 l0 = *(const uint4*)(wl2 + fr * p.pitch + k0 * 2);
+                const uint4 l1 = *(const uint4*)(wl2 + (32 + fr) * p.pitch + k0 * 2);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, l0),
+                                                                 __builtin_bit_cast(bf16x8, bv), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, l1),
+                                                                 __builtin_bit_cast(bf16x8, bv), acc[1], 0, 0, 0);
+            }
         }
 
         if (!mvalid) continue;
@@ -653,14 +677,14 @@ int stem_supported(int C, int K, int R, int S, int x_dtype, int out_dtype) {
 
 int stem_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C, int H,
                 int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act, int x_dtype, int out_dtype,
-                int tok_stride, int tok_offset, const float* pos, hipStream_t st) {
+                int tok_stride, int tok_offset, const float* pos, hipStream_t st, const void* w_lo) {
     (void)out_dtype;
-    if (patch_v2_ok(C, H, W, K, R, S, sh, sw, ph, pw, x_dtype) && !get_flag("stem_v0"))
+    if (!w_lo && patch_v2_ok(C, H, W, K, R, S, sh, sw, ph, pw, x_dtype) && !get_flag("stem_v0"))
         return patch_v2_launch(x, w, scale, shift, y, N, C, H, W, K, R, S, act, x_dtype, tok_stride, tok_offset, pos, st);
-    if (stem_v1_ok(C, K, R, S, sw, tok_stride) && !get_flag("stem_v0"))
+    if (!w_lo && stem_v1_ok(C, K, R, S, sw, tok_stride) && !get_flag("stem_v0"))
         return stem_v1_launch(x, w, scale, shift, y, N, C, H, W, K, R, S, sh, sw, ph, pw, act, x_dtype, st);
     StemP p;
-    p.x = x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.pos = pos; p.y = (bf16_t*)y;
+    p.x = x; p.w = (const bf16_t*)w; p.w2 = (const bf16_t*)w_lo; p.scale = scale; p.shift = shift; p.pos = pos; p.y = (bf16_t*)y;
     p.N = N; p.C = C; p.H = H; p.W = W; p.K = K; p.R = R; p.S = S;
     p.Ho = (H + 2 * ph - R) / sh + 1;
     p.Wo = (W + 2 * pw - S) / sw + 1;
@@ -676,13 +700,14 @@ int stem_launch(const void* x, const void* w, const float* scale, const float* s
     p.M = (int)M;
     p.tiles_m = (p.M + 127) / 128;
     p.act = act; p.tok_stride = tok_stride; p.tok_offset = tok_offset;
-    const size_t smem = (size_t)64 * p.pitch + (size_t)p.Kp * sizeof(int2);
+    const size_t smem = (size_t)(w_lo ? 128 : 64) * p.pitch + (size_t)p.Kp * sizeof(int2);
     const int tiles_n = (K + 63) / 64;
     int gx = p.tiles_m;
     const int cap = (256 * 8) / tiles_n > 0 ? (256 * 8) / tiles_n : 1;  // a few resident blocks per CU in total
     if (gx > cap) gx = cap;
     dim3 grid(gx, tiles_n), block(256);
-    set_kernel_name(x_dtype == MV_F32 ? "stem_conv_mfma_f32in" : "stem_conv_mfma_bf16in");
+    set_kernel_name(w_lo ? (x_dtype == MV_F32 ? "stem_conv_mfma_f32in_w2" : "stem_conv_mfma_bf16in_w2")
+                         : (x_dtype == MV_F32 ? "stem_conv_mfma_f32in" : "stem_conv_mfma_bf16in"));
     if (x_dtype == MV_F32) {
         if (smem > 48 * 1024)
             MV_HIP(hipFuncSetAttribute((const void*)stem_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -10,6 +10,7 @@ from typing import Any, Callable, List, Optional, Sequence, Type, Union
 
 from ... import nn, ops
 from ... import random as jr
+from ..._act import head_fp32
 from ..._module import Module
 from ...nn import boundary
 from ...utils import load_torch_weights
@@ -219,9 +220,12 @@ class ResNet(Module):
             nxt = stages[i + 1][0] if i + 1 < len(stages) and isinstance(stages[i + 1], nn.Sequential) and \
                 len(stages[i + 1]) > 0 else None
             x = stage.call_chained(x, nxt) if isinstance(stage, nn.Sequential) else stage(x)
-        x = self.avgpool(x)
+        if type(self.avgpool) is nn.AdaptiveAvgPool2d and head_fp32():     # reference :354-356, pooled features kept fp32
+            x = ops.adaptive_avgpool2d(x, self.avgpool.target_shape, out_fp32=True)
+        else:
+            x = self.avgpool(x)
         x = ops.flatten(x)
-        return ops.linear(x, self.fc, out_fp32=True)
+        return ops.linear_head(x, self.fc)
 
 
 def _resnet(block, layers, torch_weights=None, **kwargs):

@@ -18,7 +18,7 @@ import numpy as np
 
 from ... import nn, ops
 from ... import random as jr
-from ..._act import Act, residual_fp32
+from ..._act import Act, head_fp32, residual_fp32
 from ..._module import Module
 from ...layers import DropPath, LayerNorm2d, Linear2d, MlpProjection
 from ...nn import boundary
@@ -45,8 +45,8 @@ class _PatchMerging(Module):
     def __call__(self, x, *, key=None):                                # reference :61-65
         x = ops.patch_merge_gather(x)                                  # _patch_merging_pad (:23-31)
         x = self.norm(x)
-        if type(self.reduction) is Linear2d:
-            return ops.linear(ops.as_map(x), self.reduction, out_fp32=residual_fp32())
+        if type(self.reduction) is Linear2d:      # produces the residual stream: split-precision weights (ops.linear_split)
+            return ops.linear_split(ops.as_map(x), self.reduction, out_fp32=residual_fp32())
         return self.reduction(x)
 
 
@@ -201,7 +201,8 @@ class SwinTransformer(Module):
         first = L[0]
         if (residual_fp32() and isinstance(first, nn.Sequential) and len(first) == 2
                 and type(first.layers[0]) is nn.Conv2d and isinstance(first.layers[1], nn.LayerNorm)):
-            x = ops.conv2d(x, first.layers[0])
+            y = ops.conv2d_entry_split(x, first.layers[0])          # patch embedding: split-precision weights
+            x = y if y is not None else ops.conv2d(x, first.layers[0])
             x = ops.layernorm(x, first.layers[1], out_fp32=True)
             for layer in L[1:]:
                 x = layer(x)
@@ -211,10 +212,14 @@ class SwinTransformer(Module):
     @boundary
     def __call__(self, x, *, key=None):                                # reference :760-772
         x = self._features(x)
-        x = self.norm(x)
-        x = self.avgpool(x)
+        if head_fp32() and isinstance(self.norm, nn.LayerNorm) and type(self.avgpool) is nn.AdaptiveAvgPool2d:
+            x = ops.layernorm(x, self.norm, out_fp32=True)             # reference :768-771 with fp32 features
+            x = ops.adaptive_avgpool2d(x, self.avgpool.target_shape, out_fp32=True)
+        else:
+            x = self.norm(x)
+            x = self.avgpool(x)
         x = ops.flatten(x)
-        return ops.linear(x, self.head, out_fp32=True)
+        return ops.linear_head(x, self.head)
 
 
 def _swin_transformer(arch, patch_size, embed_dim, depths, num_heads, window_size, stochastic_depth_prob,

@@ -13,7 +13,7 @@ import numpy as np
 
 from ... import nn, ops
 from ... import random as jr
-from ..._act import Act, residual_fp32
+from ..._act import Act, head_fp32, residual_fp32
 from ..._module import Module
 from ...layers import DropPath, MlpProjection, PatchEmbed
 from ...nn import boundary
@@ -147,14 +147,14 @@ class VisionTransformer(Module):
     def _head(self, x: Act) -> Act:
         # reference :272-273 normalises every token and keeps x[0]; only the cls row is needed
         if type(self.norm) is nn.LayerNorm:
-            cls = ops.layernorm_first_row(x, self.norm)
+            cls = ops.layernorm_first_row(x, self.norm, out_fp32=head_fp32() and not isinstance(self.fc, nn.Identity))
         else:
             x = self.norm(x)
             B, N, D = x.t.shape
             cls = ops.first_row(x)
         if isinstance(self.fc, nn.Identity):
             return cls
-        return ops.linear(cls, self.fc, out_fp32=True)
+        return ops.linear_head(cls, self.fc)
 
     @boundary
     def __call__(self, x, *, key=None):                                # reference :261-273

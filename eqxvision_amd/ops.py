@@ -12,7 +12,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._act import Act, is_act, DT, TORCH_DT, compute_dtype, device, empty, residual_fp32, stream_ptr
+from ._act import (Act, is_act, DT, TORCH_DT, compute_dtype, device, empty, head_fp32, residual_fp32, split_weights,
+                   stream_ptr)
 
 ACT = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "gelu": _lib.ACT_GELU_TANH}
 
@@ -90,6 +91,39 @@ def prep_linear(lin, dtype: str):
     b = None if lin.bias is None else _dev(np.asarray(lin.bias, np.float32).reshape(-1), torch.float32)
     cache[key] = (w, b)
     return w, b
+
+
+def _bf16_split(w: np.ndarray):
+    """fp32 -> (hi, lo) bf16 tensors with hi + lo ~ w to ~16 mantissa bits (host, round-to-nearest-even)."""
+    t = torch.from_numpy(np.ascontiguousarray(w.astype(np.float32)))
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.to(torch.float32)).to(torch.bfloat16)
+    return hi, lo
+
+
+def prep_linear_split(lin):
+    """[N][2K] = [hi row | lo row] bf16 + fp32 bias (cached)."""
+    cache = lin._cache()
+    hit = cache.get("lin_split")
+    if hit is None:
+        hi, lo = _bf16_split(np.asarray(lin.weight, np.float32))
+        w = torch.cat([hi, lo], dim=1).contiguous().to(device())
+        b = None if lin.bias is None else _dev(np.asarray(lin.bias, np.float32).reshape(-1), torch.float32)
+        hit = (w, b)
+        cache["lin_split"] = hit
+    return hit
+
+
+def prep_conv_split(conv):
+    """OIHW weights as (hi, lo) bf16 + fp32 bias (cached); no BatchNorm on these call sites."""
+    cache = conv._cache()
+    hit = cache.get("conv_split")
+    if hit is None:
+        hi, lo = _bf16_split(np.asarray(conv.weight, np.float32))
+        b = None if conv.bias is None else _dev(np.asarray(conv.bias, np.float32).reshape(-1), torch.float32)
+        hit = (hi.to(device()), lo.to(device()), b)
+        cache["conv_split"] = hit
+    return hit
 
 
 def prep_f32(mod, name: str, arr) -> Optional[torch.Tensor]:
@@ -375,6 +409,63 @@ def linear(x: Act, lin, act=None, residual: Optional[Act] = None, out_fp32: bool
     return Act(y, x.kind, x.batched)
 
 
+def linear_head(x: Act, lin) -> Act:
+    """The classifier head -> fp32 logits.  With `head_fp32()` (default in bf16 mode) features and weights stay fp32 and the
+    product runs on the exact-fp32 MFMA; otherwise the bf16 Linear with an fp32 store."""
+    if not head_fp32():
+        return linear(x, lin, out_fp32=True)
+    if x.t.dtype != torch.float32:
+        x = cast(x, "fp32")
+    w, b = prep_linear(lin, "fp32")
+    N, K = lin.out_features, lin.in_features
+    if x.t.shape[-1] != K:
+        raise ValueError(f"Linear expected {K} input features, got {x.t.shape[-1]}")
+    M = x.t.numel() // K
+    y = empty(tuple(x.t.shape[:-1]) + (N,), torch.float32)
+    _lib.call("mv_linear_fwd", _ptr(x.t), _ptr(w), None, _ptr(b), None, _ptr(y), M, N, K, _lib.ACT_NONE, _lib.F32, _lib.F32,
+              stream_ptr())
+    return Act(y, x.kind, x.batched)
+
+
+def linear_split(x: Act, lin, out_fp32: bool = False) -> Act:
+    """Linear with split-precision (hi + lo bf16) weights where the library has the path, else the plain Linear."""
+    dt = compute_dtype()
+    x = as_map(x) if x.kind in ("img", "map") else as_rows(x)
+    N, K = lin.out_features, lin.in_features
+    M = x.t.numel() // K
+    if not split_weights() or x.t.dtype != torch.bfloat16 or x.t.shape[-1] != K or \
+            not _lib.load().mv_linear_split_supported(M, N, K, DT[dt]):
+        return linear(x, lin, out_fp32=out_fp32)
+    w, b = prep_linear_split(lin)
+    y = empty(tuple(x.t.shape[:-1]) + (N,), torch.float32 if out_fp32 else TORCH_DT[dt])
+    _lib.call("mv_linear_split_fwd", _ptr(x.t), _ptr(w), None, _ptr(b), None, _ptr(y), M, N, K, _lib.ACT_NONE, DT[dt],
+              _lib.F32 if out_fp32 else DT[dt], stream_ptr())
+    return Act(y, x.kind, x.batched)
+
+
+def conv2d_entry_split(x: Act, conv) -> Optional[Act]:
+    """The network-entry convolution (raw NCHW image, no norm) with split-precision weights; None if not applicable."""
+    dt = compute_dtype()
+    if not split_weights() or x.kind != "img" or conv.groups != 1 or tuple(conv.dilation) != (1, 1) or \
+            conv.in_channels > STEM_MAX_CIN or x.t.shape[1] != conv.in_channels:
+        return None
+    B, C, H, W = x.t.shape
+    kh, kw = conv.kernel_size
+    sh, sw = conv.stride
+    ph, pw = conv.padding
+    K = conv.out_channels
+    hi, lo, b = prep_conv_split(conv)
+    Ho = (H + 2 * ph - kh) // sh + 1
+    Wo = (W + 2 * pw - kw) // sw + 1
+    y = empty((B, Ho, Wo, K), TORCH_DT[dt])
+    try:
+        _lib.call("mv_conv2d_nchw_split_fwd", _ptr(x.t), _ptr(hi), _ptr(lo), None, _ptr(b), _ptr(y), B, C, H, W, K, kh, kw, sh, sw,
+                  ph, pw, _lib.ACT_NONE, x.dt, DT[dt], stream_ptr())
+    except _lib.MVError:
+        return None
+    return Act(y, "map", x.batched)
+
+
 def patch_embed_tokens(x: Act, conv, cls: Optional[torch.Tensor], pos: Optional[torch.Tensor], n_extra: int) -> Act:
     """PatchEmbed conv (k = s = patch) straight from the NCHW image into token rows
     [B, n_extra + P, D]; with `pos` the position embedding is added in the epilogue and row 0 gets
@@ -426,16 +517,16 @@ def cast(x: Act, dtype: str) -> Act:
     return Act(y, x.kind, x.batched)
 
 
-def layernorm_first_row(x: Act, ln) -> Act:
+def layernorm_first_row(x: Act, ln, out_fp32: bool = False) -> Act:
     """LayerNorm of row 0 of every sample of a seq [B,N,D] -> vec [B,D] (vit.py:272-273: only
     `x[0]` of the normalised tokens is used), via the kernel's row-stride argument."""
     dt = compute_dtype()
     B, N, D = x.t.shape
     g = prep_f32(ln, "weight", ln.weight)
     b = prep_f32(ln, "bias", ln.bias)
-    y = empty((B, D), TORCH_DT[dt])
+    y = empty((B, D), torch.float32 if out_fp32 else TORCH_DT[dt])
     _lib.call("mv_layernorm_fwd", _ptr(x.t), _ptr(g), _ptr(b), _ptr(y), B, D, N * D, float(ln.eps),
-              x.dt, DT[dt], stream_ptr())
+              x.dt, _lib.F32 if out_fp32 else DT[dt], stream_ptr())
     return Act(y, "vec", x.batched)
 
 
@@ -469,14 +560,16 @@ def maxpool2d(x: Act, kernel_size, stride, padding) -> Act:
     return Act(y, "map", x.batched)
 
 
-def adaptive_avgpool2d(x: Act, target) -> Act:
+def adaptive_avgpool2d(x: Act, target, out_fp32: bool = False) -> Act:
     x = as_map(x)
     B, H, W, C = x.t.shape
     oh, ow = _pair(target)
-    if oh == H and ow == W:
+    if oh == H and ow == W and not (out_fp32 and x.t.dtype != torch.float32):
         return x
-    y = empty((B, oh, ow, C), x.t.dtype)
-    _lib.call("mv_adaptive_avgpool2d_nhwc_fwd", _ptr(x.t), _ptr(y), B, H, W, C, oh, ow, x.dt, x.dt, stream_ptr())
+    odt = torch.float32 if out_fp32 else x.t.dtype
+    y = empty((B, oh, ow, C), odt)
+    _lib.call("mv_adaptive_avgpool2d_nhwc_fwd", _ptr(x.t), _ptr(y), B, H, W, C, oh, ow, x.dt,
+              _lib.F32 if odt == torch.float32 else _lib.BF16, stream_ptr())
     return Act(y, "map", x.batched)
 
 

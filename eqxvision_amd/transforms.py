@@ -22,7 +22,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._act import Act, _to_device_f32, compute_dtype, keep_alive, residual_fp32, stream_ptr, wrap
+from ._act import (Act, _to_device_f32, compute_dtype, head_fp32, keep_alive, residual_fp32, split_weights, stream_ptr,
+                   wrap)
 from ._module import Module
 from .nn import _unwrap
 
@@ -248,7 +249,7 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
 
     @functools.wraps(fn)
     def jitted(*args, **kwargs):
-        key = (compute_dtype(), residual_fp32(), _lib.load().mv_flags_epoch(), tuple(_sig(a) for a in args),
+        key = (compute_dtype(), residual_fp32(), head_fp32(), split_weights(), _lib.load().mv_flags_epoch(), tuple(_sig(a) for a in args),
                tuple((k, _sig(v)) for k, v in sorted(kwargs.items())))
         # A graph bakes buffer addresses in.  Resident device inputs are read in place -- no staging copy -- by a
         # variant per address tuple, at most MAX_INPLACE_VARIANTS of them (a double-buffered loader stays zero-copy);

@@ -123,10 +123,25 @@ int mv_conv1x1_dual_chain_fwd(const void* x, const void* x2, const void* wcat, c
                               int dtype, mv_stream_t stream);
 
 /* eqx.nn.Linear under vmap / Linear2d (vit.py:64,74; mlps.py:60-64; resnet.py:356;
- * extensions_2d.py:31-50):  y[M,N] = act(scale[n]*(x[M,K] . w[N,K]^T) + shift[n] + residual[M,N]) */
+ * extensions_2d.py:31-50):  y[M,N] = act(scale[n]*(x[M,K] . w[N,K]^T) + shift[n] + residual[M,N]).
+ * in_dtype = out_dtype = MV_F32 with M <= 1024 (the classifier heads: resnet.py:356, vit.py:273, swin.py:771) runs on the
+ * exact-fp32 MFMA: the logits then carry no bf16 rounding of the pooled features or of the head weights. */
 int mv_linear_fwd(const void* x, const void* w, const float* scale, const float* shift,
                   const void* residual, void* y, int64_t M, int N, int K,
                   int act, int in_dtype, int out_dtype, mv_stream_t stream);
+
+/* The same Linear / entry convolution with SPLIT-PRECISION weights: the fp32 weight of the reference is carried as two bf16
+ * terms, w ~ w_hi + w_lo (w_hi = bf16(w), w_lo = bf16(w - w_hi): ~16 mantissa bits), and the kernel accumulates both products
+ * in fp32.  For the few layers whose weight rounding dominates the bf16 logit error -- layers that PRODUCE the residual stream
+ * instead of adding a correction to it (Swin patch embedding swin.py:705-711 and patch merging swin.py:61-65): 1.4e-2 -> 8e-3
+ * on swin_t.  mv_linear_split_fwd: w_hi_lo is [N][2K] = [w_hi row | w_lo row]; otherwise as mv_linear_fwd (bf16 x).
+ * mv_conv2d_nchw_split_fwd: as mv_conv2d_nchw_fwd without token mode. */
+int mv_linear_split_supported(int64_t M, int N, int K, int dtype);
+int mv_linear_split_fwd(const void* x, const void* w_hi_lo, const float* scale, const float* shift, const void* residual,
+                        void* y, int64_t M, int N, int K, int act, int in_dtype, int out_dtype, mv_stream_t stream);
+int mv_conv2d_nchw_split_fwd(const void* x, const void* w_hi, const void* w_lo, const float* scale, const float* shift,
+                             void* y, int N, int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw,
+                             int act, int x_dtype, int out_dtype, mv_stream_t stream);
 
 /* eqx.nn.MaxPool2d (resnet.py:254, alexnet.py:46,49,56): -inf padding, floor output size. */
 int mv_maxpool2d_nhwc_fwd(const void* x, void* y, int N, int H, int W, int C,

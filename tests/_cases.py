@@ -332,6 +332,85 @@ def linear_case(M, K, N, act=0, res=False, dtype="bf16", out="same", generic=Fal
     return run
 
 
+def linear_f32_head_case(M, K, N, seed=0):
+    """mv_linear_fwd with fp32 in / fp32 out, M <= 1024: the exact-fp32 MFMA head (skinny_f32) vs float64."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        b = (0.1 * rng.standard_normal(N)).astype(np.float32)
+        ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+        xd, wd, bd = dev(x, "fp32"), dev(w, "fp32"), dev(b, "fp32")
+        y = torch.empty((M, N), dtype=torch.float32, device="cuda")
+        L.call("mv_linear_fwd", xd.data_ptr(), wd.data_ptr(), None, bd.data_ptr(), None, y.data_ptr(), M, N, K, 0, 0, 0, _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, 2e-5)
+        info["kernel"] = kern
+        info["ok"] = info["ok"] and "f32" in kern
+        return info
+    return run
+
+
+def linear_split_case(M, K, N, out="fp32", seed=0):
+    """mv_linear_split_fwd: x (bf16) . (w_hi + w_lo)^T with fp32 accumulation vs float64 on the UN-rounded fp32 weights:
+    the error must be far below what bf16 weights alone would give."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        x = bf(rng.standard_normal((M, K)))
+        w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        b = (0.1 * rng.standard_normal(N)).astype(np.float32)
+        if not L.load().mv_linear_split_supported(M, N, K, 1):
+            return {"ok": False, "err": "mv_linear_split_supported says no"}
+        ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+        ref_bf16w = x.astype(np.float64) @ bf(w).astype(np.float64).T + b
+        hi = torch.from_numpy(w).to(torch.bfloat16)
+        lo = (torch.from_numpy(w) - hi.float()).to(torch.bfloat16)
+        wd = torch.cat([hi, lo], 1).contiguous().cuda()
+        xd, bd = dev(x, "bf16"), dev(b, "fp32")
+        odt = torch.float32 if out == "fp32" else torch.bfloat16
+        y = torch.empty((M, N), dtype=odt, device="cuda")
+        L.call("mv_linear_split_fwd", xd.data_ptr(), wd.data_ptr(), None, bd.data_ptr(), None, y.data_ptr(), M, N, K, 0, 1,
+               0 if out == "fp32" else 1, _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, 2e-4 if out == "fp32" else TOL_BF16)
+        info["kernel"] = kern
+        info["err_if_bf16_weights"] = float(np.abs(ref_bf16w - ref).max())
+        return info
+    return run
+
+
+def conv_nchw_split_case(N, C, H, K, R, stride, seed=0):
+    """mv_conv2d_nchw_split_fwd (entry conv with hi + lo weights) vs float64 on the un-rounded weights."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        x = rng.random((N, C, H, H)).astype(np.float32)
+        w = (rng.standard_normal((K, C, R, R)) / np.sqrt(C * R * R)).astype(np.float32)
+        b = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        ref = np.stack([O.conv2d(bf(x[i]).astype(np.float64), w.astype(np.float64), b.astype(np.float64), stride, 0) for i in range(N)])
+        ref_bf16w = np.stack([O.conv2d(bf(x[i]).astype(np.float64), bf(w).astype(np.float64), b.astype(np.float64), stride, 0)
+                              for i in range(N)])
+        hi = torch.from_numpy(w).to(torch.bfloat16)
+        lo = (torch.from_numpy(w) - hi.float()).to(torch.bfloat16)
+        xd, bd, hid, lod = dev(x, "fp32"), dev(b, "fp32"), hi.cuda(), lo.cuda()
+        Ho = (H - R) // stride + 1
+        y = torch.empty((N, Ho, Ho, K), dtype=torch.bfloat16, device="cuda")
+        L.call("mv_conv2d_nchw_split_fwd", xd.data_ptr(), hid.data_ptr(), lod.data_ptr(), None, bd.data_ptr(), y.data_ptr(),
+               N, C, H, H, K, R, R, stride, stride, 0, 0, 0, 0, 1, _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        got = host(y).transpose(0, 3, 1, 2)
+        info = _cmp(got, ref, TOL_BF16)
+        info["kernel"] = kern
+        info["err_if_bf16_weights"] = float(np.abs(ref_bf16w - ref).max())
+        return info
+    return run
+
+
 def maxpool_case(N, H, W, C, k, s, p, dtype="bf16", seed=0):
     def run():
         L = _lib()
@@ -839,6 +918,15 @@ def all_cases():
           ("igemm8s/256x128_k192_three", conv_nhwc_case(4, 20, 20, 192, 264, 1, 1, seed=470, flags=("igemm8=4",))),
           ("igemm8s/256x128_5x5", conv_nhwc_case(6, 27, 27, 64, 192, 5, 5, pad=2, act=1, scale=False, seed=471, flags=("igemm8=4",))),
           ("igemm8s/256x128_dual_s1", dual_case(3, 37, 41, 64, 64, 200, 1, act=0, seed=477, flags=("igemm8=4",))),
+          ("head/f32_resnet_fc_B256", linear_f32_head_case(256, 2048, 1000, seed=501)),
+          ("head/f32_vit_head_B200", linear_f32_head_case(200, 768, 1000, seed=502)),
+          ("head/f32_odd_rows_1", linear_f32_head_case(1, 768, 1000, seed=503)),
+          ("head/f32_K72_N40_M33", linear_f32_head_case(33, 72, 40, seed=504)),
+          ("split/linear_swin_merge_384_192", linear_split_case(128 * 28 * 28 // 4, 384, 192, seed=511)),
+          ("split/linear_swin_merge_1536_768", linear_split_case(64 * 49, 1536, 768, seed=512)),
+          ("split/linear_bf16out_ragged", linear_split_case(9000 + 37, 256, 200, out="bf16", seed=513)),
+          ("split/conv_swin_patch4", conv_nchw_split_case(3, 3, 224, 96, 4, 4, seed=514)),
+          ("split/conv_odd_k3s2", conv_nchw_split_case(2, 3, 65, 40, 3, 2, seed=515)),
           ("chain/56x56_B4", chain_case(4 * 56 * 56, seed=1)),
           ("chain/ragged_M", chain_case(8192 + 37, seed=2)),
           ("chain/many_tiles", chain_case(40 * 56 * 56 + 5, seed=3)),
