@@ -13,6 +13,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libeqxvision_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+if os.environ.get("EQV_PROF"):          # debug build: per-block / per-barrier time stamps in igemm2 / igemm8 (tools/phase_prof.py)
+    FLAGS.append("-DMV_I8_PROF")
 
 
 def _newer(src, dst):

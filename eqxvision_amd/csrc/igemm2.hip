@@ -469,7 +469,11 @@ int igemm2_launch(const void* x, const void* w, const float* scale, const float*
     p.tok = tok;
     p.x2 = nullptr; p.C2 = 0; p.H2 = 0; p.W2 = 0; p.s2 = 1;
     p.dbg = get_flag("res_early");
+#ifdef MV_I8_PROF      // debug builds only: a raw device pointer taken from flags must never reach a captured graph
     p.prof = (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo"));
+#else
+    p.prof = nullptr;
+#endif
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.zero = (const bf16_t*)zero_page(st);
     if (!p.zero) {

@@ -161,6 +161,23 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wc = wave & 3;
+#ifdef MV_I8_PROF      // debug builds only (EQV_PROF=1 python -m eqxvision_amd.build): per-block wall-clock stamps at
+                       // prologue / main loop / epilogue boundaries, and for block 0 the shader-clock of every barrier exit
+    long long pt0 = 0, pt1 = 0, pt2 = 0;
+    int nstamp = 0;
+    unsigned* stamps = (unsigned*)(smem + LDS_TOTAL) + wave * 128;
+    if (p.prof) pt0 = wall_clock64();
+#define MV_I8_STAMP()                                                                                      \
+    do {                                                                                                   \
+        if (p.prof && blockIdx.x == 0 && nstamp < 128) {                                                   \
+            const unsigned tt = (unsigned)__builtin_readcyclecounter();                                    \
+            if (lane == 0) stamps[nstamp] = tt;                                                            \
+            ++nstamp;                                                                                      \
+        }                                                                                                  \
+    } while (0)
+#else
+#define MV_I8_STAMP() do {} while (0)
+#endif
     const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     int tile_m, tile_n;
     tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n);
@@ -258,6 +275,10 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
     }
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind
+#ifdef MV_I8_PROF
+    if (p.prof) pt1 = wall_clock64();
+#endif
+    MV_I8_STAMP();
 
     u32x4 wf[2][4], xf[2][4];
     auto mfma_half = [&](int half) {
@@ -284,17 +305,26 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
     auto ktile = [&](int it, auto bufc) {
         constexpr int BUF = decltype(bufc)::value;
         // ---- phase 1 LOAD: weights + top pixel rows of tile `it`; issue Xtop(1) / Xbot of tile it+1 into the other buffer
+#ifdef MV_I8_PROF
+        const bool do_reads = !(p.dbg & 2), do_dma = !(p.dbg & 1);       // ablation (results wrong): what bounds an interval
+#else
+        constexpr bool do_reads = true, do_dma = true;
+#endif
+        if (do_reads) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            lds_read16<BUF * 32768>(wf[0][kk], waddr[kk]);
-            lds_read16<BUF * 32768 + 32 * ROWB>(wf[1][kk], waddr[kk]);
-        }
+            for (int kk = 0; kk < 4; ++kk) {
+                lds_read16<BUF * 32768>(wf[0][kk], waddr[kk]);
+                lds_read16<BUF * 32768 + 32 * ROWB>(wf[1][kk], waddr[kk]);
+            }
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            lds_read16<BUF * 16384>(xf[0][kk], xaddr[kk]);
-            lds_read16<BUF * 16384 + 32 * ROWB>(xf[1][kk], xaddr[kk]);
+            for (int kk = 0; kk < 4; ++kk) {
+                lds_read16<BUF * 16384>(xf[0][kk], xaddr[kk]);
+                lds_read16<BUF * 16384 + 32 * ROWB>(xf[1][kk], xaddr[kk]);
+            }
         }
-        if (it + 1 < nk) {
+        if (!do_dma) {
+            wait_vm_lgkm0<0>();
+        } else if (it + 1 < nk) {
             tap_next<DUAL>(p, sb, it + 1, nk1);
             MV_I8_X(BUF ^ 1, 1, sb, it + 1);
             MV_I8_X(BUF ^ 1, 2, sb, it + 1);
@@ -305,15 +335,21 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
         }
         pin_frags();
         __builtin_amdgcn_s_barrier();
+        MV_I8_STAMP();
         mfma_half(0);
         __builtin_amdgcn_s_barrier();
+        MV_I8_STAMP();
         // ---- phase 2 LOAD: bottom pixel rows of tile `it`; issue W / Xtop(0) of tile it+2 into this buffer
+        if (do_reads) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            lds_read16<(LDS_XB - LDS_XT) + BUF * 16384>(xf[0][kk], xaddr[kk]);
-            lds_read16<(LDS_XB - LDS_XT) + BUF * 16384 + 32 * ROWB>(xf[1][kk], xaddr[kk]);
+            for (int kk = 0; kk < 4; ++kk) {
+                lds_read16<(LDS_XB - LDS_XT) + BUF * 16384>(xf[0][kk], xaddr[kk]);
+                lds_read16<(LDS_XB - LDS_XT) + BUF * 16384 + 32 * ROWB>(xf[1][kk], xaddr[kk]);
+            }
         }
-        if (it + 2 < nk) {
+        if (!do_dma) {
+            wait_vm_lgkm0<0>();
+        } else if (it + 2 < nk) {
             tap_next<DUAL>(p, sa, it + 2, nk1);
             MV_I8_W(BUF, sa);
             MV_I8_X(BUF, 0, sa, it + 2);
@@ -325,14 +361,19 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
         }
         pin_frags();
         __builtin_amdgcn_s_barrier();
+        MV_I8_STAMP();
         mfma_half(1);
         __builtin_amdgcn_s_barrier();
+        MV_I8_STAMP();
     };
     for (int it = 0; it < nk; it += 2) {
         ktile(it, std::integral_constant<int, 0>{});
         if (it + 1 < nk) ktile(it + 1, std::integral_constant<int, 1>{});
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();          // balance group 1's extra barrier: nobody reads LDS any more
+#ifdef MV_I8_PROF
+    if (p.prof) pt2 = wall_clock64();
+#endif
 
     // ---------------- epilogue (igemm2's: wave-private LDS transpose, full-line stores) --------------------
     char* ep = smem + wave * (32 * EPITCH);
@@ -391,6 +432,19 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+#ifdef MV_I8_PROF
+    if (p.prof) {
+        if (tid == 0) {
+            long long* o = p.prof + 4ll * blockIdx.x;
+            o[0] = pt0; o[1] = pt1; o[2] = pt2; o[3] = wall_clock64();
+        }
+        if (blockIdx.x == 0 && lane == 0) {               // barrier stamps of the 8 waves behind the per-block table
+            long long* o = p.prof + 4ll * gridDim.x + wave * 128;
+            for (int i = 0; i < 128; ++i) o[i] = i < nstamp ? (long long)stamps[i] : -1;
+        }
+    }
+#endif
+#undef MV_I8_STAMP
 #undef MV_I8_W
 #undef MV_I8_X
 }
@@ -658,7 +712,11 @@ static int igemm8_go(Igemm2P& p, bool dual, bool out_f32, int tile, hipStream_t 
     } while (0)
     if (tile == 1) GO4(igemm8s_kernel, 3 * 384 * 128, 0);
     else if (tile == 2) GO4(igemm8s_kernel, 3 * 384 * 128, 1);
+#ifdef MV_I8_PROF
+    else GO4(igemm8_kernel, LDS_TOTAL + 4096);
+#else
     else GO4(igemm8_kernel, LDS_TOTAL);
+#endif
 #undef GO4
 #undef GO
     MV_LAUNCH_CHECK();
@@ -684,6 +742,10 @@ int igemm8_launch(const void* x, const void* w, const float* scale, const float*
     }
     p.M = (int)M;
     p.act = act;
+#ifdef MV_I8_PROF
+    p.prof = (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo"));
+    p.dbg = get_flag("i8_ablate");
+#endif
     const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
     if (tile == 2) set_kernel_name(dense ? "igemm8_bf16_128x256_dense" : "igemm8_bf16_128x256_conv");
     else if (tile == 3) set_kernel_name(dense ? "igemm8_bf16_256x128_dense" : "igemm8_bf16_256x128_conv");
