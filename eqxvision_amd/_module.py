@@ -36,7 +36,7 @@ class _ModuleMeta(type):
         fields: List[str] = []
         for klass in reversed(cls.__mro__):
             for f in klass.__dict__.get("__annotations__", {}):
-                if f not in fields:
+                if f not in fields and not f.startswith("__"):
                     fields.append(f)
         cls.__fields__ = tuple(fields)
         return cls
@@ -164,8 +164,8 @@ def tree_at(where: Callable, tree, replace):
     """Tiny `eqx.tree_at`: `where(tree)` must return one node (or a tuple of nodes); the
     returned tree has them replaced.  Implemented by identity search on a deep structural copy."""
     targets = where(tree)
-    single = not isinstance(targets, tuple)
-    targets = (targets,) if single else targets
+    single = not isinstance(targets, (tuple, list))      # eqx.tree_at takes any sequence of nodes (experimental.py:73-80 passes a list)
+    targets = (targets,) if single else tuple(targets)
     repl = (replace,) if single else tuple(replace)
     ids = {id(t): r for t, r in zip(targets, repl)}
 

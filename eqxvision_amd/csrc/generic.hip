@@ -774,7 +774,7 @@ int mv_conv1x1_dual_fwd(const void* x, const void* x2, const void* wcat, const f
         int t8 = 0;
         if (get_flag("igemm8") >= 2) t8 = get_flag("igemm8") - 1;
         else if (ovd >= 10 && ovd <= 12) t8 = ovd - 9;
-        else if (ovd == 0) t8 = igemm8_wanted(M, C1 + C2, K, 1, 1);
+        else if (ovd == 0 && (C1 + C2) / 64 >= 8) t8 = igemm8_wanted(M, C1 + C2, K, 1, 1);   // shorter: igemm2 (tuner, ResNet layer2 entry)
         if (t8)
             return igemm8_dual_launch(x, x2, wcat, scale, shift, nullptr, y, N, Ho, Wo, C1, H2, W2, C2, stride2, K, act, MV_BF16, t8,
                                       (hipStream_t)stream);

@@ -57,13 +57,18 @@ def _is_param_leaf(leaf) -> bool:
 def load_torch_weights(model: Module, torch_weights: Optional[str] = None) -> Module:
     """Return a copy of `model` whose array leaves are replaced, in order, by the tensors of a
     PyTorch checkpoint (path or URL)."""
-    try:
-        import torch
-    except ImportError as e:  # pragma: no cover
-        raise RuntimeError(" Torch package not found! Pretrained is only supported with the torch package.") from e
     if torch_weights is None:
         raise ValueError("torch_weights parameter cannot be empty!")
-    saved = torch.load(_resolve(torch_weights), map_location="cpu")
+    path = _resolve(torch_weights)
+    try:                                   # own zip + pickle reader: no torch needed to ingest a checkpoint (eqxvision_amd/pth.py)
+        from .pth import load_state_dict
+        saved = load_state_dict(path)
+    except ValueError:                     # legacy (pre-1.6) container: torch's own loader, if torch is there
+        try:
+            import torch
+        except ImportError as e:  # pragma: no cover
+            raise RuntimeError(" Torch package not found! Legacy-format checkpoints need the torch package.") from e
+        saved = torch.load(path, map_location="cpu")
     params, stats = [], []
     for name, w in saved.items():
         arr = w.detach().cpu().numpy() if hasattr(w, "detach") else np.asarray(w)

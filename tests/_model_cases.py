@@ -345,6 +345,76 @@ def conv_norm_act_case(cin, cout, hw, B, kernel=3, stride=1, dilation=1, norm="b
     return run
 
 
+def layer_getter_case(seed=0, dtype="bf16"):
+    """`intermediate_layer_getter` (reference experimental.py:35-88) on the device: (a) an nn.Sequential addressed by index --
+    each intermediate vs the oracle's conv chain; (b) a ResNet addressed through attributes (tree_at) -- final logits equal the
+    plain model's, intermediates have the reference's (C,H,W) shapes; wrapping must not change the result."""
+    def run():
+        import eqxvision_amd as eqv
+        from eqxvision_amd import nn
+        from eqxvision_amd.experimental import intermediate_layer_getter
+        rng = np.random.Generator(np.random.PCG64(seed))
+        k = eqv.random.split(eqv.random.PRNGKey(seed + 3), 3)
+        seq = nn.Sequential([nn.Conv2d(3, 64, 3, padding=1, key=k[0]), nn.Lambda(nn.relu), nn.Conv2d(64, 64, 3, padding=1, key=k[1]),
+                             nn.Lambda(nn.relu), nn.Conv2d(64, 32, 1, key=k[2])])
+        g = intermediate_layer_getter(seq, lambda m: [1, 3])
+        B, hw = 3, 20
+        x = rng.standard_normal((B, 3, hw, hw)).astype(np.float32)
+        q = O.bf16_round if dtype == "bf16" else (lambda a_: np.asarray(a_, np.float32))
+        with eqv.precision(dtype):
+            out, inter = eqv.vmap(g, axis_name="batch")(x, key=_keys(B))
+        torch.cuda.synchronize()
+
+        def conv(v, c, pad):
+            return np.stack([O.conv2d(v[i], q(np.asarray(c.weight)), np.asarray(c.bias).reshape(-1), 1, pad) for i in range(B)])
+        r1 = q(O.relu(conv(q(x), seq.layers[0], 1)))
+        r2 = q(O.relu(conv(r1, seq.layers[2], 1)))
+        r3 = conv(r2, seq.layers[4], 0)
+        tol = 1e-2 if dtype == "bf16" else 1e-3
+        i1 = _cmp(inter[0].cpu().numpy(), r1, tol, scaled=True)
+        i2 = _cmp(inter[1].cpu().numpy(), r2, 2 * tol, scaled=True)
+        i3 = _cmp(out.cpu().numpy(), r3, 2 * tol, scaled=True)
+        # (b) attribute targets on a ResNet
+        sd = S.resnet_state(1, "bottleneck", (1, 1, 1, 1), 10)
+        blk = eqv.models.classification.resnet._ResNetBottleneck
+        fac = lambda torch_weights=None, **kw: eqv.models.classification.resnet._resnet(blk, [1, 1, 1, 1], torch_weights, **kw)
+        net = _load(fac, sd, num_classes=10)
+        xi = S.synthetic_images(2, 64, seed=0)
+        plain = _run(net, xi, dtype).cpu().numpy()
+        g2 = intermediate_layer_getter(net, lambda m: [m.layer1, m.layer3])
+        with eqv.precision(dtype):
+            o2, in2 = eqv.vmap(g2, axis_name="batch")(xi, key=_keys(2))
+        torch.cuda.synchronize()
+        shapes_ok = tuple(in2[0].shape) == (2, 256, 16, 16) and tuple(in2[1].shape) == (2, 1024, 4, 4)
+        same = float(np.abs(o2.cpu().numpy() - plain).max())
+        info = {"ok": bool(i1["ok"] and i2["ok"] and i3["ok"] and shapes_ok and same <= 2e-3), "err": max(i1["err"], i2["err"], i3["err"]),
+                "seq_errs": [i1["err"], i2["err"], i3["err"]], "resnet_shapes_ok": shapes_ok, "resnet_wrapped_vs_plain": same}
+        return info
+    return run
+
+
+def pth_reader_case():
+    """A checkpoint ingested by the torch-free reader (eqxvision_amd/pth.py) gives the same model as torch.load would: the whole
+    load_torch_weights -> device forward path with `torch.load` made unavailable."""
+    def run():
+        import eqxvision_amd as eqv
+        import eqxvision_amd.utils as U
+        sd = S.resnet_state(1, "bottleneck", (1, 1, 1, 1), 10)
+        blk = eqv.models.classification.resnet._ResNetBottleneck
+        fac = lambda torch_weights=None, **kw: eqv.models.classification.resnet._resnet(blk, [1, 1, 1, 1], torch_weights, **kw)
+        real_load = torch.load
+        torch.load = None                                    # any use would raise TypeError
+        try:
+            net = _load(fac, sd, num_classes=10)
+        finally:
+            torch.load = real_load
+        x = S.synthetic_images(2, 64, seed=0)
+        got = _run(net, x, "bf16").cpu().numpy()
+        ref = O.vmap(lambda im: OM.resnet_forward(sd, im, "bottleneck", (1, 1, 1, 1)))(x)
+        return _cmp(got, ref, 1e-2)
+    return run
+
+
 def all_cases(full=True):
     c = [("model/resnet_tiny_bottleneck", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2)),
          ("model/resnet18_64px", resnet_case("basic", (2, 2, 2, 2), 64, 2)),
@@ -359,6 +429,8 @@ def all_cases(full=True):
          ("model/conv_norm_act_64_128_28_mfma", conv_norm_act_case(64, 128, 28, 6, seed=3)),
          ("model/conv_norm_act_128_256_s2_eps", conv_norm_act_case(128, 256, 28, 40, stride=2, norm="bn_partial", seed=4)),
          ("model/conv_norm_act_dil2_gelu_nonorm", conv_norm_act_case(64, 96, 20, 3, dilation=2, norm="none", act="gelu", seed=5)),
+         ("model/intermediate_layer_getter", layer_getter_case()),
+         ("model/pth_reader_no_torch_load", pth_reader_case()),
          ("model/filter_jit_replay", jit_case()),
          ("model/filter_jit_lanes2_resnet", lanes_case("resnet", 2, 6)),
          ("model/filter_jit_lanes3_resnet", lanes_case("resnet", 3, 6)),

@@ -153,3 +153,54 @@ def test_no_cpu_fallback_without_device():
     from eqxvision_amd._lib import MVError
     with pytest.raises(MVError, match="no CPU fallback"):
         eqv.vmap(eqv.models.resnet18())(np.zeros((1, 3, 64, 64), np.float32), key=eqv.random.split(eqv.random.PRNGKey(0), 1))
+
+
+def test_pth_reader_matches_torch_load(tmp_path):
+    """eqxvision_amd/pth.py (zip + restricted pickle) == torch.load on a state_dict with the dtypes a checkpoint carries."""
+    import torch
+    from collections import OrderedDict
+    from eqxvision_amd.pth import load_state_dict
+    g = torch.Generator().manual_seed(0)
+    sd = OrderedDict()
+    sd["conv.weight"] = torch.randn(8, 3, 3, 3, generator=g)
+    sd["bn.running_mean"] = torch.randn(8, generator=g)
+    sd["bn.num_batches_tracked"] = torch.tensor(7)
+    sd["idx"] = torch.arange(49).reshape(7, 7).t()            # int64, NON-contiguous view: strides must be honoured
+    sd["half"] = torch.randn(5, 4, generator=g).half()
+    sd["bf"] = torch.randn(6, generator=g).bfloat16()
+    sd["slice"] = torch.randn(10, 10, generator=g)[2:5, 1::3]  # storage offset + strides
+    p = tmp_path / "w.pth"
+    torch.save(sd, str(p))
+    got = load_state_dict(str(p))
+    assert list(got) == list(sd)
+    for k, v in sd.items():
+        ref = v.float().numpy() if v.dtype == torch.bfloat16 else v.numpy()
+        assert got[k].shape == tuple(v.shape), k
+        np.testing.assert_array_equal(got[k], ref, err_msg=k)
+    with pytest.raises(Exception):                             # arbitrary globals are refused, not executed
+        torch.save({"f": os.system}, str(tmp_path / "evil.pth"))
+        load_state_dict(str(tmp_path / "evil.pth"))
+
+
+def test_load_torch_weights_without_torch_load(tmp_path, monkeypatch):
+    import torch
+    from oracle import state as S
+    sd = S.resnet_state(1, "basic", (1, 1, 1, 1), 10)
+    p = tmp_path / "r.pth"
+    S.save_pth(sd, str(p))
+    monkeypatch.setattr(torch, "load", None)
+    blk = eqv.models.classification.resnet._ResNetBasicBlock
+    net = eqv.models.classification.resnet._resnet(blk, [1, 1, 1, 1], str(p), num_classes=10)
+    np.testing.assert_array_equal(net.conv1.weight, sd["conv1.weight"])
+    np.testing.assert_array_equal(net.bn1.state_index.value[1], sd["bn1.running_var"])
+
+
+def test_intermediate_layer_getter_structure():
+    from eqxvision_amd.experimental import intermediate_layer_getter
+    seq = nn.Sequential([nn.Conv2d(3, 4, 1), nn.Lambda(nn.relu), nn.Conv2d(4, 2, 1)])
+    g = intermediate_layer_getter(seq, lambda m: [1])
+    assert type(g.model.layers[1]).__name__ == "IntermediateWrapper" and g.model.layers[0] is seq.layers[0]
+    r = eqv.models.resnet18()
+    g = intermediate_layer_getter(r, lambda m: [m.layer2, m.layer4])
+    assert type(g.model.layer2).__name__ == "IntermediateWrapper" and g.model.layer2.layer is r.layer2
+    assert g.model.layer1.layers[0].conv1.weight is r.layer1.layers[0].conv1.weight      # leaves are shared
