@@ -345,7 +345,7 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
         skinny_supported(M, C, K, in_dtype, residual))                   // classifier heads: one wave per 32 x 32 tile
         return skinny_launch(x, w, scale, shift, y, M, C, K, act, out_dtype, st);
     const bool ok8 = igemm8_supported(M, C, K, R, S, 2LL * N * H * W * C, 2LL * K * R * S * C);
-    if (get_flag("igemm8") >= 2 && ok8)                                   // forced (tests): 2 = 256x256, 3 = 128x256, 4 = 256x128
+    if (get_flag("igemm8") >= 2 && get_flag("igemm8") <= 4 && ok8)                                   // forced (tests): 2 = 256x256, 3 = 128x256, 4 = 256x128
         return igemm8_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0,
                              get_flag("igemm8") - 1, st);
     const bool plain = !forced_old && !get_flag("no_stream");

@@ -379,18 +379,22 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
     char* ep = smem + wave * (32 * EPITCH);
     OutT* y = (OutT*)p.y;
     const int xrow0 = 128 * grp, wrow0 = 64 * wc;
+    // residual rows: fetched one pixel tile AHEAD of their use (two register sets, free now that the fragments are dead), so the
+    // HBM latency of tile b+1's rows hides under tile b's transpose + stores instead of being paid four times per block
+    R8<OutT> late[2][4];
+    auto fetch_res = [&](int b, R8<OutT>(&dst)[4]) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int m = m0 + xrow0 + b * 32 + pass * 8 + (lane >> 3);
+            const int n = n0 + wrow0 + (lane & 7) * 8;
+            const bool ok = m < p.M && n < p.K;
+            dst[pass].load(res + (ok ? (long long)m * p.K + n : 0));
+        }
+    };
+    if (res) fetch_res(0, late[0]);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        R8<OutT> late[4];
-        if (res) {
-#pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int m = m0 + xrow0 + b * 32 + pass * 8 + (lane >> 3);
-                const int n = n0 + wrow0 + (lane & 7) * 8;
-                const bool ok = m < p.M && n < p.K;
-                late[pass].load(res + (ok ? (long long)m * p.K + n : 0));
-            }
-        }
+        if (res && b + 1 < 4) fetch_res(b + 1, late[(b + 1) & 1]);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
             if (m < p.M && n < p.K) {
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 ss.apply(v);
-                if (res) late[pass].add_to(v);
+                if (res) late[b & 1][pass].add_to(v);
                 if (p.act == MV_ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -613,18 +617,20 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
 
     char* ep = smem + wave * (32 * EPITCH);
     OutT* y = (OutT*)p.y;
+    R8<OutT> late[2][4];                                     // both pixel tiles' residual rows, fetched before the first transpose
+    if (res) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        R8<OutT> late[4];
-        if (res) {
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int m = m0 + xrow0 + b * 32 + pass * 8 + (lane >> 3);
                 const int n = n0 + wrow0 + (lane & 7) * 8;
                 const bool ok = m < p.M && n < p.K;
-                late[pass].load(res + (ok ? (long long)m * p.K + n : 0));
+                late[b][pass].load(res + (ok ? (long long)m * p.K + n : 0));
             }
-        }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
             if (m < p.M && n < p.K) {
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 ss.apply(v);
-                if (res) late[pass].add_to(v);
+                if (res) late[b][pass].add_to(v);
                 if (p.act == MV_ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);

@@ -1,0 +1,90 @@
+#!/bin/bash
+# Round profiles: rocprofv3 kernel statistics of the bench command per model (in-situ durations, two graph lanes), HBM traffic
+# per launch from separate --pmc passes (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE), and an SQ pass with the
+# matrix-pipe busy counter.  usage: tools/profile_session.sh TAG  ->  gpurun_out/TAG/{MODEL}_*  (copy what matters to profiles/)
+TAG=${1:-prof}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/$TAG; mkdir -p $O
+for spec in resnet50:256 vit_base:256 swin_t:128; do
+  M=${spec%%:*}; B=${spec##*:}
+  CMD="python bench.py --model $M --batch $B --steps 20 --warmup 5 --no-cpu --extra none --soak 1"
+  timeout 400 $CMD --layers $O/${M}_per_launch.txt > $O/${M}_bench.json 2> $O/${M}_bench.err
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${M}_trace -o t -- $CMD > $O/${M}_trace.log 2>&1
+  t=$(find $O/${M}_trace -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/rocprof_trim.py $t $O/${M}_rocprofv3_warm_stats.txt
+  s=$(find $O/${M}_trace -name "*kernel_stats.csv" | head -1); [ -n "$s" ] && cp $s $O/${M}_rocprofv3_kernel_stats.csv
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/${M}_$C -o t -- python bench.py --model $M --batch $B --steps 3 --warmup 2 --no-cpu --extra none --soak 0 > $O/${M}_$C.log 2>&1
+  done
+  timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/${M}_SQ -o t -- python bench.py --model $M --batch $B --steps 2 --warmup 2 --no-cpu --extra none --soak 0 --no-graph > $O/${M}_SQ.log 2>&1
+done
+find $O -name "*.db" -delete
+O=$O python - <<'PY'
+import csv, glob, collections, json, os, re, statistics
+O = os.environ["O"]
+def fam(name):
+    n = name
+    if "igemm8_kernel<" in n: return "igemm8_dual_bf16_256x256" if ", true>" in n else "igemm8_bf16_256x256"
+    if "igemm8s_kernel<" in n:
+        arr = "128x256" if ", 0, " in n else "256x128"
+        return ("igemm8_dual_bf16_" if ", true>" in n else "igemm8_bf16_") + arr
+    for sub, f in (("unsigned short, true>", "igemm2_dual_bf16_256x256"), ("igemm2_kernel<4, 2, 2, 2, 3", "igemm2_bf16_256x128"),
+                   ("igemm2_kernel<2, 4, 4, 2, 2", "igemm2_bf16_256x256"), ("igemm2_kernel<8, 1, 1, 2, 3", "igemm2_bf16_256x64"),
+                   ("igemm_bf16_kernel<128, 128", "igemm_bf16_128x128"), ("igemm_bf16_kernel<128, 64", "igemm_bf16_128x64"),
+                   ("stream1x1_kernel", "stream1x1"), ("chain1x1_kernel<64, 8, false", "chain1x1_bf16_64_256_64"),
+                   ("chain1x1_kernel<128", "chain1x1_bf16_64_256_128"), ("chain1x1_kernel<64, 6, true", "chain1x1_dual_bf16_64+64_256_64"),
+                   ("conv3x3c64_v2_kernel", "conv3x3c64_halo"), ("stem_pool_kernel", "stem_pool_mfma_f32in"),
+                   ("patch_embed_kernel", "patch_embed_mfma_f32in"), ("mha_mfma_kernel", "mha_mfma_dh64_hm"),
+                   ("layernorm_vec_kernel", "layernorm_vec"), ("swin_attn_mfma", "swin_attn_mfma"), ("skinny_f32_kernel", "skinny_linear_f32_mfma")):
+        if sub in n: return f
+    return None
+out = {"_batch": {}, "_rocprof": {}}
+lines = []
+for M, B in (("resnet50", 256), ("vit_base", 256), ("swin_t", 128)):
+    acc = {"FETCH_SIZE": collections.defaultdict(list), "WRITE_SIZE": collections.defaultdict(list)}
+    for C in acc:
+        for f in glob.glob(f"{O}/{M}_{C}/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == C:
+                    k = fam(r["Kernel_Name"])
+                    if k: acc[C][k].append(float(r["Counter_Value"]))
+    tr = {}
+    for k in sorted(set(acc["FETCH_SIZE"]) | set(acc["WRITE_SIZE"])):
+        fs, ws = acc["FETCH_SIZE"].get(k, []), acc["WRITE_SIZE"].get(k, [])
+        rd = 2.0 * 1024.0 * sum(fs) / max(1, len(fs))           # KB, doubled (guide: gfx950 FETCH_SIZE = half of a coalesced stream)
+        wr = 1024.0 * sum(ws) / max(1, len(ws))
+        tr[k] = round(rd + wr)
+        lines.append(f"{M:9s} {k:34s} launches {len(fs):5d}  read {rd/1e6:9.2f} MB  write {wr/1e6:9.2f} MB  total {(rd+wr)/1e6:9.2f} MB per launch")
+    if tr:
+        out[M] = tr
+        out["_batch"][M] = B
+    # in-situ kernel durations (two graph lanes overlap): warm average per family
+    rp = collections.defaultdict(list)
+    for f in glob.glob(f"{O}/{M}_trace/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = fam(r["Kernel_Name"])
+            if k: rp[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    out["_rocprof"][M] = {}
+    for k, v in rp.items():
+        w = sorted(v)[: max(1, len(v) - max(1, len(v) // 50))]
+        out["_rocprof"][M][k] = {"avg_launch_us": round(sum(w) / len(w), 2), "calls": len(v), "file": f"profiles/r02/{M}_rocprofv3_warm_stats.txt"}
+    # SQ pass: MFMA busy fraction per family (busy cycles per SIMD / kernel cycles)
+    sq = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f"{O}/{M}_SQ/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = fam(r["Kernel_Name"])
+            if k: sq[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    with open(f"{O}/{M}_pmc_sq.txt", "w") as g:
+        g.write(f"# {M}: SQ counters per launch (mean over launches); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs)\n")
+        for k, d in sorted(sq.items()):
+            m = {c: sum(v) / len(v) for c, v in d.items()}
+            dur = m.get("SQ_BUSY_CYCLES", 0) / 32.0
+            frac = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024.0 / dur if dur else 0
+            g.write(f"{k:34s} n={len(next(iter(d.values()))):4d} mfma_busy_frac {frac:5.3f}  kernel_cycles {dur:12.0f}  " +
+                    "  ".join(f"{c}={m[c]:.3g}" for c in sorted(m)) + "\n")
+json.dump(out, open(f"{O}/traffic.json", "w"), indent=1)
+open(f"{O}/hbm_traffic_pmc.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+os.system(f"find {O} -size +3M -delete")
+PY
+cat $O/*_bench.json | cut -c1-400
+cat $O/*_pmc_sq.txt | cut -c1-200
