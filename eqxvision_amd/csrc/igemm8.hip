@@ -691,8 +691,12 @@ int igemm8_wanted(long long M, int C, int K, int R, int S) {
     if (nk < 4 || K < 96) return 0;
     const long long tm256 = (M + 255) / 256, tm128 = (M + 127) / 128;
     if (K <= 128) return tm256 >= 90 ? 3 : 0;
-    if (tm256 * ((K + 255) / 256) >= 150) return 1;
-    return tm128 * ((K + 255) / 256) >= 40 ? 2 : 0;
+    const long long tn = (K + 255) / 256, t256 = tm256 * tn, t128 = tm128 * tn;
+    // (a "rounds x relative tile time" refinement that prefers 128 x 256 tiles when the last round of big tiles is nearly empty
+    //  -- ViT fc2 at half batch: 154 -> 144 us alone -- LOSES 5% on the whole model: with two graph lanes the other lane's
+    //  kernels fill that round.  The plain threshold below is what tools/tune_tiles.py confirms on whole-model time.)
+    if (t256 >= 150) return 1;
+    return t128 >= 40 ? 2 : 0;
 }
 
 static int igemm8_go(Igemm2P& p, bool dual, bool out_f32, int tile, hipStream_t st) {
