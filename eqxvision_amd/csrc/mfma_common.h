@@ -13,6 +13,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// Lanes of ONE wave exchanging data through LDS with plain C++ stores and loads (epilogue transposes, V^T patches): the
+// hardware executes a wave's DS operations in order, but the compiler may not reorder or forward them across this point.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     // blocks are dispatched round-robin over the 8 XCDs; give each XCD a contiguous tile range
     const int q = nblk >> 3, r = nblk & 7;

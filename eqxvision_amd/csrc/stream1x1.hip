@@ -161,6 +161,7 @@ __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) 
                         *(float4*)(ep + fr * EPITCH + nl * 4) = v;
                     }
                 }
+                wave_lds_fence();                                  // patch written by all lanes -> read back row-major
                 const int c8 = lane & 7;
                 const int nloc = ps * BN + c * 64 + c8 * 8;        // my 8 channels inside the block's slab set
                 const float4 s0 = *(const float4*)(sct + nloc), s1 = *(const float4*)(sct + nloc + 4);
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) 
                         Out8<OutT>::st(y + (long long)m * p.N + n, v);
                     }
                 }
+                wave_lds_fence();                                  // before the patch is overwritten by the next chunk
             }
         }
     };

@@ -94,6 +94,8 @@ __global__ __launch_bounds__(256) void swin_attn_mfma_kernel(const SwinP p) {
             }
         }
 
+        wave_lds_fence();      // kreg / V^T written by the wave's lanes above, read by other lanes below
+
         // ---- K and Q fragments straight from global: token = 32*tile + fr, channels 16*kk + 8*fh .. +7
         uint4 kf[2][2], qf[2][2];
 #pragma unroll
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(256) void swin_attn_mfma_kernel(const SwinP p) {
                 }
             }
         }
+        wave_lds_fence();      // the next window's kreg / V^T overwrite what other lanes may still be reading
     }
 }
 

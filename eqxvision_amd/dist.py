@@ -24,7 +24,7 @@ import torch.distributed as dist
 
 from . import _lib
 
-_state = {"native": False}
+_state = {"native": False, "group": None}
 
 
 def _rccl_path() -> Optional[str]:
@@ -78,7 +78,14 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if world > 1 and collective == "rccl" and not _state["native"]:
-        native_comm_init(rank, world)
+        try:
+            native_comm_init(rank, world)
+        except _lib.MVError as e:
+            # The library's own RCCL binding could not come up (e.g. librccl not loadable): keep the run alive on PyTorch's
+            # binding of the SAME library -- a second process group with backend nccl (== RCCL); never a host-staged gather.
+            import warnings
+            warnings.warn(f"mv_comm_init failed ({e}); routing the logits all-gather through torch.distributed (nccl)")
+            _state["group"] = dist.new_group(backend="nccl")
     return rank, world, local
 
 
@@ -120,6 +127,8 @@ def _torch_all_gather(out: torch.Tensor, local: torch.Tensor, group=None) -> Non
 def all_gather_rows(local: torch.Tensor, batch: int, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Gather per-rank `[b_r, ...]` row blocks into `[batch, ...]` on every rank (rank order)."""
     native = _state["native"] and group is None and local.is_cuda
+    if group is None and not native and _state["group"] is not None:
+        group = _state["group"]
     if native:
         world = _lib.load().mv_comm_size()
     elif dist.is_initialized():

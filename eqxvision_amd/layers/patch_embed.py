@@ -56,4 +56,10 @@ class PatchEmbed(Module):
                 from .._act import Act
                 B, gh, gw, D = t.t.shape
                 t = Act(t.t.reshape(B, gh * gw, D), "seq", t.batched)
+        if isinstance(self.norm, nn.LayerNorm) and self.flatten:
+            # reference patch_embed.py:82-83 calls eqx.nn.LayerNorm(embed_dim) on the whole (P, D) array: the equinox the
+            # reference targets normalises over ALL P*D elements, newer ones reject the shape, timm normalises per token.
+            # Three different answers -- refuse instead of silently picking one (no hot config uses it: vit.py:224-228).
+            raise NotImplementedError("PatchEmbed(norm_layer=LayerNorm) on flattened tokens is ambiguous across equinox versions; "
+                                      "apply the LayerNorm to the returned tokens explicitly")
         return self.norm(t)

@@ -533,6 +533,10 @@ def layernorm_first_row(x: Act, ln, out_fp32: bool = False) -> Act:
 def batchnorm(x: Act, bn, act=None) -> Act:
     """Stand-alone BatchNorm inference (unfused call sites): per-channel affine."""
     _check_bn(bn)
+    if x.kind == "seq":
+        # eqx.experimental.BatchNorm treats AXIS 0 of the single-sample array as channels; a (tokens, features) array would be
+        # normalised per token there, per feature here -- refuse instead of returning different numbers (round-1 advice)
+        raise NotImplementedError("BatchNorm on a (tokens, features) array: the reference normalises axis 0; not on the hot path")
     x = as_map(x) if x.kind in ("img", "map") else as_rows(x)
     cache = bn._cache()
     hit = cache.get("fold")
