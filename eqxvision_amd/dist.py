@@ -39,11 +39,16 @@ def native_comm_init(rank: int, world: int) -> None:
         os.environ["EQV_RCCL_LIB"] = _rccl_path()      # the copy PyTorch already mapped: one RCCL per process
     box = [None]
     if rank == 0:
-        buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
-        _lib.call("mv_comm_unique_id", buf, _lib.COMM_ID_BYTES)
-        box[0] = bytes(buf.raw)
+        try:
+            buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+            _lib.call("mv_comm_unique_id", buf, _lib.COMM_ID_BYTES)
+            box[0] = bytes(buf.raw)
+        except _lib.MVError as e:          # tell the other ranks instead of leaving them in the broadcast
+            box[0] = f"ERR {e}"
     if world > 1:
         dist.broadcast_object_list(box, src=0)
+    if not isinstance(box[0], bytes):
+        raise _lib.MVError(f"rank 0 could not create the RCCL unique id: {box[0]}")
     uid = ctypes.create_string_buffer(box[0], _lib.COMM_ID_BYTES)
     _lib.call("mv_comm_init", rank, world, uid)
     _state["native"] = True
