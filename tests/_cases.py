@@ -746,7 +746,7 @@ def misc_case(kind, dtype="bf16", seed=0):
     return run
 
 
-def fuzz_cases(n, seed=0, mfma_only=False):
+def fuzz_cases(n, seed=0, mfma_only=False, flags=()):
     """`n` random convolution / linear shapes for the DEFAULT dispatch (tools/fuzz_ops.py and the `fuzz/` pytest cases):
     any tap count / stride / padding / dilation / residual / activation / output dtype, sized so the oracle stays fast."""
     rng = np.random.default_rng(seed)
@@ -771,7 +771,7 @@ def fuzz_cases(n, seed=0, mfma_only=False):
             o = "fp32" if rng.random() < 0.25 else "same"
             name = f"fuzz/s{seed}_conv_N{N}_{H}x{W}_C{C}_K{K}_{R}x{R}_s{stride}_p{pad}_d{dil}_a{act}_r{int(res)}_{o}"
             out.append((name, conv_nhwc_case(N, H, W, C, K, R, R, stride=stride, pad=pad, dil=dil, act=act, res=res, out=o,
-                                             seed=1000 + i)))
+                                             seed=1000 + i, flags=flags)))
         else:
             K = int(rng.choice(ch + [1024, 2048, 3072]))
             Nn = int(rng.choice(ch + [1000, 1024, 2304]))
@@ -781,7 +781,7 @@ def fuzz_cases(n, seed=0, mfma_only=False):
             res = bool(rng.random() < 0.4)
             o = "fp32" if rng.random() < 0.3 else "same"
             name = f"fuzz/s{seed}_linear_M{M}_K{K}_N{Nn}_a{act}_r{int(res)}_{o}"
-            out.append((name, linear_case(M, K, Nn, act=act, res=res, out=o, seed=2000 + i)))
+            out.append((name, linear_case(M, K, Nn, act=act, res=res, out=o, seed=2000 + i, flags=flags)))
     return out
 
 

@@ -11,7 +11,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 fails = 0
 kernels = {}
-cases = T.fuzz_misc_cases(n, seed) if os.environ.get("MISC") else T.fuzz_cases(n, seed, mfma_only=bool(os.environ.get("MFMA_ONLY")))
+flags = tuple(f for f in os.environ.get("FUZZ_FLAGS", "").split(",") if f)      # e.g. FUZZ_FLAGS=igemm8=3 forces a kernel family
+cases = T.fuzz_misc_cases(n, seed) if os.environ.get("MISC") else T.fuzz_cases(n, seed, mfma_only=bool(os.environ.get("MFMA_ONLY")),
+                                                                               flags=flags)
 for name, fn in cases:
     try:
         info = fn()
