@@ -61,7 +61,15 @@ int mv_set_flag(const char* name, int value) {
     if (!name) return MV_E_INVALID;
     if (value == 0) mv::g_flags.erase(name);
     else mv::g_flags[name] = value;
-    ++mv::g_flags_epoch;
+    // "epoch" = a hash of the current switch settings (std::map iterates in key order): setting a switch and setting it back
+    // gives the first value again, so a recorded launch list is re-used exactly when the switches it was recorded under are back
+    unsigned h = 2166136261u;
+    for (const auto& kv : mv::g_flags) {
+        for (char c : kv.first) h = (h ^ (unsigned char)c) * 16777619u;
+        h = (h ^ (unsigned)kv.second) * 16777619u;
+        h = (h ^ 0xffu) * 16777619u;
+    }
+    mv::g_flags_epoch = mv::g_flags.empty() ? 0 : (int)(h & 0x7fffffffu);
     return MV_OK;
 }
 int mv_flags_epoch(void) { return mv::g_flags_epoch; }

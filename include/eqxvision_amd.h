@@ -46,7 +46,7 @@ int mv_abi_version(void);
 const char* mv_last_error(void);
 int mv_set_flag(const char* name, int value);   /* flags are per calling THREAD, like mv_last_error */
 int mv_get_flag(const char* name);
-int mv_flags_epoch(void);                        /* bumped by every mv_set_flag on this thread (recorded launch lists key on it) */
+int mv_flags_epoch(void);                        /* hash of this thread's current switch settings (0 = all default): recorded launch lists key on it */
 /* name of the kernel variant the last call on this thread dispatched to (for tests/bench) */
 const char* mv_last_kernel(void);
 

@@ -27,6 +27,8 @@ for v in (0, 1):
 torch.cuda.synchronize()
 for r in range(reps):
     for v in (0, 1):
+        if not flag.startswith("lanes"):
+            _lib.set_flag(flag, v * int(os.environ.get('FLAGVAL', '1')))      # the jit cache keys on the switch settings
         e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
         e0.record()
         for _ in range(20): fw[v](net, images, keys)
