@@ -88,30 +88,68 @@ def layer_table(compiled, path, steps=5):
         us = 1e3 * float(np.median(ts))
         flops = byts = 0.0
         shape = ""
+        ob = lambda dt: 4.0 if dt == 0 else 2.0                   # bytes per element of an MV_F32 / MV_BF16 tensor
         if name == "mv_conv2d_nhwc_fwd":
             N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, g = args[6:20]
+            idt, odt = args[21], args[22]
             Ho = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1
             Wo = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
             flops = 2.0 * N * Ho * Wo * K * R * S * C / g
-            byts = 2.0 * (N * H * W * C + K * R * S * C / g + N * Ho * Wo * K * (2 if args[4] else 1))
+            byts = ob(idt) * (N * H * W * C + K * R * S * C / g) + ob(odt) * N * Ho * Wo * K * (2 if args[4] else 1)
             shape = f"N{N} {H}x{W}x{C}->{Ho}x{Wo}x{K} k{R}s{sh}"
-        elif name == "mv_linear_fwd":
+        elif name in ("mv_linear_fwd", "mv_linear_split_fwd"):
             M, N, K = args[6:9]
+            idt, odt = args[10], args[11]
+            split = 2 if name == "mv_linear_split_fwd" else 1
+            flops = 2.0 * M * N * K * split
+            byts = ob(idt) * (M * K + split * N * K) + ob(odt) * M * N * (2 if args[4] else 1)
+            shape = f"M{M} K{K} N{N}" + (" f32out" if odt == 0 else "") + (" +res" if args[4] else "") + (" hi+lo" if split == 2 else "")
+        elif name == "mv_linear_heads_fwd":
+            M, N, K = args[5:8]
             flops = 2.0 * M * N * K
-            byts = 2.0 * (M * K + N * K + M * N * (2 if args[4] else 1))
-            shape = f"M{M} K{K} N{N}"
-        elif name == "mv_conv2d_nchw_fwd":
-            N, C, H, W, K, R, S, sh, sw, ph, pw = args[5:16]
+            byts = 2.0 * (M * K + N * K + M * N)
+            shape = f"M{M} K{K} N{N} head-major"
+        elif name == "mv_conv1x1_dual_fwd":
+            N, Ho, Wo, C1, H2, W2, C2, s2, K = args[6:15]
+            M = N * Ho * Wo
+            flops = 2.0 * M * K * (C1 + C2)
+            byts = 2.0 * (M * C1 + M * C2 + K * (C1 + C2) + M * K)
+            shape = f"M{M} {C1}+{C2}(s{s2})->{K}"
+        elif name == "mv_conv1x1_chain_fwd":
+            M, C, K, N2 = args[10:14]
+            flops = 2.0 * M * (C * K + K * N2)
+            byts = 2.0 * M * (C + 2 * K + N2)
+            shape = f"M{M} {C}->{K}(+res)->{N2}"
+        elif name == "mv_conv1x1_dual_chain_fwd":
+            M, C1, C2, K, N2 = args[10:15]
+            flops = 2.0 * M * ((C1 + C2) * K + K * N2)
+            byts = 2.0 * M * (C1 + C2 + K + N2)
+            shape = f"M{M} {C1}+{C2}->{K}->{N2}"
+        elif name == "mv_stem_conv_pool_fwd":
+            N, C, H, W, K, R, S, sh, sw, ph, pw, pk, ps, pp = args[5:19]
+            Ho, Wo = (H + 2 * ph - R) // sh + 1, (W + 2 * pw - S) // sw + 1
+            Po, Qo = (Ho + 2 * pp - pk) // ps + 1, (Wo + 2 * pp - pk) // ps + 1
+            flops = 2.0 * N * Ho * Wo * K * R * S * C
+            byts = ob(args[20]) * N * C * H * W + 2.0 * N * Po * Qo * K
+            shape = f"N{N} {C}x{H}x{W}->conv{Ho}x{Wo}->pool{Po}x{Qo}x{K}"
+        elif name in ("mv_conv2d_nchw_fwd", "mv_conv2d_nchw_split_fwd"):
+            o = 1 if name.endswith("split_fwd") else 0
+            N, C, H, W, K, R, S, sh, sw, ph, pw = args[5 + o:16 + o]
             Ho = (H + 2 * ph - R) // sh + 1
             Wo = (W + 2 * pw - S) // sw + 1
-            flops = 2.0 * N * Ho * Wo * K * R * S * C
+            flops = 2.0 * N * Ho * Wo * K * R * S * C * (1 + o)
             byts = 4.0 * N * C * H * W + 2.0 * N * Ho * Wo * K
-            shape = f"N{N} {C}x{H}x{W}->{Ho}x{Wo}x{K} k{R}s{sh}"
-        elif name == "mv_mha_fwd":
+            shape = f"N{N} {C}x{H}x{W}->{Ho}x{Wo}x{K} k{R}s{sh}" + (" hi+lo" if o else "")
+        elif name in ("mv_mha_fwd", "mv_mha_heads_fwd"):
             B, N, H, dh = args[3:7]
             flops = 4.0 * B * H * N * N * dh
             byts = 2.0 * B * N * H * dh * 4
             shape = f"B{B} N{N} H{H} dh{dh}"
+        elif name == "mv_swin_window_attn_fwd":
+            B, Hf, Wf, C, heads, wh, ww = args[3:10]
+            flops = 4.0 * B * Hf * Wf * (wh * ww) * C
+            byts = 2.0 * B * Hf * Wf * C * 4
+            shape = f"B{B} {Hf}x{Wf}x{C} h{heads} w{wh}"
         elif name == "mv_maxpool2d_nhwc_fwd":
             N, H, W, C, kh, kw, sh, sw, ph, pw = args[2:12]
             Ho = (H + 2 * ph - kh) // sh + 1
@@ -119,7 +157,7 @@ def layer_table(compiled, path, steps=5):
             shape = f"N{N} {H}x{W}x{C}"
         elif name == "mv_layernorm_fwd":
             M, C = args[4:6]
-            byts = float(M) * C * sum(4 if d == 2 else 2 for d in args[8:10])
+            byts = float(M) * C * (ob(args[8]) + ob(args[9]))
             shape = f"M{M} C{C}"
         rows.append({"call": name, "kernel": kern, "shape": shape, "us": round(us, 2),
                      "tflops": round(flops / us / 1e6, 1) if us else 0, "gbs": round(byts / us / 1e3, 1) if us else 0,

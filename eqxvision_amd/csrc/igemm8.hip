@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
 #endif
     const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     int tile_m, tile_n;
-    tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n);
+    tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n, p.gm);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---------------- DMA addressing ---------------------------------------------------------------------
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
     const int wrow0 = ARR == 0 ? 64 * (wave & 3) : 64 * ((wave >> 1) & 1);
     const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     int tile_m, tile_n;
-    tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n);
+    tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n, p.gm);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int srow = lane >> 3;
@@ -703,6 +703,7 @@ static int igemm8_go(Igemm2P& p, bool dual, bool out_f32, int tile, hipStream_t 
     const int bm = tile == 1 ? 128 : 256, bn = tile == 2 ? 128 : 256;
     p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = (p.K + bn - 1) / bn;
+    p.gm = get_flag("i8_gm") ? get_flag("i8_gm") : 8;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(512);
 #define GO(KERN, SMEM)                                                                                            \
     do {                                                                                                          \

@@ -32,8 +32,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // slow index.  The ~32 blocks an XCD runs concurrently then form a (GM pixel tiles) x (32/GM channel
 // tiles) patch: every x tile is shared by 32/GM blocks and every weight tile by GM blocks out of the
 // XCD's 4 MB L2, instead of streaming all weight tiles through it for every pixel tile.
-__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
-    constexpr int GM = 8;
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int& tile_m, int& tile_n, int gm = 8) {
+    const int GM = gm;
     const int per_group = GM * tiles_n;
     const int group = t / per_group, r = t - group * per_group;
     const int gm0 = group * GM;
