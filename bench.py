@@ -272,6 +272,7 @@ def run_model(a, name, B, rank, world, soak_s):
     gemm = {k: v for k, v in fam.items() if v["gflop"] > 0}
     dk, dv = max((gemm or fam or {"n/a": {"us": 1, "gflop": 0, "mb": 0, "n": 1}}).items(), key=lambda kv: kv[1]["us"])
     dom_tflops = dv["gflop"] / dv["us"] * 1e3 if dv["us"] else 0.0   # GFLOP/us = PFLOP/s
+    bound_us = sum(max(r_["gflop"] * 1e3 / MFMA_PEAK_TFLOPS, r_["mb"] / HBM_PEAK_GBS * 1e3) for r_ in rows)
     traffic = ref = None
     tj = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per launch + rocprof averages, if collected
     if os.path.exists(tj) and world == 1:
@@ -290,7 +291,10 @@ def run_model(a, name, B, rank, world, soak_s):
             "kernel_hbm_gbs": round(dv["mb"] / dv["us"] * 1e3, 1) if dv["us"] else 0.0,
             "whole_forward": {"achieved": round(achieved, 1), "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                               "graph_launch_ms": round(dev_ms_per_step, 4), "flop_per_launch": flop_per_launch,
-                              "hbm_layerwise_bound_frac": 0.418 if name == "resnet50" else None}}
+                              # layer-wise speed of light: sum over launches of max(flops / MFMA peak, algorithmic bytes /
+                              # HBM peak) over the measured step (1.0 = every launch on its own roofline, nothing overlapped)
+                              "layerwise_bound_ms": round(bound_us / 1e3, 4),
+                              "layerwise_bound_frac": round(bound_us / 1e3 / dev_ms_per_step, 4)}}
     if ref:                                   # {"avg_launch_us": in-situ rocprofv3 average, "file": ...}
         roof["rocprof"] = dict(ref, frac=round(dv["gflop"] / max(1, dv["n"]) / ref["avg_launch_us"] * 1e3 / MFMA_PEAK_TFLOPS, 4))
     res = {"value": round(B * world * a.steps / dt, 1), "ms_per_step": round(1e3 * dt / a.steps, 4),

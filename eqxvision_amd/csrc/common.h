@@ -35,17 +35,31 @@ template <> struct io<bf16_t> {
 };
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    // jax.nn.gelu(approximate=True): 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))
-    // 0.5x(1+tanh(u)) = x * e/(e+1) with e = exp(2u) = exp2(2u*log2(e)); one v_exp_f32 + one v_rcp_f32
-    // (hardware approximations, ~1 ulp) instead of an IEEE division: the epilogue of the 768->3072 fc1
-    // GEMM spent ~28% of the layer in this function.  Clamped so e stays finite.
-    const float c0 = 2.0f * 0.7978845608028654f * 1.4426950408889634f;   // 2*sqrt(2/pi)*log2(e)
-    const float c1 = c0 * 0.044715f;
-    const float x2 = x * x;
-    float t = x * fmaf(c1, x2, c0);
-    t = fminf(t, 60.0f);
-    const float e = __builtin_amdgcn_exp2f(t);
-    return x * e * __builtin_amdgcn_rcpf(e + 1.0f);
+    // jax.nn.gelu(approximate=True): 0.5x(1+tanh(u)), u = sqrt(2/pi)(x+0.044715x^3)
+    // 0.5(1+tanh(u)) = 1/(1+exp(-2u)), exp(-2u) = exp2(x*(k0 + k1*x^2)): one v_exp_f32 + one v_rcp_f32 (hardware
+    // approximations, ~1 ulp) and four plain VALU ops; no IEEE division, no clamp (exp2 -> +inf gives rcp -> 0 -> -0, the
+    // limit for very negative x; exp2 -> 0 gives x).  The epilogue of the 768->3072 fc1 GEMM spent ~28% of the layer in the
+    // first version of this function, and the fused Swin MLP kernel (ln_mlp.hip) is bound by it.
+    const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;  // -2*sqrt(2/pi)*log2(e)
+    const float k1 = k0 * 0.044715f;
+    const float t = x * fmaf(k1, x * x, k0);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+}
+
+// Two activations at once on the packed-fp32 VALU ops (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 take two values per
+// lane per issue slot); the two transcendentals per value stay scalar.  Returns the bf16 pair.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t gelu_tanh_pack2(float a, float b) {
+    const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+    const float k1 = k0 * 0.044715f;
+    f32x2_t x = {a, b};
+    const f32x2_t kk0 = {k0, k0}, kk1 = {k1, k1}, one = {1.0f, 1.0f};
+    f32x2_t t = x * __builtin_elementwise_fma(kk1, x * x, kk0);
+    f32x2_t e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    e = e + one;
+    f32x2_t r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    x = x * r;
+    return pack_bf2(x[0], x[1]);
 }
 
 template <int ACT> __device__ __forceinline__ float apply_act(float v) {
@@ -102,6 +116,9 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
 int stream1x1_supported(int C, int K, int in_dtype, int out_dtype, long long M);
 int stream1x1_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                      void* y, long long M, int C, int K, int act, int out_dtype, hipStream_t stream);
+int ln_mlp_supported(long long M, int C, int hidden, int x_dtype);
+int ln_mlp_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, long long M,
+                  float eps, int x_dtype, hipStream_t st);
 int conv3x3c64_supported(int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int in_dtype,
                          int out_dtype, const void* residual, long long M);
 int igemm2_wanted(long long M, int C, int K, int R, int S);

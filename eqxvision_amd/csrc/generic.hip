@@ -828,6 +828,21 @@ int mv_linear_split_fwd(const void* x, const void* w_hi_lo, const float* scale, 
                               (hipStream_t)stream);
 }
 
+int mv_ln_mlp_supported(int64_t M, int C, int hidden, int x_dtype) {
+    return !get_flag("force_generic") && ln_mlp_supported(M, C, hidden, x_dtype);
+}
+
+int mv_ln_mlp_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int64_t M, int C,
+                  int hidden, float eps, int x_dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && w1 && b1 && w2 && b2 && y, "ln_mlp: NULL pointer");
+    MV_CHECK_ARG(x != y, "ln_mlp: in-place is not supported (rows are re-read for the residual add)");
+    if (!mv_ln_mlp_supported(M, C, hidden, x_dtype)) {
+        set_error("ln_mlp: unsupported configuration M=%lld C=%d hidden=%d (ask mv_ln_mlp_supported first)", (long long)M, C, hidden);
+        return MV_E_UNSUPPORTED;
+    }
+    return ln_mlp_launch(x, w1, b1, w2, b2, y, M, eps, x_dtype, (hipStream_t)stream);
+}
+
 int mv_conv2d_nchw_split_fwd(const void* x, const void* w_hi, const void* w_lo, const float* scale, const float* shift,
                              void* y, int N, int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act,
                              int x_dtype, int out_dtype, mv_stream_t stream) {

@@ -143,6 +143,10 @@ class _SwinTransformerBlock(Module):
         sd = self.stochastic_depth
         if sd.inference or sd.p == 0.0:
             x = self.attn._forward(self.norm1(x), residual=x)
+            if isinstance(self.mlp, MlpProjection):
+                y = ops.ln_mlp(x, self.norm2, self.mlp)              # one launch where the weights fit in LDS (stage 0)
+                if y is not None:
+                    return y
             return self.mlp._forward(self.norm2(x), residual=x)
         x = ops.add(x, sd(self.attn._forward(self.norm1(x)), key=key))
         return ops.add(x, sd(self.mlp._forward(self.norm2(x)), key=key))

@@ -509,6 +509,43 @@ def layernorm(x: Act, ln, out_fp32: bool = False) -> Act:
     return Act(y, x.kind, x.batched)
 
 
+def ln_mlp(x: Act, ln, mlp) -> Optional[Act]:
+    """x + mlp(ln(x)) in ONE launch where the library has the fused kernel (narrow rows: Swin stage 0), else None.
+    The LayerNorm affine is folded into fc1 on the host (fp32, then one bf16 rounding of the product)."""
+    from . import nn
+    if compute_dtype() != "bf16" or x.kind not in ("map", "seq") or x.t.dtype not in (torch.float32, torch.bfloat16):
+        return None
+    fc1, fc2 = mlp.fc1, mlp.fc2
+    if not (isinstance(fc1, nn.Linear) and isinstance(fc2, nn.Linear) and isinstance(ln, nn.LayerNorm)):
+        return None
+    if any(not (d.inference or d.p == 0.0) for d in (mlp.drop1, mlp.drop2) if isinstance(d, nn.Dropout)):
+        return None
+    if nn.act_name(mlp.act) != "gelu" or fc1.bias is None or fc2.bias is None or ln.weight is None or ln.bias is None:
+        return None
+    C, Hd = fc1.in_features, fc1.out_features
+    if x.t.shape[-1] != C or fc2.in_features != Hd or fc2.out_features != C or int(np.prod(ln.shape)) != C:
+        return None
+    M = x.t.numel() // C
+    xdt = _lib.F32 if x.t.dtype == torch.float32 else _lib.BF16
+    if not _lib.load().mv_ln_mlp_supported(M, C, Hd, xdt):
+        return None
+    cache = mlp._cache()
+    key = ("ln_mlp", id(ln.weight), id(ln.bias))
+    hit = cache.get(key)
+    if hit is None:
+        w1 = np.asarray(fc1.weight, np.float32)
+        g, b = np.asarray(ln.weight, np.float32).reshape(-1), np.asarray(ln.bias, np.float32).reshape(-1)
+        hit = (_dev(w1 * g[None, :], torch.bfloat16),
+               _dev(np.asarray(fc1.bias, np.float32).reshape(-1) + w1 @ b, torch.float32),
+               _dev(np.asarray(fc2.weight, np.float32), torch.bfloat16),
+               _dev(np.asarray(fc2.bias, np.float32).reshape(-1), torch.float32), ln)        # ln: keeps the ids alive
+        cache[key] = hit
+    y = empty(tuple(x.t.shape), x.t.dtype)
+    _lib.call("mv_ln_mlp_fwd", _ptr(x.t), _ptr(hit[0]), _ptr(hit[1]), _ptr(hit[2]), _ptr(hit[3]), _ptr(y), M, C, Hd,
+              float(ln.eps), xdt, stream_ptr())
+    return Act(y, x.kind, x.batched)
+
+
 def cast(x: Act, dtype: str) -> Act:
     if x.t.dtype == TORCH_DT[dtype]:
         return x

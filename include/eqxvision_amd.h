@@ -38,7 +38,7 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  * "igemm8" (2 / 3 / 4 = force the ping-pong GEMM with 256x256 / 128x256 / 256x128 tiles), "no_igemm8",
  * "igemm2_tile" (1 / 2 / 3 = force igemm2 with 256x64 / 256x128 / 256x256 tiles), "no_igemm2", "igemm2_dense_m",
  * "igemm_tile" (1 / 2 = force the 128x128 / 128x64 kernel), "res_early", "no_stream" (no streaming 1x1 / 3x3c64 kernels),
- * "stream_npass1", "stem_v0", "no_stem_pool", "no_dual", "no_chain", "no_dual_chain", "no_skinny", "no_tuned", and the
+ * "stream_npass1", "stem_v0", "no_stem_pool", "no_dual", "no_chain", "no_dual_chain", "no_ln_mlp", "no_skinny", "no_tuned", and the
  * per-shape kernel choice "ov:<M>:<C>:<K>:<R>:<S>:<stride>" / "ovh:<M>:<N>:<K>:1:1:1" / "ovd:<M>:<C1>:<C2>:<K>:<stride>:1"
  * (tools/tune_tiles.py; codes in csrc/igemm.hip). */
 
@@ -142,6 +142,16 @@ int mv_linear_split_fwd(const void* x, const void* w_hi_lo, const float* scale, 
 int mv_conv2d_nchw_split_fwd(const void* x, const void* w_hi, const void* w_lo, const float* scale, const float* shift,
                              void* y, int N, int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw,
                              int act, int x_dtype, int out_dtype, mv_stream_t stream);
+
+/* The MLP half of a pre-norm block in ONE launch (swin.py:572-578 `x + stochastic_depth(mlp(norm2(x)))` in inference,
+ * mlps.py:54-66, extensions_2d.py:9-28), for narrow rows whose two weight matrices fit in LDS (C = 96, hidden = 384: Swin
+ * stage 0, where the hidden activations are 154 MB per 64 images):
+ *   y[m,:] = x[m,:] + w2 . gelu_tanh( w1 . n(x[m,:]) + b1 ) + b2,   n(x) = (x - mean) * rsqrt(var + eps)   (biased var)
+ * The LayerNorm affine is folded by the caller: w1 = W1 . diag(gamma) (bf16 [hidden][C]), b1 = b1 + W1 . beta (fp32);
+ * w2 bf16 [C][hidden], b2 fp32.  x and y share x_dtype (MV_F32 = the fp32 residual stream, or MV_BF16); not in place. */
+int mv_ln_mlp_supported(int64_t M, int C, int hidden, int x_dtype);
+int mv_ln_mlp_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int64_t M, int C,
+                  int hidden, float eps, int x_dtype, mv_stream_t stream);
 
 /* eqx.nn.MaxPool2d (resnet.py:254, alexnet.py:46,49,56): -inf padding, floor output size. */
 int mv_maxpool2d_nhwc_fwd(const void* x, void* y, int N, int H, int W, int C,

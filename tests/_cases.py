@@ -383,6 +383,58 @@ def linear_split_case(M, K, N, out="fp32", seed=0):
     return run
 
 
+def ln_mlp_case(M, stream="fp32", seed=0, C=96, Hd=384):
+    """mv_ln_mlp_fwd (LayerNorm -> fc1 -> GELU -> fc2 -> + x, one launch) vs the un-fused float64 restatement
+    (swin.py:572-578 second line, mlps.py:54-66) with the affine LayerNorm applied the reference's way; the kernel gets the
+    affine folded into fc1."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        x = (rng.standard_normal((M, C)) * rng.uniform(0.5, 2.0, (M, 1)) + rng.uniform(-1, 1, (M, 1))).astype(np.float32)
+        if stream == "bf16":
+            x = bf(x)
+        g = rng.uniform(0.5, 1.5, C).astype(np.float32)
+        be = (0.1 * rng.standard_normal(C)).astype(np.float32)
+        w1 = (rng.standard_normal((Hd, C)) / np.sqrt(C)).astype(np.float32)
+        b1 = (0.1 * rng.standard_normal(Hd)).astype(np.float32)
+        w2 = (rng.standard_normal((C, Hd)) / np.sqrt(Hd)).astype(np.float32)
+        b2 = (0.1 * rng.standard_normal(C)).astype(np.float32)
+        xdt = 0 if stream == "fp32" else 1
+        if not L.load().mv_ln_mlp_supported(M, C, Hd, xdt):
+            return {"ok": False, "err": "mv_ln_mlp_supported says no"}
+        n = O.layernorm_rows(x, g, be, 1e-5).astype(np.float64)
+        h = O.gelu_tanh(n @ w1.astype(np.float64).T + b1).astype(np.float64)
+        ref = x.astype(np.float64) + h @ w2.astype(np.float64).T + b2
+        w1f = bf(w1 * g[None, :])
+        b1f = (b1 + w1 @ be).astype(np.float32)
+        xd = dev(x, stream)
+        w1d, b1d, w2d, b2d = dev(w1f, "bf16"), dev(b1f, "fp32"), dev(bf(w2), "bf16"), dev(b2, "fp32")
+        y = torch.empty_like(xd)
+        L.call("mv_ln_mlp_fwd", xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), y.data_ptr(),
+               M, C, Hd, 1e-5, xdt, _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, TOL_BF16)
+        info["kernel"] = kern
+        # the same numbers from the three separate launches (LayerNorm, fc1+GELU, fc2+residual): the fused kernel must not be
+        # further from the float64 reference than they are (plus rounding noise)
+        gd, bed = dev(g, "fp32"), dev(be, "fp32")
+        nb = torch.empty((M, C), dtype=torch.bfloat16, device="cuda")
+        L.call("mv_layernorm_fwd", xd.data_ptr(), gd.data_ptr(), bed.data_ptr(), nb.data_ptr(), M, C, 0, 1e-5, xdt, 1, _stream())
+        hb = torch.empty((M, Hd), dtype=torch.bfloat16, device="cuda")
+        w1u, b1u = dev(bf(w1), "bf16"), dev(b1, "fp32")
+        L.call("mv_linear_fwd", nb.data_ptr(), w1u.data_ptr(), None, b1u.data_ptr(), None, hb.data_ptr(), M, Hd, C, 2, 1, 1, _stream())
+        y3 = torch.empty_like(xd)
+        L.call("mv_linear_fwd", hb.data_ptr(), w2d.data_ptr(), None, b2d.data_ptr(), xd.data_ptr(), y3.data_ptr(), M, C, Hd, 0, 1,
+               xdt, _stream())
+        torch.cuda.synchronize()
+        e3 = float(np.abs(host(y3).astype(np.float64) - ref).max())
+        info["err_unfused"] = e3
+        info["ok"] = info["ok"] and "ln_mlp" in kern and info["err"] <= 1.5 * e3 + 1e-3
+        return info
+    return run
+
+
 def conv_nchw_split_case(N, C, H, K, R, stride, seed=0):
     """mv_conv2d_nchw_split_fwd (entry conv with hi + lo weights) vs float64 on the un-rounded weights."""
     def run():
@@ -925,6 +977,9 @@ def all_cases():
           ("split/linear_swin_merge_384_192", linear_split_case(128 * 28 * 28 // 4, 384, 192, seed=511)),
           ("split/linear_swin_merge_1536_768", linear_split_case(64 * 49, 1536, 768, seed=512)),
           ("split/linear_bf16out_ragged", linear_split_case(9000 + 37, 256, 200, out="bf16", seed=513)),
+          ("ln_mlp/swin_stage0_f32stream", ln_mlp_case(8 * 56 * 56, "fp32", seed=520)),
+          ("ln_mlp/bf16stream_ragged", ln_mlp_case(4096 + 77, "bf16", seed=521)),
+          ("ln_mlp/f32stream_many_tiles", ln_mlp_case(70001, "fp32", seed=522)),
           ("split/conv_swin_patch4", conv_nchw_split_case(3, 3, 224, 96, 4, 4, seed=514)),
           ("split/conv_odd_k3s2", conv_nchw_split_case(2, 3, 65, 40, 3, 2, seed=515)),
           ("chain/56x56_B4", chain_case(4 * 56 * 56, seed=1)),
