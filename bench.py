@@ -104,6 +104,16 @@ def layer_table(compiled, path, steps=5):
             flops = 2.0 * M * N * K * split
             byts = ob(idt) * (M * K + split * N * K) + ob(odt) * M * N * (2 if args[4] else 1)
             shape = f"M{M} K{K} N{N}" + (" f32out" if odt == 0 else "") + (" +res" if args[4] else "") + (" hi+lo" if split == 2 else "")
+        elif name == "mv_ln_linear_fwd":
+            M, N, K = args[4:7]
+            flops = 2.0 * M * N * K
+            byts = ob(args[9]) * M * K + 2.0 * N * K + 2.0 * M * N
+            shape = f"M{M} K{K} N{N} LN-in" + (" f32in" if args[9] == 0 else "")
+        elif name == "mv_ln_mlp_fwd":
+            M, C, Hd = args[6:9]
+            flops = 4.0 * M * C * Hd
+            byts = 2.0 * ob(args[10]) * M * C + 4.0 * C * Hd
+            shape = f"M{M} C{C} hidden{Hd} LN+MLP+res"
         elif name == "mv_linear_heads_fwd":
             M, N, K = args[5:8]
             flops = 2.0 * M * N * K

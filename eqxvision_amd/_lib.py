@@ -38,6 +38,8 @@ PROTOTYPES = {
     "mv_linear_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
     "mv_linear_split_supported": [_i64, _i, _i, _i],
     "mv_linear_split_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
+    "mv_ln_linear_supported": [_i64, _i, _i, _i, _i],
+    "mv_ln_linear_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _i, _i, _vp],
     "mv_ln_mlp_supported": [_i64, _i, _i, _i],
     "mv_ln_mlp_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp],
     "mv_conv2d_nchw_split_fwd": [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_i, _i, _i, _vp],

@@ -119,6 +119,9 @@ int stream1x1_launch(const void* x, const void* w, const float* scale, const flo
 int ln_mlp_supported(long long M, int C, int hidden, int x_dtype);
 int ln_mlp_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, long long M,
                   float eps, int x_dtype, hipStream_t st);
+int stream1x1_ln_supported(long long M, int C, int K, int x_dtype, int out_dtype);
+int stream1x1_ln_launch(const void* x, const void* w, const float* shift, void* y, long long M, int C, int K, float eps, int act,
+                        int x_dtype, hipStream_t st);
 int conv3x3c64_supported(int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int in_dtype,
                          int out_dtype, const void* residual, long long M);
 int igemm2_wanted(long long M, int C, int K, int R, int S);

@@ -828,6 +828,20 @@ int mv_linear_split_fwd(const void* x, const void* w_hi_lo, const float* scale, 
                               (hipStream_t)stream);
 }
 
+int mv_ln_linear_supported(int64_t M, int N, int K, int x_dtype, int out_dtype) {
+    return !get_flag("force_generic") && !get_flag("no_stream") && stream1x1_ln_supported(M, K, N, x_dtype, out_dtype);
+}
+
+int mv_ln_linear_fwd(const void* x, const void* w, const float* bias, void* y, int64_t M, int N, int K, float eps, int act,
+                     int x_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && w && y, "ln_linear: NULL pointer");
+    if (!mv_ln_linear_supported(M, N, K, x_dtype, out_dtype)) {
+        set_error("ln_linear: unsupported configuration M=%lld N=%d K=%d (ask mv_ln_linear_supported first)", (long long)M, N, K);
+        return MV_E_UNSUPPORTED;
+    }
+    return stream1x1_ln_launch(x, w, bias, y, M, K, N, eps, act, x_dtype, (hipStream_t)stream);
+}
+
 int mv_ln_mlp_supported(int64_t M, int C, int hidden, int x_dtype) {
     return !get_flag("force_generic") && ln_mlp_supported(M, C, hidden, x_dtype);
 }

@@ -33,6 +33,8 @@ struct StreamP {
     int M, K, N;          // rows, reduction, output channels
     int tiles_m, act, wpitch;
     int npass;            // 128-channel slabs of W resident per block (channel tiles blockIdx.y*npass ...)
+    const void* xraw;     // LN mode: the un-normalised rows (fp32 or bf16), normalised in registers on the way in
+    float eps;
 };
 
 template <typename OutT> struct SRes8;
@@ -57,7 +59,10 @@ template <> struct SRes8<float> {
 };
 
 // TN = 32-channel MFMA tiles per wave and pass (BN = 32*TN), KC = K/16 MFMA k-steps, WAVES per block.
-template <int TN, int KC, int WAVES, typename OutT>
+// LN: the rows arrive un-normalised in XT (the fp32 residual stream, or bf16); every lane holds half of its row, so the
+// LayerNorm statistics are two cross-half shuffles and (x - mean) * rstd becomes the bf16 B fragment directly (the affine
+// part of the LayerNorm is folded into w / shift by the caller).  Saves the separate LayerNorm launch and its round trip.
+template <int TN, int KC, int WAVES, typename OutT, bool LN = false, typename XT = bf16_t>
 __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) {
     constexpr int BN = 32 * TN;
     constexpr int EPITCH = 64 * 4 + 16;
@@ -195,6 +200,66 @@ __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) 
         }
     };
 
+    if constexpr (LN) {
+        // one raw row set in flight (fetched a whole tile ahead), normalised into the fragment set right before use
+        const XT* xr = (const XT*)p.xraw;
+        float raw[KC][8];
+        auto load_raw = [&](int t) {
+            int m = t * 32 + fr;
+            m = m < p.M ? m : p.M - 1;
+            const XT* src = xr + (long long)m * K + fh * 8;
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                if constexpr (sizeof(XT) == 4) {
+                    const float4 a = *(const float4*)(src + kk * 16), b = *(const float4*)(src + kk * 16 + 4);
+                    raw[kk][0] = a.x; raw[kk][1] = a.y; raw[kk][2] = a.z; raw[kk][3] = a.w;
+                    raw[kk][4] = b.x; raw[kk][5] = b.y; raw[kk][6] = b.z; raw[kk][7] = b.w;
+                } else {
+                    const uint4 u = *(const uint4*)(src + kk * 16);
+                    const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        raw[kk][2 * e] = __uint_as_float(w4[e] << 16);
+                        raw[kk][2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+                    }
+                }
+            }
+        };
+        uint4 xa[KC];
+        int tile = gw;
+        constexpr bool AHEAD = KC <= 6;                          // K = 192: 96 raw + 48 fragment registers do not fit twice
+        if (AHEAD && tile < p.tiles_m) load_raw(tile);
+        for (; tile < p.tiles_m; tile += nw) {
+            if (!AHEAD) load_raw(tile);
+            float s = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += raw[kk][e];
+            s += __shfl_xor(s, 32);
+            const float mean = s * (1.0f / K);
+            float q = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = raw[kk][e] - mean;
+                    q = fmaf(d, d, q);
+                }
+            q += __shfl_xor(q, 32);
+            const float rstd = rsqrtf(q * (1.0f / K) + p.eps);
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                xa[kk].x = pack_bf2((raw[kk][0] - mean) * rstd, (raw[kk][1] - mean) * rstd);
+                xa[kk].y = pack_bf2((raw[kk][2] - mean) * rstd, (raw[kk][3] - mean) * rstd);
+                xa[kk].z = pack_bf2((raw[kk][4] - mean) * rstd, (raw[kk][5] - mean) * rstd);
+                xa[kk].w = pack_bf2((raw[kk][6] - mean) * rstd, (raw[kk][7] - mean) * rstd);
+            }
+            if (AHEAD && tile + nw < p.tiles_m) load_raw(tile + nw);
+            run_tile(xa, tile, p.tiles_m);                       // no in-kernel refill of the fragment set
+        }
+        return;
+    }
     constexpr bool X2 = KC <= 8;                                // two fragment sets: 2 x KC x 4 VGPRs (K = 256 would spill)
     uint4 xa[KC], xb[X2 ? KC : 1];
     int tile = gw;
@@ -216,7 +281,7 @@ int stream1x1_supported(int C, int K, int in_dtype, int out_dtype, long long M) 
            (C == 64 || C == 96 || C == 128 || C == 192 || C == 256) && K % 8 == 0 && M >= 8192;
 }
 
-template <int TN, int KC, typename OutT>
+template <int TN, int KC, typename OutT, bool LN = false, typename XT = bf16_t>
 static int stream_go(StreamP& p, int tiles_n, hipStream_t st) {
     constexpr int WAVES = 8;
     // as many channel slabs per block as LDS holds next to the epilogue patches (160 KB per CU, one block per CU)
@@ -232,7 +297,7 @@ static int stream_go(StreamP& p, int tiles_n, hipStream_t st) {
     const int need = (p.tiles_m + WAVES - 1) / WAVES;
     if (gx > need) gx = need;
     dim3 grid(gx, gy), block(WAVES * 64);
-    auto kern = stream1x1_kernel<TN, KC, WAVES, OutT>;
+    auto kern = stream1x1_kernel<TN, KC, WAVES, OutT, LN, XT>;
     if (smem > 48 * 1024)
         MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, grid, block, smem, st, p);
@@ -240,9 +305,37 @@ static int stream_go(StreamP& p, int tiles_n, hipStream_t st) {
     return MV_OK;
 }
 
+int stream1x1_ln_supported(long long M, int C, int K, int x_dtype, int out_dtype) {
+    // K = 192 works (flag "ln_stream_192") but loses: only one 128-channel weight slab fits in LDS next to the epilogue patches,
+    // so 5-6 blocks re-read AND re-normalise every row (measured 46 us vs 14 + 29.5 us for LayerNorm + Linear at 50 176 x 192 -> 576)
+    const bool c_ok = C == 96 || (C == 192 && get_flag("ln_stream_192"));
+    return (x_dtype == MV_F32 || x_dtype == MV_BF16) && out_dtype == MV_BF16 && c_ok && K % 8 == 0 && K > 64 &&
+           M >= 8192 && M < (1ll << 31) - 64 && !get_flag("no_ln_stream");
+}
+
+// y = act(w . n(x) + shift): rows normalised on the way in (LayerNorm with its affine folded into w / shift by the caller)
+int stream1x1_ln_launch(const void* x, const void* w, const float* shift, void* y, long long M, int C, int K, float eps, int act,
+                        int x_dtype, hipStream_t st) {
+    StreamP p;
+    p.x = nullptr; p.xraw = x; p.eps = eps;
+    p.w = (const bf16_t*)w; p.scale = nullptr; p.shift = shift; p.residual = nullptr; p.y = y;
+    p.M = (int)M; p.K = C; p.N = K;
+    p.tiles_m = (int)((M + 31) / 32);
+    p.act = act;
+    p.wpitch = C * 2 + 16;
+    const int tiles_n = (K + 127) / 128;
+    char name[64];
+    snprintf(name, sizeof(name), "stream1x1_ln_%s_k%d", x_dtype == MV_F32 ? "f32in" : "bf16in", C);
+    set_kernel_name(name);
+    if (x_dtype == MV_F32)
+        return C == 96 ? stream_go<4, 6, bf16_t, true, float>(p, tiles_n, st) : stream_go<4, 12, bf16_t, true, float>(p, tiles_n, st);
+    return C == 96 ? stream_go<4, 6, bf16_t, true, bf16_t>(p, tiles_n, st) : stream_go<4, 12, bf16_t, true, bf16_t>(p, tiles_n, st);
+}
+
 int stream1x1_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                      void* y, long long M, int C, int K, int act, int out_dtype, hipStream_t st) {
     StreamP p;
+    p.xraw = nullptr; p.eps = 0.f;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.M = (int)M; p.K = C; p.N = K;
     p.tiles_m = (int)((M + 31) / 32);

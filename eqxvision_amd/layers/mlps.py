@@ -32,14 +32,17 @@ class MlpProjection(Module):
         self.fc2 = lin_layer(hidden_features, out_features, key=keys[1])
         self.drop2 = nn.Dropout(drop_probs[1])
 
-    def _forward(self, x, residual=None):
+    def _forward(self, x, residual=None, norm=None):
+        """`norm` given: x is the un-normalised input; the LayerNorm is folded into fc1 where the library can."""
         if x.kind in ("img", "map"):
             x = ops.as_map(x)
         name = nn.act_name(self.act)
+        if norm is not None and not isinstance(self.fc1, nn.Linear):
+            x, norm = norm(x), None
         if name is not None:
-            h = ops.linear(x, self.fc1, act=name)
+            h = ops.linear(x, self.fc1, act=name) if norm is None else ops.ln_linear(x, norm, self.fc1, act=name)
         else:
-            h = ops.linear(x, self.fc1)
+            h = ops.linear(x, self.fc1) if norm is None else ops.ln_linear(x, norm, self.fc1)
             h = self.act(h) if self.act is not None else h
         h = self.drop1(h)
         y = ops.linear(h, self.fc2, residual=residual)

@@ -102,13 +102,14 @@ class _ShiftedWindowAttention(Module):
             cache["bias"] = b
         return b
 
-    def _forward(self, x: Act, residual: Optional[Act] = None) -> Act:
+    def _forward(self, x: Act, residual: Optional[Act] = None, norm=None) -> Act:
+        """`norm` given: x is the UN-normalised input and the LayerNorm is folded into the qkv Linear where possible."""
         x = ops.as_map(x)
         B, Hf, Wf, C = x.t.shape
         if Hf % self.window_size[0] or Wf % self.window_size[1]:
             raise ValueError(f"feature map {Hf}x{Wf} is not a multiple of the window {self.window_size} "
                              "(the reference does not pad either, swin.py:782-790)")
-        qkv = ops.linear(x, self.qkv)                                  # reference :151-153
+        qkv = ops.linear(x, self.qkv) if norm is None else ops.ln_linear(x, norm, self.qkv)      # reference :151-153
         a = ops.swin_window_attention(qkv, self._bias_dev(), self.num_heads, self.window_size, self.shift_size)
         return ops.linear(a, self.proj, residual=residual)             # reference :232 (+ the block's residual)
 
@@ -142,11 +143,16 @@ class _SwinTransformerBlock(Module):
         x = ops.as_map(x)
         sd = self.stochastic_depth
         if sd.inference or sd.p == 0.0:
-            x = self.attn._forward(self.norm1(x), residual=x)
+            if type(self.attn) is _ShiftedWindowAttention and isinstance(self.norm1, nn.LayerNorm):
+                x = self.attn._forward(x, residual=x, norm=self.norm1)
+            else:
+                x = self.attn._forward(self.norm1(x), residual=x)
             if isinstance(self.mlp, MlpProjection):
                 y = ops.ln_mlp(x, self.norm2, self.mlp)              # one launch where the weights fit in LDS (stage 0)
                 if y is not None:
                     return y
+                if isinstance(self.norm2, nn.LayerNorm):
+                    return self.mlp._forward(x, residual=x, norm=self.norm2)
             return self.mlp._forward(self.norm2(x), residual=x)
         x = ops.add(x, sd(self.attn._forward(self.norm1(x)), key=key))
         return ops.add(x, sd(self.mlp._forward(self.norm2(x)), key=key))

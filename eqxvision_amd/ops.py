@@ -509,6 +509,41 @@ def layernorm(x: Act, ln, out_fp32: bool = False) -> Act:
     return Act(y, x.kind, x.batched)
 
 
+def _ln_folded(lin, ln):
+    """(W . diag(gamma) as bf16, b + W . beta as fp32) on the device, cached on the Linear."""
+    cache = lin._cache()
+    key = ("ln_fold", id(ln.weight), id(ln.bias))
+    hit = cache.get(key)
+    if hit is None:
+        w = np.asarray(lin.weight, np.float32)
+        g, b = np.asarray(ln.weight, np.float32).reshape(-1), np.asarray(ln.bias, np.float32).reshape(-1)
+        b0 = np.zeros(w.shape[0], np.float32) if lin.bias is None else np.asarray(lin.bias, np.float32).reshape(-1)
+        hit = (_dev(w * g[None, :], torch.bfloat16), _dev(b0 + w @ b, torch.float32), ln)      # ln: keeps the ids alive
+        cache[key] = hit
+    return hit
+
+
+def ln_linear(x: Act, ln, lin, act=None) -> Act:
+    """lin(ln(x)) (+ activation): ONE launch where the library folds the LayerNorm into the Linear's operand path (short rows:
+    Swin stages 0-1), else LayerNorm launch + Linear launch."""
+    from . import nn
+    C = lin.in_features
+    ok = (compute_dtype() == "bf16" and x.kind in ("map", "seq") and x.t.dtype in (torch.float32, torch.bfloat16)
+          and isinstance(ln, nn.LayerNorm) and ln.weight is not None and ln.bias is not None
+          and x.t.shape[-1] == C and int(np.prod(ln.shape)) == C)
+    if ok:
+        M = x.t.numel() // C
+        xdt = _lib.F32 if x.t.dtype == torch.float32 else _lib.BF16
+        ok = bool(_lib.load().mv_ln_linear_supported(M, lin.out_features, C, xdt, _lib.BF16))
+    if not ok:
+        return linear(layernorm(x, ln), lin, act=act)
+    w, b = _ln_folded(lin, ln)[:2]
+    y = empty(tuple(x.t.shape[:-1]) + (lin.out_features,), torch.bfloat16)
+    _lib.call("mv_ln_linear_fwd", _ptr(x.t), _ptr(w), _ptr(b), _ptr(y), M, lin.out_features, C, float(ln.eps), ACT[act], xdt,
+              _lib.BF16, stream_ptr())
+    return Act(y, x.kind, x.batched)
+
+
 def ln_mlp(x: Act, ln, mlp) -> Optional[Act]:
     """x + mlp(ln(x)) in ONE launch where the library has the fused kernel (narrow rows: Swin stage 0), else None.
     The LayerNorm affine is folded into fc1 on the host (fp32, then one bf16 rounding of the product)."""

@@ -38,7 +38,7 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  * "igemm8" (2 / 3 / 4 = force the ping-pong GEMM with 256x256 / 128x256 / 256x128 tiles), "no_igemm8",
  * "igemm2_tile" (1 / 2 / 3 = force igemm2 with 256x64 / 256x128 / 256x256 tiles), "no_igemm2", "igemm2_dense_m",
  * "igemm_tile" (1 / 2 = force the 128x128 / 128x64 kernel), "res_early", "no_stream" (no streaming 1x1 / 3x3c64 kernels),
- * "stream_npass1", "stem_v0", "no_stem_pool", "no_dual", "no_chain", "no_dual_chain", "no_ln_mlp", "no_skinny", "no_tuned", and the
+ * "stream_npass1", "stem_v0", "no_stem_pool", "no_dual", "no_chain", "no_dual_chain", "no_ln_mlp", "no_ln_stream", "ln_stream_192", "no_skinny", "no_tuned", and the
  * per-shape kernel choice "ov:<M>:<C>:<K>:<R>:<S>:<stride>" / "ovh:<M>:<N>:<K>:1:1:1" / "ovd:<M>:<C1>:<C2>:<K>:<stride>:1"
  * (tools/tune_tiles.py; codes in csrc/igemm.hip). */
 
@@ -142,6 +142,16 @@ int mv_linear_split_fwd(const void* x, const void* w_hi_lo, const float* scale, 
 int mv_conv2d_nchw_split_fwd(const void* x, const void* w_hi, const void* w_lo, const float* scale, const float* shift,
                              void* y, int N, int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw,
                              int act, int x_dtype, int out_dtype, mv_stream_t stream);
+
+/* LayerNorm folded into the Linear that consumes it (swin.py:572-578 `attn(norm1(x))` / `mlp(norm2(x))` feeding qkv / fc1;
+ * extensions_2d.py:9-50), for short rows (K = 96: Swin stage 0, where the LayerNorm launch is a 115 MB round trip; K = 192 only
+ * behind the "ln_stream_192" switch -- it loses there, see stream1x1.hip):
+ *   y[m,:] = act( w . n(x[m,:]) + bias ),   n(x) = (x - mean) * rsqrt(var + eps)   (biased var)
+ * with the LayerNorm affine folded by the caller (w = W . diag(gamma) bf16 [N][K], bias = b + W . beta fp32).
+ * x is MV_F32 (the fp32 residual stream) or MV_BF16; y is MV_BF16. */
+int mv_ln_linear_supported(int64_t M, int N, int K, int x_dtype, int out_dtype);
+int mv_ln_linear_fwd(const void* x, const void* w, const float* bias, void* y, int64_t M, int N, int K, float eps, int act,
+                     int x_dtype, int out_dtype, mv_stream_t stream);
 
 /* The MLP half of a pre-norm block in ONE launch (swin.py:572-578 `x + stochastic_depth(mlp(norm2(x)))` in inference,
  * mlps.py:54-66, extensions_2d.py:9-28), for narrow rows whose two weight matrices fit in LDS (C = 96, hidden = 384: Swin

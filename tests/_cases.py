@@ -383,6 +383,45 @@ def linear_split_case(M, K, N, out="fp32", seed=0):
     return run
 
 
+def ln_linear_case(M, K, N, stream="fp32", act=0, seed=0, flags=()):
+    """mv_ln_linear_fwd (LayerNorm folded into the consuming Linear) vs float64 LayerNorm -> Linear (swin.py:572-578)."""
+    def run():
+        L = _lib()
+        for k, v in flags:
+            L.set_flag(k, v)
+        try:
+            return body(L)
+        finally:
+            for k, _ in flags:
+                L.set_flag(k, 0)
+
+    def body(L):
+        rng = _rng(seed)
+        x = (rng.standard_normal((M, K)) * rng.uniform(0.5, 2.0, (M, 1)) + rng.uniform(-1, 1, (M, 1))).astype(np.float32)
+        if stream == "bf16":
+            x = bf(x)
+        g = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        be = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        b = (0.1 * rng.standard_normal(N)).astype(np.float32)
+        xdt = 0 if stream == "fp32" else 1
+        if not L.load().mv_ln_linear_supported(M, N, K, xdt, 1):
+            return {"ok": False, "err": "mv_ln_linear_supported says no"}
+        ref = O.layernorm_rows(x, g, be, 1e-5).astype(np.float64) @ w.astype(np.float64).T + b
+        if act == 2:
+            ref = O.gelu_tanh(ref).astype(np.float64)
+        xd, wd, bd = dev(x, stream), dev(bf(w * g[None, :]), "bf16"), dev((b + w @ be).astype(np.float32), "fp32")
+        y = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        L.call("mv_ln_linear_fwd", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), M, N, K, 1e-5, act, xdt, 1, _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, TOL_BF16)
+        info["kernel"] = kern
+        info["ok"] = info["ok"] and "_ln_" in kern
+        return info
+    return run
+
+
 def ln_mlp_case(M, stream="fp32", seed=0, C=96, Hd=384):
     """mv_ln_mlp_fwd (LayerNorm -> fc1 -> GELU -> fc2 -> + x, one launch) vs the un-fused float64 restatement
     (swin.py:572-578 second line, mlps.py:54-66) with the affine LayerNorm applied the reference's way; the kernel gets the
@@ -977,6 +1016,11 @@ def all_cases():
           ("split/linear_swin_merge_384_192", linear_split_case(128 * 28 * 28 // 4, 384, 192, seed=511)),
           ("split/linear_swin_merge_1536_768", linear_split_case(64 * 49, 1536, 768, seed=512)),
           ("split/linear_bf16out_ragged", linear_split_case(9000 + 37, 256, 200, out="bf16", seed=513)),
+          ("ln_linear/swin_qkv_96_288_f32stream", ln_linear_case(4 * 56 * 56, 96, 288, "fp32", seed=530)),
+          ("ln_linear/swin_fc1_192_768_gelu", ln_linear_case(8 * 28 * 28 * 2, 192, 768, "fp32", act=2, seed=531, flags=(("ln_stream_192", 1),))),
+          ("ln_linear/swin_qkv_192_576_bf16stream_ragged", ln_linear_case(8192 + 45, 192, 576, "bf16", seed=532, flags=(("ln_stream_192", 1),))),
+          ("ln_linear/swin_fc1_96_384_gelu_bf16stream", ln_linear_case(8192 + 45, 96, 384, "bf16", act=2, seed=534)),
+          ("ln_linear/k96_N200_tail", ln_linear_case(9000, 96, 200, "fp32", seed=533)),
           ("ln_mlp/swin_stage0_f32stream", ln_mlp_case(8 * 56 * 56, "fp32", seed=520)),
           ("ln_mlp/bf16stream_ragged", ln_mlp_case(4096 + 77, "bf16", seed=521)),
           ("ln_mlp/f32stream_many_tiles", ln_mlp_case(70001, "fp32", seed=522)),
