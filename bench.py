@@ -35,7 +35,8 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-GFLOP_PER_IMG = {"resnet50": 8.178, "vit_base": 35.13, "swin_t": 8.98, "alexnet": 1.428}
+GFLOP_PER_IMG = {"resnet50": 8.178, "vit_base": 35.13, "swin_t": 8.98, "alexnet": 1.428,
+                 "vgg16": 30.94, "vgg16_bn": 30.94, "vgg11": 15.22}   # section 8 f1 (2 x MACs of the conv / Linear layers)
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -55,6 +56,10 @@ def build_model(name: str, seed: int = 1):
             net = eqv.models.swin_t(key=key)
         elif name == "alexnet":
             net = eqv.models.alexnet(key=key)
+        elif name in ("vgg16", "vgg16_bn", "vgg11"):
+            net = getattr(eqv.models, name)(key=key)
+            if name.endswith("_bn"):
+                net = eqv.utils.randomize_batchnorm(net, seed)
         else:
             raise SystemExit(f"unknown model {name}")
     return eqv.tree_inference(net, True)

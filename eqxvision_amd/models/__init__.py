@@ -13,6 +13,7 @@ from .classification.resnet import (
     wide_resnet101_2,
 )
 from .classification.swin import SwinTransformer, swin_b, swin_s, swin_t
+from .classification.vgg import VGG, vgg11, vgg11_bn, vgg13, vgg13_bn, vgg16, vgg16_bn, vgg19, vgg19_bn
 from .classification.vit import (
     _VitAttention,
     _VitBlock,

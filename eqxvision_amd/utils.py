@@ -27,6 +27,9 @@ _STEMS = {
     "resnet101": "resnet101-5d3b4d8f", "resnet152": "resnet152-b121ed2d",
     "resnext50_32x4d": "resnext50_32x4d-7cdf4587", "resnext101_32x8d": "resnext101_32x8d-8ba56ff5",
     "wide_resnet50_2": "wide_resnet50_2-95faca4d", "wide_resnet101_2": "wide_resnet101_2-32ee1156",
+    "vgg11": "vgg11-8a719046", "vgg13": "vgg13-19584684", "vgg16": "vgg16-397923af", "vgg19": "vgg19-dcbb9e9d",
+    "vgg11_bn": "vgg11_bn-6002323d", "vgg13_bn": "vgg13_bn-abd245e5", "vgg16_bn": "vgg16_bn-6c64b313",
+    "vgg19_bn": "vgg19_bn-c79401a0",
     "swin_t": "swin_t-704ceda3", "swin_s": "swin_s-5e29d889", "sim_b": "swin_b-68c6b09e",
 }
 CLASSIFICATION_URLS = {k: f"{_PT}{v}.pth" for k, v in _STEMS.items()}

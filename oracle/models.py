@@ -80,6 +80,36 @@ def alexnet_forward(sd, x, bf16=False):
     return O.linear(x, q(sd["classifier.6.weight"]), sd["classifier.6.bias"])
 
 
+# ---------------------------------------------------------------- vgg.py:96-148
+def vgg_forward(sd, x, plan, batch_norm=False, bf16=False):
+    """features = [conv3x3(pad 1) (+BN) + relu | maxpool 2/2]*, AdaptiveAvgPool2d((7,7)), ravel, then the reference's
+    classifier: Linear, Dropout(id), Linear, relu, Dropout(id), Linear -- ONE relu (vgg.py:96-105)."""
+    q = _Q(bf16)
+    x = q(x)
+    i = 0
+    for v in plan:
+        if v == "M":
+            x = O.maxpool2d(x, 2, 2)
+            i += 1
+            continue
+        conv = f"features.{i}"
+        i += 1
+        if batch_norm:
+            y = O.conv2d(x, q(sd[conv + ".weight"]), sd[conv + ".bias"], 1, 1)
+            bn = f"features.{i}"
+            i += 1
+            y = O.batchnorm_inference(y, sd[bn + ".weight"], sd[bn + ".bias"], sd[bn + ".running_mean"], sd[bn + ".running_var"])
+        else:
+            y = O.conv2d(x, q(sd[conv + ".weight"]), sd[conv + ".bias"], 1, 1)
+        x = q(O.relu(y))
+        i += 1
+    x = q(O.adaptive_avgpool2d(x, (7, 7)))
+    x = np.ravel(x)
+    x = q(O.linear(x, q(sd["classifier.0.weight"]), sd["classifier.0.bias"]))
+    x = q(O.relu(O.linear(x, q(sd["classifier.3.weight"]), sd["classifier.3.bias"])))
+    return O.linear(x, q(sd["classifier.6.weight"]), sd["classifier.6.bias"])
+
+
 # ---------------------------------------------------------------- resnet.py:144-162, 335-358
 def resnet_forward(sd, x, block="bottleneck", layers=(3, 4, 6, 3), bf16=False, groups=1):
     q = _Q(bf16)

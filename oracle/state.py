@@ -68,6 +68,38 @@ def alexnet_state(seed=1, num_classes=1000):
     return sd
 
 
+VGG_PLANS = {
+    "A": (64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512, "M"),
+    "B": (64, 64, "M", 128, 128, "M", 256, 256, "M", 512, 512, "M", 512, 512, "M"),
+    "D": (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"),
+    "E": (64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"),
+}
+
+
+def vgg_state(seed=1, plan="A", batch_norm=False, num_classes=1000):
+    """torchvision VGG state_dict layout: `features.{i}` indexes the Sequential [conv, (bn), relu, ..., maxpool, ...];
+    classifier Linear layers at 0 / 3 / 6."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    plan = VGG_PLANS[plan] if isinstance(plan, str) else tuple(plan)
+    i, cin = 0, 3
+    for v in plan:
+        if v == "M":
+            i += 1
+            continue
+        _conv(sd, rng, f"features.{i}", cin, v, 3, True)
+        i += 1
+        if batch_norm:
+            _bn(sd, rng, f"features.{i}", v)
+            i += 1
+        i += 1                      # relu
+        cin = v
+    _linear(sd, rng, "classifier.0", cin * 7 * 7, 4096)
+    _linear(sd, rng, "classifier.3", 4096, 4096)
+    _linear(sd, rng, "classifier.6", 4096, num_classes)
+    return sd
+
+
 def resnet_state(seed=1, block="bottleneck", layers=(3, 4, 6, 3), num_classes=1000,
                  width_per_group=64, groups=1, stem=64):
     """torchvision ResNet registration order (mirrored by resnet.py:101-110,171-184)."""

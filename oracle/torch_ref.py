@@ -56,6 +56,32 @@ def alexnet_forward(sd, x):
 
 
 @torch.no_grad()
+def vgg_forward(sd, x, plan, batch_norm=False):
+    """torch.nn.functional restatement of the reference VGG (vgg.py:96-148), incl. its single-relu classifier.  Only valid
+    where equinox's AdaptiveAvgPool2d agrees with torch's (input size divisible by 7 after the pools)."""
+    t = _t(sd)
+    x = torch.as_tensor(x)
+    i = 0
+    for v in plan:
+        if v == "M":
+            x = F.max_pool2d(x, 2, 2)
+            i += 1
+            continue
+        x = F.conv2d(x, t[f"features.{i}.weight"], t[f"features.{i}.bias"], 1, 1)
+        i += 1
+        if batch_norm:
+            x = _bn(t, x, f"features.{i}")
+            i += 1
+        x = F.relu(x)
+        i += 1
+    assert x.shape[-1] % 7 == 0 and x.shape[-2] % 7 == 0
+    x = F.adaptive_avg_pool2d(x, (7, 7)).flatten(1)
+    x = F.linear(x, t["classifier.0.weight"], t["classifier.0.bias"])
+    x = F.relu(F.linear(x, t["classifier.3.weight"], t["classifier.3.bias"]))
+    return F.linear(x, t["classifier.6.weight"], t["classifier.6.bias"])
+
+
+@torch.no_grad()
 def resnet_forward(sd, x, block="bottleneck", layers=(3, 4, 6, 3), groups=1):
     sd = _t(sd)
     x = torch.as_tensor(x)

@@ -101,6 +101,29 @@ def alexnet_case(B, dtype="bf16", features_only=False):
     return run
 
 
+def vgg_case(plan, batch_norm, size, B, classes=10, dtype="bf16", full_ref="numpy"):
+    """VGG (reference models/classification/vgg.py) incl. its single-relu classifier; `plan` = a torchvision letter or a list."""
+    def run():
+        import eqxvision_amd as eqv
+        cfg = list(S.VGG_PLANS[plan]) if isinstance(plan, str) else list(plan)
+        sd = S.vgg_state(1, cfg, batch_norm, classes)
+        x = S.synthetic_images(B, size, seed=0)
+        fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(eqv.models.VGG(**kw), torch_weights)
+        net = _load(fac, sd, cfg=cfg, batch_norm=batch_norm, num_classes=classes)
+        got = _run(net, x, dtype).cpu().numpy()
+        if full_ref == "torch":
+            ref = TR.vgg_forward(sd, x, cfg, batch_norm).numpy()
+            extra = {}
+        else:
+            ref = O.vmap(lambda im: OM.vgg_forward(sd, im, cfg, batch_norm))(x)
+            extra = {}
+            if dtype == "bf16":
+                emu = O.vmap(lambda im: OM.vgg_forward(sd, im, cfg, batch_norm, bf16=True))(x)
+                extra["err_vs_bf16_emulation"] = float(np.abs(got - emu).max())
+        return _cmp(got, ref, 1e-2 if dtype == "bf16" else 1e-3, extra)
+    return run
+
+
 def vit_case(img, patch, dim, depth, heads, B, classes=10, dtype="bf16", attn=False, full_ref="numpy"):
     def run():
         import eqxvision_amd as eqv
@@ -422,6 +445,9 @@ def all_cases(full=True):
          ("model/vit_tiny", vit_case(32, 8, 64, 2, 2, 3)),
          ("model/vit_tiny_fp32", vit_case(32, 8, 64, 2, 2, 2, dtype="fp32")),
          ("model/vit_tiny_last_attn", vit_case(32, 8, 64, 2, 2, 2, attn=True)),
+         ("model/vgg_small_bn_avgpool2x2", vgg_case((16, "M", 32, 32, "M"), True, 56, 3)),
+         ("model/vgg_small_fp32", vgg_case((8, "M", 16, "M"), False, 28, 2, dtype="fp32")),
+         ("model/vgg_small_c64_128", vgg_case((64, "M", 128, 128, "M"), False, 56, 2)),
          ("model/swin_tiny", swin_case(56, 32, (2, 2), (2, 4), 2)),
          ("model/swin_tiny_fp32", swin_case(56, 32, (2, 2), (2, 4), 1, dtype="fp32")),
          ("model/conv_norm_act_reference_3_4_5x5", conv_norm_act_case(3, 4, 5, 1)),
@@ -445,6 +471,8 @@ def all_cases(full=True):
               ("model/resnet_2111_160px_B7_mixed_paths", resnet_case("bottleneck", (2, 1, 1, 1), 160, 7, classes=10, full_ref="torch")),
               ("model/resnet_1211_128px_B16_mixed_paths", resnet_case("bottleneck", (1, 2, 1, 1), 128, 16, classes=10, full_ref="torch")),
               ("model/vit_base_B2", vit_case(224, 16, 768, 12, 12, 2, classes=1000, full_ref="torch")),
+              ("model/vgg11_B2", vgg_case("A", False, 224, 2, classes=1000, full_ref="torch")),
+              ("model/vgg16_bn_B1", vgg_case("D", True, 224, 1, classes=1000, full_ref="torch")),
               ("model/swin_t_B1", swin_case(224, 96, (2, 2, 6, 2), (3, 6, 12, 24), 1, classes=1000, full_ref="torch")),
               ("model/resnet50_B256_full_config", full_batch_case("resnet50", 256)),
               ("model/vit_base_B256_full_config", full_batch_case("vit_base", 256)),

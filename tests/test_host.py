@@ -23,6 +23,8 @@ def _keys(sd):
     (lambda: eqv.models.resnet18(), lambda: S.resnet_state(1, "basic", (2, 2, 2, 2))),
     (lambda: eqv.models.vit_base(num_classes=1000), lambda: S.vit_state(1)),
     (lambda: eqv.models.vit_small(), lambda: S.vit_state(1, embed_dim=384, num_heads=6, num_classes=0)),
+    (lambda: eqv.models.vgg11(), lambda: S.vgg_state(1, "A", False)),
+    (lambda: eqv.models.vgg16_bn(num_classes=10), lambda: S.vgg_state(1, "D", True, 10)),
 ])
 def test_pytree_order_is_torchvision_registration_order(factory, state):
     with warnings.catch_warnings():
@@ -32,9 +34,12 @@ def test_pytree_order_is_torchvision_registration_order(factory, state):
     # a model exported with utils.state_dict lists its leaves in flatten order: must equal the checkpoint order
     model = eqv.utils.randomize_batchnorm(model)
     mine = eqv.utils.state_dict(model)
-    assert list(mine.keys()) == _keys(sd)
-    for k in mine:
-        assert mine[k].size == np.asarray(sd[k]).size, k
+    # the contract is the ORDER (ordered zip, utils.py:120-219); names coincide with torchvision's except where the reference's
+    # Sequential differs from torchvision's (VGG classifier: Linear at 0 / 2 / 5 instead of 0 / 3 / 6, vgg.py:96-105)
+    strip = lambda k: k if not k.startswith("classifier.") or not isinstance(model, eqv.models.VGG) else "classifier." + k.split(".")[-1]
+    assert [strip(k) for k in mine.keys()] == [strip(k) for k in _keys(sd)]
+    for k, k_sd in zip(mine, _keys(sd)):
+        assert mine[k].size == np.asarray(sd[k_sd]).size, k
 
 
 def test_load_torch_weights_roundtrip_and_bn_state():
@@ -113,6 +118,26 @@ def test_reference_error_behaviour_without_gpu():
         eqv.layers.DropPath(0.5)(x, key=None)
     with pytest.raises(ValueError):
         eqv.models.classification.swin._ShiftedWindowAttention(32, [7], [0, 0], 2)
+
+
+def test_vgg_structure_and_reference_quirks():
+    """reference vgg.py:96-148: features / avgpool / classifier, ONE relu in the classifier, key is mandatory."""
+    net = eqv.models.vgg13_bn(num_classes=7)
+    kinds = [type(l).__name__ for l in net.features.layers]
+    assert kinds[:7] == ["Conv2d", "BatchNorm", "Lambda", "Conv2d", "BatchNorm", "Lambda", "MaxPool2d"]
+    assert kinds.count("Conv2d") == 10 and kinds.count("MaxPool2d") == 5 and kinds.count("BatchNorm") == 10
+    assert net.avgpool.target_shape == (7, 7)
+    head = [type(l).__name__ for l in net.classifier.layers]
+    assert head == ["Linear", "Dropout", "Linear", "Lambda", "Dropout", "Linear"]
+    assert net.classifier.layers[0].in_features == 512 * 49 and net.classifier.layers[-1].out_features == 7
+    plain = eqv.models.vgg19()
+    assert sum(isinstance(l, nn.Conv2d) for l in plain.features.layers) == 16
+    assert not any(isinstance(l, nn.BatchNorm) for l in plain.features.layers)
+    with pytest.raises(RuntimeError, match="PRNGKey"):
+        plain(np.zeros((3, 32, 32), np.float32), key=None)
+    with pytest.raises(ValueError):
+        eqv.models.VGG()
+    assert eqv.utils.CLASSIFICATION_URLS["vgg16_bn"].endswith("vgg16_bn-6c64b313.pth")
 
 
 def test_conv_norm_activation_structure():

@@ -34,7 +34,7 @@ def fam(name):
                    ("chain1x1_kernel<128", "chain1x1_bf16_64_256_128"), ("chain1x1_kernel<64, 6, true", "chain1x1_dual_bf16_64+64_256_64"),
                    ("conv3x3c64_v2_kernel", "conv3x3c64_halo"), ("stem_pool_kernel", "stem_pool_mfma_f32in"),
                    ("patch_embed_kernel", "patch_embed_mfma_f32in"), ("mha_mfma_kernel", "mha_mfma_dh64_hm"),
-                   ("layernorm_vec_kernel", "layernorm_vec"), ("swin_attn_mfma", "swin_attn_mfma"), ("skinny_f32_kernel", "skinny_linear_f32_mfma")):
+                   ("layernorm_vec_kernel", "layernorm_vec"), ("ln_mlp96_kernel", "ln_mlp96_f32stream"), ("swin_attn_mfma", "swin_attn_mfma"), ("skinny_f32_kernel", "skinny_linear_f32_mfma")):
         if sub in n: return f
     return None
 out = {"_batch": {}, "_rocprof": {}}
