@@ -160,13 +160,22 @@ def tree_inference(tree, value: bool = True):
     return rec(tree)
 
 
-def tree_at(where: Callable, tree, replace):
+_MISSING = object()
+
+
+def tree_at(where: Callable, tree, replace=_MISSING, replace_fn: Callable = None):
     """Tiny `eqx.tree_at`: `where(tree)` must return one node (or a tuple of nodes); the
-    returned tree has them replaced.  Implemented by identity search on a deep structural copy."""
+    returned tree has them replaced by `replace` (same structure as the targets) or by `replace_fn(node)` (fcn.py:106).
+    Implemented by identity search on a deep structural copy."""
     targets = where(tree)
     single = not isinstance(targets, (tuple, list))      # eqx.tree_at takes any sequence of nodes (experimental.py:73-80 passes a list)
     targets = (targets,) if single else tuple(targets)
-    repl = (replace,) if single else tuple(replace)
+    if (replace is _MISSING) == (replace_fn is None):
+        raise ValueError("tree_at: exactly one of `replace` and `replace_fn` must be given")
+    if replace_fn is not None:
+        repl = tuple(replace_fn(t) for t in targets)
+    else:
+        repl = (replace,) if single else tuple(replace)
     ids = {id(t): r for t, r in zip(targets, repl)}
 
     def rec(n):

@@ -12,6 +12,8 @@ from .classification.resnet import (
     wide_resnet50_2,
     wide_resnet101_2,
 )
+from .segmentation.deeplabv3 import ASPP, DeepLabHead, DeepLabV3, deeplabv3
+from .segmentation.fcn import FCN, FCNHead, fcn
 from .classification.swin import SwinTransformer, swin_b, swin_s, swin_t
 from .classification.vgg import VGG, vgg11, vgg11_bn, vgg13, vgg13_bn, vgg16, vgg16_bn, vgg19, vgg19_bn
 from .classification.vit import (

@@ -225,6 +225,8 @@ class ResNet(Module):
         else:
             x = self.avgpool(x)
         x = ops.flatten(x)
+        if not isinstance(self.fc, nn.Linear):                # e.g. silenced with nn.Identity by the segmentation models (fcn.py:106)
+            return self.fc(x)
         return ops.linear_head(x, self.fc)
 
 

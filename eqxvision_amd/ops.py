@@ -225,6 +225,10 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
     w, scale, shift = prep_conv(conv, bn, "krsc", dt)
     Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
     Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    if K % 8 and dt == "bf16" and conv.groups == 1 and residual is None and C % 64 == 0:
+        # an output width the MFMA kernels cannot store in 16-byte pieces (21-class segmentation heads, fcn.py:33): run the
+        # convolution on zero-padded filters and compact the rows afterwards instead of dropping to the VALU kernel
+        return _conv2d_padded_k(x, conv, bn, act, (w, scale, shift), (B, H, W, C, Ho, Wo))
     y = empty((B, Ho, Wo, K), TORCH_DT[dt])
     res = None
     if residual is not None:
@@ -234,6 +238,32 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
         res = residual.t
     _lib.call("mv_conv2d_nhwc_fwd", _ptr(x.t), _ptr(w), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y),
               B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, conv.groups, ACT[act], DT[dt], DT[dt], stream_ptr())
+    return Act(y, "map", x.batched)
+
+
+def _conv2d_padded_k(x: Act, conv, bn, act, prep, dims) -> Act:
+    w, scale, shift = prep
+    B, H, W, C, Ho, Wo = dims
+    K = conv.out_channels
+    Kp = (K + 7) // 8 * 8
+    cache = conv._cache()
+    key = ("kpad", id(bn))
+    hit = cache.get(key)
+    if hit is None:
+        wp = torch.zeros((Kp,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+        wp[:K] = w
+        pad1 = lambda v, fill: None if v is None else torch.cat([v, torch.full((Kp - K,), fill, dtype=v.dtype, device=v.device)])
+        hit = (wp, pad1(scale, 1.0), pad1(shift, 0.0))
+        cache[key] = hit
+    kh, kw = conv.kernel_size
+    sh, sw = conv.stride
+    ph, pw = conv.padding
+    dh, dw = conv.dilation
+    yp = empty((B, Ho, Wo, Kp), torch.bfloat16)
+    _lib.call("mv_conv2d_nhwc_fwd", _ptr(x.t), _ptr(hit[0]), _ptr(hit[1]), _ptr(hit[2]), None, _ptr(yp),
+              B, H, W, C, Kp, kh, kw, sh, sw, ph, pw, dh, dw, 1, ACT[act], _lib.BF16, _lib.BF16, stream_ptr())
+    y = empty((B, Ho, Wo, K), torch.bfloat16)
+    _lib.call("mv_copy_rows", _ptr(yp), _ptr(y), B * Ho * Wo, K * 2, Kp * 2, K * 2, stream_ptr())
     return Act(y, "map", x.batched)
 
 
@@ -694,6 +724,42 @@ def swin_window_attention(qkv: Act, bias: torch.Tensor, heads: int, window, shif
     _lib.call("mv_swin_window_attn_fwd", _ptr(qkv.t), _ptr(bias), _ptr(out), B, Hf, Wf, C, heads,
               int(window[0]), int(window[1]), int(shift[0]), int(shift[1]), qkv.dt, stream_ptr())
     return Act(out, "map", qkv.batched)
+
+
+def resize_bilinear(x: Act, size, final: bool = False) -> Act:
+    """jax.image.resize(x, (C,) + size, "bilinear") of a feature map (up-sampling).  `final`: the result is what the caller of the
+    model receives -> written directly as fp32 NCHW; otherwise an NHWC map in the compute dtype for further layers."""
+    x = as_map(x)
+    B, h, w, C = x.t.shape
+    H, W = int(size[0]), int(size[1])
+    if final:
+        y = empty((B, C, H, W), torch.float32)
+        _lib.call("mv_resize_bilinear_nhwc_fwd", _ptr(x.t), _ptr(y), B, h, w, C, H, W, x.dt, _lib.F32, 1, stream_ptr())
+        return Act(y, "img", x.batched)
+    if (H, W) == (h, w):
+        return x
+    y = empty((B, H, W, C), x.t.dtype)
+    _lib.call("mv_resize_bilinear_nhwc_fwd", _ptr(x.t), _ptr(y), B, h, w, C, H, W, x.dt, x.dt, 0, stream_ptr())
+    return Act(y, "map", x.batched)
+
+
+def concat_channels(xs) -> Act:
+    """jnp.concatenate(maps, axis=0) of (C,H,W) samples == channel concatenation of NHWC maps (deeplabv3.py:132-136)."""
+    maps = [as_map(x) for x in xs]
+    B, H, W, _ = maps[0].t.shape
+    dt = maps[0].t.dtype
+    for m in maps:
+        if tuple(m.t.shape[:3]) != (B, H, W) or m.t.dtype != dt:
+            raise ValueError(f"concat_channels: mismatched maps {[tuple(m.t.shape) for m in maps]}")
+    ctot = sum(m.t.shape[3] for m in maps)
+    y = empty((B, H, W, ctot), dt)
+    es = y.element_size()
+    off = 0
+    for m in maps:
+        c = m.t.shape[3]
+        _lib.call("mv_copy_rows", _ptr(m.t), y.data_ptr() + off * es, B * H * W, c * es, c * es, ctot * es, stream_ptr())
+        off += c
+    return Act(y, "map", maps[0].batched)
 
 
 def patch_merge_gather(x: Act) -> Act:

@@ -32,6 +32,11 @@ _STEMS = {
     "vgg19_bn": "vgg19_bn-c79401a0",
     "swin_t": "swin_t-704ceda3", "swin_s": "swin_s-5e29d889", "sim_b": "swin_b-68c6b09e",
 }
+SEGMENTATION_URLS = {      # reference utils.py:20-24
+    "deeplabv3_resnet50": _PT + "deeplabv3_resnet50_coco-cd0a2569.pth",
+    "fcn_resnet50": _PT + "fcn_resnet50_coco-1167a1af.pth",
+    "lraspp_mobilenetv3_large": _PT + "lraspp_mobilenet_v3_large-d234d4ea.pth",
+}
 CLASSIFICATION_URLS = {k: f"{_PT}{v}.pth" for k, v in _STEMS.items()}
 for _arch, _dir in (("small", "deitsmall"), ("base", "vitbase")):
     for _p in (16, 8):

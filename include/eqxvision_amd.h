@@ -163,6 +163,19 @@ int mv_ln_mlp_supported(int64_t M, int C, int hidden, int x_dtype);
 int mv_ln_mlp_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int64_t M, int C,
                   int hidden, float eps, int x_dtype, mv_stream_t stream);
 
+/* jax.image.resize(x, shape, method="bilinear") for up-sampling (segmentation/_utils.py:52-58: logits -> input resolution;
+ * deeplabv3.py:66-72: the pooled ASPP branch back to the feature size): half-pixel centres, out-of-range taps dropped and the
+ * rest renormalised (== clamped taps for the 2-tap kernel).  x NHWC [N,h,w,C]; y NHWC [N,H,W,C] or, with out_nchw, NCHW
+ * [N,C,H,W] (the layout the reference returns).  H >= h and W >= w, else MV_E_UNSUPPORTED (the antialiased down-sampling
+ * window is not on the path). */
+int mv_resize_bilinear_nhwc_fwd(const void* x, void* y, int N, int h, int w, int C, int H, int W, int in_dtype, int out_dtype,
+                                int out_nchw, mv_stream_t stream);
+
+/* rows x row_bytes strided copy (jnp.concatenate of NHWC maps along channels, deeplabv3.py:132-136: one call per source with
+ * dst offset by the channels already placed).  Sizes and pitches in bytes, multiples of 2. */
+int mv_copy_rows(const void* src, void* dst, int64_t rows, int64_t row_bytes, int64_t src_pitch, int64_t dst_pitch,
+                 mv_stream_t stream);
+
 /* eqx.nn.MaxPool2d (resnet.py:254, alexnet.py:46,49,56): -inf padding, floor output size. */
 int mv_maxpool2d_nhwc_fwd(const void* x, void* y, int N, int H, int W, int C,
                           int kh, int kw, int sh, int sw, int ph, int pw, int dtype, mv_stream_t stream);

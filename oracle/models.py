@@ -111,30 +111,77 @@ def vgg_forward(sd, x, plan, batch_norm=False, bf16=False):
 
 
 # ---------------------------------------------------------------- resnet.py:144-162, 335-358
-def resnet_forward(sd, x, block="bottleneck", layers=(3, 4, 6, 3), bf16=False, groups=1):
+def resnet_stages(sd, x, block="bottleneck", layers=(3, 4, 6, 3), bf16=False, groups=1, dilate=(False, False, False),
+                  prefix=""):
+    """Stem + the four stages; returns [layer1, layer2, layer3, layer4] outputs.  `dilate` = replace_stride_with_dilation
+    (resnet.py:286-333: a dilated stage keeps stride 1, its first block uses the previous dilation, the others the new one)."""
     q = _Q(bf16)
     x = q(x)
-    x = _conv_bn(sd, q, x, "conv1", "bn1", stride=2, padding=3, relu=True)         # resnet.py:344-346
+    x = _conv_bn(sd, q, x, prefix + "conv1", prefix + "bn1", stride=2, padding=3, relu=True)   # resnet.py:344-346
     x = O.maxpool2d(x, 3, 2, 1)                                                      # resnet.py:347
+    outs, dilation = [], 1
     for li, nblk in enumerate(layers):
         stride = 1 if li == 0 else 2
+        prev = dilation
+        if li > 0 and dilate[li - 1]:
+            dilation *= stride
+            stride = 1
         for bi in range(nblk):
-            p = f"layer{li + 1}.{bi}"
+            p = f"{prefix}layer{li + 1}.{bi}"
             s = stride if bi == 0 else 1
+            d = prev if bi == 0 else dilation
             if (p + ".downsample.0.weight") in sd:                                   # resnet.py:295-303
                 identity = _conv_bn(sd, q, x, p + ".downsample.0", p + ".downsample.1", stride=s)
             else:
                 identity = x
             if block == "bottleneck":                                                # resnet.py:144-162
                 out = _conv_bn(sd, q, x, p + ".conv1", p + ".bn1", relu=True)
-                out = _conv_bn(sd, q, out, p + ".conv2", p + ".bn2", stride=s, padding=1, groups=groups, relu=True)
+                out = _conv_bn(sd, q, out, p + ".conv2", p + ".bn2", stride=s, padding=d, dilation=d, groups=groups, relu=True)
                 x = _conv_bn(sd, q, out, p + ".conv3", p + ".bn3", relu=True, residual=identity)
             else:                                                                    # resnet.py:80-92
                 out = _conv_bn(sd, q, x, p + ".conv1", p + ".bn1", stride=s, padding=1, relu=True)
                 x = _conv_bn(sd, q, out, p + ".conv2", p + ".bn2", padding=1, relu=True, residual=identity)
+        outs.append(x)
+    return outs
+
+
+def resnet_forward(sd, x, block="bottleneck", layers=(3, 4, 6, 3), bf16=False, groups=1):
+    q = _Q(bf16)
+    x = resnet_stages(sd, x, block, layers, bf16, groups)[-1]
     x = q(O.adaptive_avgpool2d(x, (1, 1)))                                           # resnet.py:354
     x = np.ravel(x)
     return O.linear(x, q(sd["fc.weight"]), sd["fc.bias"])                            # resnet.py:356
+
+
+# ---------------------------------------------------------------- segmentation/_utils.py:36-60, fcn.py:19-35, deeplabv3.py:24-136
+def _fcn_head(sd, q, x, p):
+    y = _conv_bn(sd, q, x, p + ".0", p + ".1", padding=1, relu=True)                 # conv3x3 + BN + relu (+ Dropout = id)
+    return q(O.conv2d(y, q(sd[p + ".4.weight"]), sd[p + ".4.bias"]))
+
+
+def _deeplab_head(sd, q, x, p):
+    a = p + ".0"
+    branches = [_conv_bn(sd, q, x, a + ".convs.0.0", a + ".convs.0.1", relu=True)]
+    for i, rate in enumerate((12, 24, 36)):
+        branches.append(_conv_bn(sd, q, x, f"{a}.convs.{i + 1}.0", f"{a}.convs.{i + 1}.1", padding=rate, dilation=rate, relu=True))
+    pooled = q(O.adaptive_avgpool2d(x, (1, 1)))
+    pooled = _conv_bn(sd, q, pooled, a + ".convs.4.1", a + ".convs.4.2", relu=True)
+    branches.append(q(O.resize_bilinear(pooled, x.shape[-2:])))
+    y = np.concatenate(branches, axis=0)
+    y = _conv_bn(sd, q, y, a + ".project.0", a + ".project.1", relu=True)
+    y = _conv_bn(sd, q, y, p + ".1", p + ".2", padding=1, relu=True)
+    return q(O.conv2d(y, q(sd[p + ".4.weight"]), sd[p + ".4.bias"]))
+
+
+def segmentation_forward(sd, x, kind="fcn", layers=(3, 4, 6, 3), aux=True, bf16=False):
+    """(aux, out) of fcn / deeplabv3 on the dilated ResNet backbone ([False, True, True]); both at the input resolution."""
+    q = _Q(bf16)
+    size = x.shape[-2:]
+    feats = resnet_stages(sd, x, "bottleneck", layers, bf16, dilate=(False, True, True), prefix="backbone.")
+    head = _fcn_head if kind == "fcn" else _deeplab_head
+    out = O.resize_bilinear(head(sd, q, feats[3], "classifier"), size)
+    a = O.resize_bilinear(_fcn_head(sd, q, feats[2], "aux_classifier"), size) if aux else None
+    return a, out
 
 
 # ---------------------------------------------------------------- vit.py:139-157, 261-273

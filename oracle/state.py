@@ -135,6 +135,40 @@ def resnet_state(seed=1, block="bottleneck", layers=(3, 4, 6, 3), num_classes=10
     return sd
 
 
+def segmentation_state(seed=1, kind="fcn", layers=(3, 4, 6, 3), num_classes=21, aux=True):
+    """torchvision fcn_resnet50 / deeplabv3_resnet50 state_dict order: backbone (ResNet without fc), classifier, aux_classifier."""
+    rng = np.random.Generator(np.random.PCG64(seed + 100))
+    sd = OrderedDict()
+    for k, v in resnet_state(seed, "bottleneck", layers, 10).items():
+        if not k.startswith("fc."):
+            sd["backbone." + k] = v
+
+    def fcn_head(p, cin):
+        _conv(sd, rng, p + ".0", cin, cin // 4, 3, False)
+        _bn(sd, rng, p + ".1", cin // 4)
+        _conv(sd, rng, p + ".4", cin // 4, num_classes, 1, True)
+
+    if kind == "fcn":
+        fcn_head("classifier", 2048)
+    else:
+        a = "classifier.0"
+        _conv(sd, rng, a + ".convs.0.0", 2048, 256, 1, False)
+        _bn(sd, rng, a + ".convs.0.1", 256)
+        for i in range(3):
+            _conv(sd, rng, f"{a}.convs.{i + 1}.0", 2048, 256, 3, False)
+            _bn(sd, rng, f"{a}.convs.{i + 1}.1", 256)
+        _conv(sd, rng, a + ".convs.4.1", 2048, 256, 1, False)
+        _bn(sd, rng, a + ".convs.4.2", 256)
+        _conv(sd, rng, a + ".project.0", 5 * 256, 256, 1, False)
+        _bn(sd, rng, a + ".project.1", 256)
+        _conv(sd, rng, "classifier.1", 256, 256, 3, False)
+        _bn(sd, rng, "classifier.2", 256)
+        _conv(sd, rng, "classifier.4", 256, num_classes, 1, True)
+    if aux:
+        fcn_head("aux_classifier", 1024)
+    return sd
+
+
 def _trunc_normal(rng, shape):
     x = rng.standard_normal(shape)
     bad = np.abs(x) > 2

@@ -81,30 +81,76 @@ def vgg_forward(sd, x, plan, batch_norm=False):
     return F.linear(x, t["classifier.6.weight"], t["classifier.6.bias"])
 
 
-@torch.no_grad()
-def resnet_forward(sd, x, block="bottleneck", layers=(3, 4, 6, 3), groups=1):
-    sd = _t(sd)
-    x = torch.as_tensor(x)
-    x = F.relu(_bn(sd, F.conv2d(x, sd["conv1.weight"], None, 2, 3), "bn1"))
+def _resnet_stages(sd, x, block="bottleneck", layers=(3, 4, 6, 3), groups=1, dilate=(False, False, False), prefix=""):
+    x = F.relu(_bn(sd, F.conv2d(x, sd[prefix + "conv1.weight"], None, 2, 3), prefix + "bn1"))
     x = F.max_pool2d(x, 3, 2, 1)
+    outs, dilation = [], 1
     for li, nblk in enumerate(layers):
         stride = 1 if li == 0 else 2
+        prev = dilation
+        if li > 0 and dilate[li - 1]:
+            dilation *= stride
+            stride = 1
         for bi in range(nblk):
-            p = f"layer{li + 1}.{bi}"
+            p = f"{prefix}layer{li + 1}.{bi}"
             s = stride if bi == 0 else 1
+            d = prev if bi == 0 else dilation
             idt = x
             if (p + ".downsample.0.weight") in sd:
                 idt = _bn(sd, F.conv2d(x, sd[p + ".downsample.0.weight"], None, s), p + ".downsample.1")
             if block == "bottleneck":
                 o = F.relu(_bn(sd, F.conv2d(x, sd[p + ".conv1.weight"]), p + ".bn1"))
-                o = F.relu(_bn(sd, F.conv2d(o, sd[p + ".conv2.weight"], None, s, 1, 1, groups), p + ".bn2"))
+                o = F.relu(_bn(sd, F.conv2d(o, sd[p + ".conv2.weight"], None, s, d, d, groups), p + ".bn2"))
                 o = _bn(sd, F.conv2d(o, sd[p + ".conv3.weight"]), p + ".bn3")
             else:
                 o = F.relu(_bn(sd, F.conv2d(x, sd[p + ".conv1.weight"], None, s, 1), p + ".bn1"))
                 o = _bn(sd, F.conv2d(o, sd[p + ".conv2.weight"], None, 1, 1), p + ".bn2")
             x = F.relu(o + idt)
+        outs.append(x)
+    return outs
+
+
+@torch.no_grad()
+def resnet_forward(sd, x, block="bottleneck", layers=(3, 4, 6, 3), groups=1):
+    sd = _t(sd)
+    x = _resnet_stages(sd, torch.as_tensor(x), block, layers, groups)[-1]
     x = F.adaptive_avg_pool2d(x, 1).flatten(1)
     return F.linear(x, sd["fc.weight"], sd["fc.bias"])
+
+
+def _fcn_head_t(sd, x, p):
+    y = F.relu(_bn(sd, F.conv2d(x, sd[p + ".0.weight"], None, 1, 1), p + ".1"))
+    return F.conv2d(y, sd[p + ".4.weight"], sd[p + ".4.bias"])
+
+
+def _deeplab_head_t(sd, x, p):
+    a = p + ".0"
+    br = [F.relu(_bn(sd, F.conv2d(x, sd[a + ".convs.0.0.weight"]), a + ".convs.0.1"))]
+    for i, r in enumerate((12, 24, 36)):
+        br.append(F.relu(_bn(sd, F.conv2d(x, sd[f"{a}.convs.{i + 1}.0.weight"], None, 1, r, r), f"{a}.convs.{i + 1}.1")))
+    g = F.adaptive_avg_pool2d(x, 1)
+    g = F.relu(_bn(sd, F.conv2d(g, sd[a + ".convs.4.1.weight"]), a + ".convs.4.2"))
+    br.append(F.interpolate(g, size=x.shape[-2:], mode="bilinear", align_corners=False))
+    y = torch.cat(br, 1)
+    y = F.relu(_bn(sd, F.conv2d(y, sd[a + ".project.0.weight"]), a + ".project.1"))
+    y = F.relu(_bn(sd, F.conv2d(y, sd[p + ".1.weight"], None, 1, 1), p + ".2"))
+    return F.conv2d(y, sd[p + ".4.weight"], sd[p + ".4.bias"])
+
+
+@torch.no_grad()
+def segmentation_forward(sd, x, kind="fcn", layers=(3, 4, 6, 3), aux=True):
+    """torch.nn.functional restatement of fcn / deeplabv3 on the dilated ResNet ([False, True, True]); up-sampling with
+    align_corners=False == jax.image.resize "bilinear" for out >= in (checked in tests/test_oracle.py)."""
+    sd = _t(sd)
+    x = torch.as_tensor(x)
+    size = x.shape[-2:]
+    feats = _resnet_stages(sd, x, "bottleneck", layers, dilate=(False, True, True), prefix="backbone.")
+    head = _fcn_head_t if kind == "fcn" else _deeplab_head_t
+    out = F.interpolate(head(sd, feats[3], "classifier"), size=size, mode="bilinear", align_corners=False)
+    a = None
+    if aux:
+        a = F.interpolate(_fcn_head_t(sd, feats[2], "aux_classifier"), size=size, mode="bilinear", align_corners=False)
+    return a, out
 
 
 def _vit_tokens(sd, x, patch):

@@ -383,6 +383,57 @@ def linear_split_case(M, K, N, out="fp32", seed=0):
     return run
 
 
+def resize_case(N, h, w, C, H, W, dtype="bf16", nchw=True, seed=0):
+    """mv_resize_bilinear_nhwc_fwd vs the restatement of jax.image.resize (oracle.np_ops.resize_bilinear)."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        q = bf if dtype == "bf16" else (lambda a: np.asarray(a, np.float32))
+        x = q(rng.standard_normal((N, C, h, w)))
+        ref = np.stack([O.resize_bilinear(x[i], (H, W)) for i in range(N)])
+        xd = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)), dtype)
+        odt = torch.float32 if nchw else xd.dtype
+        y = torch.empty((N, C, H, W) if nchw else (N, H, W, C), dtype=odt, device="cuda")
+        L.call("mv_resize_bilinear_nhwc_fwd", xd.data_ptr(), y.data_ptr(), N, h, w, C, H, W, DT[dtype], 0 if odt == torch.float32 else 1,
+               1 if nchw else 0, _stream())
+        torch.cuda.synchronize()
+        got = host(y) if nchw else host(y).transpose(0, 3, 1, 2)
+        return _cmp(got, ref, 1e-5 if nchw else (TOL_BF16 if dtype == "bf16" else 1e-5))
+    return run
+
+
+def resize_down_refused_case():
+    def run():
+        L = _lib()
+        x = torch.zeros((1, 8, 8, 4), dtype=torch.float32, device="cuda")
+        y = torch.zeros((1, 4, 4, 4), dtype=torch.float32, device="cuda")
+        rc = L.load().mv_resize_bilinear_nhwc_fwd(x.data_ptr(), y.data_ptr(), 1, 8, 8, 4, 4, 4, 0, 0, 0, _stream())
+        return {"ok": rc == -2, "err": float(rc)}
+    return run
+
+
+def copy_rows_case(rows, parts, dtype="bf16", seed=0):
+    """channel concatenation through mv_copy_rows (one call per source) vs np.concatenate."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        q = bf if dtype == "bf16" else (lambda a: np.asarray(a, np.float32))
+        srcs = [q(rng.standard_normal((rows, c))) for c in parts]
+        ref = np.concatenate(srcs, 1)
+        es = 2 if dtype == "bf16" else 4
+        y = torch.zeros((rows, sum(parts)), dtype=torch.bfloat16 if dtype == "bf16" else torch.float32, device="cuda")
+        off, keep = 0, []
+        for a in srcs:
+            d = dev(a, dtype)
+            keep.append(d)
+            c = a.shape[1]
+            L.call("mv_copy_rows", d.data_ptr(), y.data_ptr() + off * es, rows, c * es, c * es, sum(parts) * es, _stream())
+            off += c
+        torch.cuda.synchronize()
+        return _cmp(host(y), ref, 0.0)
+    return run
+
+
 def ln_linear_case(M, K, N, stream="fp32", act=0, seed=0, flags=()):
     """mv_ln_linear_fwd (LayerNorm folded into the consuming Linear) vs float64 LayerNorm -> Linear (swin.py:572-578)."""
     def run():
@@ -1016,6 +1067,14 @@ def all_cases():
           ("split/linear_swin_merge_384_192", linear_split_case(128 * 28 * 28 // 4, 384, 192, seed=511)),
           ("split/linear_swin_merge_1536_768", linear_split_case(64 * 49, 1536, 768, seed=512)),
           ("split/linear_bf16out_ragged", linear_split_case(9000 + 37, 256, 200, out="bf16", seed=513)),
+          ("resize/logits_28_to_224_nchw", resize_case(2, 28, 28, 21, 224, 224)),
+          ("resize/pooled_1_to_28_nhwc", resize_case(3, 1, 1, 256, 28, 28, nchw=False)),
+          ("resize/odd_7x5_to_20x33_f32", resize_case(2, 7, 5, 3, 20, 33, dtype="fp32")),
+          ("resize/identity_size_nhwc_f32", resize_case(1, 9, 9, 8, 9, 9, dtype="fp32", nchw=False)),
+          ("resize/downsample_refused", resize_down_refused_case()),
+          ("concat/aspp_5x256", copy_rows_case(2 * 28 * 28, (256, 256, 256, 256, 256))),
+          ("concat/odd_widths_f32", copy_rows_case(37, (3, 5, 2), dtype="fp32")),
+          ("concat/odd_widths_bf16", copy_rows_case(37, (3, 8, 1))),
           ("ln_linear/swin_qkv_96_288_f32stream", ln_linear_case(4 * 56 * 56, 96, 288, "fp32", seed=530)),
           ("ln_linear/swin_fc1_192_768_gelu", ln_linear_case(8 * 28 * 28 * 2, 192, 768, "fp32", act=2, seed=531, flags=(("ln_stream_192", 1),))),
           ("ln_linear/swin_qkv_192_576_bf16stream_ragged", ln_linear_case(8192 + 45, 192, 576, "bf16", seed=532, flags=(("ln_stream_192", 1),))),

@@ -124,6 +124,51 @@ def vgg_case(plan, batch_norm, size, B, classes=10, dtype="bf16", full_ref="nump
     return run
 
 
+def segmentation_case(kind, layers, size, B, classes=5, dtype="bf16", aux=True, full_ref="numpy", jit=False):
+    """fcn / deeplabv3 on the dilated ResNet (reference tests/test_models/test_fcn.py:16-28, test_deeplabv3.py): (aux, out) at the
+    input resolution vs the oracle on the same synthetic checkpoint."""
+    def run():
+        import eqxvision_amd as eqv
+        from eqxvision_amd.models.classification import resnet as R
+        sd = S.segmentation_state(1, kind, layers, classes, aux)
+        x = S.synthetic_images(B, size, seed=0)
+        bb = lambda: R._resnet(R._ResNetBottleneck, list(layers), None, replace_stride_with_dilation=[False, True, True])
+        build = eqv.models.fcn if kind == "fcn" else eqv.models.deeplabv3
+        tap = (lambda m: [m.layer3, m.layer4]) if aux else (lambda m: [m.layer4])
+        fac = lambda torch_weights=None, **kw: build(num_classes=classes, backbone=bb(), intermediate_layers=tap,
+                                                     aux_in_channels=1024 if aux else None, torch_weights=torch_weights)
+        net = _load(fac, sd)
+        if jit:
+            fwd, got = _run(net, x, dtype, jit=True)
+            with eqv.precision(dtype):
+                for _ in range(3):
+                    got = fwd(net, x, _keys(B))          # trace, capture, replay
+            torch.cuda.synchronize()
+        else:
+            got = _run(net, x, dtype)
+        g_aux, g_out = got
+        if full_ref == "torch":
+            r_aux, r_out = TR.segmentation_forward(sd, x, kind, layers, aux)
+            r_out = r_out.numpy()
+            r_aux = r_aux.numpy() if aux else None
+        else:
+            pairs = [OM.segmentation_forward(sd, im, kind, layers, aux) for im in x]
+            r_out = np.stack([p[1] for p in pairs])
+            r_aux = np.stack([p[0] for p in pairs]) if aux else None
+        tol = 1e-2 if dtype == "bf16" else 1e-3
+        info = _cmp(g_out.cpu().numpy(), r_out, tol)
+        info["shape_ok"] = tuple(g_out.shape) == (B, classes, size, size)
+        if aux:
+            ia = _cmp(g_aux.cpu().numpy(), r_aux, tol)
+            info["aux_err"] = ia.get("err")
+            info["ok"] = info["ok"] and ia["ok"]
+        else:
+            info["ok"] = info["ok"] and g_aux is None
+        info["ok"] = info["ok"] and info["shape_ok"]
+        return info
+    return run
+
+
 def vit_case(img, patch, dim, depth, heads, B, classes=10, dtype="bf16", attn=False, full_ref="numpy"):
     def run():
         import eqxvision_amd as eqv
@@ -448,6 +493,10 @@ def all_cases(full=True):
          ("model/vgg_small_bn_avgpool2x2", vgg_case((16, "M", 32, 32, "M"), True, 56, 3)),
          ("model/vgg_small_fp32", vgg_case((8, "M", 16, "M"), False, 28, 2, dtype="fp32")),
          ("model/vgg_small_c64_128", vgg_case((64, "M", 128, 128, "M"), False, 56, 2)),
+         ("model/fcn_tiny_backbone", segmentation_case("fcn", (1, 1, 1, 1), 64, 2)),
+         ("model/fcn_tiny_no_aux_fp32", segmentation_case("fcn", (1, 1, 1, 1), 64, 1, dtype="fp32", aux=False)),
+         ("model/deeplabv3_tiny_backbone", segmentation_case("deeplabv3", (1, 1, 1, 1), 64, 2)),
+         ("model/deeplabv3_tiny_jit_replay", segmentation_case("deeplabv3", (1, 1, 1, 1), 96, 3, jit=True)),
          ("model/swin_tiny", swin_case(56, 32, (2, 2), (2, 4), 2)),
          ("model/swin_tiny_fp32", swin_case(56, 32, (2, 2), (2, 4), 1, dtype="fp32")),
          ("model/conv_norm_act_reference_3_4_5x5", conv_norm_act_case(3, 4, 5, 1)),
@@ -473,6 +522,8 @@ def all_cases(full=True):
               ("model/vit_base_B2", vit_case(224, 16, 768, 12, 12, 2, classes=1000, full_ref="torch")),
               ("model/vgg11_B2", vgg_case("A", False, 224, 2, classes=1000, full_ref="torch")),
               ("model/vgg16_bn_B1", vgg_case("D", True, 224, 1, classes=1000, full_ref="torch")),
+              ("model/fcn_resnet50_B2", segmentation_case("fcn", (3, 4, 6, 3), 224, 2, classes=21, full_ref="torch")),
+              ("model/deeplabv3_resnet50_B2", segmentation_case("deeplabv3", (3, 4, 6, 3), 224, 2, classes=21, full_ref="torch")),
               ("model/swin_t_B1", swin_case(224, 96, (2, 2, 6, 2), (3, 6, 12, 24), 1, classes=1000, full_ref="torch")),
               ("model/resnet50_B256_full_config", full_batch_case("resnet50", 256)),
               ("model/vit_base_B256_full_config", full_batch_case("vit_base", 256)),
