@@ -140,6 +140,33 @@ def test_vgg_structure_and_reference_quirks():
     assert eqv.utils.CLASSIFICATION_URLS["vgg16_bn"].endswith("vgg16_bn-6c64b313.pth")
 
 
+def test_segmentation_constructors_and_checkpoint_order():
+    """reference fcn.py:86-103 / deeplabv3.py:190-207 argument validation; pytree order == torchvision's state_dict order
+    (backbone without fc, classifier, aux_classifier)."""
+    from eqxvision_amd.models.classification import resnet as R
+    small = lambda: R._resnet(R._ResNetBottleneck, [1, 1, 1, 1], None, replace_stride_with_dilation=[False, True, True])
+    two = lambda m: [m.layer3, m.layer4]
+    with pytest.raises(ValueError, match="exactly 2 layers"):
+        eqv.models.fcn(backbone=small(), intermediate_layers=lambda m: [m.layer4], aux_in_channels=1024)
+    with pytest.raises(ValueError, match="expected number of layers is 1"):
+        eqv.models.fcn(backbone=small(), intermediate_layers=two)
+    with pytest.raises(ValueError, match="exactly 2 layers"):
+        eqv.models.deeplabv3(backbone=small(), intermediate_layers=lambda m: [m.layer4])      # aux_in_channels defaults to 1024
+    for kind, build in (("fcn", eqv.models.fcn), ("deeplabv3", eqv.models.deeplabv3)):
+        net = build(num_classes=5, backbone=small(), intermediate_layers=two, aux_in_channels=1024)
+        assert isinstance(net.backbone.model.fc, nn.Identity)                                # silenced head holds no weights
+        assert type(net.backbone.model.layer4).__name__ == "IntermediateWrapper"
+        mine = eqv.utils.state_dict(eqv.utils.randomize_batchnorm(net))
+        sd = S.segmentation_state(1, kind, (1, 1, 1, 1), 5)
+        want = [np.asarray(sd[k]).size for k in _keys(sd)]
+        assert [v.size for v in mine.values()] == want
+        with pytest.raises(RuntimeError, match="PRNGKey"):
+            net(np.zeros((3, 64, 64), np.float32), key=None)
+    assert eqv.utils.SEGMENTATION_URLS["fcn_resnet50"].endswith("fcn_resnet50_coco-1167a1af.pth")
+    layer4 = eqv.models.deeplabv3(backbone=small(), intermediate_layers=two).backbone.model.layer4.layer
+    assert layer4.layers[0].conv2.dilation == (2, 2) and layer4.layers[0].conv2.stride == (1, 1)
+
+
 def test_conv_norm_activation_structure():
     c = eqv.layers.ConvNormActivation(3, 4, key=eqv.random.PRNGKey(1))
     assert [type(l).__name__ for l in c.layers] == ["Conv2d", "BatchNorm", "Lambda"] and c.out_channels == 4

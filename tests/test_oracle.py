@@ -151,3 +151,37 @@ def test_swin_shift_mask_and_window_edge_cases():
         assert rel(got, ref) < 1e-5
     with pytest.raises(ValueError):
         O.shifted_window_attention(x[:, :13], wq, wp, bias, [7, 7], heads, [0, 0], bq, bp)
+
+
+def test_resize_bilinear_restatement_matches_torch_upsampling():
+    """jax.image.resize "bilinear" (restated from jax._src.image.scale) == torch align_corners=False when up-sampling."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import np_ops as O
+    rng = np.random.default_rng(0)
+    for h, w, H, W in ((28, 28, 224, 224), (1, 1, 28, 28), (7, 5, 20, 33), (14, 14, 14, 14)):
+        x = rng.standard_normal((3, h, w)).astype(np.float32)
+        ref = F.interpolate(torch.from_numpy(x)[None], size=(H, W), mode="bilinear", align_corners=False)[0].numpy()
+        np.testing.assert_allclose(O.resize_bilinear(x, (H, W)), ref, atol=2e-6)
+    # down-sampling: the antialias window makes it a box-ish average, NOT torch's 2-tap interpolation
+    np.testing.assert_allclose(O._resize_weights(8, 4)[:, 1], [0, .125, .375, .375, .125, 0, 0, 0], atol=1e-12)
+    np.testing.assert_allclose(O.resize_bilinear(np.full((1, 8, 8), 3.0, np.float32), (4, 4)), 3.0, atol=1e-6)
+
+
+def test_segmentation_and_vgg_restatements_agree_numpy_vs_torch():
+    from oracle import models as OM
+    from oracle import state as S
+    from oracle import torch_ref as TR
+    x = S.synthetic_images(1, 64, seed=0)
+    for kind in ("fcn", "deeplabv3"):
+        sd = S.segmentation_state(1, kind, (1, 1, 1, 1), 5)
+        a, o = OM.segmentation_forward(sd, x[0], kind, (1, 1, 1, 1))
+        ta, to = TR.segmentation_forward(sd, x, kind, (1, 1, 1, 1))
+        np.testing.assert_allclose(o, to[0].numpy(), atol=1e-5)
+        np.testing.assert_allclose(a, ta[0].numpy(), atol=1e-5)
+    plan = (8, "M", 16, "M")
+    for bn in (False, True):
+        sd = S.vgg_state(1, plan, bn, 10)
+        xs = S.synthetic_images(2, 28, seed=0)
+        np.testing.assert_allclose(np.stack([OM.vgg_forward(sd, im, plan, bn) for im in xs]),
+                                   TR.vgg_forward(sd, xs, plan, bn).numpy(), atol=1e-5)
