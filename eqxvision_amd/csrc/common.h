@@ -113,6 +113,10 @@ int igemm_supported(int C, int K, int R, int S, int groups, int in_dtype, int ou
 int igemm_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                  void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
                  int dh, int dw, int act, int in_dtype, int out_dtype, hipStream_t stream);
+int igemm_grouped64_supported(int C, int K, int R, int S, int groups, int in_dtype, int out_dtype);
+int igemm_grouped64_launch(const void* x, const void* w64, const float* scale, const float* shift, const void* residual, void* y,
+                           int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int act,
+                           int out_dtype, hipStream_t stream);
 int stream1x1_supported(int C, int K, int in_dtype, int out_dtype, long long M);
 int stream1x1_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                      void* y, long long M, int C, int K, int act, int out_dtype, hipStream_t stream);

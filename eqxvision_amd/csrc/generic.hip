@@ -828,6 +828,27 @@ int mv_linear_split_fwd(const void* x, const void* w_hi_lo, const float* scale, 
                               (hipStream_t)stream);
 }
 
+int mv_conv2d_grouped64_supported(int C, int K, int R, int S, int groups, int in_dtype, int out_dtype) {
+    return !get_flag("force_generic") && !get_flag("no_grouped64") && igemm_grouped64_supported(C, K, R, S, groups, in_dtype, out_dtype);
+}
+
+int mv_conv2d_nhwc_grouped64_fwd(const void* x, const void* w64, const float* scale, const float* shift, const void* residual,
+                                 void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh,
+                                 int dw, int groups, int act, int in_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && w64 && y, "conv2d_grouped64: NULL pointer");
+    MV_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && dh > 0 &&
+                 dw > 0, "conv2d_grouped64: bad dims");
+    const long long Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
+    MV_CHECK_ARG(Ho > 0 && Wo > 0 && (long long)N * Ho * Wo < (1LL << 31) - 256, "conv2d_grouped64: bad output size");
+    if (!mv_conv2d_grouped64_supported(C, K, R, S, groups, in_dtype, out_dtype)) {
+        set_error("conv2d_grouped64: unsupported configuration C=%d K=%d groups=%d (ask mv_conv2d_grouped64_supported first)", C, K,
+                  groups);
+        return MV_E_UNSUPPORTED;
+    }
+    return igemm_grouped64_launch(x, w64, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype,
+                                  (hipStream_t)stream);
+}
+
 int mv_ln_linear_supported(int64_t M, int N, int K, int x_dtype, int out_dtype) {
     return !get_flag("force_generic") && !get_flag("no_stream") && stream1x1_ln_supported(M, K, N, x_dtype, out_dtype);
 }

@@ -81,6 +81,34 @@ def prep_conv(conv, bn, layout: str, dtype: str):
     return out
 
 
+def prep_conv_grouped64(conv, bn):
+    """Grouped filters (O, I/g, kh, kw) expanded to 64-channel super-groups: [O][kh][kw][64], block-diagonal (the layout
+    mv_conv2d_nhwc_grouped64_fwd documents), bf16; BN folded to fp32 scale / shift as in prep_conv."""
+    key = ("conv_g64", id(bn))
+    cache = conv._cache()
+    hit = cache.get(key)
+    if hit is not None:
+        return hit
+    w = np.asarray(conv.weight, np.float32)                      # (O, Cg, kh, kw)
+    O_, cg, kh, kw = w.shape
+    w64 = np.zeros((O_, kh, kw, 64), np.float32)
+    for k in range(O_):
+        g0 = (k // cg) * cg % 64                                  # first input channel of k's group inside its super-group
+        w64[k, :, :, g0:g0 + cg] = w[k].transpose(1, 2, 0)
+    bias = None if conv.bias is None else np.asarray(conv.bias, np.float32).reshape(-1)
+    scale = shift = None
+    if bn is not None:
+        scale, shift = bn_fold(bn)
+        if bias is not None:
+            shift = shift + bias * scale
+    elif bias is not None:
+        shift = bias
+    hit = (_dev(w64, torch.bfloat16), None if scale is None else _dev(scale, torch.float32),
+           None if shift is None else _dev(shift, torch.float32))
+    cache[key] = hit
+    return hit
+
+
 def prep_linear(lin, dtype: str):
     key = ("lin", dtype)
     cache = lin._cache()
@@ -225,6 +253,18 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
     w, scale, shift = prep_conv(conv, bn, "krsc", dt)
     Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
     Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    if conv.groups > 1 and dt == "bf16" and _lib.load().mv_conv2d_grouped64_supported(C, K, kh, kw, conv.groups, _lib.BF16, _lib.BF16):
+        w64, scale, shift = prep_conv_grouped64(conv, bn)
+        y = empty((B, Ho, Wo, K), torch.bfloat16)
+        res = None
+        if residual is not None:
+            residual = as_map(residual)
+            if tuple(residual.t.shape) != (B, Ho, Wo, K):
+                raise ValueError(f"residual shape {tuple(residual.t.shape)} != conv output {(B, Ho, Wo, K)}")
+            res = residual.t
+        _lib.call("mv_conv2d_nhwc_grouped64_fwd", _ptr(x.t), _ptr(w64), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y),
+                  B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, conv.groups, ACT[act], _lib.BF16, _lib.BF16, stream_ptr())
+        return Act(y, "map", x.batched)
     if K % 8 and dt == "bf16" and conv.groups == 1 and residual is None and C % 64 == 0:
         # an output width the MFMA kernels cannot store in 16-byte pieces (21-class segmentation heads, fcn.py:33): run the
         # convolution on zero-padded filters and compact the rows afterwards instead of dropping to the VALU kernel

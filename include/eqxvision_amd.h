@@ -38,7 +38,7 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  * "igemm8" (2 / 3 / 4 = force the ping-pong GEMM with 256x256 / 128x256 / 256x128 tiles), "no_igemm8",
  * "igemm2_tile" (1 / 2 / 3 = force igemm2 with 256x64 / 256x128 / 256x256 tiles), "no_igemm2", "igemm2_dense_m",
  * "igemm_tile" (1 / 2 = force the 128x128 / 128x64 kernel), "res_early", "no_stream" (no streaming 1x1 / 3x3c64 kernels),
- * "stream_npass1", "stem_v0", "no_stem_pool", "no_dual", "no_chain", "no_dual_chain", "no_ln_mlp", "no_ln_stream", "ln_stream_192", "no_skinny", "no_tuned", and the
+ * "stream_npass1", "stem_v0", "no_stem_pool", "no_dual", "no_chain", "no_dual_chain", "no_grouped64", "no_ln_mlp", "ln_mlp_waves" (8 / 12 / 16), "no_ln_stream", "ln_stream_192", "no_skinny", "no_tuned", and the
  * per-shape kernel choice "ov:<M>:<C>:<K>:<R>:<S>:<stride>" / "ovh:<M>:<N>:<K>:1:1:1" / "ovd:<M>:<C1>:<C2>:<K>:<stride>:1"
  * (tools/tune_tiles.py; codes in csrc/igemm.hip). */
 
@@ -142,6 +142,16 @@ int mv_linear_split_fwd(const void* x, const void* w_hi_lo, const float* scale, 
 int mv_conv2d_nchw_split_fwd(const void* x, const void* w_hi, const void* w_lo, const float* scale, const float* shift,
                              void* y, int N, int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw,
                              int act, int x_dtype, int out_dtype, mv_stream_t stream);
+
+/* Grouped Conv2d on the matrix cores (ResNeXt conv2: resnet.py:17-27 `groups`, :440-471 `groups=32, width_per_group=4 | 8`), for
+ * C == K, (C / groups) | 64: groups are processed in 64-channel super-groups whose filter tile is block-diagonal.  The CALLER
+ * expands the [K][R][S][C/groups] filters to w64 [K][R][S][64]: output channel k = 64*q + j reads input channels 64*q .. 64*q+63,
+ * w64[k][r][s][i] = w[k][r][s][i - g0] for the C/groups inputs of k's own group (g0 = its first channel inside the super-group), 0
+ * elsewhere.  Everything else as mv_conv2d_nhwc_fwd. */
+int mv_conv2d_grouped64_supported(int C, int K, int R, int S, int groups, int in_dtype, int out_dtype);
+int mv_conv2d_nhwc_grouped64_fwd(const void* x, const void* w64, const float* scale, const float* shift, const void* residual,
+                                 void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh,
+                                 int dw, int groups, int act, int in_dtype, int out_dtype, mv_stream_t stream);
 
 /* LayerNorm folded into the Linear that consumes it (swin.py:572-578 `attn(norm1(x))` / `mlp(norm2(x))` feeding qkv / fc1;
  * extensions_2d.py:9-50), for short rows (K = 96: Swin stage 0, where the LayerNorm launch is a 115 MB round trip; K = 192 only

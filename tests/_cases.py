@@ -383,6 +383,46 @@ def linear_split_case(M, K, N, out="fp32", seed=0):
     return run
 
 
+def conv_grouped64_case(N, H, W, C, groups, R=3, stride=1, pad=1, dil=1, act=1, res=False, seed=0):
+    """mv_conv2d_nhwc_grouped64_fwd (grouped conv as block-diagonal 64-channel super-groups on the MFMA) vs the oracle's grouped
+    conv2d (resnet.py:17-27 with groups > 1)."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        cg = C // groups
+        x = bf(rng.standard_normal((N, C, H, W)))
+        w = bf(rng.standard_normal((C, cg, R, R)) / np.sqrt(cg * R * R))
+        sc = rng.uniform(0.5, 1.5, C).astype(np.float32)
+        sf = (0.1 * rng.standard_normal(C)).astype(np.float32)
+        if not L.load().mv_conv2d_grouped64_supported(C, C, R, R, groups, 1, 1):
+            return {"ok": False, "err": "mv_conv2d_grouped64_supported says no"}
+        Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+        r = bf(rng.standard_normal((N, C, Ho, Ho))) if res else None
+        ref = np.stack([O.conv2d(x[i], w, None, stride, pad, dil, groups) for i in range(N)]).astype(np.float64)
+        ref = ref * sc[None, :, None, None] + sf[None, :, None, None]
+        if res:
+            ref = ref + r
+        if act == 1:
+            ref = np.maximum(ref, 0)
+        w64 = np.zeros((C, R, R, 64), np.float32)
+        for k in range(C):
+            g0 = (k // cg) * cg % 64
+            w64[k, :, :, g0:g0 + cg] = w[k].transpose(1, 2, 0)
+        xd = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)), "bf16")
+        wd, scd, sfd = dev(w64, "bf16"), dev(sc, "fp32"), dev(sf, "fp32")
+        rd = dev(np.ascontiguousarray(r.transpose(0, 2, 3, 1)), "bf16") if res else None
+        y = torch.empty((N, Ho, Ho, C), dtype=torch.bfloat16, device="cuda")
+        L.call("mv_conv2d_nhwc_grouped64_fwd", xd.data_ptr(), wd.data_ptr(), scd.data_ptr(), sfd.data_ptr(),
+               rd.data_ptr() if res else None, y.data_ptr(), N, H, W, C, C, R, R, stride, stride, pad, pad, dil, dil, groups, act, 1, 1,
+               _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(y).transpose(0, 3, 1, 2), ref, TOL_BF16)
+        info["kernel"] = kern
+        return info
+    return run
+
+
 def resize_case(N, h, w, C, H, W, dtype="bf16", nchw=True, seed=0):
     """mv_resize_bilinear_nhwc_fwd vs the restatement of jax.image.resize (oracle.np_ops.resize_bilinear)."""
     def run():
@@ -1067,6 +1107,12 @@ def all_cases():
           ("split/linear_swin_merge_384_192", linear_split_case(128 * 28 * 28 // 4, 384, 192, seed=511)),
           ("split/linear_swin_merge_1536_768", linear_split_case(64 * 49, 1536, 768, seed=512)),
           ("split/linear_bf16out_ragged", linear_split_case(9000 + 37, 256, 200, out="bf16", seed=513)),
+          ("grouped64/resnext_layer1_128_g32", conv_grouped64_case(3, 28, 28, 128, 32, seed=540)),
+          ("grouped64/resnext_layer2_256_g32_s2", conv_grouped64_case(2, 28, 28, 256, 32, stride=2, seed=541)),
+          ("grouped64/resnext101_256_g32_w8", conv_grouped64_case(2, 14, 14, 256, 32, seed=542)),
+          ("grouped64/cg32_1024_res_noact", conv_grouped64_case(1, 7, 7, 1024, 32, act=0, res=True, seed=543)),
+          ("grouped64/cg64_is_plain_grouping_dil2", conv_grouped64_case(2, 15, 15, 128, 2, pad=2, dil=2, seed=544)),
+          ("grouped64/k1_cg16", conv_grouped64_case(2, 9, 9, 64, 4, R=1, pad=0, seed=545)),
           ("resize/logits_28_to_224_nchw", resize_case(2, 28, 28, 21, 224, 224)),
           ("resize/pooled_1_to_28_nhwc", resize_case(3, 1, 1, 256, 28, 28, nchw=False)),
           ("resize/odd_7x5_to_20x33_f32", resize_case(2, 7, 5, 3, 20, 33, dtype="fp32")),

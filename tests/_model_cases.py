@@ -58,13 +58,19 @@ def _run(net, x, dtype, jit=False):
     return out
 
 
-def resnet_case(block, layers, size, B, classes=10, dtype="bf16", full_ref="numpy"):
+def resnet_case(block, layers, size, B, classes=10, dtype="bf16", full_ref="numpy", groups=1, width_per_group=64):
     def run():
         import eqxvision_amd as eqv
-        sd = S.resnet_state(1, block, layers, classes)
+        sd = S.resnet_state(1, block, layers, classes, width_per_group=width_per_group, groups=groups)
         x = S.synthetic_images(B, size, seed=0)
         fac = {("bottleneck", (3, 4, 6, 3)): eqv.models.resnet50, ("basic", (2, 2, 2, 2)): eqv.models.resnet18}.get(
-            (block, tuple(layers)))
+            (block, tuple(layers))) if groups == 1 else None
+        if groups > 1 and tuple(layers) == (3, 4, 6, 3) and width_per_group == 4:
+            fac = eqv.models.resnext50_32x4d
+        if fac is None and groups > 1:
+            blk = eqv.models.classification.resnet._ResNetBottleneck
+            fac = lambda torch_weights=None, **kw: eqv.models.classification.resnet._resnet(
+                blk, list(layers), torch_weights, groups=groups, width_per_group=width_per_group, **kw)
         if fac is None:
             blk = eqv.models.classification.resnet._ResNetBottleneck if block == "bottleneck" else \
                 eqv.models.classification.resnet._ResNetBasicBlock
@@ -72,11 +78,11 @@ def resnet_case(block, layers, size, B, classes=10, dtype="bf16", full_ref="nump
         net = _load(fac, sd, num_classes=classes)
         got = _run(net, x, dtype).cpu().numpy()
         if full_ref == "torch":
-            ref = TR.resnet_forward(sd, x, block, layers).numpy()
+            ref = TR.resnet_forward(sd, x, block, layers, groups).numpy()
             emu = None
         else:
-            ref = O.vmap(lambda im: OM.resnet_forward(sd, im, block, layers))(x)
-            emu = O.vmap(lambda im: OM.resnet_forward(sd, im, block, layers, bf16=True))(x) if dtype == "bf16" else None
+            ref = O.vmap(lambda im: OM.resnet_forward(sd, im, block, layers, groups=groups))(x)
+            emu = O.vmap(lambda im: OM.resnet_forward(sd, im, block, layers, bf16=True, groups=groups))(x) if dtype == "bf16" else None
         extra = {}
         if emu is not None:
             extra["err_vs_bf16_emulation"] = float(np.abs(got - emu).max())
@@ -486,6 +492,7 @@ def pth_reader_case():
 def all_cases(full=True):
     c = [("model/resnet_tiny_bottleneck", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2)),
          ("model/resnet18_64px", resnet_case("basic", (2, 2, 2, 2), 64, 2)),
+         ("model/resnext_tiny_32x4d", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2, groups=32, width_per_group=4)),
          ("model/resnet_tiny_fp32", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2, dtype="fp32")),
          ("model/vit_tiny", vit_case(32, 8, 64, 2, 2, 3)),
          ("model/vit_tiny_fp32", vit_case(32, 8, 64, 2, 2, 2, dtype="fp32")),
@@ -519,6 +526,8 @@ def all_cases(full=True):
               ("model/resnet50_B5_odd_200px", resnet_case("bottleneck", (3, 4, 6, 3), 200, 5, classes=1000, full_ref="torch")),
               ("model/resnet_2111_160px_B7_mixed_paths", resnet_case("bottleneck", (2, 1, 1, 1), 160, 7, classes=10, full_ref="torch")),
               ("model/resnet_1211_128px_B16_mixed_paths", resnet_case("bottleneck", (1, 2, 1, 1), 128, 16, classes=10, full_ref="torch")),
+              ("model/resnext50_32x4d_B2", resnet_case("bottleneck", (3, 4, 6, 3), 224, 2, classes=1000, full_ref="torch",
+                                                       groups=32, width_per_group=4)),
               ("model/vit_base_B2", vit_case(224, 16, 768, 12, 12, 2, classes=1000, full_ref="torch")),
               ("model/vgg11_B2", vgg_case("A", False, 224, 2, classes=1000, full_ref="torch")),
               ("model/vgg16_bn_B1", vgg_case("D", True, 224, 1, classes=1000, full_ref="torch")),
