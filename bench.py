@@ -36,7 +36,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 GFLOP_PER_IMG = {"resnet50": 8.178, "vit_base": 35.13, "swin_t": 8.98, "alexnet": 1.428,
-                 "vgg16": 30.94, "vgg16_bn": 30.94, "vgg11": 15.22, "resnext50_32x4d": 8.46}   # section 8 f1 (2 x MACs of the conv / Linear layers)
+                 "vgg16": 30.94, "vgg16_bn": 30.94, "vgg11": 15.22, "resnext50_32x4d": 8.46, "mobilenet_v2": 0.601}   # section 8 f1 (2 x MACs of the conv / Linear layers)
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -56,6 +56,8 @@ def build_model(name: str, seed: int = 1):
             net = eqv.models.swin_t(key=key)
         elif name == "alexnet":
             net = eqv.models.alexnet(key=key)
+        elif name == "mobilenet_v2":
+            net = eqv.utils.randomize_batchnorm(eqv.models.mobilenet_v2(key=key), seed)
         elif name == "resnext50_32x4d":
             net = eqv.utils.randomize_batchnorm(eqv.models.resnext50_32x4d(key=key), seed)
         elif name in ("vgg16", "vgg16_bn", "vgg11"):
@@ -104,6 +106,13 @@ def layer_table(compiled, path, steps=5):
             flops = 2.0 * N * Ho * Wo * K * R * S * C / g
             byts = ob(idt) * (N * H * W * C + K * R * S * C / g) + ob(odt) * N * Ho * Wo * K * (2 if args[4] else 1)
             shape = f"N{N} {H}x{W}x{C}->{Ho}x{Wo}x{K} k{R}s{sh}"
+        elif name == "mv_dwconv2d_nhwc_fwd":
+            N, H, W, C, R, S, sh, sw, ph, pw, dh, dw = args[5:17]
+            Ho = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1
+            Wo = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
+            flops = 2.0 * N * Ho * Wo * C * R * S
+            byts = 2.0 * N * C * (H * W + Ho * Wo)
+            shape = f"N{N} {H}x{W}x{C} dw k{R}s{sh}"
         elif name == "mv_conv2d_nhwc_grouped64_fwd":
             N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, g = args[6:20]
             Ho = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1

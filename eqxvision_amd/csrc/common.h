@@ -117,6 +117,13 @@ int igemm_grouped64_supported(int C, int K, int R, int S, int groups, int in_dty
 int igemm_grouped64_launch(const void* x, const void* w64, const float* scale, const float* shift, const void* residual, void* y,
                            int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int act,
                            int out_dtype, hipStream_t stream);
+int igemm_oddc_supported(int C, int K, int groups, int in_dtype, int out_dtype);
+int igemm_oddc_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y, int N,
+                      int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int act,
+                      int out_dtype, hipStream_t stream);
+int dwconv_supported(int C, int K, int groups, int R, int S, int in_dtype, int out_dtype);
+int dwconv_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H, int W, int C, int R,
+                  int S, int sh, int sw, int ph, int pw, int dh, int dw, int act, hipStream_t stream);
 int stream1x1_supported(int C, int K, int in_dtype, int out_dtype, long long M);
 int stream1x1_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                      void* y, long long M, int C, int K, int act, int out_dtype, hipStream_t stream);

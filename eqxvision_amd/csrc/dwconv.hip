@@ -1,0 +1,162 @@
+// Depthwise convolution (groups == channels: `ConvNormActivation(hidden, hidden, groups=hidden)` of the inverted-residual
+// blocks, reference mobilenetv2.py:58-68) with the folded BatchNorm and the activation in the same pass, NHWC bf16, gfx950.
+//
+// There is no reduction over channels, so there is nothing for the matrix cores: 9 multiply-adds per output value against
+// 2 + 2 bytes moved -- HBM-bound by an order of magnitude.  One thread owns 8 consecutive channels (16 bytes) of one output
+// pixel: per tap one 16-byte load of the input pixel (neighbouring threads = neighbouring channel chunks of the same pixel ->
+// whole 128-byte lines; the 3x3 neighbourhood is shared by adjacent output pixels through L1 / L2) and one 16-byte load of the
+// tap's weights ([R][S][C] layout: channel-contiguous, a few KB, cache-resident), fp32 accumulation, one 16-byte store.
+#include "mfma_common.h"
+
+namespace mv {
+
+struct DwP {
+    const bf16_t* x;
+    const bf16_t* w;      // [R][S][C]
+    const float* scale;   // [C] or null
+    const float* shift;   // [C] or null
+    bf16_t* y;
+    int N, H, W, C, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw, act;
+};
+
+__device__ __forceinline__ void unpack8(const uint4 u, float* v) {
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+__global__ __launch_bounds__(256) void dwconv_kernel(const DwP p) {
+    const int C8 = p.C >> 3;
+    const long long total = (long long)p.N * p.Ho * p.Wo * C8;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        long long r = idx;
+        const int c8 = (int)(r % C8); r /= C8;
+        const int wo = (int)(r % p.Wo); r /= p.Wo;
+        const int ho = (int)(r % p.Ho);
+        const int b = (int)(r / p.Ho);
+        const int c = c8 * 8;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int h0 = ho * p.sh - p.ph, w0 = wo * p.sw - p.pw;
+        for (int rr = 0; rr < p.R; ++rr) {
+            const int hi = h0 + rr * p.dh;
+            if ((unsigned)hi >= (unsigned)p.H) continue;
+            for (int ss = 0; ss < p.S; ++ss) {
+                const int wi = w0 + ss * p.dw;
+                if ((unsigned)wi >= (unsigned)p.W) continue;
+                float xv[8], wv[8];
+                unpack8(*(const uint4*)(p.x + (((long long)b * p.H + hi) * p.W + wi) * p.C + c), xv);
+                unpack8(*(const uint4*)(p.w + ((long long)rr * p.S + ss) * p.C + c), wv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(xv[e], wv[e], acc[e]);
+            }
+        }
+        if (p.scale) {
+            const float4 a = *(const float4*)(p.scale + c), b2 = *(const float4*)(p.scale + c + 4);
+            acc[0] *= a.x; acc[1] *= a.y; acc[2] *= a.z; acc[3] *= a.w; acc[4] *= b2.x; acc[5] *= b2.y; acc[6] *= b2.z; acc[7] *= b2.w;
+        }
+        if (p.shift) {
+            const float4 a = *(const float4*)(p.shift + c), b2 = *(const float4*)(p.shift + c + 4);
+            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b2.x; acc[5] += b2.y; acc[6] += b2.z; acc[7] += b2.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = apply_act_rt(acc[e], p.act);
+        Out8<bf16_t>::st(p.y + idx * 8, acc);
+    }
+}
+
+// 3x3, pad 1, no dilation (every depthwise layer of MobileNetV2): one thread = 4 consecutive output columns x 8 channels.  The
+// 3 x (4*STRIDE + 2) input window is loaded once and every loaded pixel feeds up to 3 outputs (18 loads for 4 outputs at
+// stride 1 instead of 36), the 9 weight vectors are loaded once per thread.
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwP p) {
+    constexpr int TW = 4, IW = (TW - 1) * STRIDE + 3;
+    const int C8 = p.C >> 3, WT = (p.Wo + TW - 1) / TW;
+    const long long total = (long long)p.N * p.Ho * WT * C8;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        long long r = idx;
+        const int c8 = (int)(r % C8); r /= C8;
+        const int wt = (int)(r % WT); r /= WT;
+        const int ho = (int)(r % p.Ho);
+        const int b = (int)(r / p.Ho);
+        const int c = c8 * 8, wo0 = wt * TW;
+        float wv[9][8];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) unpack8(*(const uint4*)(p.w + (long long)t * p.C + c), wv[t]);
+        float acc[TW][8];
+#pragma unroll
+        for (int o = 0; o < TW; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][e] = 0.f;
+        const int h0 = ho * STRIDE - 1, w0 = wo0 * STRIDE - 1;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const int hi = h0 + rr;
+            if ((unsigned)hi >= (unsigned)p.H) continue;
+            const bf16_t* row = p.x + ((long long)b * p.H + hi) * p.W * p.C + c;
+#pragma unroll
+            for (int j = 0; j < IW; ++j) {
+                const int wi = w0 + j;
+                if ((unsigned)wi >= (unsigned)p.W) continue;
+                float xv[8];
+                unpack8(*(const uint4*)(row + (long long)wi * p.C), xv);
+#pragma unroll
+                for (int o = 0; o < TW; ++o) {
+                    const int ss = j - o * STRIDE;                   // tap column of output o that this input column feeds
+                    if (ss >= 0 && ss < 3) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(xv[e], wv[rr * 3 + ss][e], acc[o][e]);
+                    }
+                }
+            }
+        }
+        float sc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, sf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.scale) {
+            const float4 a = *(const float4*)(p.scale + c), b2 = *(const float4*)(p.scale + c + 4);
+            sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b2.x; sc[5] = b2.y; sc[6] = b2.z; sc[7] = b2.w;
+        }
+        if (p.shift) {
+            const float4 a = *(const float4*)(p.shift + c), b2 = *(const float4*)(p.shift + c + 4);
+            sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b2.x; sf[5] = b2.y; sf[6] = b2.z; sf[7] = b2.w;
+        }
+#pragma unroll
+        for (int o = 0; o < TW; ++o) {
+            if (wo0 + o >= p.Wo) break;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][e] = apply_act_rt(fmaf(acc[o][e], sc[e], sf[e]), p.act);
+            Out8<bf16_t>::st(p.y + (((long long)b * p.Ho + ho) * p.Wo + wo0 + o) * p.C + c, acc[o]);
+        }
+    }
+}
+
+int dwconv_supported(int C, int K, int groups, int R, int S, int in_dtype, int out_dtype) {
+    return groups == C && K == C && C % 8 == 0 && R * S <= 49 && in_dtype == MV_BF16 && out_dtype == MV_BF16;
+}
+
+int dwconv_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H, int W, int C, int R,
+                  int S, int sh, int sw, int ph, int pw, int dh, int dw, int act, hipStream_t st) {
+    DwP p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.y = (bf16_t*)y;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.R = R; p.S = S;
+    p.Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1;
+    p.Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
+    p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw; p.act = act;
+    const bool fast = R == 3 && S == 3 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && sh == sw && (sh == 1 || sh == 2) &&
+                      !get_flag("dwconv_generic");
+    const long long total = (long long)N * p.Ho * (fast ? (p.Wo + 3) / 4 : p.Wo) * (C / 8);
+    long long g = (total + 255) / 256;
+    if (g > 256 * 32) g = 256 * 32;
+    if (fast) {
+        set_kernel_name(sh == 1 ? "dwconv3x3_s1_bf16x8x4" : "dwconv3x3_s2_bf16x8x4");
+        if (sh == 1) hipLaunchKernelGGL(dwconv3x3_kernel<1>, dim3((unsigned)g), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(dwconv3x3_kernel<2>, dim3((unsigned)g), dim3(256), 0, st, p);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
+    set_kernel_name("dwconv_nhwc_bf16x8");
+    hipLaunchKernelGGL(dwconv_kernel, dim3((unsigned)g), dim3(256), 0, st, p);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+}  // namespace mv

@@ -683,6 +683,9 @@ int mv_conv2d_nhwc_fwd(const void* x, const void* w, const float* scale, const f
     if (!get_flag("force_generic") && igemm_supported(C, K, R, S, groups, in_dtype, out_dtype))
         return igemm_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, in_dtype,
                             out_dtype, st);
+    if (!get_flag("force_generic") && !get_flag("no_oddc") && igemm_oddc_supported(C, K, groups, in_dtype, out_dtype) &&
+        (long long)N * Ho * Wo < (1LL << 31) - 256)                // widths like 24 / 96 / 144 / 160: zero-filled last k-tile
+        return igemm_oddc_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, st);
     ConvP p;
     p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S; p.Ho = Ho; p.Wo = Wo;
     p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw; p.groups = groups;
@@ -826,6 +829,25 @@ int mv_linear_split_fwd(const void* x, const void* w_hi_lo, const float* scale, 
     // the second reduction source IS x: [x | x] . [w_hi | w_lo]^T = x . (w_hi + w_lo)^T, accumulated in fp32
     return igemm8_dual_launch(x, x, w_hi_lo, scale, shift, residual, y, 1, (int)M, 1, K, (int)M, 1, K, 1, N, act, out_dtype, tile,
                               (hipStream_t)stream);
+}
+
+int mv_dwconv2d_supported(int C, int K, int groups, int R, int S, int in_dtype, int out_dtype) {
+    return !get_flag("force_generic") && !get_flag("no_dwconv") && dwconv_supported(C, K, groups, R, S, in_dtype, out_dtype);
+}
+
+int mv_dwconv2d_nhwc_fwd(const void* x, const void* w_rsc, const float* scale, const float* shift, void* y, int N, int H, int W,
+                         int C, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int act, int in_dtype, int out_dtype,
+                         mv_stream_t stream) {
+    MV_CHECK_ARG(x && w_rsc && y, "dwconv2d: NULL pointer");
+    MV_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && dh > 0 && dw > 0,
+                 "dwconv2d: bad dims");
+    const long long Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
+    MV_CHECK_ARG(Ho > 0 && Wo > 0, "dwconv2d: empty output");
+    if (!mv_dwconv2d_supported(C, C, C, R, S, in_dtype, out_dtype)) {
+        set_error("dwconv2d: unsupported configuration C=%d %dx%d (ask mv_dwconv2d_supported first)", C, R, S);
+        return MV_E_UNSUPPORTED;
+    }
+    return dwconv_launch(x, w_rsc, scale, shift, y, N, H, W, C, R, S, sh, sw, ph, pw, dh, dw, act, (hipStream_t)stream);
 }
 
 int mv_conv2d_grouped64_supported(int C, int K, int R, int S, int groups, int in_dtype, int out_dtype) {

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
     // ---------------- staging constants -------------------------------------------------------
     const int srow = lane >> 3;                                    // row inside the 8-row DMA group
     const int chunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);  // which 16-B chunk of the row I fetch
-    const int cpt = p.C >> 6;                                      // k-tiles per filter tap
+    const int cpt = (p.C + 63) >> 6;                               // k-tiles per filter tap
     const int nk = p.R * p.S * cpt;
     const long long wrow_stride = (long long)p.R * p.S * p.C;
 
@@ -119,21 +119,22 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
         char* xs = smem + buf * STAGE;
         char* ws = xs + BM * ROWB;
         const int tapoff = (r * p.S + s) * p.C + c0;
+        const bool kin = c0 + chunk * 8 < p.C;                     // C % 64 != 0: the last k-tile of a tap is zero-filled past C
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
             const bf16_t* src = p.zero;
             if (DENSE) {
-                if (xoff[j] >= 0) src = p.x + xoff[j] + c0;
+                if (xoff[j] >= 0 && kin) src = p.x + xoff[j] + c0;
             } else {
                 const int hi = xh[j] + r * p.dh, wi = xw[j] + s * p.dw;
-                if (xb[j] >= 0 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                if (kin && xb[j] >= 0 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
                     src = p.x + (((long long)xb[j] * p.H + hi) * p.W + wi) * p.xpitch + (p.grouped ? n0 : 0) + c0 + chunk * 8;
             }
             glds16(src, xs + 8 * (wave + 4 * j) * ROWB);
         }
 #pragma unroll
         for (int j = 0; j < WI; ++j) {
-            const bf16_t* src = woff[j] >= 0 ? p.w + woff[j] + tapoff : p.zero;
+            const bf16_t* src = (woff[j] >= 0 && kin) ? p.w + woff[j] + tapoff : p.zero;
             glds16(src, ws + 8 * (wave + 4 * j) * ROWB);
         }
     };
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
         // 2) prefetch tile it+1 into the other buffer (asynchronous LDS-DMA)
         if (it + 1 < nk) {
             c0 += 64;
-            if (c0 == p.C) {
+            if (c0 >= p.C) {
                 c0 = 0;
                 if (++s == p.S) {
                     s = 0;
@@ -434,6 +435,39 @@ int igemm_grouped64_launch(const void* x, const void* w64, const float* scale, c
     p.act = act; p.m_off = 0;
     set_kernel_name("igemm_grouped64_bf16_128x64");
     return launch_tile<128, 64, 4, 1>(p, false, out_dtype == MV_F32, st);
+}
+
+// Channel counts that are multiples of 8 but not of 64 (MobileNet-style widths: 16, 24, 32, 96, 144, 160 ...): the 128 x 128 /
+// 128 x 64 kernel of this file with the last k-tile of every tap zero-filled past C.
+int igemm_oddc_supported(int C, int K, int groups, int in_dtype, int out_dtype) {
+    return in_dtype == MV_BF16 && (out_dtype == MV_BF16 || out_dtype == MV_F32) && groups == 1 && C % 8 == 0 && C % 64 != 0 &&
+           K % 8 == 0;
+}
+
+int igemm_oddc_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y, int N,
+                      int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int act,
+                      int out_dtype, hipStream_t st) {
+    IgemmP p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.zero = (const bf16_t*)zero_page(st);
+    if (!p.zero) {
+        set_error("igemm_oddc: zero page allocation failed");
+        return MV_E_OOM;
+    }
+    p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S;
+    p.xpitch = C; p.grouped = 0;
+    p.Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1;
+    p.Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
+    p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw;
+    p.M = N * p.Ho * p.Wo;
+    p.act = act; p.m_off = 0;
+    const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
+    if (K <= 64) {
+        set_kernel_name(dense ? "igemm_bf16_128x64_dense_oddc" : "igemm_bf16_128x64_conv_oddc");
+        return launch_tile<128, 64, 4, 1>(p, dense, out_dtype == MV_F32, st);
+    }
+    set_kernel_name(dense ? "igemm_bf16_128x128_dense_oddc" : "igemm_bf16_128x128_conv_oddc");
+    return launch_tile<128, 128, 4, 1>(p, dense, out_dtype == MV_F32, st);
 }
 
 }  // namespace mv

@@ -1,5 +1,6 @@
 """Flat model namespace (reference eqxvision/models/__init__.py:1-105) for the hot-path families."""
 from .classification.alexnet import AlexNet, alexnet
+from .classification.mobilenetv2 import MobileNetV2, mobilenet_v2
 from .classification.resnet import (
     ResNet,
     resnet18,

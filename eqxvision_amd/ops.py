@@ -253,6 +253,19 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
     w, scale, shift = prep_conv(conv, bn, "krsc", dt)
     Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
     Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    if conv.groups > 1 and dt == "bf16" and residual is None and \
+            _lib.load().mv_dwconv2d_supported(C, K, conv.groups, kh, kw, _lib.BF16, _lib.BF16):
+        cache = conv._cache()
+        hit = cache.get(("dw", id(bn)))
+        if hit is None:
+            _, scale, shift = prep_conv(conv, bn, "oihw", dt)
+            wr = np.ascontiguousarray(np.asarray(conv.weight, np.float32)[:, 0].transpose(1, 2, 0))     # (C,1,R,S) -> [R][S][C]
+            hit = (_dev(wr, torch.bfloat16), scale, shift)
+            cache[("dw", id(bn))] = hit
+        y = empty((B, Ho, Wo, K), torch.bfloat16)
+        _lib.call("mv_dwconv2d_nhwc_fwd", _ptr(x.t), _ptr(hit[0]), _ptr(hit[1]), _ptr(hit[2]), _ptr(y), B, H, W, C, kh, kw, sh, sw,
+                  ph, pw, dh, dw, ACT[act], _lib.BF16, _lib.BF16, stream_ptr())
+        return Act(y, "map", x.batched)
     if conv.groups > 1 and dt == "bf16" and _lib.load().mv_conv2d_grouped64_supported(C, K, kh, kw, conv.groups, _lib.BF16, _lib.BF16):
         w64, scale, shift = prep_conv_grouped64(conv, bn)
         y = empty((B, Ho, Wo, K), torch.bfloat16)

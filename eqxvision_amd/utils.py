@@ -30,6 +30,7 @@ _STEMS = {
     "vgg11": "vgg11-8a719046", "vgg13": "vgg13-19584684", "vgg16": "vgg16-397923af", "vgg19": "vgg19-dcbb9e9d",
     "vgg11_bn": "vgg11_bn-6002323d", "vgg13_bn": "vgg13_bn-abd245e5", "vgg16_bn": "vgg16_bn-6c64b313",
     "vgg19_bn": "vgg19_bn-c79401a0",
+    "mobilenet_v2": "mobilenet_v2-b0353104",
     "swin_t": "swin_t-704ceda3", "swin_s": "swin_s-5e29d889", "sim_b": "swin_b-68c6b09e",
 }
 SEGMENTATION_URLS = {      # reference utils.py:20-24
@@ -42,6 +43,14 @@ for _arch, _dir in (("small", "deitsmall"), ("base", "vitbase")):
     for _p in (16, 8):
         CLASSIFICATION_URLS[f"vit_{_arch}_patch{_p}_224_dino"] = (
             f"{_DINO}dino_{_dir}{_p}_pretrain/dino_{_dir}{_p}_pretrain.pth")
+
+
+def _make_divisible(v: float, divisor: int, min_value: Optional[int] = None) -> int:
+    """Channel rounding of the MobileNet family (reference utils.py:104-117): nearest multiple of `divisor`, never more than
+    10% below `v`."""
+    floor = divisor if min_value is None else min_value
+    rounded = max(floor, int(v + divisor / 2) // divisor * divisor)
+    return rounded + divisor if rounded < 0.9 * v else rounded
 
 
 def _resolve(torch_weights: str) -> str:

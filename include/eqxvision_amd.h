@@ -38,7 +38,7 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  * "igemm8" (2 / 3 / 4 = force the ping-pong GEMM with 256x256 / 128x256 / 256x128 tiles), "no_igemm8",
  * "igemm2_tile" (1 / 2 / 3 = force igemm2 with 256x64 / 256x128 / 256x256 tiles), "no_igemm2", "igemm2_dense_m",
  * "igemm_tile" (1 / 2 = force the 128x128 / 128x64 kernel), "res_early", "no_stream" (no streaming 1x1 / 3x3c64 kernels),
- * "stream_npass1", "stem_v0", "no_stem_pool", "no_dual", "no_chain", "no_dual_chain", "no_grouped64", "no_ln_mlp", "ln_mlp_waves" (8 / 12 / 16), "no_ln_stream", "ln_stream_192", "no_skinny", "no_tuned", and the
+ * "stream_npass1", "stem_v0", "no_stem_pool", "no_dual", "no_chain", "no_dual_chain", "no_grouped64", "no_dwconv", "no_oddc" (channel counts that are not multiples of 64 back on the scalar kernel), "no_ln_mlp", "ln_mlp_waves" (8 / 12 / 16), "no_ln_stream", "ln_stream_192", "no_skinny", "no_tuned", and the
  * per-shape kernel choice "ov:<M>:<C>:<K>:<R>:<S>:<stride>" / "ovh:<M>:<N>:<K>:1:1:1" / "ovd:<M>:<C1>:<C2>:<K>:<stride>:1"
  * (tools/tune_tiles.py; codes in csrc/igemm.hip). */
 
@@ -142,6 +142,14 @@ int mv_linear_split_fwd(const void* x, const void* w_hi_lo, const float* scale, 
 int mv_conv2d_nchw_split_fwd(const void* x, const void* w_hi, const void* w_lo, const float* scale, const float* shift,
                              void* y, int N, int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw,
                              int act, int x_dtype, int out_dtype, mv_stream_t stream);
+
+/* Depthwise Conv2d (groups == in_channels == out_channels: mobilenetv2.py:58-68 `ConvNormActivation(hidden, hidden,
+ * groups=hidden)`) with the folded BatchNorm and the activation in the same pass.  w_rsc: the (C, 1, R, S) filters re-laid
+ * by the caller to [R][S][C] (channel-contiguous taps); x, y NHWC bf16; scale / shift fp32 [C] or NULL. */
+int mv_dwconv2d_supported(int C, int K, int groups, int R, int S, int in_dtype, int out_dtype);
+int mv_dwconv2d_nhwc_fwd(const void* x, const void* w_rsc, const float* scale, const float* shift, void* y, int N, int H, int W,
+                         int C, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int act, int in_dtype, int out_dtype,
+                         mv_stream_t stream);
 
 /* Grouped Conv2d on the matrix cores (ResNeXt conv2: resnet.py:17-27 `groups`, :440-471 `groups=32, width_per_group=4 | 8`), for
  * C == K, (C / groups) | 64: groups are processed in 64-channel super-groups whose filter tile is block-diagonal.  The CALLER

@@ -153,6 +153,32 @@ def resnet_forward(sd, x, block="bottleneck", layers=(3, 4, 6, 3), bf16=False, g
     return O.linear(x, q(sd["fc.weight"]), sd["fc.bias"])                            # resnet.py:356
 
 
+# ---------------------------------------------------------------- mobilenetv2.py:16-229
+def mobilenet_v2_forward(sd, x, setting, bf16=False):
+    """stem conv3x3/2 + BN + relu; inverted residuals ([1x1 expand + BN + relu,] 3x3 depthwise + BN + relu, 1x1 project + BN,
+    + input when stride 1 and equal widths); 1x1 conv + BN + relu; global mean; Linear.  relu, not relu6 (mobilenetv2.py:54,66)."""
+    q = _Q(bf16)
+    x = _conv_bn(sd, q, q(x), "features.0.0", "features.0.1", stride=2, padding=1, relu=True)
+    cin, i = x.shape[0], 1
+    for t, c, n, s in setting:
+        for r in range(n):
+            stride = s if r == 0 else 1
+            p, j = f"features.{i}.conv", 0
+            h = x
+            if t != 1:
+                h = _conv_bn(sd, q, h, f"{p}.0.0", f"{p}.0.1", relu=True)
+                j = 1
+            hidden = h.shape[0]
+            h = _conv_bn(sd, q, h, f"{p}.{j}.0", f"{p}.{j}.1", stride=stride, padding=1, groups=hidden, relu=True)
+            res = x if (stride == 1 and cin == c) else None
+            x = _conv_bn(sd, q, h, f"{p}.{j + 1}", f"{p}.{j + 2}", residual=res)
+            cin = c
+            i += 1
+    x = _conv_bn(sd, q, x, f"features.{i}.0", f"features.{i}.1", relu=True)
+    x = np.ravel(O.adaptive_avgpool2d(x, (1, 1)))
+    return O.linear(x, q(sd["classifier.1.weight"]), sd["classifier.1.bias"])
+
+
 # ---------------------------------------------------------------- segmentation/_utils.py:36-60, fcn.py:19-35, deeplabv3.py:24-136
 def _fcn_head(sd, q, x, p):
     y = _conv_bn(sd, q, x, p + ".0", p + ".1", padding=1, relu=True)                 # conv3x3 + BN + relu (+ Dropout = id)

@@ -135,6 +135,37 @@ def resnet_state(seed=1, block="bottleneck", layers=(3, 4, 6, 3), num_classes=10
     return sd
 
 
+MBV2_SETTING = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
+
+
+def mobilenet_v2_state(seed=1, num_classes=1000, setting=MBV2_SETTING, stem=32, last=1280):
+    """torchvision mobilenet_v2 state_dict order: features.0 (conv, bn), features.i.conv.{0,1,2,3} per inverted-residual block
+    ([expand conv+bn,] depthwise conv+bn, project conv, bn), features.18 (conv, bn), classifier.1."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    _conv(sd, rng, "features.0.0", 3, stem, 3, False)
+    _bn(sd, rng, "features.0.1", stem)
+    cin, i = stem, 1
+    for t, c, n, s in setting:
+        for _ in range(n):
+            hidden = int(round(cin * t))
+            p, j = f"features.{i}.conv", 0
+            if t != 1:
+                _conv(sd, rng, f"{p}.{j}.0", cin, hidden, 1, False)
+                _bn(sd, rng, f"{p}.{j}.1", hidden)
+                j += 1
+            _conv(sd, rng, f"{p}.{j}.0", hidden, hidden, 3, False, groups=hidden)
+            _bn(sd, rng, f"{p}.{j}.1", hidden)
+            _conv(sd, rng, f"{p}.{j + 1}", hidden, c, 1, False)
+            _bn(sd, rng, f"{p}.{j + 2}", c)
+            cin = c
+            i += 1
+    _conv(sd, rng, f"features.{i}.0", cin, last, 1, False)
+    _bn(sd, rng, f"features.{i}.1", last)
+    _linear(sd, rng, "classifier.1", last, num_classes)
+    return sd
+
+
 def segmentation_state(seed=1, kind="fcn", layers=(3, 4, 6, 3), num_classes=21, aux=True):
     """torchvision fcn_resnet50 / deeplabv3_resnet50 state_dict order: backbone (ResNet without fc), classifier, aux_classifier."""
     rng = np.random.Generator(np.random.PCG64(seed + 100))

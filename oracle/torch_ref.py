@@ -118,6 +118,32 @@ def resnet_forward(sd, x, block="bottleneck", layers=(3, 4, 6, 3), groups=1):
     return F.linear(x, sd["fc.weight"], sd["fc.bias"])
 
 
+@torch.no_grad()
+def mobilenet_v2_forward(sd, x, setting):
+    sd = _t(sd)
+    x = torch.as_tensor(x)
+    cbr = lambda x, c, b, stride=1, pad=0, groups=1, relu=True: (lambda y: F.relu(y) if relu else y)(
+        _bn(sd, F.conv2d(x, sd[c + ".weight"], None, stride, pad, 1, groups), b))
+    x = cbr(x, "features.0.0", "features.0.1", 2, 1)
+    cin, i = x.shape[1], 1
+    for t, c, n, s in setting:
+        for r in range(n):
+            stride = s if r == 0 else 1
+            p, j = f"features.{i}.conv", 0
+            h = x
+            if t != 1:
+                h = cbr(h, f"{p}.0.0", f"{p}.0.1")
+                j = 1
+            h = cbr(h, f"{p}.{j}.0", f"{p}.{j}.1", stride, 1, h.shape[1])
+            y = cbr(h, f"{p}.{j + 1}", f"{p}.{j + 2}", relu=False)
+            x = x + y if (stride == 1 and cin == c) else y
+            cin = c
+            i += 1
+    x = cbr(x, f"features.{i}.0", f"features.{i}.1")
+    x = x.mean((2, 3))
+    return F.linear(x, sd["classifier.1.weight"], sd["classifier.1.bias"])
+
+
 def _fcn_head_t(sd, x, p):
     y = F.relu(_bn(sd, F.conv2d(x, sd[p + ".0.weight"], None, 1, 1), p + ".1"))
     return F.conv2d(y, sd[p + ".4.weight"], sd[p + ".4.bias"])

@@ -383,6 +383,38 @@ def linear_split_case(M, K, N, out="fp32", seed=0):
     return run
 
 
+def dwconv_case(N, H, W, C, R=3, stride=1, pad=1, dil=1, act=1, scale=True, seed=0):
+    """mv_dwconv2d_nhwc_fwd (depthwise conv + folded BN + act) vs the oracle's conv2d with groups == channels."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        x = bf(rng.standard_normal((N, C, H, W)))
+        w = bf(rng.standard_normal((C, 1, R, R)) / np.sqrt(R * R))
+        sc = rng.uniform(0.5, 1.5, C).astype(np.float32) if scale else None
+        sf = (0.1 * rng.standard_normal(C)).astype(np.float32)
+        if not L.load().mv_dwconv2d_supported(C, C, C, R, R, 1, 1):
+            return {"ok": False, "err": "mv_dwconv2d_supported says no"}
+        ref = np.stack([O.conv2d(x[i], w, None, stride, pad, dil, C) for i in range(N)]).astype(np.float64)
+        if scale:
+            ref = ref * sc[None, :, None, None]
+        ref = ref + sf[None, :, None, None]
+        if act == 1:
+            ref = np.maximum(ref, 0)
+        Ho = ref.shape[2]
+        xd = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)), "bf16")
+        wd = dev(np.ascontiguousarray(w[:, 0].transpose(1, 2, 0)), "bf16")
+        scd, sfd = (dev(sc, "fp32") if scale else None), dev(sf, "fp32")
+        y = torch.empty((N, Ho, ref.shape[3], C), dtype=torch.bfloat16, device="cuda")
+        L.call("mv_dwconv2d_nhwc_fwd", xd.data_ptr(), wd.data_ptr(), scd.data_ptr() if scale else None, sfd.data_ptr(), y.data_ptr(),
+               N, H, W, C, R, R, stride, stride, pad, pad, dil, dil, act, 1, 1, _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(y).transpose(0, 3, 1, 2), ref, TOL_BF16)
+        info["kernel"] = kern
+        return info
+    return run
+
+
 def conv_grouped64_case(N, H, W, C, groups, R=3, stride=1, pad=1, dil=1, act=1, res=False, seed=0):
     """mv_conv2d_nhwc_grouped64_fwd (grouped conv as block-diagonal 64-channel super-groups on the MFMA) vs the oracle's grouped
     conv2d (resnet.py:17-27 with groups > 1)."""
@@ -1107,6 +1139,18 @@ def all_cases():
           ("split/linear_swin_merge_384_192", linear_split_case(128 * 28 * 28 // 4, 384, 192, seed=511)),
           ("split/linear_swin_merge_1536_768", linear_split_case(64 * 49, 1536, 768, seed=512)),
           ("split/linear_bf16out_ragged", linear_split_case(9000 + 37, 256, 200, out="bf16", seed=513)),
+          ("dwconv/mbv2_96_112_s2", dwconv_case(2, 112, 112, 96, stride=2, seed=550)),
+          ("dwconv/mbv2_144_56", dwconv_case(3, 56, 56, 144, seed=551)),
+          ("dwconv/mbv2_960_7", dwconv_case(4, 7, 7, 960, seed=552)),
+          ("dwconv/w_tail_s1_13x17", dwconv_case(2, 13, 17, 40, seed=560)),
+          ("dwconv/w_tail_s2_15x21", dwconv_case(3, 15, 21, 16, stride=2, seed=561)),
+          ("dwconv/odd_hw_k5_dil2_noscale_noact", dwconv_case(2, 13, 17, 24, R=5, pad=4, dil=2, act=0, scale=False, seed=553)),
+          ("oddc/pw_24_144", conv_nhwc_case(4, 56, 56, 24, 144, 1, 1, act=1, seed=554)),
+          ("oddc/pw_144_24_res", conv_nhwc_case(4, 56, 56, 144, 24, 1, 1, act=0, res=True, seed=555)),
+          ("oddc/pw_16_96", conv_nhwc_case(2, 112, 112, 16, 96, 1, 1, act=1, seed=556)),
+          ("oddc/pw_160_960", conv_nhwc_case(8, 7, 7, 160, 960, 1, 1, act=1, seed=557)),
+          ("oddc/conv3x3_40_72_s2", conv_nhwc_case(2, 19, 19, 40, 72, 3, 3, stride=2, pad=1, act=1, seed=558)),
+          ("oddc/linear_M77_K200_N136", conv_nhwc_case(1, 77, 1, 200, 136, 1, 1, act=0, seed=559)),
           ("grouped64/resnext_layer1_128_g32", conv_grouped64_case(3, 28, 28, 128, 32, seed=540)),
           ("grouped64/resnext_layer2_256_g32_s2", conv_grouped64_case(2, 28, 28, 256, 32, stride=2, seed=541)),
           ("grouped64/resnext101_256_g32_w8", conv_grouped64_case(2, 14, 14, 256, 32, seed=542)),

@@ -107,6 +107,38 @@ def alexnet_case(B, dtype="bf16", features_only=False):
     return run
 
 
+def mobilenet_v2_case(setting, size, B, classes=10, last=1280, dtype="bf16", full_ref="numpy"):
+    """MobileNetV2 (reference models/classification/mobilenetv2.py): depthwise + odd-width pointwise layers, residual in the GEMM
+    epilogue; `setting` None = the published architecture."""
+    def run():
+        import eqxvision_amd as eqv
+        st = tuple(tuple(r) for r in setting) if setting is not None else S.MBV2_SETTING
+        sd = S.mobilenet_v2_state(1, classes, st, last=last)
+        x = S.synthetic_images(B, size, seed=0)
+        kw = {} if setting is None else {"inverted_residual_setting": [list(r) for r in st]}
+        if setting is None:
+            fac = eqv.models.mobilenet_v2
+        else:      # a reduced stack: same constructor, the last 1x1 conv narrowed through width rounding is not available -> patch it
+            def fac(torch_weights=None, **k):
+                net = eqv.models.MobileNetV2(**k)
+                if last != 1280:
+                    from eqxvision_amd.layers import ConvNormActivation
+                    from eqxvision_amd._module import tree_at
+                    cin = net.features.layers[-1].layers[0].in_channels
+                    net = tree_at(lambda m: (m.features.layers[-1], m.classifier.layers[-1]), net,
+                                  (ConvNormActivation(cin, last, kernel_size=1, key=eqv.random.PRNGKey(5)),
+                                   eqv.nn.Linear(last, k.get("num_classes", 1000), key=eqv.random.PRNGKey(6))))
+                return eqv.utils.load_torch_weights(net, torch_weights)
+        net = _load(fac, sd, num_classes=classes, **kw)
+        got = _run(net, x, dtype).cpu().numpy()
+        if full_ref == "torch":
+            ref = TR.mobilenet_v2_forward(sd, x, st).numpy()
+        else:
+            ref = np.stack([OM.mobilenet_v2_forward(sd, im, st) for im in x])
+        return _cmp(got, ref, 1e-2 if dtype == "bf16" else 1e-3)
+    return run
+
+
 def vgg_case(plan, batch_norm, size, B, classes=10, dtype="bf16", full_ref="numpy"):
     """VGG (reference models/classification/vgg.py) incl. its single-relu classifier; `plan` = a torchvision letter or a list."""
     def run():
@@ -497,6 +529,8 @@ def all_cases(full=True):
          ("model/vit_tiny", vit_case(32, 8, 64, 2, 2, 3)),
          ("model/vit_tiny_fp32", vit_case(32, 8, 64, 2, 2, 2, dtype="fp32")),
          ("model/vit_tiny_last_attn", vit_case(32, 8, 64, 2, 2, 2, attn=True)),
+         ("model/mobilenet_v2_reduced", mobilenet_v2_case(((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 2, 1)), 64, 3, last=64)),
+         ("model/mobilenet_v2_reduced_fp32", mobilenet_v2_case(((1, 16, 1, 1), (6, 24, 2, 2)), 32, 2, last=64, dtype="fp32")),
          ("model/vgg_small_bn_avgpool2x2", vgg_case((16, "M", 32, 32, "M"), True, 56, 3)),
          ("model/vgg_small_fp32", vgg_case((8, "M", 16, "M"), False, 28, 2, dtype="fp32")),
          ("model/vgg_small_c64_128", vgg_case((64, "M", 128, 128, "M"), False, 56, 2)),
@@ -529,6 +563,7 @@ def all_cases(full=True):
               ("model/resnext50_32x4d_B2", resnet_case("bottleneck", (3, 4, 6, 3), 224, 2, classes=1000, full_ref="torch",
                                                        groups=32, width_per_group=4)),
               ("model/vit_base_B2", vit_case(224, 16, 768, 12, 12, 2, classes=1000, full_ref="torch")),
+              ("model/mobilenet_v2_B4", mobilenet_v2_case(None, 224, 4, classes=1000, full_ref="torch")),
               ("model/vgg11_B2", vgg_case("A", False, 224, 2, classes=1000, full_ref="torch")),
               ("model/vgg16_bn_B1", vgg_case("D", True, 224, 1, classes=1000, full_ref="torch")),
               ("model/fcn_resnet50_B2", segmentation_case("fcn", (3, 4, 6, 3), 224, 2, classes=21, full_ref="torch")),

@@ -23,6 +23,8 @@ def _keys(sd):
     (lambda: eqv.models.resnet18(), lambda: S.resnet_state(1, "basic", (2, 2, 2, 2))),
     (lambda: eqv.models.vit_base(num_classes=1000), lambda: S.vit_state(1)),
     (lambda: eqv.models.vit_small(), lambda: S.vit_state(1, embed_dim=384, num_heads=6, num_classes=0)),
+    (lambda: eqv.models.mobilenet_v2(), lambda: S.mobilenet_v2_state(1)),
+    (lambda: eqv.models.resnext50_32x4d(), lambda: S.resnet_state(1, groups=32, width_per_group=4)),
     (lambda: eqv.models.vgg11(), lambda: S.vgg_state(1, "A", False)),
     (lambda: eqv.models.vgg16_bn(num_classes=10), lambda: S.vgg_state(1, "D", True, 10)),
 ])
@@ -165,6 +167,25 @@ def test_segmentation_constructors_and_checkpoint_order():
     assert eqv.utils.SEGMENTATION_URLS["fcn_resnet50"].endswith("fcn_resnet50_coco-1167a1af.pth")
     layer4 = eqv.models.deeplabv3(backbone=small(), intermediate_layers=two).backbone.model.layer4.layer
     assert layer4.layers[0].conv2.dilation == (2, 2) and layer4.layers[0].conv2.stride == (1, 1)
+
+
+def test_mobilenet_v2_structure_and_errors():
+    """reference mobilenetv2.py: relu (not relu6) blocks, use_res_connect only for stride 1 and equal widths, argument checks."""
+    net = eqv.models.mobilenet_v2(num_classes=11)
+    blocks = [m for m in net.features.layers if type(m).__name__ == "_InvertedResidual"]
+    assert len(blocks) == 17 and len(net.features.layers) == 19
+    assert [b.use_res_connect for b in blocks[:4]] == [False, False, True, False]
+    assert len(blocks[0].conv.layers) == 3 and len(blocks[1].conv.layers) == 4                  # expand_ratio 1 has no expansion conv
+    dw = blocks[1].conv.layers[1].layers[0]
+    assert dw.groups == dw.in_channels == dw.out_channels == 96 and dw.stride == (2, 2)
+    assert net.classifier.layers[-1].in_features == 1280 and net.classifier.layers[-1].out_features == 11
+    assert eqv.utils._make_divisible(32 * 0.75, 8) == 24 and eqv.utils._make_divisible(10, 8) == 16
+    with pytest.raises(ValueError, match="inverted_residual_setting"):
+        eqv.models.MobileNetV2(inverted_residual_setting=[[1, 2, 3]])
+    with pytest.raises(AssertionError):
+        eqv.models.classification.mobilenetv2._InvertedResidual(8, 8, 3, 6, key=eqv.random.PRNGKey(0))
+    with pytest.raises(RuntimeError, match="PRNGKey"):
+        net(np.zeros((3, 32, 32), np.float32), key=None)
 
 
 def test_conv_norm_activation_structure():

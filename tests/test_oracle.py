@@ -179,6 +179,11 @@ def test_segmentation_and_vgg_restatements_agree_numpy_vs_torch():
         ta, to = TR.segmentation_forward(sd, x, kind, (1, 1, 1, 1))
         np.testing.assert_allclose(o, to[0].numpy(), atol=1e-5)
         np.testing.assert_allclose(a, ta[0].numpy(), atol=1e-5)
+    setting = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 1, 1))
+    sd = S.mobilenet_v2_state(1, 10, setting, last=64)
+    xs = S.synthetic_images(2, 32, seed=0)
+    np.testing.assert_allclose(np.stack([OM.mobilenet_v2_forward(sd, im, setting) for im in xs]),
+                               TR.mobilenet_v2_forward(sd, xs, setting).numpy(), atol=1e-5)
     plan = (8, "M", 16, "M")
     for bn in (False, True):
         sd = S.vgg_state(1, plan, bn, 10)
