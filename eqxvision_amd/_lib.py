@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libeqxvision_amd.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU_TANH = 0, 1, 2
+ACT_HARD_SWISH, ACT_HARD_SIGMOID, ACT_SIGMOID, ACT_SILU = 3, 4, 5, 6       # element-wise entries and the depthwise conv only
 ABI_VERSION = 1
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
@@ -38,6 +39,7 @@ PROTOTYPES = {
     "mv_linear_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
     "mv_linear_split_supported": [_i64, _i, _i, _i],
     "mv_linear_split_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
+    "mv_channel_scale_nhwc_fwd": [_vp, _vp, _vp, _i, _i64, _i, _i, _vp],
     "mv_dwconv2d_supported": [_i] * 7,
     "mv_dwconv2d_nhwc_fwd": [_vp, _vp, _vp, _vp, _vp] + [_i] * 12 + [_i, _i, _i, _vp],
     "mv_conv2d_grouped64_supported": [_i] * 7,

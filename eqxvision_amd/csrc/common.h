@@ -70,6 +70,10 @@ template <int ACT> __device__ __forceinline__ float apply_act(float v) {
 __device__ __forceinline__ float apply_act_rt(float v, int act) {
     if (act == MV_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == MV_ACT_GELU_TANH) return gelu_tanh_f(v);
+    if (act == MV_ACT_HARD_SWISH) return v * fminf(fmaxf(v + 3.0f, 0.f), 6.0f) * (1.0f / 6.0f);       // jax.nn.hard_swish
+    if (act == MV_ACT_HARD_SIGMOID) return fminf(fmaxf(v + 3.0f, 0.f), 6.0f) * (1.0f / 6.0f);         // jax.nn.hard_sigmoid
+    if (act == MV_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+    if (act == MV_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
     return v;
 }
 
@@ -88,6 +92,10 @@ inline size_t dsize(int dt) { return dt == MV_BF16 ? 2 : 4; }
             return MV_E_INVALID;                     \
         }                                            \
     } while (0)
+
+// the matrix-core epilogues implement none / relu / gelu only
+#define MV_CHECK_FUSED_ACT(act, who) \
+    MV_CHECK_ARG((act) >= MV_ACT_NONE && (act) <= MV_ACT_GELU_TANH, who ": activation %d is not fused into this entry (use mv_eltwise_fwd)", (act))
 
 #define MV_LAUNCH_CHECK()                                                            \
     do {                                                                             \

@@ -544,6 +544,15 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* 
         io<T>::st(y + i, apply_act_rt(io<T>::ld(a + i) + io<T>::ld(b + i), act));
 }
 template <typename T>
+__global__ void channel_scale_kernel(const T* __restrict__ x, const T* __restrict__ sc, T* __restrict__ y, long long HW, int C,
+                                     long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long b = i / ((long long)C * HW);
+        io<T>::st(y + i, io<T>::ld(x + i) * io<T>::ld(sc + b * C + c));
+    }
+}
+template <typename T>
 __global__ void channel_affine_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                       const float* __restrict__ shift, T* __restrict__ y, long long rows, int C,
                                       int act) {
@@ -664,6 +673,7 @@ extern "C" {
 int mv_conv2d_nhwc_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                        void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
                        int dh, int dw, int groups, int act, int in_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_FUSED_ACT(act, "conv2d_nhwc");
     MV_CHECK_ARG(x && w && y, "conv2d_nhwc: NULL pointer");
     MV_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0, "conv2d_nhwc: non-positive dims");
     MV_CHECK_ARG(sh > 0 && sw > 0 && dh > 0 && dw > 0 && ph >= 0 && pw >= 0, "conv2d_nhwc: bad stride/dilation/pad");
@@ -699,6 +709,7 @@ int mv_conv2d_nhwc_fwd(const void* x, const void* w, const float* scale, const f
 int mv_conv2d_nchw_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
                        int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act, int x_dtype,
                        int out_dtype, int tok_stride, int tok_offset, const float* pos, mv_stream_t stream) {
+    MV_CHECK_FUSED_ACT(act, "conv2d_nchw");
     MV_CHECK_ARG(x && w && y, "conv2d_nchw: NULL pointer");
     MV_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0, "conv2d_nchw: non-positive dims");
     MV_CHECK_ARG(sh > 0 && sw > 0 && ph >= 0 && pw >= 0, "conv2d_nchw: bad stride/pad");
@@ -728,6 +739,7 @@ int mv_stem_conv_pool_supported(int C, int K, int R, int S, int sh, int sw, int 
 int mv_stem_conv_pool_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
                           int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int pool_k, int pool_s,
                           int pool_p, int act, int x_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_FUSED_ACT(act, "stem_conv_pool");
     MV_CHECK_ARG(x && w && y, "stem_conv_pool: NULL pointer");
     MV_CHECK_ARG(N > 0 && H > 0 && W > 0, "stem_conv_pool: non-positive dims");
     if (!mv_stem_conv_pool_supported(C, K, R, S, sh, sw, ph, pw, pool_k, pool_s, pool_p, act, x_dtype, out_dtype,
@@ -763,6 +775,7 @@ int mv_conv1x1_dual_supported(int64_t M, int C1, int C2, int K, int dtype) {
 int mv_conv1x1_dual_fwd(const void* x, const void* x2, const void* wcat, const float* scale, const float* shift, void* y,
                         int N, int Ho, int Wo, int C1, int H2, int W2, int C2, int stride2, int K, int act, int dtype,
                         mv_stream_t stream) {
+    MV_CHECK_FUSED_ACT(act, "conv1x1_dual");
     MV_CHECK_ARG(x && x2 && wcat && y, "conv1x1_dual: NULL pointer");
     MV_CHECK_ARG(N > 0 && Ho > 0 && Wo > 0 && stride2 >= 1 && (Ho - 1) * stride2 < H2 && (Wo - 1) * stride2 < W2,
                  "conv1x1_dual: the strided source does not cover the output map");
@@ -803,6 +816,7 @@ int mv_conv1x1_dual_chain_fwd(const void* x, const void* x2, const void* wcat, c
 
 int mv_linear_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                   void* y, int64_t M, int N, int K, int act, int in_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_FUSED_ACT(act, "linear");
     MV_CHECK_ARG(x && w && y, "linear: NULL pointer");
     MV_CHECK_ARG(M > 0 && N > 0 && K > 0 && M < (1LL << 31), "linear: bad dims M=%lld N=%d K=%d", (long long)M, N, K);
     if (skinny_f32_supported(M, K, N, in_dtype, out_dtype, residual))       // fp32 classifier heads (exact-fp32 MFMA)
@@ -819,6 +833,7 @@ int mv_linear_split_supported(int64_t M, int N, int K, int dtype) {
 
 int mv_linear_split_fwd(const void* x, const void* w_hi_lo, const float* scale, const float* shift, const void* residual,
                         void* y, int64_t M, int N, int K, int act, int in_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_FUSED_ACT(act, "linear_split");
     MV_CHECK_ARG(x && w_hi_lo && y, "linear_split: NULL pointer");
     if (!mv_linear_split_supported(M, N, K, in_dtype)) {
         set_error("linear_split: unsupported shape M=%lld N=%d K=%d (ask mv_linear_split_supported first)", (long long)M, N, K);
@@ -857,6 +872,7 @@ int mv_conv2d_grouped64_supported(int C, int K, int R, int S, int groups, int in
 int mv_conv2d_nhwc_grouped64_fwd(const void* x, const void* w64, const float* scale, const float* shift, const void* residual,
                                  void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh,
                                  int dw, int groups, int act, int in_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_FUSED_ACT(act, "conv2d_grouped64");
     MV_CHECK_ARG(x && w64 && y, "conv2d_grouped64: NULL pointer");
     MV_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && dh > 0 &&
                  dw > 0, "conv2d_grouped64: bad dims");
@@ -877,6 +893,7 @@ int mv_ln_linear_supported(int64_t M, int N, int K, int x_dtype, int out_dtype) 
 
 int mv_ln_linear_fwd(const void* x, const void* w, const float* bias, void* y, int64_t M, int N, int K, float eps, int act,
                      int x_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_FUSED_ACT(act, "ln_linear");
     MV_CHECK_ARG(x && w && y, "ln_linear: NULL pointer");
     if (!mv_ln_linear_supported(M, N, K, x_dtype, out_dtype)) {
         set_error("ln_linear: unsupported configuration M=%lld N=%d K=%d (ask mv_ln_linear_supported first)", (long long)M, N, K);
@@ -903,6 +920,7 @@ int mv_ln_mlp_fwd(const void* x, const void* w1, const float* b1, const void* w2
 int mv_conv2d_nchw_split_fwd(const void* x, const void* w_hi, const void* w_lo, const float* scale, const float* shift,
                              void* y, int N, int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act,
                              int x_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_FUSED_ACT(act, "conv2d_nchw_split");
     MV_CHECK_ARG(x && w_hi && w_lo && y, "conv2d_nchw_split: NULL pointer");
     MV_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0,
                  "conv2d_nchw_split: bad dims");
@@ -1168,6 +1186,21 @@ int mv_eltwise_fwd(const void* x, void* y, int64_t n, int act, int dtype, mv_str
     else
         hipLaunchKernelGGL(eltwise_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, (float*)y,
                            (long long)n, act);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_channel_scale_nhwc_fwd(const void* x, const void* sc, void* y, int N, int64_t HW, int C, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && sc && y && N > 0 && HW > 0 && C > 0, "channel_scale: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)N * HW * C;
+    set_kernel_name("channel_scale");
+    if (dtype == MV_BF16)
+        hipLaunchKernelGGL(channel_scale_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)sc,
+                           (bf16_t*)y, (long long)HW, C, n);
+    else
+        hipLaunchKernelGGL(channel_scale_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, (const float*)sc,
+                           (float*)y, (long long)HW, C, n);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

@@ -1,6 +1,7 @@
 """Flat model namespace (reference eqxvision/models/__init__.py:1-105) for the hot-path families."""
 from .classification.alexnet import AlexNet, alexnet
 from .classification.mobilenetv2 import MobileNetV2, mobilenet_v2
+from .classification.mobilenetv3 import MobileNetV3, mobilenet_v3_large, mobilenet_v3_small
 from .classification.resnet import (
     ResNet,
     resnet18,
@@ -15,6 +16,7 @@ from .classification.resnet import (
 )
 from .segmentation.deeplabv3 import ASPP, DeepLabHead, DeepLabV3, deeplabv3
 from .segmentation.fcn import FCN, FCNHead, fcn
+from .segmentation.lraspp import LRASPP, LRASPPHead, lraspp_mobilenet_v3_large
 from .classification.swin import SwinTransformer, swin_b, swin_s, swin_t
 from .classification.vgg import VGG, vgg11, vgg11_bn, vgg13, vgg13_bn, vgg16, vgg16_bn, vgg19, vgg19_bn
 from .classification.vit import (

@@ -60,7 +60,22 @@ def gelu(x):
     return _unwrap(ops.eltwise(wrap(x, False), "gelu"), False)
 
 
-_ACT_NAMES = {relu: "relu", gelu: "gelu"}
+def _eltwise_fn(name, doc):
+    def fn(x):
+        if is_act(x):
+            return ops.eltwise(x, name)
+        return _unwrap(ops.eltwise(wrap(x, False), name), False)
+    fn.__name__ = fn.__qualname__ = name
+    fn.__doc__ = doc
+    return fn
+
+
+hard_swish = _eltwise_fn("hard_swish", "jax.nn.hard_swish: x * relu6(x + 3) / 6 (mobilenetv3.py:72)")
+hard_sigmoid = _eltwise_fn("hard_sigmoid", "jax.nn.hard_sigmoid: relu6(x + 3) / 6 (mobilenetv3.py:57)")
+sigmoid = _eltwise_fn("sigmoid", "jax.nn.sigmoid (layers/squeeze.py:40, lraspp.py:102)")
+silu = _eltwise_fn("silu", "jax.nn.silu: x * sigmoid(x)")
+
+_ACT_NAMES = {relu: "relu", gelu: "gelu", hard_swish: "hard_swish", hard_sigmoid: "hard_sigmoid", sigmoid: "sigmoid", silu: "silu"}
 
 
 def act_name(fn) -> Optional[str]:

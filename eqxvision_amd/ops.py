@@ -15,7 +15,9 @@ from . import _lib
 from ._act import (Act, is_act, DT, TORCH_DT, compute_dtype, device, empty, head_fp32, residual_fp32, split_weights,
                    stream_ptr)
 
-ACT = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "gelu": _lib.ACT_GELU_TANH}
+ACT = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "gelu": _lib.ACT_GELU_TANH,
+       "hard_swish": _lib.ACT_HARD_SWISH, "hard_sigmoid": _lib.ACT_HARD_SIGMOID, "sigmoid": _lib.ACT_SIGMOID, "silu": _lib.ACT_SILU}
+UNFUSED_ACTS = ("hard_swish", "hard_sigmoid", "sigmoid", "silu")    # element-wise entries + depthwise conv only (header: MV_ACT_*)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -228,6 +230,9 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
     """Conv2d [+ BatchNorm(inference)] [+ residual] [+ relu/gelu], one launch."""
     _check_bn(bn)
     dt = compute_dtype()
+    if act in UNFUSED_ACTS and not (dt == "bf16" and conv.groups > 1 and conv.groups == conv.in_channels == conv.out_channels
+                                    and residual is None and x.kind != "img"):
+        return eltwise(conv2d(x, conv, bn, None, residual), act)       # hard_swish & co. are not in the GEMM epilogues
     kh, kw = conv.kernel_size
     sh, sw = conv.stride
     ph, pw = conv.padding
@@ -278,7 +283,7 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
         _lib.call("mv_conv2d_nhwc_grouped64_fwd", _ptr(x.t), _ptr(w64), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y),
                   B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, conv.groups, ACT[act], _lib.BF16, _lib.BF16, stream_ptr())
         return Act(y, "map", x.batched)
-    if K % 8 and dt == "bf16" and conv.groups == 1 and residual is None and C % 64 == 0:
+    if K % 8 and dt == "bf16" and conv.groups == 1 and residual is None and C % 8 == 0:
         # an output width the MFMA kernels cannot store in 16-byte pieces (21-class segmentation heads, fcn.py:33): run the
         # convolution on zero-padded filters and compact the rows afterwards instead of dropping to the VALU kernel
         return _conv2d_padded_k(x, conv, bn, act, (w, scale, shift), (B, H, W, C, Ho, Wo))
@@ -470,6 +475,8 @@ def stem_conv_pool(x: Act, conv, bn, act, pool) -> Act:
 def linear(x: Act, lin, act=None, residual: Optional[Act] = None, out_fp32: bool = False) -> Act:
     """Linear over the last (feature) axis of rows: seq [B,N,D], vec [B,D] or map (Linear2d)."""
     dt = compute_dtype()
+    if act in UNFUSED_ACTS:
+        return eltwise(linear(x, lin, None, residual, out_fp32), act)
     x = as_map(x) if x.kind in ("img", "map") else as_rows(x)
     if x.t.dtype != TORCH_DT[dt]:
         x = cast(x, dt)
@@ -813,6 +820,21 @@ def concat_channels(xs) -> Act:
         _lib.call("mv_copy_rows", _ptr(m.t), y.data_ptr() + off * es, B * H * W, c * es, c * es, ctot * es, stream_ptr())
         off += c
     return Act(y, "map", maps[0].batched)
+
+
+def channel_scale(x: Act, s: Act) -> Act:
+    """x * s with s one value per (image, channel): SqueezeExcitation's last line (layers/squeeze.py:60)."""
+    x = as_map(x)
+    B, H, W, C = x.t.shape
+    st = s.t.reshape(B, -1)
+    if st.shape[1] != C:
+        raise ValueError(f"channel_scale: scale has {st.shape[1]} channels, the map {C}")
+    if st.dtype != x.t.dtype:
+        s = cast(Act(st, "vec", s.batched), "bf16" if x.t.dtype == torch.bfloat16 else "fp32")
+        st = s.t
+    y = empty(tuple(x.t.shape), x.t.dtype)
+    _lib.call("mv_channel_scale_nhwc_fwd", _ptr(x.t), _ptr(st.contiguous()), _ptr(y), B, H * W, C, x.dt, stream_ptr())
+    return Act(y, "map", x.batched)
 
 
 def patch_merge_gather(x: Act) -> Act:

@@ -30,7 +30,8 @@ _STEMS = {
     "vgg11": "vgg11-8a719046", "vgg13": "vgg13-19584684", "vgg16": "vgg16-397923af", "vgg19": "vgg19-dcbb9e9d",
     "vgg11_bn": "vgg11_bn-6002323d", "vgg13_bn": "vgg13_bn-abd245e5", "vgg16_bn": "vgg16_bn-6c64b313",
     "vgg19_bn": "vgg19_bn-c79401a0",
-    "mobilenet_v2": "mobilenet_v2-b0353104",
+    "mobilenet_v2": "mobilenet_v2-b0353104", "mobilenet_v3_small": "mobilenet_v3_small-047dcff4",
+    "mobilenet_v3_large": "mobilenet_v3_large-8738ca79",
     "swin_t": "swin_t-704ceda3", "swin_s": "swin_s-5e29d889", "sim_b": "swin_b-68c6b09e",
 }
 SEGMENTATION_URLS = {      # reference utils.py:20-24

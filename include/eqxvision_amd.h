@@ -31,7 +31,11 @@ extern "C" {
 typedef void* mv_stream_t; /* hipStream_t */
 
 enum { MV_F32 = 0, MV_BF16 = 1 };
-enum { MV_ACT_NONE = 0, MV_ACT_RELU = 1, MV_ACT_GELU_TANH = 2 };
+/* Activations.  0-2 are fused into every GEMM / convolution epilogue.  3-6 (jax.nn.hard_swish / hard_sigmoid / sigmoid / silu:
+ * mobilenetv3.py:57,72, lraspp.py:102) are implemented by the element-wise entries (mv_eltwise_fwd, mv_add_fwd,
+ * mv_channel_affine_fwd) and the depthwise convolution; the matrix-core entries refuse them with MV_E_INVALID. */
+enum { MV_ACT_NONE = 0, MV_ACT_RELU = 1, MV_ACT_GELU_TANH = 2, MV_ACT_HARD_SWISH = 3, MV_ACT_HARD_SIGMOID = 4, MV_ACT_SIGMOID = 5,
+       MV_ACT_SILU = 6 };
 enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
 /* mv_set_flag names (A/B and test switches, per calling thread; 0 = the tuned default):
  * "force_generic" (route every op to the simple VALU kernels: on-device cross-check of the MFMA kernels),
@@ -142,6 +146,10 @@ int mv_linear_split_fwd(const void* x, const void* w_hi_lo, const float* scale, 
 int mv_conv2d_nchw_split_fwd(const void* x, const void* w_hi, const void* w_lo, const float* scale, const float* shift,
                              void* y, int N, int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw,
                              int act, int x_dtype, int out_dtype, mv_stream_t stream);
+
+/* x * scale broadcast over the pixels of each image: the last line of SqueezeExcitation.__call__ (layers/squeeze.py:60),
+ * `x * scale_activation(fc2(...))`.  x, y NHWC [N, HW, C]; s [N, C]; all of `dtype`. */
+int mv_channel_scale_nhwc_fwd(const void* x, const void* s, void* y, int N, int64_t HW, int C, int dtype, mv_stream_t stream);
 
 /* Depthwise Conv2d (groups == in_channels == out_channels: mobilenetv2.py:58-68 `ConvNormActivation(hidden, hidden,
  * groups=hidden)`) with the folded BatchNorm and the activation in the same pass.  w_rsc: the (C, 1, R, S) filters re-laid

@@ -33,20 +33,22 @@ def _bn_fold(sd, name, eps=1e-5):
     return scale.astype(F32), shift.astype(F32)
 
 
-def _conv_bn(sd, q, x, conv, bn, stride=1, padding=0, dilation=1, groups=1, relu=False, residual=None):
-    """conv -> BN(inference) [-> + residual] [-> relu]; rounding only at the layer output."""
+def _conv_bn(sd, q, x, conv, bn, stride=1, padding=0, dilation=1, groups=1, relu=False, residual=None, eps=1e-5, act=None):
+    """conv -> BN(inference) [-> + residual] [-> relu / `act`]; rounding only at the layer output."""
     y = O.conv2d(x, q(sd[conv + ".weight"]), None, stride, padding, dilation, groups)
     if bn is not None:
         if q.on:       # product folds BN into an fp32 scale/shift epilogue
-            sc, sh = _bn_fold(sd, bn)
+            sc, sh = _bn_fold(sd, bn, eps)
             y = y * sc[:, None, None] + sh[:, None, None]
         else:          # literal reference order: (x-mean)/sqrt(var+eps)*w+b
             y = O.batchnorm_inference(y, sd[bn + ".weight"], sd[bn + ".bias"],
-                                      sd[bn + ".running_mean"], sd[bn + ".running_var"])
+                                      sd[bn + ".running_mean"], sd[bn + ".running_var"], eps)
     if residual is not None:
         y = y + residual
     if relu:
         y = O.relu(y)
+    if act is not None:
+        y = act(y)
     return q(y)
 
 
@@ -177,6 +179,65 @@ def mobilenet_v2_forward(sd, x, setting, bf16=False):
     x = _conv_bn(sd, q, x, f"features.{i}.0", f"features.{i}.1", relu=True)
     x = np.ravel(O.adaptive_avgpool2d(x, (1, 1)))
     return O.linear(x, q(sd["classifier.1.weight"]), sd["classifier.1.bias"])
+
+
+# ---------------------------------------------------------------- mobilenetv3.py:46-245, layers/squeeze.py:11-61
+def _se(sd, q, x, p):
+    s = O.adaptive_avgpool2d(x, (1, 1))
+    s = q(O.relu(O.conv2d(q(s), q(sd[p + ".fc1.weight"]), sd[p + ".fc1.bias"])))
+    s = q(O.hard_sigmoid(O.conv2d(s, q(sd[p + ".fc2.weight"]), sd[p + ".fc2.bias"])))
+    return q(x * s)
+
+
+def mobilenet_v3_features(sd, x, conf, bf16=False, taps=(), prefix="features."):
+    """The `features` stack; `conf` rows = (in, kernel, expanded, out, use_se, "RE"|"HS", stride, dilation) after channel
+    adjustment; BatchNorm eps 1e-3 (mobilenetv3.py:188).  Returns (output, [outputs of the layers listed in `taps`])."""
+    q = _Q(bf16)
+    outs = {}
+    x = _conv_bn(sd, q, q(x), prefix + "0.0", prefix + "0.1", stride=2, padding=1, eps=1e-3, act=O.hard_swish)
+    if 0 in taps:
+        outs[0] = x
+    for i, (cin, k, cexp, cout, use_se, a, stride, dil) in enumerate(conf, start=1):
+        act = O.hard_swish if a == "HS" else O.relu
+        p, j, h = f"{prefix}{i}.block", 0, x
+        if cexp != cin:
+            h = _conv_bn(sd, q, h, f"{p}.0.0", f"{p}.0.1", eps=1e-3, act=act)
+            j = 1
+        h = _conv_bn(sd, q, h, f"{p}.{j}.0", f"{p}.{j}.1", stride=1 if dil > 1 else stride, padding=(k - 1) // 2 * dil, dilation=dil,
+                     groups=cexp, eps=1e-3, act=act)
+        j += 1
+        if use_se:
+            h = _se(sd, q, h, f"{p}.{j}")
+            j += 1
+        x = _conv_bn(sd, q, h, f"{p}.{j}.0", f"{p}.{j}.1", eps=1e-3, residual=x if (stride == 1 and cin == cout) else None)
+        if i in taps:
+            outs[i] = x
+    i = len(conf) + 1
+    x = _conv_bn(sd, q, x, f"{prefix}{i}.0", f"{prefix}{i}.1", eps=1e-3, act=O.hard_swish)
+    if i in taps:
+        outs[i] = x
+    return x, [outs[t] for t in taps]
+
+
+def mobilenet_v3_forward(sd, x, conf, bf16=False):
+    q = _Q(bf16)
+    x, _ = mobilenet_v3_features(sd, x, conf, bf16)
+    x = q(np.ravel(O.adaptive_avgpool2d(x, (1, 1))))
+    x = q(O.hard_swish(O.linear(x, q(sd["classifier.0.weight"]), sd["classifier.0.bias"])))
+    return O.linear(x, q(sd["classifier.3.weight"]), sd["classifier.3.bias"])
+
+
+# ---------------------------------------------------------------- lraspp.py:13-118
+def lraspp_forward(sd, x, conf, taps=(4, 16), bf16=False):
+    q = _Q(bf16)
+    size = x.shape[-2:]
+    _, (low, high) = mobilenet_v3_features(sd, x, conf, bf16, taps, prefix="backbone.")
+    y = _conv_bn(sd, q, high, "classifier.cbr.0", "classifier.cbr.1", relu=True)
+    s = q(O.sigmoid(O.conv2d(q(O.adaptive_avgpool2d(high, (1, 1))), q(sd["classifier.scale.1.weight"]))))
+    y = q(O.resize_bilinear(q(y * s), low.shape[-2:]))
+    out = q(O.conv2d(low, q(sd["classifier.low_classifier.weight"]), sd["classifier.low_classifier.bias"])) + \
+        q(O.conv2d(y, q(sd["classifier.high_classifier.weight"]), sd["classifier.high_classifier.bias"]))
+    return O.resize_bilinear(q(out), size)
 
 
 # ---------------------------------------------------------------- segmentation/_utils.py:36-60, fcn.py:19-35, deeplabv3.py:24-136

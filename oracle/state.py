@@ -166,6 +166,86 @@ def mobilenet_v2_state(seed=1, num_classes=1000, setting=MBV2_SETTING, stem=32, 
     return sd
 
 
+def _md(v, d=8):
+    n = max(d, int(v + d / 2) // d * d)
+    return n + d if n < 0.9 * v else n
+
+
+def mobilenet_v3_conf(arch="large", dilated=False, reduced_tail=False):
+    """Rows (in, kernel, expanded, out, use_se, "RE"|"HS", stride, dilation) of the two published tables (mobilenetv3.py:266-338),
+    channels already rounded to multiples of 8; plus the width of the classifier's hidden layer."""
+    dv, dl = (2 if reduced_tail else 1), (2 if dilated else 1)
+    if arch == "large":
+        t = [(16, 3, 16, 16, False, "RE", 1, 1), (16, 3, 64, 24, False, "RE", 2, 1), (24, 3, 72, 24, False, "RE", 1, 1),
+             (24, 5, 72, 40, True, "RE", 2, 1), (40, 5, 120, 40, True, "RE", 1, 1), (40, 5, 120, 40, True, "RE", 1, 1),
+             (40, 3, 240, 80, False, "HS", 2, 1), (80, 3, 200, 80, False, "HS", 1, 1), (80, 3, 184, 80, False, "HS", 1, 1),
+             (80, 3, 184, 80, False, "HS", 1, 1), (80, 3, 480, 112, True, "HS", 1, 1), (112, 3, 672, 112, True, "HS", 1, 1),
+             (112, 5, 672, 160 // dv, True, "HS", 2, dl), (160 // dv, 5, 960 // dv, 160 // dv, True, "HS", 1, dl),
+             (160 // dv, 5, 960 // dv, 160 // dv, True, "HS", 1, dl)]
+        last = 1280 // dv
+    else:
+        t = [(16, 3, 16, 16, True, "RE", 2, 1), (16, 3, 72, 24, False, "RE", 2, 1), (24, 3, 88, 24, False, "RE", 1, 1),
+             (24, 5, 96, 40, True, "HS", 2, 1), (40, 5, 240, 40, True, "HS", 1, 1), (40, 5, 240, 40, True, "HS", 1, 1),
+             (40, 5, 120, 48, True, "HS", 1, 1), (48, 5, 144, 48, True, "HS", 1, 1), (48, 5, 288, 96 // dv, True, "HS", 2, dl),
+             (96 // dv, 5, 576 // dv, 96 // dv, True, "HS", 1, dl), (96 // dv, 5, 576 // dv, 96 // dv, True, "HS", 1, dl)]
+        last = 1024 // dv
+    return [(_md(a), k, _md(e), _md(o), se, act, s, d) for a, k, e, o, se, act, s, d in t], _md(last)
+
+
+def _mbv3_features(sd, rng, conf, prefix):
+    _conv(sd, rng, prefix + "0.0", 3, conf[0][0], 3, False)
+    _bn(sd, rng, prefix + "0.1", conf[0][0])
+    for i, (cin, k, cexp, cout, use_se, a, stride, dil) in enumerate(conf, start=1):
+        p, j = f"{prefix}{i}.block", 0
+        if cexp != cin:
+            _conv(sd, rng, f"{p}.0.0", cin, cexp, 1, False)
+            _bn(sd, rng, f"{p}.0.1", cexp)
+            j = 1
+        _conv(sd, rng, f"{p}.{j}.0", cexp, cexp, k, False, groups=cexp)
+        _bn(sd, rng, f"{p}.{j}.1", cexp)
+        j += 1
+        if use_se:
+            sq = _md(cexp // 4)
+            _conv(sd, rng, f"{p}.{j}.fc1", cexp, sq, 1, True)
+            _conv(sd, rng, f"{p}.{j}.fc2", sq, cexp, 1, True)
+            j += 1
+        _conv(sd, rng, f"{p}.{j}.0", cexp, cout, 1, False)
+        _bn(sd, rng, f"{p}.{j}.1", cout)
+    i = len(conf) + 1
+    _conv(sd, rng, f"{prefix}{i}.0", conf[-1][3], 6 * conf[-1][3], 1, False)
+    _bn(sd, rng, f"{prefix}{i}.1", 6 * conf[-1][3])
+    return 6 * conf[-1][3]
+
+
+def mobilenet_v3_state(seed=1, conf=None, last=1280, num_classes=1000):
+    """torchvision mobilenet_v3 state_dict order: features.{i}[.block.{j}] ..., classifier.0, classifier.3."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    if conf is None:
+        conf, last = mobilenet_v3_conf("large")
+    width = _mbv3_features(sd, rng, conf, "features.")
+    _linear(sd, rng, "classifier.0", width, last)
+    _linear(sd, rng, "classifier.3", last, num_classes)
+    return sd
+
+
+def lraspp_state(seed=1, conf=None, taps=(4, 16), num_classes=21, inter=128):
+    """torchvision lraspp_mobilenet_v3_large order: backbone.{i}..., classifier.{cbr.0, cbr.1, scale.1, low_classifier, high_classifier}."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    if conf is None:
+        conf, _ = mobilenet_v3_conf("large", dilated=True)
+    width = _mbv3_features(sd, rng, conf, "backbone.")
+    outc = lambda i: conf[0][0] if i == 0 else (width if i == len(conf) + 1 else conf[i - 1][3])
+    low_c, high_c = outc(taps[0]), outc(taps[1])
+    _conv(sd, rng, "classifier.cbr.0", high_c, inter, 1, False)
+    _bn(sd, rng, "classifier.cbr.1", inter)
+    _conv(sd, rng, "classifier.scale.1", high_c, inter, 1, False)
+    _conv(sd, rng, "classifier.low_classifier", low_c, num_classes, 1, True)
+    _conv(sd, rng, "classifier.high_classifier", inter, num_classes, 1, True)
+    return sd
+
+
 def segmentation_state(seed=1, kind="fcn", layers=(3, 4, 6, 3), num_classes=21, aux=True):
     """torchvision fcn_resnet50 / deeplabv3_resnet50 state_dict order: backbone (ResNet without fc), classifier, aux_classifier."""
     rng = np.random.Generator(np.random.PCG64(seed + 100))

@@ -26,9 +26,9 @@ def _t(sd):
     return out
 
 
-def _bn(sd, x, name):
+def _bn(sd, x, name, eps=1e-5):
     return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"],
-                        sd[name + ".weight"], sd[name + ".bias"], False, 0.0, 1e-5)
+                        sd[name + ".weight"], sd[name + ".bias"], False, 0.0, eps)
 
 
 @torch.no_grad()
@@ -142,6 +142,60 @@ def mobilenet_v2_forward(sd, x, setting):
     x = cbr(x, f"features.{i}.0", f"features.{i}.1")
     x = x.mean((2, 3))
     return F.linear(x, sd["classifier.1.weight"], sd["classifier.1.bias"])
+
+
+def _mbv3_features_t(sd, x, conf, taps=(), prefix="features."):
+    outs = {}
+    hs = F.hardswish
+    cba = lambda x, c, b, act, stride=1, pad=0, dil=1, groups=1: (lambda y: y if act is None else act(y))(
+        _bn(sd, F.conv2d(x, sd[c + ".weight"], None, stride, pad, dil, groups), b, 1e-3))
+    x = cba(x, prefix + "0.0", prefix + "0.1", hs, 2, 1)
+    for i, (cin, k, cexp, cout, use_se, a, stride, dil) in enumerate(conf, start=1):
+        act = hs if a == "HS" else F.relu
+        p, j, h = f"{prefix}{i}.block", 0, x
+        if cexp != cin:
+            h = cba(h, f"{p}.0.0", f"{p}.0.1", act)
+            j = 1
+        h = cba(h, f"{p}.{j}.0", f"{p}.{j}.1", act, 1 if dil > 1 else stride, (k - 1) // 2 * dil, dil, cexp)
+        j += 1
+        if use_se:
+            s = F.adaptive_avg_pool2d(h, 1)
+            s = F.relu(F.conv2d(s, sd[f"{p}.{j}.fc1.weight"], sd[f"{p}.{j}.fc1.bias"]))
+            s = F.hardsigmoid(F.conv2d(s, sd[f"{p}.{j}.fc2.weight"], sd[f"{p}.{j}.fc2.bias"]))
+            h = h * s
+            j += 1
+        y = cba(h, f"{p}.{j}.0", f"{p}.{j}.1", None)
+        x = x + y if (stride == 1 and cin == cout) else y
+        if i in taps:
+            outs[i] = x
+    i = len(conf) + 1
+    x = cba(x, f"{prefix}{i}.0", f"{prefix}{i}.1", hs)
+    if i in taps:
+        outs[i] = x
+    return x, [outs[t] for t in taps]
+
+
+@torch.no_grad()
+def mobilenet_v3_forward(sd, x, conf):
+    sd = _t(sd)
+    x, _ = _mbv3_features_t(sd, torch.as_tensor(x), conf)
+    x = x.mean((2, 3))
+    x = F.hardswish(F.linear(x, sd["classifier.0.weight"], sd["classifier.0.bias"]))
+    return F.linear(x, sd["classifier.3.weight"], sd["classifier.3.bias"])
+
+
+@torch.no_grad()
+def lraspp_forward(sd, x, conf, taps=(4, 16)):
+    sd = _t(sd)
+    x = torch.as_tensor(x)
+    size = x.shape[-2:]
+    _, (low, high) = _mbv3_features_t(sd, x, conf, taps, prefix="backbone.")
+    y = F.relu(_bn(sd, F.conv2d(high, sd["classifier.cbr.0.weight"]), "classifier.cbr.1"))
+    s = torch.sigmoid(F.conv2d(F.adaptive_avg_pool2d(high, 1), sd["classifier.scale.1.weight"]))
+    y = F.interpolate(y * s, size=low.shape[-2:], mode="bilinear", align_corners=False)
+    out = F.conv2d(low, sd["classifier.low_classifier.weight"], sd["classifier.low_classifier.bias"]) + \
+        F.conv2d(y, sd["classifier.high_classifier.weight"], sd["classifier.high_classifier.bias"])
+    return F.interpolate(out, size=size, mode="bilinear", align_corners=False)
 
 
 def _fcn_head_t(sd, x, p):

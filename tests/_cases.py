@@ -455,6 +455,48 @@ def conv_grouped64_case(N, H, W, C, groups, R=3, stride=1, pad=1, dil=1, act=1, 
     return run
 
 
+def eltwise_act_case(name, code, dtype="bf16", seed=0):
+    """mv_eltwise_fwd with the extended activations vs the oracle (jax.nn.hard_swish / hard_sigmoid / sigmoid / silu)."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        q = bf if dtype == "bf16" else (lambda a: np.asarray(a, np.float32))
+        x = q(rng.uniform(-8, 8, 100003))
+        ref = getattr(O, name)(x)
+        xd = dev(x, dtype)
+        y = torch.empty_like(xd)
+        L.call("mv_eltwise_fwd", xd.data_ptr(), y.data_ptr(), x.size, code, DT[dtype], _stream())
+        torch.cuda.synchronize()
+        return _cmp(host(y), ref, TOL_BF16 if dtype == "bf16" else 2e-6)
+    return run
+
+
+def fused_act_refused_case():
+    """the matrix-core entries implement none / relu / gelu only: anything else is MV_E_INVALID, not a silently un-activated result."""
+    def run():
+        L = _lib()
+        x = torch.zeros((256, 64), dtype=torch.bfloat16, device="cuda")
+        w = torch.zeros((64, 64), dtype=torch.bfloat16, device="cuda")
+        y = torch.zeros((256, 64), dtype=torch.bfloat16, device="cuda")
+        rc = L.load().mv_linear_fwd(x.data_ptr(), w.data_ptr(), None, None, None, y.data_ptr(), 256, 64, 64, 3, 1, 1, _stream())
+        return {"ok": rc == -1, "err": float(rc)}
+    return run
+
+
+def channel_scale_case(N, HW, C, dtype="bf16", seed=0):
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        q = bf if dtype == "bf16" else (lambda a: np.asarray(a, np.float32))
+        x, s = q(rng.standard_normal((N, HW, C))), q(rng.uniform(0, 1, (N, C)))
+        xd, sd_ = dev(x, dtype), dev(s, dtype)
+        y = torch.empty_like(xd)
+        L.call("mv_channel_scale_nhwc_fwd", xd.data_ptr(), sd_.data_ptr(), y.data_ptr(), N, HW, C, DT[dtype], _stream())
+        torch.cuda.synchronize()
+        return _cmp(host(y), x.astype(np.float64) * s[:, None, :], TOL_BF16 if dtype == "bf16" else 1e-6)
+    return run
+
+
 def resize_case(N, h, w, C, H, W, dtype="bf16", nchw=True, seed=0):
     """mv_resize_bilinear_nhwc_fwd vs the restatement of jax.image.resize (oracle.np_ops.resize_bilinear)."""
     def run():
@@ -1157,6 +1199,13 @@ def all_cases():
           ("grouped64/cg32_1024_res_noact", conv_grouped64_case(1, 7, 7, 1024, 32, act=0, res=True, seed=543)),
           ("grouped64/cg64_is_plain_grouping_dil2", conv_grouped64_case(2, 15, 15, 128, 2, pad=2, dil=2, seed=544)),
           ("grouped64/k1_cg16", conv_grouped64_case(2, 9, 9, 64, 4, R=1, pad=0, seed=545)),
+          ("act/hard_swish", eltwise_act_case("hard_swish", 3, seed=570)),
+          ("act/hard_sigmoid_f32", eltwise_act_case("hard_sigmoid", 4, dtype="fp32", seed=571)),
+          ("act/sigmoid_f32", eltwise_act_case("sigmoid", 5, dtype="fp32", seed=572)),
+          ("act/silu", eltwise_act_case("silu", 6, seed=573)),
+          ("act/not_fused_into_gemm_entries", fused_act_refused_case()),
+          ("act/se_channel_scale", channel_scale_case(3, 14 * 14, 120, seed=574)),
+          ("act/se_channel_scale_f32", channel_scale_case(2, 49, 24, dtype="fp32", seed=575)),
           ("resize/logits_28_to_224_nchw", resize_case(2, 28, 28, 21, 224, 224)),
           ("resize/pooled_1_to_28_nhwc", resize_case(3, 1, 1, 256, 28, 28, nchw=False)),
           ("resize/odd_7x5_to_20x33_f32", resize_case(2, 7, 5, 3, 20, 33, dtype="fp32")),

@@ -139,6 +139,59 @@ def mobilenet_v2_case(setting, size, B, classes=10, last=1280, dtype="bf16", ful
     return run
 
 
+def mobilenet_v3_case(arch, size, B, classes=10, dtype="bf16", full_ref="numpy", rows=None):
+    """MobileNetV3 (reference mobilenetv3.py): SE blocks, hard_swish / hard_sigmoid, 5x5 depthwise; `rows` truncates the table."""
+    def run():
+        import eqxvision_amd as eqv
+        from eqxvision_amd.models.classification import mobilenetv3 as M3
+        conf, last = S.mobilenet_v3_conf(arch)
+        if rows:
+            conf, last = conf[:rows], 64
+        sd = S.mobilenet_v3_state(1, conf, last, classes)
+        x = S.synthetic_images(B, size, seed=0)
+        if rows:
+            setting, _ = M3._mobilenet_v3_conf(f"mobilenet_v3_{arch}")
+            fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(M3.MobileNetV3(setting[:rows], last, **kw), torch_weights)
+        else:
+            fac = eqv.models.mobilenet_v3_large if arch == "large" else eqv.models.mobilenet_v3_small
+        net = _load(fac, sd, num_classes=classes)
+        got = _run(net, x, dtype).cpu().numpy()
+        if full_ref == "torch":
+            ref = TR.mobilenet_v3_forward(sd, x, conf).numpy()
+        else:
+            ref = np.stack([OM.mobilenet_v3_forward(sd, im, conf) for im in x])
+        return _cmp(got, ref, 1e-2 if dtype == "bf16" else 1e-3)
+    return run
+
+
+def lraspp_case(size, B, classes=21, dtype="bf16", full_ref="torch", jit=False):
+    """lraspp_mobilenet_v3_large (reference lraspp.py, tests/test_models/test_lraspp.py): dilated backbone, taps [4, 16]."""
+    def run():
+        import eqxvision_amd as eqv
+        conf, _ = S.mobilenet_v3_conf("large", dilated=True)
+        sd = S.lraspp_state(1, conf, (4, 16), classes)
+        x = S.synthetic_images(B, size, seed=0)
+        net = _load(lambda torch_weights=None, **kw: eqv.models.lraspp_mobilenet_v3_large(torch_weights=torch_weights, **kw), sd,
+                    num_classes=classes)
+        if jit:
+            fwd, got = _run(net, x, dtype, jit=True)
+            with eqv.precision(dtype):
+                for _ in range(3):
+                    got = fwd(net, x, _keys(B))
+            torch.cuda.synchronize()
+        else:
+            got = _run(net, x, dtype)
+        none, out = got
+        if full_ref == "torch":
+            ref = TR.lraspp_forward(sd, x, conf).numpy()
+        else:
+            ref = np.stack([OM.lraspp_forward(sd, im, conf) for im in x])
+        info = _cmp(out.cpu().numpy(), ref, 1e-2 if dtype == "bf16" else 1e-3)
+        info["ok"] = info["ok"] and none is None and tuple(out.shape) == (B, classes, size, size)
+        return info
+    return run
+
+
 def vgg_case(plan, batch_norm, size, B, classes=10, dtype="bf16", full_ref="numpy"):
     """VGG (reference models/classification/vgg.py) incl. its single-relu classifier; `plan` = a torchvision letter or a list."""
     def run():
@@ -531,6 +584,8 @@ def all_cases(full=True):
          ("model/vit_tiny_last_attn", vit_case(32, 8, 64, 2, 2, 2, attn=True)),
          ("model/mobilenet_v2_reduced", mobilenet_v2_case(((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 2, 1)), 64, 3, last=64)),
          ("model/mobilenet_v2_reduced_fp32", mobilenet_v2_case(((1, 16, 1, 1), (6, 24, 2, 2)), 32, 2, last=64, dtype="fp32")),
+         ("model/mobilenet_v3_small_5rows", mobilenet_v3_case("small", 64, 3, rows=5)),
+         ("model/mobilenet_v3_small_5rows_fp32", mobilenet_v3_case("small", 64, 2, rows=5, dtype="fp32")),
          ("model/vgg_small_bn_avgpool2x2", vgg_case((16, "M", 32, 32, "M"), True, 56, 3)),
          ("model/vgg_small_fp32", vgg_case((8, "M", 16, "M"), False, 28, 2, dtype="fp32")),
          ("model/vgg_small_c64_128", vgg_case((64, "M", 128, 128, "M"), False, 56, 2)),
@@ -564,6 +619,10 @@ def all_cases(full=True):
                                                        groups=32, width_per_group=4)),
               ("model/vit_base_B2", vit_case(224, 16, 768, 12, 12, 2, classes=1000, full_ref="torch")),
               ("model/mobilenet_v2_B4", mobilenet_v2_case(None, 224, 4, classes=1000, full_ref="torch")),
+              ("model/mobilenet_v3_large_B4", mobilenet_v3_case("large", 224, 4, classes=1000, full_ref="torch")),
+              ("model/mobilenet_v3_small_B3", mobilenet_v3_case("small", 224, 3, classes=1000, full_ref="torch")),
+              ("model/lraspp_mobilenet_v3_large_B2", lraspp_case(224, 2)),
+              ("model/lraspp_jit_replay_160px_numpy", lraspp_case(160, 2, classes=7, full_ref="numpy", jit=True)),
               ("model/vgg11_B2", vgg_case("A", False, 224, 2, classes=1000, full_ref="torch")),
               ("model/vgg16_bn_B1", vgg_case("D", True, 224, 1, classes=1000, full_ref="torch")),
               ("model/fcn_resnet50_B2", segmentation_case("fcn", (3, 4, 6, 3), 224, 2, classes=21, full_ref="torch")),

@@ -24,6 +24,8 @@ def _keys(sd):
     (lambda: eqv.models.vit_base(num_classes=1000), lambda: S.vit_state(1)),
     (lambda: eqv.models.vit_small(), lambda: S.vit_state(1, embed_dim=384, num_heads=6, num_classes=0)),
     (lambda: eqv.models.mobilenet_v2(), lambda: S.mobilenet_v2_state(1)),
+    (lambda: eqv.models.mobilenet_v3_large(), lambda: S.mobilenet_v3_state(1)),
+    (lambda: eqv.models.mobilenet_v3_small(), lambda: S.mobilenet_v3_state(1, *S.mobilenet_v3_conf("small"))),
     (lambda: eqv.models.resnext50_32x4d(), lambda: S.resnet_state(1, groups=32, width_per_group=4)),
     (lambda: eqv.models.vgg11(), lambda: S.vgg_state(1, "A", False)),
     (lambda: eqv.models.vgg16_bn(num_classes=10), lambda: S.vgg_state(1, "D", True, 10)),
@@ -186,6 +188,38 @@ def test_mobilenet_v2_structure_and_errors():
         eqv.models.classification.mobilenetv2._InvertedResidual(8, 8, 3, 6, key=eqv.random.PRNGKey(0))
     with pytest.raises(RuntimeError, match="PRNGKey"):
         net(np.zeros((3, 32, 32), np.float32), key=None)
+
+
+def test_mobilenet_v3_se_and_lraspp_structure():
+    """reference mobilenetv3.py / layers/squeeze.py / lraspp.py: tables, SE defaults, dilated tail, taps [4, 16]."""
+    from eqxvision_amd.models.classification import mobilenetv3 as M3
+    large = eqv.models.mobilenet_v3_large()
+    assert len(large.features.layers) == 17 and large.classifier.layers[0].out_features == 1280
+    se = large.features.layers[4].block.layers[2]
+    assert type(se).__name__ == "SqueezeExcitation" and se.fc1.out_channels == 24 and se.scale_activation.fn is nn.hard_sigmoid
+    assert eqv.layers.SqueezeExcitation(16, 8, key=eqv.random.PRNGKey(0)).scale_activation.fn is nn.sigmoid
+    bn = large.features.layers[0].layers[1]
+    assert abs(bn.eps - 1e-3) < 1e-12                                         # partial(BatchNorm, eps=0.001, momentum=0.01)
+    dil = eqv.models.mobilenet_v3_large(dilated=True).features.layers[13].block.layers[1].layers[0]
+    assert dil.dilation == (2, 2) and dil.stride == (1, 1) and dil.padding == (4, 4)
+    small = eqv.models.mobilenet_v3_small(num_classes=5)
+    assert len(small.features.layers) == 13 and small.classifier.layers[-1].out_features == 5
+    with pytest.raises(ValueError, match="Unsupported model type"):
+        M3._mobilenet_v3_conf("mobilenet_v3_medium")
+    with pytest.raises(TypeError):
+        M3.MobileNetV3([1, 2], 10)
+    with pytest.raises(ValueError, match="should not be empty"):
+        M3.MobileNetV3([], 10)
+    with pytest.raises(ValueError, match="illegal stride"):
+        M3._InvertedResidual(M3._InvertedResidualConfig(16, 3, 16, 16, False, "RE", 3, 1, 1.0), nn.BatchNorm)
+    net = eqv.models.lraspp_mobilenet_v3_large(num_classes=None)
+    assert net.classifier.low_classifier.in_channels == 40 and net.classifier.cbr.layers[0].in_channels == 960
+    assert net.classifier.high_classifier.out_channels == 21
+    sd = S.lraspp_state(1)
+    mine = eqv.utils.state_dict(eqv.utils.randomize_batchnorm(net))
+    assert [v.size for v in mine.values()] == [np.asarray(sd[k]).size for k in _keys(sd)]
+    for name, val in ((nn.hard_swish, "hard_swish"), (nn.hard_sigmoid, "hard_sigmoid"), (nn.sigmoid, "sigmoid"), (nn.silu, "silu")):
+        assert nn.act_name(name) == val
 
 
 def test_conv_norm_activation_structure():

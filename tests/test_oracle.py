@@ -184,6 +184,14 @@ def test_segmentation_and_vgg_restatements_agree_numpy_vs_torch():
     xs = S.synthetic_images(2, 32, seed=0)
     np.testing.assert_allclose(np.stack([OM.mobilenet_v2_forward(sd, im, setting) for im in xs]),
                                TR.mobilenet_v2_forward(sd, xs, setting).numpy(), atol=1e-5)
+    conf, _ = S.mobilenet_v3_conf("small")
+    sd = S.mobilenet_v3_state(1, conf[:5], 64, 10)
+    xs = S.synthetic_images(2, 64, seed=0)
+    np.testing.assert_allclose(np.stack([OM.mobilenet_v3_forward(sd, im, conf[:5]) for im in xs]),
+                               TR.mobilenet_v3_forward(sd, xs, conf[:5]).numpy(), atol=1e-5)
+    conf_d, _ = S.mobilenet_v3_conf("large", dilated=True)
+    sd = S.lraspp_state(1, conf_d, (4, 16), 5)
+    np.testing.assert_allclose(OM.lraspp_forward(sd, xs[0], conf_d), TR.lraspp_forward(sd, xs[:1], conf_d)[0].numpy(), atol=1e-5)
     plan = (8, "M", 16, "M")
     for bn in (False, True):
         sd = S.vgg_state(1, plan, bn, 10)
