@@ -65,12 +65,12 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwP p) {
     }
 }
 
-// 3x3, pad 1, no dilation (every depthwise layer of MobileNetV2): one thread = 4 consecutive output columns x 8 channels.  The
-// 3 x (4*STRIDE + 2) input window is loaded once and every loaded pixel feeds up to 3 outputs (18 loads for 4 outputs at
-// stride 1 instead of 36), the 9 weight vectors are loaded once per thread.
-template <int STRIDE>
-__global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwP p) {
-    constexpr int TW = 4, IW = (TW - 1) * STRIDE + 3;
+// k x k (3 or 5), pad k/2, no dilation (every depthwise layer of MobileNetV2 / V3 / EfficientNet): one thread = 4 consecutive output
+// columns x 8 channels.  The KS x ((4-1)*STRIDE + KS) input window is loaded once and every loaded pixel feeds up to KS outputs
+// (18 loads for 4 outputs at 3x3 stride 1 instead of 36; 40 instead of 100 at 5x5), a filter row's KS weight vectors once per row.
+template <int STRIDE, int KS>
+__global__ __launch_bounds__(256) void dwconv_kxk_kernel(const DwP p) {
+    constexpr int TW = 4, IW = (TW - 1) * STRIDE + KS, PAD = KS / 2;
     const int C8 = p.C >> 3, WT = (p.Wo + TW - 1) / TW;
     const long long total = (long long)p.N * p.Ho * WT * C8;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -80,19 +80,19 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwP p) {
         const int ho = (int)(r % p.Ho);
         const int b = (int)(r / p.Ho);
         const int c = c8 * 8, wo0 = wt * TW;
-        float wv[9][8];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) unpack8(*(const uint4*)(p.w + (long long)t * p.C + c), wv[t]);
         float acc[TW][8];
 #pragma unroll
         for (int o = 0; o < TW; ++o)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[o][e] = 0.f;
-        const int h0 = ho * STRIDE - 1, w0 = wo0 * STRIDE - 1;
+        const int h0 = ho * STRIDE - PAD, w0 = wo0 * STRIDE - PAD;
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
+        for (int rr = 0; rr < KS; ++rr) {
             const int hi = h0 + rr;
             if ((unsigned)hi >= (unsigned)p.H) continue;
+            float wv[KS][8];
+#pragma unroll
+            for (int t = 0; t < KS; ++t) unpack8(*(const uint4*)(p.w + (long long)(rr * KS + t) * p.C + c), wv[t]);
             const bf16_t* row = p.x + ((long long)b * p.H + hi) * p.W * p.C + c;
 #pragma unroll
             for (int j = 0; j < IW; ++j) {
@@ -103,9 +103,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwP p) {
 #pragma unroll
                 for (int o = 0; o < TW; ++o) {
                     const int ss = j - o * STRIDE;                   // tap column of output o that this input column feeds
-                    if (ss >= 0 && ss < 3) {
+                    if (ss >= 0 && ss < KS) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(xv[e], wv[rr * 3 + ss][e], acc[o][e]);
+                        for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(xv[e], wv[ss][e], acc[o][e]);
                     }
                 }
             }
@@ -141,15 +141,20 @@ int dwconv_launch(const void* x, const void* w, const float* scale, const float*
     p.Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1;
     p.Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
     p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw; p.act = act;
-    const bool fast = R == 3 && S == 3 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && sh == sw && (sh == 1 || sh == 2) &&
+    const bool fast = R == S && (R == 3 || R == 5) && ph == R / 2 && pw == R / 2 && dh == 1 && dw == 1 && sh == sw && (sh == 1 || sh == 2) &&
                       !get_flag("dwconv_generic");
     const long long total = (long long)N * p.Ho * (fast ? (p.Wo + 3) / 4 : p.Wo) * (C / 8);
     long long g = (total + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
     if (fast) {
-        set_kernel_name(sh == 1 ? "dwconv3x3_s1_bf16x8x4" : "dwconv3x3_s2_bf16x8x4");
-        if (sh == 1) hipLaunchKernelGGL(dwconv3x3_kernel<1>, dim3((unsigned)g), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(dwconv3x3_kernel<2>, dim3((unsigned)g), dim3(256), 0, st, p);
+        char name[48];
+        snprintf(name, sizeof(name), "dwconv%dx%d_s%d_bf16x8x4", R, R, sh);
+        set_kernel_name(name);
+        const dim3 grid((unsigned)g), block(256);
+        if (R == 3 && sh == 1) hipLaunchKernelGGL((dwconv_kxk_kernel<1, 3>), grid, block, 0, st, p);
+        else if (R == 3) hipLaunchKernelGGL((dwconv_kxk_kernel<2, 3>), grid, block, 0, st, p);
+        else if (sh == 1) hipLaunchKernelGGL((dwconv_kxk_kernel<1, 5>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((dwconv_kxk_kernel<2, 5>), grid, block, 0, st, p);
         MV_LAUNCH_CHECK();
         return MV_OK;
     }

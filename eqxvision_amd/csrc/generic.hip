@@ -366,6 +366,41 @@ __global__ void global_avgpool_bf16x8_kernel(const uint4* __restrict__ x, TO* __
     }
 }
 
+// The same reduction for LARGE maps (squeeze-excitation on 112 x 112 ... 14 x 14 maps, layers/squeeze.py:56; DeepLab's pooled
+// branch): one thread per (image, 8 channels) would walk 12 544 pixels serially with a few thousand threads on the whole chip
+// (measured 1.27 ms for 128 x 112 x 112 x 32).  Here a block of 256 threads owns one image and up to 32 channel chunks; the
+// threads of a chunk stride over the pixels (whole 128-byte lines per pixel across the chunk lanes) and meet in LDS.
+template <typename TO>
+__global__ __launch_bounds__(256) void global_avgpool_wide_kernel(const uint4* __restrict__ x, TO* __restrict__ y, int HW, int C8,
+                                                                  int cpb, int pl) {
+    __shared__ float red[256 * 8];
+    const int n = blockIdx.x, c8 = blockIdx.y * cpb + (int)threadIdx.x % cpb, lp = (int)threadIdx.x / cpb;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (lp < pl && c8 < C8) {
+        const uint4* xp = x + (long long)n * HW * C8 + c8;
+        for (int p = lp; p < HW; p += pl) {
+            const uint4 v = xp[(long long)p * C8];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[2 * e] += __uint_as_float(w[e] << 16);
+                s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[e];
+    __syncthreads();
+    if (lp == 0 && c8 < C8) {
+        for (int q = 1; q < pl; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += red[(q * cpb + (int)threadIdx.x) * 8 + e];
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) io<TO>::st(y + ((long long)n * C8 + c8) * 8 + e, s[e] * inv);
+    }
+}
+
 // LayerNorm: one wave per row, two-pass in registers/LDS-free (row re-read from L1/L2).
 template <typename TI, typename TO>
 __global__ void layernorm_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
@@ -965,6 +1000,17 @@ int mv_adaptive_avgpool2d_nhwc_fwd(const void* x, void* y, int N, int H, int W, 
     hipStream_t st = (hipStream_t)stream;
     const long long total = (long long)N * oh * ow * C;
     if (oh == 1 && ow == 1 && in_dtype == MV_BF16 && C % 8 == 0 && !get_flag("force_generic")) {
+        if ((long long)H * W >= 256 && N <= 65535) {
+            const int C8 = C / 8, cpb = C8 < 32 ? C8 : 32, pl = 256 / cpb;
+            set_kernel_name("global_avgpool_wide_bf16x8");
+            dim3 g((unsigned)N, (unsigned)((C8 + cpb - 1) / cpb));
+            if (out_dtype == MV_BF16)
+                hipLaunchKernelGGL(global_avgpool_wide_kernel<bf16_t>, g, dim3(256), 0, st, (const uint4*)x, (bf16_t*)y, H * W, C8, cpb, pl);
+            else
+                hipLaunchKernelGGL(global_avgpool_wide_kernel<float>, g, dim3(256), 0, st, (const uint4*)x, (float*)y, H * W, C8, cpb, pl);
+            MV_LAUNCH_CHECK();
+            return MV_OK;
+        }
         set_kernel_name("global_avgpool_bf16x8");
         const long long nt = (long long)N * (C / 8);
         if (out_dtype == MV_BF16)

@@ -1,5 +1,19 @@
 """Flat model namespace (reference eqxvision/models/__init__.py:1-105) for the hot-path families."""
 from .classification.alexnet import AlexNet, alexnet
+from .classification.efficientnet import (
+    EfficientNet,
+    efficientnet_b0,
+    efficientnet_b1,
+    efficientnet_b2,
+    efficientnet_b3,
+    efficientnet_b4,
+    efficientnet_b5,
+    efficientnet_b6,
+    efficientnet_b7,
+    efficientnet_v2_l,
+    efficientnet_v2_m,
+    efficientnet_v2_s,
+)
 from .classification.mobilenetv2 import MobileNetV2, mobilenet_v2
 from .classification.mobilenetv3 import MobileNetV3, mobilenet_v3_large, mobilenet_v3_small
 from .classification.resnet import (

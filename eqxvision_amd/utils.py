@@ -30,6 +30,12 @@ _STEMS = {
     "vgg11": "vgg11-8a719046", "vgg13": "vgg13-19584684", "vgg16": "vgg16-397923af", "vgg19": "vgg19-dcbb9e9d",
     "vgg11_bn": "vgg11_bn-6002323d", "vgg13_bn": "vgg13_bn-abd245e5", "vgg16_bn": "vgg16_bn-6c64b313",
     "vgg19_bn": "vgg19_bn-c79401a0",
+    "efficientnet_b0": "efficientnet_b0_rwightman-3dd342df", "efficientnet_b1": "efficientnet_b1_rwightman-533bc792",
+    "efficientnet_b2": "efficientnet_b2_rwightman-bcdf34b7", "efficientnet_b3": "efficientnet_b3_rwightman-cf984f9c",
+    "efficientnet_b4": "efficientnet_b4_rwightman-7eb33cd5", "efficientnet_b5": "efficientnet_b5_lukemelas-b6417697",
+    "efficientnet_b6": "efficientnet_b6_lukemelas-c76e70fd", "efficientnet_b7": "efficientnet_b7_lukemelas-dcc49843",
+    "efficientnet_v2_s": "efficientnet_v2_s-dd5fe13b", "efficientnet_v2_m": "efficientnet_v2_m-dc08266a",
+    "efficientnet_v2_l": "efficientnet_v2_l-59c71312",
     "mobilenet_v2": "mobilenet_v2-b0353104", "mobilenet_v3_small": "mobilenet_v3_small-047dcff4",
     "mobilenet_v3_large": "mobilenet_v3_large-8738ca79",
     "swin_t": "swin_t-704ceda3", "swin_s": "swin_s-5e29d889", "sim_b": "swin_b-68c6b09e",

@@ -227,6 +227,45 @@ def mobilenet_v3_forward(sd, x, conf, bf16=False):
     return O.linear(x, q(sd["classifier.3.weight"]), sd["classifier.3.bias"])
 
 
+# ---------------------------------------------------------------- efficientnet.py:95-400
+def efficientnet_forward(sd, x, stages, eps=1e-5, bf16=False):
+    """stem 3x3/2 + BN + SiLU; per stage row (fused, expand, kernel, stride, in, out, layers): MBConv = [1x1 expand,] k x k depthwise,
+    SE (SiLU inside, sigmoid gate, squeeze width max(1, in // 4)), 1x1 project; FusedMBConv = k x k conv [+ 1x1 project]; residual when
+    stride 1 and in == out (stochastic depth = identity in inference); 1x1 conv + BN + SiLU; global mean; Linear."""
+    q = _Q(bf16)
+    md = lambda v: (lambda n: n + 8 if n < 0.9 * v else n)(max(8, int(v + 4) // 8 * 8))
+    x = _conv_bn(sd, q, q(x), "features.0.0", "features.0.1", stride=2, padding=1, eps=eps, act=O.silu)
+    for si, (fused, e, k, s, cin, cout, n) in enumerate(stages, start=1):
+        for b in range(n):
+            ci, stride = (cin, s) if b == 0 else (cout, 1)
+            p = f"features.{si}.{b}.block"
+            cexp = md(ci * e)
+            res = x if (stride == 1 and ci == cout) else None
+            if fused:
+                if cexp != ci:
+                    h = _conv_bn(sd, q, x, p + ".0.0", p + ".0.1", stride=stride, padding=(k - 1) // 2, eps=eps, act=O.silu)
+                    x = _conv_bn(sd, q, h, p + ".1.0", p + ".1.1", eps=eps, residual=res)
+                else:
+                    h = _conv_bn(sd, q, x, p + ".0.0", p + ".0.1", stride=stride, padding=(k - 1) // 2, eps=eps, act=O.silu)
+                    x = q(h + res) if res is not None else h
+                continue
+            j, h = 0, x
+            if cexp != ci:
+                h = _conv_bn(sd, q, h, f"{p}.0.0", f"{p}.0.1", eps=eps, act=O.silu)
+                j = 1
+            h = _conv_bn(sd, q, h, f"{p}.{j}.0", f"{p}.{j}.1", stride=stride, padding=(k - 1) // 2, groups=cexp, eps=eps, act=O.silu)
+            se = f"{p}.{j + 1}"
+            g = q(O.adaptive_avgpool2d(h, (1, 1)))
+            g = q(O.silu(O.conv2d(g, q(sd[se + ".fc1.weight"]), sd[se + ".fc1.bias"])))
+            g = q(O.sigmoid(O.conv2d(g, q(sd[se + ".fc2.weight"]), sd[se + ".fc2.bias"])))
+            h = q(h * g)
+            x = _conv_bn(sd, q, h, f"{p}.{j + 2}.0", f"{p}.{j + 2}.1", eps=eps, residual=res)
+    i = len(stages) + 1
+    x = _conv_bn(sd, q, x, f"features.{i}.0", f"features.{i}.1", eps=eps, act=O.silu)
+    x = np.ravel(O.adaptive_avgpool2d(x, (1, 1)))
+    return O.linear(x, q(sd["classifier.1.weight"]), sd["classifier.1.bias"])
+
+
 # ---------------------------------------------------------------- lraspp.py:13-118
 def lraspp_forward(sd, x, conf, taps=(4, 16), bf16=False):
     q = _Q(bf16)

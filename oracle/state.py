@@ -246,6 +246,65 @@ def lraspp_state(seed=1, conf=None, taps=(4, 16), num_classes=21, inter=128):
     return sd
 
 
+def efficientnet_stages(arch="b0"):
+    """Stage rows (fused, expand, kernel, stride, in, out, layers) AFTER width / depth scaling, the width of the last 1x1 conv and the
+    BatchNorm eps (efficientnet.py:404-715)."""
+    import math
+    b = {"b0": (1.0, 1.0), "b1": (1.0, 1.1), "b2": (1.1, 1.2), "b3": (1.2, 1.4), "b4": (1.4, 1.8), "b5": (1.6, 2.2), "b6": (1.8, 2.6),
+         "b7": (2.0, 3.1)}
+    if arch in b:
+        wm, dm = b[arch]
+        t = ((1, 3, 1, 32, 16, 1), (6, 3, 2, 16, 24, 2), (6, 5, 2, 24, 40, 2), (6, 3, 2, 40, 80, 3), (6, 5, 1, 80, 112, 3),
+             (6, 5, 2, 112, 192, 4), (6, 3, 1, 192, 320, 1))
+        rows = [(0, e, k, s, _md(i * wm), _md(o * wm), int(math.ceil(n * dm))) for e, k, s, i, o, n in t]
+        return rows, 4 * rows[-1][5], (1e-3 if arch in ("b5", "b6", "b7") else 1e-5)
+    v2 = {"v2_s": ((1, 1, 3, 1, 24, 24, 2), (1, 4, 3, 2, 24, 48, 4), (1, 4, 3, 2, 48, 64, 4), (0, 4, 3, 2, 64, 128, 6),
+                   (0, 6, 3, 1, 128, 160, 9), (0, 6, 3, 2, 160, 256, 15))}
+    return list(v2[arch]), 1280, 1e-3
+
+
+def efficientnet_state(seed=1, stages=None, last=None, num_classes=1000):
+    """torchvision efficientnet state_dict order: features.0 (conv, bn), features.{s}.{b}.block.{j}..., features.{S+1}, classifier.1."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    if stages is None:
+        stages, last, _ = efficientnet_stages("b0")
+    _conv(sd, rng, "features.0.0", 3, stages[0][4], 3, False)
+    _bn(sd, rng, "features.0.1", stages[0][4])
+    for si, (fused, e, k, s, cin, cout, n) in enumerate(stages, start=1):
+        for b in range(n):
+            ci = cin if b == 0 else cout
+            p = f"features.{si}.{b}.block"
+            cexp = _md(ci * e)
+            if fused:
+                if cexp != ci:
+                    _conv(sd, rng, p + ".0.0", ci, cexp, k, False)
+                    _bn(sd, rng, p + ".0.1", cexp)
+                    _conv(sd, rng, p + ".1.0", cexp, cout, 1, False)
+                    _bn(sd, rng, p + ".1.1", cout)
+                else:
+                    _conv(sd, rng, p + ".0.0", ci, cout, k, False)
+                    _bn(sd, rng, p + ".0.1", cout)
+                continue
+            j = 0
+            if cexp != ci:
+                _conv(sd, rng, f"{p}.0.0", ci, cexp, 1, False)
+                _bn(sd, rng, f"{p}.0.1", cexp)
+                j = 1
+            _conv(sd, rng, f"{p}.{j}.0", cexp, cexp, k, False, groups=cexp)
+            _bn(sd, rng, f"{p}.{j}.1", cexp)
+            sq = max(1, ci // 4)
+            _conv(sd, rng, f"{p}.{j + 1}.fc1", cexp, sq, 1, True)
+            _conv(sd, rng, f"{p}.{j + 1}.fc2", sq, cexp, 1, True)
+            _conv(sd, rng, f"{p}.{j + 2}.0", cexp, cout, 1, False)
+            _bn(sd, rng, f"{p}.{j + 2}.1", cout)
+    i = len(stages) + 1
+    _conv(sd, rng, f"features.{i}.0", stages[-1][5], last, 1, False)
+    _bn(sd, rng, f"features.{i}.1", last)
+    _linear(sd, rng, "classifier.1", last, num_classes)
+    return sd
+
+
 def segmentation_state(seed=1, kind="fcn", layers=(3, 4, 6, 3), num_classes=21, aux=True):
     """torchvision fcn_resnet50 / deeplabv3_resnet50 state_dict order: backbone (ResNet without fc), classifier, aux_classifier."""
     rng = np.random.Generator(np.random.PCG64(seed + 100))

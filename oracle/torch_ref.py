@@ -198,6 +198,40 @@ def lraspp_forward(sd, x, conf, taps=(4, 16)):
     return F.interpolate(out, size=size, mode="bilinear", align_corners=False)
 
 
+@torch.no_grad()
+def efficientnet_forward(sd, x, stages, eps=1e-5):
+    sd = _t(sd)
+    x = torch.as_tensor(x)
+    md = lambda v: (lambda n: n + 8 if n < 0.9 * v else n)(max(8, int(v + 4) // 8 * 8))
+    cba = lambda x, c, b, act, stride=1, pad=0, groups=1: (lambda y: y if act is None else act(y))(
+        _bn(sd, F.conv2d(x, sd[c + ".weight"], None, stride, pad, 1, groups), b, eps))
+    x = cba(x, "features.0.0", "features.0.1", F.silu, 2, 1)
+    for si, (fused, e, k, s, cin, cout, n) in enumerate(stages, start=1):
+        for b in range(n):
+            ci, stride = (cin, s) if b == 0 else (cout, 1)
+            p = f"features.{si}.{b}.block"
+            cexp = md(ci * e)
+            use_res = stride == 1 and ci == cout
+            if fused:
+                h = cba(x, p + ".0.0", p + ".0.1", F.silu, stride, (k - 1) // 2)
+                y = cba(h, p + ".1.0", p + ".1.1", None) if cexp != ci else h
+            else:
+                j, h = 0, x
+                if cexp != ci:
+                    h = cba(h, f"{p}.0.0", f"{p}.0.1", F.silu)
+                    j = 1
+                h = cba(h, f"{p}.{j}.0", f"{p}.{j}.1", F.silu, stride, (k - 1) // 2, cexp)
+                se = f"{p}.{j + 1}"
+                g = F.adaptive_avg_pool2d(h, 1)
+                g = F.silu(F.conv2d(g, sd[se + ".fc1.weight"], sd[se + ".fc1.bias"]))
+                g = torch.sigmoid(F.conv2d(g, sd[se + ".fc2.weight"], sd[se + ".fc2.bias"]))
+                y = cba(h * g, f"{p}.{j + 2}.0", f"{p}.{j + 2}.1", None)
+            x = x + y if use_res else y
+    i = len(stages) + 1
+    x = cba(x, f"features.{i}.0", f"features.{i}.1", F.silu)
+    return F.linear(x.mean((2, 3)), sd["classifier.1.weight"], sd["classifier.1.bias"])
+
+
 def _fcn_head_t(sd, x, p):
     y = F.relu(_bn(sd, F.conv2d(x, sd[p + ".0.weight"], None, 1, 1), p + ".1"))
     return F.conv2d(y, sd[p + ".4.weight"], sd[p + ".4.bias"])

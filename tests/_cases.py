@@ -400,6 +400,8 @@ def dwconv_case(N, H, W, C, R=3, stride=1, pad=1, dil=1, act=1, scale=True, seed
         ref = ref + sf[None, :, None, None]
         if act == 1:
             ref = np.maximum(ref, 0)
+        elif act == 3:
+            ref = O.hard_swish(ref).astype(np.float64)
         Ho = ref.shape[2]
         xd = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)), "bf16")
         wd = dev(np.ascontiguousarray(w[:, 0].transpose(1, 2, 0)), "bf16")
@@ -1186,6 +1188,9 @@ def all_cases():
           ("dwconv/mbv2_960_7", dwconv_case(4, 7, 7, 960, seed=552)),
           ("dwconv/w_tail_s1_13x17", dwconv_case(2, 13, 17, 40, seed=560)),
           ("dwconv/w_tail_s2_15x21", dwconv_case(3, 15, 21, 16, stride=2, seed=561)),
+          ("dwconv/k5_s1_120_28", dwconv_case(3, 28, 28, 120, R=5, pad=2, seed=562)),
+          ("dwconv/k5_s2_72_w_tail", dwconv_case(2, 27, 31, 72, R=5, stride=2, pad=2, seed=563)),
+          ("dwconv/k5_hard_swish_fused", dwconv_case(2, 14, 14, 672, R=5, pad=2, act=3, seed=564)),
           ("dwconv/odd_hw_k5_dil2_noscale_noact", dwconv_case(2, 13, 17, 24, R=5, pad=4, dil=2, act=0, scale=False, seed=553)),
           ("oddc/pw_24_144", conv_nhwc_case(4, 56, 56, 24, 144, 1, 1, act=1, seed=554)),
           ("oddc/pw_144_24_res", conv_nhwc_case(4, 56, 56, 144, 24, 1, 1, act=0, res=True, seed=555)),
@@ -1293,6 +1298,9 @@ def all_cases():
           ("maxpool/f32_oddC", maxpool_case(1, 13, 13, 5, 3, 2, 0, dtype="fp32")),
           ("avgpool/global", avgpool_case(2, 7, 7, 2048, 1, 1)),
           ("avgpool/13to6", avgpool_case(1, 13, 13, 16, 6, 6)),
+          ("avgpool/global_wide_se_112x112x32", avgpool_case(3, 112, 112, 32, 1, 1, seed=580)),
+          ("avgpool/global_wide_28x28x96", avgpool_case(4, 28, 28, 96, 1, 1, seed=581)),
+          ("avgpool/global_wide_16x16x520", avgpool_case(2, 16, 16, 520, 1, 1, seed=582)),
           ("avgpool/global_swin_7x7x768", avgpool_case(5, 7, 7, 768, 1, 1, seed=2)),
           ("avgpool/global_hw_not_mult4_c8", avgpool_case(3, 5, 3, 8, 1, 1, seed=3)),
           ("avgpool/global_odd_c_scalar_path", avgpool_case(3, 5, 3, 12, 1, 1, seed=4)),

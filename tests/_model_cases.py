@@ -192,6 +192,31 @@ def lraspp_case(size, B, classes=21, dtype="bf16", full_ref="torch", jit=False):
     return run
 
 
+def efficientnet_case(arch, size, B, classes=10, dtype="bf16", full_ref="numpy", stages=None, last=64):
+    """EfficientNet / EfficientNetV2 (reference efficientnet.py): MBConv with SE + SiLU, FusedMBConv; `stages` = a reduced table."""
+    def run():
+        import eqxvision_amd as eqv
+        from eqxvision_amd.models.classification import efficientnet as E
+        if stages is None:
+            st, lastc, eps = S.efficientnet_stages(arch)
+            fac = getattr(eqv.models, f"efficientnet_{arch}")
+        else:
+            st, lastc, eps = list(stages), last, 1e-5
+            cfgs = [(E._FusedMBConvConfig if f else E._MBConvConfig)(e, k, s_, i, o, n) for f, e, k, s_, i, o, n in st]
+            fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(E.EfficientNet(cfgs, 0.2, last_channel=lastc, **kw),
+                                                                                torch_weights)
+        sd = S.efficientnet_state(1, st, lastc, classes)
+        x = S.synthetic_images(B, size, seed=0)
+        net = _load(fac, sd, num_classes=classes)
+        got = _run(net, x, dtype).cpu().numpy()
+        if full_ref == "torch":
+            ref = TR.efficientnet_forward(sd, x, st, eps).numpy()
+        else:
+            ref = np.stack([OM.efficientnet_forward(sd, im, st, eps) for im in x])
+        return _cmp(got, ref, 1e-2 if dtype == "bf16" else 1e-3)
+    return run
+
+
 def vgg_case(plan, batch_norm, size, B, classes=10, dtype="bf16", full_ref="numpy"):
     """VGG (reference models/classification/vgg.py) incl. its single-relu classifier; `plan` = a torchvision letter or a list."""
     def run():
@@ -586,6 +611,9 @@ def all_cases(full=True):
          ("model/mobilenet_v2_reduced_fp32", mobilenet_v2_case(((1, 16, 1, 1), (6, 24, 2, 2)), 32, 2, last=64, dtype="fp32")),
          ("model/mobilenet_v3_small_5rows", mobilenet_v3_case("small", 64, 3, rows=5)),
          ("model/mobilenet_v3_small_5rows_fp32", mobilenet_v3_case("small", 64, 2, rows=5, dtype="fp32")),
+         ("model/efficientnet_reduced_mb_and_fused", efficientnet_case(None, 64, 3, stages=((0, 1, 3, 1, 16, 8, 1), (0, 6, 5, 2, 8, 16, 2),
+                                                                                        (1, 4, 3, 2, 16, 24, 2), (1, 1, 3, 1, 24, 24, 1)))),
+         ("model/efficientnet_reduced_fp32", efficientnet_case(None, 32, 2, dtype="fp32", stages=((0, 1, 3, 1, 16, 8, 1), (0, 6, 3, 2, 8, 16, 2)))),
          ("model/vgg_small_bn_avgpool2x2", vgg_case((16, "M", 32, 32, "M"), True, 56, 3)),
          ("model/vgg_small_fp32", vgg_case((8, "M", 16, "M"), False, 28, 2, dtype="fp32")),
          ("model/vgg_small_c64_128", vgg_case((64, "M", 128, 128, "M"), False, 56, 2)),
@@ -623,6 +651,8 @@ def all_cases(full=True):
               ("model/mobilenet_v3_small_B3", mobilenet_v3_case("small", 224, 3, classes=1000, full_ref="torch")),
               ("model/lraspp_mobilenet_v3_large_B2", lraspp_case(224, 2)),
               ("model/lraspp_jit_replay_160px_numpy", lraspp_case(160, 2, classes=7, full_ref="numpy", jit=True)),
+              ("model/efficientnet_b0_B4", efficientnet_case("b0", 224, 4, classes=1000, full_ref="torch")),
+              ("model/efficientnet_v2_s_B2", efficientnet_case("v2_s", 224, 2, classes=1000, full_ref="torch")),
               ("model/vgg11_B2", vgg_case("A", False, 224, 2, classes=1000, full_ref="torch")),
               ("model/vgg16_bn_B1", vgg_case("D", True, 224, 1, classes=1000, full_ref="torch")),
               ("model/fcn_resnet50_B2", segmentation_case("fcn", (3, 4, 6, 3), 224, 2, classes=21, full_ref="torch")),

@@ -24,6 +24,8 @@ def _keys(sd):
     (lambda: eqv.models.vit_base(num_classes=1000), lambda: S.vit_state(1)),
     (lambda: eqv.models.vit_small(), lambda: S.vit_state(1, embed_dim=384, num_heads=6, num_classes=0)),
     (lambda: eqv.models.mobilenet_v2(), lambda: S.mobilenet_v2_state(1)),
+    (lambda: eqv.models.efficientnet_b0(), lambda: S.efficientnet_state(1)),
+    (lambda: eqv.models.efficientnet_v2_s(), lambda: S.efficientnet_state(1, *S.efficientnet_stages("v2_s")[:2])),
     (lambda: eqv.models.mobilenet_v3_large(), lambda: S.mobilenet_v3_state(1)),
     (lambda: eqv.models.mobilenet_v3_small(), lambda: S.mobilenet_v3_state(1, *S.mobilenet_v3_conf("small"))),
     (lambda: eqv.models.resnext50_32x4d(), lambda: S.resnet_state(1, groups=32, width_per_group=4)),
@@ -220,6 +222,36 @@ def test_mobilenet_v3_se_and_lraspp_structure():
     assert [v.size for v in mine.values()] == [np.asarray(sd[k]).size for k in _keys(sd)]
     for name, val in ((nn.hard_swish, "hard_swish"), (nn.hard_sigmoid, "hard_sigmoid"), (nn.sigmoid, "sigmoid"), (nn.silu, "silu")):
         assert nn.act_name(name) == val
+
+
+def test_efficientnet_structure_and_errors():
+    """reference efficientnet.py: width / depth scaling, SE squeeze width max(1, in // 4) with SiLU, BatchNorm eps overrides,
+    stochastic-depth schedule, argument checks."""
+    from eqxvision_amd.models.classification import efficientnet as E
+    b0 = eqv.models.efficientnet_b0()
+    assert len(b0.features.layers) == 9 and [len(s.layers) for s in b0.features.layers[1:8]] == [1, 2, 2, 3, 3, 4, 1]
+    blk = b0.features.layers[2].layers[0]
+    se = blk.block.layers[2]
+    assert se.fc1.out_channels == 4 and se.activation.fn is nn.silu and se.scale_activation.fn is nn.sigmoid
+    assert blk.stochastic_depth.mode == "per_channel" and abs(blk.stochastic_depth.p - 0.2 * 1 / 16) < 1e-12
+    assert b0.classifier.layers[-1].in_features == 1280
+    b3 = eqv.models.efficientnet_b3()
+    assert b3.features.layers[0].layers[0].out_channels == 40 and [len(s.layers) for s in b3.features.layers[1:8]] == [2, 3, 3, 5, 5, 6, 2]
+    assert abs(eqv.models.efficientnet_b5().features.layers[0].layers[1].eps - 1e-3) < 1e-12
+    v2 = eqv.models.efficientnet_v2_s(num_classes=3)
+    fused = v2.features.layers[1].layers[0]
+    assert type(fused).__name__ == "_FusedMBConv" and len(fused.block.layers) == 1 and fused.use_res_connect
+    assert type(v2.features.layers[4].layers[0]).__name__ == "_MBConv" and v2.classifier.layers[-1].out_features == 3
+    with pytest.raises(ValueError, match="Unsupported model type"):
+        E._efficientnet_conf("efficientnet_x")
+    with pytest.raises(TypeError):
+        E.EfficientNet([1], 0.2)
+    with pytest.raises(ValueError, match="should not be empty"):
+        E.EfficientNet([], 0.2)
+    with pytest.raises(ValueError, match="illegal stride"):
+        E._MBConv(E._MBConvConfig(1, 3, 3, 16, 16, 1), 0.0, nn.BatchNorm)
+    with pytest.raises(RuntimeError, match="PRNGKey"):
+        b0(np.zeros((3, 32, 32), np.float32), key=None)
 
 
 def test_conv_norm_activation_structure():

@@ -192,6 +192,10 @@ def test_segmentation_and_vgg_restatements_agree_numpy_vs_torch():
     conf_d, _ = S.mobilenet_v3_conf("large", dilated=True)
     sd = S.lraspp_state(1, conf_d, (4, 16), 5)
     np.testing.assert_allclose(OM.lraspp_forward(sd, xs[0], conf_d), TR.lraspp_forward(sd, xs[:1], conf_d)[0].numpy(), atol=1e-5)
+    st = [(0, 1, 3, 1, 16, 8, 1), (0, 6, 5, 2, 8, 16, 2), (1, 4, 3, 2, 16, 24, 2), (1, 1, 3, 1, 24, 24, 1)]
+    sd = S.efficientnet_state(1, st, 64, 10)
+    np.testing.assert_allclose(np.stack([OM.efficientnet_forward(sd, im, st) for im in xs]),
+                               TR.efficientnet_forward(sd, xs, st).numpy(), atol=1e-5)
     plan = (8, "M", 16, "M")
     for bn in (False, True):
         sd = S.vgg_state(1, plan, bn, 10)
