@@ -36,7 +36,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 GFLOP_PER_IMG = {"resnet50": 8.178, "vit_base": 35.13, "swin_t": 8.98, "alexnet": 1.428,
-                 "vgg16": 30.94, "vgg16_bn": 30.94, "vgg11": 15.22, "resnext50_32x4d": 8.46, "mobilenet_v2": 0.601, "mobilenet_v3_large": 0.434, "efficientnet_b0": 0.772, "efficientnet_v2_s": 16.8}   # section 8 f1 (2 x MACs of the conv / Linear layers)
+                 "vgg16": 30.94, "vgg16_bn": 30.94, "vgg11": 15.22, "resnext50_32x4d": 8.46, "mobilenet_v2": 0.601, "mobilenet_v3_large": 0.434, "efficientnet_b0": 0.772, "efficientnet_v2_s": 16.8, "regnet_y_400mf": 0.80, "regnet_x_3_2gf": 6.35}   # section 8 f1 (2 x MACs of the conv / Linear layers)
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -56,7 +56,7 @@ def build_model(name: str, seed: int = 1):
             net = eqv.models.swin_t(key=key)
         elif name == "alexnet":
             net = eqv.models.alexnet(key=key)
-        elif name in ("efficientnet_b0", "efficientnet_v2_s"):
+        elif name in ("efficientnet_b0", "efficientnet_v2_s", "regnet_y_400mf", "regnet_x_3_2gf"):
             net = eqv.utils.randomize_batchnorm(getattr(eqv.models, name)(key=key), seed)
         elif name == "mobilenet_v3_large":
             net = eqv.utils.randomize_batchnorm(eqv.models.mobilenet_v3_large(key=key), seed)

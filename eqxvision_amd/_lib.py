@@ -43,6 +43,7 @@ PROTOTYPES = {
     "mv_dwconv2d_supported": [_i] * 7,
     "mv_dwconv2d_nhwc_fwd": [_vp, _vp, _vp, _vp, _vp] + [_i] * 12 + [_i, _i, _i, _vp],
     "mv_conv2d_grouped64_supported": [_i] * 7,
+    "mv_conv2d_grouped64_window": [_i, _i],
     "mv_conv2d_nhwc_grouped64_fwd": [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 14 + [_i, _i, _i, _vp],
     "mv_ln_linear_supported": [_i64, _i, _i, _i, _i],
     "mv_ln_linear_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _i, _i, _vp],

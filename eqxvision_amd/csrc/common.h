@@ -122,9 +122,10 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
                  void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
                  int dh, int dw, int act, int in_dtype, int out_dtype, hipStream_t stream);
 int igemm_grouped64_supported(int C, int K, int R, int S, int groups, int in_dtype, int out_dtype);
+int igemm_grouped64_window(int C, int groups);
 int igemm_grouped64_launch(const void* x, const void* w64, const float* scale, const float* shift, const void* residual, void* y,
-                           int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int act,
-                           int out_dtype, hipStream_t stream);
+                           int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int groups,
+                           int act, int out_dtype, hipStream_t stream);
 int igemm_oddc_supported(int C, int K, int groups, int in_dtype, int out_dtype);
 int igemm_oddc_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y, int N,
                       int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int act,

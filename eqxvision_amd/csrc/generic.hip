@@ -918,8 +918,12 @@ int mv_conv2d_nhwc_grouped64_fwd(const void* x, const void* w64, const float* sc
                   groups);
         return MV_E_UNSUPPORTED;
     }
-    return igemm_grouped64_launch(x, w64, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype,
+    return igemm_grouped64_launch(x, w64, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, groups, act, out_dtype,
                                   (hipStream_t)stream);
+}
+
+int mv_conv2d_grouped64_window(int C, int groups) {
+    return (groups > 0 && C > 0 && C % groups == 0) ? igemm_grouped64_window(C, groups) : 0;
 }
 
 int mv_ln_linear_supported(int64_t M, int N, int K, int x_dtype, int out_dtype) {

@@ -38,8 +38,10 @@ struct IgemmP {
     int M, tiles_m, tiles_n, act;
     int m_off;   // first output row this launch covers (rows m_off .. M-1)
     int xpitch;  // channels per input pixel in memory (== C except in grouped mode)
-    int grouped; // 1: grouped convolution in 64-channel super-groups: C = 64 is the reduction length per tap, the input channels
-                 // of output tile n0 .. n0+63 are xpitch-strided pixels at channel offset n0 (weights [K][R][S][64], block-diagonal)
+    int grouped; // > 0: grouped convolution, `grouped` = channels per group (== outputs per group).  C is the per-tap WINDOW (a multiple of
+                 // 64) of input channels that the 64 output channels of a tile can touch: it starts at the first channel of the first
+                 // group the tile touches, (n0 / grouped) * grouped; pixels are xpitch channels apart; weights [K][R][S][C] hold each
+                 // filter at its offset inside its tile's window, zeros elsewhere.
 };
 
 // 8 consecutive residual values of one output row, fetched as raw bits early, decoded in the epilogue
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
     const int cpt = (p.C + 63) >> 6;                               // k-tiles per filter tap
     const int nk = p.R * p.S * cpt;
     const long long wrow_stride = (long long)p.R * p.S * p.C;
+    const int goff = p.grouped ? (n0 / p.grouped) * p.grouped : 0;  // grouped: first input channel of the tile's window
 
     long long xoff[XI];   // DENSE: element offset of the row, -1 = past the end
     int xb[XI], xh[XI], xw[XI];
@@ -119,7 +122,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
         char* xs = smem + buf * STAGE;
         char* ws = xs + BM * ROWB;
         const int tapoff = (r * p.S + s) * p.C + c0;
-        const bool kin = c0 + chunk * 8 < p.C;                     // C % 64 != 0: the last k-tile of a tap is zero-filled past C
+        // C % 64 != 0: the last k-tile of a tap is zero-filled past C; grouped: so is the part of the window past the last channel
+        const bool kin = c0 + chunk * 8 < p.C && goff + c0 + chunk * 8 < p.xpitch;
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
             const bf16_t* src = p.zero;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
             } else {
                 const int hi = xh[j] + r * p.dh, wi = xw[j] + s * p.dw;
                 if (kin && xb[j] >= 0 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                    src = p.x + (((long long)xb[j] * p.H + hi) * p.W + wi) * p.xpitch + (p.grouped ? n0 : 0) + c0 + chunk * 8;
+                    src = p.x + (((long long)xb[j] * p.H + hi) * p.W + wi) * p.xpitch + goff + c0 + chunk * 8;
             }
             glds16(src, xs + 8 * (wave + 4 * j) * ROWB);
         }
@@ -404,21 +408,35 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
     return launch_tile<128, 128, 4, 1>(p, dense, out_f32, st);
 }
 
-// Grouped convolution on the matrix cores (ResNeXt / RegNet conv2, resnet.py:440-471 `groups=32, width_per_group=4|8`): groups
-// of Cg = C / groups input channels with Cg | 64 and as many output channels per group.  Sixteen 4-channel groups (or eight 8-channel
-// groups, ...) are processed as ONE 64 -> 64 channel convolution whose weight tile is block-diagonal (zeros between the groups,
-// expanded once by the caller): the k-tile stays a full 128-byte line per pixel, every fragment load is aligned, and the wasted
-// MFMA work (64 / Cg x) is cheaper than what the scalar kernel costs (0.9 TFLOP/s).  One 128-pixel x 64-channel tile per
-// super-group: tile_n selects both the output channels and the input channel offset.
+// Grouped convolution on the matrix cores (ResNeXt conv2, resnet.py:440-471 `groups=32, width_per_group=4|8`; RegNet, regnet.py:49-70,
+// group widths 8 ... 264): Cg = C / groups input channels per group and as many output channels.  A tile of 64 output channels
+// touches the groups (n0 / Cg) ... ((n0 + 63) / Cg); their input channels form one contiguous WINDOW starting at (n0 / Cg) * Cg.
+// The caller expands the filters to [K][R][S][win] (win = the widest window, rounded up to 64): every filter sits at its offset
+// inside its tile's window, zeros elsewhere -- sixteen 4-channel groups become ONE 64 -> 64 convolution with a block-diagonal
+// weight tile, a 264-channel group a 64 x 320..576 slice.  The k-tile stays a full 128-byte line per pixel, every fragment load is
+// aligned (Cg % 8 == 0 or Cg | 64), and the padded MFMA work (win / Cg x) is far cheaper than the scalar kernel (0.9 TFLOP/s).
 int igemm_grouped64_supported(int C, int K, int R, int S, int groups, int in_dtype, int out_dtype) {
-    if (groups <= 1 || C != K || C % 64 != 0) return 0;
+    if (groups <= 1 || C != K || C % groups != 0) return 0;
     const int cg = C / groups;
-    return in_dtype == MV_BF16 && (out_dtype == MV_BF16 || out_dtype == MV_F32) && cg > 0 && 64 % cg == 0 && R * S <= 64;
+    return in_dtype == MV_BF16 && (out_dtype == MV_BF16 || out_dtype == MV_F32) && C % 8 == 0 && (cg % 8 == 0 || 64 % cg == 0) &&
+           R * S <= 64;
+}
+
+// the widest per-tile input window, rounded up to a multiple of 64 (what the caller's expanded filters must be laid out for)
+int igemm_grouped64_window(int C, int groups) {
+    const int cg = C / groups;
+    int w = 0;
+    for (int n0 = 0; n0 < C; n0 += 64) {
+        const int last = (n0 + 63 < C ? n0 + 63 : C - 1);
+        const int width = (last / cg + 1) * cg - (n0 / cg) * cg;
+        if (width > w) w = width;
+    }
+    return (w + 63) / 64 * 64;
 }
 
 int igemm_grouped64_launch(const void* x, const void* w64, const float* scale, const float* shift, const void* residual, void* y,
-                           int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int act,
-                           int out_dtype, hipStream_t st) {
+                           int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int groups,
+                           int act, int out_dtype, hipStream_t st) {
     IgemmP p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w64; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.zero = (const bf16_t*)zero_page(st);
@@ -426,8 +444,8 @@ int igemm_grouped64_launch(const void* x, const void* w64, const float* scale, c
         set_error("igemm_grouped64: zero page allocation failed");
         return MV_E_OOM;
     }
-    p.N = N; p.H = H; p.W = W; p.C = 64; p.K = K; p.R = R; p.S = S;
-    p.xpitch = C; p.grouped = 1;
+    p.N = N; p.H = H; p.W = W; p.C = igemm_grouped64_window(C, groups); p.K = K; p.R = R; p.S = S;
+    p.xpitch = C; p.grouped = C / groups;
     p.Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1;
     p.Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
     p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw;

@@ -16,6 +16,24 @@ from .classification.efficientnet import (
 )
 from .classification.mobilenetv2 import MobileNetV2, mobilenet_v2
 from .classification.mobilenetv3 import MobileNetV3, mobilenet_v3_large, mobilenet_v3_small
+from .classification.regnet import (
+    RegNet,
+    regnet_x_1_6gf,
+    regnet_x_3_2gf,
+    regnet_x_8gf,
+    regnet_x_16gf,
+    regnet_x_32gf,
+    regnet_x_400mf,
+    regnet_x_800mf,
+    regnet_y_1_6gf,
+    regnet_y_3_2gf,
+    regnet_y_8gf,
+    regnet_y_16gf,
+    regnet_y_32gf,
+    regnet_y_128gf,
+    regnet_y_400mf,
+    regnet_y_800mf,
+)
 from .classification.resnet import (
     ResNet,
     resnet18,

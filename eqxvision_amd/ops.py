@@ -84,8 +84,9 @@ def prep_conv(conv, bn, layout: str, dtype: str):
 
 
 def prep_conv_grouped64(conv, bn):
-    """Grouped filters (O, I/g, kh, kw) expanded to 64-channel super-groups: [O][kh][kw][64], block-diagonal (the layout
-    mv_conv2d_nhwc_grouped64_fwd documents), bf16; BN folded to fp32 scale / shift as in prep_conv."""
+    """Grouped filters (O, I/g, kh, kw) expanded to the per-tile input windows: [O][kh][kw][win] (the layout
+    mv_conv2d_nhwc_grouped64_fwd documents; block-diagonal 64 x 64 tiles when the group width divides 64), bf16; BN folded to
+    fp32 scale / shift as in prep_conv."""
     key = ("conv_g64", id(bn))
     cache = conv._cache()
     hit = cache.get(key)
@@ -93,10 +94,11 @@ def prep_conv_grouped64(conv, bn):
         return hit
     w = np.asarray(conv.weight, np.float32)                      # (O, Cg, kh, kw)
     O_, cg, kh, kw = w.shape
-    w64 = np.zeros((O_, kh, kw, 64), np.float32)
+    win = int(_lib.load().mv_conv2d_grouped64_window(O_, conv.groups))
+    w64 = np.zeros((O_, kh, kw, win), np.float32)
     for k in range(O_):
-        g0 = (k // cg) * cg % 64                                  # first input channel of k's group inside its super-group
-        w64[k, :, :, g0:g0 + cg] = w[k].transpose(1, 2, 0)
+        off = (k // cg) * cg - ((k // 64 * 64) // cg) * cg       # my group's first channel inside my tile's window
+        w64[k, :, :, off:off + cg] = w[k].transpose(1, 2, 0)
     bias = None if conv.bias is None else np.asarray(conv.bias, np.float32).reshape(-1)
     scale = shift = None
     if bn is not None:

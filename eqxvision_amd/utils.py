@@ -36,6 +36,12 @@ _STEMS = {
     "efficientnet_b6": "efficientnet_b6_lukemelas-c76e70fd", "efficientnet_b7": "efficientnet_b7_lukemelas-dcc49843",
     "efficientnet_v2_s": "efficientnet_v2_s-dd5fe13b", "efficientnet_v2_m": "efficientnet_v2_m-dc08266a",
     "efficientnet_v2_l": "efficientnet_v2_l-59c71312",
+    "regnet_y_400mf": "regnet_y_400mf-e6988f5f", "regnet_y_800mf": "regnet_y_800mf-58fc7688", "regnet_y_1_6gf": "regnet_y_1_6gf-0d7bc02a",
+    "regnet_y_3_2gf": "regnet_y_3_2gf-9180c971", "regnet_y_8gf": "regnet_y_8gf-dc2b1b54", "regnet_y_16gf": "regnet_y_16gf-3e4a00f9",
+    "regnet_y_32gf": "regnet_y_32gf-8db6d4b5", "regnet_y_128gf": "regnet_y_128gf_swag-c8ce3e52",
+    "regnet_x_400mf": "regnet_x_400mf-62229a5f", "regnet_x_800mf": "regnet_x_800mf-94a99ebd", "regnet_x_1_6gf": "regnet_x_1_6gf-a12f2b72",
+    "regnet_x_3_2gf": "regnet_x_3_2gf-7071aa85", "regnet_x_8gf": "regnet_x_8gf-2b70d774", "regnet_x_16gf": "regnet_x_16gf-ba3796d7",
+    "regnet_x_32gf": "regnet_x_32gf-6eb8fdc6",
     "mobilenet_v2": "mobilenet_v2-b0353104", "mobilenet_v3_small": "mobilenet_v3_small-047dcff4",
     "mobilenet_v3_large": "mobilenet_v3_large-8738ca79",
     "swin_t": "swin_t-704ceda3", "swin_s": "swin_s-5e29d889", "sim_b": "swin_b-68c6b09e",

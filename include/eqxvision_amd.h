@@ -159,12 +159,14 @@ int mv_dwconv2d_nhwc_fwd(const void* x, const void* w_rsc, const float* scale, c
                          int C, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw, int act, int in_dtype, int out_dtype,
                          mv_stream_t stream);
 
-/* Grouped Conv2d on the matrix cores (ResNeXt conv2: resnet.py:17-27 `groups`, :440-471 `groups=32, width_per_group=4 | 8`), for
- * C == K, (C / groups) | 64: groups are processed in 64-channel super-groups whose filter tile is block-diagonal.  The CALLER
- * expands the [K][R][S][C/groups] filters to w64 [K][R][S][64]: output channel k = 64*q + j reads input channels 64*q .. 64*q+63,
- * w64[k][r][s][i] = w[k][r][s][i - g0] for the C/groups inputs of k's own group (g0 = its first channel inside the super-group), 0
- * elsewhere.  Everything else as mv_conv2d_nhwc_fwd. */
+/* Grouped Conv2d on the matrix cores (ResNeXt conv2: resnet.py:17-27 `groups`, :440-471 `groups=32, width_per_group=4 | 8`; RegNet:
+ * regnet.py:49-70, group widths 8 ... 264), for C == K and Cg = C / groups with Cg % 8 == 0 or Cg | 64.  A tile of 64 output
+ * channels n0 .. n0+63 reads the contiguous WINDOW of input channels of the groups it touches, starting at (n0 / Cg) * Cg.  The CALLER
+ * expands the [K][R][S][Cg] filters to w64 [K][R][S][win], win = mv_conv2d_grouped64_window(C, groups) (the widest window, a
+ * multiple of 64): w64[k][r][s][(k / Cg) * Cg - ((k / 64 * 64) / Cg) * Cg + i] = w[k][r][s][i], 0 elsewhere (for Cg | 64 this is the
+ * block-diagonal 64 x 64 tile).  Everything else as mv_conv2d_nhwc_fwd. */
 int mv_conv2d_grouped64_supported(int C, int K, int R, int S, int groups, int in_dtype, int out_dtype);
+int mv_conv2d_grouped64_window(int C, int groups);
 int mv_conv2d_nhwc_grouped64_fwd(const void* x, const void* w64, const float* scale, const float* shift, const void* residual,
                                  void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh,
                                  int dw, int groups, int act, int in_dtype, int out_dtype, mv_stream_t stream);

@@ -227,6 +227,31 @@ def mobilenet_v3_forward(sd, x, conf, bf16=False):
     return O.linear(x, q(sd["classifier.3.weight"]), sd["classifier.3.bias"])
 
 
+# ---------------------------------------------------------------- regnet.py:15-400
+def regnet_forward(sd, x, widths, depths, group_widths, se_ratio=0.25, bf16=False):
+    """stem 3x3/2 + BN + relu; per block relu(proj(x) + c(se(b(a(x))))) with a = 1x1, b = 3x3 grouped (stride 2 in a stage's first
+    block), se = squeeze-excitation (relu inside, sigmoid gate) for the Y variants, c = 1x1; global mean; fc."""
+    q = _Q(bf16)
+    x = _conv_bn(sd, q, q(x), "stem.0", "stem.1", stride=2, padding=1, relu=True)
+    for si, (w, d, gw) in enumerate(zip(widths, depths, group_widths)):
+        for b in range(d):
+            p = f"trunk_output.{si}.{b}"
+            stride = 2 if b == 0 else 1
+            sc = _conv_bn(sd, q, x, p + ".proj.0", p + ".proj.1", stride=stride) if (p + ".proj.0.weight") in sd else x
+            h = _conv_bn(sd, q, x, p + ".f.0.0", p + ".f.0.1", relu=True)
+            h = _conv_bn(sd, q, h, p + ".f.1.0", p + ".f.1.1", stride=stride, padding=1, groups=w // gw, relu=True)
+            j = 2
+            if se_ratio:
+                g = q(O.adaptive_avgpool2d(h, (1, 1)))
+                g = q(O.relu(O.conv2d(g, q(sd[p + ".f.2.fc1.weight"]), sd[p + ".f.2.fc1.bias"])))
+                g = q(O.sigmoid(O.conv2d(g, q(sd[p + ".f.2.fc2.weight"]), sd[p + ".f.2.fc2.bias"])))
+                h = q(h * g)
+                j = 3
+            x = _conv_bn(sd, q, h, f"{p}.f.{j}.0", f"{p}.f.{j}.1", relu=True, residual=sc)
+    x = np.ravel(O.adaptive_avgpool2d(x, (1, 1)))
+    return O.linear(x, q(sd["fc.weight"]), sd["fc.bias"])
+
+
 # ---------------------------------------------------------------- efficientnet.py:95-400
 def efficientnet_forward(sd, x, stages, eps=1e-5, bf16=False):
     """stem 3x3/2 + BN + SiLU; per stage row (fused, expand, kernel, stride, in, out, layers): MBConv = [1x1 expand,] k x k depthwise,

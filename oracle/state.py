@@ -305,6 +305,39 @@ def efficientnet_state(seed=1, stages=None, last=None, num_classes=1000):
     return sd
 
 
+def regnet_state(seed=1, widths=(48, 104, 208, 440), depths=(1, 3, 6, 6), group_widths=(8, 8, 8, 8), se_ratio=0.25, stem=32,
+                 num_classes=1000):
+    """torchvision regnet state_dict ORDER (names follow this package's Sequential indices): stem conv + bn; per block [proj conv + bn,]
+    a (1x1) conv + bn, b (3x3 grouped) conv + bn, [se fc1, fc2,] c (1x1) conv + bn; fc.  Bottleneck multiplier 1."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    _conv(sd, rng, "stem.0", 3, stem, 3, False)
+    _bn(sd, rng, "stem.1", stem)
+    win = stem
+    for si, (w, d, gw) in enumerate(zip(widths, depths, group_widths)):
+        for b in range(d):
+            p = f"trunk_output.{si}.{b}"
+            stride = 2 if b == 0 else 1
+            if win != w or stride != 1:
+                _conv(sd, rng, p + ".proj.0", win, w, 1, False)
+                _bn(sd, rng, p + ".proj.1", w)
+            _conv(sd, rng, p + ".f.0.0", win, w, 1, False)
+            _bn(sd, rng, p + ".f.0.1", w)
+            _conv(sd, rng, p + ".f.1.0", w, w, 3, False, groups=w // gw)
+            _bn(sd, rng, p + ".f.1.1", w)
+            j = 2
+            if se_ratio:
+                sq = int(round(se_ratio * win))
+                _conv(sd, rng, p + ".f.2.fc1", w, sq, 1, True)
+                _conv(sd, rng, p + ".f.2.fc2", sq, w, 1, True)
+                j = 3
+            _conv(sd, rng, f"{p}.f.{j}.0", w, w, 1, False)
+            _bn(sd, rng, f"{p}.f.{j}.1", w)
+            win = w
+    _linear(sd, rng, "fc", win, num_classes)
+    return sd
+
+
 def segmentation_state(seed=1, kind="fcn", layers=(3, 4, 6, 3), num_classes=21, aux=True):
     """torchvision fcn_resnet50 / deeplabv3_resnet50 state_dict order: backbone (ResNet without fc), classifier, aux_classifier."""
     rng = np.random.Generator(np.random.PCG64(seed + 100))

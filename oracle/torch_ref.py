@@ -232,6 +232,29 @@ def efficientnet_forward(sd, x, stages, eps=1e-5):
     return F.linear(x.mean((2, 3)), sd["classifier.1.weight"], sd["classifier.1.bias"])
 
 
+@torch.no_grad()
+def regnet_forward(sd, x, widths, depths, group_widths, se_ratio=0.25):
+    sd = _t(sd)
+    x = torch.as_tensor(x)
+    cb = lambda x, c, b, stride=1, pad=0, groups=1: _bn(sd, F.conv2d(x, sd[c + ".weight"], None, stride, pad, 1, groups), b)
+    x = F.relu(cb(x, "stem.0", "stem.1", 2, 1))
+    for si, (w, d, gw) in enumerate(zip(widths, depths, group_widths)):
+        for b in range(d):
+            p = f"trunk_output.{si}.{b}"
+            stride = 2 if b == 0 else 1
+            sc = cb(x, p + ".proj.0", p + ".proj.1", stride) if (p + ".proj.0.weight") in sd else x
+            h = F.relu(cb(x, p + ".f.0.0", p + ".f.0.1"))
+            h = F.relu(cb(h, p + ".f.1.0", p + ".f.1.1", stride, 1, w // gw))
+            j = 2
+            if se_ratio:
+                g = F.adaptive_avg_pool2d(h, 1)
+                g = F.relu(F.conv2d(g, sd[p + ".f.2.fc1.weight"], sd[p + ".f.2.fc1.bias"]))
+                h = h * torch.sigmoid(F.conv2d(g, sd[p + ".f.2.fc2.weight"], sd[p + ".f.2.fc2.bias"]))
+                j = 3
+            x = F.relu(sc + cb(h, f"{p}.f.{j}.0", f"{p}.f.{j}.1"))
+    return F.linear(x.mean((2, 3)), sd["fc.weight"], sd["fc.bias"])
+
+
 def _fcn_head_t(sd, x, p):
     y = F.relu(_bn(sd, F.conv2d(x, sd[p + ".0.weight"], None, 1, 1), p + ".1"))
     return F.conv2d(y, sd[p + ".4.weight"], sd[p + ".4.bias"])

@@ -438,9 +438,10 @@ def conv_grouped64_case(N, H, W, C, groups, R=3, stride=1, pad=1, dil=1, act=1, 
             ref = ref + r
         if act == 1:
             ref = np.maximum(ref, 0)
-        w64 = np.zeros((C, R, R, 64), np.float32)
+        win = int(L.load().mv_conv2d_grouped64_window(C, groups))
+        w64 = np.zeros((C, R, R, win), np.float32)
         for k in range(C):
-            g0 = (k // cg) * cg % 64
+            g0 = (k // cg) * cg - ((k // 64 * 64) // cg) * cg
             w64[k, :, :, g0:g0 + cg] = w[k].transpose(1, 2, 0)
         xd = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)), "bf16")
         wd, scd, sfd = dev(w64, "bf16"), dev(sc, "fp32"), dev(sf, "fp32")
@@ -1203,6 +1204,10 @@ def all_cases():
           ("grouped64/resnext101_256_g32_w8", conv_grouped64_case(2, 14, 14, 256, 32, seed=542)),
           ("grouped64/cg32_1024_res_noact", conv_grouped64_case(1, 7, 7, 1024, 32, act=0, res=True, seed=543)),
           ("grouped64/cg64_is_plain_grouping_dil2", conv_grouped64_case(2, 15, 15, 128, 2, pad=2, dil=2, seed=544)),
+          ("grouped64/regnet_104_gw8", conv_grouped64_case(2, 28, 28, 104, 13, seed=546)),
+          ("grouped64/regnet_208_gw24_s2", conv_grouped64_case(2, 28, 28, 216, 9, stride=2, seed=547)),
+          ("grouped64/regnet_gw56_448", conv_grouped64_case(2, 14, 14, 448, 8, seed=548)),
+          ("grouped64/regnet_gw264_528", conv_grouped64_case(1, 7, 7, 528, 2, seed=549)),
           ("grouped64/k1_cg16", conv_grouped64_case(2, 9, 9, 64, 4, R=1, pad=0, seed=545)),
           ("act/hard_swish", eltwise_act_case("hard_swish", 3, seed=570)),
           ("act/hard_sigmoid_f32", eltwise_act_case("hard_sigmoid", 4, dtype="fp32", seed=571)),

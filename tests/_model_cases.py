@@ -217,6 +217,31 @@ def efficientnet_case(arch, size, B, classes=10, dtype="bf16", full_ref="numpy",
     return run
 
 
+def regnet_case(name, size, B, classes=10, dtype="bf16", full_ref="numpy", custom=None):
+    """RegNet (reference regnet.py): grouped 3x3 convolutions through per-tile input windows, SE for the Y variants, shortcut + relu in
+    the last GEMM's epilogue.  `custom` = (widths, depths, group_widths, se_ratio) for a reduced net."""
+    def run():
+        import eqxvision_amd as eqv
+        from eqxvision_amd.models.classification import regnet as R
+        if custom is None:
+            bp = R.BlockParams.from_init_params(**R._CONFIGS[name])
+            fac = getattr(eqv.models, name)
+        else:
+            w, d, g, se = custom
+            bp = R.BlockParams(list(d), list(w), list(g), [1.0] * len(w), [2] * len(w), se)
+            fac = lambda torch_weights=None, **kw: R._regnet("custom", bp, torch_weights, **kw)
+        sd = S.regnet_state(1, bp.widths, bp.depths, bp.group_widths, bp.se_ratio, 32, classes)
+        x = S.synthetic_images(B, size, seed=0)
+        net = _load(fac, sd, num_classes=classes)
+        got = _run(net, x, dtype).cpu().numpy()
+        if full_ref == "torch":
+            ref = TR.regnet_forward(sd, x, bp.widths, bp.depths, bp.group_widths, bp.se_ratio).numpy()
+        else:
+            ref = np.stack([OM.regnet_forward(sd, im, bp.widths, bp.depths, bp.group_widths, bp.se_ratio) for im in x])
+        return _cmp(got, ref, 1e-2 if dtype == "bf16" else 1e-3)
+    return run
+
+
 def vgg_case(plan, batch_norm, size, B, classes=10, dtype="bf16", full_ref="numpy"):
     """VGG (reference models/classification/vgg.py) incl. its single-relu classifier; `plan` = a torchvision letter or a list."""
     def run():
@@ -614,6 +639,8 @@ def all_cases(full=True):
          ("model/efficientnet_reduced_mb_and_fused", efficientnet_case(None, 64, 3, stages=((0, 1, 3, 1, 16, 8, 1), (0, 6, 5, 2, 8, 16, 2),
                                                                                         (1, 4, 3, 2, 16, 24, 2), (1, 1, 3, 1, 24, 24, 1)))),
          ("model/efficientnet_reduced_fp32", efficientnet_case(None, 32, 2, dtype="fp32", stages=((0, 1, 3, 1, 16, 8, 1), (0, 6, 3, 2, 8, 16, 2)))),
+         ("model/regnet_reduced_y_gw8_24", regnet_case(None, 64, 3, custom=((48, 120), (1, 2), (8, 24), 0.25))),
+         ("model/regnet_reduced_x_fp32", regnet_case(None, 32, 2, dtype="fp32", custom=((32, 64), (1, 1), (16, 16), None))),
          ("model/vgg_small_bn_avgpool2x2", vgg_case((16, "M", 32, 32, "M"), True, 56, 3)),
          ("model/vgg_small_fp32", vgg_case((8, "M", 16, "M"), False, 28, 2, dtype="fp32")),
          ("model/vgg_small_c64_128", vgg_case((64, "M", 128, 128, "M"), False, 56, 2)),
@@ -653,6 +680,8 @@ def all_cases(full=True):
               ("model/lraspp_jit_replay_160px_numpy", lraspp_case(160, 2, classes=7, full_ref="numpy", jit=True)),
               ("model/efficientnet_b0_B4", efficientnet_case("b0", 224, 4, classes=1000, full_ref="torch")),
               ("model/efficientnet_v2_s_B2", efficientnet_case("v2_s", 224, 2, classes=1000, full_ref="torch")),
+              ("model/regnet_y_400mf_B4", regnet_case("regnet_y_400mf", 224, 4, classes=1000, full_ref="torch")),
+              ("model/regnet_x_3_2gf_B2_gw48", regnet_case("regnet_x_3_2gf", 224, 2, classes=1000, full_ref="torch")),
               ("model/vgg11_B2", vgg_case("A", False, 224, 2, classes=1000, full_ref="torch")),
               ("model/vgg16_bn_B1", vgg_case("D", True, 224, 1, classes=1000, full_ref="torch")),
               ("model/fcn_resnet50_B2", segmentation_case("fcn", (3, 4, 6, 3), 224, 2, classes=21, full_ref="torch")),

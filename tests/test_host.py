@@ -24,6 +24,8 @@ def _keys(sd):
     (lambda: eqv.models.vit_base(num_classes=1000), lambda: S.vit_state(1)),
     (lambda: eqv.models.vit_small(), lambda: S.vit_state(1, embed_dim=384, num_heads=6, num_classes=0)),
     (lambda: eqv.models.mobilenet_v2(), lambda: S.mobilenet_v2_state(1)),
+    (lambda: eqv.models.regnet_y_400mf(), lambda: S.regnet_state(1)),
+    (lambda: eqv.models.regnet_x_400mf(), lambda: S.regnet_state(1, (32, 64, 160, 400), (1, 2, 7, 12), (16,) * 4, None)),
     (lambda: eqv.models.efficientnet_b0(), lambda: S.efficientnet_state(1)),
     (lambda: eqv.models.efficientnet_v2_s(), lambda: S.efficientnet_state(1, *S.efficientnet_stages("v2_s")[:2])),
     (lambda: eqv.models.mobilenet_v3_large(), lambda: S.mobilenet_v3_state(1)),
@@ -252,6 +254,29 @@ def test_efficientnet_structure_and_errors():
         E._MBConv(E._MBConvConfig(1, 3, 3, 16, 16, 1), 0.0, nn.BatchNorm)
     with pytest.raises(RuntimeError, match="PRNGKey"):
         b0(np.zeros((3, 32, 32), np.float32), key=None)
+
+
+def test_regnet_block_params_and_structure():
+    """reference regnet.py:197-262: the quantised-linear width rule reproduces the published stage widths / depths (float32
+    arithmetic, like jnp / torch); blocks: projection only when the shape changes, SE width relative to the block input."""
+    from eqxvision_amd.models.classification import regnet as R
+    published = {"regnet_y_400mf": ([48, 104, 208, 440], [1, 3, 6, 6]), "regnet_x_400mf": ([32, 64, 160, 400], [1, 2, 7, 12]),
+                 "regnet_y_8gf": ([224, 448, 896, 2016], [2, 4, 10, 1]), "regnet_x_32gf": ([336, 672, 1344, 2520], [2, 7, 13, 1]),
+                 "regnet_y_800mf": ([64, 144, 320, 784], [1, 3, 8, 2]), "regnet_x_8gf": ([80, 240, 720, 1920], [2, 5, 15, 1])}
+    for name, (w, d) in published.items():
+        bp = R.BlockParams.from_init_params(**R._CONFIGS[name])
+        assert (bp.widths, bp.depths) == (w, d), name
+    assert R.BlockParams.from_init_params(**R._CONFIGS["regnet_x_8gf"]).group_widths == [80, 120, 120, 120]
+    with pytest.raises(ValueError, match="Invalid RegNet settings"):
+        R.BlockParams.from_init_params(depth=4, w_0=30, w_a=10.0, w_m=2.0, group_width=8)
+    net = eqv.models.regnet_y_400mf(num_classes=9)
+    first, second = net.trunk_output.layers[1].layers[:2]
+    assert type(first.proj).__name__ == "ConvNormActivation" and isinstance(second.proj, nn.Identity)
+    assert first.f.layers[1].layers[0].groups == 13 and first.f.layers[2].fc1.out_channels == 12        # round(0.25 * 48)
+    assert net.fc.in_features == 440 and net.fc.out_features == 9
+    assert abs(net.stem.layers[1].eps - 1e-5) < 1e-12
+    with pytest.raises(RuntimeError, match="PRNGKey"):
+        net(np.zeros((3, 32, 32), np.float32), key=None)
 
 
 def test_conv_norm_activation_structure():

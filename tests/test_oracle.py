@@ -196,6 +196,9 @@ def test_segmentation_and_vgg_restatements_agree_numpy_vs_torch():
     sd = S.efficientnet_state(1, st, 64, 10)
     np.testing.assert_allclose(np.stack([OM.efficientnet_forward(sd, im, st) for im in xs]),
                                TR.efficientnet_forward(sd, xs, st).numpy(), atol=1e-5)
+    sd = S.regnet_state(1, (48, 120), (1, 2), (8, 24), 0.25, 32, 10)
+    np.testing.assert_allclose(np.stack([OM.regnet_forward(sd, im, (48, 120), (1, 2), (8, 24), 0.25) for im in xs]),
+                               TR.regnet_forward(sd, xs, (48, 120), (1, 2), (8, 24), 0.25).numpy(), atol=1e-5)
     plan = (8, "M", 16, "M")
     for bn in (False, True):
         sd = S.vgg_state(1, plan, bn, 10)
