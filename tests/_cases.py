@@ -1102,6 +1102,53 @@ def fuzz_misc_cases(n, seed=0):
     return out
 
 
+def fuzz_family_cases(n, seed=0):
+    """Random shapes for the kernels added for the section-8 "next" rows: depthwise (all four fast paths + the general kernel),
+    grouped convolutions through input windows (group widths that divide 64 and multiples of 8 that do not), bilinear
+    up-sampling and the wide global average pool."""
+    rng = np.random.default_rng(seed)
+    out = []
+    i = 0
+    while len(out) < n:
+        i += 1
+        k = int(rng.integers(0, 4))
+        sd = 4000 + i
+        if k == 0:
+            C = int(rng.choice([8, 16, 24, 40, 72, 96, 120, 184, 240, 480, 672, 960]))
+            R = int(rng.choice([3, 3, 5, 7]))
+            dil = int(rng.choice([1, 1, 1, 2]))
+            stride = int(rng.choice([1, 2]))
+            H, W = int(rng.integers(5, 40)), int(rng.integers(5, 40))
+            pad = (R - 1) // 2 * dil
+            out.append((f"fuzzf/s{seed}_dw_C{C}_{H}x{W}_k{R}s{stride}d{dil}", dwconv_case(int(rng.integers(1, 4)), H, W, C, R=R, stride=stride,
+                                                                                        pad=pad, dil=dil, act=int(rng.choice([0, 1, 3])),
+                                                                                        scale=bool(rng.random() < 0.7), seed=sd)))
+        elif k == 1:
+            cg = int(rng.choice([1, 2, 4, 8, 16, 24, 32, 40, 48, 56, 64, 104, 120, 168]))
+            groups = int(rng.integers(2, 9)) if cg >= 24 else int(rng.choice([16, 32, 64])) if cg <= 4 else int(rng.integers(2, 17))
+            C = cg * groups
+            if C % 8 or C > 1400:
+                continue
+            H = int(rng.integers(5, 20))
+            R = int(rng.choice([1, 3]))
+            out.append((f"fuzzf/s{seed}_grouped_C{C}_g{groups}_k{R}_{H}", conv_grouped64_case(int(rng.integers(1, 3)), H, H, C, groups, R=R,
+                                                                                           stride=int(rng.choice([1, 2])), pad=R // 2,
+                                                                                           act=int(rng.choice([0, 1])),
+                                                                                           res=bool(rng.random() < 0.3), seed=sd)))
+        elif k == 2:
+            h, w = int(rng.integers(1, 20)), int(rng.integers(1, 20))
+            out.append((f"fuzzf/s{seed}_resize_{h}x{w}_{i}", resize_case(int(rng.integers(1, 4)), h, w, int(rng.choice([1, 3, 21, 40, 128])),
+                                                                        h * int(rng.integers(1, 9)) + int(rng.integers(0, 3)),
+                                                                        w * int(rng.integers(1, 9)) + int(rng.integers(0, 3)),
+                                                                        dtype=str(rng.choice(["bf16", "fp32"])), nchw=bool(rng.random() < 0.5),
+                                                                        seed=sd)))
+        else:
+            hw = int(rng.choice([16, 17, 28, 56, 112]))
+            out.append((f"fuzzf/s{seed}_avgpool_wide_{i}", avgpool_case(int(rng.integers(1, 5)), hw, hw, int(rng.choice([8, 16, 32, 96, 240, 672])),
+                                                                       1, 1, seed=sd)))
+    return out
+
+
 def all_cases():
     c = []
     # ---- implicit-GEMM conv (MFMA) : ResNet-50 shapes at reduced spatial size + edge cases
@@ -1361,4 +1408,5 @@ def all_cases():
           ("misc/affine_cls", misc_case("affine_cls"))]
     c += fuzz_cases(24, seed=3) + fuzz_cases(16, seed=4, mfma_only=True)      # default dispatch, random shapes
     c += fuzz_misc_cases(24, seed=5)
+    c += fuzz_family_cases(28, seed=6)
     return c
