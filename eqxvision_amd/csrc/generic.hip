@@ -708,7 +708,7 @@ extern "C" {
 int mv_conv2d_nhwc_fwd(const void* x, const void* w, const float* scale, const float* shift, const void* residual,
                        void* y, int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
                        int dh, int dw, int groups, int act, int in_dtype, int out_dtype, mv_stream_t stream) {
-    MV_CHECK_FUSED_ACT(act, "conv2d_nhwc");
+    MV_CHECK_ARG(act >= MV_ACT_NONE && act <= MV_ACT_SILU, "conv2d_nhwc: unknown activation %d", act);
     MV_CHECK_ARG(x && w && y, "conv2d_nhwc: NULL pointer");
     MV_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0, "conv2d_nhwc: non-positive dims");
     MV_CHECK_ARG(sh > 0 && sw > 0 && dh > 0 && dw > 0 && ph >= 0 && pw >= 0, "conv2d_nhwc: bad stride/dilation/pad");
@@ -720,7 +720,7 @@ int mv_conv2d_nhwc_fwd(const void* x, const void* w, const float* scale, const f
     hipStream_t st = (hipStream_t)stream;
     {   // pointwise layers whose reduction is not a multiple of 64 (Swin C = 96) still fit the streaming kernel
         const long long M = (long long)N * Ho * Wo;
-        const bool dense1x1 = R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && groups == 1;
+        const bool dense1x1 = R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && groups == 1 && act <= MV_ACT_GELU_TANH;
         if (!get_flag("force_generic") && !get_flag("no_stream") && !get_flag("igemm_tile") && dense1x1 && C % 64 != 0 &&
             stream1x1_supported(C, K, in_dtype, out_dtype, M))
             return stream1x1_launch(x, w, scale, shift, residual, y, M, C, K, act, out_dtype, st);

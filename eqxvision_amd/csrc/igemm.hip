@@ -270,6 +270,9 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
                 } else if (p.act == MV_ACT_GELU_TANH) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                } else if (p.act != MV_ACT_NONE) {                // hard_swish / hard_sigmoid / sigmoid / silu: this kernel only
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = apply_act_rt(v[e], p.act);
                 }
                 Out8<OutT>::st(y + o, v);
             }
@@ -349,6 +352,16 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
     p.act = act;
     const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
     const bool out_f32 = out_dtype == MV_F32;
+    if (act > MV_ACT_GELU_TANH) {
+        // jax.nn.hard_swish / hard_sigmoid / sigmoid / silu (MobileNetV3, EfficientNet): only this file's epilogue implements them;
+        // fused here they save the element-wise pass over the layer's output that a faster main loop would not buy back
+        if (K <= 64) {
+            set_kernel_name(dense ? "igemm_bf16_128x64_dense_act" : "igemm_bf16_128x64_conv_act");
+            return launch_tile<128, 64, 4, 1>(p, dense, out_f32, st);
+        }
+        set_kernel_name(dense ? "igemm_bf16_128x128_dense_act" : "igemm_bf16_128x128_conv_act");
+        return launch_tile<128, 128, 4, 1>(p, dense, out_f32, st);
+    }
     const bool forced_old = get_flag("igemm_tile") || get_flag("igemm2_tile") || get_flag("no_igemm2") || get_flag("igemm2_dense_m");
     if (dense && !get_flag("no_skinny") && !forced_old && get_flag("igemm8") < 2 &&
         skinny_supported(M, C, K, in_dtype, residual))                   // classifier heads: one wave per 32 x 32 tile

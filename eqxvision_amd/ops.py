@@ -232,9 +232,11 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
     """Conv2d [+ BatchNorm(inference)] [+ residual] [+ relu/gelu], one launch."""
     _check_bn(bn)
     dt = compute_dtype()
-    if act in UNFUSED_ACTS and not (dt == "bf16" and conv.groups > 1 and conv.groups == conv.in_channels == conv.out_channels
-                                    and residual is None and x.kind != "img"):
-        return eltwise(conv2d(x, conv, bn, None, residual), act)       # hard_swish & co. are not in the GEMM epilogues
+    if act in UNFUSED_ACTS and (dt != "bf16" or x.kind == "img" or conv.out_channels % 8 or
+                                (conv.groups > 1 and not conv.groups == conv.in_channels == conv.out_channels)):
+        # hard_swish & co. are fused by the NHWC bf16 convolution (dense: one GEMM kernel has them; depthwise: in the kernel); the
+        # image-entry kernel, the grouped / padded-width paths and fp32 mode take an element-wise pass instead
+        return eltwise(conv2d(x, conv, bn, None, residual), act)
     kh, kw = conv.kernel_size
     sh, sw = conv.stride
     ph, pw = conv.padding

@@ -86,6 +86,8 @@ def conv_nhwc_case(N, H, W, C, K, R, S, stride=1, pad=0, dil=1, groups=1, act=0,
             ref = O.relu(ref)
         elif act == 2:
             ref = O.gelu_tanh(ref)
+        elif act >= 3:
+            ref = {3: O.hard_swish, 4: O.hard_sigmoid, 5: O.sigmoid, 6: O.silu}[act](ref)
         xd = dev(x.transpose(0, 2, 3, 1), dtype)
         wd = dev(w.transpose(0, 2, 3, 1), dtype)
         scd = None if sc is None else dev(sc, "fp32")
@@ -1260,6 +1262,11 @@ def all_cases():
           ("act/hard_sigmoid_f32", eltwise_act_case("hard_sigmoid", 4, dtype="fp32", seed=571)),
           ("act/sigmoid_f32", eltwise_act_case("sigmoid", 5, dtype="fp32", seed=572)),
           ("act/silu", eltwise_act_case("silu", 6, seed=573)),
+          ("act/conv_fused_silu_pw_96_576", conv_nhwc_case(4, 28, 28, 96, 576, 1, 1, act=6, seed=576)),
+          ("act/conv_fused_hard_swish_pw_640_128", conv_nhwc_case(2, 14, 14, 640, 128, 1, 1, act=3, seed=577)),
+          ("act/conv_fused_silu_3x3_s2_64_48", conv_nhwc_case(2, 30, 30, 64, 48, 3, 3, stride=2, pad=1, act=6, seed=578)),
+          ("act/conv_fused_sigmoid_k64_res", conv_nhwc_case(2, 9, 9, 128, 64, 1, 1, act=5, res=True, seed=579)),
+          ("act/conv_generic_hard_sigmoid_f32", conv_nhwc_case(1, 7, 7, 12, 20, 1, 1, act=4, dtype="fp32", seed=580)),
           ("act/not_fused_into_gemm_entries", fused_act_refused_case()),
           ("act/se_channel_scale", channel_scale_case(3, 14 * 14, 120, seed=574)),
           ("act/se_channel_scale_f32", channel_scale_case(2, 49, 24, dtype="fp32", seed=575)),
