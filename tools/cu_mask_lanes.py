@@ -86,10 +86,25 @@ t, allt = timed(eager(plain))
 print(f"  eager, {NL} plain streams        : {t:.3f} ms/step {B/t*1e3:.0f} img/s  {['%.3f' % x for x in allt]}", flush=True)
 check("plain")
 masked = [masked_stream(m) for m in lane_masks(NL)]
-for off in (0, 3, 7, 15, 40):
+for off in (0,):
     t, allt = timed(eager(masked, off))
     print(f"  eager, {NL} CU-masked streams off={off:2d}: {t:.3f} ms/step {B/t*1e3:.0f} img/s  {['%.3f' % x for x in allt]}", flush=True)
 check("masked")
+# different stream priorities for the two lanes: lane 0's kernels get the CUs first, lane 1 fills what is left
+hip.hipStreamCreateWithPriority.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint, ctypes.c_int]
+lo_p, hi_p = ctypes.c_int(), ctypes.c_int()
+hip.hipDeviceGetStreamPriorityRange(ctypes.byref(lo_p), ctypes.byref(hi_p))
+def prio_stream(pr):
+    s = ctypes.c_void_p()
+    rc = hip.hipStreamCreateWithPriority(ctypes.byref(s), 1, pr)
+    assert rc == 0, rc
+    return s.value
+pst = [prio_stream(hi_p.value if l == 0 else lo_p.value) for l in range(NL)]
+t, allt = timed(eager(pst))
+print(f"  eager, priorities {hi_p.value} / {lo_p.value}            : {t:.3f} ms/step {B/t*1e3:.0f} img/s  {['%.3f' % x for x in allt]}", flush=True)
+check("priorities")
+t, allt = timed(eager(plain))
+print(f"  eager, {NL} plain streams (again) : {t:.3f} ms/step {B/t*1e3:.0f} img/s  {['%.3f' % x for x in allt]}", flush=True)
 # host-side issue rate, for reference
 t0 = time.perf_counter(); eager(plain)(3); t1 = time.perf_counter()
 print(f"  (host issue time per step, queue not full: {(t1-t0)/3*1e3:.2f} ms)")
