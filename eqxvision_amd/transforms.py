@@ -208,33 +208,51 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
                     o = fn(*la, **lk)
             finally:
                 _lib.set_recording(old)
-            if not (isinstance(o, torch.Tensor) and o.is_cuda and o.shape[0] == step and o.is_contiguous()):
-                return                               # only single batched tensor outputs are laned; fall back
+            leaves = list(o) if isinstance(o, (tuple, list)) else [o]
+            if not leaves or not all(t is None or (isinstance(t, torch.Tensor) and t.is_cuda and t.shape[0] == step and t.is_contiguous())
+                                     for t in leaves) or all(t is None for t in leaves):
+                return                               # only batched tensors (or tuples of them / None) are laned; fall back
             lane_calls.append(calls)
             outs.append(o)
-        full = torch.empty((B,) + tuple(outs[0].shape[1:]), dtype=outs[0].dtype, device=outs[0].device)
+        structured = isinstance(outs[0], (tuple, list))
+        if structured and any(type(o) is not type(outs[0]) or len(o) != len(outs[0]) or
+                              [t is None for t in o] != [t is None for t in outs[0]] for o in outs):
+            return
         c.keep.append(outs)
-        for l, o in enumerate(outs):
-            dst = full[l * step:(l + 1) * step]
-            # The lane's result is normally the output buffer of its LAST launch (the classifier head): point that
-            # launch at the lane's rows of the full result instead of copying them there afterwards.
-            cfn, cargs, cname = lane_calls[l][-1] if lane_calls[l] else (None, (), "")
-            hits = [i for i, a in enumerate(cargs) if isinstance(a, int) and a == o.data_ptr()]
-            earlier = any(isinstance(a, int) and a == o.data_ptr() for _, args_, _ in lane_calls[l][:-1] for a in args_)
-            if len(hits) == 1 and not earlier and o.data_ptr() != 0:
-                patched = list(cargs)
-                patched[hits[0]] = dst.data_ptr()
-                lane_calls[l][-1] = (cfn, tuple(patched), cname)
-                rc = cfn(*patched)                       # the trace ran eagerly: produce this call's rows in `full` too
-                if rc != 0:
-                    raise _lib.MVError(f"lane output redirect of {cname} failed (rc={rc})")
-                continue
-            dt = _lib.F32 if o.dtype == torch.float32 else _lib.BF16     # otherwise: the library's copy kernel
-            old = _lib.set_recording(lane_calls[l])
-            try:
-                _lib.call("mv_cast", o.data_ptr(), dst.data_ptr(), o.numel(), dt, dt, stream_ptr())
-            finally:
-                _lib.set_recording(old)
+
+        def gather(lane_leaves, allow_redirect):
+            """one full-batch tensor for one output leaf: lane l's rows land in rows l*step .. (l+1)*step"""
+            first = lane_leaves[0]
+            full = torch.empty((B,) + tuple(first.shape[1:]), dtype=first.dtype, device=first.device)
+            for l, o in enumerate(lane_leaves):
+                dst = full[l * step:(l + 1) * step]
+                # The lane's result is normally the output buffer of exactly ONE launch (the classifier head; the final resize of a
+                # segmentation output) and nobody reads it afterwards: point that launch at the lane's rows of the full result
+                # instead of copying them there.
+                where = [(ci, i) for ci, (_, cargs, _) in enumerate(lane_calls[l]) for i, a in enumerate(cargs)
+                         if isinstance(a, int) and a == o.data_ptr()]
+                if allow_redirect and len(where) == 1 and o.data_ptr() != 0:
+                    ci, ai = where[0]
+                    cfn, cargs, cname = lane_calls[l][ci]
+                    patched = list(cargs)
+                    patched[ai] = dst.data_ptr()
+                    lane_calls[l][ci] = (cfn, tuple(patched), cname)
+                    rc = cfn(*patched)                       # the trace ran eagerly: produce this call's rows in `full` too
+                    if rc != 0:
+                        raise _lib.MVError(f"lane output redirect of {cname} failed (rc={rc})")
+                    continue
+                dt = _lib.F32 if o.dtype == torch.float32 else _lib.BF16     # otherwise: the library's copy kernel
+                old = _lib.set_recording(lane_calls[l])
+                try:
+                    _lib.call("mv_cast", o.data_ptr(), dst.data_ptr(), o.numel(), dt, dt, stream_ptr())
+                finally:
+                    _lib.set_recording(old)
+            return full
+
+        if structured:                                   # e.g. the (aux, out) pair of the segmentation models
+            full = type(outs[0])(None if outs[0][i] is None else gather([o[i] for o in outs], True) for i in range(len(outs[0])))
+        else:
+            full = gather(outs, True)
         c.lane_calls = lane_calls
         c.calls = [x for lc in lane_calls for x in lc]
         c.out = full

@@ -265,7 +265,7 @@ def vgg_case(plan, batch_norm, size, B, classes=10, dtype="bf16", full_ref="nump
     return run
 
 
-def segmentation_case(kind, layers, size, B, classes=5, dtype="bf16", aux=True, full_ref="numpy", jit=False):
+def segmentation_case(kind, layers, size, B, classes=5, dtype="bf16", aux=True, full_ref="numpy", jit=False, lanes=1):
     """fcn / deeplabv3 on the dilated ResNet (reference tests/test_models/test_fcn.py:16-28, test_deeplabv3.py): (aux, out) at the
     input resolution vs the oracle on the same synthetic checkpoint."""
     def run():
@@ -280,13 +280,16 @@ def segmentation_case(kind, layers, size, B, classes=5, dtype="bf16", aux=True, 
                                                      aux_in_channels=1024 if aux else None, torch_weights=torch_weights)
         net = _load(fac, sd)
         if jit:
-            fwd, got = _run(net, x, dtype, jit=True)
             with eqv.precision(dtype):
-                for _ in range(3):
-                    got = fwd(net, x, _keys(B))          # trace, capture, replay
+                fwd = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k), lanes=lanes)
+                for _ in range(4):
+                    got = fwd(net, x, _keys(B))          # trace, capture, replays
             torch.cuda.synchronize()
+            entry = fwd._entries()[0]
+            lane_note = len(entry.lane_calls) if entry.lane_calls else 1
         else:
             got = _run(net, x, dtype)
+            lane_note = 1
         g_aux, g_out = got
         if full_ref == "torch":
             r_aux, r_out = TR.segmentation_forward(sd, x, kind, layers, aux)
@@ -305,7 +308,8 @@ def segmentation_case(kind, layers, size, B, classes=5, dtype="bf16", aux=True, 
             info["ok"] = info["ok"] and ia["ok"]
         else:
             info["ok"] = info["ok"] and g_aux is None
-        info["ok"] = info["ok"] and info["shape_ok"]
+        info["ok"] = info["ok"] and info["shape_ok"] and lane_note == lanes
+        info["lanes"] = lane_note
         return info
     return run
 
@@ -648,6 +652,8 @@ def all_cases(full=True):
          ("model/fcn_tiny_no_aux_fp32", segmentation_case("fcn", (1, 1, 1, 1), 64, 1, dtype="fp32", aux=False)),
          ("model/deeplabv3_tiny_backbone", segmentation_case("deeplabv3", (1, 1, 1, 1), 64, 2)),
          ("model/deeplabv3_tiny_jit_replay", segmentation_case("deeplabv3", (1, 1, 1, 1), 96, 3, jit=True)),
+         ("model/deeplabv3_tiny_jit_lanes2_tuple_outputs", segmentation_case("deeplabv3", (1, 1, 1, 1), 96, 4, jit=True, lanes=2)),
+         ("model/fcn_tiny_jit_lanes2_no_aux", segmentation_case("fcn", (1, 1, 1, 1), 64, 6, aux=False, jit=True, lanes=2)),
          ("model/swin_tiny", swin_case(56, 32, (2, 2), (2, 4), 2)),
          ("model/swin_tiny_fp32", swin_case(56, 32, (2, 2), (2, 4), 1, dtype="fp32")),
          ("model/conv_norm_act_reference_3_4_5x5", conv_norm_act_case(3, 4, 5, 1)),

@@ -14,7 +14,8 @@ net = build(intermediate_layers=lambda m: [m.layer3, m.layer4], aux_in_channels=
 net = eqv.tree_inference(eqv.utils.randomize_batchnorm(net, 1), True)
 x = torch.rand((B, 3, size, size), dtype=torch.float32).cuda()
 keys = eqv.random.split(eqv.random.PRNGKey(0), B)
-f = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k), use_graph=True, clone_outputs=False)
+LANES = int(os.environ.get("LANES", "2"))
+f = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k), use_graph=True, clone_outputs=False, lanes=LANES)
 for _ in range(4):
     aux, out = f(net, x, keys)
 torch.cuda.synchronize()
@@ -24,7 +25,7 @@ for _ in range(20):
     f(net, x, keys)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
-print(f"{kind}_resnet50 B={B} {size}px: {ms:.3f} ms/step  {B / ms * 1e3:.0f} img/s  out {tuple(out.shape)} aux {tuple(aux.shape)}")
+print(f"{kind}_resnet50 B={B} {size}px lanes={LANES}: {ms:.3f} ms/step  {B / ms * 1e3:.0f} img/s  out {tuple(out.shape)} aux {tuple(aux.shape)}")
 rows = layer_table(f._entries()[0], f"gpurun_out/{kind}_layers.txt")
 rows.sort(key=lambda r: -r["us"])
 for r in rows[:12]:
