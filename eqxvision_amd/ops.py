@@ -836,8 +836,10 @@ def channel_scale(x: Act, s: Act) -> Act:
     if st.dtype != x.t.dtype:
         s = cast(Act(st, "vec", s.batched), "bf16" if x.t.dtype == torch.bfloat16 else "fp32")
         st = s.t
+    if not st.is_contiguous():          # a temporary copy would not be pinned for the recorded launch list
+        raise ValueError("channel_scale: the scale must be a contiguous [B, C] tensor")
     y = empty(tuple(x.t.shape), x.t.dtype)
-    _lib.call("mv_channel_scale_nhwc_fwd", _ptr(x.t), _ptr(st.contiguous()), _ptr(y), B, H * W, C, x.dt, stream_ptr())
+    _lib.call("mv_channel_scale_nhwc_fwd", _ptr(x.t), _ptr(st), _ptr(y), B, H * W, C, x.dt, stream_ptr())
     return Act(y, "map", x.batched)
 
 
