@@ -259,9 +259,17 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
         raise ValueError(f"Conv2d expected {Cin} input channels, got {C}")
     if x.t.dtype != TORCH_DT[dt]:
         raise ValueError(f"activation dtype {x.t.dtype} does not match compute dtype {dt}")
-    w, scale, shift = prep_conv(conv, bn, "krsc", dt)
     Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
     Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+
+    def res_ptr():
+        if residual is None:
+            return None
+        r = as_map(residual)
+        if tuple(r.t.shape) != (B, Ho, Wo, K):
+            raise ValueError(f"residual shape {tuple(r.t.shape)} != conv output {(B, Ho, Wo, K)}")
+        return _ptr(r.t)
+
     if conv.groups > 1 and dt == "bf16" and residual is None and \
             _lib.load().mv_dwconv2d_supported(C, K, conv.groups, kh, kw, _lib.BF16, _lib.BF16):
         cache = conv._cache()
@@ -278,27 +286,16 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
     if conv.groups > 1 and dt == "bf16" and _lib.load().mv_conv2d_grouped64_supported(C, K, kh, kw, conv.groups, _lib.BF16, _lib.BF16):
         w64, scale, shift = prep_conv_grouped64(conv, bn)
         y = empty((B, Ho, Wo, K), torch.bfloat16)
-        res = None
-        if residual is not None:
-            residual = as_map(residual)
-            if tuple(residual.t.shape) != (B, Ho, Wo, K):
-                raise ValueError(f"residual shape {tuple(residual.t.shape)} != conv output {(B, Ho, Wo, K)}")
-            res = residual.t
-        _lib.call("mv_conv2d_nhwc_grouped64_fwd", _ptr(x.t), _ptr(w64), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y),
+        _lib.call("mv_conv2d_nhwc_grouped64_fwd", _ptr(x.t), _ptr(w64), _ptr(scale), _ptr(shift), res_ptr(), _ptr(y),
                   B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, conv.groups, ACT[act], _lib.BF16, _lib.BF16, stream_ptr())
         return Act(y, "map", x.batched)
+    w, scale, shift = prep_conv(conv, bn, "krsc", dt)
     if K % 8 and dt == "bf16" and conv.groups == 1 and residual is None and C % 8 == 0:
         # an output width the MFMA kernels cannot store in 16-byte pieces (21-class segmentation heads, fcn.py:33): run the
         # convolution on zero-padded filters and compact the rows afterwards instead of dropping to the VALU kernel
         return _conv2d_padded_k(x, conv, bn, act, (w, scale, shift), (B, H, W, C, Ho, Wo))
     y = empty((B, Ho, Wo, K), TORCH_DT[dt])
-    res = None
-    if residual is not None:
-        residual = as_map(residual)
-        if tuple(residual.t.shape) != (B, Ho, Wo, K):
-            raise ValueError(f"residual shape {tuple(residual.t.shape)} != conv output {(B, Ho, Wo, K)}")
-        res = residual.t
-    _lib.call("mv_conv2d_nhwc_fwd", _ptr(x.t), _ptr(w), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y),
+    _lib.call("mv_conv2d_nhwc_fwd", _ptr(x.t), _ptr(w), _ptr(scale), _ptr(shift), res_ptr(), _ptr(y),
               B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, conv.groups, ACT[act], DT[dt], DT[dt], stream_ptr())
     return Act(y, "map", x.batched)
 
