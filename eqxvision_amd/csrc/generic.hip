@@ -788,7 +788,8 @@ int mv_stem_conv_pool_fwd(const void* x, const void* w, const float* scale, cons
 }
 
 int mv_conv1x1_chain_supported(int64_t M, int C, int K, int N2, int dtype) {
-    return !get_flag("force_generic") && !get_flag("no_stream") && chain1x1_supported(M, C, K, N2, dtype);
+    return !get_flag("force_generic") && !get_flag("no_stream") &&
+           (chain1x1_supported(M, C, K, N2, dtype) || chain_stream_supported(M, C, K, N2, dtype));
 }
 
 int mv_conv1x1_chain_fwd(const void* x, const void* w3, const float* scale3, const float* shift3, const void* residual,
@@ -800,6 +801,9 @@ int mv_conv1x1_chain_fwd(const void* x, const void* w3, const float* scale3, con
                   (long long)M, C, K, N2);
         return MV_E_UNSUPPORTED;
     }
+    MV_CHECK_ARG(y != residual && y != x && t1 != y, "conv1x1_chain: y must not alias x / residual / t1");
+    if (chain_stream_supported(M, C, K, N2, dtype))        // weights streamed through LDS (layer2's 128 -> 512 -> 128)
+        return chain_stream_launch(x, w3, scale3, shift3, residual, y, w1, scale1, shift1, t1, M, (hipStream_t)stream);
     return chain1x1_launch(x, w3, scale3, shift3, residual, y, w1, scale1, shift1, t1, M, N2, (hipStream_t)stream);
 }
 

@@ -43,7 +43,7 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  * "igemm8" (2 / 3 / 4 = force the ping-pong GEMM with 256x256 / 128x256 / 256x128 tiles), "no_igemm8",
  * "igemm2_tile" (1 / 2 / 3 = force igemm2 with 256x64 / 256x128 / 256x256 tiles), "no_igemm2", "igemm2_dense_m",
  * "igemm_tile" (1 / 2 = force the 128x128 / 128x64 kernel), "res_early", "no_stream" (no streaming 1x1 / 3x3c64 kernels),
- * "stream_npass1", "stem_v0", "no_stem_pool", "no_dual", "no_chain", "no_dual_chain", "no_grouped64", "no_dwconv", "dwconv_generic" (one output pixel per thread for every depthwise shape), "no_oddc" (channel counts that are not multiples of 64 back on the scalar kernel), "no_ln_mlp", "ln_mlp_waves" (8 / 12 / 16), "no_ln_stream", "ln_stream_192", "no_skinny", "no_tuned", and the
+ * "stream_npass1", "stem_v0", "no_stem_pool", "no_dual", "no_chain", "no_chain_stream" (only the streamed-weights variant off), "no_dual_chain", "no_grouped64", "no_dwconv", "dwconv_generic" (one output pixel per thread for every depthwise shape), "no_oddc" (channel counts that are not multiples of 64 back on the scalar kernel), "no_ln_mlp", "ln_mlp_waves" (8 / 12 / 16), "no_ln_stream", "ln_stream_192", "no_skinny", "no_tuned", and the
  * per-shape kernel choice "ov:<M>:<C>:<K>:<R>:<S>:<stride>" / "ovh:<M>:<N>:<K>:1:1:1" / "ovd:<M>:<C1>:<C2>:<K>:<stride>:1"
  * (tools/tune_tiles.py; codes in csrc/igemm.hip). */
 
@@ -97,8 +97,9 @@ int mv_stem_conv_pool_fwd(const void* x, const void* w, const float* scale, cons
  *   y [M,K]  = relu(scale3[k] * (x[M,C] . w3[K,C]^T) + shift3[k] + residual[M,K])
  *   t1[M,N2] = relu(scale1[n] * (y[M,K] . w1[N2,K]^T) + shift1[n])
  * All operands bf16, NHWC rows; y is rounded to bf16 before the second product, exactly as the un-fused pair
- * (two mv_conv2d_nhwc_fwd calls) would see it.  mv_conv1x1_chain_supported() says whether the shape has the path
- * (C=64, K=256, N2=64 or 128, M >= 8192). */
+ * (two mv_conv2d_nhwc_fwd calls) would see it.  mv_conv1x1_chain_supported() says whether the shape has the path:
+ * C=64, K=256, N2=64 or 128, M >= 8192 (both weight matrices resident in LDS), or C=128, K=512, N2=128, M >= 16384
+ * (ResNet-50 layer2: the weights streamed through LDS in 32-channel chunks of y).  y must not alias x, residual or t1. */
 int mv_conv1x1_chain_supported(int64_t M, int C, int K, int N2, int dtype);
 int mv_conv1x1_chain_fwd(const void* x, const void* w3, const float* scale3, const float* shift3,
                          const void* residual, void* y, const void* w1, const float* scale1,

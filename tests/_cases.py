@@ -116,13 +116,12 @@ def conv_nhwc_case(N, H, W, C, K, R, S, stride=1, pad=0, dil=1, groups=1, act=0,
     return run
 
 
-def chain_case(M, seed=0, N2=64):
+def chain_case(M, seed=0, N2=64, C=64, K=256):
     """mv_conv1x1_chain_fwd (bottleneck tail + next bottleneck head in one launch, resnet.py:144-162) vs the oracle,
     and bit-for-bit vs the library's own un-fused pair of 1x1 convolutions."""
     def run():
         L = _lib()
         rng = _rng(seed)
-        C, K = 64, 256
         x = bf(rng.standard_normal((M, C)))
         w3 = bf(rng.standard_normal((K, C)) / np.sqrt(C))
         s3 = rng.uniform(0.5, 1.5, K).astype(np.float32)
@@ -1300,6 +1299,9 @@ def all_cases():
           ("chain/dual_ragged_many", dual_chain_case(29 * 56 * 56 + 13, seed=7)),
           ("chain/n128_56x56_B4", chain_case(4 * 56 * 56, seed=4, N2=128)),
           ("chain/n128_ragged_many", chain_case(33 * 56 * 56 + 21, seed=5, N2=128)),
+          ("chain/stream_28x28_B32", chain_case(32 * 28 * 28, seed=8, N2=128, C=128, K=512)),
+          ("chain/stream_ragged", chain_case(16384 + 37, seed=9, N2=128, C=128, K=512)),
+          ("chain/stream_many_rounds", chain_case(150 * 28 * 28 + 5, seed=10, N2=128, C=128, K=512)),
           ("igemm/old_kernel_3x3_128_28", conv_nhwc_case(8, 28, 28, 128, 128, 3, 3, pad=1, act=1, seed=11, flags=("no_igemm2",))),
           ("igemm/old_kernel_1x1_64_256", conv_nhwc_case(4, 56, 56, 64, 256, 1, 1, act=1, res=True, flags=("no_stream",))),
           ("stream/64_256_res", conv_nhwc_case(4, 56, 56, 64, 256, 1, 1, act=1, res=True)),
