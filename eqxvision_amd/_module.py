@@ -21,10 +21,20 @@ class StateIndex:
     """Stand-in for `eqx.experimental.StateIndex`: a mutable slot holding BatchNorm running
     statistics outside the parameter leaves (reference utils.py:203-218)."""
 
-    __slots__ = ("value",)
+    __slots__ = ("_value", "version")
 
     def __init__(self, value=None):
-        self.value = value
+        self._value = value
+        self.version = 0            # bumped by every assignment: weights prepared with the old statistics folded in are stale
+
+    @property
+    def value(self):
+        return self._value
+
+    @value.setter
+    def value(self, v):
+        self._value = v
+        self.version += 1
 
     def __repr__(self):
         return f"StateIndex({'set' if self.value is not None else 'unset'})"
@@ -112,7 +122,7 @@ def _rebuild(n: "Module", rec: Callable, override: Callable = None) -> "Module":
             v = d[k]
             object.__setattr__(new, k, override(k, v) if override is not None else rec(v))
     for k, v in d.items():
-        if k not in n.__fields__ and k not in ("_dev_cache", "_sig_cache"):
+        if k not in n.__fields__ and k not in ("_dev_cache", "_sig_cache", "_eager_cache"):
             object.__setattr__(new, k, v)
     return new
 

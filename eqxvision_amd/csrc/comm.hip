@@ -20,6 +20,7 @@ typedef void* nccl_comm_t;
 typedef int (*fn_get_uid)(nccl_uid_t*);
 typedef int (*fn_init_rank)(nccl_comm_t*, int, nccl_uid_t, int);
 typedef int (*fn_allgather)(const void*, void*, size_t, int /*ncclDataType_t*/, nccl_comm_t, hipStream_t);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, nccl_comm_t, hipStream_t);
 typedef int (*fn_destroy)(nccl_comm_t);
 typedef const char* (*fn_errstr)(int);
 
@@ -28,6 +29,7 @@ struct Rccl {
     fn_get_uid get_uid = nullptr;
     fn_init_rank init_rank = nullptr;
     fn_allgather allgather = nullptr;
+    fn_allreduce allreduce = nullptr;
     fn_destroy destroy = nullptr;
     fn_errstr errstr = nullptr;
 };
@@ -54,6 +56,7 @@ int load_rccl() {
     r.get_uid = (fn_get_uid)dlsym(h, "ncclGetUniqueId");
     r.init_rank = (fn_init_rank)dlsym(h, "ncclCommInitRank");
     r.allgather = (fn_allgather)dlsym(h, "ncclAllGather");
+    r.allreduce = (fn_allreduce)dlsym(h, "ncclAllReduce");
     r.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
     r.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
     if (!r.get_uid || !r.init_rank || !r.allgather || !r.destroy) {
@@ -118,6 +121,24 @@ int mv_allgather(const void* send, void* recv, size_t bytes_per_rank, mv_stream_
     if (bytes_per_rank == 0) return MV_OK;
     const int n = mv::g_rccl.allgather(send, recv, bytes_per_rank, /*ncclInt8*/ 0, mv::g_comm, (hipStream_t)stream);
     if (n != 0) return mv::nccl_fail("ncclAllGather", n);
+    return MV_OK;
+}
+
+// In-place sum over ranks of `count` fp32 values: BatchNorm's training-mode `pmean` of the per-channel batch moments
+// (2 x C floats per layer: latency-bound, a direct exchange over xGMI).
+int mv_allreduce_sum_f32(void* buf, size_t count, mv_stream_t stream) {
+    MV_CHECK_ARG(buf, "mv_allreduce_sum_f32: NULL buffer");
+    if (!mv::g_comm) {
+        mv::set_error("mv_allreduce_sum_f32: no communicator (mv_comm_init first)");
+        return MV_E_INVALID;
+    }
+    if (!mv::g_rccl.allreduce) {
+        mv::set_error("mv_allreduce_sum_f32: librccl lacks ncclAllReduce");
+        return MV_E_UNSUPPORTED;
+    }
+    if (count == 0) return MV_OK;
+    const int n = mv::g_rccl.allreduce(buf, buf, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, mv::g_comm, (hipStream_t)stream);
+    if (n != 0) return mv::nccl_fail("ncclAllReduce", n);
     return MV_OK;
 }
 

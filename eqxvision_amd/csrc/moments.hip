@@ -1,0 +1,93 @@
+// Per-channel batch moments of an NHWC map / row matrix: the statistics half of eqx.experimental.BatchNorm's TRAINING branch
+// (called from resnet.py:132-136, 252, 301 when the model is not in inference mode):
+//   batch_mean[c] = pmean(mean(x[c]));  batch_var[c] = pmean(mean((x[c] - batch_mean[c])^2))      (two passes, like the reference)
+// One launch produces out[c] = sum_rows (x[r][c] - shift[c])^p, p = 1 (shift = NULL) or 2; the caller divides by the global row
+// count after the cross-rank sum (mv_allreduce_sum_f32).  HBM-bound: rows * C * sizeof(T) bytes read once per pass.
+// Deterministic: block b reduces rows b, b + G, ... into partial[b][C] (fixed order), a second kernel adds the G partials in order.
+#include "mfma_common.h"
+
+namespace mv {
+
+constexpr int MOM_BLOCKS = 512;
+
+template <typename T>
+__global__ __launch_bounds__(256) void moments_partial_kernel(const T* x, const float* shift, float* partial, long long rows, int C,
+                                                              int sq) {
+    extern __shared__ float red[];                          // [RS][C]
+    const int V = C >> 3;                                   // 8-channel vectors per row
+    const int RS = 256 / V;                                 // rows a block covers per step
+    const int rs = threadIdx.x / V, v = threadIdx.x - rs * V;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (rs < RS) {
+        float sh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (shift) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sh[e] = shift[v * 8 + e];
+        }
+        for (long long r = (long long)blockIdx.x * RS + rs; r < rows; r += (long long)gridDim.x * RS) {
+            const T* p = x + r * C + v * 8;
+            const float4 a = Out4<T>::ld(p), b = Out4<T>::ld(p + 4);
+            const float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = xv[e] - sh[e];
+                acc[e] += sq ? d * d : d;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rs * C + v * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int j = 0; j < RS; ++j) s += red[j * C + c];
+        partial[(long long)blockIdx.x * C + c] = s;
+    }
+}
+
+__global__ void moments_final_kernel(const float* partial, float* out, int G, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += partial[(long long)g * C + c];
+    out[c] = s;
+}
+
+}  // namespace mv
+
+using namespace mv;
+
+extern "C" {
+
+// floats of workspace mv_channel_moments_fwd needs for C channels
+int mv_channel_moments_ws(int C) { return MOM_BLOCKS * C; }
+
+int mv_channel_moments_supported(int64_t rows, int C, int dtype) {
+    return (dtype == MV_BF16 || dtype == MV_F32) && rows > 0 && C > 0 && C % 8 == 0 && C <= 2048;
+}
+
+int mv_channel_moments_fwd(const void* x, const float* shift, float* out, float* workspace, int64_t rows, int C, int squared,
+                           int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && out && workspace, "channel_moments: NULL pointer");
+    if (!mv_channel_moments_supported(rows, C, dtype)) {
+        set_error("channel_moments: unsupported rows=%lld C=%d dtype=%d (C must be a multiple of 8, <= 2048)", (long long)rows, C, dtype);
+        return MV_E_UNSUPPORTED;
+    }
+    const int RS = 256 / (C >> 3);
+    long long need = (rows + RS - 1) / RS;
+    const int G = (int)(need < MOM_BLOCKS ? need : MOM_BLOCKS);
+    const size_t smem = (size_t)RS * C * sizeof(float);
+    set_kernel_name(squared ? "channel_sqdev" : "channel_sum");
+    if (dtype == MV_F32)
+        hipLaunchKernelGGL(moments_partial_kernel<float>, dim3(G), dim3(256), smem, (hipStream_t)stream, (const float*)x, shift, workspace,
+                           (long long)rows, C, squared);
+    else
+        hipLaunchKernelGGL(moments_partial_kernel<bf16_t>, dim3(G), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)x, shift, workspace,
+                           (long long)rows, C, squared);
+    MV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(moments_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, out, G, C);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+}  // extern "C"

@@ -167,6 +167,36 @@ def all_gather_rows(local: torch.Tensor, batch: int, group=None, out: Optional[t
     return torch.cat([full[r * mx: r * mx + (hi - lo)] for r, (lo, hi) in enumerate(per)], 0)
 
 
+def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over ranks of a small fp32 tensor (training-mode BatchNorm moments: 2 x C floats per layer).  RCCL
+    (`mv_allreduce_sum_f32`) when the native communicator is up, else `torch.distributed` (gloo stages through the host);
+    a single process returns `t` unchanged."""
+    native = _state["native"] and group is None and t.is_cuda
+    if group is None and not native and _state["group"] is not None:
+        group = _state["group"]
+    if native:
+        if _lib.load().mv_comm_size() > 1:
+            _lib.call("mv_allreduce_sum_f32", t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream)
+        return t
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def world_size(group=None) -> int:
+    if _state["native"] and group is None:
+        return max(1, _lib.load().mv_comm_size())
+    if group is None and _state["group"] is not None:
+        group = _state["group"]
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
 def sharded_forward(forward: Callable, images, *, global_batch: Optional[int] = None, group=None) -> torch.Tensor:
     """Run `forward(local_images) -> [b_local, classes]` on this rank's shard of the GLOBAL batch
     `images` and all-gather the logits."""

@@ -52,15 +52,71 @@ def bn_fold(bn) -> Tuple[np.ndarray, np.ndarray]:
     return scale, shift
 
 
-def _check_bn(bn):
-    if bn is not None and not bn.inference:
-        raise NotImplementedError(
-            "BatchNorm in training mode (batch statistics + pmean over axis_name) is outside the inference "
-            "hot path; call eqxvision_amd.tree_inference(model, True) first")
+def _bn_training(bn) -> bool:
+    return bn is not None and not bn.inference
+
+
+def _bn_id(bn):
+    """Cache-key part for weights prepared WITH a BatchNorm folded in: identity + the version of its running statistics (the
+    StateIndex is shared by every copy of the module, e.g. tree_inference's; a training-mode update bumps it, so an inference
+    call afterwards refolds)."""
+    return None if bn is None else (id(bn), bn.state_index.version)
+
+
+def bn_train_update(bn, y: Act) -> None:
+    """The statistics half of eqx.experimental.BatchNorm's TRAINING branch (resnet.py:132-136 with the model
+    not in inference mode): per-channel batch mean, then the mean of squared deviations from it -- two passes, each summed over
+    the ranks of `axis_name`'s data-parallel group (RCCL all-reduce of C floats) --, then the running statistics:
+    first call: running = batch; later: running = (1 - momentum) * batch + momentum * running.  The state lives on the host
+    (StateIndex), as in the reference; the caller normalises with the UPDATED running statistics (reference semantics)."""
+    from . import dist as _dist
+    t = y.t
+    C = t.shape[-1]
+    if C != bn.input_size:
+        raise ValueError(f"BatchNorm({bn.input_size}) applied to {C} channels")
+    rows = t.numel() // C
+    if not _lib.load().mv_channel_moments_supported(rows, C, y.dt):
+        raise NotImplementedError(f"training-mode BatchNorm over {C} channels (multiples of 8 up to 2048 only)")
+    ws = empty((int(_lib.load().mv_channel_moments_ws(C)),), torch.float32)
+    s = empty((C,), torch.float32)
+    reduce_ranks = bn.axis_name is not None and _dist.world_size() > 1
+    n = float(rows)
+    if reduce_ranks:                       # rows of the GLOBAL batch (shards may be ragged)
+        cnt = _dev(np.array([rows], np.float32), torch.float32)
+        n = float(_dist.all_reduce_sum_(cnt).cpu()[0])
+    _lib.call("mv_channel_moments_fwd", _ptr(t), None, _ptr(s), _ptr(ws), rows, C, 0, y.dt, stream_ptr())
+    if reduce_ranks:
+        _dist.all_reduce_sum_(s)
+    mean = (s.cpu().numpy().astype(np.float64) / n).astype(np.float32)
+    mean_dev = _dev(mean, torch.float32)
+    _lib.call("mv_channel_moments_fwd", _ptr(t), _ptr(mean_dev), _ptr(s), _ptr(ws), rows, C, 1, y.dt, stream_ptr())
+    if reduce_ranks:
+        _dist.all_reduce_sum_(s)
+    var = (s.cpu().numpy().astype(np.float64) / n).astype(np.float32)
+    if bn.first_time_index.value or bn.state_index.value is None:
+        run_mean, run_var = mean, var
+        bn.first_time_index.value = False
+    else:
+        m = np.float32(bn.momentum)
+        old_mean, old_var = (np.asarray(a, np.float32) for a in bn.state_index.value)
+        run_mean = (np.float32(1) - m) * mean + m * old_mean
+        run_var = (np.float32(1) - m) * var + m * old_var
+    bn.state_index.value = (run_mean, run_var)
+    # (the assignment bumped state_index.version: every fold prepared with the old statistics is stale now, see _bn_id)
+
+
+def _bn_apply_fresh(y: Act, bn, act=None) -> Act:
+    """(y - running_mean) / sqrt(running_var + eps) * weight + bias with the statistics as they are NOW (no cached fold)."""
+    s, h = bn_fold(bn)
+    sd, hd = _dev(s, torch.float32), _dev(h, torch.float32)      # (held until after the call: the allocator reuses freed blocks)
+    C = y.t.shape[-1]
+    out = empty(tuple(y.t.shape), y.t.dtype)
+    _lib.call("mv_channel_affine_fwd", _ptr(y.t), _ptr(sd), _ptr(hd), _ptr(out), y.t.numel() // C, C, ACT[act], y.dt, stream_ptr())
+    return Act(out, y.kind, y.batched)
 
 
 def prep_conv(conv, bn, layout: str, dtype: str):
-    key = ("conv", layout, dtype, id(bn))
+    key = ("conv", layout, dtype, _bn_id(bn))
     cache = conv._cache()
     hit = cache.get(key)
     if hit is not None:
@@ -87,7 +143,7 @@ def prep_conv_grouped64(conv, bn):
     """Grouped filters (O, I/g, kh, kw) expanded to the per-tile input windows: [O][kh][kw][win] (the layout
     mv_conv2d_nhwc_grouped64_fwd documents; block-diagonal 64 x 64 tiles when the group width divides 64), bf16; BN folded to
     fp32 scale / shift as in prep_conv."""
-    key = ("conv_g64", id(bn))
+    key = ("conv_g64", _bn_id(bn))
     cache = conv._cache()
     hit = cache.get(key)
     if hit is not None:
@@ -229,8 +285,14 @@ STEM_MAX_CIN = 4
 
 
 def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> Act:
-    """Conv2d [+ BatchNorm(inference)] [+ residual] [+ relu/gelu], one launch."""
-    _check_bn(bn)
+    """Conv2d [+ BatchNorm(inference)] [+ residual] [+ relu/gelu], one launch.  A BatchNorm in TRAINING mode cannot be folded:
+    convolution, batch statistics (+ cross-rank sum), running-statistics update, normalisation, (+ residual, activation)."""
+    if _bn_training(bn):
+        y = conv2d(x, conv, None, None, None)
+        bn_train_update(bn, y)
+        if residual is None:
+            return _bn_apply_fresh(y, bn, act)
+        return add(_bn_apply_fresh(y, bn, None), residual, act)
     dt = compute_dtype()
     if act in UNFUSED_ACTS and (dt != "bf16" or x.kind == "img" or conv.out_channels % 8 or
                                 (conv.groups > 1 and not conv.groups == conv.in_channels == conv.out_channels)):
@@ -273,12 +335,12 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
     if conv.groups > 1 and dt == "bf16" and residual is None and \
             _lib.load().mv_dwconv2d_supported(C, K, conv.groups, kh, kw, _lib.BF16, _lib.BF16):
         cache = conv._cache()
-        hit = cache.get(("dw", id(bn)))
+        hit = cache.get(("dw", _bn_id(bn)))
         if hit is None:
             _, scale, shift = prep_conv(conv, bn, "oihw", dt)
             wr = np.ascontiguousarray(np.asarray(conv.weight, np.float32)[:, 0].transpose(1, 2, 0))     # (C,1,R,S) -> [R][S][C]
             hit = (_dev(wr, torch.bfloat16), scale, shift)
-            cache[("dw", id(bn))] = hit
+            cache[("dw", _bn_id(bn))] = hit
         y = empty((B, Ho, Wo, K), torch.bfloat16)
         _lib.call("mv_dwconv2d_nhwc_fwd", _ptr(x.t), _ptr(hit[0]), _ptr(hit[1]), _ptr(hit[2]), _ptr(y), B, H, W, C, kh, kw, sh, sw,
                   ph, pw, dh, dw, ACT[act], _lib.BF16, _lib.BF16, stream_ptr())
@@ -306,7 +368,7 @@ def _conv2d_padded_k(x: Act, conv, bn, act, prep, dims) -> Act:
     K = conv.out_channels
     Kp = (K + 7) // 8 * 8
     cache = conv._cache()
-    key = ("kpad", id(bn))
+    key = ("kpad", _bn_id(bn))
     hit = cache.get(key)
     if hit is None:
         wp = torch.zeros((Kp,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
@@ -338,8 +400,8 @@ def conv1x1_chain(x: Act, conv3, bn3, residual: Act, conv1n, bn1n) -> Optional[A
     dt = compute_dtype()
     if dt != "bf16" or not (_pointwise(conv3) and _pointwise(conv1n)) or conv3.out_channels != conv1n.in_channels:
         return None
-    _check_bn(bn3)
-    _check_bn(bn1n)
+    if _bn_training(bn3) or _bn_training(bn1n):
+        return None
     x, residual = as_map(x), as_map(residual)
     B, H, W, C = x.t.shape
     K, N2 = conv3.out_channels, conv1n.out_channels
@@ -375,7 +437,7 @@ def _scaled_rows(conv, bn) -> Tuple[np.ndarray, np.ndarray]:
 def _dual_weights(conv3, bn3, ds_conv, ds_bn):
     """[scale3 * W3 | scale_d * W_d] as bf16 rows and shift3 + shift_d (cached on conv3)."""
     cache = conv3._cache()
-    key = ("dual", id(bn3), id(ds_conv), id(ds_bn))
+    key = ("dual", _bn_id(bn3), id(ds_conv), _bn_id(ds_bn))
     hit = cache.get(key)
     if hit is None:
         w3, h3 = _scaled_rows(conv3, bn3)
@@ -395,8 +457,8 @@ def conv1x1_dual(x: Act, conv3, bn3, xin: Act, ds_conv, ds_bn, act="relu") -> Op
     if tuple(ds_conv.kernel_size) != (1, 1) or tuple(ds_conv.padding) != (0, 0) or tuple(ds_conv.dilation) != (1, 1) \
             or ds_conv.groups != 1 or sd[0] != sd[1] or conv3.out_channels != ds_conv.out_channels:
         return None
-    _check_bn(bn3)
-    _check_bn(ds_bn)
+    if _bn_training(bn3) or _bn_training(ds_bn):
+        return None
     x, xin = as_map(x), as_map(xin)
     B, Ho, Wo, C1 = x.t.shape
     B2, H2, W2, C2 = xin.t.shape
@@ -423,8 +485,8 @@ def conv1x1_dual_chain(x: Act, conv3, bn3, xin: Act, ds_conv, ds_bn, conv1n, bn1
         return None
     if conv3.out_channels != ds_conv.out_channels or conv3.out_channels != conv1n.in_channels:
         return None
-    for b in (bn3, ds_bn, bn1n):
-        _check_bn(b)
+    if any(_bn_training(b) for b in (bn3, ds_bn, bn1n)):
+        return None
     x, xin = as_map(x), as_map(xin)
     B, H, W, C1 = x.t.shape
     C2, K, N2 = xin.t.shape[-1], conv3.out_channels, conv1n.out_channels
@@ -448,7 +510,8 @@ def conv1x1_dual_chain(x: Act, conv3, bn3, xin: Act, ds_conv, ds_bn, conv1n, bn1
 def stem_conv_pool(x: Act, conv, bn, act, pool) -> Act:
     """ResNet entry (resnet.py:243-254): conv1 + bn1 + relu + maxpool.  One launch when the library has the fused
     path for this configuration (the 112x112x64 map then never reaches HBM), else conv2d followed by maxpool2d."""
-    _check_bn(bn)
+    if _bn_training(bn):
+        return maxpool2d(conv2d(x, conv, bn, act), pool.kernel_size, pool.stride, pool.padding)
     dt = compute_dtype()
     kh, kw = conv.kernel_size
     sh, sw = conv.stride
@@ -694,19 +757,22 @@ def layernorm_first_row(x: Act, ln, out_fp32: bool = False) -> Act:
 
 
 def batchnorm(x: Act, bn, act=None) -> Act:
-    """Stand-alone BatchNorm inference (unfused call sites): per-channel affine."""
-    _check_bn(bn)
+    """Stand-alone BatchNorm (unfused call sites): per-channel affine with the running statistics -- after updating them from
+    this batch when the module is in training mode (reference semantics)."""
     if x.kind == "seq":
         # eqx.experimental.BatchNorm treats AXIS 0 of the single-sample array as channels; a (tokens, features) array would be
         # normalised per token there, per feature here -- refuse instead of returning different numbers (round-1 advice)
         raise NotImplementedError("BatchNorm on a (tokens, features) array: the reference normalises axis 0; not on the hot path")
     x = as_map(x) if x.kind in ("img", "map") else as_rows(x)
+    if _bn_training(bn):
+        bn_train_update(bn, x)
+        return _bn_apply_fresh(x, bn, act)
     cache = bn._cache()
-    hit = cache.get("fold")
+    hit = cache.get(("fold", bn.state_index.version))
     if hit is None:
         s, h = bn_fold(bn)
         hit = (_dev(s, torch.float32), _dev(h, torch.float32))
-        cache["fold"] = hit
+        cache[("fold", bn.state_index.version)] = hit
     C = x.t.shape[-1]
     y = empty(tuple(x.t.shape), x.t.dtype)
     _lib.call("mv_channel_affine_fwd", _ptr(x.t), _ptr(hit[0]), _ptr(hit[1]), _ptr(y), x.t.numel() // C, C,

@@ -24,7 +24,7 @@ import torch
 from . import _lib
 from ._act import (Act, _to_device_f32, compute_dtype, head_fp32, keep_alive, residual_fp32, split_weights, stream_ptr,
                    wrap)
-from ._module import Module
+from ._module import Module, StateIndex
 from .nn import _unwrap
 
 
@@ -95,10 +95,14 @@ def _module_sig(m: Module):
     fresh `tree_inference(net, True)` copy made inside the caller's loop (new Module objects, shared leaves) hits the cache
     instead of retracing.  Cached on the instance: Modules are frozen by convention, like eqx.Module."""
     hit = m.__dict__.get("_sig_cache")
-    if hit is not None:
-        return hit
+    if hit is not None and all(st.version == v for st, v in hit[1]):
+        return hit[0]
+    states = []                                # StateIndex slots (BatchNorm running statistics): mutable, shared by identity
 
     def rec(n):
+        if isinstance(n, StateIndex):          # a training-mode step rewrote the statistics -> folded weights / graphs are stale
+            states.append((n, n.version))
+            return ("state", id(n), n.version)
         if isinstance(n, Module):
             return (type(n).__qualname__,) + tuple((f, rec(getattr(n, f))) for f in n.__fields__ if hasattr(n, f))
         if isinstance(n, (list, tuple)):
@@ -112,8 +116,34 @@ def _module_sig(m: Module):
         return ("o", id(n))                    # StateIndex slots, callables, ...: shared by identity
 
     sig = ("mod", hash(rec(m)), id(type(m)))
-    object.__setattr__(m, "_sig_cache", sig)
+    object.__setattr__(m, "_sig_cache", (sig, states))
     return sig
+
+
+def _needs_eager(x) -> bool:
+    """True when a Module tree holds a layer in TRAINING mode whose forward involves the host between launches: BatchNorm
+    (batch moments read back, running statistics updated -- ops.bn_train_update) or Dropout / DropPath with p > 0 (fresh random
+    masks per call).  Such a forward is neither recorded, split into lanes nor captured: it runs launch by launch, every call."""
+    hit = x.__dict__.get("_eager_cache") if isinstance(x, Module) else None
+    if hit is not None:
+        return hit
+
+    def rec(n):
+        if isinstance(n, Module):
+            if getattr(n, "inference", True) is False:
+                if type(n).__name__ == "BatchNorm" or float(getattr(n, "p", 0.0) or 0.0) > 0.0:
+                    return True
+            return any(rec(getattr(n, f)) for f in n.__fields__ if hasattr(n, f))
+        if isinstance(n, (list, tuple)):
+            return any(rec(c) for c in n)
+        if isinstance(n, dict):
+            return any(rec(c) for c in n.values())
+        return False
+
+    r = rec(x)
+    if isinstance(x, Module):
+        object.__setattr__(x, "_eager_cache", r)
+    return r
 
 
 def _sig(x):
@@ -267,6 +297,8 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
 
     @functools.wraps(fn)
     def jitted(*args, **kwargs):
+        if any(_needs_eager(v) for v in list(args) + list(kwargs.values()) if isinstance(v, (Module, list, tuple, dict))):
+            return fn(*args, **kwargs)             # training-mode layers: host logic between launches, nothing to replay
         key = (compute_dtype(), residual_fp32(), head_fp32(), split_weights(), _lib.load().mv_flags_epoch(), tuple(_sig(a) for a in args),
                tuple((k, _sig(v)) for k, v in sorted(kwargs.items())))
         # A graph bakes buffer addresses in.  Resident device inputs are read in place -- no staging copy -- by a

@@ -274,6 +274,17 @@ int mv_graph_end_capture(mv_stream_t stream, void** graph_exec);
 int mv_graph_launch(void* graph_exec, mv_stream_t stream);
 int mv_graph_destroy(void* graph_exec);
 
+/* Per-channel batch moments of rows x[rows][C] (an NHWC map or a row matrix): the statistics of eqx.experimental.BatchNorm's
+ * TRAINING branch (reference resnet.py:132-136 / :252 / :301 with the model not in inference mode):
+ *   out[c] = sum over rows of (x[r][c] - shift[c])        (squared = 0; shift may be NULL)
+ *   out[c] = sum over rows of (x[r][c] - shift[c])^2      (squared = 1)
+ * Two passes like the reference (mean, then the mean of squared deviations from the cross-replica mean); the caller divides by
+ * the global row count after mv_allreduce_sum_f32.  workspace: mv_channel_moments_ws(C) floats.  Deterministic summation order. */
+int mv_channel_moments_ws(int C);
+int mv_channel_moments_supported(int64_t rows, int C, int dtype);
+int mv_channel_moments_fwd(const void* x, const float* shift, float* out, float* workspace, int64_t rows, int C, int squared,
+                           int dtype, mv_stream_t stream);
+
 /* The path's one collective: the batch axis of `jax.vmap(net, axis_name="batch")(images)` (README.md:37-40)
  * shards over the GPUs of a node, one process per GPU; rank r runs images[r*B/W:(r+1)*B/W] and ONE all-gather of the fp32 logits
  * rebuilds the (B, classes) array the single-device vmap returns.  RCCL over xGMI (librccl is dlopen'ed by the first call;
@@ -287,6 +298,7 @@ int mv_comm_init(int rank, int nranks, const void* unique_id);
 int mv_comm_size(void); /* 0 = no communicator */
 int mv_comm_rank(void);
 int mv_allgather(const void* send, void* recv, size_t bytes_per_rank, mv_stream_t stream);
+int mv_allreduce_sum_f32(void* buf, size_t count, mv_stream_t stream);   /* in place, sum over ranks (training-mode BatchNorm moments) */
 int mv_comm_destroy(void);
 
 /* HIP-event timing helpers on the caller's stream (bench.py's live roofline measurement) */

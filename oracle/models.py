@@ -155,6 +155,41 @@ def resnet_forward(sd, x, block="bottleneck", layers=(3, 4, 6, 3), bf16=False, g
     return O.linear(x, q(sd["fc.weight"]), sd["fc.bias"])                            # resnet.py:356
 
 
+def resnet_forward_train(sd, xs, running, block="bottleneck", layers=(3, 4, 6, 3), bf16=False):
+    """resnet_forward with every BatchNorm in TRAINING mode (np_ops.batchnorm_train), on a whole batch xs [B,3,H,W]: batch
+    statistics couple the samples, so the layers run batch-wide.  `running`: dict bn-name -> (mean, var) or missing (first call);
+    updated in place.  Returns logits [B, classes].  Data-parallel runs: pass the GLOBAL batch and slice the rank's rows."""
+    q = _Q(bf16)
+
+    def cbn(xs, conv, bn, stride=1, padding=0, relu=False, residual=None):
+        ys = np.stack([O.conv2d(x, q(sd[conv + ".weight"]), None, stride, padding) for x in xs])
+        ys = q(ys)                                              # the product materialises the convolution output
+        ys, running[bn] = O.batchnorm_train(ys, sd[bn + ".weight"], sd[bn + ".bias"], running.get(bn), bn not in running)
+        if residual is not None:
+            ys = q(ys) + residual
+        if relu:
+            ys = O.relu(ys)
+        return q(ys)
+
+    xs = q(np.asarray(xs, np.float32))
+    xs = cbn(xs, "conv1", "bn1", stride=2, padding=3, relu=True)
+    xs = np.stack([O.maxpool2d(x, 3, 2, 1) for x in xs])
+    for li, nblk in enumerate(layers):
+        for bi in range(nblk):
+            p = f"layer{li + 1}.{bi}"
+            s = (1 if li == 0 else 2) if bi == 0 else 1
+            identity = cbn(xs, p + ".downsample.0", p + ".downsample.1", stride=s) if (p + ".downsample.0.weight") in sd else xs
+            if block == "bottleneck":
+                out = cbn(xs, p + ".conv1", p + ".bn1", relu=True)
+                out = cbn(out, p + ".conv2", p + ".bn2", stride=s, padding=1, relu=True)
+                xs = cbn(out, p + ".conv3", p + ".bn3", relu=True, residual=identity)
+            else:
+                out = cbn(xs, p + ".conv1", p + ".bn1", stride=s, padding=1, relu=True)
+                xs = cbn(out, p + ".conv2", p + ".bn2", padding=1, relu=True, residual=identity)
+    feats = q(xs.mean(axis=(2, 3)))
+    return np.stack([O.linear(f, q(sd["fc.weight"]), sd["fc.bias"]) for f in feats])
+
+
 # ---------------------------------------------------------------- mobilenetv2.py:16-229
 def mobilenet_v2_forward(sd, x, setting, bf16=False):
     """stem conv3x3/2 + BN + relu; inverted residuals ([1x1 expand + BN + relu,] 3x3 depthwise + BN + relu, 1x1 project + BN,

@@ -591,6 +591,36 @@ def ln_linear_case(M, K, N, stream="fp32", act=0, seed=0, flags=()):
     return run
 
 
+def moments_case(rows, C, dtype="bf16", seed=0):
+    """mv_channel_moments_fwd (per-channel batch sums of training-mode BatchNorm, two passes) vs float64 sums."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        x = (rng.standard_normal((rows, C)) * rng.uniform(0.5, 2.0, (1, C)) + rng.uniform(-2, 2, (1, C))).astype(np.float32)
+        if dtype == "bf16":
+            x = bf(x)
+        dtc = 1 if dtype == "bf16" else 0
+        if not L.load().mv_channel_moments_supported(rows, C, dtc):
+            return {"ok": False, "err": "mv_channel_moments_supported says no"}
+        xd = dev(x, dtype)
+        ws = torch.empty((int(L.load().mv_channel_moments_ws(C)),), dtype=torch.float32, device="cuda")
+        s1 = torch.full((C,), -7.0, dtype=torch.float32, device="cuda")
+        s2 = torch.full((C,), -7.0, dtype=torch.float32, device="cuda")
+        L.call("mv_channel_moments_fwd", xd.data_ptr(), None, s1.data_ptr(), ws.data_ptr(), rows, C, 0, dtc, _stream())
+        mean = (host(s1).astype(np.float64) / rows).astype(np.float32)
+        md = dev(mean, "fp32")
+        L.call("mv_channel_moments_fwd", xd.data_ptr(), md.data_ptr(), s2.data_ptr(), ws.data_ptr(), rows, C, 1, dtc, _stream())
+        s1b = torch.empty_like(s1)
+        L.call("mv_channel_moments_fwd", xd.data_ptr(), None, s1b.data_ptr(), ws.data_ptr(), rows, C, 0, dtc, _stream())
+        torch.cuda.synchronize()
+        x64 = x.astype(np.float64)
+        e1 = float(np.abs(host(s1) / rows - x64.mean(0)).max())
+        e2 = float(np.abs(host(s2) / rows - ((x64 - mean.astype(np.float64)) ** 2).mean(0)).max())
+        return {"ok": e1 < 1e-4 and e2 < 1e-3 and bool(torch.equal(s1, s1b)), "err": max(e1, e2), "lim": 1e-3, "mean_err": e1,
+                "var_err": e2, "deterministic": bool(torch.equal(s1, s1b)), "kernel": L.last_kernel()}
+    return run
+
+
 def ln_mlp_case(M, stream="fp32", seed=0, C=96, Hd=384):
     """mv_ln_mlp_fwd (LayerNorm -> fc1 -> GELU -> fc2 -> + x, one launch) vs the un-fused float64 restatement
     (swin.py:572-578 second line, mlps.py:54-66) with the affine LayerNorm applied the reference's way; the kernel gets the
@@ -1282,6 +1312,10 @@ def all_cases():
           ("ln_linear/swin_qkv_192_576_bf16stream_ragged", ln_linear_case(8192 + 45, 192, 576, "bf16", seed=532, flags=(("ln_stream_192", 1),))),
           ("ln_linear/swin_fc1_96_384_gelu_bf16stream", ln_linear_case(8192 + 45, 96, 384, "bf16", act=2, seed=534)),
           ("ln_linear/k96_N200_tail", ln_linear_case(9000, 96, 200, "fp32", seed=533)),
+          ("moments/c64_map_bf16", moments_case(8 * 112 * 112, 64, "bf16", seed=550)),
+          ("moments/c2048_few_rows", moments_case(8 * 7 * 7, 2048, "bf16", seed=551)),
+          ("moments/c96_fp32_ragged", moments_case(12345, 96, "fp32", seed=552)),
+          ("moments/c8_one_row", moments_case(1, 8, "fp32", seed=553)),
           ("ln_mlp/swin_stage0_f32stream", ln_mlp_case(8 * 56 * 56, "fp32", seed=520)),
           ("ln_mlp/bf16stream_ragged", ln_mlp_case(4096 + 77, "bf16", seed=521)),
           ("ln_mlp/f32stream_many_tiles", ln_mlp_case(70001, "fp32", seed=522)),

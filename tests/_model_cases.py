@@ -90,6 +90,50 @@ def resnet_case(block, layers, size, B, classes=10, dtype="bf16", full_ref="nump
     return run
 
 
+def resnet_train_case(B=8, size=64, classes=10, jit=False):
+    """resnet18 with every BatchNorm in TRAINING mode (reference resnet.py:132-136 / 252 / 301 before tree_inference; the
+    semantics of eqx.experimental.BatchNorm's training branch): two steps -- batch statistics, running
+    statistics by EMA, normalisation with the updated running statistics -- against oracle.models.resnet_forward_train, the
+    running statistics of the first and last BatchNorm against the oracle's, then an INFERENCE forward of the same modules
+    (shared state) against the oracle's inference forward with the updated statistics."""
+    def run():
+        import eqxvision_amd as eqv
+        block, layers = "basic", (2, 2, 2, 2)
+        sd = S.resnet_state(1, block, layers, classes)
+        net_inf = _load(eqv.models.resnet18, sd, num_classes=classes)
+        net = eqv.tree_inference(net_inf, False)
+        running = {k[:-len(".running_mean")]: (sd[k], sd[k[:-len("mean")] + "var"]) for k in sd if k.endswith(".running_mean")}
+        fwd = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k)) if jit else \
+            (lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k))
+        errs, info = [], {}
+        with eqv.precision("bf16"):
+            for step in range(2):
+                x = S.synthetic_images(B, size, seed=step)
+                got = fwd(net, x, _keys(B))
+                torch.cuda.synchronize()
+                ref = OM.resnet_forward_train(sd, x, running, block, layers, bf16=True)
+                info[f"refmax_step{step}"] = float(np.abs(ref).max())
+                errs.append(float(np.abs(got.cpu().numpy() - ref).max()) / max(1.0, float(np.abs(ref).max())))
+            for name, mod in (("bn1", net.bn1), ("layer4.1.bn2", net.layer4.layers[1].bn2)):
+                m, v = mod.state_index.value
+                info[f"{name}_running_err"] = max(float(np.abs(np.asarray(m) - running[name][0]).max()),
+                                                  float(np.abs(np.asarray(v) - running[name][1]).max() /
+                                                        max(1.0, float(np.abs(running[name][1]).max()))))
+            sd2 = dict(sd)
+            for name, (m, v) in running.items():
+                sd2[name + ".running_mean"], sd2[name + ".running_var"] = m, v
+            x = S.synthetic_images(B, size, seed=7)
+            got = eqv.vmap(net_inf, axis_name="batch")(x, key=_keys(B)).cpu().numpy()
+            ref = O.vmap(lambda im: OM.resnet_forward(sd2, im, block, layers, bf16=True))(x)
+            errs.append(float(np.abs(got - ref).max()))
+        # bf16 against the bf16-emulating oracle; training steps relative to max|logit| (un-normalised activations grow: the
+        # reference normalises with the RUNNING statistics even in training mode)
+        info.update({"err": max(errs), "lim": 1e-2, "train_step_errs_scaled": errs[:2], "inference_after_err": errs[2]})
+        info["ok"] = max(errs) <= 1e-2 and all(v < 1e-2 for k, v in info.items() if k.endswith("_running_err"))
+        return info
+    return run
+
+
 def alexnet_case(B, dtype="bf16", features_only=False):
     def run():
         import eqxvision_amd as eqv
@@ -631,6 +675,8 @@ def pth_reader_case():
 def all_cases(full=True):
     c = [("model/resnet_tiny_bottleneck", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2)),
          ("model/resnet18_64px", resnet_case("basic", (2, 2, 2, 2), 64, 2)),
+         ("model/resnet18_train_mode_bn", resnet_train_case()),
+         ("model/resnet18_train_mode_bn_under_filter_jit", resnet_train_case(jit=True)),
          ("model/resnext_tiny_32x4d", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2, groups=32, width_per_group=4)),
          ("model/resnet_tiny_fp32", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2, dtype="fp32")),
          ("model/vit_tiny", vit_case(32, 8, 64, 2, 2, 3)),

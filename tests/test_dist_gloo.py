@@ -56,3 +56,44 @@ def test_shard_bounds_cover_batch():
             assert spans[0][0] == 0 and spans[-1][1] == B
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _bn_worker(rank, world, port, batch, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from eqxvision_amd import dist as D
+    D.init_from_env("gloo")
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(batch, 5, 6, 8, generator=g) * 3 + 1                 # NHWC map, the same on every rank
+    lo, hi = D.shard_bounds(batch, rank, world)
+    rows = x[lo:hi].reshape(-1, 8)
+    # the two passes of ops.bn_train_update with the device sums replaced by torch (the HIP kernels need a GPU): sum -> all-reduce
+    # -> mean; squared deviations from the GLOBAL mean -> all-reduce -> variance
+    n = torch.tensor([float(rows.shape[0])])
+    D.all_reduce_sum_(n)
+    s = rows.sum(0)
+    D.all_reduce_sum_(s)
+    mean = s / n
+    sq = ((rows - mean) ** 2).sum(0)
+    D.all_reduce_sum_(sq)
+    q.put((rank, D.world_size(), mean.numpy(), (sq / n).numpy()))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [8, 7])
+def test_batchnorm_moments_all_reduce_gloo(batch):
+    """Training-mode BatchNorm's cross-rank moments: every rank ends with the statistics of the whole batch,
+    equal shards or ragged."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_bn_worker, args=(r, world, port, batch, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=120) for _ in range(world)]
+    [p.join(60) for p in ps]
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(batch, 5, 6, 8, generator=g) * 3 + 1).reshape(-1, 8).double()
+    for rank, w, mean, var in res:
+        assert w == 2
+        np.testing.assert_allclose(mean, x.mean(0).numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(var, x.var(0, unbiased=False).numpy(), rtol=1e-4, atol=1e-5)

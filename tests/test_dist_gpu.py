@@ -42,6 +42,20 @@ def test_two_ranks_hip_forward_and_gather(tmp_path, B):
     assert info["world"] == 2 and info["shape"] == [B, 1000] and info["rows_rank1_nonzero"] and info["ok"], info
 
 
+def test_two_ranks_training_mode_batchnorm(tmp_path):
+    """SURVEY section 8 f4, first item: BatchNorm batch statistics over a data-parallel batch (the reference's `pmean` over
+    axis_name, across GPUs): 2 ranks x 8 images = the moments of 16."""
+    assert torch.cuda.is_available()
+    out = tmp_path / "bn.json"
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_worker.py"), str(out), "16", "bn_train"]
+    r = subprocess.run(cmd, env=_env(port), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    info = json.load(open(out))
+    assert info["world"] == 2 and info["shard_rows"] == 8 and info["logits_shape"] == [8, 1000] and info["ok"], info
+
+
 def test_rccl_abi_single_rank():
     """mv_comm_* over librccl on the device: a 1-rank communicator's all-gather is a copy on the launch stream."""
     from eqxvision_amd import _lib, dist as D
@@ -56,6 +70,12 @@ def test_rccl_abi_single_rank():
         y = D.all_gather_rows(x, 256)
         torch.cuda.synchronize()
         assert y.data_ptr() != x.data_ptr() and torch.equal(x, y)
+        s = torch.randn(2 * 2048, device="cuda")
+        s0 = s.clone()
+        assert D.all_reduce_sum_(s) is s                        # mv_allreduce_sum_f32 skipped for one rank ...
+        _lib.call("mv_allreduce_sum_f32", s.data_ptr(), s.numel(), torch.cuda.current_stream().cuda_stream)   # ... ncclAllReduce itself
+        torch.cuda.synchronize()
+        assert torch.equal(s, s0)
         with pytest.raises(_lib.MVError):                       # one communicator per process
             import ctypes
             _lib.call("mv_comm_init", 0, 1, ctypes.create_string_buffer(128))
