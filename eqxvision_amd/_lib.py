@@ -34,6 +34,7 @@ PROTOTYPES = {
     "mv_comm_rank": [],
     "mv_allgather": [_vp, _vp, C.c_size_t, _vp],
     "mv_allreduce_sum_f32": [_vp, C.c_size_t, _vp],
+    "mv_dropout_fwd": [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp],
     "mv_channel_moments_ws": [_i],
     "mv_channel_moments_supported": [_i64, _i, _i],
     "mv_channel_moments_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],

@@ -1,5 +1,6 @@
-"""Stochastic depth (reference layers/drop_path.py:8-61).  Inference / p == 0 is the identity,
-which is all the forward hot path needs; the Bernoulli training branch is out of scope."""
+"""Stochastic depth (reference layers/drop_path.py:8-61).  Inference / p == 0 is the identity; the training branch draws
+`bernoulli(key, 1 - p)` per sample ("global") or per entry of the sample's first axis ("local") from JAX's bit stream
+(eqxvision_amd/random.py) and scales on the device (ops.drop_path)."""
 from __future__ import annotations
 
 from .._module import Module
@@ -21,6 +22,9 @@ class DropPath(Module):
         if key is None:                                      # reference :46-49
             raise RuntimeError(
                 "DropPath requires a key when running in non-deterministic mode. Did you mean to enable inference?")
-        raise NotImplementedError(
-            "DropPath's random training branch is outside the inference hot path; "
-            "use eqxvision_amd.tree_inference(model, True)")
+        from .. import ops
+        from .._act import is_act, wrap
+        from ..nn import _unwrap
+        if is_act(x):
+            return ops.drop_path(x, self.p, self.mode, key)
+        return _unwrap(ops.drop_path(wrap(x, False), self.p, self.mode, key), False)

@@ -42,10 +42,16 @@ class AlexNet(Module):
     def __call__(self, x, *, key):
         if key is None:                                  # reference :78-79
             raise RuntimeError("The model requires a PRNGKey.")
-        return self._forward(x)
+        return self._forward(x, key)
 
     @boundary
-    def _forward(self, x):
+    def _forward(self, x, key=None):
+        from ...transforms import _needs_eager
+        if key is not None and _needs_eager(self):       # training mode: the classifier's Dropouts draw from keys[1] (alexnet.py:80-84)
+            keys = jr.split(key, 2)
+            x = self.features(x, key=keys[0])
+            x = self.avgpool(x)
+            return self.classifier(ops.flatten(x), key=keys[1])
         x = self.features(x)
         x = self.avgpool(x)
         x = ops.flatten(x)                               # jnp.ravel in CHW order (reference :83)

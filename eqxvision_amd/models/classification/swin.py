@@ -154,8 +154,11 @@ class _SwinTransformerBlock(Module):
                 if isinstance(self.norm2, nn.LayerNorm):
                     return self.mlp._forward(x, residual=x, norm=self.norm2)
             return self.mlp._forward(self.norm2(x), residual=x)
-        x = ops.add(x, sd(self.attn._forward(self.norm1(x)), key=key))
-        return ops.add(x, sd(self.mlp._forward(self.norm2(x)), key=key))
+        if key is None:
+            raise RuntimeError("stochastic depth outside inference mode requires a key")
+        keys = jr.split(key, 4)                                        # reference :573 (attention / MLP dropouts are p = 0 here)
+        x = ops.add(x, sd(self.attn._forward(self.norm1(x)), key=keys[1]))
+        return ops.add(x, sd(self.mlp._forward(self.norm2(x)), key=keys[3]))
 
 
 class SwinTransformer(Module):
@@ -205,23 +208,25 @@ class SwinTransformer(Module):
         self.avgpool = nn.AdaptiveAvgPool2d(1)
         self.head = nn.Linear(num_features, num_classes, key=keys[1])
 
-    def _features(self, x):
-        """self.features(x); the patch-embed LayerNorm2d starts the fp32 residual stream when enabled."""
+    def _features(self, x, key=None):
+        """self.features(x); the patch-embed LayerNorm2d starts the fp32 residual stream when enabled.  `key`: split per layer
+        like nn.Sequential does (stochastic depth in training mode)."""
         L = self.features.layers
+        ks = [None] * len(L) if key is None else list(jr.split(key, len(L)))
         first = L[0]
         if (residual_fp32() and isinstance(first, nn.Sequential) and len(first) == 2
                 and type(first.layers[0]) is nn.Conv2d and isinstance(first.layers[1], nn.LayerNorm)):
             y = ops.conv2d_entry_split(x, first.layers[0])          # patch embedding: split-precision weights
             x = y if y is not None else ops.conv2d(x, first.layers[0])
             x = ops.layernorm(x, first.layers[1], out_fp32=True)
-            for layer in L[1:]:
-                x = layer(x)
+            for layer, k in zip(L[1:], ks[1:]):
+                x = layer(x, key=k)
             return x
-        return self.features(x)
+        return self.features(x, key=key)
 
     @boundary
     def __call__(self, x, *, key=None):                                # reference :760-772
-        x = self._features(x)
+        x = self._features(x, None if key is None else jr.split(key, 2)[0])
         if head_fp32() and isinstance(self.norm, nn.LayerNorm) and type(self.avgpool) is nn.AdaptiveAvgPool2d:
             x = ops.layernorm(x, self.norm, out_fp32=True)             # reference :768-771 with fp32 features
             x = ops.adaptive_avgpool2d(x, self.avgpool.target_shape, out_fp32=True)

@@ -76,10 +76,16 @@ class VGG(Module):
         # the reference splits `key` unconditionally (vgg.py:113): a missing key is an error there too
         if key is None:
             raise RuntimeError("The model requires a PRNGKey.")
-        return self._forward(x)
+        return self._forward(x, key)
 
     @boundary
-    def _forward(self, x):
+    def _forward(self, x, key=None):
+        from ...transforms import _needs_eager
+        if key is not None and _needs_eager(self):       # training mode: the classifier's Dropouts draw from keys[1] (vgg.py:113-118)
+            keys = jr.split(key, 2)
+            x = self.features(x, key=keys[0])
+            x = self.avgpool(x)
+            return self.classifier(ops.flatten(x), key=keys[1])
         x = self.features(x)
         x = self.avgpool(x)
         x = ops.flatten(x)                               # jnp.ravel in CHW order (vgg.py:116)

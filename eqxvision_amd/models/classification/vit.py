@@ -90,10 +90,11 @@ class _VitBlock(Module):
         if self._residual_ok():            # x + Identity(y): fold the add into the GEMM epilogues
             x, _ = self.attn._forward(y, residual=x, need_probs=False)
             return self.mlp._forward(self.norm2(x), residual=x)
+        keys = [None] * 4 if key is None else jr.split(key, 4)          # reference :148 (the dropouts inside are p = 0 or raise)
         y, _ = self.attn._forward(y, need_probs=False)
-        x = ops.add(x, self.drop_path(y, key=key))
+        x = ops.add(x, self.drop_path(y, key=keys[1]))
         y = self.mlp._forward(self.norm2(x))
-        return ops.add(x, self.drop_path(y, key=key))
+        return ops.add(x, self.drop_path(y, key=keys[3]))
 
 
 class VisionTransformer(Module):
@@ -159,8 +160,9 @@ class VisionTransformer(Module):
     @boundary
     def __call__(self, x, *, key=None):                                # reference :261-273
         x = self._tokens(x)
-        for blk in self.blocks:
-            x = blk(x)
+        keys = [None] * len(self.blocks) if key is None else jr.split(key, len(self.blocks))     # reference :267
+        for blk, k in zip(self.blocks, keys):
+            x = blk(x, key=k)
         return self._head(x)
 
     @boundary

@@ -125,9 +125,13 @@ class Dropout(Module):
         inf = self.inference if inference is None else inference
         if inf or self.p == 0:
             return x
-        raise NotImplementedError(
-            "Dropout with p>0 outside inference mode needs the training RNG path, which is outside the "
-            "inference hot path; use eqxvision_amd.tree_inference(model, True)")
+        if key is None:                                  # eqx.nn.Dropout: the same RuntimeError
+            raise RuntimeError("Dropout requires a key when running in non-deterministic mode.")
+        if self.p == 1:
+            raise NotImplementedError("Dropout(p=1)")
+        if is_act(x):
+            return ops.dropout(x, self.p, key)
+        return _unwrap(ops.dropout(wrap(x, False), self.p, key), False)
 
 
 class Conv2d(Module):

@@ -906,6 +906,57 @@ def channel_scale(x: Act, s: Act) -> Act:
     return Act(y, "map", x.batched)
 
 
+def _batched_keys(key, B: int) -> np.ndarray:
+    """uint32 [B, 2]: the per-sample keys of a vmapped call; one key [2] serves an un-batched call (B == 1)."""
+    k = np.asarray(key, np.uint32)
+    if k.ndim == 1 and k.shape[0] == 2 and B == 1:
+        k = k[None]
+    if k.shape != (B, 2):
+        raise ValueError(f"expected one PRNG key per sample, uint32 [{B}, 2]; got {k.shape}")
+    return np.ascontiguousarray(k)
+
+
+def dropout(x: Act, p: float, key) -> Act:
+    """eqx.nn.Dropout's training branch: where(bernoulli(key, 1 - p, x.shape), x / (1 - p), 0) per sample, the mask from the
+    sample's key in JAX's bit stream (generated on the device, rng.hip)."""
+    if x.kind == "img":
+        x = as_map(x)
+    B = x.t.shape[0]
+    keys = torch.from_numpy(_batched_keys(key, B).view(np.int32)).to(device())
+    per = x.t.numel() // B
+    C = x.t.shape[-1]
+    y = empty(tuple(x.t.shape), x.t.dtype)
+    _lib.call("mv_dropout_fwd", _ptr(x.t), _ptr(keys), _ptr(y), B, per, C, 1 if x.kind == "map" else 0, float(1.0 - p), x.dt,
+              stream_ptr())
+    return Act(y, x.kind, x.batched)
+
+
+def drop_path(x: Act, p: float, mode: str, key) -> Act:
+    """DropPath's training branch (drop_path.py:51-61): noise = bernoulli(key, 1 - p) for the whole sample (mode "global") or one
+    draw per entry of the sample's FIRST logical axis (mode "local": channels of a (C,H,W) map, tokens of an (N,D) matrix),
+    divided by 1 - p when that is positive; x * noise.  The draws come from the host (a handful per sample, JAX's bit stream:
+    random.bernoulli); the multiply is the broadcast-scale kernel."""
+    from . import random as jr
+    if x.kind == "img":
+        x = as_map(x)
+    B = x.t.shape[0]
+    keys = _batched_keys(key, B)
+    keep = 1.0 - float(p)
+    if x.kind == "seq" and mode != "global":
+        raise NotImplementedError("DropPath(mode='local') on a (tokens, features) array is not on any model's path")
+    C = x.t.shape[-1]
+    if mode == "global":
+        noise = np.repeat(jr.bernoulli(keys, keep).reshape(B, 1).astype(np.float32), C, axis=1)
+    else:
+        noise = jr.bernoulli(keys, keep, (C,)).astype(np.float32)
+    if keep > 0.0:
+        noise = noise / np.float32(keep)
+    s = _dev(np.ascontiguousarray(noise), x.t.dtype)
+    xm = x if x.kind == "map" else Act(x.t.reshape(B, -1, 1, C), "map", x.batched)
+    y = channel_scale(xm, Act(s, "vec", x.batched))
+    return y if x.kind == "map" else Act(y.t.reshape(x.t.shape), x.kind, x.batched)
+
+
 def patch_merge_gather(x: Act) -> Act:
     x = as_map(x)
     B, H, W, C = x.t.shape
@@ -928,6 +979,9 @@ def eltwise(x: Act, act: str) -> Act:
 
 def add(a: Act, b: Act, act=None) -> Act:
     a, b = _canon(a), _canon(b)
+    if a.t.dtype != b.t.dtype and {a.t.dtype, b.t.dtype} == {torch.float32, torch.bfloat16}:
+        # an fp32 residual stream + a compute-dtype branch (the un-fused x + drop_path(f(x)) of training mode): add in fp32
+        a, b = (a if a.t.dtype == torch.float32 else cast(a, "fp32")), (b if b.t.dtype == torch.float32 else cast(b, "fp32"))
     if tuple(a.t.shape) != tuple(b.t.shape) or a.t.dtype != b.t.dtype:
         raise ValueError(f"add: mismatched operands {a} vs {b}")
     y = empty(tuple(a.t.shape), a.t.dtype)

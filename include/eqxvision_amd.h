@@ -274,6 +274,14 @@ int mv_graph_end_capture(mv_stream_t stream, void** graph_exec);
 int mv_graph_launch(void* graph_exec, mv_stream_t stream);
 int mv_graph_destroy(void* graph_exec);
 
+/* Training-mode Dropout (eqx.nn.Dropout with inference = False: alexnet.py:63-68, vit.py:39-53, mlps.py:43-52 before
+ * tree_inference): y = where(bernoulli(key_b, keep_prob, x_b.shape), x_b / keep_prob, 0) for every sample b, keys [B][2]
+ * uint32 on the device (one jax.random key per sample, as under vmap).  The mask is JAX's bit stream: Threefry-2x32 words in
+ * jax.random's counter layout, word i for element i of the LOGICAL single-sample array in row-major order -- the reference's
+ * (C,H,W) when chw_logical != 0 (x is NHWC [B][per_sample / C][C] here), else the physical order ((N,D) rows, (D,) vectors). */
+int mv_dropout_fwd(const void* x, const void* keys, void* y, int B, int64_t per_sample, int C, int chw_logical, float keep_prob,
+                   int dtype, mv_stream_t stream);
+
 /* Per-channel batch moments of rows x[rows][C] (an NHWC map or a row matrix): the statistics of eqx.experimental.BatchNorm's
  * TRAINING branch (reference resnet.py:132-136 / :252 / :301 with the model not in inference mode):
  *   out[c] = sum over rows of (x[r][c] - shift[c])        (squared = 0; shift may be NULL)

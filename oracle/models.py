@@ -72,12 +72,19 @@ def alexnet_features(sd, x, bf16=False):
     return x
 
 
-def alexnet_forward(sd, x, bf16=False):
+def alexnet_forward(sd, x, bf16=False, key=None, dropout=0.5):
+    """`key` given: TRAINING mode -- the classifier's two Dropout(p) layers (alexnet.py:63-68) draw from the keys
+    nn.Sequential hands them: split(split(key, 2)[1], 7)[0] and [3] (alexnet.py:80-84)."""
     q = _Q(bf16)
     x = alexnet_features(sd, x, bf16)
     x = q(O.adaptive_avgpool2d(x, (6, 6)))                     # alexnet.py:82
     x = np.ravel(x)                                            # alexnet.py:83
+    ks = None if key is None else O.jax_split(O.jax_split(key, 2)[1], 7)
+    if ks is not None:
+        x = q(O.dropout(x, dropout, ks[0]))
     x = q(O.relu(O.linear(x, q(sd["classifier.1.weight"]), sd["classifier.1.bias"])))
+    if ks is not None:
+        x = q(O.dropout(x, dropout, ks[3]))
     x = q(O.relu(O.linear(x, q(sd["classifier.4.weight"]), sd["classifier.4.bias"])))
     return O.linear(x, q(sd["classifier.6.weight"]), sd["classifier.6.bias"])
 
@@ -423,29 +430,46 @@ def vit_last_self_attention(sd, x, patch=16, num_heads=12, depth=12, bf16=False)
 
 
 # ---------------------------------------------------------------- swin.py:572-578, 760-772
-def swin_block(sd, q, x, p, num_heads, window, shift):
+def swin_block(sd, q, x, p, num_heads, window, shift, sd_prob=0.0, key=None):
+    """`key` given (training mode): x + stochastic_depth(attn(norm1 x), key=keys[1]), then the same around the MLP with keys[3],
+    keys = split(key, 4); DropPath(sd_prob, mode="local"): one draw per channel (swin.py:545, 572-578)."""
+    ks = None if key is None or sd_prob == 0.0 else O.jax_split(key, 4)
     y = q(O.layernorm2d(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"]))
     bias = O.relative_position_bias(sd[p + ".attn.relative_position_bias_table"],
                                     sd[p + ".attn.relative_position_index"], window)
     y = O.shifted_window_attention(y, q(sd[p + ".attn.qkv.weight"]), q(sd[p + ".attn.proj.weight"]), bias,
                                    window, num_heads, shift, sd[p + ".attn.qkv.bias"], sd[p + ".attn.proj.bias"])
+    if ks is not None:
+        y = O.drop_path(q(y), sd_prob, "local", ks[1])
     x = q(x + y)
     y = q(O.layernorm2d(x, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"]))
     h = q(O.gelu_tanh(O.linear2d(y, q(sd[p + ".mlp.0.weight"]), sd[p + ".mlp.0.bias"])))
     y = O.linear2d(h, q(sd[p + ".mlp.3.weight"]), sd[p + ".mlp.3.bias"])
+    if ks is not None:
+        y = O.drop_path(q(y), sd_prob, "local", ks[3])
     return q(x + y)
 
 
-def swin_forward(sd, x, patch=(4, 4), depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window=(7, 7), bf16=False):
+def swin_forward(sd, x, patch=(4, 4), depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window=(7, 7), bf16=False, key=None,
+                 stochastic_depth_prob=0.0):
+    """`key` given: TRAINING mode.  Keys as the reference derives them: split(key, 2)[0] for `features` (swin.py:766-767),
+    nn.Sequential splits it per layer, each stage Sequential per block; block id / (total - 1) scales the drop rate (:730-733)."""
     q = _Q(bf16)
     x = q(x)
+    nfeat = 2 * len(depths)                                   # patch embedding, then stage / merge alternating
+    fkeys = None if key is None else O.jax_split(O.jax_split(key, 2)[0], nfeat)
+    total, blk_id = sum(depths), 0
     x = O.conv2d(x, q(sd["features.0.0.weight"]), sd["features.0.0.bias"], stride=tuple(patch))   # swin.py:705-711
     x = q(O.layernorm2d(q(x), sd["features.0.2.weight"], sd["features.0.2.bias"]))
     fi = 1
     for si, depth in enumerate(depths):
+        bkeys = None if fkeys is None else O.jax_split(fkeys[fi], depth)
         for bi in range(depth):
             shift = [0 if bi % 2 == 0 else w // 2 for w in window]                    # swin.py:736-738
-            x = swin_block(sd, q, x, f"features.{fi}.{bi}", num_heads[si], list(window), shift)
+            sdp = stochastic_depth_prob * float(blk_id) / (total - 1) if total > 1 else 0.0
+            x = swin_block(sd, q, x, f"features.{fi}.{bi}", num_heads[si], list(window), shift, sdp,
+                           None if bkeys is None else bkeys[bi])
+            blk_id += 1
         fi += 1
         if si < len(depths) - 1:
             p = f"features.{fi}"

@@ -134,6 +134,76 @@ def resnet_train_case(B=8, size=64, classes=10, jit=False):
     return run
 
 
+def stochastic_layers_case():
+    """Dropout / DropPath outside inference mode: the reference's own checks (tests/test_layers.py:36-68:
+    shape kept, some zeros; none after tree_inference) and, beyond them, the SAME elements dropped as eqx.nn.Dropout /
+    DropPath would drop for these keys (oracle.np_ops.dropout / drop_path on JAX's bit stream) -- outputs equal bit for bit."""
+    def run():
+        import eqxvision_amd as eqv
+        from eqxvision_amd import layers, nn
+        jr = eqv.random
+        info, ok = {}, True
+        rng = np.random.Generator(np.random.PCG64(5))
+        keys = jr.split(jr.PRNGKey(11), 10)
+        x = rng.uniform(1, 10, (10, 20)).astype(np.float32)                              # tests/test_layers.py:43
+        bfr = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+        for name, mod, ref in (("drop_path_global", layers.DropPath(0.5, mode="global"), lambda v, k: O.drop_path(v, 0.5, "global", k)),
+                               ("drop_path_local", layers.DropPath(0.5, mode="local"), lambda v, k: O.drop_path(v, 0.5, "local", k)),
+                               ("dropout_vec", nn.Dropout(0.3), lambda v, k: O.dropout(v, 0.3, k))):
+            with eqv.precision("fp32"):
+                got = eqv.filter_jit(lambda m, a, k: eqv.vmap(m)(a, key=k))(mod, x, keys).cpu().numpy()
+                idn = eqv.vmap(eqv.tree_inference(mod, True))(x, key=keys).cpu().numpy()
+            want = np.stack([ref(x[i], keys[i]) for i in range(10)])
+            good = got.shape == (10, 20) and bool((got == 0).any()) and bool((idn != 0).all()) and np.array_equal(got, want)
+            info[name] = {"bit_identical": bool(np.array_equal(got, want)), "zeros": int((got == 0).sum())}
+            ok = ok and good
+        # feature maps (C,H,W) in bf16: the mask follows the LOGICAL (C,H,W) order although the device layout is NHWC
+        xm = bfr(rng.standard_normal((6, 24, 5, 7)))
+        km = jr.split(jr.PRNGKey(12), 6)
+        with eqv.precision("bf16"):
+            got = eqv.vmap(nn.Dropout(0.4))(xm, key=km).cpu().numpy()
+            gl = eqv.vmap(layers.DropPath(0.5, mode="local"))(xm, key=km).cpu().numpy()
+        want = np.stack([bfr(O.dropout(xm[i], 0.4, km[i])) for i in range(6)])
+        wl = np.stack([bfr(O.drop_path(xm[i], 0.5, "local", km[i])) for i in range(6)])
+        info["dropout_map_bf16"] = {"bit_identical": bool(np.array_equal(got, want)), "kept": float((got != 0).mean())}
+        info["drop_path_local_map_bf16"] = {"bit_identical": bool(np.array_equal(gl, wl))}
+        # token matrices (N,D), odd element count (the padded counter)
+        xs = rng.standard_normal((3, 7, 9)).astype(np.float32)
+        ksq = jr.split(jr.PRNGKey(13), 3)
+        with eqv.precision("fp32"):
+            got = eqv.vmap(nn.Dropout(0.5))(xs, key=ksq).cpu().numpy()
+        want = np.stack([O.dropout(xs[i], 0.5, ksq[i]) for i in range(3)])
+        info["dropout_seq_odd"] = {"bit_identical": bool(np.array_equal(got, want))}
+        ok = ok and all(v["bit_identical"] for v in info.values())
+        info.update(ok=ok, err=0.0 if ok else 1.0, lim=0.0)
+        return info
+    return run
+
+
+def alexnet_train_case(B=2):
+    """AlexNet outside inference mode: the classifier's Dropout(0.5) pair is live (alexnet.py:63-68); keys split as the reference
+    splits them (alexnet.py:80-84 + nn.Sequential) -> the same activations dropped as in the reference -> logits within the
+    bf16 tolerance of the oracle that applies the same masks."""
+    def run():
+        import eqxvision_amd as eqv
+        sd = S.alexnet_state(1, 1000)
+        x = S.synthetic_images(B, 224, seed=0)
+        net = eqv.tree_inference(_load(eqv.models.alexnet, sd), False)
+        keys = eqv.random.split(eqv.random.PRNGKey(21), B)
+        with eqv.precision("bf16"):
+            fwd = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k))
+            got = fwd(net, x, keys).cpu().numpy()
+            again = fwd(net, x, eqv.random.split(eqv.random.PRNGKey(22), B)).cpu().numpy()
+        ref = np.stack([OM.alexnet_forward(sd, x[i], bf16=True, key=keys[i]) for i in range(B)])
+        inf = np.stack([OM.alexnet_forward(sd, x[i], bf16=True) for i in range(B)])
+        out = _cmp(got, ref, 1e-2, scaled=True)
+        out["differs_from_inference"] = float(np.abs(got - inf).max())
+        out["other_keys_differ"] = float(np.abs(got - again).max())
+        out["ok"] = out["ok"] and out["differs_from_inference"] > 10 * out["err"] and out["other_keys_differ"] > 10 * out["err"]
+        return out
+    return run
+
+
 def alexnet_case(B, dtype="bf16", features_only=False):
     def run():
         import eqxvision_amd as eqv
@@ -406,6 +476,33 @@ def swin_case(size, embed, depths, heads, B, classes=10, dtype="bf16", full_ref=
     return run
 
 
+def swin_train_case(size=56, embed=32, depths=(2, 2), heads=(2, 4), B=4, classes=10, sd_prob=0.5):
+    """Swin outside inference mode: stochastic depth is live (DropPath(mode="local"), one draw per channel, rate growing with the
+    block index: swin.py:545, 572-578, 726-730); keys split as the reference splits them -> the oracle drops the same channels."""
+    def run():
+        import warnings
+        import eqxvision_amd as eqv
+        sd = S.swin_state(1, (4, 4), embed, depths, heads, (7, 7), 4.0, classes)
+        x = S.synthetic_images(B, size, seed=0)
+        fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(eqv.models.SwinTransformer(**kw), torch_weights)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            net = _load(fac, sd, patch_size=[4, 4], embed_dim=embed, depths=list(depths), num_heads=list(heads),
+                        window_size=[7, 7], num_classes=classes, stochastic_depth_prob=sd_prob)
+        net = eqv.tree_inference(net, False)
+        keys = eqv.random.split(eqv.random.PRNGKey(31), B)
+        with eqv.precision("bf16"):
+            got = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k))(net, x, keys).cpu().numpy()
+        ref = np.stack([OM.swin_forward(sd, x[i], (4, 4), depths, heads, (7, 7), bf16=True, key=keys[i],
+                                        stochastic_depth_prob=sd_prob) for i in range(B)])
+        inf = np.stack([OM.swin_forward(sd, x[i], (4, 4), depths, heads, (7, 7), bf16=True) for i in range(B)])
+        out = _cmp(got, ref, 1e-2)
+        out["differs_from_inference"] = float(np.abs(got - inf).max())
+        out["ok"] = out["ok"] and out["differs_from_inference"] > 5 * max(out["err"], 1e-3)
+        return out
+    return run
+
+
 def jit_case():
     """filter_jit: the Python body runs once; replays (call 2 = hipGraph capture, call 3 = graph launch)
     with NEW inputs must equal eager results (reference semantics: tests/test_models/test_vit.py:35)."""
@@ -675,6 +772,9 @@ def pth_reader_case():
 def all_cases(full=True):
     c = [("model/resnet_tiny_bottleneck", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2)),
          ("model/resnet18_64px", resnet_case("basic", (2, 2, 2, 2), 64, 2)),
+         ("model/stochastic_layers_jax_bitstream", stochastic_layers_case()),
+         ("model/alexnet_train_mode_dropout", alexnet_train_case()),
+         ("model/swin_train_mode_stochastic_depth", swin_train_case()),
          ("model/resnet18_train_mode_bn", resnet_train_case()),
          ("model/resnet18_train_mode_bn_under_filter_jit", resnet_train_case(jit=True)),
          ("model/resnext_tiny_32x4d", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2, groups=32, width_per_group=4)),

@@ -368,3 +368,40 @@ def test_intermediate_layer_getter_structure():
     g = intermediate_layer_getter(r, lambda m: [m.layer2, m.layer4])
     assert type(g.model.layer2).__name__ == "IntermediateWrapper" and g.model.layer2.layer is r.layer2
     assert g.model.layer1.layers[0].conv1.weight is r.layer1.layers[0].conv1.weight      # leaves are shared
+
+
+def test_prng_is_jax_threefry():
+    """eqxvision_amd.random: Threefry-2x32 known answers (Random123 kat_vectors), and the two values JAX's documentation prints
+    for PRNGKey(0): split -> [[4146024105, 967050713], [2718843009, 1272950319]], uniform -> 0.41845703."""
+    from eqxvision_amd import random as jr
+    for k, c, e in (((0, 0), (0, 0), (0x6B200159, 0x99BA4EFE)),
+                    ((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF), (0x1CB996FC, 0xBB002BE7)),
+                    ((0x13198A2E, 0x03707344), (0x243F6A88, 0x85A308D3), (0xC4923A9C, 0x483DF7A0))):
+        o = jr.threefry2x32(k[0], k[1], [c[0]], [c[1]])
+        assert (int(o[0][0]), int(o[1][0])) == e
+    assert jr.split(jr.PRNGKey(0)).tolist() == [[4146024105, 967050713], [2718843009, 1272950319]]
+    assert float(jr.uniform01(jr.PRNGKey(0), 1)[0]) == np.float32(0.41845703)
+    keys = jr.split(jr.PRNGKey(3), 6)                                   # batched keys: what vmap over the key axis computes
+    kids = jr.split(keys, 4)
+    assert kids.shape == (4, 6, 2)
+    for b in range(6):
+        np.testing.assert_array_equal(kids[:, b], jr.split(keys[b], 4))
+        np.testing.assert_array_equal(jr.bernoulli(keys, 0.3, (5, 3))[b], jr.bernoulli(keys[b], 0.3, (5, 3)))
+    assert jr.bernoulli(keys, 0.5).shape == (6,)
+    assert abs(float(jr.bernoulli(jr.PRNGKey(1), 0.3, (20000,)).mean()) - 0.3) < 0.02
+
+
+def test_stochastic_layers_need_keys_and_inference_is_identity():
+    import eqxvision_amd as eqv
+    from eqxvision_amd import layers, nn
+    x = np.ones((4, 5), np.float32)
+    for mod in (nn.Dropout(0.5), layers.DropPath(0.5), layers.DropPath(0.5, mode="local")):
+        with pytest.raises(RuntimeError):
+            mod(x, key=None)                                           # reference drop_path.py:46-49 / eqx.nn.Dropout
+        assert eqv.tree_inference(mod, True)(x, key=None) is x
+    assert nn.Dropout(0.0)(x, key=None) is x
+    from eqxvision_amd.transforms import _needs_eager
+    assert _needs_eager(nn.Sequential([nn.Linear(4, 4, key=eqv.random.PRNGKey(0)), nn.Dropout(0.5)]))
+    assert not _needs_eager(eqv.tree_inference(nn.Sequential([nn.Dropout(0.5), nn.BatchNorm(8)]), True))
+    assert _needs_eager(nn.Sequential([nn.BatchNorm(8)]))
+

@@ -205,3 +205,25 @@ def test_segmentation_and_vgg_restatements_agree_numpy_vs_torch():
         xs = S.synthetic_images(2, 28, seed=0)
         np.testing.assert_allclose(np.stack([OM.vgg_forward(sd, im, plan, bn) for im in xs]),
                                    TR.vgg_forward(sd, xs, plan, bn).numpy(), atol=1e-5)
+
+
+def test_oracle_jax_random_known_answers():
+    """oracle.np_ops' restatement of jax.random (not under /root/reference): Random123 Threefry-2x32 known-answer vectors and the
+    PRNGKey(0) values printed in JAX's documentation; dropout / drop_path follow eqx.nn.Dropout and drop_path.py:51-61."""
+    from oracle import np_ops as O
+    assert O.threefry_2x32([0, 0], [0, 0]).tolist() == [0x6B200159, 0x99BA4EFE]
+    assert O.threefry_2x32([0xFFFFFFFF, 0xFFFFFFFF], [0xFFFFFFFF, 0xFFFFFFFF]).tolist() == [0x1CB996FC, 0xBB002BE7]
+    assert O.threefry_2x32([0x13198A2E, 0x03707344], [0x243F6A88, 0x85A308D3]).tolist() == [0xC4923A9C, 0x483DF7A0]
+    assert O.jax_split(np.array([0, 0], np.uint32)).tolist() == [[4146024105, 967050713], [2718843009, 1272950319]]
+    assert float(O.jax_uniform(np.array([0, 0], np.uint32))) == np.float32(0.41845703)
+    key = O.jax_split(np.array([0, 42], np.uint32), 3)[1]
+    x = np.arange(1, 61, dtype=np.float32).reshape(3, 4, 5)
+    y = O.dropout(x, 0.25, key)
+    kept = y != 0
+    assert 0.5 < kept.mean() < 0.95 and np.allclose(y[kept], x[kept] / 0.75)
+    g = O.drop_path(x, 0.5, "global", key)
+    assert (g == 0).all() or np.allclose(g, x * 2)
+    l = O.drop_path(x, 0.5, "local", key)
+    per_row = (l.reshape(3, -1) != 0).all(1) | (l.reshape(3, -1) == 0).all(1)      # whole first-axis slices are kept or dropped
+    assert per_row.all()
+
