@@ -378,7 +378,9 @@ def segmentation_forward(sd, x, kind="fcn", layers=(3, 4, 6, 3), aux=True, bf16=
 
 
 # ---------------------------------------------------------------- vit.py:139-157, 261-273
-def vit_block(sd, q, x, p, num_heads, return_attention=False):
+def vit_block(sd, q, x, p, num_heads, return_attention=False, drop_path=0.0, key=None):
+    """`key` given with drop_path > 0 (training mode): x + DropPath(y, key=keys[1]) / keys[3], keys = split(key, 4) (vit.py:148-156);
+    DropPath mode "global": one draw for the whole sample."""
     y = q(O.layernorm_rows(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"]))       # vit.py:149
     N, C = y.shape
     dh = C // num_heads
@@ -393,10 +395,15 @@ def vit_block(sd, q, x, p, num_heads, return_attention=False):
         return attn[None]                                                            # (1, heads, N, N)
     a = q(np.transpose(q(attn) @ vv if q.on else attn @ vv, (1, 0, 2)).reshape(N, C))  # vit.py:73
     y = a @ q(sd[p + ".attn.proj.weight"]).T + sd[p + ".attn.proj.bias"]             # vit.py:74
+    ks = None if key is None or drop_path == 0.0 else O.jax_split(key, 4)
+    if ks is not None:
+        y = O.drop_path(q(y), drop_path, "global", ks[1])
     x = q(x + y)                                                                     # vit.py:153
     y = q(O.layernorm_rows(x, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"]))       # vit.py:154
     h = q(O.gelu_tanh(y @ q(sd[p + ".mlp.fc1.weight"]).T + sd[p + ".mlp.fc1.bias"]))  # mlps.py:61-62
     y = h @ q(sd[p + ".mlp.fc2.weight"]).T + sd[p + ".mlp.fc2.bias"]                 # mlps.py:64
+    if ks is not None:
+        y = O.drop_path(q(y), drop_path, "global", ks[3])
     return q(x + y)                                                                  # vit.py:156
 
 
@@ -409,11 +416,15 @@ def vit_tokens(sd, q, x, patch):
     return q(np.concatenate([cls, t], 0) + pos)                                      # vit.py:269
 
 
-def vit_forward(sd, x, patch=16, num_heads=12, depth=12, bf16=False):
+def vit_forward(sd, x, patch=16, num_heads=12, depth=12, bf16=False, key=None, drop_path_rate=0.0):
+    """`key` given: TRAINING mode with stochastic depth: block i drops with linspace(0, drop_path_rate, depth)[i] (vit.py:236-246)
+    from split(key, depth)[i] (vit.py:267-271)."""
     q = _Q(bf16)
     x = vit_tokens(sd, q, x, patch)
+    bkeys = None if key is None else O.jax_split(key, depth)
+    dpr = np.linspace(0, drop_path_rate, depth)
     for i in range(depth):
-        x = vit_block(sd, q, x, f"blocks.{i}", num_heads)
+        x = vit_block(sd, q, x, f"blocks.{i}", num_heads, drop_path=float(dpr[i]), key=None if bkeys is None else bkeys[i])
     x = q(O.layernorm_rows(x, sd["norm.weight"], sd["norm.bias"]))                   # vit.py:272
     if "fc.weight" in sd:
         return O.linear(x[0], q(sd["fc.weight"]), sd["fc.bias"])                     # vit.py:273

@@ -503,6 +503,28 @@ def swin_train_case(size=56, embed=32, depths=(2, 2), heads=(2, 4), B=4, classes
     return run
 
 
+def vit_train_case(img=32, patch=8, dim=64, depth=4, heads=2, B=4, classes=10, rate=0.6):
+    """ViT outside inference mode with drop_path_rate > 0: DropPath(mode="global") per block, rates linspace(0, rate, depth), keys
+    split per block and 4 ways inside (vit.py:148-156, 236-246, 267-271) -> the oracle drops the same residual branches."""
+    def run():
+        import eqxvision_amd as eqv
+        sd = S.vit_state(1, img, patch, dim, depth, heads, 4, classes)
+        x = S.synthetic_images(B, img, seed=0)
+        fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(eqv.models.VisionTransformer(**kw), torch_weights)
+        net = eqv.tree_inference(_load(fac, sd, img_size=img, patch_size=patch, embed_dim=dim, depth=depth, num_heads=heads,
+                                       num_classes=classes, drop_path_rate=rate), False)
+        keys = eqv.random.split(eqv.random.PRNGKey(41), B)
+        with eqv.precision("bf16"):
+            got = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k))(net, x, keys).cpu().numpy()
+        ref = np.stack([OM.vit_forward(sd, x[i], patch, heads, depth, bf16=True, key=keys[i], drop_path_rate=rate) for i in range(B)])
+        inf = np.stack([OM.vit_forward(sd, x[i], patch, heads, depth, bf16=True) for i in range(B)])
+        out = _cmp(got, ref, 1e-2)
+        out["differs_from_inference"] = float(np.abs(got - inf).max())
+        out["ok"] = out["ok"] and out["differs_from_inference"] > 5 * max(out["err"], 1e-3)
+        return out
+    return run
+
+
 def jit_case():
     """filter_jit: the Python body runs once; replays (call 2 = hipGraph capture, call 3 = graph launch)
     with NEW inputs must equal eager results (reference semantics: tests/test_models/test_vit.py:35)."""
@@ -775,6 +797,7 @@ def all_cases(full=True):
          ("model/stochastic_layers_jax_bitstream", stochastic_layers_case()),
          ("model/alexnet_train_mode_dropout", alexnet_train_case()),
          ("model/swin_train_mode_stochastic_depth", swin_train_case()),
+         ("model/vit_train_mode_stochastic_depth", vit_train_case()),
          ("model/resnet18_train_mode_bn", resnet_train_case()),
          ("model/resnet18_train_mode_bn_under_filter_jit", resnet_train_case(jit=True)),
          ("model/resnext_tiny_32x4d", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2, groups=32, width_per_group=4)),
