@@ -621,6 +621,37 @@ def moments_case(rows, C, dtype="bf16", seed=0):
     return run
 
 
+def dropout_case(B, per, C, chw, p, dtype="bf16", seed=0):
+    """mv_dropout_fwd vs the oracle's eqx.nn.Dropout on JAX's bit stream (oracle.np_ops.dropout), bit for bit; x is NHWC
+    [B][per / C][C], the mask indexed in the LOGICAL (C, per / C) order when `chw`."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        keys = np.stack([O.jax_split(np.array([seed, b], np.uint32), 2)[1] for b in range(B)])
+        x = rng.standard_normal((B, per // C, C)).astype(np.float32)
+        if dtype == "bf16":
+            x = bf(x)
+        xd = dev(x, dtype)
+        kd = torch.from_numpy(keys.view(np.int32)).cuda()
+        y = torch.empty_like(xd)
+        L.call("mv_dropout_fwd", xd.data_ptr(), kd.data_ptr(), y.data_ptr(), B, per, C, 1 if chw else 0, float(1.0 - p),
+               1 if dtype == "bf16" else 0, _stream())
+        torch.cuda.synchronize()
+        want = []
+        for b in range(B):
+            logical = x[b].T if chw else x[b]                   # (C, HW) or the physical order
+            r = O.dropout(logical, p, keys[b])
+            want.append(r.T if chw else r)
+        want = np.stack(want)
+        if dtype == "bf16":
+            want = bf(want)
+        got = host(y)
+        same = bool(np.array_equal(got, want))
+        return {"ok": same, "err": 0.0 if same else float(np.abs(got - want).max()), "lim": 0.0, "kept": float((got != 0).mean()),
+                "kernel": L.last_kernel()}
+    return run
+
+
 def ln_mlp_case(M, stream="fp32", seed=0, C=96, Hd=384):
     """mv_ln_mlp_fwd (LayerNorm -> fc1 -> GELU -> fc2 -> + x, one launch) vs the un-fused float64 restatement
     (swin.py:572-578 second line, mlps.py:54-66) with the affine LayerNorm applied the reference's way; the kernel gets the
@@ -1142,8 +1173,19 @@ def fuzz_family_cases(n, seed=0):
     i = 0
     while len(out) < n:
         i += 1
-        k = int(rng.integers(0, 4))
+        k = int(rng.integers(0, 6))
         sd = 4000 + i
+        if k == 4:            # training-mode BatchNorm moments: widths of every family, few and many rows
+            C = int(rng.choice([8, 16, 24, 40, 64, 96, 120, 256, 672, 1280, 2048]))
+            out.append((f"fuzzf/s{seed}_moments_C{C}_{i}", moments_case(int(rng.integers(1, 40000)), C, str(rng.choice(["bf16", "fp32"])), seed=sd)))
+            continue
+        if k == 5:            # training-mode Dropout: even / odd element counts, logical (C,H,W) or physical order
+            C = int(rng.choice([1, 3, 8, 21, 64, 100]))
+            hw = int(rng.integers(1, 300))
+            out.append((f"fuzzf/s{seed}_dropout_C{C}_hw{hw}_{i}", dropout_case(int(rng.integers(1, 5)), hw * C, C, bool(rng.random() < 0.5),
+                                                                            float(rng.choice([0.1, 0.5, 0.9])),
+                                                                            str(rng.choice(["bf16", "fp32"])), seed=sd)))
+            continue
         if k == 0:
             C = int(rng.choice([8, 16, 24, 40, 72, 96, 120, 184, 240, 480, 672, 960]))
             R = int(rng.choice([3, 3, 5, 7]))
@@ -1316,6 +1358,9 @@ def all_cases():
           ("moments/c2048_few_rows", moments_case(8 * 7 * 7, 2048, "bf16", seed=551)),
           ("moments/c96_fp32_ragged", moments_case(12345, 96, "fp32", seed=552)),
           ("moments/c8_one_row", moments_case(1, 8, "fp32", seed=553)),
+          ("dropout/map_chw_bf16", dropout_case(3, 24 * 35, 24, True, 0.4, "bf16", seed=560)),
+          ("dropout/rows_odd_count_fp32", dropout_case(2, 7 * 9, 9, False, 0.5, "fp32", seed=561)),
+          ("dropout/one_element", dropout_case(4, 1, 1, False, 0.5, "fp32", seed=562)),
           ("ln_mlp/swin_stage0_f32stream", ln_mlp_case(8 * 56 * 56, "fp32", seed=520)),
           ("ln_mlp/bf16stream_ragged", ln_mlp_case(4096 + 77, "bf16", seed=521)),
           ("ln_mlp/f32stream_many_tiles", ln_mlp_case(70001, "fp32", seed=522)),
@@ -1451,5 +1496,5 @@ def all_cases():
           ("misc/affine_cls", misc_case("affine_cls"))]
     c += fuzz_cases(24, seed=3) + fuzz_cases(16, seed=4, mfma_only=True)      # default dispatch, random shapes
     c += fuzz_misc_cases(24, seed=5)
-    c += fuzz_family_cases(28, seed=6)
+    c += fuzz_family_cases(42, seed=6)
     return c
