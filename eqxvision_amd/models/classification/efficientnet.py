@@ -98,7 +98,8 @@ class _MBConv(Module):
         sd = self.stochastic_depth
         if sd.inference or sd.p == 0.0:
             return _residual_tail(self.block, x, key)
-        return ops.add(sd(self.block(x, key=key), key=key), x)
+        keys = [None, None] if key is None else jr.split(key, 2)          # reference :181-184 / :261-264
+        return ops.add(sd(self.block(x, key=keys[0]), key=keys[1]), x)
 
 
 class _FusedMBConv(Module):
@@ -133,7 +134,8 @@ class _FusedMBConv(Module):
         sd = self.stochastic_depth
         if sd.inference or sd.p == 0.0:
             return _residual_tail(self.block, x, key)
-        return ops.add(sd(self.block(x, key=key), key=key), x)
+        keys = [None, None] if key is None else jr.split(key, 2)          # reference :181-184 / :261-264
+        return ops.add(sd(self.block(x, key=keys[0]), key=keys[1]), x)
 
 
 class EfficientNet(Module):
@@ -180,11 +182,16 @@ class EfficientNet(Module):
     def __call__(self, x, *, key):
         if key is None:                                  # the reference splits the key first thing (:392)
             raise RuntimeError("The model requires a PRNGKey.")
-        return self._forward(x)
+        return self._forward(x, key)
 
     @boundary
-    def _forward(self, x):
+    def _forward(self, x, key=None):
         from ..._act import head_fp32
+        from ...transforms import _needs_eager
+        if key is not None and _needs_eager(self):       # training mode: stochastic depth in the blocks, the classifier's Dropout
+            keys = jr.split(key, 2)                      # reference :398-403
+            x = self.features(x, key=keys[0])
+            return self.classifier(ops.flatten(self.avgpool(x)), key=keys[1])
         x = self.features(x)
         if type(self.avgpool) is nn.AdaptiveAvgPool2d and head_fp32():
             x = ops.adaptive_avgpool2d(x, self.avgpool.target_shape, out_fp32=True)

@@ -92,11 +92,16 @@ class MobileNetV2(Module):
     def __call__(self, x, *, key):
         if key is None:                                  # the reference splits the key first thing (mobilenetv2.py:222)
             raise RuntimeError("The model requires a PRNGKey.")
-        return self._forward(x)
+        return self._forward(x, key)
 
     @boundary
-    def _forward(self, x):
+    def _forward(self, x, key=None):
         from ..._act import head_fp32
+        from ...transforms import _needs_eager
+        if key is not None and _needs_eager(self):       # training mode: the classifier's Dropout draws from keys[2]
+            keys = jr.split(key, 3)                      # reference mobilenetv2.py:223-227
+            x = self.features(x, key=keys[0])
+            return self.classifier(ops.flatten(self.pool(x)), key=keys[2])
         x = self.features(x)
         if type(self.pool) is nn.AdaptiveAvgPool2d and head_fp32():
             x = ops.adaptive_avgpool2d(x, self.pool.target_shape, out_fp32=True)

@@ -112,10 +112,15 @@ class MobileNetV3(Module):
     def __call__(self, x, *, key):
         if key is None:                                  # the reference splits the key first thing (:240)
             raise RuntimeError("The model requires a PRNGKey.")
-        return self._forward(x)
+        return self._forward(x, key)
 
     @boundary
-    def _forward(self, x):
+    def _forward(self, x, key=None):
+        from ...transforms import _needs_eager
+        if key is not None and _needs_eager(self):       # training mode: the classifier's Dropout draws from keys[2]
+            keys = jr.split(key, 3)                      # reference mobilenetv3.py:242-246
+            x = self.features(x, key=keys[0])
+            return self.classifier(ops.flatten(self.avgpool(x)), key=keys[2])
         x = self.features(x)
         x = self.avgpool(x)
         x = ops.flatten(x)

@@ -525,6 +525,46 @@ def vit_train_case(img=32, patch=8, dim=64, depth=4, heads=2, B=4, classes=10, r
     return run
 
 
+def cna_family_train_case():
+    """Training-mode BatchNorm inside the ConvNormActivation families (depthwise / odd-width / squeeze-excitation stacks: the
+    Sequential peephole may not fold a BatchNorm that is not in inference mode): a reduced MobileNetV2 takes two training steps;
+    every BatchNorm's running statistics must have moved (EMA: 0.01 of the batch moments per step), and an INFERENCE forward of the
+    same modules must equal the oracle's inference forward on the exported state (statistics refolded into every kernel's
+    epilogue: the folds are keyed on the shared state's version)."""
+    def run():
+        import eqxvision_amd as eqv
+        st = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 2, 1))
+        sd = S.mobilenet_v2_state(1, 10, st, last=64)
+        from eqxvision_amd._module import tree_at
+        from eqxvision_amd.layers import ConvNormActivation
+
+        def fac(torch_weights=None, **k):
+            net = eqv.models.MobileNetV2(**k)
+            cin = net.features.layers[-1].layers[0].in_channels
+            net = tree_at(lambda m: (m.features.layers[-1], m.classifier.layers[-1]), net,
+                          (ConvNormActivation(cin, 64, kernel_size=1, key=eqv.random.PRNGKey(5)),
+                           eqv.nn.Linear(64, 10, key=eqv.random.PRNGKey(6))))
+            return eqv.utils.load_torch_weights(net, torch_weights)
+        net_inf = _load(fac, sd, num_classes=10, inverted_residual_setting=[list(r) for r in st])
+        x = S.synthetic_images(6, 64, seed=0)
+        with eqv.precision("bf16"):
+            before = eqv.vmap(net_inf, axis_name="batch")(x, key=_keys(6)).cpu().numpy()      # folds of the LOADED statistics cached
+            net = eqv.tree_inference(net_inf, False)
+            for step in range(2):
+                out = eqv.vmap(net, axis_name="batch")(S.synthetic_images(6, 64, seed=step + 1), key=_keys(6))
+            torch.cuda.synchronize()
+            after = eqv.vmap(net_inf, axis_name="batch")(x, key=_keys(6)).cpu().numpy()
+        sd2 = {k: np.asarray(v) for k, v in eqv.utils.state_dict(net_inf).items()}
+        moved = [float(np.abs(sd2[k] - sd[k]).max()) for k in sd if k.endswith("running_mean")]
+        ref = np.stack([OM.mobilenet_v2_forward(sd2, im, st, bf16=True) for im in x])
+        info = _cmp(after, ref, 1e-2)
+        info.update(batchnorms=len(moved), min_running_mean_shift=min(moved), logits_changed=float(np.abs(after - before).max()),
+                    train_logits_finite=bool(torch.isfinite(out).all()))
+        info["ok"] = info["ok"] and min(moved) > 0.0 and info["logits_changed"] > 0.0 and info["train_logits_finite"]
+        return info
+    return run
+
+
 def jit_case():
     """filter_jit: the Python body runs once; replays (call 2 = hipGraph capture, call 3 = graph launch)
     with NEW inputs must equal eager results (reference semantics: tests/test_models/test_vit.py:35)."""
@@ -798,6 +838,7 @@ def all_cases(full=True):
          ("model/alexnet_train_mode_dropout", alexnet_train_case()),
          ("model/swin_train_mode_stochastic_depth", swin_train_case()),
          ("model/vit_train_mode_stochastic_depth", vit_train_case()),
+         ("model/mobilenet_v2_train_mode_bn_refold", cna_family_train_case()),
          ("model/resnet18_train_mode_bn", resnet_train_case()),
          ("model/resnet18_train_mode_bn_under_filter_jit", resnet_train_case(jit=True)),
          ("model/resnext_tiny_32x4d", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2, groups=32, width_per_group=4)),
