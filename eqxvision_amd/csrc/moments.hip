@@ -3,12 +3,12 @@
 //   batch_mean[c] = pmean(mean(x[c]));  batch_var[c] = pmean(mean((x[c] - batch_mean[c])^2))      (two passes, like the reference)
 // One launch produces out[c] = sum_rows (x[r][c] - shift[c])^p, p = 1 (shift = NULL) or 2; the caller divides by the global row
 // count after the cross-rank sum (mv_allreduce_sum_f32).  HBM-bound: rows * C * sizeof(T) bytes read once per pass.
-// Deterministic: block b reduces rows b, b + G, ... into partial[b][C] (fixed order), a second kernel adds the G partials in order.
+// Deterministic: block b reduces rows b, b + G, ... into partial[b][C] (fixed order), a second kernel adds the G partials in a fixed order.
 #include "mfma_common.h"
 
 namespace mv {
 
-constexpr int MOM_BLOCKS = 512;
+constexpr int MOM_BLOCKS = 1024;                           // 4 blocks of 4 waves per CU: enough loads in flight to stream HBM
 
 template <typename T>
 __global__ __launch_bounds__(256) void moments_partial_kernel(const T* x, const float* shift, float* partial, long long rows, int C,
@@ -24,15 +24,30 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const T* x, const 
 #pragma unroll
             for (int e = 0; e < 8; ++e) sh[e] = shift[v * 8 + e];
         }
-        for (long long r = (long long)blockIdx.x * RS + rs; r < rows; r += (long long)gridDim.x * RS) {
-            const T* p = x + r * C + v * 8;
-            const float4 a = Out4<T>::ld(p), b = Out4<T>::ld(p + 4);
+        const long long step = (long long)gridDim.x * RS;
+        long long r = (long long)blockIdx.x * RS + rs;
+        auto accum = [&](const float4& a, const float4& b) {
             const float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float d = xv[e] - sh[e];
                 acc[e] += sq ? d * d : d;
             }
+        };
+        for (; r + 3 * step < rows; r += 4 * step) {        // four rows in flight per thread (the summation order stays fixed)
+            float4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T* p = x + (r + u * step) * C + v * 8;
+                a[u] = Out4<T>::ld(p);
+                b[u] = Out4<T>::ld(p + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accum(a[u], b[u]);
+        }
+        for (; r < rows; r += step) {
+            const T* p = x + r * C + v * 8;
+            accum(Out4<T>::ld(p), Out4<T>::ld(p + 4));
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[rs * C + v * 8 + e] = acc[e];
@@ -45,12 +60,29 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const T* x, const 
     }
 }
 
-__global__ void moments_final_kernel(const float* partial, float* out, int G, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] = sum over the G block partials, always in the same order: 16 slices of the partials per channel, then the 16 slice sums
+__global__ __launch_bounds__(1024) void moments_final_kernel(const float* partial, float* out, int G, int C) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += partial[(long long)g * C + c];
-    out[c] = s;
+    if (c < C) {
+        int g = q;
+        for (; g + 48 < G; g += 64) {                       // four partials in flight; added in the order they would be one by one
+            const float a0 = partial[(long long)g * C + c], a1 = partial[(long long)(g + 16) * C + c];
+            const float a2 = partial[(long long)(g + 32) * C + c], a3 = partial[(long long)(g + 48) * C + c];
+            s = (((s + a0) + a1) + a2) + a3;
+        }
+        for (; g < G; g += 16) s += partial[(long long)g * C + c];
+    }
+    red[q][cl] = s;
+    __syncthreads();
+    if (q == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][cl];
+        out[c] = t;
+    }
 }
 
 }  // namespace mv
@@ -74,7 +106,7 @@ int mv_channel_moments_fwd(const void* x, const float* shift, float* out, float*
         return MV_E_UNSUPPORTED;
     }
     const int RS = 256 / (C >> 3);
-    long long need = (rows + RS - 1) / RS;
+    long long need = (rows + 16LL * RS - 1) / (16LL * RS);   // >= 16 row steps per block: the G x C partials stay small next to x
     const int G = (int)(need < MOM_BLOCKS ? need : MOM_BLOCKS);
     const size_t smem = (size_t)RS * C * sizeof(float);
     set_kernel_name(squared ? "channel_sqdev" : "channel_sum");
@@ -85,7 +117,7 @@ int mv_channel_moments_fwd(const void* x, const float* shift, float* out, float*
         hipLaunchKernelGGL(moments_partial_kernel<bf16_t>, dim3(G), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)x, shift, workspace,
                            (long long)rows, C, squared);
     MV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(moments_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, out, G, C);
+    hipLaunchKernelGGL(moments_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, workspace, out, G, C);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

@@ -3,7 +3,8 @@
 // (the caller vmaps over the keys).  The mask is JAX's bit stream (jax.random.bernoulli = uniform(key, shape) < q; uniform =
 // mantissa bits of Threefry-2x32 words in the counter layout of `_threefry_random_bits`, see eqxvision_amd/random.py), generated
 // here per element: element i of the LOGICAL single-sample array (row-major over the reference's (C,H,W) / (N,D) / (D,) shape)
-// is word i of the sample's stream.  HBM-bound (read x, write y); ~110 integer ops per element ride along.
+// is word i of the sample's stream.  Read x, write y; the ~110 integer operations of a Threefry call per element (55 when a call
+// serves two elements, dropout_pair_kernel) are what bounds it: 2.5 TB/s of the 4-5 a pure stream reaches.
 #include "mfma_common.h"
 
 namespace mv {
@@ -61,6 +62,101 @@ __global__ void dropout_kernel(const T* x, const uint32_t* keys, T* y, long long
     }
 }
 
+// 8 physically consecutive values per thread (16-byte accesses for bf16, 2 x 16 for fp32): C % 8 == 0, so in the NHWC / (C,H,W)
+// case they are 8 channels of one pixel -- logical indices HW apart
+template <typename T>
+__global__ void dropout_vec8_kernel(const T* x, const uint32_t* keys, T* y, long long per, int C, long long HW, int chw, float q,
+                                    long long total8) {
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total8; g += (long long)gridDim.x * blockDim.x) {
+        const long long e0 = g * 8;
+        const long long b = e0 / per, pi = e0 - b * per;
+        const uint32_t k0 = keys[2 * b], k1 = keys[2 * b + 1];
+        long long li = pi, lstep = 1;
+        if (chw) {
+            const long long hw = pi / C;
+            li = (pi - hw * C) * HW + hw;
+            lstep = HW;
+        }
+        float v[8];
+        if constexpr (sizeof(T) == 2) {
+            const uint4 u = *(const uint4*)(x + e0);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] = __uint_as_float(w[e] << 16);
+                v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+            }
+        } else {
+            const float4 a = *(const float4*)(x + e0), c = *(const float4*)(x + e0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t w = stream_word(k0, k1, (uint32_t)(li + e * lstep), (uint32_t)per);
+            const float u = __uint_as_float((w >> 9) | 0x3F800000u) - 1.0f;
+            v[e] = u < q ? v[e] / q : 0.f;
+        }
+        Out8<T>::st(y + e0, v);
+    }
+}
+
+// One Threefry call yields TWO words of the stream: those of logical elements i and i + n/2.  When n is even and the two
+// elements' 8-value vectors are both 16-byte aligned -- physically n/2 apart (row-major samples) or C/2 channels apart at the same
+// pixel ((C,H,W) samples stored NHWC: (c + C/2) * HW + hw = i + n/2) -- a thread produces both vectors from 8 calls: half the
+// integer work, which is what bounds this kernel (the plain x8 kernel runs at 1.5 TB/s).
+template <typename T>
+__global__ void dropout_pair_kernel(const T* x, const uint32_t* keys, T* y, long long per, int C, long long HW, int chw, float q,
+                                    long long pairs_per_sample, long long total_pairs) {
+    const uint32_t half = (uint32_t)(per >> 1);
+    const long long poff = chw ? (long long)(C >> 1) : (long long)half;      // physical distance of the partner vector
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total_pairs; g += (long long)gridDim.x * blockDim.x) {
+        const long long b = g / pairs_per_sample, j = g - b * pairs_per_sample;
+        long long pi, li, lstep = 1;
+        if (chw) {
+            const long long vpp = C >> 4;                                    // first-half vectors per pixel
+            const long long hw = j / vpp;
+            const long long c0 = (j - hw * vpp) * 8;
+            pi = hw * C + c0;
+            li = c0 * HW + hw;
+            lstep = HW;
+        } else {
+            pi = j * 8;
+            li = pi;
+        }
+        const uint32_t k0 = keys[2 * b], k1 = keys[2 * b + 1];
+        const T* xa = x + b * per + pi;
+        T* ya = y + b * per + pi;
+        float va[8], vb[8];
+        if constexpr (sizeof(T) == 2) {
+            const uint4 ua = *(const uint4*)xa, ub = *(const uint4*)(xa + poff);
+            const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w}, wb[4] = {ub.x, ub.y, ub.z, ub.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                va[2 * e] = __uint_as_float(wa[e] << 16); va[2 * e + 1] = __uint_as_float(wa[e] & 0xffff0000u);
+                vb[2 * e] = __uint_as_float(wb[e] << 16); vb[2 * e + 1] = __uint_as_float(wb[e] & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 a = *(const float4*)(xa + 4 * h), c = *(const float4*)(xa + poff + 4 * h);
+                va[4 * h] = a.x; va[4 * h + 1] = a.y; va[4 * h + 2] = a.z; va[4 * h + 3] = a.w;
+                vb[4 * h] = c.x; vb[4 * h + 1] = c.y; vb[4 * h + 2] = c.z; vb[4 * h + 3] = c.w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            uint32_t x0 = (uint32_t)(li + e * lstep), x1 = x0 + half;       // both < n: n is even, no padding counter
+            threefry2x32(k0, k1, x0, x1);
+            const float u0 = __uint_as_float((x0 >> 9) | 0x3F800000u) - 1.0f;
+            const float u1 = __uint_as_float((x1 >> 9) | 0x3F800000u) - 1.0f;
+            va[e] = u0 < q ? va[e] / q : 0.f;
+            vb[e] = u1 < q ? vb[e] / q : 0.f;
+        }
+        Out8<T>::st(ya, va);
+        Out8<T>::st(ya + poff, vb);
+    }
+}
+
 }  // namespace mv
 
 using namespace mv;
@@ -77,6 +173,39 @@ int mv_dropout_fwd(const void* x, const void* keys, void* y, int B, int64_t per_
     const long long total = (long long)B * per_sample;
     long long gl = (total + 255) / 256;
     const int grid = (int)(gl > 256 * 16 ? 256 * 16 : gl);
+    const bool pair_ok = chw_logical ? (C % 16 == 0) : (per_sample % 16 == 0);
+    if (pair_ok && !get_flag("dropout_scalar") && !get_flag("dropout_x8")) {
+        const long long pps = per_sample / 16, total_pairs = (long long)B * pps;
+        long long gv = (total_pairs + 255) / 256;
+        const int gridv = (int)(gv > 256 * 32 ? 256 * 32 : gv);
+        set_kernel_name("dropout_threefry_pairs");
+        if (dtype == MV_F32)
+            hipLaunchKernelGGL(dropout_pair_kernel<float>, dim3(gridv), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                               (const uint32_t*)keys, (float*)y, (long long)per_sample, C, (long long)(per_sample / C), chw_logical,
+                               keep_prob, pps, total_pairs);
+        else
+            hipLaunchKernelGGL(dropout_pair_kernel<bf16_t>, dim3(gridv), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                               (const uint32_t*)keys, (bf16_t*)y, (long long)per_sample, C, (long long)(per_sample / C), chw_logical,
+                               keep_prob, pps, total_pairs);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
+    if (C % 8 == 0 && !get_flag("dropout_scalar")) {
+        const long long total8 = total / 8;
+        long long gv = (total8 + 255) / 256;
+        const int gridv = (int)(gv > 256 * 32 ? 256 * 32 : gv);
+        set_kernel_name("dropout_threefry_x8");
+        if (dtype == MV_F32)
+            hipLaunchKernelGGL(dropout_vec8_kernel<float>, dim3(gridv), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                               (const uint32_t*)keys, (float*)y, (long long)per_sample, C, (long long)(per_sample / C), chw_logical,
+                               keep_prob, total8);
+        else
+            hipLaunchKernelGGL(dropout_vec8_kernel<bf16_t>, dim3(gridv), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                               (const uint32_t*)keys, (bf16_t*)y, (long long)per_sample, C, (long long)(per_sample / C), chw_logical,
+                               keep_prob, total8);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
     set_kernel_name("dropout_threefry");
     if (dtype == MV_F32)
         hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const uint32_t*)keys,

@@ -621,7 +621,7 @@ def moments_case(rows, C, dtype="bf16", seed=0):
     return run
 
 
-def dropout_case(B, per, C, chw, p, dtype="bf16", seed=0):
+def dropout_case(B, per, C, chw, p, dtype="bf16", seed=0, flag=None):
     """mv_dropout_fwd vs the oracle's eqx.nn.Dropout on JAX's bit stream (oracle.np_ops.dropout), bit for bit; x is NHWC
     [B][per / C][C], the mask indexed in the LOGICAL (C, per / C) order when `chw`."""
     def run():
@@ -634,8 +634,15 @@ def dropout_case(B, per, C, chw, p, dtype="bf16", seed=0):
         xd = dev(x, dtype)
         kd = torch.from_numpy(keys.view(np.int32)).cuda()
         y = torch.empty_like(xd)
-        L.call("mv_dropout_fwd", xd.data_ptr(), kd.data_ptr(), y.data_ptr(), B, per, C, 1 if chw else 0, float(1.0 - p),
-               1 if dtype == "bf16" else 0, _stream())
+        if flag:
+            L.set_flag(flag, 1)
+        try:
+            L.call("mv_dropout_fwd", xd.data_ptr(), kd.data_ptr(), y.data_ptr(), B, per, C, 1 if chw else 0, float(1.0 - p),
+                   1 if dtype == "bf16" else 0, _stream())
+            kern = L.last_kernel()
+        finally:
+            if flag:
+                L.set_flag(flag, 0)
         torch.cuda.synchronize()
         want = []
         for b in range(B):
@@ -648,7 +655,7 @@ def dropout_case(B, per, C, chw, p, dtype="bf16", seed=0):
         got = host(y)
         same = bool(np.array_equal(got, want))
         return {"ok": same, "err": 0.0 if same else float(np.abs(got - want).max()), "lim": 0.0, "kept": float((got != 0).mean()),
-                "kernel": L.last_kernel()}
+                "kernel": kern}
     return run
 
 
@@ -1361,6 +1368,11 @@ def all_cases():
           ("dropout/map_chw_bf16", dropout_case(3, 24 * 35, 24, True, 0.4, "bf16", seed=560)),
           ("dropout/rows_odd_count_fp32", dropout_case(2, 7 * 9, 9, False, 0.5, "fp32", seed=561)),
           ("dropout/one_element", dropout_case(4, 1, 1, False, 0.5, "fp32", seed=562)),
+          ("dropout/map_chw_c32_pairs", dropout_case(3, 32 * 35, 32, True, 0.3, "bf16", seed=563)),
+          ("dropout/map_chw_c32_x8", dropout_case(3, 32 * 35, 32, True, 0.3, "bf16", seed=563, flag="dropout_x8")),
+          ("dropout/map_chw_c32_scalar", dropout_case(3, 32 * 35, 32, True, 0.3, "fp32", seed=563, flag="dropout_scalar")),
+          ("dropout/rows_pairs_fp32", dropout_case(2, 48 * 16, 16, False, 0.5, "fp32", seed=564)),
+          ("dropout/vec_9216_pairs", dropout_case(5, 9216, 9216, False, 0.5, "bf16", seed=565)),
           ("ln_mlp/swin_stage0_f32stream", ln_mlp_case(8 * 56 * 56, "fp32", seed=520)),
           ("ln_mlp/bf16stream_ragged", ln_mlp_case(4096 + 77, "bf16", seed=521)),
           ("ln_mlp/f32stream_many_tiles", ln_mlp_case(70001, "fp32", seed=522)),
