@@ -14,7 +14,17 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 STATIC = os.path.join(HERE, "golden", "reference_static")
-CKPT = {"alexnet": "alexnet-owt-7be5be79.pth", "resnet18": "resnet18-f37072fd.pth", "swin_t": "swin_t-704ceda3.pth"}
+CKPT = {"alexnet": "alexnet-owt-7be5be79.pth", "resnet18": "resnet18-f37072fd.pth", "swin_t": "swin_t-704ceda3.pth",
+        # SURVEY section 8 f1 (reference eqxvision/utils.py:36-95)
+        "vgg11": "vgg11-8a719046.pth", "vgg11_bn": "vgg11_bn-6002323d.pth", "mobilenet_v2": "mobilenet_v2-b0353104.pth",
+        "mobilenet_v3_small": "mobilenet_v3_small-047dcff4.pth", "efficientnet_b0": "efficientnet_b0_rwightman-3dd342df.pth",
+        "efficientnet_v2_s": "efficientnet_v2_s-dd5fe13b.pth", "regnet_x_400mf": "regnet_x_400mf-62229a5f.pth"}
+# what the reference's own test asserts for each family: (fixture, the sub-module it runs, "close" = atol 1e-4 / "argmax")
+F1 = {"vgg11": ("vgg11_features", "features", "close"), "vgg11_bn": ("vgg11_bn_features", "features", "close"),        # test_vgg.py:31-32
+      "mobilenet_v2": ("mobilenet_v2_logits", None, "argmax"),                                                            # test_mobilenetv2.py:24
+      "mobilenet_v3_small": ("mobilenet_v3_small_logits", None, "close"),                                                 # test_mobilenetv3.py:26
+      "efficientnet_b0": ("efficientnet_b0_logits", None, "argmax"), "efficientnet_v2_s": ("efficientnet_v2_s_logits", None, "argmax"),
+      "regnet_x_400mf": ("regnet_x_400mf_logits", None, "close")}                                                          # test_regnet.py:26
 
 
 def demo_image(size=224):
@@ -50,6 +60,12 @@ def test_fixtures_and_preprocessing():
     assert a.shape == (1, 256, 6, 6) and r.shape == (1, 1000) and s.shape == (1, 1000)
     assert a.min() >= 0.0                                         # features end in ReLU + MaxPool
     assert int(r.argmax()) in np.argsort(-s[0])[:5] and int(s.argmax()) in np.argsort(-r[0])[:5]   # same bird, top-5
+    top5 = set(np.argsort(-r[0])[:5].tolist())
+    for name, (fix, sub, _) in F1.items():                        # the section-8 f1 fixtures: present, shaped, the same birds
+        a = np.load(os.path.join(STATIC, fix + ".npy"))
+        assert a.shape == ((1, 512, 7, 7) if sub == "features" else (1, 1000)) and np.isfinite(a).all(), name
+        if sub is None:
+            assert len(top5 & set(np.argsort(-a[0])[:5].tolist())) >= 2, name
 
 
 def _oracle_state(path):
@@ -102,3 +118,28 @@ def test_hip_path_vs_reference_golden(name):
         assert np.allclose(got, np.load(os.path.join(STATIC, "resnet18_logits.npy")), atol=1e-3)
     else:
         assert int(got.argmax()) == int(np.load(os.path.join(STATIC, "swin_t_logits.npy")).argmax())
+
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(F1))
+def test_hip_path_f1_families_vs_reference_golden(name):
+    """SURVEY section 8 f1 families on the HIP path (fp32 mode) against the reference's goldens, each with the assertion the
+    reference's own test makes (tests/test_models/test_{vgg,mobilenetv2,mobilenetv3,efficientnet,regnet}.py)."""
+    import torch
+    import eqxvision_amd as eqv
+    path = _ckpt(name)
+    fix, sub, how = F1[name]
+    eqv.set_compute_dtype("fp32")
+    try:
+        net = eqv.tree_inference(getattr(eqv.models, name)(torch_weights=path), True)
+        x = torch.from_numpy(demo_image(224)).cuda()
+        keys = eqv.random.split(eqv.random.PRNGKey(0), 1)
+        got = eqv.vmap(getattr(net, sub) if sub else net, axis_name="batch")(x, key=keys).float().cpu().numpy()
+    finally:
+        eqv.set_compute_dtype("bf16")
+    want = np.load(os.path.join(STATIC, fix + ".npy"))
+    if how == "close":
+        assert np.allclose(got, want, atol=1e-3)
+    else:
+        assert int(got.argmax()) == int(want.argmax())
