@@ -36,3 +36,9 @@ by = 2.0 * M * (C + 2 * K + N2)
 print(f"fused   [{L.last_kernel()}]: {us:.1f} us  ({by/us/1e3:.0f} GB/s algorithmic, {2.0*M*K*(C+N2)/us/1e6:.0f} TFLOP/s)")
 us = t(unfused)
 print(f"unfused (two launches): {us:.1f} us  ({2.0*M*(C+3*K+N2)/us/1e3:.0f} GB/s of their own traffic)")
+for extra in sys.argv[5:]:                      # e.g. chain_stream_w4=1: the same launch under a library switch
+    k, v = extra.split("=")
+    L.set_flag(k, int(v))
+    us = t(fused)
+    print(f"fused {extra} [{L.last_kernel()}]: {us:.1f} us  ({by/us/1e3:.0f} GB/s algorithmic)")
+    L.set_flag(k, 0)
