@@ -35,7 +35,8 @@ def _is_array(x) -> bool:
 def vmap(fn: Callable, in_axes=0, out_axes=0, axis_name=None, **_ignored) -> Callable:
     """Map `fn` over axis 0 of its array arguments.  `in_axes` may be an int/None or a tuple with
     one entry per positional argument (None = broadcast, as in tests/test_models/test_vit.py:44).
-    `axis_name` only matters for BatchNorm's training-mode `pmean`, which is out of scope."""
+    `axis_name` only matters for BatchNorm's training-mode `pmean`: the batch axis is physical here, so the batch statistics are
+    taken over it directly, and over the data-parallel ranks when the module names an axis (ops.bn_train_update)."""
 
     @functools.wraps(fn)
     def batched(*args, **kwargs):
@@ -50,8 +51,9 @@ def vmap(fn: Callable, in_axes=0, out_axes=0, axis_name=None, **_ignored) -> Cal
                 call_args.append(wrap(a, batched=True))
             else:
                 raise NotImplementedError("vmap: only in_axes 0/None are supported")
-        # `key=keys` (B,2) and other keyword arrays are passed through untouched: in inference they are
-        # dead values; modules only check `key is None` like the reference (resnet.py:341-342).
+        # `key=keys` (B,2) and other keyword arrays are passed through untouched: in inference they are dead values (modules only
+        # check `key is None` like the reference, resnet.py:341-342); training-mode Dropout / DropPath split them per sample
+        # (random.split on a [B,2] array) and draw their masks from them.
         out = fn(*call_args, **kwargs)
         return _unwrap(out, True)
 
