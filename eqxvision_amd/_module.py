@@ -21,20 +21,36 @@ class StateIndex:
     """Stand-in for `eqx.experimental.StateIndex`: a mutable slot holding BatchNorm running
     statistics outside the parameter leaves (reference utils.py:203-218)."""
 
-    __slots__ = ("_value", "version")
+    __slots__ = ("_value", "version", "_dev", "_dev_newer")
 
     def __init__(self, value=None):
         self._value = value
-        self.version = 0            # bumped by every assignment: weights prepared with the old statistics folded in are stale
+        self.version = 0            # bumped by every update: weights prepared with the old statistics folded in are stale
+        self._dev = None            # device copy of the statistics (training-mode steps update THIS, ops.bn_train_update)
+        self._dev_newer = False     # ... and the host value is fetched when somebody asks for it
 
     @property
     def value(self):
+        if self._dev_newer:
+            self._value = tuple(t.cpu().numpy() for t in self._dev)
+            self._dev_newer = False
         return self._value
 
     @value.setter
     def value(self, v):
         self._value = v
+        self._dev, self._dev_newer = None, False
         self.version += 1
+
+    def device_updated(self, tensors):
+        """A training-mode step rewrote the statistics on the device: `tensors` are the current values."""
+        self._dev, self._dev_newer = tuple(tensors), True
+        self.version += 1
+
+    def __copy__(self):
+        new = StateIndex(self.value)
+        new.version = self.version
+        return new
 
     def __repr__(self):
         return f"StateIndex({'set' if self.value is not None else 'unset'})"

@@ -85,6 +85,34 @@ __global__ __launch_bounds__(1024) void moments_final_kernel(const float* partia
     }
 }
 
+// mean[c] = sum[c] / n, n from the host (one rank) or from the device (the all-reduced row count of ragged shards)
+__global__ void bn_mean_kernel(const float* sum, const float* count_dev, float count_host, float* mean, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) mean[c] = sum[c] / (count_dev ? count_dev[0] : count_host);
+}
+
+// The rest of the training-mode update, on the device (no host round trip between the launches of a step):
+//   var = sqdev / n;  first call: running = (mean, var), else running = (1 - momentum) * batch + momentum * running (in place);
+//   scale = weight / sqrt(running_var + eps), shift = bias - running_mean * scale      -- what the normalisation launch applies
+__global__ void bn_ema_fold_kernel(const float* sqdev, const float* mean, const float* count_dev, float count_host, float* run_mean,
+                                   float* run_var, const float* weight, const float* bias, float* scale, float* shift, float momentum,
+                                   float eps, int first_time, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float var = sqdev[c] / (count_dev ? count_dev[0] : count_host);
+    float rm = mean[c], rv = var;
+    if (!first_time) {
+        rm = (1.f - momentum) * rm + momentum * run_mean[c];
+        rv = (1.f - momentum) * rv + momentum * run_var[c];
+    }
+    run_mean[c] = rm;
+    run_var[c] = rv;
+    const float inv = 1.0f / sqrtf(rv + eps);
+    const float sc = (weight ? weight[c] : 1.f) * inv;
+    scale[c] = sc;
+    shift[c] = (bias ? bias[c] : 0.f) - rm * sc;
+}
+
 }  // namespace mv
 
 using namespace mv;
@@ -118,6 +146,26 @@ int mv_channel_moments_fwd(const void* x, const float* shift, float* out, float*
                            (long long)rows, C, squared);
     MV_LAUNCH_CHECK();
     hipLaunchKernelGGL(moments_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, workspace, out, G, C);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_bn_mean_fwd(const float* sum, const float* count_dev, float count_host, float* mean, int C, mv_stream_t stream) {
+    MV_CHECK_ARG(sum && mean && C > 0 && (count_dev || count_host > 0.f), "bn_mean: bad arguments");
+    set_kernel_name("bn_mean");
+    hipLaunchKernelGGL(bn_mean_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, count_dev, count_host, mean, C);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_bn_ema_fold_fwd(const float* sqdev, const float* mean, const float* count_dev, float count_host, float* run_mean,
+                       float* run_var, const float* weight, const float* bias, float* scale, float* shift, float momentum, float eps,
+                       int first_time, int C, mv_stream_t stream) {
+    MV_CHECK_ARG(sqdev && mean && run_mean && run_var && scale && shift && C > 0 && (count_dev || count_host > 0.f),
+                 "bn_ema_fold: bad arguments");
+    set_kernel_name("bn_ema_fold");
+    hipLaunchKernelGGL(bn_ema_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sqdev, mean, count_dev, count_host,
+                       run_mean, run_var, weight, bias, scale, shift, momentum, eps, first_time, C);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

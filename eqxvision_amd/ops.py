@@ -63,12 +63,14 @@ def _bn_id(bn):
     return None if bn is None else (id(bn), bn.state_index.version)
 
 
-def bn_train_update(bn, y: Act) -> None:
+def bn_train_update(bn, y: Act):
     """The statistics half of eqx.experimental.BatchNorm's TRAINING branch (resnet.py:132-136 with the model
     not in inference mode): per-channel batch mean, then the mean of squared deviations from it -- two passes, each summed over
-    the ranks of `axis_name`'s data-parallel group (RCCL all-reduce of C floats) --, then the running statistics:
-    first call: running = batch; later: running = (1 - momentum) * batch + momentum * running.  The state lives on the host
-    (StateIndex), as in the reference; the caller normalises with the UPDATED running statistics (reference semantics)."""
+    the ranks of `axis_name`'s data-parallel group (RCCL all-reduce of C floats on the launch stream) --, then the running
+    statistics: first call: running = batch; later: running = (1 - momentum) * batch + momentum * running.  Everything stays on
+    the device and in stream order (no host round trip inside a step); the host `StateIndex.value` is fetched when asked for.
+    Returns the (scale, shift) device vectors of the UPDATED running statistics: what the caller normalises with (reference
+    semantics)."""
     from . import dist as _dist
     t = y.t
     C = t.shape[-1]
@@ -78,40 +80,42 @@ def bn_train_update(bn, y: Act) -> None:
     if not _lib.load().mv_channel_moments_supported(rows, C, y.dt):
         raise NotImplementedError(f"training-mode BatchNorm over {C} channels (multiples of 8 up to 2048 only)")
     ws = empty((int(_lib.load().mv_channel_moments_ws(C)),), torch.float32)
-    s = empty((C,), torch.float32)
+    s, q, mean = (empty((C,), torch.float32) for _ in range(3))
     reduce_ranks = bn.axis_name is not None and _dist.world_size() > 1
-    n = float(rows)
-    if reduce_ranks:                       # rows of the GLOBAL batch (shards may be ragged)
-        cnt = _dev(np.array([rows], np.float32), torch.float32)
-        n = float(_dist.all_reduce_sum_(cnt).cpu()[0])
-    _lib.call("mv_channel_moments_fwd", _ptr(t), None, _ptr(s), _ptr(ws), rows, C, 0, y.dt, stream_ptr())
+    cnt = None
+    if reduce_ranks:                       # rows of the GLOBAL batch (shards may be ragged): summed on the device
+        cnt = _dist.all_reduce_sum_(_dev(np.array([rows], np.float32), torch.float32))
+    st = stream_ptr()
+    _lib.call("mv_channel_moments_fwd", _ptr(t), None, _ptr(s), _ptr(ws), rows, C, 0, y.dt, st)
     if reduce_ranks:
         _dist.all_reduce_sum_(s)
-    mean = (s.cpu().numpy().astype(np.float64) / n).astype(np.float32)
-    mean_dev = _dev(mean, torch.float32)
-    _lib.call("mv_channel_moments_fwd", _ptr(t), _ptr(mean_dev), _ptr(s), _ptr(ws), rows, C, 1, y.dt, stream_ptr())
+    _lib.call("mv_bn_mean_fwd", _ptr(s), _ptr(cnt), float(rows), _ptr(mean), C, st)
+    _lib.call("mv_channel_moments_fwd", _ptr(t), _ptr(mean), _ptr(q), _ptr(ws), rows, C, 1, y.dt, st)
     if reduce_ranks:
-        _dist.all_reduce_sum_(s)
-    var = (s.cpu().numpy().astype(np.float64) / n).astype(np.float32)
-    if bn.first_time_index.value or bn.state_index.value is None:
-        run_mean, run_var = mean, var
-        bn.first_time_index.value = False
+        _dist.all_reduce_sum_(q)
+    sidx = bn.state_index
+    first = bool(bn.first_time_index.value) or (sidx._dev is None and sidx._value is None)
+    if sidx._dev is None:                  # the running statistics move to the device once and stay there
+        host = sidx._value
+        run = (torch.zeros(C, dtype=torch.float32, device=device()), torch.ones(C, dtype=torch.float32, device=device())) \
+            if host is None else tuple(_dev(np.asarray(a, np.float32), torch.float32) for a in host)
     else:
-        m = np.float32(bn.momentum)
-        old_mean, old_var = (np.asarray(a, np.float32) for a in bn.state_index.value)
-        run_mean = (np.float32(1) - m) * mean + m * old_mean
-        run_var = (np.float32(1) - m) * var + m * old_var
-    bn.state_index.value = (run_mean, run_var)
-    # (the assignment bumped state_index.version: every fold prepared with the old statistics is stale now, see _bn_id)
+        run = sidx._dev
+    w = prep_f32(bn, "weight", bn.weight) if bn.weight is not None else None
+    b = prep_f32(bn, "bias", bn.bias) if bn.bias is not None else None
+    scale, shift = empty((C,), torch.float32), empty((C,), torch.float32)
+    _lib.call("mv_bn_ema_fold_fwd", _ptr(q), _ptr(mean), _ptr(cnt), float(rows), _ptr(run[0]), _ptr(run[1]), _ptr(w), _ptr(b),
+              _ptr(scale), _ptr(shift), float(bn.momentum), float(bn.eps), 1 if first else 0, C, st)
+    if first:
+        bn.first_time_index.value = False
+    sidx.device_updated(run)               # bumps the version: every fold prepared with the old statistics is stale (_bn_id)
+    return scale, shift
 
 
-def _bn_apply_fresh(y: Act, bn, act=None) -> Act:
-    """(y - running_mean) / sqrt(running_var + eps) * weight + bias with the statistics as they are NOW (no cached fold)."""
-    s, h = bn_fold(bn)
-    sd, hd = _dev(s, torch.float32), _dev(h, torch.float32)      # (held until after the call: the allocator reuses freed blocks)
+def _bn_affine(y: Act, scale: torch.Tensor, shift: torch.Tensor, act=None) -> Act:
     C = y.t.shape[-1]
     out = empty(tuple(y.t.shape), y.t.dtype)
-    _lib.call("mv_channel_affine_fwd", _ptr(y.t), _ptr(sd), _ptr(hd), _ptr(out), y.t.numel() // C, C, ACT[act], y.dt, stream_ptr())
+    _lib.call("mv_channel_affine_fwd", _ptr(y.t), _ptr(scale), _ptr(shift), _ptr(out), y.t.numel() // C, C, ACT[act], y.dt, stream_ptr())
     return Act(out, y.kind, y.batched)
 
 
@@ -289,10 +293,10 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
     convolution, batch statistics (+ cross-rank sum), running-statistics update, normalisation, (+ residual, activation)."""
     if _bn_training(bn):
         y = conv2d(x, conv, None, None, None)
-        bn_train_update(bn, y)
+        sc, sh = bn_train_update(bn, y)
         if residual is None:
-            return _bn_apply_fresh(y, bn, act)
-        return add(_bn_apply_fresh(y, bn, None), residual, act)
+            return _bn_affine(y, sc, sh, act)
+        return add(_bn_affine(y, sc, sh, None), residual, act)
     dt = compute_dtype()
     if act in UNFUSED_ACTS and (dt != "bf16" or x.kind == "img" or conv.out_channels % 8 or
                                 (conv.groups > 1 and not conv.groups == conv.in_channels == conv.out_channels)):
@@ -765,8 +769,8 @@ def batchnorm(x: Act, bn, act=None) -> Act:
         raise NotImplementedError("BatchNorm on a (tokens, features) array: the reference normalises axis 0; not on the hot path")
     x = as_map(x) if x.kind in ("img", "map") else as_rows(x)
     if _bn_training(bn):
-        bn_train_update(bn, x)
-        return _bn_apply_fresh(x, bn, act)
+        sc, sh = bn_train_update(bn, x)
+        return _bn_affine(x, sc, sh, act)
     cache = bn._cache()
     hit = cache.get(("fold", bn.state_index.version))
     if hit is None:

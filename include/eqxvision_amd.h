@@ -292,6 +292,15 @@ int mv_channel_moments_ws(int C);
 int mv_channel_moments_supported(int64_t rows, int C, int dtype);
 int mv_channel_moments_fwd(const void* x, const float* shift, float* out, float* workspace, int64_t rows, int C, int squared,
                            int dtype, mv_stream_t stream);
+/* The rest of the training-mode BatchNorm update on the device, so that a step has no host round trip: mean = sum / n after the
+ * first pass (n: the global row count, from the host, or -- ragged shards -- the all-reduced count on the device); after the second:
+ * var = sqdev / n, running statistics in place (first call: = batch; else (1 - momentum) * batch + momentum * running, momentum 0.99
+ * in the reference), and the scale / shift the normalisation applies (mv_channel_affine_fwd): weight / sqrt(running_var + eps),
+ * bias - running_mean * scale -- the UPDATED running statistics, as eqx.experimental.BatchNorm does. */
+int mv_bn_mean_fwd(const float* sum, const float* count_dev, float count_host, float* mean, int C, mv_stream_t stream);
+int mv_bn_ema_fold_fwd(const float* sqdev, const float* mean, const float* count_dev, float count_host, float* run_mean,
+                       float* run_var, const float* weight, const float* bias, float* scale, float* shift, float momentum, float eps,
+                       int first_time, int C, mv_stream_t stream);
 
 /* The path's one collective: the batch axis of `jax.vmap(net, axis_name="batch")(images)` (README.md:37-40)
  * shards over the GPUs of a node, one process per GPU; rank r runs images[r*B/W:(r+1)*B/W] and ONE all-gather of the fp32 logits
