@@ -115,6 +115,24 @@ def keep_alive(lst):
         _tls.keep = old
 
 
+@contextlib.contextmanager
+def collect_replay_hooks(lst):
+    """While a forward is being recorded: callables that must run after EVERY replay of the recording (host-side bookkeeping of
+    device-side effects, e.g. "the BatchNorm statistics on the device changed")."""
+    old = getattr(_tls, "hooks", None)
+    _tls.hooks = lst
+    try:
+        yield
+    finally:
+        _tls.hooks = old
+
+
+def on_replay(fn) -> None:
+    h = getattr(_tls, "hooks", None)
+    if h is not None:
+        h.append(fn)
+
+
 class Act:
     __slots__ = ("t", "kind", "batched", "pre")
 

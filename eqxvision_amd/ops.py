@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._act import (Act, is_act, DT, TORCH_DT, compute_dtype, device, empty, head_fp32, residual_fp32, split_weights,
+from ._act import (Act, is_act, DT, TORCH_DT, compute_dtype, device, empty, head_fp32, on_replay, residual_fp32, split_weights,
                    stream_ptr)
 
 ACT = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "gelu": _lib.ACT_GELU_TANH,
@@ -83,9 +83,12 @@ def bn_train_update(bn, y: Act):
     s, q, mean = (empty((C,), torch.float32) for _ in range(3))
     reduce_ranks = bn.axis_name is not None and _dist.world_size() > 1
     cnt = None
-    if reduce_ranks:                       # rows of the GLOBAL batch (shards may be ragged): summed on the device
-        cnt = _dist.all_reduce_sum_(_dev(np.array([rows], np.float32), torch.float32))
     st = stream_ptr()
+    if reduce_ranks:                       # rows of the GLOBAL batch (shards may be ragged): summed on the device
+        mine, cnt = empty((1,), torch.float32), empty((1,), torch.float32)
+        mine.fill_(float(rows))            # (a constant of the recording; the copy + in-place sum below are what a replay repeats)
+        _lib.call("mv_cast", _ptr(mine), _ptr(cnt), 1, _lib.F32, _lib.F32, st)
+        _dist.all_reduce_sum_(cnt)
     _lib.call("mv_channel_moments_fwd", _ptr(t), None, _ptr(s), _ptr(ws), rows, C, 0, y.dt, st)
     if reduce_ranks:
         _dist.all_reduce_sum_(s)
@@ -109,6 +112,7 @@ def bn_train_update(bn, y: Act):
     if first:
         bn.first_time_index.value = False
     sidx.device_updated(run)               # bumps the version: every fold prepared with the old statistics is stale (_bn_id)
+    on_replay(lambda s=sidx, r=run: s.device_updated(r))     # ... and again after every replay of a recorded step
     return scale, shift
 
 

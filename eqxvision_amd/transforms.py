@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._act import (Act, _to_device_f32, compute_dtype, head_fp32, keep_alive, residual_fp32, split_weights, stream_ptr,
+from ._act import (Act, _to_device_f32, collect_replay_hooks, compute_dtype, head_fp32, keep_alive, residual_fp32, split_weights, stream_ptr,
                    wrap)
 from ._module import Module, StateIndex
 from .nn import _unwrap
@@ -64,7 +64,7 @@ MAX_INPLACE_VARIANTS = 2   # per signature: graphs that read resident device inp
 
 
 class _Compiled:
-    __slots__ = ("static_in", "calls", "keep", "out", "graph", "replays", "refs", "lane_calls", "own_resident")
+    __slots__ = ("static_in", "calls", "keep", "out", "graph", "replays", "refs", "lane_calls", "own_resident", "hooks")
 
     def __init__(self):
         self.own_resident = False      # True: resident device inputs are copied into owned buffers before each replay
@@ -76,6 +76,7 @@ class _Compiled:
         self.graph = None
         self.replays = 0
         self.refs = None
+        self.hooks = []                # run after every replay (ops register them while recording: _act.on_replay)
 
 
 def _is_key_array(x) -> bool:
@@ -106,6 +107,12 @@ def _module_sig(m: Module):
             states.append((n, n.version))
             return ("state", id(n), n.version)
         if isinstance(n, Module):
+            if type(n).__name__ == "BatchNorm" and getattr(n, "inference", True) is False:
+                # a training-mode BatchNorm READS AND WRITES its statistics on the device inside the recording: the same launch
+                # list serves every step, whatever the version
+                return (type(n).__qualname__,) + tuple(
+                    (f, ("state-rw", id(getattr(n, f))) if isinstance(getattr(n, f), StateIndex) else rec(getattr(n, f)))
+                    for f in n.__fields__ if hasattr(n, f))
             return (type(n).__qualname__,) + tuple((f, rec(getattr(n, f))) for f in n.__fields__ if hasattr(n, f))
         if isinstance(n, (list, tuple)):
             return (type(n).__name__,) + tuple(rec(c) for c in n)
@@ -122,30 +129,56 @@ def _module_sig(m: Module):
     return sig
 
 
-def _needs_eager(x) -> bool:
-    """True when a Module tree holds a layer in TRAINING mode whose forward involves the host between launches: BatchNorm
-    (batch moments read back, running statistics updated -- ops.bn_train_update) or Dropout / DropPath with p > 0 (fresh random
-    masks per call).  Such a forward is neither recorded, split into lanes nor captured: it runs launch by launch, every call."""
+def _train_layers(x):
+    """(BatchNorm modules in training mode, True if a Dropout / DropPath with p > 0 is in training mode) of a Module tree; cached
+    on the instance (Modules are frozen; tree_inference builds new ones)."""
     hit = x.__dict__.get("_eager_cache") if isinstance(x, Module) else None
     if hit is not None:
         return hit
+    bns, stochastic = [], [False]
 
     def rec(n):
         if isinstance(n, Module):
             if getattr(n, "inference", True) is False:
-                if type(n).__name__ == "BatchNorm" or float(getattr(n, "p", 0.0) or 0.0) > 0.0:
-                    return True
-            return any(rec(getattr(n, f)) for f in n.__fields__ if hasattr(n, f))
-        if isinstance(n, (list, tuple)):
-            return any(rec(c) for c in n)
-        if isinstance(n, dict):
-            return any(rec(c) for c in n.values())
-        return False
+                if type(n).__name__ == "BatchNorm":
+                    bns.append(n)
+                elif float(getattr(n, "p", 0.0) or 0.0) > 0.0:
+                    stochastic[0] = True
+            for f in n.__fields__:
+                if hasattr(n, f):
+                    rec(getattr(n, f))
+        elif isinstance(n, (list, tuple)):
+            for c in n:
+                rec(c)
+        elif isinstance(n, dict):
+            for c in n.values():
+                rec(c)
 
-    r = rec(x)
+    rec(x)
+    r = (tuple(bns), stochastic[0])
     if isinstance(x, Module):
         object.__setattr__(x, "_eager_cache", r)
     return r
+
+
+def _needs_eager(x) -> bool:
+    """True when this call of a Module tree cannot be recorded: Dropout / DropPath in training mode (fresh host-derived masks per
+    call), a training-mode BatchNorm on its FIRST step (running = batch is a different launch argument than the EMA of later
+    steps), or one whose cross-rank sum would go through torch.distributed (not a recorded library call).  Training-mode BatchNorm
+    otherwise IS recordable: moments, all-reduce, EMA and fold are stream-ordered library calls (ops.bn_train_update)."""
+    bns, stochastic = _train_layers(x)
+    if stochastic:
+        return True
+    if not bns:
+        return False
+    from . import dist as _dist
+    if any(b.first_time_index.value or (b.state_index._dev is None and b.state_index._value is None) for b in bns):
+        return True
+    return any(b.axis_name is not None for b in bns) and _dist.world_size() > 1 and not _dist._state["native"]
+
+
+def _has_train_bn(x) -> bool:
+    return bool(_train_layers(x)[0])
 
 
 def _sig(x):
@@ -219,6 +252,8 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
         """lanes if every array argument has the same leading (batch) extent, divisible by `lanes`; else 1."""
         if lanes <= 1 or not use_graph:
             return 1
+        if any(_has_train_bn(v) for v in list(a) + list(kw.values()) if isinstance(v, Module)):
+            return 1                                 # batch statistics are over the WHOLE batch: no sub-batches
         ext = {int(v.shape[0]) for v in list(a) + list(kw.values()) if _is_array(v) and v.ndim >= 1}
         if len(ext) != 1:
             return 1
@@ -357,7 +392,7 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
             if c.lane_calls is None:
                 old = _lib.set_recording(c.calls)
                 try:
-                    with keep_alive(c.keep):
+                    with keep_alive(c.keep), collect_replay_hooks(c.hooks):
                         c.out = fn(*new_args, **new_kwargs)
                 finally:
                     _lib.set_recording(old)
@@ -406,6 +441,8 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
             _lib.call("mv_graph_launch", c.graph, stream_ptr())
         else:
             _replay(c)
+        for h in c.hooks:
+            h()
         c.replays += 1
         return _outputs(c)
 
