@@ -35,6 +35,8 @@ PROTOTYPES = {
     "mv_allgather": [_vp, _vp, C.c_size_t, _vp],
     "mv_allreduce_sum_f32": [_vp, C.c_size_t, _vp],
     "mv_dropout_fwd": [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp],
+    "mv_channel_moments2_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "mv_bn_ema_fold1_fwd": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp],
     "mv_bn_mean_fwd": [_vp, _vp, _f, _vp, _i, _vp],
     "mv_bn_ema_fold_fwd": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp],
     "mv_channel_moments_ws": [_i],

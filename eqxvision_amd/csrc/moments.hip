@@ -60,6 +60,63 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const T* x, const 
     }
 }
 
+// Both moments in ONE pass about a shift that is close to the mean (the running mean of the previous steps -- identical on every
+// rank, so the sums of the ranks add up): partial[b][0:C] = sum (x - shift), partial[b][C:2C] = sum (x - shift)^2.
+// mean = shift + S1 / n, var = S2 / n - (S1 / n)^2: no cancellation worth speaking of when |mean - shift| is a fraction of sigma.
+template <typename T>
+__global__ __launch_bounds__(256) void moments2_partial_kernel(const T* x, const float* shift, float* partial, long long rows, int C) {
+    extern __shared__ float red[];                          // [RS][2C]
+    const int V = C >> 3;
+    const int RS = 256 / V;
+    const int rs = threadIdx.x / V, v = threadIdx.x - rs * V;
+    if (rs < RS) {
+        float sh[8], a1[8], a2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sh[e] = shift[v * 8 + e];
+            a1[e] = 0.f;
+            a2[e] = 0.f;
+        }
+        const long long step = (long long)gridDim.x * RS;
+        long long r = (long long)blockIdx.x * RS + rs;
+        auto accum = [&](const float4& a, const float4& b) {
+            const float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = xv[e] - sh[e];
+                a1[e] += d;
+                a2[e] = fmaf(d, d, a2[e]);
+            }
+        };
+        for (; r + 3 * step < rows; r += 4 * step) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T* p = x + (r + u * step) * C + v * 8;
+                a[u] = Out4<T>::ld(p);
+                b[u] = Out4<T>::ld(p + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accum(a[u], b[u]);
+        }
+        for (; r < rows; r += step) {
+            const T* p = x + r * C + v * 8;
+            accum(Out4<T>::ld(p), Out4<T>::ld(p + 4));
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[rs * 2 * C + v * 8 + e] = a1[e];
+            red[rs * 2 * C + C + v * 8 + e] = a2[e];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        float s = 0.f;
+        for (int j = 0; j < RS; ++j) s += red[j * 2 * C + c];
+        partial[(long long)blockIdx.x * 2 * C + c] = s;
+    }
+}
+
 // out[c] = sum over the G block partials, always in the same order: 16 slices of the partials per channel, then the 16 slice sums
 __global__ __launch_bounds__(1024) void moments_final_kernel(const float* partial, float* out, int G, int C) {
     __shared__ float red[16][64];
@@ -113,6 +170,26 @@ __global__ void bn_ema_fold_kernel(const float* sqdev, const float* mean, const 
     shift[c] = (bias ? bias[c] : 0.f) - rm * sc;
 }
 
+// single-pass form: sums[0:C] = sum (x - shift), sums[C:2C] = sum (x - shift)^2 over the global batch, shift = the running mean the
+// pass was centred on (== run_mean on entry)
+__global__ void bn_ema_fold1_kernel(const float* sums, const float* count_dev, float count_host, float* run_mean, float* run_var,
+                                    const float* weight, const float* bias, float* scale, float* shift, float momentum, float eps, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float n = count_dev ? count_dev[0] : count_host;
+    const float d = sums[c] / n;
+    const float var = fmaxf(sums[C + c] / n - d * d, 0.f);
+    const float mean = run_mean[c] + d;
+    const float rm = (1.f - momentum) * mean + momentum * run_mean[c];
+    const float rv = (1.f - momentum) * var + momentum * run_var[c];
+    run_mean[c] = rm;
+    run_var[c] = rv;
+    const float inv = 1.0f / sqrtf(rv + eps);
+    const float sc = (weight ? weight[c] : 1.f) * inv;
+    scale[c] = sc;
+    shift[c] = (bias ? bias[c] : 0.f) - rm * sc;
+}
+
 }  // namespace mv
 
 using namespace mv;
@@ -146,6 +223,42 @@ int mv_channel_moments_fwd(const void* x, const float* shift, float* out, float*
                            (long long)rows, C, squared);
     MV_LAUNCH_CHECK();
     hipLaunchKernelGGL(moments_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, workspace, out, G, C);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+// workspace: 2 * mv_channel_moments_ws(C) floats; out: 2 * C floats
+int mv_channel_moments2_fwd(const void* x, const float* shift, float* out, float* workspace, int64_t rows, int C, int dtype,
+                            mv_stream_t stream) {
+    MV_CHECK_ARG(x && shift && out && workspace, "channel_moments2: NULL pointer");
+    if (!mv_channel_moments_supported(rows, C, dtype)) {
+        set_error("channel_moments2: unsupported rows=%lld C=%d dtype=%d (C must be a multiple of 8, <= 2048)", (long long)rows, C, dtype);
+        return MV_E_UNSUPPORTED;
+    }
+    const int RS = 256 / (C >> 3);
+    long long need = (rows + 16LL * RS - 1) / (16LL * RS);
+    const int G = (int)(need < MOM_BLOCKS ? need : MOM_BLOCKS);
+    const size_t smem = (size_t)RS * 2 * C * sizeof(float);
+    set_kernel_name("channel_moments2");
+    if (dtype == MV_F32)
+        hipLaunchKernelGGL(moments2_partial_kernel<float>, dim3(G), dim3(256), smem, (hipStream_t)stream, (const float*)x, shift, workspace,
+                           (long long)rows, C);
+    else
+        hipLaunchKernelGGL(moments2_partial_kernel<bf16_t>, dim3(G), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)x, shift,
+                           workspace, (long long)rows, C);
+    MV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(moments_final_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, workspace, out, G, 2 * C);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_bn_ema_fold1_fwd(const float* sums, const float* count_dev, float count_host, float* run_mean, float* run_var,
+                        const float* weight, const float* bias, float* scale, float* shift, float momentum, float eps, int C,
+                        mv_stream_t stream) {
+    MV_CHECK_ARG(sums && run_mean && run_var && scale && shift && C > 0 && (count_dev || count_host > 0.f), "bn_ema_fold1: bad arguments");
+    set_kernel_name("bn_ema_fold1");
+    hipLaunchKernelGGL(bn_ema_fold1_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count_dev, count_host, run_mean,
+                       run_var, weight, bias, scale, shift, momentum, eps, C);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

@@ -89,13 +89,6 @@ def bn_train_update(bn, y: Act):
         mine.fill_(float(rows))            # (a constant of the recording; the copy + in-place sum below are what a replay repeats)
         _lib.call("mv_cast", _ptr(mine), _ptr(cnt), 1, _lib.F32, _lib.F32, st)
         _dist.all_reduce_sum_(cnt)
-    _lib.call("mv_channel_moments_fwd", _ptr(t), None, _ptr(s), _ptr(ws), rows, C, 0, y.dt, st)
-    if reduce_ranks:
-        _dist.all_reduce_sum_(s)
-    _lib.call("mv_bn_mean_fwd", _ptr(s), _ptr(cnt), float(rows), _ptr(mean), C, st)
-    _lib.call("mv_channel_moments_fwd", _ptr(t), _ptr(mean), _ptr(q), _ptr(ws), rows, C, 1, y.dt, st)
-    if reduce_ranks:
-        _dist.all_reduce_sum_(q)
     sidx = bn.state_index
     first = bool(bn.first_time_index.value) or (sidx._dev is None and sidx._value is None)
     if sidx._dev is None:                  # the running statistics move to the device once and stay there
@@ -107,8 +100,25 @@ def bn_train_update(bn, y: Act):
     w = prep_f32(bn, "weight", bn.weight) if bn.weight is not None else None
     b = prep_f32(bn, "bias", bn.bias) if bn.bias is not None else None
     scale, shift = empty((C,), torch.float32), empty((C,), torch.float32)
-    _lib.call("mv_bn_ema_fold_fwd", _ptr(q), _ptr(mean), _ptr(cnt), float(rows), _ptr(run[0]), _ptr(run[1]), _ptr(w), _ptr(b),
-              _ptr(scale), _ptr(shift), float(bn.momentum), float(bn.eps), 1 if first else 0, C, st)
+    if first or _lib.get_flag("bn_two_pass"):
+        # the reference's literal two passes (mean, then squared deviations from it): nothing to centre a single pass on yet
+        _lib.call("mv_channel_moments_fwd", _ptr(t), None, _ptr(s), _ptr(ws), rows, C, 0, y.dt, st)
+        if reduce_ranks:
+            _dist.all_reduce_sum_(s)
+        _lib.call("mv_bn_mean_fwd", _ptr(s), _ptr(cnt), float(rows), _ptr(mean), C, st)
+        _lib.call("mv_channel_moments_fwd", _ptr(t), _ptr(mean), _ptr(q), _ptr(ws), rows, C, 1, y.dt, st)
+        if reduce_ranks:
+            _dist.all_reduce_sum_(q)
+        _lib.call("mv_bn_ema_fold_fwd", _ptr(q), _ptr(mean), _ptr(cnt), float(rows), _ptr(run[0]), _ptr(run[1]), _ptr(w), _ptr(b),
+                  _ptr(scale), _ptr(shift), float(bn.momentum), float(bn.eps), 1 if first else 0, C, st)
+    else:
+        # steady state: both moments about the running mean in ONE pass, ONE all-reduce of 2 x C floats per layer
+        ws2, sums = empty((2 * ws.numel(),), torch.float32), empty((2 * C,), torch.float32)
+        _lib.call("mv_channel_moments2_fwd", _ptr(t), _ptr(run[0]), _ptr(sums), _ptr(ws2), rows, C, y.dt, st)
+        if reduce_ranks:
+            _dist.all_reduce_sum_(sums)
+        _lib.call("mv_bn_ema_fold1_fwd", _ptr(sums), _ptr(cnt), float(rows), _ptr(run[0]), _ptr(run[1]), _ptr(w), _ptr(b),
+                  _ptr(scale), _ptr(shift), float(bn.momentum), float(bn.eps), C, st)
     if first:
         bn.first_time_index.value = False
     sidx.device_updated(run)               # bumps the version: every fold prepared with the old statistics is stale (_bn_id)

@@ -297,6 +297,16 @@ int mv_channel_moments_fwd(const void* x, const float* shift, float* out, float*
  * var = sqdev / n, running statistics in place (first call: = batch; else (1 - momentum) * batch + momentum * running, momentum 0.99
  * in the reference), and the scale / shift the normalisation applies (mv_channel_affine_fwd): weight / sqrt(running_var + eps),
  * bias - running_mean * scale -- the UPDATED running statistics, as eqx.experimental.BatchNorm does. */
+/* Steady state (running statistics exist): ONE pass and ONE all-reduce of 2 x C floats per layer.  Both moments are taken about the
+ * running mean of the previous steps -- the same on every rank, so the ranks' sums add up, and within a fraction of sigma of the batch
+ * mean, so var = S2 / n - (S1 / n)^2 loses nothing: out[0:C] = sum (x - shift), out[C:2C] = sum (x - shift)^2 (workspace:
+ * 2 * mv_channel_moments_ws(C) floats); mv_bn_ema_fold1_fwd then does what mv_bn_mean_fwd + mv_bn_ema_fold_fwd do for the two-pass
+ * form (which the first step of a BatchNorm, with no running statistics yet, still takes -- the reference's literal order). */
+int mv_channel_moments2_fwd(const void* x, const float* shift, float* out, float* workspace, int64_t rows, int C, int dtype,
+                            mv_stream_t stream);
+int mv_bn_ema_fold1_fwd(const float* sums, const float* count_dev, float count_host, float* run_mean, float* run_var,
+                        const float* weight, const float* bias, float* scale, float* shift, float momentum, float eps, int C,
+                        mv_stream_t stream);
 int mv_bn_mean_fwd(const float* sum, const float* count_dev, float count_host, float* mean, int C, mv_stream_t stream);
 int mv_bn_ema_fold_fwd(const float* sqdev, const float* mean, const float* count_dev, float count_host, float* run_mean,
                        float* run_var, const float* weight, const float* bias, float* scale, float* shift, float momentum, float eps,

@@ -621,6 +621,40 @@ def moments_case(rows, C, dtype="bf16", seed=0):
     return run
 
 
+def moments2_case(rows, C, dtype="bf16", seed=0, off=0.3):
+    """mv_channel_moments2_fwd (both moments about a shift near the mean, one pass) + mv_bn_ema_fold1_fwd vs float64: the batch
+    mean / variance they imply, the EMA of the running statistics and the folded scale / shift."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        mu = rng.uniform(-3, 3, (1, C))
+        x = (rng.standard_normal((rows, C)) * rng.uniform(0.5, 2.0, (1, C)) + mu).astype(np.float32)
+        if dtype == "bf16":
+            x = bf(x)
+        dtc = 1 if dtype == "bf16" else 0
+        rm = (mu[0] + off * rng.standard_normal(C)).astype(np.float32)           # running mean: near the batch mean, not on it
+        rv = rng.uniform(0.5, 2.0, C).astype(np.float32)
+        w, b = rng.uniform(0.5, 1.5, C).astype(np.float32), (0.1 * rng.standard_normal(C)).astype(np.float32)
+        xd = dev(x, dtype)
+        ws = torch.empty((2 * int(L.load().mv_channel_moments_ws(C)),), dtype=torch.float32, device="cuda")
+        sums = torch.empty((2 * C,), dtype=torch.float32, device="cuda")
+        rmd, rvd, wd, bd = (dev(a, "fp32") for a in (rm, rv, w, b))
+        sc, sh = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        L.call("mv_channel_moments2_fwd", xd.data_ptr(), rmd.data_ptr(), sums.data_ptr(), ws.data_ptr(), rows, C, dtc, _stream())
+        L.call("mv_bn_ema_fold1_fwd", sums.data_ptr(), None, float(rows), rmd.data_ptr(), rvd.data_ptr(), wd.data_ptr(), bd.data_ptr(),
+               sc.data_ptr(), sh.data_ptr(), 0.99, 1e-5, C, _stream())
+        torch.cuda.synchronize()
+        x64 = x.astype(np.float64)
+        bm, bvar = x64.mean(0), x64.var(0)
+        erm, erv = 0.01 * bm + 0.99 * rm, 0.01 * bvar + 0.99 * rv
+        esc = w / np.sqrt(erv + 1e-5)
+        errs = {"run_mean": float(np.abs(host(rmd) - erm).max()), "run_var": float(np.abs(host(rvd) - erv).max()),
+                "scale": float(np.abs(host(sc) - esc).max()), "shift": float(np.abs(host(sh) - (b - erm * esc)).max())}
+        e = max(errs.values())
+        return {"ok": e < 1e-4, "err": e, "lim": 1e-4, **errs, "kernel": L.last_kernel()}
+    return run
+
+
 def dropout_case(B, per, C, chw, p, dtype="bf16", seed=0, flag=None):
     """mv_dropout_fwd vs the oracle's eqx.nn.Dropout on JAX's bit stream (oracle.np_ops.dropout), bit for bit; x is NHWC
     [B][per / C][C], the mask indexed in the LOGICAL (C, per / C) order when `chw`."""
@@ -1365,6 +1399,9 @@ def all_cases():
           ("moments/c2048_few_rows", moments_case(8 * 7 * 7, 2048, "bf16", seed=551)),
           ("moments/c96_fp32_ragged", moments_case(12345, 96, "fp32", seed=552)),
           ("moments/c8_one_row", moments_case(1, 8, "fp32", seed=553)),
+          ("moments/single_pass_c64_map", moments2_case(8 * 56 * 56, 64, "bf16", seed=554)),
+          ("moments/single_pass_c2048", moments2_case(300, 2048, "fp32", seed=555)),
+          ("moments/single_pass_far_shift", moments2_case(5000, 96, "fp32", seed=556, off=3.0)),
           ("dropout/map_chw_bf16", dropout_case(3, 24 * 35, 24, True, 0.4, "bf16", seed=560)),
           ("dropout/rows_odd_count_fp32", dropout_case(2, 7 * 9, 9, False, 0.5, "fp32", seed=561)),
           ("dropout/one_element", dropout_case(4, 1, 1, False, 0.5, "fp32", seed=562)),

@@ -569,6 +569,32 @@ def cna_family_train_case():
     return run
 
 
+def bn_first_steps_case(C=40, hw=9, B=5):
+    """A fresh BatchNorm (no running statistics: what the reference constructs) through its first three training steps, as a
+    module on a map: step 1 takes the reference's literal two passes and running = batch; steps 2-3 the single pass centred on the
+    running mean and the EMA -- outputs and statistics against oracle.np_ops.batchnorm_train each step."""
+    def run():
+        import eqxvision_amd as eqv
+        from eqxvision_amd import nn
+        rng = np.random.Generator(np.random.PCG64(9))
+        bn = nn.BatchNorm(C, axis_name="batch")
+        object.__setattr__(bn, "weight", rng.uniform(0.5, 1.5, C).astype(np.float32))
+        object.__setattr__(bn, "bias", (0.1 * rng.standard_normal(C)).astype(np.float32))
+        running, errs, serr = None, [], []
+        with eqv.precision("fp32"):
+            for step in range(3):
+                x = (rng.standard_normal((B, C, hw, hw)) * rng.uniform(0.5, 3.0, (1, C, 1, 1)) + rng.uniform(-4, 4, (1, C, 1, 1))
+                     + 0.3 * step).astype(np.float32)
+                got = eqv.vmap(bn, axis_name="batch")(x, key=_keys(B)).cpu().numpy()
+                want, running = O.batchnorm_train(x, bn.weight, bn.bias, running, step == 0)
+                errs.append(float(np.abs(got - want).max()))
+                m, v = bn.state_index.value
+                serr.append(max(float(np.abs(np.asarray(m) - running[0]).max()), float(np.abs(np.asarray(v) - running[1]).max())))
+        ok = max(errs) < 1e-4 and max(serr) < 1e-4 and not bn.first_time_index.value
+        return {"ok": ok, "err": max(errs), "lim": 1e-4, "output_errs": errs, "running_stat_errs": serr}
+    return run
+
+
 def jit_case():
     """filter_jit: the Python body runs once; replays (call 2 = hipGraph capture, call 3 = graph launch)
     with NEW inputs must equal eager results (reference semantics: tests/test_models/test_vit.py:35)."""
@@ -843,6 +869,7 @@ def all_cases(full=True):
          ("model/swin_train_mode_stochastic_depth", swin_train_case()),
          ("model/vit_train_mode_stochastic_depth", vit_train_case()),
          ("model/mobilenet_v2_train_mode_bn_refold", cna_family_train_case()),
+         ("model/batchnorm_fresh_first_three_train_steps", bn_first_steps_case()),
          ("model/resnet18_train_mode_bn", resnet_train_case()),
          ("model/resnet18_train_mode_bn_under_filter_jit", resnet_train_case(jit=True)),
          ("model/resnext_tiny_32x4d", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2, groups=32, width_per_group=4)),
