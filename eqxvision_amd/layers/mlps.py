@@ -44,9 +44,9 @@ class MlpProjection(Module):
         else:
             h = ops.linear(x, self.fc1) if norm is None else ops.ln_linear(x, norm, self.fc1)
             h = self.act(h) if self.act is not None else h
-        h = self.drop1(h)
-        y = ops.linear(h, self.fc2, residual=residual)
-        return self.drop2(y)
+        nn.refuse_live_dropout(self.drop1, "MlpProjection.drop1")          # identity in inference / p = 0 (mlps.py:63, :65)
+        nn.refuse_live_dropout(self.drop2, "MlpProjection.drop2")
+        return ops.linear(h, self.fc2, residual=residual)
 
     @boundary
     def __call__(self, x, *, key=None):

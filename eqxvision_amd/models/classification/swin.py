@@ -69,6 +69,10 @@ class _ShiftedWindowAttention(Module):
         self.window_size = list(window_size)
         self.shift_size = list(shift_size)
         self.num_heads = num_heads
+        if attention_dropout or dropout:
+            # the reference's `_func_dropout` (swin.py:17-20, 227, 233) has no inference switch: a non-zero rate drops in every
+            # mode, in window layout -- not built; refuse instead of silently not dropping
+            raise NotImplementedError("Swin attention_dropout / dropout > 0 (applied in every mode by the reference) is not built")
         self.attention_dropout = attention_dropout
         self.dropout = dropout
         self.qkv = Linear2d(dim, dim * 3, use_bias=qkv_bias, key=keys[0])

@@ -44,9 +44,9 @@ class _VitAttention(Module):
         if x.kind != "seq":
             raise ValueError(f"_VitAttention expects (tokens, dim), got {x.shape}")
         y, probs = ops.qkv_attention(x, self.qkv, self.num_heads, self.scale, need_probs)   # reference :64-73
-        self.attn_drop(y)                                              # identity (or a loud error) -- reference :71
+        nn.refuse_live_dropout(self.attn_drop, "_VitAttention.attn_drop")   # reference :71: identity in inference / p = 0
+        nn.refuse_live_dropout(self.proj_drop, "_VitAttention.proj_drop")
         y = ops.linear(y, self.proj, residual=residual)                # reference :74 (+ the block's residual)
-        y = self.proj_drop(y)
         attn = None
         if probs is not None:                                          # reference returns (1, heads, N, N) per sample
             B, H, N, _ = probs.shape
