@@ -82,6 +82,7 @@ PROTOTYPES = {
     "mv_eltwise_fwd": [_vp, _vp, _i64, _i, _i, _vp],
     "mv_add_fwd": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "mv_channel_affine_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "mv_channel_affine_res_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "mv_nchw_to_nhwc": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mv_nhwc_to_nchw": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mv_cast": [_vp, _vp, _i64, _i, _i, _vp],

@@ -5,7 +5,7 @@
 // The contraction kernels here are the "any shape" path (odd channel counts such as the
 // MlpProjection(20,5,10) of the reference's tests/test_layers.py:25-40) and the on-device
 // cross-check for the MFMA kernels (flag "force_generic").  They are NOT the fast path.
-#include "common.h"
+#include "mfma_common.h"
 
 namespace mv {
 
@@ -587,6 +587,55 @@ __global__ void channel_scale_kernel(const T* __restrict__ x, const T* __restric
         io<T>::st(y + i, io<T>::ld(x + i) * io<T>::ld(sc + b * C + c));
     }
 }
+// The element-wise passes with 8 values (16 bytes in bf16) per thread: what the SqueezeExcitation multiply, the un-fused activations
+// (hard_swish after a kernel that does not fuse it) and the un-fused residual adds of the section-8 f1 families run on.  HBM-bound;
+// the one-value-per-thread kernels above reach 1.9 TB/s, these > 5.
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float* v) {
+    const float4 a = Out4<T>::ld(p), b = Out4<T>::ld(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <typename T>
+__global__ void eltwise_vec8_kernel(const T* __restrict__ x, T* __restrict__ y, long long n8, int act) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        float v[8];
+        ld8(x + i * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = apply_act_rt(v[e], act);
+        Out8<T>::st(y + i * 8, v);
+    }
+}
+template <typename T>
+__global__ void add_vec8_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long long n8, int act) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        float v[8], w[8];
+        ld8(a + i * 8, v);
+        ld8(b + i * 8, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = apply_act_rt(v[e] + w[e], act);
+        Out8<T>::st(y + i * 8, v);
+    }
+}
+template <typename T>
+__global__ void channel_scale_vec8_kernel(const T* __restrict__ x, const T* __restrict__ sc, T* __restrict__ y, long long HW, int C,
+                                          long long n8) {
+    const long long V = C >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / V;
+        const int c = (int)(i - pix * V) * 8;
+        const long long b = pix / HW;
+        float v[8], w[8];
+        ld8(x + i * 8, v);
+        ld8(sc + b * C + c, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= w[e];
+        Out8<T>::st(y + i * 8, v);
+    }
+}
+static inline int grid_vec8(long long n8) {
+    const long long g = (n8 + 255) / 256;
+    return (int)(g > 256 * 32 ? 256 * 32 : (g < 1 ? 1 : g));
+}
+
 template <typename T>
 __global__ void channel_affine_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                       const float* __restrict__ shift, T* __restrict__ y, long long rows, int C,
@@ -601,6 +650,36 @@ __global__ void channel_affine_kernel(const T* __restrict__ x, const float* __re
         io<T>::st(y + i, apply_act_rt(v, act));
     }
 }
+// 8 consecutive channels per thread (16-byte accesses in bf16), optional residual: y = act(x * scale[c] + shift[c] + residual) --
+// the normalisation pass of a training-mode BatchNorm (every convolution output goes through it once: HBM-bound)
+template <typename T>
+__global__ void channel_affine_vec8_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                           const T* __restrict__ residual, T* __restrict__ y, long long n8, int C, int act) {
+    const int V = C >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((unsigned long long)i % (unsigned)V) * 8;
+        const T* p = x + i * 8;
+        const float4 a = Out4<T>::ld(p), b = Out4<T>::ld(p + 4);
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, h0 = make_float4(0.f, 0.f, 0.f, 0.f), h1 = h0;
+        if (scale) { s0 = *(const float4*)(scale + c); s1 = *(const float4*)(scale + c + 4); }      // c % 8 == 0: 32-byte aligned
+        if (shift) { h0 = *(const float4*)(shift + c); h1 = *(const float4*)(shift + c + 4); }
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+        if (residual) {
+            const float4 ra = Out4<T>::ld(residual + i * 8), rb = Out4<T>::ld(residual + i * 8 + 4);
+            const float r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = apply_act_rt(v[e], act);
+        Out8<T>::st(y + i * 8, v);
+    }
+}
+
 template <typename TI, typename TO>
 __global__ void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -1233,6 +1312,17 @@ int mv_vit_cls_pos_fwd(const float* cls, const float* pos, void* tokens, int B, 
 int mv_eltwise_fwd(const void* x, void* y, int64_t n, int act, int dtype, mv_stream_t stream) {
     MV_CHECK_ARG(x && y && n > 0, "eltwise: bad args");
     hipStream_t st = (hipStream_t)stream;
+    if (n % 8 == 0 && !get_flag("eltwise_scalar")) {
+        set_kernel_name("eltwise_x8");
+        if (dtype == MV_BF16)
+            hipLaunchKernelGGL(eltwise_vec8_kernel<bf16_t>, dim3(grid_vec8(n / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
+                               (long long)(n / 8), act);
+        else
+            hipLaunchKernelGGL(eltwise_vec8_kernel<float>, dim3(grid_vec8(n / 8)), dim3(256), 0, st, (const float*)x, (float*)y,
+                               (long long)(n / 8), act);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
     set_kernel_name("eltwise");
     if (dtype == MV_BF16)
         hipLaunchKernelGGL(eltwise_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
@@ -1248,6 +1338,17 @@ int mv_channel_scale_nhwc_fwd(const void* x, const void* sc, void* y, int N, int
     MV_CHECK_ARG(x && sc && y && N > 0 && HW > 0 && C > 0, "channel_scale: bad args");
     hipStream_t st = (hipStream_t)stream;
     const long long n = (long long)N * HW * C;
+    if (C % 8 == 0 && !get_flag("eltwise_scalar")) {
+        set_kernel_name("channel_scale_x8");
+        if (dtype == MV_BF16)
+            hipLaunchKernelGGL(channel_scale_vec8_kernel<bf16_t>, dim3(grid_vec8(n / 8)), dim3(256), 0, st, (const bf16_t*)x,
+                               (const bf16_t*)sc, (bf16_t*)y, (long long)HW, C, n / 8);
+        else
+            hipLaunchKernelGGL(channel_scale_vec8_kernel<float>, dim3(grid_vec8(n / 8)), dim3(256), 0, st, (const float*)x,
+                               (const float*)sc, (float*)y, (long long)HW, C, n / 8);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
     set_kernel_name("channel_scale");
     if (dtype == MV_BF16)
         hipLaunchKernelGGL(channel_scale_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)sc,
@@ -1262,6 +1363,17 @@ int mv_channel_scale_nhwc_fwd(const void* x, const void* sc, void* y, int N, int
 int mv_add_fwd(const void* a, const void* b, void* y, int64_t n, int act, int dtype, mv_stream_t stream) {
     MV_CHECK_ARG(a && b && y && n > 0, "add: bad args");
     hipStream_t st = (hipStream_t)stream;
+    if (n % 8 == 0 && !get_flag("eltwise_scalar")) {
+        set_kernel_name("add_x8");
+        if (dtype == MV_BF16)
+            hipLaunchKernelGGL(add_vec8_kernel<bf16_t>, dim3(grid_vec8(n / 8)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b,
+                               (bf16_t*)y, (long long)(n / 8), act);
+        else
+            hipLaunchKernelGGL(add_vec8_kernel<float>, dim3(grid_vec8(n / 8)), dim3(256), 0, st, (const float*)a, (const float*)b,
+                               (float*)y, (long long)(n / 8), act);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
     set_kernel_name("add");
     if (dtype == MV_BF16)
         hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b,
@@ -1273,12 +1385,28 @@ int mv_add_fwd(const void* a, const void* b, void* y, int64_t n, int act, int dt
     return MV_OK;
 }
 
-int mv_channel_affine_fwd(const void* x, const float* scale, const float* shift, void* y, int64_t rows, int C,
-                          int act, int dtype, mv_stream_t stream) {
-    MV_CHECK_ARG(x && y && rows > 0 && C > 0, "channel_affine: bad args");
-    hipStream_t st = (hipStream_t)stream;
-    set_kernel_name("channel_affine");
+static int channel_affine_go(const void* x, const float* scale, const float* shift, const void* residual, void* y, int64_t rows, int C,
+                             int act, int dtype, hipStream_t st) {
     const long long n = (long long)rows * C;
+    if (C % 8 == 0 && !get_flag("affine_scalar")) {          // 16-byte accesses; the scalar kernel serves odd widths (and residual-free calls only)
+        const long long n8 = n / 8;
+        long long g = (n8 + 255) / 256;
+        const int grid = (int)(g > 256 * 32 ? 256 * 32 : g);
+        set_kernel_name(residual ? "channel_affine_res_x8" : "channel_affine_x8");
+        if (dtype == MV_BF16)
+            hipLaunchKernelGGL(channel_affine_vec8_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, scale, shift,
+                               (const bf16_t*)residual, (bf16_t*)y, n8, C, act);
+        else
+            hipLaunchKernelGGL(channel_affine_vec8_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, scale, shift,
+                               (const float*)residual, (float*)y, n8, C, act);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
+    if (residual) {
+        set_error("channel_affine_res: C=%d is not a multiple of 8", C);
+        return MV_E_UNSUPPORTED;
+    }
+    set_kernel_name("channel_affine");
     if (dtype == MV_BF16)
         hipLaunchKernelGGL(channel_affine_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)x, scale,
                            shift, (bf16_t*)y, (long long)rows, C, act);
@@ -1287,6 +1415,20 @@ int mv_channel_affine_fwd(const void* x, const float* scale, const float* shift,
                            shift, (float*)y, (long long)rows, C, act);
     MV_LAUNCH_CHECK();
     return MV_OK;
+}
+
+int mv_channel_affine_fwd(const void* x, const float* scale, const float* shift, void* y, int64_t rows, int C,
+                          int act, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && y && rows > 0 && C > 0, "channel_affine: bad args");
+    return channel_affine_go(x, scale, shift, nullptr, y, rows, C, act, dtype, (hipStream_t)stream);
+}
+
+// y = act(x * scale[c] + shift[c] + residual): BatchNorm's normalisation + the block's identity + ReLU in one pass (the tail of a
+// residual block whose BatchNorm is in training mode and therefore not in the convolution's epilogue; resnet.py:155-160)
+int mv_channel_affine_res_fwd(const void* x, const float* scale, const float* shift, const void* residual, void* y, int64_t rows, int C,
+                              int act, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && y && residual && rows > 0 && C > 0, "channel_affine_res: bad args");
+    return channel_affine_go(x, scale, shift, residual, y, rows, C, act, dtype, (hipStream_t)stream);
 }
 
 static int layout_launch(const void* x, void* y, int N, int C, int H, int W, int in_dtype, int out_dtype, bool to_nhwc,

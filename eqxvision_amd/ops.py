@@ -126,11 +126,17 @@ def bn_train_update(bn, y: Act):
     return scale, shift
 
 
-def _bn_affine(y: Act, scale: torch.Tensor, shift: torch.Tensor, act=None) -> Act:
+def _bn_affine(y: Act, scale: torch.Tensor, shift: torch.Tensor, act=None, residual: Optional[Act] = None) -> Act:
     C = y.t.shape[-1]
     out = empty(tuple(y.t.shape), y.t.dtype)
-    _lib.call("mv_channel_affine_fwd", _ptr(y.t), _ptr(scale), _ptr(shift), _ptr(out), y.t.numel() // C, C, ACT[act], y.dt, stream_ptr())
-    return Act(out, y.kind, y.batched)
+    if residual is not None and C % 8 == 0 and residual.t.dtype == y.t.dtype and tuple(residual.t.shape) == tuple(y.t.shape):
+        _lib.call("mv_channel_affine_res_fwd", _ptr(y.t), _ptr(scale), _ptr(shift), _ptr(residual.t), _ptr(out), y.t.numel() // C, C,
+                  ACT[act], y.dt, stream_ptr())
+        return Act(out, y.kind, y.batched)
+    _lib.call("mv_channel_affine_fwd", _ptr(y.t), _ptr(scale), _ptr(shift), _ptr(out), y.t.numel() // C, C,
+              ACT[act if residual is None else None], y.dt, stream_ptr())
+    z = Act(out, y.kind, y.batched)
+    return z if residual is None else add(z, residual, act)
 
 
 def prep_conv(conv, bn, layout: str, dtype: str):
@@ -308,9 +314,7 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
     if _bn_training(bn):
         y = conv2d(x, conv, None, None, None)
         sc, sh = bn_train_update(bn, y)
-        if residual is None:
-            return _bn_affine(y, sc, sh, act)
-        return add(_bn_affine(y, sc, sh, None), residual, act)
+        return _bn_affine(y, sc, sh, act, None if residual is None else as_map(residual))
     dt = compute_dtype()
     if act in UNFUSED_ACTS and (dt != "bf16" or x.kind == "img" or conv.out_channels % 8 or
                                 (conv.groups > 1 and not conv.groups == conv.in_channels == conv.out_channels)):

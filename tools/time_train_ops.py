@@ -26,3 +26,13 @@ for B, per, C, chw in ((256, 9216, 9216, 0), (128, 56 * 56 * 256, 256, 1), (256,
     keys = torch.randint(0, 2**31 - 1, (B, 2), device="cuda", dtype=torch.int32)
     us = t(lambda: L.call("mv_dropout_fwd", x.data_ptr(), keys.data_ptr(), y.data_ptr(), B, per, C, chw, 0.5, 1, s))
     print(f"dropout B={B} per={per} chw={chw}: {us:.1f} us  {B*per*4/us/1e3:.0f} GB/s")
+for rows, C in ((128 * 56 * 56, 256), (128 * 112 * 112, 64)):
+    x = torch.randn(rows, C, device="cuda").bfloat16(); y = torch.empty_like(x); r = torch.randn(rows, C, device="cuda").bfloat16()
+    sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda")
+    for flag in (0, 1):
+        L.set_flag("affine_scalar", flag)
+        us = t(lambda: L.call("mv_channel_affine_fwd", x.data_ptr(), sc.data_ptr(), sh.data_ptr(), y.data_ptr(), rows, C, 1, 1, s))
+        print(f"channel_affine rows={rows} C={C} scalar={flag} [{L.last_kernel()}]: {us:.1f} us  {rows*C*4/us/1e3:.0f} GB/s")
+    L.set_flag("affine_scalar", 0)
+    us = t(lambda: L.call("mv_channel_affine_res_fwd", x.data_ptr(), sc.data_ptr(), sh.data_ptr(), r.data_ptr(), y.data_ptr(), rows, C, 1, 1, s))
+    print(f"channel_affine_res rows={rows} C={C}: {us:.1f} us  {rows*C*6/us/1e3:.0f} GB/s")
