@@ -799,7 +799,7 @@ int mv_conv2d_nhwc_fwd(const void* x, const void* w, const float* scale, const f
     hipStream_t st = (hipStream_t)stream;
     {   // pointwise layers whose reduction is not a multiple of 64 (Swin C = 96) still fit the streaming kernel
         const long long M = (long long)N * Ho * Wo;
-        const bool dense1x1 = R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && groups == 1 && act <= MV_ACT_GELU_TANH;
+        const bool dense1x1 = R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && groups == 1;
         if (!get_flag("force_generic") && !get_flag("no_stream") && !get_flag("igemm_tile") && dense1x1 && C % 64 != 0 &&
             stream1x1_supported(C, K, in_dtype, out_dtype, M))
             return stream1x1_launch(x, w, scale, shift, residual, y, M, C, K, act, out_dtype, st);

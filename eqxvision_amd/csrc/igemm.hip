@@ -352,6 +352,9 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
     p.act = act;
     const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
     const bool out_f32 = out_dtype == MV_F32;
+    if (act > MV_ACT_GELU_TANH && dense && !get_flag("no_stream") && !get_flag("igemm_tile") && !get_flag("igemm2_tile") &&
+        stream1x1_supported(C, K, in_dtype, out_dtype, M))             // the streaming kernel's epilogue has every activation
+        return stream1x1_launch(x, w, scale, shift, residual, y, M, C, K, act, out_dtype, st);
     if (act > MV_ACT_GELU_TANH) {
         // jax.nn.hard_swish / hard_sigmoid / sigmoid / silu (MobileNetV3, EfficientNet): only this file's epilogue implements them;
         // fused here they save the element-wise pass over the layer's output that a faster main loop would not buy back

@@ -191,6 +191,9 @@ __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) 
                         } else if (p.act == MV_ACT_GELU_TANH) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                        } else if (p.act > MV_ACT_GELU_TANH) {     // hard_swish / hard_sigmoid / sigmoid / silu (MobileNetV3, EfficientNet)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = apply_act_rt(v[e], p.act);
                         }
                         Out8<OutT>::st(y + (long long)m * p.N + n, v);
                     }
@@ -277,8 +280,13 @@ __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) 
 
 int stream1x1_supported(int C, int K, int in_dtype, int out_dtype, long long M) {
     // C = reduction length, K = output channels (igemm naming)
-    return in_dtype == MV_BF16 && (out_dtype == MV_BF16 || out_dtype == MV_F32) &&
-           (C == 64 || C == 96 || C == 128 || C == 192 || C == 256) && K % 8 == 0 && M >= 8192;
+    // the narrow widths (16 ... 160: the expansions / projections of MobileNet / EfficientNet stacks, whose outputs dominate the
+    // bytes) came later: before, they ran on the 128 x 128 tile kernel with a zero-filled k-tile at 1.5-1.8 TB/s
+    const int kc = C / 16;
+    const bool wide = C == 64 || C == 96 || C == 128 || C == 192 || C == 256;
+    const bool narrow = C % 16 == 0 && (kc == 1 || kc == 2 || kc == 3 || kc == 5 || kc == 7 || kc == 9 || kc == 10) &&
+                        !get_flag("no_stream_narrow");
+    return in_dtype == MV_BF16 && (out_dtype == MV_BF16 || out_dtype == MV_F32) && (wide || narrow) && K % 8 == 0 && M >= 8192;
 }
 
 template <int TN, int KC, typename OutT, bool LN = false, typename XT = bf16_t>
@@ -349,18 +357,24 @@ int stream1x1_launch(const void* x, const void* w, const float* scale, const flo
     set_kernel_name(name);
 #define GO(TN_, KC_)                                                              \
     return f32o ? stream_go<TN_, KC_, float>(p, tiles_n, st) : stream_go<TN_, KC_, bf16_t>(p, tiles_n, st)
-    if (bn == 64) {
-        if (C == 64) GO(2, 4);
-        if (C == 96) GO(2, 6);
-        if (C == 128) GO(2, 8);
-        if (C == 192) GO(2, 12);
-        GO(2, 16);
+#define GOK(TN_)                  \
+    switch (C / 16) {             \
+        case 1: GO(TN_, 1);       \
+        case 2: GO(TN_, 2);       \
+        case 3: GO(TN_, 3);       \
+        case 4: GO(TN_, 4);       \
+        case 5: GO(TN_, 5);       \
+        case 6: GO(TN_, 6);       \
+        case 7: GO(TN_, 7);       \
+        case 8: GO(TN_, 8);       \
+        case 9: GO(TN_, 9);       \
+        case 10: GO(TN_, 10);     \
+        case 12: GO(TN_, 12);     \
+        default: GO(TN_, 16);     \
     }
-    if (C == 64) GO(4, 4);
-    if (C == 96) GO(4, 6);
-    if (C == 128) GO(4, 8);
-    if (C == 192) GO(4, 12);
-    GO(4, 16);
+    if (bn == 64) GOK(2);
+    GOK(4);
+#undef GOK
 #undef GO
 }
 

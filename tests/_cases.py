@@ -1357,6 +1357,15 @@ def all_cases():
           ("oddc/pw_24_144", conv_nhwc_case(4, 56, 56, 24, 144, 1, 1, act=1, seed=554)),
           ("oddc/pw_144_24_res", conv_nhwc_case(4, 56, 56, 144, 24, 1, 1, act=0, res=True, seed=555)),
           ("oddc/pw_16_96", conv_nhwc_case(2, 112, 112, 16, 96, 1, 1, act=1, seed=556)),
+          ("stream_narrow/16_96_silu", conv_nhwc_case(2, 112, 112, 16, 96, 1, 1, act=6, seed=570)),
+          ("stream_narrow/32_192_hswish_ragged", conv_nhwc_case(3, 57, 57, 32, 192, 1, 1, act=3, seed=571)),
+          ("stream_narrow/48_288_relu", conv_nhwc_case(4, 56, 56, 48, 288, 1, 1, act=1, seed=572)),
+          ("stream_narrow/80_480_hswish", conv_nhwc_case(12, 28, 28, 80, 480, 1, 1, act=3, seed=573)),
+          ("stream_narrow/112_672_silu", conv_nhwc_case(12, 28, 28, 112, 672, 1, 1, act=6, seed=574)),
+          ("stream_narrow/144_24_res_project", conv_nhwc_case(4, 56, 56, 144, 24, 1, 1, act=0, res=True, seed=575)),
+          ("stream_narrow/160_960_hswish", conv_nhwc_case(48, 14, 14, 160, 960, 1, 1, act=3, seed=576)),
+          ("stream_narrow/96_576_hsigmoid_f32out", conv_nhwc_case(4, 56, 56, 96, 576, 1, 1, act=4, out="fp32", seed=577)),
+          ("stream_narrow/off_16_96", conv_nhwc_case(2, 112, 112, 16, 96, 1, 1, act=6, seed=570, flags=("no_stream_narrow",))),
           ("oddc/pw_160_960", conv_nhwc_case(8, 7, 7, 160, 960, 1, 1, act=1, seed=557)),
           ("oddc/conv3x3_40_72_s2", conv_nhwc_case(2, 19, 19, 40, 72, 3, 3, stride=2, pad=1, act=1, seed=558)),
           ("oddc/linear_M77_K200_N136", conv_nhwc_case(1, 77, 1, 200, 136, 1, 1, act=0, seed=559)),
