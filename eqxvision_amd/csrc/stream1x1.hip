@@ -62,7 +62,9 @@ template <> struct SRes8<float> {
 // LN: the rows arrive un-normalised in XT (the fp32 residual stream, or bf16); every lane holds half of its row, so the
 // LayerNorm statistics are two cross-half shuffles and (x - mean) * rstd becomes the bf16 B fragment directly (the affine
 // part of the LayerNorm is folded into w / shift by the caller).  Saves the separate LayerNorm launch and its round trip.
-template <int TN, int KC, int WAVES, typename OutT, bool LN = false, typename XT = bf16_t>
+// KPAD: the reduction p.K is a multiple of 8 but not of 16 (24, 40, 72, 120 ... : MobileNet / EfficientNet / RegNet widths): the
+// last k-step is half empty -- its upper 8 channels are zero in the LDS weight rows and in the fragments (masked loads).
+template <int TN, int KC, int WAVES, typename OutT, bool LN = false, typename XT = bf16_t, bool KPAD = false>
 __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) {
     constexpr int BN = 32 * TN;
     constexpr int EPITCH = 64 * 4 + 16;
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) 
     float* sct = (float*)(smem + rows * p.wpitch);              // [2][rows]: scale, shift of the block's channels
     char* ep = (char*)(sct + 2 * rows) + wave * (32 * EPITCH);  // wave-private epilogue patch
     const int nb = blockIdx.y * rows;                           // first channel of the block
-    const int K = KC * 16;
+    const int K = KPAD ? p.K : KC * 16;                         // row pitch of x and w in memory
 
     // ---- weight slab + scale / shift -> LDS (once).  16-byte chunks, zero rows past N.
     {
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) 
                 const int i = base + j * WAVES * 64 + tid;
                 const int row = i / CH, ch = i - row * CH;
                 const int n = nb + row;
-                const bool ok = i < rows * CH && n < p.N;
+                const bool ok = i < rows * CH && n < p.N && (!KPAD || ch * 8 < K);
                 v[j] = *(const uint4*)(p.w + (ok ? (long long)n * K + ch * 8 : 0));
                 if (!ok) v[j] = make_uint4(0, 0, 0, 0);
             }
@@ -115,7 +117,15 @@ __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) 
         m = m < p.M ? m : p.M - 1;                              // clamp: rows past the end are never stored
         const bf16_t* src = p.x + (long long)m * K + fh * 8;
 #pragma unroll
-        for (int kk = 0; kk < KC; ++kk) xf[kk] = *(const uint4*)(src + kk * 16);
+        for (int kk = 0; kk < KC; ++kk) {
+            if (KPAD && kk == KC - 1) {                         // the half-empty last step: lanes of the upper half hold zeros
+                const bool in = fh == 0;
+                xf[kk] = *(const uint4*)(src + (in ? kk * 16 : 0));
+                if (!in) xf[kk] = make_uint4(0, 0, 0, 0);
+            } else {
+                xf[kk] = *(const uint4*)(src + kk * 16);
+            }
+        }
     };
     auto load_res = [&](SRes8<OutT> (*rr)[4], int tile, int n0) {
 #pragma unroll
@@ -280,16 +290,17 @@ __global__ __launch_bounds__(WAVES * 64) void stream1x1_kernel(const StreamP p) 
 
 int stream1x1_supported(int C, int K, int in_dtype, int out_dtype, long long M) {
     // C = reduction length, K = output channels (igemm naming)
-    // the narrow widths (16 ... 160: the expansions / projections of MobileNet / EfficientNet stacks, whose outputs dominate the
-    // bytes) came later: before, they ran on the 128 x 128 tile kernel with a zero-filled k-tile at 1.5-1.8 TB/s
-    const int kc = C / 16;
+    // the narrow / odd widths (16 ... 248 in steps of 8: the expansions / projections of MobileNet / EfficientNet / RegNet stacks,
+    // whose outputs dominate the bytes) came later: before, they ran on the 128 x 128 tile kernel with a zero-filled k-tile at
+    // 1.2-1.8 TB/s.  Multiples of 8 that are not multiples of 16 take the KPAD variant (half-empty last k-step).
     const bool wide = C == 64 || C == 96 || C == 128 || C == 192 || C == 256;
-    const bool narrow = C % 16 == 0 && (kc == 1 || kc == 2 || kc == 3 || kc == 5 || kc == 7 || kc == 9 || kc == 10) &&
-                        !get_flag("no_stream_narrow");
+    const int kc = (C + 15) / 16;
+    const bool narrow = C % 8 == 0 && C >= 16 && C < 256 && !get_flag("no_stream_narrow") &&
+                        (C % 16 == 0 || (kc >= 2 && kc <= 13) || kc == 15);
     return in_dtype == MV_BF16 && (out_dtype == MV_BF16 || out_dtype == MV_F32) && (wide || narrow) && K % 8 == 0 && M >= 8192;
 }
 
-template <int TN, int KC, typename OutT, bool LN = false, typename XT = bf16_t>
+template <int TN, int KC, typename OutT, bool LN = false, typename XT = bf16_t, bool KPAD = false>
 static int stream_go(StreamP& p, int tiles_n, hipStream_t st) {
     constexpr int WAVES = 8;
     // as many channel slabs per block as LDS holds next to the epilogue patches (160 KB per CU, one block per CU)
@@ -305,7 +316,7 @@ static int stream_go(StreamP& p, int tiles_n, hipStream_t st) {
     const int need = (p.tiles_m + WAVES - 1) / WAVES;
     if (gx > need) gx = need;
     dim3 grid(gx, gy), block(WAVES * 64);
-    auto kern = stream1x1_kernel<TN, KC, WAVES, OutT, LN, XT>;
+    auto kern = stream1x1_kernel<TN, KC, WAVES, OutT, LN, XT, KPAD>;
     if (smem > 48 * 1024)
         MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, grid, block, smem, st, p);
@@ -348,7 +359,7 @@ int stream1x1_launch(const void* x, const void* w, const float* scale, const flo
     p.M = (int)M; p.K = C; p.N = K;
     p.tiles_m = (int)((M + 31) / 32);
     p.act = act;
-    p.wpitch = C * 2 + 16;                                     // odd number of 16-byte slots: conflict-free fragments
+    p.wpitch = ((C + 15) / 16) * 32 + 16;                      // odd number of 16-byte slots: conflict-free fragments
     const bool f32o = out_dtype == MV_F32;
     const int bn = (K <= 64) ? 64 : 128;
     const int tiles_n = (K + bn - 1) / bn;
@@ -357,23 +368,50 @@ int stream1x1_launch(const void* x, const void* w, const float* scale, const flo
     set_kernel_name(name);
 #define GO(TN_, KC_)                                                              \
     return f32o ? stream_go<TN_, KC_, float>(p, tiles_n, st) : stream_go<TN_, KC_, bf16_t>(p, tiles_n, st)
-#define GOK(TN_)                  \
-    switch (C / 16) {             \
-        case 1: GO(TN_, 1);       \
-        case 2: GO(TN_, 2);       \
-        case 3: GO(TN_, 3);       \
-        case 4: GO(TN_, 4);       \
-        case 5: GO(TN_, 5);       \
-        case 6: GO(TN_, 6);       \
-        case 7: GO(TN_, 7);       \
-        case 8: GO(TN_, 8);       \
-        case 9: GO(TN_, 9);       \
-        case 10: GO(TN_, 10);     \
-        case 12: GO(TN_, 12);     \
-        default: GO(TN_, 16);     \
+#define GOP(TN_, KC_)                                                             \
+    return f32o ? stream_go<TN_, KC_, float, false, bf16_t, true>(p, tiles_n, st)  \
+                : stream_go<TN_, KC_, bf16_t, false, bf16_t, true>(p, tiles_n, st)
+#define GOK(TN_)                                                   \
+    if (C % 16) {                                                  \
+        switch ((C + 15) / 16) {                                   \
+            case 2: GOP(TN_, 2);                                   \
+            case 3: GOP(TN_, 3);                                   \
+            case 4: GOP(TN_, 4);                                   \
+            case 5: GOP(TN_, 5);                                   \
+            case 6: GOP(TN_, 6);                                   \
+            case 7: GOP(TN_, 7);                                   \
+            case 8: GOP(TN_, 8);                                   \
+            case 9: GOP(TN_, 9);                                   \
+            case 10: GOP(TN_, 10);                                 \
+            case 11: GOP(TN_, 11);                                 \
+            case 12: GOP(TN_, 12);                                 \
+            case 13: GOP(TN_, 13);                                 \
+            default: GOP(TN_, 15);                                 \
+        }                                                          \
+    }                                                              \
+    switch (C / 16) {                                              \
+        case 1: GO(TN_, 1);                                        \
+        case 2: GO(TN_, 2);                                        \
+        case 3: GO(TN_, 3);                                        \
+        case 4: GO(TN_, 4);                                        \
+        case 5: GO(TN_, 5);                                        \
+        case 6: GO(TN_, 6);                                        \
+        case 7: GO(TN_, 7);                                        \
+        case 8: GO(TN_, 8);                                        \
+        case 9: GO(TN_, 9);                                        \
+        case 10: GO(TN_, 10);                                      \
+        case 11: GO(TN_, 11);                                      \
+        case 12: GO(TN_, 12);                                      \
+        case 13: GO(TN_, 13);                                      \
+        case 14: GO(TN_, 14);                                      \
+        case 15: GO(TN_, 15);                                      \
+        default: GO(TN_, 16);                                      \
     }
-    if (bn == 64) GOK(2);
+    if (bn == 64) {
+        GOK(2);
+    }
     GOK(4);
+#undef GOP
 #undef GOK
 #undef GO
 }

@@ -1365,6 +1365,14 @@ def all_cases():
           ("stream_narrow/144_24_res_project", conv_nhwc_case(4, 56, 56, 144, 24, 1, 1, act=0, res=True, seed=575)),
           ("stream_narrow/160_960_hswish", conv_nhwc_case(48, 14, 14, 160, 960, 1, 1, act=3, seed=576)),
           ("stream_narrow/96_576_hsigmoid_f32out", conv_nhwc_case(4, 56, 56, 96, 576, 1, 1, act=4, out="fp32", seed=577)),
+          ("stream_narrow/pad_24_144_relu", conv_nhwc_case(4, 56, 56, 24, 144, 1, 1, act=1, seed=578)),
+          ("stream_narrow/pad_40_240_hswish_ragged", conv_nhwc_case(11, 28, 28, 40, 240, 1, 1, act=3, seed=579)),
+          ("stream_narrow/pad_72_24_res", conv_nhwc_case(4, 56, 56, 72, 24, 1, 1, act=0, res=True, seed=580)),
+          ("stream_narrow/pad_120_480_silu", conv_nhwc_case(12, 28, 28, 120, 480, 1, 1, act=6, seed=581)),
+          ("stream_narrow/pad_184_80", conv_nhwc_case(48, 14, 14, 184, 80, 1, 1, act=0, seed=582)),
+          ("stream_narrow/pad_200_80_f32out", conv_nhwc_case(48, 14, 14, 200, 80, 1, 1, act=0, out="fp32", seed=583)),
+          ("stream_narrow/pad_232_464_relu", conv_nhwc_case(48, 14, 14, 232, 464, 1, 1, act=1, seed=584)),
+          ("stream_narrow/exact_240_40_res", conv_nhwc_case(12, 28, 28, 240, 40, 1, 1, act=0, res=True, seed=585)),
           ("stream_narrow/off_16_96", conv_nhwc_case(2, 112, 112, 16, 96, 1, 1, act=6, seed=570, flags=("no_stream_narrow",))),
           ("oddc/pw_160_960", conv_nhwc_case(8, 7, 7, 160, 960, 1, 1, act=1, seed=557)),
           ("oddc/conv3x3_40_72_s2", conv_nhwc_case(2, 19, 19, 40, 72, 3, 3, stride=2, pad=1, act=1, seed=558)),
