@@ -39,6 +39,8 @@ PROTOTYPES = {
     "mv_bn_ema_fold1_fwd": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp],
     "mv_bn_mean_fwd": [_vp, _vp, _f, _vp, _i, _vp],
     "mv_bn_ema_fold_fwd": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp],
+    "mv_se_scale_supported": [_i, _i, _i],
+    "mv_se_scale_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp],
     "mv_channel_moments_ws": [_i],
     "mv_channel_moments_supported": [_i64, _i, _i],
     "mv_channel_moments_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],

@@ -32,6 +32,12 @@ class SqueezeExcitation(Module):
     @boundary
     def __call__(self, x, *, key=None):
         x = ops.as_map(x)
+        a, g = nn.act_name(self.activation.fn), nn.act_name(self.scale_activation.fn)
+        if a and g and type(self.avgpool) is nn.AdaptiveAvgPool2d and tuple(self.avgpool.target_shape) == (1, 1) \
+                and type(self.fc1) is nn.Conv2d and type(self.fc2) is nn.Conv2d:
+            s = ops.se_scale(x, self.fc1, self.fc2, a, g)            # the whole squeeze path in one launch
+            if s is not None:
+                return ops.channel_scale(x, s)
         s = self.avgpool(x)
         a = nn.act_name(self.activation.fn)
         s = ops.conv2d(s, self.fc1, None, a) if a else self.activation(ops.conv2d(s, self.fc1))

@@ -911,6 +911,32 @@ def concat_channels(xs) -> Act:
     return Act(y, "map", maps[0].batched)
 
 
+def se_scale(x: Act, fc1, fc2, act1, act2) -> Optional[Act]:
+    """SqueezeExcitation's scale vector [B, C] (layers/squeeze.py:47-60: mean -> fc1 -> activation -> fc2 -> scale activation) in
+    ONE launch, or None when the library has no fused path (caller: avgpool + two convolutions + activations)."""
+    x = as_map(x)
+    B, H, W, C = x.t.shape
+    S = fc1.out_channels
+    plain = all(tuple(c.kernel_size) == (1, 1) and tuple(c.stride) == (1, 1) and tuple(c.padding) == (0, 0) and c.groups == 1
+                for c in (fc1, fc2))
+    if (compute_dtype() != "bf16" or x.t.dtype != torch.bfloat16 or not plain or fc1.in_channels != C or fc2.in_channels != S
+            or fc2.out_channels != C or act1 not in ACT or act2 not in ACT or not _lib.load().mv_se_scale_supported(C, S, _lib.BF16)):
+        return None
+    w1, _, b1 = prep_conv(fc1, None, "krsc", "bf16")
+    cache = fc2._cache()
+    hit = cache.get("se_w2t")
+    if hit is None:                     # [S][C]: the kernel's threads read consecutive channels of a row
+        w = np.asarray(fc2.weight, np.float32).reshape(C, S)
+        hit = (_dev(np.ascontiguousarray(w.T), torch.bfloat16),
+               None if fc2.bias is None else _dev(np.asarray(fc2.bias, np.float32).reshape(-1), torch.float32))
+        cache["se_w2t"] = hit
+    w2, b2 = hit
+    s = empty((B, C), torch.bfloat16)
+    _lib.call("mv_se_scale_fwd", _ptr(x.t), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(s), B, H * W, C, S, ACT[act1], ACT[act2],
+              _lib.BF16, stream_ptr())
+    return Act(s, "vec", x.batched)
+
+
 def channel_scale(x: Act, s: Act) -> Act:
     """x * s with s one value per (image, channel): SqueezeExcitation's last line (layers/squeeze.py:60)."""
     x = as_map(x)

@@ -153,6 +153,15 @@ int mv_conv2d_nchw_split_fwd(const void* x, const void* w_hi, const void* w_lo, 
  * `x * scale_activation(fc2(...))`.  x, y NHWC [N, HW, C]; s [N, C]; all of `dtype`. */
 int mv_channel_scale_nhwc_fwd(const void* x, const void* s, void* y, int N, int64_t HW, int C, int dtype, mv_stream_t stream);
 
+/* SqueezeExcitation's scale vector in one launch (layers/squeeze.py:47-60): scale[n, c] = act2(b2 + w2 . act1(b1 + w1 . mean_hw x[n]))
+ * for an NHWC bf16 map x[N, HW, C]; w1 [S][C] and w2t [S][C] bf16 (the first 1x1 convolution's weights, the second's TRANSPOSED:
+ * both read along C), b1 / b2 fp32 or NULL; scale
+ * [N][C] bf16.  act1 / act2: any MV_ACT_* (relu / silu and sigmoid / hard_sigmoid in the reference's models).  Follow with
+ * mv_channel_scale_nhwc_fwd.  Flag "no_se_fused": pool, two B-row GEMMs and activation passes as separate launches. */
+int mv_se_scale_supported(int C, int S, int dtype);
+int mv_se_scale_fwd(const void* x, const void* w1, const float* b1, const void* w2t, const float* b2, void* scale, int N, int64_t HW,
+                    int C, int S, int act1, int act2, int dtype, mv_stream_t stream);
+
 /* Depthwise Conv2d (groups == in_channels == out_channels: mobilenetv2.py:58-68 `ConvNormActivation(hidden, hidden,
  * groups=hidden)`) with the folded BatchNorm and the activation in the same pass.  w_rsc: the (C, 1, R, S) filters re-laid
  * by the caller to [R][S][C] (channel-contiguous taps); x, y NHWC bf16; scale / shift fp32 [C] or NULL. */

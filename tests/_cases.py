@@ -591,6 +591,41 @@ def ln_linear_case(M, K, N, stream="fp32", act=0, seed=0, flags=()):
     return run
 
 
+def se_scale_case(N, H, W, C, S, act1=1, act2=5, seed=0):
+    """mv_se_scale_fwd (SqueezeExcitation's scale vector in one launch, layers/squeeze.py:47-60) vs float64:
+    act2(b2 + w2 . act1(b1 + w1 . mean_hw x))."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        acts = {0: lambda v: v, 1: O.relu, 3: O.hard_swish, 4: O.hard_sigmoid, 5: O.sigmoid, 6: O.silu}
+        x = bf(rng.standard_normal((N, H * W, C)) + rng.uniform(-1, 1, (N, 1, C)))
+        w1, w2 = bf(rng.standard_normal((S, C)) / np.sqrt(C)), bf(rng.standard_normal((C, S)) / np.sqrt(S))
+        b1, b2 = (0.2 * rng.standard_normal(S)).astype(np.float32), (0.2 * rng.standard_normal(C)).astype(np.float32)
+        L.set_flag("se_fused_always", 1)
+        try:
+            return body(L, rng, acts, x, w1, w2, b1, b2)
+        finally:
+            L.set_flag("se_fused_always", 0)
+
+    def body(L, rng, acts, x, w1, w2, b1, b2):
+        if not L.load().mv_se_scale_supported(C, S, 1):
+            return {"ok": False, "err": "mv_se_scale_supported says no"}
+        p = x.astype(np.float64).mean(1)
+        h = np.asarray(acts[act1]((p @ w1.astype(np.float64).T + b1).astype(np.float32)), np.float64)
+        ref = np.asarray(acts[act2]((h @ w2.astype(np.float64).T + b2).astype(np.float32)), np.float64)
+        xd, w1d, w2d = dev(x, "bf16"), dev(w1, "bf16"), dev(np.ascontiguousarray(w2.T), "bf16")      # w2 handed over transposed
+        b1d, b2d = dev(b1, "fp32"), dev(b2, "fp32")
+        y = torch.full((N, C), -7.0, dtype=torch.bfloat16, device="cuda")
+        L.call("mv_se_scale_fwd", xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), y.data_ptr(), N, H * W, C, S,
+               act1, act2, 1, _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, TOL_BF16)
+        info["kernel"] = kern
+        return info
+    return run
+
+
 def moments_case(rows, C, dtype="bf16", seed=0):
     """mv_channel_moments_fwd (per-channel batch sums of training-mode BatchNorm, two passes) vs float64 sums."""
     def run():
@@ -1412,6 +1447,12 @@ def all_cases():
           ("ln_linear/swin_qkv_192_576_bf16stream_ragged", ln_linear_case(8192 + 45, 192, 576, "bf16", seed=532, flags=(("ln_stream_192", 1),))),
           ("ln_linear/swin_fc1_96_384_gelu_bf16stream", ln_linear_case(8192 + 45, 96, 384, "bf16", act=2, seed=534)),
           ("ln_linear/k96_N200_tail", ln_linear_case(9000, 96, 200, "fp32", seed=533)),
+          ("se_scale/effnet_32_8_silu_sigmoid_112", se_scale_case(3, 112, 112, 32, 8, act1=6, act2=5, seed=590)),
+          ("se_scale/effnet_1152_48_7x7", se_scale_case(5, 7, 7, 1152, 48, act1=6, act2=5, seed=591)),
+          ("se_scale/mbv3_72_24_relu_hsigmoid", se_scale_case(4, 28, 28, 72, 24, act1=1, act2=4, seed=592)),
+          ("se_scale/regnet_104_26_odd_squeeze", se_scale_case(4, 14, 14, 104, 26, act1=1, act2=5, seed=593)),
+          ("se_scale/squeeze_4_one_pixel", se_scale_case(2, 1, 1, 96, 4, act1=6, act2=5, seed=594)),
+          ("se_scale/wide_2048_512", se_scale_case(2, 5, 5, 2048, 512, act1=1, act2=5, seed=595)),
           ("moments/c64_map_bf16", moments_case(8 * 112 * 112, 64, "bf16", seed=550)),
           ("moments/c2048_few_rows", moments_case(8 * 7 * 7, 2048, "bf16", seed=551)),
           ("moments/c96_fp32_ragged", moments_case(12345, 96, "fp32", seed=552)),
