@@ -68,9 +68,17 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwP p) {
 // k x k (3 or 5), pad k/2, no dilation (every depthwise layer of MobileNetV2 / V3 / EfficientNet): one thread = 4 consecutive output
 // columns x 8 channels.  The KS x ((4-1)*STRIDE + KS) input window is loaded once and every loaded pixel feeds up to KS outputs
 // (18 loads for 4 outputs at 3x3 stride 1 instead of 36; 40 instead of 100 at 5x5), a filter row's KS weight vectors once per row.
-template <int STRIDE, int KS>
+// WLDS: the KS x KS weight vectors of every channel sit in LDS for the whole block (loaded once) instead of being re-read through
+// the vector memory pipe by every thread -- 25 of the 65 loads per thread-iteration at 5x5.
+template <int STRIDE, int KS, bool WLDS = false>
 __global__ __launch_bounds__(256) void dwconv_kxk_kernel(const DwP p) {
     constexpr int TW = 4, IW = (TW - 1) * STRIDE + KS, PAD = KS / 2;
+    extern __shared__ __attribute__((aligned(16))) char wl[];
+    if (WLDS) {
+        const int nvec = KS * KS * (p.C >> 3);
+        for (int i = threadIdx.x; i < nvec; i += 256) ((uint4*)wl)[i] = ((const uint4*)p.w)[i];
+        __syncthreads();
+    }
     const int C8 = p.C >> 3, WT = (p.Wo + TW - 1) / TW;
     const long long total = (long long)p.N * p.Ho * WT * C8;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -92,7 +100,10 @@ __global__ __launch_bounds__(256) void dwconv_kxk_kernel(const DwP p) {
             if ((unsigned)hi >= (unsigned)p.H) continue;
             float wv[KS][8];
 #pragma unroll
-            for (int t = 0; t < KS; ++t) unpack8(*(const uint4*)(p.w + (long long)(rr * KS + t) * p.C + c), wv[t]);
+            for (int t = 0; t < KS; ++t) {
+                if (WLDS) unpack8(*(const uint4*)(wl + ((rr * KS + t) * p.C + c) * 2), wv[t]);
+                else unpack8(*(const uint4*)(p.w + (long long)(rr * KS + t) * p.C + c), wv[t]);
+            }
             const bf16_t* row = p.x + ((long long)b * p.H + hi) * p.W * p.C + c;
 #pragma unroll
             for (int j = 0; j < IW; ++j) {
@@ -151,6 +162,15 @@ int dwconv_launch(const void* x, const void* w, const float* scale, const float*
         snprintf(name, sizeof(name), "dwconv%dx%d_s%d_bf16x8x4", R, R, sh);
         set_kernel_name(name);
         const dim3 grid((unsigned)g), block(256);
+        const size_t wbytes = (size_t)R * R * C * 2;
+        if (wbytes <= 40 * 1024 && !get_flag("dwconv_no_wlds")) {        // weights in LDS (<= 40 KB: still four blocks per CU)
+            if (R == 3 && sh == 1) hipLaunchKernelGGL((dwconv_kxk_kernel<1, 3, true>), grid, block, wbytes, st, p);
+            else if (R == 3) hipLaunchKernelGGL((dwconv_kxk_kernel<2, 3, true>), grid, block, wbytes, st, p);
+            else if (sh == 1) hipLaunchKernelGGL((dwconv_kxk_kernel<1, 5, true>), grid, block, wbytes, st, p);
+            else hipLaunchKernelGGL((dwconv_kxk_kernel<2, 5, true>), grid, block, wbytes, st, p);
+            MV_LAUNCH_CHECK();
+            return MV_OK;
+        }
         if (R == 3 && sh == 1) hipLaunchKernelGGL((dwconv_kxk_kernel<1, 3>), grid, block, 0, st, p);
         else if (R == 3) hipLaunchKernelGGL((dwconv_kxk_kernel<2, 3>), grid, block, 0, st, p);
         else if (sh == 1) hipLaunchKernelGGL((dwconv_kxk_kernel<1, 5>), grid, block, 0, st, p);
