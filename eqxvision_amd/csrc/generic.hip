@@ -831,7 +831,7 @@ int mv_conv2d_nhwc_fwd(const void* x, const void* w, const float* scale, const f
 int mv_conv2d_nchw_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
                        int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act, int x_dtype,
                        int out_dtype, int tok_stride, int tok_offset, const float* pos, mv_stream_t stream) {
-    MV_CHECK_FUSED_ACT(act, "conv2d_nchw");
+    MV_CHECK_ARG(act >= MV_ACT_NONE && act <= MV_ACT_SILU, "conv2d_nchw: unknown activation %d", act);   // every epilogue of this entry has them all
     MV_CHECK_ARG(x && w && y, "conv2d_nchw: NULL pointer");
     MV_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0, "conv2d_nchw: non-positive dims");
     MV_CHECK_ARG(sh > 0 && sw > 0 && ph >= 0 && pw >= 0, "conv2d_nchw: bad stride/pad");

@@ -183,6 +183,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemP p) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 } else if (p.act == MV_ACT_GELU_TANH) {
                     v.x = gelu_tanh_f(v.x); v.y = gelu_tanh_f(v.y); v.z = gelu_tanh_f(v.z); v.w = gelu_tanh_f(v.w);
+                } else if (p.act > MV_ACT_GELU_TANH) {              // hard_swish / silu stems (MobileNetV3, EfficientNet)
+                    v.x = apply_act_rt(v.x, p.act); v.y = apply_act_rt(v.y, p.act); v.z = apply_act_rt(v.z, p.act); v.w = apply_act_rt(v.w, p.act);
                 }
                 uint2 u;
                 u.x = pack_bf2(v.x, v.y);
@@ -380,6 +382,9 @@ __global__ __launch_bounds__(256) void stem_patch_kernel(const StemV1P p) {
                 } else if (p.act == MV_ACT_GELU_TANH) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                } else if (p.act > MV_ACT_GELU_TANH) {              // hard_swish / silu stems (MobileNetV3, EfficientNet)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = apply_act_rt(v[e], p.act);
                 }
                 uint4 u;
                 u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
@@ -621,6 +626,9 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const PatchP p) {
                 } else if (p.act == MV_ACT_GELU_TANH) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                } else if (p.act > MV_ACT_GELU_TANH) {              // hard_swish / silu stems (MobileNetV3, EfficientNet)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = apply_act_rt(v[e], p.act);
                 }
                 Out8<bf16_t>::st(p.y + orow * p.K + n, v);
             }

@@ -316,10 +316,10 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
         sc, sh = bn_train_update(bn, y)
         return _bn_affine(y, sc, sh, act, None if residual is None else as_map(residual))
     dt = compute_dtype()
-    if act in UNFUSED_ACTS and (dt != "bf16" or x.kind == "img" or conv.out_channels % 8 or
+    if act in UNFUSED_ACTS and (dt != "bf16" or (x.kind != "img" and conv.out_channels % 8) or
                                 (conv.groups > 1 and not conv.groups == conv.in_channels == conv.out_channels)):
-        # hard_swish & co. are fused by the NHWC bf16 convolution (dense: one GEMM kernel has them; depthwise: in the kernel); the
-        # image-entry kernel, the grouped / padded-width paths and fp32 mode take an element-wise pass instead
+        # hard_swish & co. are fused by the NHWC bf16 convolution (dense: the streaming / one tile kernel have them; depthwise: in
+        # the kernel) and by the image-entry kernels; the grouped / padded-width paths and fp32 mode take an element-wise pass
         return eltwise(conv2d(x, conv, bn, None, residual), act)
     kh, kw = conv.kernel_size
     sh, sw = conv.stride

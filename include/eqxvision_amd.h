@@ -32,9 +32,10 @@ typedef void* mv_stream_t; /* hipStream_t */
 
 enum { MV_F32 = 0, MV_BF16 = 1 };
 /* Activations.  0-2 are fused into every GEMM / convolution epilogue.  3-6 (jax.nn.hard_swish / hard_sigmoid / sigmoid / silu:
- * mobilenetv3.py:57,72, efficientnet.py:117, lraspp.py:102) are implemented by mv_conv2d_nhwc_fwd (routed to the one GEMM kernel
- * whose epilogue has them), the depthwise convolution and the element-wise entries (mv_eltwise_fwd, mv_add_fwd,
- * mv_channel_affine_fwd); every other matrix-core entry refuses them with MV_E_INVALID. */
+ * mobilenetv3.py:57,72, efficientnet.py:117, lraspp.py:102) are implemented by mv_conv2d_nhwc_fwd (routed to the streaming kernel or
+ * the one tile kernel whose epilogues have them), mv_conv2d_nchw_fwd (the image-entry kernels: the SiLU / hard-swish stems), the
+ * depthwise convolution, mv_se_scale_fwd and the element-wise entries (mv_eltwise_fwd, mv_add_fwd, mv_channel_affine_fwd); every
+ * other matrix-core entry refuses them with MV_E_INVALID. */
 enum { MV_ACT_NONE = 0, MV_ACT_RELU = 1, MV_ACT_GELU_TANH = 2, MV_ACT_HARD_SWISH = 3, MV_ACT_HARD_SIGMOID = 4, MV_ACT_SIGMOID = 5,
        MV_ACT_SILU = 6 };
 enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
