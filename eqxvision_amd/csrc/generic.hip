@@ -370,31 +370,35 @@ __global__ void global_avgpool_bf16x8_kernel(const uint4* __restrict__ x, TO* __
 // branch): one thread per (image, 8 channels) would walk 12 544 pixels serially with a few thousand threads on the whole chip
 // (measured 1.27 ms for 128 x 112 x 112 x 32).  Here a block of 256 threads owns one image and up to 32 channel chunks; the
 // threads of a chunk stride over the pixels (whole 128-byte lines per pixel across the chunk lanes) and meet in LDS.
-template <typename TO>
-__global__ __launch_bounds__(1024) void global_avgpool_wide_kernel(const uint4* __restrict__ x, TO* __restrict__ y, int HW, int C8,
+template <typename TI, typename TO>
+__global__ __launch_bounds__(1024) void global_avgpool_wide_kernel(const TI* __restrict__ x, TO* __restrict__ y, int HW, int C8,
                                                                    int cpb, int pl) {
     __shared__ float red[1024 * 8];
     const int n = blockIdx.x, c8 = blockIdx.y * cpb + (int)threadIdx.x % cpb, lp = (int)threadIdx.x / cpb;
+    const long long C = (long long)C8 * 8;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (lp < pl && c8 < C8) {
-        const uint4* xp = x + (long long)n * HW * C8 + c8;
-        auto acc = [&](const uint4& v) {
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s[2 * e] += __uint_as_float(w[e] << 16);
-                s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
-            }
+        const TI* xp = x + (long long)n * HW * C + c8 * 8;
+        auto ld = [&](int p, float4& a, float4& b) {
+            a = Out4<TI>::ld(xp + (long long)p * C);
+            b = Out4<TI>::ld(xp + (long long)p * C + 4);
+        };
+        auto acc = [&](const float4& a, const float4& b) {
+            s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w; s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
         };
         int p = lp;
         for (; p + 3 * pl < HW; p += 4 * pl) {              // four pixels in flight per thread (1024 threads per image: the block
-            uint4 v[4];                                    // count is only images x channel chunks)
+            float4 a[4], b[4];                              // count is only images x channel chunks)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = xp[(long long)(p + u * pl) * C8];
+            for (int u = 0; u < 4; ++u) ld(p + u * pl, a[u], b[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc(v[u]);
+            for (int u = 0; u < 4; ++u) acc(a[u], b[u]);
         }
-        for (; p < HW; p += pl) acc(xp[(long long)p * C8]);
+        for (; p < HW; p += pl) {
+            float4 a, b;
+            ld(p, a, b);
+            acc(a, b);
+        }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[e];
@@ -1094,21 +1098,25 @@ int mv_adaptive_avgpool2d_nhwc_fwd(const void* x, void* y, int N, int H, int W, 
     MV_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && oh > 0 && ow > 0 && oh <= H && ow <= W, "avgpool: bad args");
     hipStream_t st = (hipStream_t)stream;
     const long long total = (long long)N * oh * ow * C;
-    if (oh == 1 && ow == 1 && in_dtype == MV_BF16 && C % 8 == 0 && !get_flag("force_generic")) {
+    if (oh == 1 && ow == 1 && C % 8 == 0 && !get_flag("force_generic")) {
         // a block per (image, 32-channel-vector chunk): big maps always; small maps too when one thread per (image, 8 channels)
-        // would leave most of the chip without a wave (squeeze-excitation on 14 x 14 / 7 x 7 maps at 128 images)
+        // would leave most of the chip without a wave (squeeze-excitation on 14 x 14 / 7 x 7 maps at 128 images; Swin's last map in fp32)
         const bool wide = (long long)H * W >= 256 || ((long long)H * W >= 32 && (long long)N * (C / 8) <= 24576);
         if (wide && N <= 65535 && !get_flag("avgpool_narrow")) {
             const int C8 = C / 8, cpb = C8 < 32 ? C8 : 32, pl = 1024 / cpb;
-            set_kernel_name("global_avgpool_wide_bf16x8");
+            set_kernel_name(in_dtype == MV_BF16 ? "global_avgpool_wide_bf16x8" : "global_avgpool_wide_f32x8");
             dim3 g((unsigned)N, (unsigned)((C8 + cpb - 1) / cpb));
-            if (out_dtype == MV_BF16)
-                hipLaunchKernelGGL(global_avgpool_wide_kernel<bf16_t>, g, dim3(1024), 0, st, (const uint4*)x, (bf16_t*)y, H * W, C8, cpb, pl);
-            else
-                hipLaunchKernelGGL(global_avgpool_wide_kernel<float>, g, dim3(1024), 0, st, (const uint4*)x, (float*)y, H * W, C8, cpb, pl);
+#define GOW(TI, TO) hipLaunchKernelGGL((global_avgpool_wide_kernel<TI, TO>), g, dim3(1024), 0, st, (const TI*)x, (TO*)y, H * W, C8, cpb, pl)
+            if (in_dtype == MV_BF16 && out_dtype == MV_BF16) GOW(bf16_t, bf16_t);
+            else if (in_dtype == MV_BF16) GOW(bf16_t, float);
+            else if (out_dtype == MV_BF16) GOW(float, bf16_t);
+            else GOW(float, float);
+#undef GOW
             MV_LAUNCH_CHECK();
             return MV_OK;
         }
+    }
+    if (oh == 1 && ow == 1 && in_dtype == MV_BF16 && C % 8 == 0 && !get_flag("force_generic")) {
         set_kernel_name("global_avgpool_bf16x8");
         const long long nt = (long long)N * (C / 8);
         if (out_dtype == MV_BF16)
