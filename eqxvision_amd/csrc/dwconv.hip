@@ -140,6 +140,89 @@ __global__ __launch_bounds__(256) void dwconv_kxk_kernel(const DwP p) {
     }
 }
 
+// Stride 1, k = 3 / 5, pad k/2: the input window of an 8 x 16 output tile and a slab of 64 channels (8 vectors) goes through LDS --
+// every input pixel is fetched from memory ONCE per tile (coalesced 128-byte pieces) instead of up to k x k times through L1 by the
+// threads that need it (40 vector loads per 4 outputs at 5x5: the kernel above runs at 1.1-1.3 TB/s there).  256 threads: thread =
+// (vector v of the slab, 4 consecutive output columns of one row); pixel pitch 144 bytes in LDS: the 8 pixel groups a wave reads at
+// once start 64 bytes apart modulo the 256-byte bank period (conflict-free 16-byte reads).  The filter vectors of the slab sit in
+// LDS too.  What bounds it then is the fp32 FMA count (25 per value at 5x5).
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_tile_kernel(const DwP p) {
+    constexpr int TH = 8, TWB = 16, PAD = KS / 2, IH = TH + KS - 1, IWB = TWB + KS - 1, PP = 144;
+    __shared__ __attribute__((aligned(16))) char xl[IH * IWB * PP];
+    __shared__ __attribute__((aligned(16))) uint4 wl[KS * KS * 8];
+    const int C8 = p.C >> 3;
+    const int tiles_w = (p.Wo + TWB - 1) / TWB;
+    const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
+    const int v0 = blockIdx.y * 8, b = blockIdx.z;
+    const int nvec = (C8 - v0) < 8 ? (C8 - v0) : 8;
+    const int ho0 = th * TH, wo0 = tw * TWB;
+    const int tid = threadIdx.x;
+    // ---- filter vectors and the input window -> LDS (zeros outside the image / past the last channel vector)
+    for (int i = tid; i < KS * KS * 8; i += 256) {
+        const int t = i >> 3, v = i & 7;
+        wl[i] = v < nvec ? *(const uint4*)(p.w + (long long)t * p.C + (v0 + v) * 8) : make_uint4(0, 0, 0, 0);
+    }
+    const bf16_t* xb = p.x + (long long)b * p.H * p.W * p.C;
+    for (int i = tid; i < IH * IWB * 8; i += 256) {
+        const int pix = i >> 3, v = i & 7;
+        const int iy = pix / IWB, ix = pix - iy * IWB;
+        const int hi = ho0 - PAD + iy, wi = wo0 - PAD + ix;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (v < nvec && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+            u = *(const uint4*)(xb + ((long long)hi * p.W + wi) * p.C + (v0 + v) * 8);
+        *(uint4*)(xl + pix * PP + v * 16) = u;
+    }
+    __syncthreads();
+    const int v = tid & 7, q = tid >> 3;
+    const int row = q >> 2, col0 = (q & 3) * 4;
+    if (v >= nvec) return;
+    float acc[4][8];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[o][e] = 0.f;
+#pragma unroll 1
+    for (int rr = 0; rr < KS; ++rr) {                       // (not unrolled: the whole window in registers costs the occupancy)
+        float wv[KS][8];
+#pragma unroll
+        for (int t = 0; t < KS; ++t) unpack8(wl[(rr * KS + t) * 8 + v], wv[t]);
+        const char* xr = xl + ((row + rr) * IWB + col0) * PP + v * 16;
+#pragma unroll
+        for (int j = 0; j < 4 + KS - 1; ++j) {
+            float xv[8];
+            unpack8(*(const uint4*)(xr + j * PP), xv);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int ss = j - o;
+                if (ss >= 0 && ss < KS) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(xv[e], wv[ss][e], acc[o][e]);
+                }
+            }
+        }
+    }
+    const int c = (v0 + v) * 8, ho = ho0 + row;
+    if (ho >= p.Ho) return;
+    float sc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, sf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.scale) {
+        const float4 a = *(const float4*)(p.scale + c), b2 = *(const float4*)(p.scale + c + 4);
+        sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b2.x; sc[5] = b2.y; sc[6] = b2.z; sc[7] = b2.w;
+    }
+    if (p.shift) {
+        const float4 a = *(const float4*)(p.shift + c), b2 = *(const float4*)(p.shift + c + 4);
+        sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w; sf[4] = b2.x; sf[5] = b2.y; sf[6] = b2.z; sf[7] = b2.w;
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const int wo = wo0 + col0 + o;
+        if (wo >= p.Wo) break;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[o][e] = apply_act_rt(fmaf(acc[o][e], sc[e], sf[e]), p.act);
+        Out8<bf16_t>::st(p.y + (((long long)b * p.Ho + ho) * p.Wo + wo) * p.C + c, acc[o]);
+    }
+}
+
 int dwconv_supported(int C, int K, int groups, int R, int S, int in_dtype, int out_dtype) {
     return groups == C && K == C && C % 8 == 0 && R * S <= 49 && in_dtype == MV_BF16 && out_dtype == MV_BF16;
 }
@@ -157,6 +240,18 @@ int dwconv_launch(const void* x, const void* w, const float* scale, const float*
     const long long total = (long long)N * p.Ho * (fast ? (p.Wo + 3) / 4 : p.Wo) * (C / 8);
     long long g = (total + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
+    // stride 1, 5 x 5: the LDS-tiled kernel.  (3 x 3 too with flag "dwconv_tile3": its window overlaps little enough that L1 serves the
+    // register-window kernel well; the tile's 40 % halo and barrier cost more: -2.5 % / -4 % on mobilenet_v2 / v3.)
+    if (fast && sh == 1 && N <= 65535 && !get_flag("dwconv_no_tile") && (R == 5 || get_flag("dwconv_tile3"))) {
+        char name[48];
+        snprintf(name, sizeof(name), "dwconv%dx%d_s1_lds_tile", R, R);
+        set_kernel_name(name);
+        const dim3 grid((unsigned)(((p.Ho + 7) / 8) * ((p.Wo + 15) / 16)), (unsigned)((C / 8 + 7) / 8), (unsigned)N);
+        if (R == 3) hipLaunchKernelGGL((dwconv_tile_kernel<3>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((dwconv_tile_kernel<5>), grid, dim3(256), 0, st, p);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
     if (fast) {
         char name[48];
         snprintf(name, sizeof(name), "dwconv%dx%d_s%d_bf16x8x4", R, R, sh);

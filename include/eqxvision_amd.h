@@ -44,7 +44,7 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  * "igemm8" (2 / 3 / 4 = force the ping-pong GEMM with 256x256 / 128x256 / 256x128 tiles), "no_igemm8",
  * "igemm2_tile" (1 / 2 / 3 = force igemm2 with 256x64 / 256x128 / 256x256 tiles), "no_igemm2", "igemm2_dense_m",
  * "igemm_tile" (1 / 2 = force the 128x128 / 128x64 kernel), "res_early", "no_stream" (no streaming 1x1 / 3x3c64 kernels),
- * "stream_npass1", "no_stream_narrow" (reductions of 16 ... 160 channels back on the tile kernels), "stem_v0", "no_stem_pool", "no_dual", "no_chain", "no_chain_stream" (only the streamed-weights variant off), "no_dual_chain", "no_grouped64", "no_dwconv", "dwconv_generic" (one output pixel per thread for every depthwise shape), "no_oddc" (channel counts that are not multiples of 64 back on the scalar kernel), "no_ln_mlp", "ln_mlp_waves" (8 / 12 / 16), "no_ln_stream", "ln_stream_192", "eltwise_scalar" / "affine_scalar" (the one-value-per-thread element-wise kernels for every size), "dropout_x8" / "dropout_scalar" (training-mode Dropout without the pair-sharing / vector kernels), "no_skinny", "no_tuned", and the
+ * "stream_npass1", "no_stream_narrow" (reductions of 16 ... 160 channels back on the tile kernels), "stem_v0", "no_stem_pool", "no_dual", "no_chain", "no_chain_stream" (only the streamed-weights variant off), "no_dual_chain", "no_grouped64", "no_dwconv", "dwconv_generic" (one output pixel per thread for every depthwise shape), "dwconv_no_tile" (stride-1 depthwise layers back on the register-window kernel), "no_oddc" (channel counts that are not multiples of 64 back on the scalar kernel), "no_ln_mlp", "ln_mlp_waves" (8 / 12 / 16), "no_ln_stream", "ln_stream_192", "eltwise_scalar" / "affine_scalar" (the one-value-per-thread element-wise kernels for every size), "dropout_x8" / "dropout_scalar" (training-mode Dropout without the pair-sharing / vector kernels), "no_skinny", "no_tuned", and the
  * per-shape kernel choice "ov:<M>:<C>:<K>:<R>:<S>:<stride>" / "ovh:<M>:<N>:<K>:1:1:1" / "ovd:<M>:<C1>:<C2>:<K>:<stride>:1"
  * (tools/tune_tiles.py; codes in csrc/igemm.hip). */
 

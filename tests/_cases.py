@@ -384,10 +384,19 @@ def linear_split_case(M, K, N, out="fp32", seed=0):
     return run
 
 
-def dwconv_case(N, H, W, C, R=3, stride=1, pad=1, dil=1, act=1, scale=True, seed=0):
+def dwconv_case(N, H, W, C, R=3, stride=1, pad=1, dil=1, act=1, scale=True, seed=0, flag=None):
     """mv_dwconv2d_nhwc_fwd (depthwise conv + folded BN + act) vs the oracle's conv2d with groups == channels."""
     def run():
         L = _lib()
+        if flag:
+            L.set_flag(flag, 1)
+        try:
+            return body(L)
+        finally:
+            if flag:
+                L.set_flag(flag, 0)
+
+    def body(L):
         rng = _rng(seed)
         x = bf(rng.standard_normal((N, C, H, W)))
         w = bf(rng.standard_normal((C, 1, R, R)) / np.sqrt(R * R))
@@ -403,6 +412,10 @@ def dwconv_case(N, H, W, C, R=3, stride=1, pad=1, dil=1, act=1, scale=True, seed
             ref = np.maximum(ref, 0)
         elif act == 3:
             ref = O.hard_swish(ref).astype(np.float64)
+        elif act == 6:
+            ref = O.silu(ref).astype(np.float64)
+        elif act != 0:
+            raise ValueError(f"dwconv_case: no reference for activation {act}")
         Ho = ref.shape[2]
         xd = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1)), "bf16")
         wd = dev(np.ascontiguousarray(w[:, 0].transpose(1, 2, 0)), "bf16")
@@ -1388,6 +1401,10 @@ def all_cases():
           ("dwconv/k5_s1_120_28", dwconv_case(3, 28, 28, 120, R=5, pad=2, seed=562)),
           ("dwconv/k5_s2_72_w_tail", dwconv_case(2, 27, 31, 72, R=5, stride=2, pad=2, seed=563)),
           ("dwconv/k5_hard_swish_fused", dwconv_case(2, 14, 14, 672, R=5, pad=2, act=3, seed=564)),
+          ("dwconv/k5_tile_ragged_9x21_c200", dwconv_case(3, 9, 21, 200, R=5, pad=2, act=6, seed=565)),
+          ("dwconv/k5_tile_one_pixel_c8", dwconv_case(2, 1, 1, 8, R=5, pad=2, seed=566)),
+          ("dwconv/k3_tile_flag_57x33_c72", dwconv_case(2, 57, 33, 72, seed=567, flag="dwconv_tile3")),
+          ("dwconv/k5_register_window_flag", dwconv_case(3, 28, 28, 120, R=5, pad=2, seed=562, flag="dwconv_no_tile")),
           ("dwconv/odd_hw_k5_dil2_noscale_noact", dwconv_case(2, 13, 17, 24, R=5, pad=4, dil=2, act=0, scale=False, seed=553)),
           ("oddc/pw_24_144", conv_nhwc_case(4, 56, 56, 24, 144, 1, 1, act=1, seed=554)),
           ("oddc/pw_144_24_res", conv_nhwc_case(4, 56, 56, 144, 24, 1, 1, act=0, res=True, seed=555)),
