@@ -34,6 +34,7 @@ PROTOTYPES = {
     "mv_comm_rank": [],
     "mv_allgather": [_vp, _vp, C.c_size_t, _vp],
     "mv_allreduce_sum_f32": [_vp, C.c_size_t, _vp],
+    "mv_prng_split": [_vp, _vp, _i64, _i, _i, _vp],
     "mv_dropout_fwd": [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp],
     "mv_channel_moments2_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "mv_bn_ema_fold1_fwd": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp],
@@ -78,6 +79,7 @@ PROTOTYPES = {
     "mv_linear_heads_supported": [_i64, _i, _i, _i, _i, _i],
     "mv_linear_heads_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
     "mv_mha_heads_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "mv_mha_dropout_fwd": [_vp, _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _f, _i, _vp],
     "mv_swin_window_attn_fwd": [_vp, _vp, _vp] + [_i] * 9 + [_i, _vp],
     "mv_patch_merge_gather_nhwc": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mv_vit_cls_pos_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -15,6 +15,7 @@
 // Whole-row softmax (N <= 256 keys held in accumulators): no online rescaling needed for ViT's
 // N = 197.  Longer sequences / odd head sizes use the generic kernel.
 #include "common.h"
+#include "rng_common.h"
 
 namespace mv {
 
@@ -23,7 +24,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int DH, int NT, bool HM, bool PR>
 __global__ __launch_bounds__(512) void mha_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                      float* __restrict__ probs, int B, int N, int H, float scale) {
+                                                      float* __restrict__ probs, int B, int N, int H, float scale,
+                                                      const uint32_t* __restrict__ drop_keys, float keep) {
     constexpr int NP = NT * 32;                                     // padded key count
     constexpr int KPITCH = DH * 2 + 16;                             // bytes; odd number of 16-B slots
     constexpr int VPITCH = NP * 2 + 16;                             // bytes; 16 * odd: 16-byte aligned, conflict-free b128 rows
@@ -198,7 +200,41 @@ __global__ __launch_bounds__(512) void mha_mfma_kernel(const bf16_t* __restrict_
             sum += __shfl_xor(sum, 32);
             const float inv = 1.f / sum;
 
-            if (PR && qvalid) {
+            if constexpr (PR) {
+                // live attention dropout (vit.py:71, training mode): attn = where(bernoulli(key, keep, (1,H,N,N)), attn / keep, 0)
+                // -- word ((h * N + q) * N + key) of the sample's Threefry stream (rng_common.h) decides each probability; the
+                // dropped matrix is what multiplies V AND what the block returns.  A run-time branch of the probs variant only.
+                if (drop_keys) {
+                    const uint32_t k0 = drop_keys[2 * b], k1 = drop_keys[2 * b + 1];
+                    const uint32_t nel = (uint32_t)H * N * N, base = ((uint32_t)h * N + (qvalid ? q : 0)) * N;
+                    const float rk = 1.f / keep;
+                    // the draws first, one key tile per trip of a ROLLED loop into a bit mask (unrolling 16 * NT Threefry calls
+                    // next to the score registers goes past the compiler's unroll budget and the scores land in scratch) ...
+                    uint64_t mlo = 0, mhi = 0;
+#pragma unroll 1
+                    for (int kt = 0; kt < NT; ++kt) {
+                        uint32_t bits = 0;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                            const uint32_t el = base + (key < N ? key : 0);
+                            bits |= (word_uniform01(stream_word(k0, k1, el, nel)) < keep ? 1u : 0u) << e;
+                        }
+                        const uint64_t sh = (uint64_t)bits << (16 * (kt & 3));
+                        mlo |= kt < 4 ? sh : 0ull;
+                        mhi |= kt < 4 ? 0ull : sh;
+                    }
+                    // ... then applied with static register indices
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const uint64_t m = kt < 4 ? mlo : mhi;
+                            sacc[kt][e] = (m >> (16 * (kt & 3) + e)) & 1ull ? sacc[kt][e] * rk : 0.f;
+                        }
+                }
+            }
+            if (PR && qvalid && probs) {
                 float* pr = probs + (((long long)b * H + h) * N + q) * N;
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt)
@@ -274,18 +310,18 @@ int mha_mfma_supported(int N, int dh, int dtype) {
 
 template <int DH>
 static int mha_launch_dh(const void* qkv, bool hm, void* out, float* probs, int B, int N, int H, float scale,
-                         hipStream_t st) {
+                         const uint32_t* drop_keys, float keep, hipStream_t st) {
     const int nt = (N + 31) / 32;
     const int pairs = B * H;
     dim3 grid(pairs < 256 ? pairs : 256), block(512);       // persistent: one 8-wave block per CU walks the (image, head) pairs
 #define LAUNCH(NT_, HM_, PR_)                                                                           \
     hipLaunchKernelGGL((mha_mfma_kernel<DH, NT_, HM_, PR_>), grid, block, 0, st, (const bf16_t*)qkv, (bf16_t*)out, \
-                       probs, B, N, H, scale)
+                       probs, B, N, H, scale, drop_keys, keep)
 #define GO(NT_)                                                                                                 \
     case NT_:                                                                                                   \
-        if (hm && probs) LAUNCH(NT_, true, true);                                                               \
+        if (hm && (probs || drop_keys)) LAUNCH(NT_, true, true);                                                \
         else if (hm) LAUNCH(NT_, true, false);                                                                  \
-        else if (probs) LAUNCH(NT_, false, true);                                                               \
+        else if (probs || drop_keys) LAUNCH(NT_, false, true);                                                  \
         else LAUNCH(NT_, false, false);                                                                         \
         break;
     switch (nt) {
@@ -301,15 +337,15 @@ static int mha_launch_dh(const void* qkv, bool hm, void* out, float* probs, int 
 }
 
 int mha_mfma_launch(const void* qkv, int head_major, void* out, float* probs, int B, int N, int H, int dh, float scale,
-                    hipStream_t st) {
+                    const uint32_t* drop_keys, float keep, hipStream_t st) {
     if ((long long)B * H >= (1LL << 31)) {
         set_error("mha_mfma: B*H too large");
         return MV_E_UNSUPPORTED;
     }
     if (head_major) set_kernel_name(dh == 64 ? "mha_mfma_dh64_hm" : "mha_mfma_dh32_hm");
     else set_kernel_name(dh == 64 ? "mha_mfma_dh64" : "mha_mfma_dh32");
-    if (dh == 64) return mha_launch_dh<64>(qkv, head_major != 0, out, probs, B, N, H, scale, st);
-    return mha_launch_dh<32>(qkv, head_major != 0, out, probs, B, N, H, scale, st);
+    if (dh == 64) return mha_launch_dh<64>(qkv, head_major != 0, out, probs, B, N, H, scale, drop_keys, keep, st);
+    return mha_launch_dh<32>(qkv, head_major != 0, out, probs, B, N, H, scale, drop_keys, keep, st);
 }
 
 }  // namespace mv

@@ -193,6 +193,6 @@ int stem_pool_launch(const void* x, const void* w, const float* scale, const flo
                      int x_dtype, hipStream_t stream);
 int mha_mfma_supported(int N, int dh, int dtype);
 int mha_mfma_launch(const void* qkv, int head_major, void* out, float* probs, int B, int N, int H, int dh, float scale,
-                    hipStream_t stream);
+                    const uint32_t* drop_keys, float keep, hipStream_t st);
 
 }  // namespace mv

@@ -1199,7 +1199,7 @@ int mv_mha_fwd(const void* qkv, void* out, float* probs, int B, int N, int H, in
     MV_CHECK_ARG(qkv && out && B > 0 && N > 0 && H > 0 && dh > 0, "mha: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (!get_flag("force_generic") && dtype == MV_BF16 && mha_mfma_supported(N, dh, dtype))
-        return mha_mfma_launch(qkv, 0, out, probs, B, N, H, dh, scale, st);
+        return mha_mfma_launch(qkv, 0, out, probs, B, N, H, dh, scale, nullptr, 1.f, st);
     MV_CHECK_ARG(H <= 65535 && B <= 65535, "mha: H/B too large for the generic kernel");
     const size_t smem = (size_t)(N + dh) * sizeof(float);
     MV_CHECK_ARG(smem <= 64 * 1024, "mha: sequence too long for the generic kernel (N=%d)", N);
@@ -1256,7 +1256,19 @@ int mv_mha_heads_fwd(const void* qkv, void* out, float* probs, int B, int N, int
         set_error("mha_heads: unsupported N=%d dh=%d dtype=%d", N, dh, dtype);
         return MV_E_UNSUPPORTED;
     }
-    return mha_mfma_launch(qkv, 1, out, probs, B, N, H, dh, scale, (hipStream_t)stream);
+    return mha_mfma_launch(qkv, 1, out, probs, B, N, H, dh, scale, nullptr, 1.f, (hipStream_t)stream);
+}
+
+int mv_mha_dropout_fwd(const void* qkv, int head_major, void* out, float* probs, const uint32_t* keys, float keep_prob,
+                       int B, int N, int H, int dh, float scale, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(qkv && out && keys && B > 0 && N > 0 && H > 0 && dh > 0, "mha_dropout: bad args");
+    MV_CHECK_ARG(keep_prob > 0.f && keep_prob <= 1.f, "mha_dropout: keep_prob %g outside (0, 1]", (double)keep_prob);
+    MV_CHECK_ARG((long long)H * N * N < (1LL << 32), "mha_dropout: more than 2^32 probabilities per sample");
+    if (dtype != MV_BF16 || !mha_mfma_supported(N, dh, dtype)) {
+        set_error("mha_dropout: unsupported N=%d dh=%d dtype=%d (bf16, dh 32 / 64, N <= 256)", N, dh, dtype);
+        return MV_E_UNSUPPORTED;
+    }
+    return mha_mfma_launch(qkv, head_major, out, probs, B, N, H, dh, scale, keys, keep_prob, (hipStream_t)stream);
 }
 
 int mv_swin_window_attn_fwd(const void* qkv, const float* bias, void* out, int B, int Hf, int Wf, int C, int heads,

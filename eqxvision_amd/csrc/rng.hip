@@ -6,39 +6,9 @@
 // is word i of the sample's stream.  Read x, write y; the ~110 integer operations of a Threefry call per element (55 when a call
 // serves two elements, dropout_pair_kernel) are what bounds it: 2.5 TB/s of the 4-5 a pure stream reaches.
 #include "mfma_common.h"
+#include "rng_common.h"
 
 namespace mv {
-
-__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
-
-// Threefry-2x32-20 (Random123; jax/_src/prng.py threefry2x32)
-__device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1) {
-    const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
-    constexpr int R[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
-    x0 += ks[0];
-    x1 += ks[1];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            x0 += x1;
-            x1 = rotl32(x1, R[i & 1][j]) ^ x0;
-        }
-        x0 += ks[(i + 1) % 3];
-        x1 += ks[(i + 2) % 3] + (uint32_t)(i + 1);
-    }
-}
-
-// word i of the n-word stream of one key: counters 0 .. n-1 (+ one 0 when n is odd) cut in two halves (x0 | x1)
-__device__ __forceinline__ uint32_t stream_word(uint32_t k0, uint32_t k1, uint32_t i, uint32_t n) {
-    const uint32_t half = (n + 1) >> 1;
-    const bool lo = i < half;
-    uint32_t x0 = lo ? i : i - half;
-    uint32_t c1 = x0 + half;
-    uint32_t x1 = c1 < n ? c1 : 0u;                 // the padding counter
-    threefry2x32(k0, k1, x0, x1);
-    return lo ? x0 : x1;
-}
 
 template <typename T>
 __global__ void dropout_kernel(const T* x, const uint32_t* keys, T* y, long long per, int C, long long HW, int chw, float q,
@@ -161,7 +131,31 @@ __global__ void dropout_pair_kernel(const T* x, const uint32_t* keys, T* y, long
 
 using namespace mv;
 
+// jax.random.split of R keys at once: child i of key r = words (2i, 2i + 1) of r's 2 * num-word stream (a thread per child)
+__global__ void prng_split_kernel(const uint32_t* keys, uint32_t* out, long long R, int num, int child_major) {
+    const long long total = R * num;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const long long r = g / num;
+        const int i = (int)(g - r * num);
+        const uint32_t k0 = keys[2 * r], k1 = keys[2 * r + 1], n = 2u * (uint32_t)num;
+        const long long o = child_major ? ((long long)i * R + r) * 2 : g * 2;
+        out[o] = stream_word(k0, k1, 2u * i, n);
+        out[o + 1] = stream_word(k0, k1, 2u * i + 1, n);
+    }
+}
+
 extern "C" {
+
+int mv_prng_split(const void* keys, void* out, int64_t R, int num, int child_major, mv_stream_t stream) {
+    MV_CHECK_ARG(keys && out && keys != out, "prng_split: NULL or aliased pointers");
+    MV_CHECK_ARG(R > 0 && num > 0 && num < (1 << 30), "prng_split: bad dims R=%lld num=%d", (long long)R, num);
+    long long g = (R * num + 255) / 256;
+    set_kernel_name("prng_split");
+    hipLaunchKernelGGL(prng_split_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint32_t*)keys, (uint32_t*)out, (long long)R, num, child_major);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
 
 int mv_dropout_fwd(const void* x, const void* keys, void* y, int B, int64_t per_sample, int C, int chw_logical, float keep_prob,
                    int dtype, mv_stream_t stream) {

@@ -6,6 +6,7 @@ from __future__ import annotations
 
 from typing import Callable, Tuple, Union
 
+
 from .. import nn, ops
 from .. import random as jr
 from .._module import Module
@@ -32,8 +33,14 @@ class MlpProjection(Module):
         self.fc2 = lin_layer(hidden_features, out_features, key=keys[1])
         self.drop2 = nn.Dropout(drop_probs[1])
 
-    def _forward(self, x, residual=None, norm=None):
-        """`norm` given: x is the un-normalised input; the LayerNorm is folded into fc1 where the library can."""
+    def _live(self) -> bool:
+        return nn.dropout_live(self.drop1) or nn.dropout_live(self.drop2)
+
+    def _forward(self, x, residual=None, norm=None, keys=None, per_row=False):
+        """`norm` given: x is the un-normalised input; the LayerNorm is folded into fc1 where the library can.
+        `keys` (training mode with a live Dropout): one PRNG key per sample, or per ROW of a (tokens, features) input when
+        `per_row` -- the reference's ViT vmaps the layer over the tokens (vit.py:155); each is split in two for drop1 / drop2
+        (mlps.py:60-65)."""
         if x.kind in ("img", "map"):
             x = ops.as_map(x)
         name = nn.act_name(self.act)
@@ -44,10 +51,21 @@ class MlpProjection(Module):
         else:
             h = ops.linear(x, self.fc1) if norm is None else ops.ln_linear(x, norm, self.fc1)
             h = self.act(h) if self.act is not None else h
-        nn.refuse_live_dropout(self.drop1, "MlpProjection.drop1")          # identity in inference / p = 0 (mlps.py:63, :65)
-        nn.refuse_live_dropout(self.drop2, "MlpProjection.drop2")
-        return ops.linear(h, self.fc2, residual=residual)
+        if not self._live():                                           # identity in inference / p = 0 (mlps.py:63, :65)
+            return ops.linear(h, self.fc2, residual=residual)
+        if keys is None:
+            raise RuntimeError("Dropout requires a key when running in non-deterministic mode.")
+        if h.kind not in ("seq", "vec"):
+            raise NotImplementedError(f"MlpProjection: training-mode Dropout on a {h.kind} input is not built")
+        ks = ops.split_keys(keys, 2)
+        per_row = per_row and h.kind == "seq"
+        if nn.dropout_live(self.drop1):
+            h = ops.dropout(h, self.drop1.p, ks[0], per_row=per_row)
+        y = ops.linear(h, self.fc2)
+        if nn.dropout_live(self.drop2):
+            y = ops.dropout(y, self.drop2.p, ks[1], per_row=per_row)
+        return y if residual is None else ops.add(residual, y)
 
     @boundary
     def __call__(self, x, *, key=None):
-        return self._forward(x)
+        return self._forward(x, keys=key)

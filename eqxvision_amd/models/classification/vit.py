@@ -39,14 +39,29 @@ class _VitAttention(Module):
         self.proj = nn.Linear(dim, dim, key=keys[1])
         self.proj_drop = nn.Dropout(proj_drop)
 
-    def _forward(self, x: Act, residual: Optional[Act] = None, need_probs: bool = True):
+    def _live(self) -> bool:
+        return nn.dropout_live(self.attn_drop) or nn.dropout_live(self.proj_drop)
+
+    def _forward(self, x: Act, residual: Optional[Act] = None, need_probs: bool = True, key=None):
         x = ops.as_rows(x)          # GEMM operand: compute dtype
         if x.kind != "seq":
             raise ValueError(f"_VitAttention expects (tokens, dim), got {x.shape}")
-        y, probs = ops.qkv_attention(x, self.qkv, self.num_heads, self.scale, need_probs)   # reference :64-73
-        nn.refuse_live_dropout(self.attn_drop, "_VitAttention.attn_drop")   # reference :71: identity in inference / p = 0
-        nn.refuse_live_dropout(self.proj_drop, "_VitAttention.proj_drop")
-        y = ops.linear(y, self.proj, residual=residual)                # reference :74 (+ the block's residual)
+        drop, pkey = None, None
+        if self._live():            # training mode: keys = split(key, 2) (reference :63); [0] -> attn_drop (:71), [1] -> proj_drop (:75)
+            if key is None:
+                raise RuntimeError("Dropout requires a key when running in non-deterministic mode.")
+            ks = jr.split(ops._batched_keys(key, x.t.shape[0]), 2)
+            if nn.dropout_live(self.attn_drop):
+                drop = (self.attn_drop.p, ks[0])
+            if nn.dropout_live(self.proj_drop):
+                pkey = ks[1]
+        y, probs = ops.qkv_attention(x, self.qkv, self.num_heads, self.scale, need_probs, drop=drop)   # reference :64-73
+        if pkey is None:
+            y = ops.linear(y, self.proj, residual=residual)            # reference :74 (+ the block's residual)
+        else:
+            y = self.proj_drop(ops.linear(y, self.proj), key=pkey)     # reference :74-75
+            if residual is not None:
+                y = ops.add(residual, y)
         attn = None
         if probs is not None:                                          # reference returns (1, heads, N, N) per sample
             B, H, N, _ = probs.shape
@@ -55,7 +70,7 @@ class _VitAttention(Module):
 
     @boundary
     def __call__(self, x, *, key=None):
-        return self._forward(x)
+        return self._forward(x, key=key)
 
 
 class _VitBlock(Module):
@@ -76,24 +91,31 @@ class _VitBlock(Module):
         self.mlp = MlpProjection(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer,
                                  drop=drop, key=keys[1])
 
-    def _residual_ok(self) -> bool:
+    def _deterministic(self) -> bool:
         dp = self.drop_path
-        return isinstance(dp, nn.Identity) or dp.inference or dp.p == 0.0
+        return ((isinstance(dp, nn.Identity) or dp.inference or dp.p == 0.0)
+                and not self.attn._live() and not self.mlp._live())
 
     @boundary
     def __call__(self, x, return_attention=False, *, key=None):        # reference :139-157
         x = ops.as_rows(x, keep_fp32=True)      # the residual stream may be fp32 (see _act.residual_fp32)
         y = self.norm1(x)
-        if return_attention:
-            _, attn = self.attn._forward(y, need_probs=True)
-            return attn
-        if self._residual_ok():            # x + Identity(y): fold the add into the GEMM epilogues
+        if self._deterministic():          # x + Identity(y): fold the adds into the GEMM epilogues
+            if return_attention:
+                _, attn = self.attn._forward(y, need_probs=True)
+                return attn
             x, _ = self.attn._forward(y, residual=x, need_probs=False)
             return self.mlp._forward(self.norm2(x), residual=x)
-        keys = [None] * 4 if key is None else jr.split(key, 4)          # reference :148 (the dropouts inside are p = 0 or raise)
-        y, _ = self.attn._forward(y, need_probs=False)
+        # training mode with a live Dropout / DropPath: keys = split(key, 4) (reference :148) -> attention, drop_path, the
+        # tokens' MLP keys (split again per token, :155), drop_path
+        B, N = x.t.shape[0], x.t.shape[1]
+        keys = [None] * 4 if key is None else jr.split(ops._batched_keys(key, B), 4)
+        y, attn = self.attn._forward(y, need_probs=bool(return_attention), key=keys[0])
+        if return_attention:
+            return attn
         x = ops.add(x, self.drop_path(y, key=keys[1]))
-        y = self.mlp._forward(self.norm2(x))
+        mkeys = ops.token_keys(keys[2], B, N) if self.mlp._live() and keys[2] is not None else None
+        y = self.mlp._forward(self.norm2(x), keys=mkeys, per_row=True)
         return ops.add(x, self.drop_path(y, key=keys[3]))
 
 

@@ -134,14 +134,9 @@ class Dropout(Module):
         return _unwrap(ops.dropout(wrap(x, False), self.p, key), False)
 
 
-def refuse_live_dropout(d, where: str) -> None:
-    """Call sites whose Dropout the training-mode forward does not implement (attention probabilities inside the fused attention
-    kernels, the transformer MLPs' per-token dropouts, Swin's dropout in window layout): loud, instead of silently not dropping.
-    The reference's defaults for all of them are p = 0."""
-    if isinstance(d, Dropout) and not d.inference and d.p > 0:
-        raise NotImplementedError(
-            f"{where}: Dropout(p={d.p}) outside inference mode is not built (training-mode forward: BatchNorm batch statistics, "
-            "classifier Dropout, DropPath); use p = 0 or eqxvision_amd.tree_inference(model, True)")
+def dropout_live(d) -> bool:
+    """A Dropout that drops on this call: training mode and 0 < p."""
+    return isinstance(d, Dropout) and not d.inference and d.p > 0
 
 
 class Conv2d(Module):

@@ -25,7 +25,15 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _dev(a: np.ndarray, dtype: torch.dtype) -> torch.Tensor:
-    t = torch.from_numpy(np.ascontiguousarray(a))
+    a = np.ascontiguousarray(a)
+    if dtype == torch.bfloat16 and a.dtype == np.float32 and a.size < (1 << 20):
+        # small per-call constants (DropPath noise, folded scales): round to bf16 with integer numpy -- a torch CPU cast wakes the
+        # whole intra-op thread pool, 16 ms per call on a 100+-core host against microseconds here
+        u = a.view(np.uint32)
+        r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+        b = np.where(np.isnan(a), np.uint32(0x7FC0), (u + r) >> np.uint32(16)).astype(np.uint16)
+        return torch.from_numpy(b.view(np.int16)).to(device()).view(torch.bfloat16)
+    t = torch.from_numpy(a)
     if t.dtype != dtype:
         t = t.to(dtype)            # host-side RNE conversion of constants (weights)
     return t.to(device())
@@ -829,7 +837,21 @@ def adaptive_avgpool2d(x: Act, target, out_fp32: bool = False) -> Act:
 
 
 # ------------------------------------------------------------------ attention
-def mha(qkv: Act, heads: int, scale: float, need_probs: bool):
+def _mha_call(qkv_t, head_major: bool, out, probs, B, N, heads, dh, scale, dt, drop):
+    """The attention core; `drop` = (p, keys) runs the reference's live attention dropout inside the kernel (vit.py:71)."""
+    if drop is None:
+        _lib.call("mv_mha_heads_fwd" if head_major else "mv_mha_fwd", _ptr(qkv_t), _ptr(out), _ptr(probs), B, N, heads, dh,
+                  float(scale), dt, stream_ptr())
+        return
+    p, key = drop
+    if not 0.0 < float(p) < 1.0:
+        raise NotImplementedError(f"attention Dropout(p={p})")
+    keys = _keys_dev(key, B)
+    _lib.call("mv_mha_dropout_fwd", _ptr(qkv_t), 1 if head_major else 0, _ptr(out), _ptr(probs), _ptr(keys), float(1.0 - p),
+              B, N, heads, dh, float(scale), dt, stream_ptr())
+
+
+def mha(qkv: Act, heads: int, scale: float, need_probs: bool, drop=None):
     """qkv rows [B,N,3D] -> ([B,N,D], probs fp32 [B,heads,N,N] or None)   (vit.py:65-73)."""
     qkv = cast(qkv, compute_dtype())
     B, N, D3 = qkv.t.shape
@@ -837,15 +859,16 @@ def mha(qkv: Act, heads: int, scale: float, need_probs: bool):
     dh = D // heads
     out = empty((B, N, D), qkv.t.dtype)
     probs = empty((B, heads, N, N), torch.float32) if need_probs else None
-    _lib.call("mv_mha_fwd", _ptr(qkv.t), _ptr(out), _ptr(probs), B, N, heads, dh, float(scale), qkv.dt, stream_ptr())
+    _mha_call(qkv.t, False, out, probs, B, N, heads, dh, scale, qkv.dt, drop)
     return Act(out, "seq", qkv.batched), probs
 
 
-def qkv_attention(x: Act, lin, heads: int, scale: float, need_probs: bool):
+def qkv_attention(x: Act, lin, heads: int, scale: float, need_probs: bool, drop=None):
     """qkv Linear + attention core of `_VitAttention` (vit.py:64-73): rows [B,N,D] -> ([B,N,D], probs or None).
     When the library has the path for this shape the projection writes q/k/v head-major
     ([B, 3*heads, N, dh]: what the reference's reshape + transpose produce) and the attention kernel reads
-    contiguous heads; otherwise Linear -> [B,N,3D] -> strided attention.  Both are the HIP path."""
+    contiguous heads; otherwise Linear -> [B,N,3D] -> strided attention.  Both are the HIP path.
+    `drop` = (p, per-sample keys): training-mode attention dropout, applied to the probabilities inside the kernel."""
     dt = compute_dtype()
     x = as_rows(x)
     if x.t.dtype != TORCH_DT[dt]:
@@ -855,14 +878,14 @@ def qkv_attention(x: Act, lin, heads: int, scale: float, need_probs: bool):
         raise ValueError(f"qkv projection {lin.in_features}->{lin.out_features} does not fit rows of {D} / {heads} heads")
     dh = D // heads
     if not _lib.load().mv_linear_heads_supported(B * N, 3 * D, D, N, dh, DT[dt]):
-        return mha(linear(x, lin), heads, scale, need_probs)
+        return mha(linear(x, lin), heads, scale, need_probs, drop)
     w, b = prep_linear(lin, dt)
     qkv = empty((B, 3 * heads, N, dh), TORCH_DT[dt])
     _lib.call("mv_linear_heads_fwd", _ptr(x.t), _ptr(w), None, _ptr(b), _ptr(qkv), B * N, 3 * D, D, N, dh, DT[dt],
               stream_ptr())
     out = empty((B, N, D), TORCH_DT[dt])
     probs = empty((B, heads, N, N), torch.float32) if need_probs else None
-    _lib.call("mv_mha_heads_fwd", _ptr(qkv), _ptr(out), _ptr(probs), B, N, heads, dh, float(scale), DT[dt], stream_ptr())
+    _mha_call(qkv, True, out, probs, B, N, heads, dh, scale, DT[dt], drop)
     return Act(out, "seq", x.batched), probs
 
 
@@ -964,15 +987,49 @@ def _batched_keys(key, B: int) -> np.ndarray:
     return np.ascontiguousarray(k)
 
 
-def dropout(x: Act, p: float, key) -> Act:
+def _keys_dev(key, B: int) -> torch.Tensor:
+    """int32 [B, 2] on the device: host keys (numpy, one per sample) are uploaded, keys derived on the device pass through."""
+    if isinstance(key, torch.Tensor):
+        if tuple(key.shape) != (B, 2) or key.dtype != torch.int32 or not key.is_contiguous():
+            raise ValueError(f"expected device keys int32 [{B}, 2], got {key.dtype} {tuple(key.shape)}")
+        return key
+    return torch.from_numpy(_batched_keys(key, B).view(np.int32)).to(device())
+
+
+def split_keys(keys, num: int):
+    """jax.random.split of batched keys [R, 2] -> [num, R, 2] (child i of every key): numpy in, numpy out (random.split); a
+    device tensor in, a device tensor out (mv_prng_split) -- what the per-token keys of a transformer MLP go through."""
+    if not isinstance(keys, torch.Tensor):
+        from . import random as jr
+        return jr.split(np.asarray(keys, np.uint32), num)
+    R = keys.shape[0]
+    out = empty((num, R, 2), torch.int32)
+    _lib.call("mv_prng_split", _ptr(_keys_dev(keys, R)), _ptr(out), R, int(num), 1, stream_ptr())
+    return out
+
+
+def token_keys(key, B: int, N: int) -> torch.Tensor:
+    """int32 [B*N, 2] on the device: jax.random.split(key, N) of every sample's key, rows in (sample, token) order -- the keys
+    `jax.vmap(self.mlp)(y, key=jrandom.split(keys[2], x.shape[0]))` hands the tokens (vit.py:155)."""
+    out = empty((B * N, 2), torch.int32)
+    _lib.call("mv_prng_split", _ptr(_keys_dev(key, B)), _ptr(out), B, int(N), 0, stream_ptr())
+    return out
+
+
+def dropout(x: Act, p: float, key, per_row: bool = False) -> Act:
     """eqx.nn.Dropout's training branch: where(bernoulli(key, 1 - p, x.shape), x / (1 - p), 0) per sample, the mask from the
-    sample's key in JAX's bit stream (generated on the device, rng.hip)."""
+    sample's key in JAX's bit stream (generated on the device, rng.hip).  `per_row`: x is (tokens, features) rows and `key`
+    holds one key per ROW (uint32 [B*N, 2], `token_keys`): the reference vmaps the layer over the tokens."""
     if x.kind == "img":
         x = as_map(x)
     B = x.t.shape[0]
-    keys = torch.from_numpy(_batched_keys(key, B).view(np.int32)).to(device())
-    per = x.t.numel() // B
     C = x.t.shape[-1]
+    if per_row:
+        if x.kind != "seq":
+            raise ValueError(f"per-row dropout expects (tokens, features) rows, got {x.kind} {tuple(x.t.shape)}")
+        B = x.t.numel() // C
+    keys = _keys_dev(key, B)
+    per = x.t.numel() // B
     y = empty(tuple(x.t.shape), x.t.dtype)
     _lib.call("mv_dropout_fwd", _ptr(x.t), _ptr(keys), _ptr(y), B, per, C, 1 if x.kind == "map" else 0, float(1.0 - p), x.dt,
               stream_ptr())

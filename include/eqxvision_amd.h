@@ -251,6 +251,16 @@ int mv_linear_heads_fwd(const void* x, const void* w, const float* scale, const 
 int mv_mha_heads_fwd(const void* qkv_head_major, void* out, float* probs, int B, int N, int H, int dh,
                      float scale, int dtype, mv_stream_t stream);
 
+/* The same attention core with the reference's LIVE attention dropout (vit.py:71, training mode: attn =
+ * attn_drop(softmax(...), key)): every probability is kept (and divided by keep_prob) or zeroed by word
+ * ((h * N + i) * N + j) of the sample's Threefry-2x32 stream -- jax.random.bernoulli(key, keep_prob,
+ * (1, H, N, N)) bit for bit -- before it multiplies V; probs (optional) receives the dropped matrix, which
+ * is what the reference returns.  keys: B x 2 uint32 (one key per sample); qkv token-major (head_major = 0,
+ * as mv_mha_fwd) or head-major (1, as mv_mha_heads_fwd).  bf16, dh 32 / 64, N <= 256, else MV_E_UNSUPPORTED. */
+int mv_mha_dropout_fwd(const void* qkv, int head_major, void* out, float* probs, const uint32_t* keys,
+                       float keep_prob, int B, int N, int H, int dh, float scale, int dtype,
+                       mv_stream_t stream);
+
 /* _shifted_window_attention core (swin.py:123-250) on the qkv Linear2d output:
  * qkv NHWC [B,Hf,Wf,3*C] -> out NHWC [B,Hf,Wf,C]; cyclic shift, window partition/reverse and
  * the shift mask are folded into addressing; bias fp32 [heads][ws*ws][ws*ws] (table[index]). */
@@ -295,6 +305,12 @@ int mv_graph_destroy(void* graph_exec);
  * (C,H,W) when chw_logical != 0 (x is NHWC [B][per_sample / C][C] here), else the physical order ((N,D) rows, (D,) vectors). */
 int mv_dropout_fwd(const void* x, const void* keys, void* y, int B, int64_t per_sample, int C, int chw_logical, float keep_prob,
                    int dtype, mv_stream_t stream);
+
+/* jax.random.split(key, num) for R keys at once, on the device (the reference derives one key per TOKEN for the vmapped
+ * transformer MLP, vit.py:155: R = batch * tokens keys per block is host work worth a launch): keys [R][2] uint32 ->
+ * out [R][num][2] (child_major = 0: the children of a key together, e.g. the per-token keys of every sample) or [num][R][2]
+ * (child_major = 1: what a vmapped split returns, child i of every key contiguous). */
+int mv_prng_split(const void* keys, void* out, int64_t R, int num, int child_major, mv_stream_t stream);
 
 /* Per-channel batch moments of rows x[rows][C] (an NHWC map or a row matrix): the statistics of eqx.experimental.BatchNorm's
  * TRAINING branch (reference resnet.py:132-136 / :252 / :301 with the model not in inference mode):

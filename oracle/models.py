@@ -378,12 +378,16 @@ def segmentation_forward(sd, x, kind="fcn", layers=(3, 4, 6, 3), aux=True, bf16=
 
 
 # ---------------------------------------------------------------- vit.py:139-157, 261-273
-def vit_block(sd, q, x, p, num_heads, return_attention=False, drop_path=0.0, key=None):
-    """`key` given with drop_path > 0 (training mode): x + DropPath(y, key=keys[1]) / keys[3], keys = split(key, 4) (vit.py:148-156);
-    DropPath mode "global": one draw for the whole sample."""
+def vit_block(sd, q, x, p, num_heads, return_attention=False, drop_path=0.0, key=None, drop=0.0, attn_drop=0.0):
+    """`key` given (training mode): keys = split(key, 4) (vit.py:148): [0] -> the attention, which splits it again (vit.py:63) for
+    attn_drop on the (1, heads, N, N) probabilities (vit.py:71) and proj_drop = `drop` on its output (vit.py:75); [1] / [3] ->
+    x + DropPath(y) (vit.py:153, 156; mode "global": one draw for the whole sample); [2] -> split(., N): one key per TOKEN of the
+    vmapped MLP (vit.py:155), each split in two for its Dropouts after the activation and after fc2 (mlps.py:60-65)."""
     y = q(O.layernorm_rows(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"]))       # vit.py:149
     N, C = y.shape
     dh = C // num_heads
+    ks = None if key is None else O.jax_split(key, 4)
+    aks = None if ks is None else O.jax_split(ks[0], 2)
     qkv = y @ q(sd[p + ".attn.qkv.weight"]).T
     if (p + ".attn.qkv.bias") in sd:
         qkv = qkv + sd[p + ".attn.qkv.bias"]
@@ -391,18 +395,27 @@ def vit_block(sd, q, x, p, num_heads, return_attention=False, drop_path=0.0, key
     qq, kk, vv = qkv[0], qkv[1], qkv[2]
     attn = (qq @ np.transpose(kk, (0, 2, 1))) * F32(dh ** -0.5)                      # vit.py:69
     attn = O.softmax(attn, -1)                                                       # vit.py:70
+    if aks is not None and attn_drop > 0.0:
+        attn = O.dropout(attn[None], attn_drop, aks[0])[0]                           # vit.py:71
     if return_attention:
         return attn[None]                                                            # (1, heads, N, N)
     a = q(np.transpose(q(attn) @ vv if q.on else attn @ vv, (1, 0, 2)).reshape(N, C))  # vit.py:73
     y = a @ q(sd[p + ".attn.proj.weight"]).T + sd[p + ".attn.proj.bias"]             # vit.py:74
-    ks = None if key is None or drop_path == 0.0 else O.jax_split(key, 4)
-    if ks is not None:
+    if aks is not None and drop > 0.0:
+        y = O.dropout(q(y), drop, aks[1])                                            # vit.py:75
+    if ks is not None and drop_path > 0.0:
         y = O.drop_path(q(y), drop_path, "global", ks[1])
     x = q(x + y)                                                                     # vit.py:153
     y = q(O.layernorm_rows(x, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"]))       # vit.py:154
     h = q(O.gelu_tanh(y @ q(sd[p + ".mlp.fc1.weight"]).T + sd[p + ".mlp.fc1.bias"]))  # mlps.py:61-62
+    mks = None
+    if ks is not None and drop > 0.0:
+        mks = [O.jax_split(tk, 2) for tk in O.jax_split(ks[2], N)]                   # vit.py:155, mlps.py:60
+        h = q(np.stack([O.dropout(h[t], drop, mks[t][0]) for t in range(N)]))        # mlps.py:63
     y = h @ q(sd[p + ".mlp.fc2.weight"]).T + sd[p + ".mlp.fc2.bias"]                 # mlps.py:64
-    if ks is not None:
+    if mks is not None:
+        y = np.stack([O.dropout(q(y[t]), drop, mks[t][1]) for t in range(N)])        # mlps.py:65
+    if ks is not None and drop_path > 0.0:
         y = O.drop_path(q(y), drop_path, "global", ks[3])
     return q(x + y)                                                                  # vit.py:156
 
@@ -416,15 +429,18 @@ def vit_tokens(sd, q, x, patch):
     return q(np.concatenate([cls, t], 0) + pos)                                      # vit.py:269
 
 
-def vit_forward(sd, x, patch=16, num_heads=12, depth=12, bf16=False, key=None, drop_path_rate=0.0):
-    """`key` given: TRAINING mode with stochastic depth: block i drops with linspace(0, drop_path_rate, depth)[i] (vit.py:236-246)
-    from split(key, depth)[i] (vit.py:267-271)."""
+def vit_forward(sd, x, patch=16, num_heads=12, depth=12, bf16=False, key=None, drop_path_rate=0.0, drop_rate=0.0,
+                attn_drop_rate=0.0):
+    """`key` given: TRAINING mode: block i drops its paths with linspace(0, drop_path_rate, depth)[i] (vit.py:236-246) and runs
+    its Dropouts (drop_rate: projection + MLP, attn_drop_rate: attention probabilities) from split(key, depth)[i] (vit.py:267-271).
+    (`pos_drop` is constructed but never applied by the reference's __call__.)"""
     q = _Q(bf16)
     x = vit_tokens(sd, q, x, patch)
     bkeys = None if key is None else O.jax_split(key, depth)
     dpr = np.linspace(0, drop_path_rate, depth)
     for i in range(depth):
-        x = vit_block(sd, q, x, f"blocks.{i}", num_heads, drop_path=float(dpr[i]), key=None if bkeys is None else bkeys[i])
+        x = vit_block(sd, q, x, f"blocks.{i}", num_heads, drop_path=float(dpr[i]), key=None if bkeys is None else bkeys[i],
+                      drop=drop_rate, attn_drop=attn_drop_rate)
     x = q(O.layernorm_rows(x, sd["norm.weight"], sd["norm.bias"]))                   # vit.py:272
     if "fc.weight" in sd:
         return O.linear(x[0], q(sd["fc.weight"]), sd["fc.bias"])                     # vit.py:273

@@ -922,6 +922,69 @@ def layernorm_case(M, C, dtype="bf16", generic=False, stride=None, seed=0, out=N
     return run
 
 
+def prng_split_case(R, num, child_major, seed=0):
+    """mv_prng_split vs the oracle's jax.random.split of every key: bit-exact."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        keys = rng.integers(0, 2 ** 32, size=(R, 2), dtype=np.uint64).astype(np.uint32)
+        ref = np.stack([O.jax_split(keys[r], num) for r in range(R)])              # [R, num, 2]
+        if child_major:
+            ref = ref.transpose(1, 0, 2)
+        kd = torch.from_numpy(keys.view(np.int32)).cuda()
+        out = torch.zeros(ref.shape, dtype=torch.int32, device="cuda")
+        L.call("mv_prng_split", kd.data_ptr(), out.data_ptr(), R, num, child_major, _stream())
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(np.uint32)
+        bad = int((got != ref).sum())
+        return {"ok": bad == 0, "mismatches": bad, "kernel": L.last_kernel()}
+    return run
+
+
+def mha_dropout_case(B, N, H, dh, p=0.2, head_major=False, probs=True, seed=0):
+    """mv_mha_dropout_fwd: the attention core with vit.py:71's live dropout.  The returned (dropped) probabilities must be ZERO
+    exactly where jax.random.bernoulli(key_b, 1 - p, (1, H, N, N)) is False (oracle bit stream) and the kernel's own un-dropped
+    probabilities / (1 - p) elsewhere; the output must be that matrix times V."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        D = H * dh
+        keep = np.float32(1.0 - p)
+        qkv = bf(rng.standard_normal((B, N, 3 * D)).astype(np.float32))
+        keys = rng.integers(0, 2 ** 32, size=(B, 2), dtype=np.uint64).astype(np.uint32)
+        scale = dh ** -0.5
+        t = qkv.reshape(B, N, 3, H, dh).transpose(2, 0, 3, 1, 4).astype(np.float64)       # [3, B, H, N, dh]
+        q, k, v = t[0], t[1], t[2]
+        a = O.softmax((q @ k.transpose(0, 1, 3, 2)) * scale, -1).astype(np.float64)
+        mask = np.stack([O.jax_bernoulli(keys[b], keep, (1, H, N, N))[0] for b in range(B)])
+        ad = np.where(mask, a / np.float64(keep), 0.0)
+        ref = (ad @ v).transpose(0, 2, 1, 3).reshape(B, N, D)
+        src = np.ascontiguousarray(qkv.reshape(B, N, 3 * H, dh).transpose(0, 2, 1, 3)) if head_major else qkv
+        qd = dev(src, "bf16")
+        kd = torch.from_numpy(keys.view(np.int32)).cuda()
+        y = torch.empty((B, N, D), dtype=qd.dtype, device="cuda")
+        pr = torch.zeros((B, H, N, N), dtype=torch.float32, device="cuda") if probs else None
+        p0 = torch.empty((B, H, N, N), dtype=torch.float32, device="cuda")
+        y0 = torch.empty_like(y)
+        L.call("mv_mha_heads_fwd" if head_major else "mv_mha_fwd", qd.data_ptr(), y0.data_ptr(), p0.data_ptr(), B, N, H, dh,
+               float(scale), DT["bf16"], _stream())
+        L.call("mv_mha_dropout_fwd", qd.data_ptr(), 1 if head_major else 0, y.data_ptr(), None if pr is None else pr.data_ptr(),
+               kd.data_ptr(), float(keep), B, N, H, dh, float(scale), DT["bf16"], _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, TOL_BF16)
+        info["kernel"] = kern
+        if probs:
+            got, base = host(pr), host(p0)
+            info["mask_mismatches"] = int(((got != 0) != (mask & (base != 0))).sum())
+            pi = _cmp(got, np.where(mask, base / keep, np.float32(0)), 1e-5)
+            info["probs_err"] = pi.get("err")
+            info["kept_fraction"] = float(mask.mean())
+            info["ok"] = info["ok"] and pi["ok"] and info["mask_mismatches"] == 0 and abs(info["kept_fraction"] - float(keep)) < 0.02
+        return info
+    return run
+
+
 def mha_case(B, N, H, dh, dtype="bf16", probs=True, generic=False, seed=0, spike=False):
     def run():
         L = _lib()
@@ -1599,7 +1662,16 @@ def all_cases():
           ("mha/qkv_heads_50tok", qkv_heads_case(100, 50, 4, 64, seed=2)),
           ("mha/many_pairs_persistent", mha_case(70, 197, 12, 64, probs=False, seed=3)),
           ("mha/many_pairs_225", mha_case(40, 225, 8, 32, probs=True, seed=4)),
-          ("mha/one_pair", mha_case(1, 33, 1, 64, seed=5))]
+          ("mha/one_pair", mha_case(1, 33, 1, 64, seed=5)),
+          ("mha/dropout_vit_197_64", mha_dropout_case(2, 197, 12, 64)),
+          ("mha/dropout_heads_197_64", mha_dropout_case(3, 197, 4, 64, p=0.5, head_major=True, seed=1)),
+          ("mha/dropout_17_32", mha_dropout_case(4, 17, 2, 32, p=0.1, seed=2)),
+          ("mha/dropout_256_32_noprobs", mha_dropout_case(1, 256, 2, 32, probs=False, seed=3)),
+          ("mha/dropout_odd_count", mha_dropout_case(1, 33, 1, 64, p=0.3, seed=4)),
+          ("prng/split_tokens", prng_split_case(37, 197, 0)),
+          ("prng/split_pairs_child_major", prng_split_case(5000, 2, 1, seed=1)),
+          ("prng/split_one", prng_split_case(3, 1, 0, seed=2)),
+          ("prng/split_five_child_major", prng_split_case(64, 5, 1, seed=3))]
     c += [("swin/shift3", swin_attn_case(2, 14, 96, 3, 7, 3)),
           ("swin/noshift", swin_attn_case(2, 14, 96, 3, 7, 0)),
           ("swin/window_ge_map", swin_attn_case(1, 7, 192, 6, 7, 3)),

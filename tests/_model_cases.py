@@ -529,6 +529,36 @@ def vit_train_case(img=32, patch=8, dim=64, depth=4, heads=2, B=4, classes=10, r
     return run
 
 
+def vit_dropout_case(img=32, patch=8, dim=64, depth=3, heads=2, B=4, classes=10, drop=0.1, attn_drop=0.2, path=0.2):
+    """ViT outside inference mode with drop_rate / attn_drop_rate / drop_path_rate > 0: the attention probabilities' dropout inside
+    the attention kernel, the projection's per-sample dropout and the MLP's per-TOKEN dropouts (the reference vmaps the MLP over the
+    tokens with split keys, vit.py:155) -- the oracle draws the same masks from the same keys."""
+    def run():
+        import eqxvision_amd as eqv
+        sd = S.vit_state(1, img, patch, dim, depth, heads, 4, classes)
+        x = S.synthetic_images(B, img, seed=0)
+        fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(eqv.models.VisionTransformer(**kw), torch_weights)
+        net = eqv.tree_inference(_load(fac, sd, img_size=img, patch_size=patch, embed_dim=dim, depth=depth, num_heads=heads,
+                                       num_classes=classes, drop_rate=drop, attn_drop_rate=attn_drop, drop_path_rate=path), False)
+        keys = eqv.random.split(eqv.random.PRNGKey(43), B)
+        with eqv.precision("bf16"):
+            got = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k))(net, x, keys).cpu().numpy()
+            try:
+                eqv.vmap(net, axis_name="batch")(x)
+                keyless = "no error"
+            except RuntimeError as e:
+                keyless = "RuntimeError" if "requires a key" in str(e) else repr(e)
+        ref = np.stack([OM.vit_forward(sd, x[i], patch, heads, depth, bf16=True, key=keys[i], drop_path_rate=path, drop_rate=drop,
+                                       attn_drop_rate=attn_drop) for i in range(B)])
+        inf = np.stack([OM.vit_forward(sd, x[i], patch, heads, depth, bf16=True) for i in range(B)])
+        out = _cmp(got, ref, 1e-2)
+        out["differs_from_inference"] = float(np.abs(got - inf).max())
+        out["keyless_call"] = keyless
+        out["ok"] = out["ok"] and out["differs_from_inference"] > 5 * max(out["err"], 1e-3) and keyless == "RuntimeError"
+        return out
+    return run
+
+
 def cna_family_train_case():
     """Training-mode BatchNorm inside the ConvNormActivation families (depthwise / odd-width / squeeze-excitation stacks: the
     Sequential peephole may not fold a BatchNorm that is not in inference mode): a reduced MobileNetV2 takes two training steps;
@@ -868,6 +898,9 @@ def all_cases(full=True):
          ("model/alexnet_train_mode_dropout", alexnet_train_case()),
          ("model/swin_train_mode_stochastic_depth", swin_train_case()),
          ("model/vit_train_mode_stochastic_depth", vit_train_case()),
+         ("model/vit_train_mode_dropouts", vit_dropout_case()),
+         ("model/vit_train_mode_attn_dropout_only", vit_dropout_case(drop=0.0, attn_drop=0.3, path=0.0, depth=2)),
+         ("model/vit_train_mode_mlp_dropout_only", vit_dropout_case(drop=0.25, attn_drop=0.0, path=0.0, depth=2)),
          ("model/mobilenet_v2_train_mode_bn_refold", cna_family_train_case()),
          ("model/batchnorm_fresh_first_three_train_steps", bn_first_steps_case()),
          ("model/resnet18_train_mode_bn", resnet_train_case()),
