@@ -181,7 +181,7 @@ int skinny_f32_launch(const void* x, const void* w, const float* scale, const fl
                       int act, hipStream_t stream);
 int swin_mfma_supported(int C, int heads, int ws_h, int ws_w, int dtype);
 int swin_mfma_launch(const void* qkv, const float* bias, void* out, int B, int Hf, int Wf, int C, int heads, int ws_h,
-                     int ws_w, int shift_h, int shift_w, hipStream_t stream);
+                     int ws_w, int shift_h, int shift_w, const uint32_t* drop_keys, float keep, hipStream_t st);
 int conv3x3c64_v2_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H,
                          int W, int act, hipStream_t stream);
 int skinny_supported(long long M, int C, int K, int in_dtype, const void* residual);

@@ -1283,7 +1283,7 @@ int mv_swin_window_attn_fwd(const void* qkv, const float* bias, void* out, int B
     if (ws_w >= Wf) shift_w = 0;
     hipStream_t st = (hipStream_t)stream;
     if (!get_flag("force_generic") && swin_mfma_supported(C, heads, ws_h, ws_w, dtype))
-        return swin_mfma_launch(qkv, bias, out, B, Hf, Wf, C, heads, ws_h, ws_w, shift_h, shift_w, st);
+        return swin_mfma_launch(qkv, bias, out, B, Hf, Wf, C, heads, ws_h, ws_w, shift_h, shift_w, nullptr, 1.f, st);
     const int n = ws_h * ws_w, dh = C / heads;
     const int tokens = Hf * Wf;
     MV_CHECK_ARG(heads <= 65535 && B <= 65535, "swin_attn: grid too large");
@@ -1297,6 +1297,27 @@ int mv_swin_window_attn_fwd(const void* qkv, const float* bias, void* out, int B
                            (const float*)qkv, bias, (float*)out, B, Hf, Wf, C, heads, ws_h, ws_w, shift_h, shift_w);
     MV_LAUNCH_CHECK();
     return MV_OK;
+}
+
+int mv_swin_window_attn_dropout_fwd(const void* qkv, const float* bias, void* out, const void* keys, float keep_prob, int B,
+                                    int Hf, int Wf, int C, int heads, int ws_h, int ws_w, int shift_h, int shift_w, int dtype,
+                                    mv_stream_t stream) {
+    MV_CHECK_ARG(qkv && bias && out && keys && B > 0 && Hf > 0 && Wf > 0 && C > 0 && heads > 0, "swin_attn_dropout: bad args");
+    MV_CHECK_ARG(C % heads == 0, "swin_attn_dropout: C %% heads != 0");
+    MV_CHECK_ARG(ws_h > 0 && ws_w > 0 && Hf % ws_h == 0 && Wf % ws_w == 0,
+                 "swin_attn_dropout: feature map %dx%d is not a multiple of the window %dx%d (reference swin.py:782-790)", Hf, Wf,
+                 ws_h, ws_w);
+    MV_CHECK_ARG(shift_h >= 0 && shift_w >= 0 && shift_h < ws_h && shift_w < ws_w, "swin_attn_dropout: bad shift");
+    MV_CHECK_ARG(keep_prob > 0.f && keep_prob <= 1.f, "swin_attn_dropout: keep_prob %g outside (0, 1]", (double)keep_prob);
+    if (ws_h >= Hf) shift_h = 0;  // swin.py:116-120
+    if (ws_w >= Wf) shift_w = 0;
+    if (!swin_mfma_supported(C, heads, ws_h, ws_w, dtype)) {
+        set_error("swin_attn_dropout: unsupported C=%d heads=%d window %dx%d dtype=%d (bf16, 32 channels per head, <= 64 tokens)", C,
+                  heads, ws_h, ws_w, dtype);
+        return MV_E_UNSUPPORTED;
+    }
+    return swin_mfma_launch(qkv, bias, out, B, Hf, Wf, C, heads, ws_h, ws_w, shift_h, shift_w, (const uint32_t*)keys, keep_prob,
+                            (hipStream_t)stream);
 }
 
 int mv_patch_merge_gather_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, mv_stream_t stream) {

@@ -131,6 +131,44 @@ __global__ void dropout_pair_kernel(const T* x, const uint32_t* keys, T* y, long
 
 using namespace mv;
 
+// Dropout of an NHWC map whose LOGICAL layout is the reference's window partition of the cyclically shifted map
+// ((num_windows, tokens, C), swin.py:150-160): `_func_dropout(x, dropout, key)` after the attention's projection (swin.py:233),
+// before the windows are put back.  Physical pixel (oy, ox) sits at rolled position p = (o - shift) mod size, i.e. in window
+// (py / wsh, px / wsw) as token (py % wsh) * wsw + px % wsw.  8 channels per thread.
+template <typename T>
+__global__ void dropout_windows_kernel(const T* x, const uint32_t* keys, T* y, int Hf, int Wf, int C, int wsh, int wsw, int shh,
+                                       int shw, float q, long long total8) {
+    const long long per = (long long)Hf * Wf * C;
+    const int n = wsh * wsw, nWw = Wf / wsw;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total8; g += (long long)gridDim.x * blockDim.x) {
+        const long long e0 = g * 8, pix = e0 / C;
+        const int c = (int)(e0 - pix * C);
+        const long long b = pix / ((long long)Hf * Wf);
+        const int r = (int)(pix - b * Hf * Wf), oy = r / Wf, ox = r - oy * Wf;
+        const int py = oy - shh + (oy < shh ? Hf : 0), px = ox - shw + (ox < shw ? Wf : 0);
+        const int w = (py / wsh) * nWw + px / wsw, t = (py % wsh) * wsw + px % wsw;
+        const uint32_t li = (uint32_t)(((long long)w * n + t) * C + c);
+        const uint32_t k0 = keys[2 * b], k1 = keys[2 * b + 1];
+        float v[8];
+        if constexpr (sizeof(T) == 2) {
+            const uint4 u = *(const uint4*)(x + e0);
+            const uint32_t wd[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] = __uint_as_float(wd[e] << 16);
+                v[2 * e + 1] = __uint_as_float(wd[e] & 0xffff0000u);
+            }
+        } else {
+            const float4 a = *(const float4*)(x + e0), d = *(const float4*)(x + e0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = d.x; v[5] = d.y; v[6] = d.z; v[7] = d.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = word_uniform01(stream_word(k0, k1, li + e, (uint32_t)per)) < q ? v[e] / q : 0.f;
+        Out8<T>::st(y + e0, v);
+    }
+}
+
 // jax.random.split of R keys at once: child i of key r = words (2i, 2i + 1) of r's 2 * num-word stream (a thread per child)
 __global__ void prng_split_kernel(const uint32_t* keys, uint32_t* out, long long R, int num, int child_major) {
     const long long total = R * num;
@@ -153,6 +191,32 @@ int mv_prng_split(const void* keys, void* out, int64_t R, int num, int child_maj
     set_kernel_name("prng_split");
     hipLaunchKernelGGL(prng_split_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)stream,
                        (const uint32_t*)keys, (uint32_t*)out, (long long)R, num, child_major);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_dropout_windows_fwd(const void* x, const void* keys, void* y, int B, int Hf, int Wf, int C, int ws_h, int ws_w, int shift_h,
+                           int shift_w, float keep_prob, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && keys && y, "dropout_windows: NULL pointer");
+    MV_CHECK_ARG(B > 0 && Hf > 0 && Wf > 0 && C > 0 && C % 8 == 0, "dropout_windows: bad dims (C must be a multiple of 8)");
+    MV_CHECK_ARG(ws_h > 0 && ws_w > 0 && Hf % ws_h == 0 && Wf % ws_w == 0, "dropout_windows: map %dx%d is not a multiple of the window %dx%d",
+                 Hf, Wf, ws_h, ws_w);
+    MV_CHECK_ARG(shift_h >= 0 && shift_w >= 0 && shift_h < ws_h && shift_w < ws_w, "dropout_windows: bad shift");
+    MV_CHECK_ARG((long long)Hf * Wf * C < (1LL << 32), "dropout_windows: more than 2^32 values per sample");
+    MV_CHECK_ARG(keep_prob > 0.f && keep_prob <= 1.f, "dropout_windows: keep probability %g outside (0, 1]", keep_prob);
+    MV_CHECK_ARG(dtype == MV_BF16 || dtype == MV_F32, "dropout_windows: unknown dtype %d", dtype);
+    if (ws_h >= Hf) shift_h = 0;  // swin.py:116-120
+    if (ws_w >= Wf) shift_w = 0;
+    const long long total8 = (long long)B * Hf * Wf * C / 8;
+    long long gv = (total8 + 255) / 256;
+    const int gridv = (int)(gv > 256 * 32 ? 256 * 32 : gv);
+    set_kernel_name("dropout_threefry_windows");
+    if (dtype == MV_F32)
+        hipLaunchKernelGGL(dropout_windows_kernel<float>, dim3(gridv), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                           (const uint32_t*)keys, (float*)y, Hf, Wf, C, ws_h, ws_w, shift_h, shift_w, keep_prob, total8);
+    else
+        hipLaunchKernelGGL(dropout_windows_kernel<bf16_t>, dim3(gridv), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           (const uint32_t*)keys, (bf16_t*)y, Hf, Wf, C, ws_h, ws_w, shift_h, shift_w, keep_prob, total8);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

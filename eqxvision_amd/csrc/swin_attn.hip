@@ -13,6 +13,7 @@
 //   * block = 4 waves sharing one head: the head's relative-position bias, padded to 64x64 fp32, is staged in
 //     LDS once per block and re-used for all the windows the block walks.
 #include "mfma_common.h"
+#include "rng_common.h"
 
 namespace mv {
 
@@ -22,8 +23,14 @@ struct SwinP {
     bf16_t* out;
     int B, Hf, Wf, C, heads, wsh, wsw, shh, shw;
     int n, nWw, nW, total_windows;
+    const uint32_t* drop_keys;   // DROP: one Threefry key per sample, [B][2]
+    float keep;
 };
 
+// DROP: the reference's `_func_dropout(attn, attention_dropout, key)` (swin.py:227, applied in EVERY mode): probability
+// (window w, head h, query i, key j) of a sample is kept (/ keep) or zeroed by word ((w * heads + h) * n + i) * n + j of the
+// sample's Threefry stream = jax.random.bernoulli(key, keep, (nW, heads, n, n)), between the softmax and P . V.
+template <bool DROP>
 __global__ __launch_bounds__(256) void swin_attn_mfma_kernel(const SwinP p) {
     constexpr int DH = 32;
     constexpr int VPITCH = 64 * 2 + 8;                  // bytes per V^T row (64 keys + pad): 8 * odd
@@ -167,6 +174,20 @@ __global__ __launch_bounds__(256) void swin_attn_mfma_kernel(const SwinP p) {
                 }
             sum += __shfl_xor(sum, 32);
             const float inv = 1.f / sum;
+            if constexpr (DROP) {
+                const uint32_t k0 = p.drop_keys[2 * b], k1 = p.drop_keys[2 * b + 1];
+                const uint32_t nel = (uint32_t)p.nW * p.heads * n * n;
+                const uint32_t base = (((uint32_t)wloc * p.heads + h) * n + (q < n ? q : 0)) * n;
+                const float rk = 1.f / p.keep;
+#pragma unroll
+                for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = tk * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                        const bool on = word_uniform01(stream_word(k0, k1, base + (key < n ? key : 0), nel)) < p.keep;
+                        s[tk][e] = on ? s[tk][e] * rk : 0.f;
+                    }
+            }
             // O^T[d][q] = sum_key V^T[d][key] P[key][q]
             f32x16 o;
 #pragma unroll
@@ -209,8 +230,9 @@ int swin_mfma_supported(int C, int heads, int ws_h, int ws_w, int dtype) {
 }
 
 int swin_mfma_launch(const void* qkv, const float* bias, void* out, int B, int Hf, int Wf, int C, int heads, int ws_h,
-                     int ws_w, int shift_h, int shift_w, hipStream_t st) {
+                     int ws_w, int shift_h, int shift_w, const uint32_t* drop_keys, float keep, hipStream_t st) {
     SwinP p;
+    p.drop_keys = drop_keys; p.keep = keep;
     p.qkv = (const bf16_t*)qkv; p.bias = bias; p.out = (bf16_t*)out;
     p.B = B; p.Hf = Hf; p.Wf = Wf; p.C = C; p.heads = heads; p.wsh = ws_h; p.wsw = ws_w; p.shh = shift_h; p.shw = shift_w;
     p.n = ws_h * ws_w;
@@ -228,8 +250,13 @@ int swin_mfma_launch(const void* qkv, const float* bias, void* out, int B, int H
     const int per_cu = get_flag("swin_blocks_per_cu") ? get_flag("swin_blocks_per_cu") : 2;
     const int cap = (256 * per_cu) / heads > 0 ? (256 * per_cu) / heads : 1;
     if (gx > cap) gx = cap;
-    set_kernel_name("swin_attn_mfma");
-    hipLaunchKernelGGL(swin_attn_mfma_kernel, dim3(gx, heads), dim3(256), 0, st, p);
+    if (drop_keys && (long long)p.nW * heads * p.n * p.n >= (1LL << 32)) {
+        set_error("swin_attn: more than 2^32 probabilities per sample");
+        return MV_E_UNSUPPORTED;
+    }
+    set_kernel_name(drop_keys ? "swin_attn_mfma_dropout" : "swin_attn_mfma");
+    if (drop_keys) hipLaunchKernelGGL(swin_attn_mfma_kernel<true>, dim3(gx, heads), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(swin_attn_mfma_kernel<false>, dim3(gx, heads), dim3(256), 0, st, p);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

@@ -55,15 +55,16 @@ class MlpProjection(Module):
             return ops.linear(h, self.fc2, residual=residual)
         if keys is None:
             raise RuntimeError("Dropout requires a key when running in non-deterministic mode.")
-        if h.kind not in ("seq", "vec"):
+        hwc = h.kind == "map"            # a map reaches an MLP through Linear2d layers: channels-last (H, W, C) in the reference
+        if h.kind not in ("seq", "vec") and not (hwc and type(self.fc1).__name__ == "Linear2d"):
             raise NotImplementedError(f"MlpProjection: training-mode Dropout on a {h.kind} input is not built")
         ks = ops.split_keys(keys, 2)
         per_row = per_row and h.kind == "seq"
         if nn.dropout_live(self.drop1):
-            h = ops.dropout(h, self.drop1.p, ks[0], per_row=per_row)
+            h = ops.dropout(h, self.drop1.p, ks[0], per_row=per_row, hwc=hwc)
         y = ops.linear(h, self.fc2)
         if nn.dropout_live(self.drop2):
-            y = ops.dropout(y, self.drop2.p, ks[1], per_row=per_row)
+            y = ops.dropout(y, self.drop2.p, ks[1], per_row=per_row, hwc=hwc)
         return y if residual is None else ops.add(residual, y)
 
     @boundary

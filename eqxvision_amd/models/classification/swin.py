@@ -69,10 +69,6 @@ class _ShiftedWindowAttention(Module):
         self.window_size = list(window_size)
         self.shift_size = list(shift_size)
         self.num_heads = num_heads
-        if attention_dropout or dropout:
-            # the reference's `_func_dropout` (swin.py:17-20, 227, 233) has no inference switch: a non-zero rate drops in every
-            # mode, in window layout -- not built; refuse instead of silently not dropping
-            raise NotImplementedError("Swin attention_dropout / dropout > 0 (applied in every mode by the reference) is not built")
         self.attention_dropout = attention_dropout
         self.dropout = dropout
         self.qkv = Linear2d(dim, dim * 3, use_bias=qkv_bias, key=keys[0])
@@ -106,7 +102,11 @@ class _ShiftedWindowAttention(Module):
             cache["bias"] = b
         return b
 
-    def _forward(self, x: Act, residual: Optional[Act] = None, norm=None) -> Act:
+    def _live(self) -> bool:
+        """The reference's `_func_dropout` (swin.py:17-20, 227, 233) has no inference switch: a non-zero rate drops in EVERY mode."""
+        return self.attention_dropout > 0 or self.dropout > 0
+
+    def _forward(self, x: Act, residual: Optional[Act] = None, norm=None, key=None) -> Act:
         """`norm` given: x is the UN-normalised input and the LayerNorm is folded into the qkv Linear where possible."""
         x = ops.as_map(x)
         B, Hf, Wf, C = x.t.shape
@@ -114,12 +114,22 @@ class _ShiftedWindowAttention(Module):
             raise ValueError(f"feature map {Hf}x{Wf} is not a multiple of the window {self.window_size} "
                              "(the reference does not pad either, swin.py:782-790)")
         qkv = ops.linear(x, self.qkv) if norm is None else ops.ln_linear(x, norm, self.qkv)      # reference :151-153
-        a = ops.swin_window_attention(qkv, self._bias_dev(), self.num_heads, self.window_size, self.shift_size)
-        return ops.linear(a, self.proj, residual=residual)             # reference :232 (+ the block's residual)
+        if not self._live():
+            a = ops.swin_window_attention(qkv, self._bias_dev(), self.num_heads, self.window_size, self.shift_size)
+            return ops.linear(a, self.proj, residual=residual)         # reference :232 (+ the block's residual)
+        if key is None:
+            raise RuntimeError("Swin attention_dropout / dropout > 0 requires a key (drawn in every mode, swin.py:17-20)")
+        kd = ops._keys_dev(key, B)                                     # ONE key for both draws (reference :227, :233)
+        drop = (self.attention_dropout, kd) if self.attention_dropout > 0 else None
+        a = ops.swin_window_attention(qkv, self._bias_dev(), self.num_heads, self.window_size, self.shift_size, drop=drop)
+        y = ops.linear(a, self.proj)
+        if self.dropout > 0:
+            y = ops.dropout_windows(y, self.dropout, kd, self.window_size, self.shift_size)
+        return y if residual is None else ops.add(residual, y)
 
     @boundary
     def __call__(self, x, *, key=None):
-        return self._forward(x)
+        return self._forward(x, key=key)
 
 
 class _SwinTransformerBlock(Module):
@@ -146,7 +156,9 @@ class _SwinTransformerBlock(Module):
     def __call__(self, x, *, key=None):                                # reference :572-578
         x = ops.as_map(x)
         sd = self.stochastic_depth
-        if sd.inference or sd.p == 0.0:
+        attn_live = bool(getattr(self.attn, "_live", lambda: False)())
+        mlp_live = isinstance(self.mlp, MlpProjection) and self.mlp._live()
+        if (sd.inference or sd.p == 0.0) and not attn_live and not mlp_live:
             if type(self.attn) is _ShiftedWindowAttention and isinstance(self.norm1, nn.LayerNorm):
                 x = self.attn._forward(x, residual=x, norm=self.norm1)
             else:
@@ -159,10 +171,11 @@ class _SwinTransformerBlock(Module):
                     return self.mlp._forward(x, residual=x, norm=self.norm2)
             return self.mlp._forward(self.norm2(x), residual=x)
         if key is None:
-            raise RuntimeError("stochastic depth outside inference mode requires a key")
-        keys = jr.split(key, 4)                                        # reference :573 (attention / MLP dropouts are p = 0 here)
-        x = ops.add(x, sd(self.attn._forward(self.norm1(x)), key=keys[1]))
-        return ops.add(x, sd(self.mlp._forward(self.norm2(x)), key=keys[3]))
+            raise RuntimeError("stochastic depth outside inference mode / Swin dropout > 0 requires a key")
+        keys = jr.split(ops._batched_keys(key, x.t.shape[0]), 4)       # reference :573: attention, path, MLP, path
+        x = ops.add(x, sd(self.attn._forward(self.norm1(x), key=keys[0]), key=keys[1]))
+        m = self.mlp._forward(self.norm2(x), keys=keys[2]) if mlp_live else self.mlp._forward(self.norm2(x))
+        return ops.add(x, sd(m, key=keys[3]))
 
 
 class SwinTransformer(Module):

@@ -889,13 +889,34 @@ def qkv_attention(x: Act, lin, heads: int, scale: float, need_probs: bool, drop=
     return Act(out, "seq", x.batched), probs
 
 
-def swin_window_attention(qkv: Act, bias: torch.Tensor, heads: int, window, shift) -> Act:
+def swin_window_attention(qkv: Act, bias: torch.Tensor, heads: int, window, shift, drop=None) -> Act:
+    """`drop` = (p, per-sample keys): the reference's `_func_dropout(attn, attention_dropout, key)` (swin.py:227) inside the kernel."""
     B, Hf, Wf, C3 = qkv.t.shape
     C = C3 // 3
     out = empty((B, Hf, Wf, C), qkv.t.dtype)
-    _lib.call("mv_swin_window_attn_fwd", _ptr(qkv.t), _ptr(bias), _ptr(out), B, Hf, Wf, C, heads,
-              int(window[0]), int(window[1]), int(shift[0]), int(shift[1]), qkv.dt, stream_ptr())
+    if drop is None:
+        _lib.call("mv_swin_window_attn_fwd", _ptr(qkv.t), _ptr(bias), _ptr(out), B, Hf, Wf, C, heads,
+                  int(window[0]), int(window[1]), int(shift[0]), int(shift[1]), qkv.dt, stream_ptr())
+    else:
+        p, key = drop
+        if not 0.0 < float(p) < 1.0:
+            raise NotImplementedError(f"Swin attention_dropout = {p}")
+        _lib.call("mv_swin_window_attn_dropout_fwd", _ptr(qkv.t), _ptr(bias), _ptr(out), _ptr(_keys_dev(key, B)), float(1.0 - p),
+                  B, Hf, Wf, C, heads, int(window[0]), int(window[1]), int(shift[0]), int(shift[1]), qkv.dt, stream_ptr())
     return Act(out, "map", qkv.batched)
+
+
+def dropout_windows(x: Act, p: float, key, window, shift) -> Act:
+    """`_func_dropout(x, dropout, key)` on the projection output of `_shifted_window_attention` (swin.py:233): the mask is drawn
+    for the (num_windows, tokens, C) layout the reference holds there; x is the NHWC map of the same values."""
+    x = as_map(x)
+    if not 0.0 < float(p) < 1.0:
+        raise NotImplementedError(f"Swin dropout = {p}")
+    B, Hf, Wf, C = x.t.shape
+    y = empty(tuple(x.t.shape), x.t.dtype)
+    _lib.call("mv_dropout_windows_fwd", _ptr(x.t), _ptr(_keys_dev(key, B)), _ptr(y), B, Hf, Wf, C, int(window[0]), int(window[1]),
+              int(shift[0]), int(shift[1]), float(1.0 - p), x.dt, stream_ptr())
+    return Act(y, "map", x.batched)
 
 
 def resize_bilinear(x: Act, size, final: bool = False) -> Act:
@@ -1016,10 +1037,11 @@ def token_keys(key, B: int, N: int) -> torch.Tensor:
     return out
 
 
-def dropout(x: Act, p: float, key, per_row: bool = False) -> Act:
+def dropout(x: Act, p: float, key, per_row: bool = False, hwc: bool = False) -> Act:
     """eqx.nn.Dropout's training branch: where(bernoulli(key, 1 - p, x.shape), x / (1 - p), 0) per sample, the mask from the
     sample's key in JAX's bit stream (generated on the device, rng.hip).  `per_row`: x is (tokens, features) rows and `key`
-    holds one key per ROW (uint32 [B*N, 2], `token_keys`): the reference vmaps the layer over the tokens."""
+    holds one key per ROW (uint32 [B*N, 2], `token_keys`): the reference vmaps the layer over the tokens.  `hwc`: a map whose
+    reference-side array is channels-LAST (H, W, C) (Swin's Linear2d layers), not (C, H, W)."""
     if x.kind == "img":
         x = as_map(x)
     B = x.t.shape[0]
@@ -1031,8 +1053,8 @@ def dropout(x: Act, p: float, key, per_row: bool = False) -> Act:
     keys = _keys_dev(key, B)
     per = x.t.numel() // B
     y = empty(tuple(x.t.shape), x.t.dtype)
-    _lib.call("mv_dropout_fwd", _ptr(x.t), _ptr(keys), _ptr(y), B, per, C, 1 if x.kind == "map" else 0, float(1.0 - p), x.dt,
-              stream_ptr())
+    _lib.call("mv_dropout_fwd", _ptr(x.t), _ptr(keys), _ptr(y), B, per, C, 1 if x.kind == "map" and not hwc else 0,
+              float(1.0 - p), x.dt, stream_ptr())
     return Act(y, x.kind, x.batched)
 
 

@@ -139,6 +139,8 @@ def _train_layers(x):
 
     def rec(n):
         if isinstance(n, Module):
+            if hasattr(n, "attention_dropout") and (float(n.attention_dropout or 0) > 0 or float(getattr(n, "dropout", 0) or 0) > 0):
+                stochastic[0] = True       # Swin's `_func_dropout` draws in EVERY mode (swin.py:17-20)
             if getattr(n, "inference", True) is False:
                 if type(n).__name__ == "BatchNorm":
                     bns.append(n)

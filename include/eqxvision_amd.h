@@ -268,6 +268,19 @@ int mv_swin_window_attn_fwd(const void* qkv, const float* bias, void* out, int B
                             int heads, int ws_h, int ws_w, int shift_h, int shift_w,
                             int dtype, mv_stream_t stream);
 
+/* The reference's two `_func_dropout` calls inside `_shifted_window_attention` (swin.py:17-20, :227, :233 -- applied in
+ * EVERY mode, the function has no inference switch; both draw from the SAME key):
+ * mv_swin_window_attn_dropout_fwd: the attention core with the probabilities (num_windows, heads, n, n) of every sample dropped
+ * by jax.random.bernoulli(key, keep_prob, that shape) between the softmax and P . V (MFMA path only: bf16, 32 channels per
+ * head, <= 64 tokens per window, else MV_E_UNSUPPORTED);
+ * mv_dropout_windows_fwd: Dropout of the projection's output, an NHWC map here, in the LOGICAL order (num_windows, n, C) of the
+ * shifted, window-partitioned map it has in the reference at that point.  keys: [B][2] uint32 on the device. */
+int mv_swin_window_attn_dropout_fwd(const void* qkv, const float* bias, void* out, const void* keys, float keep_prob, int B,
+                                    int Hf, int Wf, int C, int heads, int ws_h, int ws_w, int shift_h, int shift_w,
+                                    int dtype, mv_stream_t stream);
+int mv_dropout_windows_fwd(const void* x, const void* keys, void* y, int B, int Hf, int Wf, int C, int ws_h, int ws_w,
+                           int shift_h, int shift_w, float keep_prob, int dtype, mv_stream_t stream);
+
 /* _patch_merging_pad (swin.py:23-31): NHWC [B,H,W,C] -> [B,H/2,W/2,4C], channel blocks
  * [x(0::2,0::2) | x(1::2,0::2) | x(0::2,1::2) | x(1::2,1::2)], zero pad odd H/W. */
 int mv_patch_merge_gather_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, mv_stream_t stream);

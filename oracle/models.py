@@ -457,28 +457,36 @@ def vit_last_self_attention(sd, x, patch=16, num_heads=12, depth=12, bf16=False)
 
 
 # ---------------------------------------------------------------- swin.py:572-578, 760-772
-def swin_block(sd, q, x, p, num_heads, window, shift, sd_prob=0.0, key=None):
-    """`key` given (training mode): x + stochastic_depth(attn(norm1 x), key=keys[1]), then the same around the MLP with keys[3],
-    keys = split(key, 4); DropPath(sd_prob, mode="local"): one draw per channel (swin.py:545, 572-578)."""
-    ks = None if key is None or sd_prob == 0.0 else O.jax_split(key, 4)
+def swin_block(sd, q, x, p, num_heads, window, shift, sd_prob=0.0, key=None, dropout=0.0, attention_dropout=0.0, training=True):
+    """`key` given: keys = split(key, 4) (swin.py:573): [0] -> the attention's two `_func_dropout` draws (every mode), [2] -> the
+    MLP (split in two for its Dropouts on the (H, W, C) arrays, mlps.py:60-65; training mode only), [1] / [3] ->
+    x + stochastic_depth(., key) with DropPath(sd_prob, mode="local"): one draw per channel (swin.py:545, 572-578; training mode)."""
+    ks = None if key is None else O.jax_split(key, 4)
     y = q(O.layernorm2d(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"]))
     bias = O.relative_position_bias(sd[p + ".attn.relative_position_bias_table"],
                                     sd[p + ".attn.relative_position_index"], window)
     y = O.shifted_window_attention(y, q(sd[p + ".attn.qkv.weight"]), q(sd[p + ".attn.proj.weight"]), bias,
-                                   window, num_heads, shift, sd[p + ".attn.qkv.bias"], sd[p + ".attn.proj.bias"])
-    if ks is not None:
+                                   window, num_heads, shift, sd[p + ".attn.qkv.bias"], sd[p + ".attn.proj.bias"],
+                                   attention_dropout=attention_dropout, dropout=dropout, key=None if ks is None else ks[0])
+    if ks is not None and training and sd_prob > 0.0:
         y = O.drop_path(q(y), sd_prob, "local", ks[1])
     x = q(x + y)
     y = q(O.layernorm2d(x, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"]))
     h = q(O.gelu_tanh(O.linear2d(y, q(sd[p + ".mlp.0.weight"]), sd[p + ".mlp.0.bias"])))
+    mk = O.jax_split(ks[2], 2) if ks is not None and training and dropout > 0.0 else None
+    hwc = lambda a, f: np.transpose(f(np.transpose(a, (1, 2, 0))), (2, 0, 1))      # the reference's arrays are (H, W, C) here
+    if mk is not None:
+        h = q(hwc(h, lambda a: O.dropout(a, dropout, mk[0])))
     y = O.linear2d(h, q(sd[p + ".mlp.3.weight"]), sd[p + ".mlp.3.bias"])
-    if ks is not None:
+    if mk is not None:
+        y = hwc(q(y), lambda a: O.dropout(a, dropout, mk[1]))
+    if ks is not None and training and sd_prob > 0.0:
         y = O.drop_path(q(y), sd_prob, "local", ks[3])
     return q(x + y)
 
 
 def swin_forward(sd, x, patch=(4, 4), depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window=(7, 7), bf16=False, key=None,
-                 stochastic_depth_prob=0.0):
+                 stochastic_depth_prob=0.0, dropout=0.0, attention_dropout=0.0, training=True):
     """`key` given: TRAINING mode.  Keys as the reference derives them: split(key, 2)[0] for `features` (swin.py:766-767),
     nn.Sequential splits it per layer, each stage Sequential per block; block id / (total - 1) scales the drop rate (:730-733)."""
     q = _Q(bf16)
@@ -495,7 +503,7 @@ def swin_forward(sd, x, patch=(4, 4), depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 
             shift = [0 if bi % 2 == 0 else w // 2 for w in window]                    # swin.py:736-738
             sdp = stochastic_depth_prob * float(blk_id) / (total - 1) if total > 1 else 0.0
             x = swin_block(sd, q, x, f"features.{fi}.{bi}", num_heads[si], list(window), shift, sdp,
-                           None if bkeys is None else bkeys[bi])
+                           None if bkeys is None else bkeys[bi], dropout, attention_dropout, training)
             blk_id += 1
         fi += 1
         if si < len(depths) - 1:

@@ -922,6 +922,39 @@ def layernorm_case(M, C, dtype="bf16", generic=False, stride=None, seed=0, out=N
     return run
 
 
+def dropout_windows_case(B, Hf, Wf, C, ws, shift, p=0.25, dtype="bf16", seed=0):
+    """mv_dropout_windows_fwd vs the reference's order of operations (swin.py:141-160, 233-250): roll, partition into windows,
+    `_func_dropout` on (num_windows, n, C), reverse -- bit-exact mask, values x / keep."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        x = rng.standard_normal((B, Hf, Wf, C)).astype(np.float32)
+        if dtype == "bf16":
+            x = bf(x)
+        keys = rng.integers(0, 2 ** 32, size=(B, 2), dtype=np.uint64).astype(np.uint32)
+        sh = [0 if ws[0] >= Hf else shift[0], 0 if ws[1] >= Wf else shift[1]]
+        ref = np.empty_like(x)
+        for b in range(B):
+            r = np.roll(x[b], (-sh[0], -sh[1]), axis=(0, 1))
+            w = r.reshape(Hf // ws[0], ws[0], Wf // ws[1], ws[1], C).transpose(0, 2, 1, 3, 4).reshape(-1, ws[0] * ws[1], C)
+            w = O.dropout_fn(w, p, keys[b])
+            r = w.reshape(Hf // ws[0], Wf // ws[1], ws[0], ws[1], C).transpose(0, 2, 1, 3, 4).reshape(Hf, Wf, C)
+            ref[b] = np.roll(r, (sh[0], sh[1]), axis=(0, 1))
+        xd = dev(x, dtype)
+        kd = torch.from_numpy(keys.view(np.int32)).cuda()
+        y = torch.empty_like(xd)
+        L.call("mv_dropout_windows_fwd", xd.data_ptr(), kd.data_ptr(), y.data_ptr(), B, Hf, Wf, C, ws[0], ws[1], shift[0], shift[1],
+               float(np.float32(1.0 - p)), DT[dtype], _stream())
+        torch.cuda.synchronize()
+        got = host(y)
+        info = _cmp(got, ref, TOL_BF16 if dtype == "bf16" else 1e-6)
+        info["mask_mismatches"] = int(((got != 0) != (ref != 0)).sum())
+        info["kernel"] = L.last_kernel()
+        info["ok"] = info["ok"] and info["mask_mismatches"] == 0
+        return info
+    return run
+
+
 def prng_split_case(R, num, child_major, seed=0):
     """mv_prng_split vs the oracle's jax.random.split of every key: bit-exact."""
     def run():
@@ -1668,6 +1701,10 @@ def all_cases():
           ("mha/dropout_17_32", mha_dropout_case(4, 17, 2, 32, p=0.1, seed=2)),
           ("mha/dropout_256_32_noprobs", mha_dropout_case(1, 256, 2, 32, probs=False, seed=3)),
           ("mha/dropout_odd_count", mha_dropout_case(1, 33, 1, 64, p=0.3, seed=4)),
+          ("dropout/windows_shifted", dropout_windows_case(2, 14, 14, 64, (7, 7), (3, 3))),
+          ("dropout/windows_unshifted_f32", dropout_windows_case(2, 14, 21, 32, (7, 7), (0, 0), dtype="fp32", seed=1)),
+          ("dropout/windows_one_window", dropout_windows_case(3, 7, 7, 128, (7, 7), (3, 3), seed=2)),
+          ("dropout/windows_rect", dropout_windows_case(1, 8, 12, 40, (4, 6), (1, 2), p=0.5, seed=3)),
           ("prng/split_tokens", prng_split_case(37, 197, 0)),
           ("prng/split_pairs_child_major", prng_split_case(5000, 2, 1, seed=1)),
           ("prng/split_one", prng_split_case(3, 1, 0, seed=2)),

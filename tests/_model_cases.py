@@ -507,6 +507,46 @@ def swin_train_case(size=56, embed=32, depths=(2, 2), heads=(2, 4), B=4, classes
     return run
 
 
+def swin_dropout_case(training=True, size=56, embed=64, depths=(2, 2), heads=(2, 4), B=3, classes=10, sd_prob=0.2, dropout=0.1,
+                      attention_dropout=0.2, effect=5.0):
+    """Swin with dropout / attention_dropout > 0: the reference's `_func_dropout` draws on the window-layout probabilities and
+    projection output in EVERY mode (swin.py:17-20, 227, 233), the MLP's Dropouts and stochastic depth in training mode only; masks
+    from the same keys as the oracle's.  32 channels per head: the MFMA window-attention kernel's dropout variant."""
+    def run():
+        import warnings
+        import eqxvision_amd as eqv
+        sd = S.swin_state(1, (4, 4), embed, depths, heads, (7, 7), 4.0, classes)
+        x = S.synthetic_images(B, size, seed=0)
+        fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(eqv.models.SwinTransformer(**kw), torch_weights)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            net = _load(fac, sd, patch_size=[4, 4], embed_dim=embed, depths=list(depths), num_heads=list(heads),
+                        window_size=[7, 7], num_classes=classes, stochastic_depth_prob=sd_prob, dropout=dropout,
+                        attention_dropout=attention_dropout)
+        net = eqv.tree_inference(net, not training)
+        keys = eqv.random.split(eqv.random.PRNGKey(37), B)
+        with eqv.precision("bf16"):
+            f = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k))
+            got = f(net, x, keys).cpu().numpy()
+            again = f(net, x, eqv.random.split(eqv.random.PRNGKey(38), B)).cpu().numpy()     # fresh keys -> fresh masks (never replayed)
+            try:
+                eqv.vmap(net, axis_name="batch")(x)
+                keyless = "no error"
+            except RuntimeError:
+                keyless = "RuntimeError"
+        ref = np.stack([OM.swin_forward(sd, x[i], (4, 4), depths, heads, (7, 7), bf16=True, key=keys[i], stochastic_depth_prob=sd_prob,
+                                        dropout=dropout, attention_dropout=attention_dropout, training=training) for i in range(B)])
+        inf = np.stack([OM.swin_forward(sd, x[i], (4, 4), depths, heads, (7, 7), bf16=True) for i in range(B)])
+        out = _cmp(got, ref, 1e-2)
+        out["differs_from_no_dropout"] = float(np.abs(got - inf).max())
+        out["differs_with_other_keys"] = float(np.abs(got - again).max())
+        out["keyless_call"] = keyless
+        out["ok"] = (out["ok"] and out["differs_from_no_dropout"] > effect * max(out["err"], 1e-3)
+                     and out["differs_with_other_keys"] > effect * max(out["err"], 1e-3) and keyless == "RuntimeError")
+        return out
+    return run
+
+
 def vit_train_case(img=32, patch=8, dim=64, depth=4, heads=2, B=4, classes=10, rate=0.6):
     """ViT outside inference mode with drop_path_rate > 0: DropPath(mode="global") per block, rates linspace(0, rate, depth), keys
     split per block and 4 ways inside (vit.py:148-156, 236-246, 267-271) -> the oracle drops the same residual branches."""
@@ -898,6 +938,9 @@ def all_cases(full=True):
          ("model/alexnet_train_mode_dropout", alexnet_train_case()),
          ("model/swin_train_mode_stochastic_depth", swin_train_case()),
          ("model/vit_train_mode_stochastic_depth", vit_train_case()),
+         ("model/swin_dropouts_training_mode", swin_dropout_case(True)),
+         ("model/swin_dropouts_inference_mode", swin_dropout_case(False)),
+         ("model/swin_attention_dropout_only", swin_dropout_case(True, dropout=0.0, sd_prob=0.0, attention_dropout=0.5, effect=2.0)),
          ("model/vit_train_mode_dropouts", vit_dropout_case()),
          ("model/vit_train_mode_attn_dropout_only", vit_dropout_case(drop=0.0, attn_drop=0.3, path=0.0, depth=2)),
          ("model/vit_train_mode_mlp_dropout_only", vit_dropout_case(drop=0.25, attn_drop=0.0, path=0.0, depth=2)),
