@@ -389,6 +389,12 @@ def test_prng_is_jax_threefry():
         np.testing.assert_array_equal(jr.bernoulli(keys, 0.3, (5, 3))[b], jr.bernoulli(keys[b], 0.3, (5, 3)))
     assert jr.bernoulli(keys, 0.5).shape == (6,)
     assert abs(float(jr.bernoulli(jr.PRNGKey(1), 0.3, (20000,)).mean()) - 0.3) < 0.02
+    many = jr.split(jr.PRNGKey(4), 301)                                 # many keys, few words each: the keys-innermost layout
+    for n in (1, 2, 3, 4):
+        got = jr.random_bits(many, n)
+        assert got.shape == (301, n) and got.flags["C_CONTIGUOUS"]
+        for b in (0, 150, 300):
+            np.testing.assert_array_equal(got[b], jr.random_bits(many[b], n))
 
 
 def test_stochastic_layers_need_keys_and_inference_is_identity():
@@ -404,4 +410,14 @@ def test_stochastic_layers_need_keys_and_inference_is_identity():
     assert _needs_eager(nn.Sequential([nn.Linear(4, 4, key=eqv.random.PRNGKey(0)), nn.Dropout(0.5)]))
     assert not _needs_eager(eqv.tree_inference(nn.Sequential([nn.Dropout(0.5), nn.BatchNorm(8)]), True))
     assert _needs_eager(nn.Sequential([nn.BatchNorm(8)]))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # Swin's `_func_dropout` has no inference switch (swin.py:17-20): a model built with those rates is stochastic in EVERY mode
+        kw = dict(patch_size=[4, 4], embed_dim=32, depths=[2], num_heads=[1], window_size=[7, 7], num_classes=3, stochastic_depth_prob=0.0)
+        assert _needs_eager(eqv.tree_inference(eqv.models.SwinTransformer(attention_dropout=0.1, **kw), True))
+        assert _needs_eager(eqv.tree_inference(eqv.models.SwinTransformer(dropout=0.1, **kw), True))
+        assert not _needs_eager(eqv.tree_inference(eqv.models.SwinTransformer(**kw), True))
+    vit = eqv.models.VisionTransformer(img_size=16, patch_size=8, embed_dim=32, depth=1, num_heads=1, num_classes=3, attn_drop_rate=0.1)
+    assert _needs_eager(vit) and not _needs_eager(eqv.tree_inference(vit, True))
 
