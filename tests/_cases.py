@@ -1407,6 +1407,33 @@ def fuzz_family_cases(n, seed=0):
     return out
 
 
+def fuzz_stochastic_cases(n, seed=0):
+    """Random shapes for the in-kernel / window-layout / per-token draws of the training-mode transformers: attention dropout
+    (both qkv layouts, with and without the probabilities), Dropout in window layout, key splits."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        k = int(rng.integers(0, 3))
+        sd = 6000 + i
+        if k == 0:
+            N, H, dh = int(rng.integers(1, 257)), int(rng.integers(1, 7)), int(rng.choice([32, 64]))
+            out.append((f"fuzzs/s{seed}_mha_dropout_N{N}_H{H}_dh{dh}_{i}",
+                        mha_dropout_case(int(rng.integers(1, 4)), N, H, dh, p=float(rng.choice([0.05, 0.3, 0.7])),
+                                         head_major=bool(rng.random() < 0.5), probs=bool(rng.random() < 0.7), seed=sd)))
+        elif k == 1:
+            ws = (int(rng.integers(1, 9)), int(rng.integers(1, 9)))
+            g = (int(rng.integers(1, 5)), int(rng.integers(1, 5)))
+            shift = (int(rng.integers(0, ws[0])), int(rng.integers(0, ws[1])))
+            C = 8 * int(rng.integers(1, 25))
+            out.append((f"fuzzs/s{seed}_dropout_windows_{g[0] * ws[0]}x{g[1] * ws[1]}_C{C}_{i}",
+                        dropout_windows_case(int(rng.integers(1, 4)), g[0] * ws[0], g[1] * ws[1], C, ws, shift,
+                                             p=float(rng.choice([0.1, 0.5, 0.9])), dtype=str(rng.choice(["bf16", "fp32"])), seed=sd)))
+        else:
+            out.append((f"fuzzs/s{seed}_prng_split_{i}", prng_split_case(int(rng.integers(1, 3000)), int(rng.integers(1, 12)),
+                                                                        int(rng.integers(0, 2)), seed=sd)))
+    return out
+
+
 def all_cases():
     c = []
     # ---- implicit-GEMM conv (MFMA) : ResNet-50 shapes at reduced spatial size + edge cases
@@ -1730,4 +1757,5 @@ def all_cases():
     c += fuzz_cases(24, seed=3) + fuzz_cases(16, seed=4, mfma_only=True)      # default dispatch, random shapes
     c += fuzz_misc_cases(24, seed=5)
     c += fuzz_family_cases(42, seed=6)
+    c += fuzz_stochastic_cases(18, seed=7)
     return c
