@@ -36,6 +36,7 @@ PROTOTYPES = {
     "mv_allreduce_sum_f32": [_vp, C.c_size_t, _vp],
     "mv_swin_window_attn_dropout_fwd": [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mv_dropout_windows_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "mv_drop_path_noise": [_vp, _vp, _i, _i, _i, _f, _i, _vp],
     "mv_prng_split": [_vp, _vp, _i64, _i, _i, _vp],
     "mv_dropout_fwd": [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _vp],
     "mv_channel_moments2_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp],

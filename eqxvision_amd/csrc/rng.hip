@@ -169,6 +169,22 @@ __global__ void dropout_windows_kernel(const T* x, const uint32_t* keys, T* y, i
     }
 }
 
+// DropPath's noise (drop_path.py:51-61) as the [B][C] scale the broadcast-multiply kernel takes: bernoulli(key_b, keep) for the whole
+// sample ("global": the single word of a 1-word stream, repeated over C) or bernoulli(key_b, keep, (C,)) per entry of the first
+// axis ("local": word c of a C-word stream), divided by keep
+template <typename T>
+__global__ void drop_path_noise_kernel(const uint32_t* keys, T* out, int B, int C, int local, float keep) {
+    const long long total = (long long)B * C;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(g / C), c = (int)(g - (long long)b * C);
+        const uint32_t w = local ? stream_word(keys[2 * b], keys[2 * b + 1], (uint32_t)c, (uint32_t)C)
+                                 : stream_word(keys[2 * b], keys[2 * b + 1], 0u, 1u);
+        const float v = word_uniform01(w) < keep ? 1.f / keep : 0.f;
+        if constexpr (sizeof(T) == 2) out[g] = (T)(pack_bf2(v, 0.f) & 0xffffu);
+        else out[g] = v;
+    }
+}
+
 // jax.random.split of R keys at once: child i of key r = words (2i, 2i + 1) of r's 2 * num-word stream (a thread per child)
 __global__ void prng_split_kernel(const uint32_t* keys, uint32_t* out, long long R, int num, int child_major) {
     const long long total = R * num;
@@ -183,6 +199,23 @@ __global__ void prng_split_kernel(const uint32_t* keys, uint32_t* out, long long
 }
 
 extern "C" {
+
+int mv_drop_path_noise(const void* keys, void* out, int B, int C, int local, float keep_prob, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(keys && out && B > 0 && C > 0, "drop_path_noise: bad args");
+    MV_CHECK_ARG(keep_prob > 0.f && keep_prob <= 1.f, "drop_path_noise: keep probability %g outside (0, 1]", keep_prob);
+    MV_CHECK_ARG(dtype == MV_BF16 || dtype == MV_F32, "drop_path_noise: unknown dtype %d", dtype);
+    long long g = ((long long)B * C + 255) / 256;
+    const unsigned grid = (unsigned)(g > 4096 ? 4096 : g);
+    set_kernel_name("drop_path_noise");
+    if (dtype == MV_F32)
+        hipLaunchKernelGGL(drop_path_noise_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)keys,
+                           (float*)out, B, C, local, keep_prob);
+    else
+        hipLaunchKernelGGL(drop_path_noise_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)keys,
+                           (bf16_t*)out, B, C, local, keep_prob);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
 
 int mv_prng_split(const void* keys, void* out, int64_t R, int num, int child_major, mv_stream_t stream) {
     MV_CHECK_ARG(keys && out && keys != out, "prng_split: NULL or aliased pointers");

@@ -1061,24 +1061,22 @@ def dropout(x: Act, p: float, key, per_row: bool = False, hwc: bool = False) -> 
 def drop_path(x: Act, p: float, mode: str, key) -> Act:
     """DropPath's training branch (drop_path.py:51-61): noise = bernoulli(key, 1 - p) for the whole sample (mode "global") or one
     draw per entry of the sample's FIRST logical axis (mode "local": channels of a (C,H,W) map, tokens of an (N,D) matrix),
-    divided by 1 - p when that is positive; x * noise.  The draws come from the host (a handful per sample, JAX's bit stream:
-    random.bernoulli); the multiply is the broadcast-scale kernel."""
-    from . import random as jr
+    divided by 1 - p when that is positive; x * noise.  The draws are made on the device from the samples' keys (JAX's bit stream,
+    mv_drop_path_noise -> a [B, C] scale); the multiply is the broadcast-scale kernel."""
     if x.kind == "img":
         x = as_map(x)
     B = x.t.shape[0]
-    keys = _batched_keys(key, B)
     keep = 1.0 - float(p)
     if x.kind == "seq" and mode != "global":
         raise NotImplementedError("DropPath(mode='local') on a (tokens, features) array is not on any model's path")
     C = x.t.shape[-1]
-    if mode == "global":
-        noise = np.repeat(jr.bernoulli(keys, keep).reshape(B, 1).astype(np.float32), C, axis=1)
+    if keep <= 0.0:                    # p = 1: bernoulli(key, 0) is all False and the reference skips the division
+        _keys_dev(key, B)
+        s = torch.zeros((B, C), dtype=x.t.dtype, device=device())
     else:
-        noise = jr.bernoulli(keys, keep, (C,)).astype(np.float32)
-    if keep > 0.0:
-        noise = noise / np.float32(keep)
-    s = _dev(np.ascontiguousarray(noise), x.t.dtype)
+        s = empty((B, C), x.t.dtype)
+        _lib.call("mv_drop_path_noise", _ptr(_keys_dev(key, B)), _ptr(s), B, C, 0 if mode == "global" else 1,
+                  float(np.float32(keep)), x.dt, stream_ptr())
     xm = x if x.kind == "map" else Act(x.t.reshape(B, -1, 1, C), "map", x.batched)
     y = channel_scale(xm, Act(s, "vec", x.batched))
     return y if x.kind == "map" else Act(y.t.reshape(x.t.shape), x.kind, x.batched)

@@ -325,6 +325,11 @@ int mv_dropout_fwd(const void* x, const void* keys, void* y, int B, int64_t per_
  * (child_major = 1: what a vmapped split returns, child i of every key contiguous). */
 int mv_prng_split(const void* keys, void* out, int64_t R, int num, int child_major, mv_stream_t stream);
 
+/* DropPath's draws (drop_path.py:51-61, training mode) as the scale mv_channel_scale_nhwc_fwd multiplies by: out [B][C] =
+ * bernoulli(key_b, keep_prob) / keep_prob for the whole sample (local = 0, mode "global") or bernoulli(key_b, keep_prob, (C,))[c] /
+ * keep_prob (local = 1, mode "local": one draw per entry of the sample's first axis), in `dtype`. */
+int mv_drop_path_noise(const void* keys, void* out, int B, int C, int local, float keep_prob, int dtype, mv_stream_t stream);
+
 /* Per-channel batch moments of rows x[rows][C] (an NHWC map or a row matrix): the statistics of eqx.experimental.BatchNorm's
  * TRAINING branch (reference resnet.py:132-136 / :252 / :301 with the model not in inference mode):
  *   out[c] = sum over rows of (x[r][c] - shift[c])        (squared = 0; shift may be NULL)
