@@ -109,8 +109,14 @@ class _ResNetBottleneck(Module):
             out = pre[1]
         else:
             out = ops.conv2d(x, self.conv1, self.bn1, "relu")
-        out = ops.conv2d(out, self.conv2, self.bn2, "relu")
         ds = self.downsample
+        if isinstance(ds, nn.Identity):
+            # identity block on a map that fits a CU: conv2 + conv3 + identity in one launch, the `width`-channel intermediate
+            # stays in LDS (ops.bottleneck_tail; None when the library has no such path for the shapes)
+            y = ops.bottleneck_tail(out, self.conv2, self.bn2, self.conv3, self.bn3, x)
+            if y is not None:
+                return y
+        out = ops.conv2d(out, self.conv2, self.bn2, "relu")
         conv_ds = isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d) and \
             isinstance(ds[1], nn.BatchNorm)
         if conv_ds:

@@ -452,6 +452,63 @@ def conv1x1_chain(x: Act, conv3, bn3, residual: Act, conv1n, bn1n) -> Optional[A
     return out
 
 
+def _fold(conv, bn):
+    """fp32 (scale, shift) of a convolution's bias + BatchNorm(inference) epilogue (ones / zeros where absent)."""
+    K = conv.out_channels
+    bias = None if conv.bias is None else np.asarray(conv.bias, np.float32).reshape(-1)
+    if bn is not None:
+        scale, shift = bn_fold(bn)
+        if bias is not None:
+            shift = shift + bias * scale
+        return scale, shift
+    return np.ones(K, np.float32), (np.zeros(K, np.float32) if bias is None else bias)
+
+
+def prep_bneck_tail(conv2, bn2, conv3, bn3):
+    """Weights of a bottleneck's 3x3 and expansion convolutions in the FRAGMENT ORDER of mv_bottleneck_tail_fwd (header): a wave
+    owns 32 output channels and fetches each k16-step of them as one contiguous 1 KB piece (cached on conv2)."""
+    key = ("bneck_tail", _bn_id(bn2), id(conv3), _bn_id(bn3))
+    cache = conv2._cache()
+    hit = cache.get(key)
+    if hit is None:
+        w2 = np.ascontiguousarray(np.asarray(conv2.weight, np.float32).transpose(0, 2, 3, 1))     # [K][R][S][C]
+        K, R, S, C = w2.shape
+        w2f = w2.reshape(K // 32, 32, R * S, C // 16, 2, 8).transpose(0, 2, 3, 4, 1, 5)            # (wave, tap, j, h, m, e)
+        w3 = np.asarray(conv3.weight, np.float32).reshape(conv3.out_channels, C)
+        w3f = w3.reshape(conv3.out_channels // 256, 8, 32, C // 16, 2, 8).transpose(0, 1, 3, 4, 2, 5)   # (chunk, wave, j, h, m, e)
+        s2, h2 = _fold(conv2, bn2)
+        s3, h3 = _fold(conv3, bn3)
+        hit = (_dev(w2f, torch.bfloat16), _dev(s2, torch.float32), _dev(h2, torch.float32),
+               _dev(w3f, torch.bfloat16), _dev(s3, torch.float32), _dev(h3, torch.float32))
+        cache[key] = hit
+    return hit
+
+
+def bottleneck_tail(t1: Act, conv2, bn2, conv3, bn3, identity: Act) -> Optional[Act]:
+    """relu(bn3(conv3(relu(bn2(conv2(t1))))) + identity) in ONE launch with the `width`-channel intermediate resident in LDS,
+    one workgroup per image (resnet.py:144-162, identity blocks).  None when the library has no such path for the shapes."""
+    dt = compute_dtype()
+    if dt != "bf16" or _bn_training(bn2) or _bn_training(bn3) or not _pointwise(conv3):
+        return None
+    if tuple(conv2.kernel_size) != (3, 3) or tuple(conv2.stride) != (1, 1) or tuple(conv2.padding) != (1, 1) \
+            or tuple(conv2.dilation) != (1, 1) or conv2.groups != 1 or conv2.in_channels != conv2.out_channels \
+            or conv3.in_channels != conv2.out_channels:
+        return None
+    t1, identity = as_map(t1), as_map(identity)
+    B, H, W, C = t1.t.shape
+    K = conv3.out_channels
+    if C != conv2.in_channels or tuple(identity.t.shape) != (B, H, W, K) or t1.t.dtype != torch.bfloat16 \
+            or identity.t.dtype != torch.bfloat16:
+        return None
+    if not _lib.load().mv_bottleneck_tail_supported(H, W, C, K, DT[dt]):
+        return None
+    w2f, s2, h2, w3f, s3, h3 = prep_bneck_tail(conv2, bn2, conv3, bn3)
+    y = empty((B, H, W, K), torch.bfloat16)
+    _lib.call("mv_bottleneck_tail_fwd", _ptr(t1.t), _ptr(w2f), _ptr(s2), _ptr(h2), _ptr(w3f), _ptr(s3), _ptr(h3),
+              _ptr(identity.t), _ptr(y), B, H, W, C, K, DT[dt], stream_ptr())
+    return Act(y, "map", t1.batched)
+
+
 def _scaled_rows(conv, bn) -> Tuple[np.ndarray, np.ndarray]:
     """A pointwise conv + BatchNorm(inference) as (scale[k] * W[k, :], shift[k]) in fp32."""
     w = np.asarray(conv.weight, np.float32).reshape(conv.out_channels, -1)

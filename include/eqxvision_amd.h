@@ -107,6 +107,21 @@ int mv_conv1x1_chain_fwd(const void* x, const void* w3, const float* scale3, con
                          const float* shift1, void* t1, int64_t M, int C, int K, int N2, int dtype,
                          mv_stream_t stream);
 
+/* The tail of an identity ResNet bottleneck, CU-resident per image (resnet.py:144-162: conv2 3x3 -> bn2 -> relu -> conv3 1x1 ->
+ * bn3 -> + identity -> relu; stride 1, no downsample branch), one launch, one workgroup per image:
+ *   t2[B,H,W,width] = relu(scale2 * conv3x3_pad1(t1[B,H,W,width], w2) + shift2)      (stays in LDS, rounded to bf16)
+ *   y [B,H,W,cout]  = relu(scale3 * (t2 . w3[cout,width]^T) + shift3 + residual[B,H,W,cout])
+ * Weights in FRAGMENT ORDER (prepared once by the caller, eqxvision_amd/ops.py:prep_bneck_tail): a wave owns 32 output
+ * channels and fetches each k16-step of them as one 1 KB piece,
+ *   w2f[wave 0..7][tap r*3+s][j 0..width/16-1][lane 0..63][e 0..7] = w2[k = 32*wave + lane%32][r][s][c = 16*j + 8*(lane/32) + e]
+ *   w3f[chunk 0..cout/256-1][wave][j][lane][e]                     = w3[k = 256*chunk + 32*wave + lane%32][c = 16*j + 8*(lane/32) + e]
+ * (w2 in KRSC, w3 [cout][width]).  Supported: bf16, 14x14 maps, width 256, cout 1024 (ResNet-50/101/152 layer3).  y must
+ * not alias t1 or residual. */
+int mv_bottleneck_tail_supported(int H, int W, int width, int cout, int dtype);
+int mv_bottleneck_tail_fwd(const void* t1, const void* w2f, const float* scale2, const float* shift2, const void* w3f,
+                           const float* scale3, const float* shift3, const void* residual, void* y, int B, int H, int W,
+                           int width, int cout, int dtype, mv_stream_t stream);
+
 /* conv3 + BN and the downsample conv + BN of a stage's first bottleneck (resnet.py:144-162, 295-303) as ONE GEMM over
  * the concatenated reduction: both add into the same output, so
  *   y[N,Ho,Wo,K] = act(scale[k] * (x[N,Ho,Wo,C1] . wcat[k, 0:C1] + x2[N, s*ho, s*wo, C2] . wcat[k, C1:C1+C2]) + shift[k])

@@ -160,6 +160,47 @@ def chain_case(M, seed=0, N2=64, C=64, K=256):
     return run
 
 
+def bneck_tail_case(B, seed=0, HW=14, WID=256, COUT=1024, big=False):
+    """mv_bottleneck_tail_fwd (an identity bottleneck's conv2 3x3 + BN + ReLU -> conv3 1x1 + BN + identity + ReLU in one launch,
+    one workgroup per image, resnet.py:144-162) vs the oracle; the intermediate is rounded to bf16 exactly where the un-fused
+    pair of launches stores it.  Weights are handed over in the fragment order the header documents (ops.prep_bneck_tail)."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        amp = 4.0 if big else 1.0
+        t1 = bf(np.maximum(rng.standard_normal((B, WID, HW, HW)), 0) * amp)
+        w2 = bf(rng.standard_normal((WID, WID, 3, 3)) / np.sqrt(WID * 9))
+        s2 = rng.uniform(0.5, 1.5, WID).astype(np.float32)
+        s2[::7] *= -1.0
+        h2 = (0.1 * rng.standard_normal(WID)).astype(np.float32)
+        w3 = bf(rng.standard_normal((COUT, WID)) / np.sqrt(WID))
+        s3 = rng.uniform(0.5, 1.5, COUT).astype(np.float32)
+        s3[::5] *= -1.0
+        h3 = (0.1 * rng.standard_normal(COUT)).astype(np.float32)
+        r = bf(rng.standard_normal((B, COUT, HW, HW)) * amp)
+        if not L.load().mv_bottleneck_tail_supported(HW, HW, WID, COUT, 1):
+            return {"ok": False, "err": "mv_bottleneck_tail_supported says no"}
+        t2 = np.stack([O.conv2d(t1[i], w2, None, 1, 1, 1, 1) for i in range(B)])
+        t2 = bf(O.relu(t2 * s2[None, :, None, None] + h2[None, :, None, None]))
+        yref = np.einsum("bchw,kc->bkhw", t2.astype(np.float64), w3.astype(np.float64))
+        yref = O.relu(yref * s3[None, :, None, None] + h3[None, :, None, None] + r)
+        w2k = np.ascontiguousarray(w2.transpose(0, 2, 3, 1))                                              # KRSC
+        w2f = w2k.reshape(WID // 32, 32, 9, WID // 16, 2, 8).transpose(0, 2, 3, 4, 1, 5)
+        w3f = w3.reshape(COUT // 256, 8, 32, WID // 16, 2, 8).transpose(0, 1, 3, 4, 2, 5)
+        d = {k: dev(v, "bf16") for k, v in dict(t1=t1.transpose(0, 2, 3, 1), w2f=w2f, w3f=w3f, r=r.transpose(0, 2, 3, 1)).items()}
+        f = {k: dev(v, "fp32") for k, v in dict(s2=s2, h2=h2, s3=s3, h3=h3).items()}
+        y = torch.full((B, HW, HW, COUT), -7.0, dtype=torch.bfloat16, device="cuda")
+        L.call("mv_bottleneck_tail_fwd", d["t1"].data_ptr(), d["w2f"].data_ptr(), f["s2"].data_ptr(), f["h2"].data_ptr(),
+               d["w3f"].data_ptr(), f["s3"].data_ptr(), f["h3"].data_ptr(), d["r"].data_ptr(), y.data_ptr(), B, HW, HW, WID, COUT, 1,
+               _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(y).transpose(0, 3, 1, 2), yref, TOL_BF16)
+        info["kernel"] = kern
+        return info
+    return run
+
+
 def dual_chain_case(M, seed=0):
     """mv_conv1x1_dual_chain_fwd: conv3 + BN and the downsample conv + BN as one GEMM over [t2 | x] (scales folded into
     the bf16 weight rows, as ops.conv1x1_dual_chain does), ReLU, then the next block's conv1 + BN + ReLU -- vs the oracle
@@ -1622,6 +1663,9 @@ def all_cases():
           ("dual/layer4_entry_s2_ragged", dual_case(86, 7, 7, 512, 1024, 2048, 2, seed=3)),
           ("dual/s1_64_64_K200_noact", dual_case(3, 37, 41, 64, 64, 200, 1, act=0, seed=4)),
           ("dual/s2_odd_input", dual_case(5, 31, 29, 192, 128, 320, 2, seed=5)),
+          ("bneck_tail/14x14_B1", bneck_tail_case(1, seed=11)),
+          ("bneck_tail/14x14_B5", bneck_tail_case(5, seed=12)),
+          ("bneck_tail/14x14_B3_big", bneck_tail_case(3, seed=13, big=True)),
           ("chain/dual_56x56_B4", dual_chain_case(4 * 56 * 56, seed=6)),
           ("chain/dual_ragged_many", dual_chain_case(29 * 56 * 56 + 13, seed=7)),
           ("chain/n128_56x56_B4", chain_case(4 * 56 * 56, seed=4, N2=128)),
