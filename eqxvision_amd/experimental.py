@@ -1,68 +1,82 @@
-"""`eqxvision.experimental.intermediate_layer_getter` (reference experimental.py:8-88): wrap chosen sub-modules so that a
-forward also returns their outputs.  Same contract: `get_target_layers(model)` returns the target layers (or, for an
-`nn.Sequential`, their indices); the returned module's call gives `(output, [intermediate activations in order])`; only the
-most recent call of a layer is kept.  On the device an intermediate is whatever the wrapped layer returns at the module
-boundary -- a fp32 torch tensor in the reference's logical layout ((C,H,W) per sample, batched under `vmap`)."""
+"""`eqxvision.experimental.intermediate_layer_getter` (reference experimental.py:35-88) -- public contract only:
+
+    getter = intermediate_layer_getter(model, get_target_layers)
+    out, feats = getter(x, key=key)          # feats: outputs of the target layers, in the order get_target_layers listed them
+
+`get_target_layers(model)` returns the target sub-modules (or, for an `nn.Sequential`, their indices); a layer that runs several
+times in one forward reports its LAST output.
+
+Own design (not the reference's per-layer closure classes): ONE `_Capture` frame per getter, shared by every copy of the tree
+(`tree_inference` shares non-field attributes), and ONE module type, `_Tap`, that forwards to the layer it stands in for and
+drops the result into its numbered slot of the frame.  A call of the getter opens a fresh frame, runs the model, and hands the
+slots back -- so nothing leaks from one call into the next and a layer that did not run reports `None` instead of a stale tensor.
+On the device a captured value is whatever the layer returns at the module boundary: under `vmap` a fp32 tensor in the
+reference's logical layout, (B, C, H, W) for a feature map."""
 from __future__ import annotations
 
-from typing import Any, Callable
+from typing import Callable, List, Sequence
 
 from . import nn
 from ._module import Module, tree_at
 from .nn import boundary
 
 
-class AuxData:
-    """A simple container for auxiliary data (reference experimental.py:8-20)."""
+class _Capture:
+    """Slots of the forward in flight.  Deliberately NOT a Module field: module copies share it by reference."""
 
-    def __init__(self):
-        self.data = None
+    __slots__ = ("slots",)
 
-    def update(self, x: Any):
-        self.data = x
+    def __init__(self, n: int):
+        self.slots: List = [None] * n
+
+    def open(self):
+        self.slots = [None] * len(self.slots)
+
+    def take(self) -> list:
+        return list(self.slots)
 
 
-def _make_intermediate_layer_wrapper():
-    aux = AuxData()
+class _Tap(Module):
+    """Stands where a target layer stood: same call signature, same result, plus a copy of the result in slot `slot`."""
+    inner: Module
+    slot: int
 
-    class IntermediateWrapper(Module):
-        layer: Module
+    def __init__(self, inner: Module, slot: int, frame: _Capture):
+        self.inner = inner
+        self.slot = slot
+        object.__setattr__(self, "_frame", frame)
 
-        def __init__(self, layer):
-            self.layer = layer
+    @boundary
+    def __call__(self, x, *, key=None):
+        y = self.inner(x, key=key)
+        self._frame.slots[self.slot] = y
+        return y
 
-        @boundary
-        def __call__(self, x, *, key=None):
-            out = self.layer(x, key=key)
-            aux.update(out)
-            return out
 
-    return aux, IntermediateWrapper
+class LayerGetter(Module):
+    model: Module
+    n_taps: int
+
+    def __init__(self, model: Module, frame: _Capture):
+        self.model = model
+        self.n_taps = len(frame.slots)
+        object.__setattr__(self, "_frame", frame)
+
+    def __call__(self, x, *, key=None):
+        self._frame.open()
+        out = self.model(x, key=key)
+        return out, self._frame.take()
+
+
+def _tap_sequential(seq: nn.Sequential, indices: Sequence[int], frame: _Capture) -> nn.Sequential:
+    order = {int(i): k for k, i in enumerate(indices)}           # layer index -> slot, in the caller's order
+    return nn.Sequential([_Tap(layer, order[i], frame) if i in order else layer for i, layer in enumerate(seq.layers)])
 
 
 def intermediate_layer_getter(model: Module, get_target_layers: Callable) -> Module:
-    target_layers = get_target_layers(model)
-    auxs, wrappers = zip(*[_make_intermediate_layer_wrapper() for _ in range(len(target_layers))])
+    targets = list(get_target_layers(model))
+    frame = _Capture(len(targets))
     if isinstance(model, nn.Sequential):
-        new_modules, updated = [], 0
-        for idx, module in enumerate(model.layers):
-            if idx in target_layers:
-                new_modules.append(wrappers[updated](module))
-                updated += 1
-            else:
-                new_modules.append(module)
-        model = nn.Sequential(new_modules)
-    else:
-        model = tree_at(get_target_layers, model, [w(t) for w, t in zip(wrappers, target_layers)])
-
-    class IntermediateLayerGetter(Module):
-        model: Module
-
-        def __init__(self, model):
-            self.model = model
-
-        def __call__(self, x, *, key=None):
-            out = self.model(x, key=key)
-            return out, [aux.data for aux in auxs]
-
-    return IntermediateLayerGetter(model)
+        return LayerGetter(_tap_sequential(model, targets, frame), frame)
+    taps = [_Tap(layer, k, frame) for k, layer in enumerate(targets)]
+    return LayerGetter(tree_at(get_target_layers, model, taps), frame)

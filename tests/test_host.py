@@ -163,7 +163,7 @@ def test_segmentation_constructors_and_checkpoint_order():
     for kind, build in (("fcn", eqv.models.fcn), ("deeplabv3", eqv.models.deeplabv3)):
         net = build(num_classes=5, backbone=small(), intermediate_layers=two, aux_in_channels=1024)
         assert isinstance(net.backbone.model.fc, nn.Identity)                                # silenced head holds no weights
-        assert type(net.backbone.model.layer4).__name__ == "IntermediateWrapper"
+        assert type(net.backbone.model.layer4).__name__ == "_Tap"
         mine = eqv.utils.state_dict(eqv.utils.randomize_batchnorm(net))
         sd = S.segmentation_state(1, kind, (1, 1, 1, 1), 5)
         want = [np.asarray(sd[k]).size for k in _keys(sd)]
@@ -171,7 +171,7 @@ def test_segmentation_constructors_and_checkpoint_order():
         with pytest.raises(RuntimeError, match="PRNGKey"):
             net(np.zeros((3, 64, 64), np.float32), key=None)
     assert eqv.utils.SEGMENTATION_URLS["fcn_resnet50"].endswith("fcn_resnet50_coco-1167a1af.pth")
-    layer4 = eqv.models.deeplabv3(backbone=small(), intermediate_layers=two).backbone.model.layer4.layer
+    layer4 = eqv.models.deeplabv3(backbone=small(), intermediate_layers=two).backbone.model.layer4.inner
     assert layer4.layers[0].conv2.dilation == (2, 2) and layer4.layers[0].conv2.stride == (1, 1)
 
 
@@ -363,10 +363,12 @@ def test_intermediate_layer_getter_structure():
     from eqxvision_amd.experimental import intermediate_layer_getter
     seq = nn.Sequential([nn.Conv2d(3, 4, 1), nn.Lambda(nn.relu), nn.Conv2d(4, 2, 1)])
     g = intermediate_layer_getter(seq, lambda m: [1])
-    assert type(g.model.layers[1]).__name__ == "IntermediateWrapper" and g.model.layers[0] is seq.layers[0]
+    assert type(g.model.layers[1]).__name__ == "_Tap" and g.model.layers[0] is seq.layers[0]
     r = eqv.models.resnet18()
     g = intermediate_layer_getter(r, lambda m: [m.layer2, m.layer4])
-    assert type(g.model.layer2).__name__ == "IntermediateWrapper" and g.model.layer2.layer is r.layer2
+    assert type(g.model.layer2).__name__ == "_Tap" and g.model.layer2.inner is r.layer2 and g.model.layer4.slot == 1
+    g2 = eqv.tree_inference(g, True)                       # copies of the tree report into the same frame
+    assert g2.model.layer2._frame is g.model.layer2._frame and g2._frame is g._frame
     assert g.model.layer1.layers[0].conv1.weight is r.layer1.layers[0].conv1.weight      # leaves are shared
 
 

@@ -63,3 +63,32 @@ for B in [int(a) for a in sys.argv[1:]] or [128, 256]:
             d = w[:, :, i + 1] - w[:, :, i]
             dc = (c[:, :, i + 1] - c[:, :, i]) & 0xffffffff
             print(f"    {nm:18s} {d.mean():7.2f} ({d.min():6.2f} .. {d.max():6.2f})   cycles {dc.mean():9.0f}  -> {dc.mean() / max(d.mean(), 1e-9) / 1e3:.2f} GHz")
+
+if os.environ.get("BNECK_2STREAM"):
+    # two half-batches on two streams, free-running: in phase (both start together) and offset by roughly half a launch
+    B = 128
+    def mk():
+        t1, r = bf(B, HW, HW, WID).relu(), bf(B, HW, HW, COUT)
+        y = torch.empty(B, HW, HW, COUT, device="cuda", dtype=torch.bfloat16)
+        return t1, r, y
+    bufs = [mk(), mk()]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    def go(i, n):
+        t1, r, y = bufs[i]
+        st = streams[i].cuda_stream
+        for _ in range(n):
+            L.call("mv_bottleneck_tail_fwd", t1.data_ptr(), w2f.data_ptr(), s2.data_ptr(), h2.data_ptr(), w3f.data_ptr(), s3.data_ptr(),
+                   h3.data_ptr(), r.data_ptr(), y.data_ptr(), B, HW, HW, WID, COUT, 1, st)
+    for off in (0, 32, 64):
+        go(0, 3); go(1, 3); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        n = 40
+        e0.record(streams[0]); streams[1].wait_event(e0)
+        if off:
+            t1, r, y = bufs[1]
+            L.call("mv_bottleneck_tail_fwd", t1.data_ptr(), w2f.data_ptr(), s2.data_ptr(), h2.data_ptr(), w3f.data_ptr(), s3.data_ptr(),
+                   h3.data_ptr(), r.data_ptr(), y.data_ptr(), off, HW, HW, WID, COUT, 1, streams[1].cuda_stream)
+        go(0, n); go(1, n)
+        d = torch.cuda.Event(); d.record(streams[1]); streams[0].wait_event(d); e1.record(streams[0]); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        print(f"two streams x B=128, offset launch of {off} images: {us:.1f} us per pair (256 images)  {fl*0+2.0*256*HW*HW*WID*(9*WID+COUT)/us/1e6:.0f} TFLOP/s")
