@@ -34,6 +34,7 @@ struct BneckP {
     const float* h3;
     const bf16_t* res;    // [B][HW][HW][COUT]
     bf16_t* y;
+    int skew;             // conv3: waves 4-7 start `skew` x 512 cycles late (0 = in phase)
     long long* prof;      // experiments only (tools/time_bneck.py --prof): per-wave wall-clock / shader-clock stamps at the phase boundaries
 };
 
@@ -132,22 +133,23 @@ __global__ __launch_bounds__(512) void bneck_tail_kernel(const BneckP p) {
             const int tapn = tap < 8 ? tap + 1 : 8;
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
-                // one k16-step: the NEXT step's position fragments and the weight fragment D2 steps ahead are issued first,
-                // then the 7 MFMAs of this step run back to back (the schedule is pinned: left alone, hipcc pairs every
-                // ds_read with a wait + its MFMA and batches the weight loads four at a time)
+                // one k16-step: the weight fragment D2 steps ahead is requested, then the 7 MFMAs of this step, each followed by the
+                // read of the NEXT step's fragment of the same position block (pinned pairs: left alone, hipcc pairs every ds_read
+                // with a wait + its MFMA and batches the weight loads four at a time; all 7 reads up front make the 8 waves hit
+                // the LDS in bursts while the matrix pipe idles)
                 const char* q = (j == KS - 1) ? bptr2(tapn, 0) : bptr2(tap, j + 1);
                 int nxt = tap * KS + j + D2;
                 nxt = nxt < NSTEP2 ? nxt : NSTEP2 - 1;
                 const uint4* an = ap2 + (size_t)nxt * 64;
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int b = 0; b < NB; ++b) bn[b] = *(const bf16x8*)(q + b * 32 * ROWB);
                 const bf16x8 af = __builtin_bit_cast(bf16x8, a2[j % D2]);
                 a2[j % D2] = *an;
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bc[b], acc[b], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int b = 0; b < NB; ++b) {
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bc[b], acc[b], 0, 0, 0);
+                    bn[b] = *(const bf16x8*)(q + b * 32 * ROWB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int b = 0; b < NB; ++b) bc[b] = bn[b];
             }
@@ -196,31 +198,43 @@ __global__ __launch_bounds__(512) void bneck_tail_kernel(const BneckP p) {
     MV_BT_STAMP(3);
 
     // ---------------- conv3: 1x1 expansion, per 256-channel chunk and position half ------------------------------
+    // Order of a wave's memory requests (they complete in order): the weight fragments run D3 = 8 steps ahead of their use,
+    // straight through the half boundaries; the residual rows of half h+1 are requested DURING the epilogue of half h, block
+    // by block into the registers that block's epilogue has just released -- so they are younger than the 8 fragments the next
+    // main loop starts on and have an epilogue plus 8 k-steps to arrive before a fragment queued behind them is needed.
     char* ep = smem + T2B + wave * (32 * EPITCH);
     const int er = lane >> 2, ec = lane & 3;
     const bf16_t* resi = p.res + (size_t)img * NPIX * COUT;
     bf16_t* yi = p.y + (size_t)img * NPIX * COUT;
     const int lb3 = fr * ROWB;
     const int sw3 = fr & 15;
+    constexpr int NBA = (NB + 1) / 2, NBB = NB / 2;          // blocks of the two halves: 4 + 3
 
-    auto do_half = [&](auto b0c, auto nbc, int cn, int t0, const float4& sca, const float4& scb, const float4& sha,
-                       const float4& shb) {
-        constexpr int B0 = decltype(b0c)::value, NBH = decltype(nbc)::value;
+    uint4 rr[NBA][2];                                        // residual rows of the half whose epilogue comes next
+    auto pix_of = [&](int blk, int ps) -> int {              // image pixel of this lane's row in pass ps of position block blk
+        int o = 32 * blk + 16 * ps + er;
+        asm volatile("" : "+v"(o));                          // recomputed where used: hoisted, the 14 row addresses spill
+        const int oy = o >> 4, ox = o & 15;
+        return ox < HW ? oy * HW + ox : -1;
+    };
+    auto fetch_res = [&](int slot, int blk, int cn) {
         const int n = cn * 256 + wave * 32 + ec * 8;
-        // residual rows of this half, row-major (16 positions x 64 bytes per instruction)
-        uint4 rr[NBH][2];
-        int pixs[NBH][2];
 #pragma unroll
-        for (int b = 0; b < NBH; ++b)
+        for (int ps = 0; ps < 2; ++ps) {
+            const int pix = pix_of(blk, ps);
+            rr[slot][ps] = *(const uint4*)(resi + (size_t)(pix < 0 ? 0 : pix) * COUT + n);
+        }
+    };
 #pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                int o = 32 * (B0 + b) + 16 * ps + er;
-                asm volatile("" : "+v"(o));      // recomputed per chunk: hoisted out of the chunk loop, the 14 row addresses spill
-                const int oy = o >> 4, ox = o & 15;
-                const int pix = ox < HW ? oy * HW + ox : -1;
-                pixs[b][ps] = pix;
-                rr[b][ps] = *(const uint4*)(resi + (size_t)(pix < 0 ? 0 : pix) * COUT + n);
-            }
+    for (int b = 0; b < NBA; ++b) fetch_res(b, b, 0);        // half (chunk 0, A)
+    if (p.skew > 0 && wave >= 4)                             // the second wave of every SIMD starts half a period late: one in
+        for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(8);     // its main loop while the other is in its epilogue
+
+    auto do_half = [&](auto b0c, auto nbc, auto b0n, auto nbn, int cn, int cn_next, int t0, const float4& sca, const float4& scb,
+                       const float4& sha, const float4& shb) {
+        constexpr int B0 = decltype(b0c)::value, NBH = decltype(nbc)::value;
+        constexpr int B0N = decltype(b0n)::value, NBN = decltype(nbn)::value;      // the half that follows (cn_next < 0: none)
+        const int n = cn * 256 + wave * 32 + ec * 8;
         f32x16 c3[NBH];
 #pragma unroll
         for (int b = 0; b < NBH; ++b)
@@ -236,16 +250,21 @@ __global__ __launch_bounds__(512) void bneck_tail_kernel(const BneckP p) {
             const uint4* an = ap3 + aidx3(t0 + j + D3);
             const char* qn = q0 + (((2 * jn + fh) ^ sw3) << 4);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int b = 0; b < NBH; ++b) bn[b] = *(const bf16x8*)(qn + b * 32 * ROWB);
             const bf16x8 af = __builtin_bit_cast(bf16x8, a3[j % D3]);
             a3[j % D3] = *an;
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int b = 0; b < NBH; ++b) c3[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bc[b], c3[b], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int b = 0; b < NBH; ++b) {
+                c3[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bc[b], c3[b], 0, 0, 0);
+                bn[b] = *(const bf16x8*)(qn + b * 32 * ROWB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int b = 0; b < NBH; ++b) bc[b] = bn[b];
+        }
+        // residual slots the next half uses and this epilogue does not: requested right away
+        if (cn_next >= 0) {
+#pragma unroll
+            for (int b = NBH; b < NBN; ++b) fetch_res(b, B0N + b, cn_next);
         }
         // epilogue: transpose through the wave's patch, BN + identity + ReLU, 16-byte stores
 #pragma unroll
@@ -273,9 +292,11 @@ __global__ __launch_bounds__(512) void bneck_tail_kernel(const BneckP p) {
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                if (pixs[b][ps] >= 0) Out8<bf16_t>::st(yi + (size_t)pixs[b][ps] * COUT + n, v);
+                const int pix = pix_of(B0 + b, ps);
+                if (pix >= 0) Out8<bf16_t>::st(yi + (size_t)pix * COUT + n, v);
             }
             wave_lds_fence();
+            if (cn_next >= 0 && b < NBN) fetch_res(b, B0N + b, cn_next);     // this block's registers are free again
         }
     };
 
@@ -283,8 +304,8 @@ __global__ __launch_bounds__(512) void bneck_tail_kernel(const BneckP p) {
         const int n = cn * 256 + wave * 32 + ec * 8;
         const float4 sca = *(const float4*)(p.s3 + n), scb = *(const float4*)(p.s3 + n + 4);
         const float4 sha = *(const float4*)(p.h3 + n), shb = *(const float4*)(p.h3 + n + 4);
-        do_half(IC<0>{}, IC<(NB + 1) / 2>{}, cn, (2 * cn) * KS, sca, scb, sha, shb);
-        do_half(IC<(NB + 1) / 2>{}, IC<NB / 2>{}, cn, (2 * cn + 1) * KS, sca, scb, sha, shb);
+        do_half(IC<0>{}, IC<NBA>{}, IC<NBA>{}, IC<NBB>{}, cn, cn, (2 * cn) * KS, sca, scb, sha, shb);
+        do_half(IC<NBA>{}, IC<NBB>{}, IC<0>{}, IC<NBA>{}, cn, cn + 1 < NCHUNK ? cn + 1 : -1, (2 * cn + 1) * KS, sca, scb, sha, shb);
         if (cn == 0) MV_BT_STAMP(4);
     }
     MV_BT_STAMP(5);
@@ -323,6 +344,7 @@ int mv_bottleneck_tail_fwd(const void* t1, const void* w2f, const float* scale2,
     BneckP p;
     p.t1 = (const bf16_t*)t1; p.w2f = (const bf16_t*)w2f; p.s2 = scale2; p.h2 = shift2;
     p.w3f = (const bf16_t*)w3f; p.s3 = scale3; p.h3 = shift3; p.res = (const bf16_t*)residual; p.y = (bf16_t*)y;
+    p.skew = get_flag("bneck_skew");
     p.prof = get_flag("bneck_prof") ? (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo")) : nullptr;
     constexpr int SMEM = 7 * 32 * 512 + 8 * 32 * 144;        // t2 + the 8 epilogue patches (>= the zero-bordered t1 map)
     static_assert(SMEM >= (7 * 32 + 34) * 512, "t1 map must fit");
