@@ -39,7 +39,19 @@ class StateIndex:
     @value.setter
     def value(self, v):
         self._value = v
-        self._dev, self._dev_newer = None, False
+        if self._dev is not None and v is not None:
+            # a recorded training-mode step has the ADDRESSES of the device copy baked in (transforms: 'state-rw' signature):
+            # refresh those tensors in place instead of dropping them, or the replay would keep updating the old statistics and
+            # its hook would hand them back over the values set here (round-2 advice)
+            try:
+                import torch
+                for t, a in zip(self._dev, v):
+                    t.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(a, np.float32)).reshape(tuple(t.shape))))
+            except Exception:
+                self._dev = None
+        else:
+            self._dev = None
+        self._dev_newer = False
         self.version += 1
 
     def device_updated(self, tensors):

@@ -55,16 +55,19 @@ class MlpProjection(Module):
             return ops.linear(h, self.fc2, residual=residual)
         if keys is None:
             raise RuntimeError("Dropout requires a key when running in non-deterministic mode.")
-        hwc = h.kind == "map"            # a map reaches an MLP through Linear2d layers: channels-last (H, W, C) in the reference
-        if h.kind not in ("seq", "vec") and not (hwc and type(self.fc1).__name__ == "Linear2d"):
+        # A map reaches an MLP through Linear2d layers (Swin, swin.py:562-570).  Linear2d hands back `(out_features, h, w)`
+        # (extensions_2d.py:46-50), so eqx.nn.Dropout draws its mask for a (C, H, W) array: word c * H * W + hw of the sample's
+        # stream decides element (c, hw) -- the same logical index every other feature map uses (round-2 advice: the (H, W, C)
+        # order used here before dropped different elements than the reference for the same key).
+        if h.kind not in ("seq", "vec") and not (h.kind == "map" and type(self.fc1).__name__ == "Linear2d"):
             raise NotImplementedError(f"MlpProjection: training-mode Dropout on a {h.kind} input is not built")
         ks = ops.split_keys(keys, 2)
         per_row = per_row and h.kind == "seq"
         if nn.dropout_live(self.drop1):
-            h = ops.dropout(h, self.drop1.p, ks[0], per_row=per_row, hwc=hwc)
+            h = ops.dropout(h, self.drop1.p, ks[0], per_row=per_row)
         y = ops.linear(h, self.fc2)
         if nn.dropout_live(self.drop2):
-            y = ops.dropout(y, self.drop2.p, ks[1], per_row=per_row, hwc=hwc)
+            y = ops.dropout(y, self.drop2.p, ks[1], per_row=per_row)
         return y if residual is None else ops.add(residual, y)
 
     @boundary

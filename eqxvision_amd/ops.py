@@ -1094,11 +1094,11 @@ def token_keys(key, B: int, N: int) -> torch.Tensor:
     return out
 
 
-def dropout(x: Act, p: float, key, per_row: bool = False, hwc: bool = False) -> Act:
+def dropout(x: Act, p: float, key, per_row: bool = False) -> Act:
     """eqx.nn.Dropout's training branch: where(bernoulli(key, 1 - p, x.shape), x / (1 - p), 0) per sample, the mask from the
     sample's key in JAX's bit stream (generated on the device, rng.hip).  `per_row`: x is (tokens, features) rows and `key`
-    holds one key per ROW (uint32 [B*N, 2], `token_keys`): the reference vmaps the layer over the tokens.  `hwc`: a map whose
-    reference-side array is channels-LAST (H, W, C) (Swin's Linear2d layers), not (C, H, W)."""
+    holds one key per ROW (uint32 [B*N, 2], `token_keys`): the reference vmaps the layer over the tokens.  A map is always the
+    reference's (C, H, W) array (also behind Swin's Linear2d layers, extensions_2d.py:46-50): the kernel maps NHWC positions to it."""
     if x.kind == "img":
         x = as_map(x)
     B = x.t.shape[0]
@@ -1110,7 +1110,7 @@ def dropout(x: Act, p: float, key, per_row: bool = False, hwc: bool = False) -> 
     keys = _keys_dev(key, B)
     per = x.t.numel() // B
     y = empty(tuple(x.t.shape), x.t.dtype)
-    _lib.call("mv_dropout_fwd", _ptr(x.t), _ptr(keys), _ptr(y), B, per, C, 1 if x.kind == "map" and not hwc else 0,
+    _lib.call("mv_dropout_fwd", _ptr(x.t), _ptr(keys), _ptr(y), B, per, C, 1 if x.kind == "map" else 0,
               float(1.0 - p), x.dt, stream_ptr())
     return Act(y, x.kind, x.batched)
 

@@ -41,7 +41,18 @@ def _rebuild_tensor_v2(storage, storage_offset, size, stride, requires_grad=Fals
         base = (np.frombuffer(storage.raw, dtype="<u2").astype(np.uint32) << 16).view(np.float32)
     else:
         base = np.frombuffer(storage.raw, dtype=np.dtype(storage.dtype).newbyteorder("<"))
-    size, stride = tuple(size), tuple(stride)
+    size, stride = tuple(int(v) for v in size), tuple(int(v) for v in stride)
+    storage_offset = int(storage_offset)
+    # the view must stay inside the storage: offset, sizes and strides come from the (untrusted) pickle, and as_strided checks nothing
+    if len(size) != len(stride) or storage_offset < 0 or any(v < 0 for v in size) or any(v < 0 for v in stride):
+        raise pickle.UnpicklingError(f"tensor view with offset {storage_offset}, size {size}, stride {stride} is not a plain forward view")
+    if all(v > 0 for v in size):
+        last = storage_offset + sum((n - 1) * st for n, st in zip(size, stride))
+        if last >= base.size:
+            raise pickle.UnpicklingError(f"tensor view (offset {storage_offset}, size {size}, stride {stride}) reaches element {last} of a "
+                                         f"{base.size}-element storage")
+    else:
+        return np.zeros(size, dtype=base.dtype)
     if len(size) == 0:
         return np.array(base[storage_offset])
     item = base.itemsize

@@ -90,15 +90,16 @@ def load_torch_weights(model: Module, torch_weights: Optional[str] = None) -> Mo
     if torch_weights is None:
         raise ValueError("torch_weights parameter cannot be empty!")
     path = _resolve(torch_weights)
-    try:                                   # own zip + pickle reader: no torch needed to ingest a checkpoint (eqxvision_amd/pth.py)
-        from .pth import load_state_dict
+    import zipfile
+    if zipfile.is_zipfile(path):           # own zip + restricted-pickle reader: no torch needed, nothing in the file is executed
+        from .pth import load_state_dict   # (eqxvision_amd/pth.py); its errors are final -- no fallback to an unrestricted loader
         saved = load_state_dict(path)
-    except ValueError:                     # legacy (pre-1.6) container: torch's own loader, if torch is there
+    else:                                  # legacy (pre-1.6, non-zip) container: torch's own loader, tensors only
         try:
             import torch
         except ImportError as e:  # pragma: no cover
             raise RuntimeError(" Torch package not found! Legacy-format checkpoints need the torch package.") from e
-        saved = torch.load(path, map_location="cpu")
+        saved = torch.load(path, map_location="cpu", weights_only=True)
     params, stats = [], []
     for name, w in saved.items():
         arr = w.detach().cpu().numpy() if hasattr(w, "detach") else np.asarray(w)

@@ -474,12 +474,12 @@ def swin_block(sd, q, x, p, num_heads, window, shift, sd_prob=0.0, key=None, dro
     y = q(O.layernorm2d(x, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"]))
     h = q(O.gelu_tanh(O.linear2d(y, q(sd[p + ".mlp.0.weight"]), sd[p + ".mlp.0.bias"])))
     mk = O.jax_split(ks[2], 2) if ks is not None and training and dropout > 0.0 else None
-    hwc = lambda a, f: np.transpose(f(np.transpose(a, (1, 2, 0))), (2, 0, 1))      # the reference's arrays are (H, W, C) here
+    # Linear2d returns (out_features, h, w) (extensions_2d.py:46-50): eqx.nn.Dropout sees (C, H, W) arrays here
     if mk is not None:
-        h = q(hwc(h, lambda a: O.dropout(a, dropout, mk[0])))
+        h = q(O.dropout(h, dropout, mk[0]))
     y = O.linear2d(h, q(sd[p + ".mlp.3.weight"]), sd[p + ".mlp.3.bias"])
     if mk is not None:
-        y = hwc(q(y), lambda a: O.dropout(a, dropout, mk[1]))
+        y = O.dropout(q(y), dropout, mk[1])
     if ks is not None and training and sd_prob > 0.0:
         y = O.drop_path(q(y), sd_prob, "local", ks[3])
     return q(x + y)

@@ -423,3 +423,16 @@ def test_stochastic_layers_need_keys_and_inference_is_identity():
     vit = eqv.models.VisionTransformer(img_size=16, patch_size=8, embed_dim=32, depth=1, num_heads=1, num_classes=3, attn_drop_rate=0.1)
     assert _needs_eager(vit) and not _needs_eager(eqv.tree_inference(vit, True))
 
+
+
+def test_pth_reader_rejects_views_outside_the_storage():
+    """a checkpoint's (offset, size, stride) triple is untrusted: views that leave the storage must not reach as_strided"""
+    import pickle
+    from eqxvision_amd import pth
+    st = pth._Storage("<f4", np.arange(12, dtype=np.float32).tobytes())
+    ok = pth._rebuild_tensor_v2(st, 2, (2, 3), (3, 1))
+    np.testing.assert_array_equal(ok, np.arange(2, 8, dtype=np.float32).reshape(2, 3))
+    assert pth._rebuild_tensor_v2(st, 0, (0, 4), (4, 1)).shape == (0, 4)
+    for off, size, stride in ((0, (4, 4), (4, 1)), (11, (2,), (1,)), (-1, (2,), (1,)), (0, (2, 2), (-1, 1)), (0, (3,), (1000,))):
+        with pytest.raises(pickle.UnpicklingError):
+            pth._rebuild_tensor_v2(st, off, size, stride)
