@@ -11,9 +11,15 @@ already resident in HBM.  W untimed warm-up steps, then exactly K timed steps br
 barrier + synchronize; MAX over ranks; rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     algorithmic FLOPs of one forward launch (8.178 GFLOP/img resnet50,
-               35.13 GFLOP/img vit_base) / the launch's average duration measured with HIP events on the
-               launch stream over the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s).
+  roofline     the dominant kernel = the GEMM-type kernel family with the largest summed duration in one forward.
+               `achieved` = its algorithmic FLOPs per launch (2 x MACs, `flop_per_launch`) / its average launch duration
+               (`avg_launch_us`) measured IN SITU with HIP events on the stream each launch runs on (an eager replay of the
+               lanes' launch lists on their own streams, right after the timed region) -- the duration rocprofv3's kernel
+               trace of this command reports for the same kernel (profiles/r03/<model>_rocprofv3_warm_stats.txt);
+               `frac` = achieved / 2.5 PFLOP/s (dense bf16 MFMA peak).  `lanes1`: the same model as ONE launch list (lanes
+               overlap in time, so only there does the sum over the dominant kernel's launches compare with a step);
+               `isolated` (with --layers): every launch alone on the chip.  `whole_forward`: SURVEY section 8d's FLOPs per
+               image x batch / the step (`frac`), algorithmic HBM bytes / the step / 8 TB/s (`hbm_frac`).
   cpu_baseline the CPU restatement (oracle/torch_ref.py, fp32, all host cores -- NOT JAX, which is not
                installed) timed on a bounded sample of the same workload, rank 0 at N=1 only.
 `--layers FILE` additionally replays the recorded launch list kernel by kernel with HIP events and
@@ -80,8 +86,117 @@ def _ev():
     return e
 
 
+def launch_meta(name, args):
+    """(algorithmic FLOPs, algorithmic HBM bytes, shape string) of one recorded C-ABI call: 2 x MACs of the contraction, and the
+    bytes the launch has to move at least once (operands + result + residual; fp32 tensors at 4 bytes)."""
+    flops = byts = 0.0
+    shape = ""
+    ob = lambda dt: 4.0 if dt == 0 else 2.0                   # bytes per element of an MV_F32 / MV_BF16 tensor
+    if name == "mv_conv2d_nhwc_fwd":
+        N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, g = args[6:20]
+        idt, odt = args[21], args[22]
+        Ho = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1
+        Wo = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
+        flops = 2.0 * N * Ho * Wo * K * R * S * C / g
+        byts = ob(idt) * (N * H * W * C + K * R * S * C / g) + ob(odt) * N * Ho * Wo * K * (2 if args[4] else 1)
+        shape = f"N{N} {H}x{W}x{C}->{Ho}x{Wo}x{K} k{R}s{sh}"
+    elif name == "mv_dwconv2d_nhwc_fwd":
+        N, H, W, C, R, S, sh, sw, ph, pw, dh, dw = args[5:17]
+        Ho = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1
+        Wo = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
+        flops = 2.0 * N * Ho * Wo * C * R * S
+        byts = 2.0 * N * C * (H * W + Ho * Wo)
+        shape = f"N{N} {H}x{W}x{C} dw k{R}s{sh}"
+    elif name == "mv_conv2d_nhwc_grouped64_fwd":
+        N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, g = args[6:20]
+        Ho = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1
+        Wo = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
+        flops = 2.0 * N * Ho * Wo * K * R * S * C / g                  # the grouped convolution's own FLOPs (not the padded tile's)
+        byts = 2.0 * (N * H * W * C + K * R * S * 64 + N * Ho * Wo * K)
+        shape = f"N{N} {H}x{W}x{C}->{Ho}x{Wo}x{K} k{R}s{sh} g{g}"
+    elif name in ("mv_linear_fwd", "mv_linear_split_fwd"):
+        M, N, K = args[6:9]
+        idt, odt = args[10], args[11]
+        split = 2 if name == "mv_linear_split_fwd" else 1
+        flops = 2.0 * M * N * K * split
+        byts = ob(idt) * (M * K + split * N * K) + ob(odt) * M * N * (2 if args[4] else 1)
+        shape = f"M{M} K{K} N{N}" + (" f32out" if odt == 0 else "") + (" +res" if args[4] else "") + (" hi+lo" if split == 2 else "")
+    elif name == "mv_ln_linear_fwd":
+        M, N, K = args[4:7]
+        flops = 2.0 * M * N * K
+        byts = ob(args[9]) * M * K + 2.0 * N * K + 2.0 * M * N
+        shape = f"M{M} K{K} N{N} LN-in" + (" f32in" if args[9] == 0 else "")
+    elif name == "mv_ln_mlp_fwd":
+        M, C, Hd = args[6:9]
+        flops = 4.0 * M * C * Hd
+        byts = 2.0 * ob(args[10]) * M * C + 4.0 * C * Hd
+        shape = f"M{M} C{C} hidden{Hd} LN+MLP+res"
+    elif name == "mv_linear_heads_fwd":
+        M, N, K = args[5:8]
+        flops = 2.0 * M * N * K
+        byts = 2.0 * (M * K + N * K + M * N)
+        shape = f"M{M} K{K} N{N} head-major"
+    elif name == "mv_conv1x1_dual_fwd":
+        N, Ho, Wo, C1, H2, W2, C2, s2, K = args[6:15]
+        M = N * Ho * Wo
+        flops = 2.0 * M * K * (C1 + C2)
+        byts = 2.0 * (M * C1 + M * C2 + K * (C1 + C2) + M * K)
+        shape = f"M{M} {C1}+{C2}(s{s2})->{K}"
+    elif name == "mv_bottleneck_tail_fwd":
+        B_, H, W, wid, cout = args[9:14]
+        M = B_ * H * W
+        flops = 2.0 * M * wid * (9 * wid + cout)
+        byts = 2.0 * (M * (wid + 2 * cout) + 9 * wid * wid + wid * cout)
+        shape = f"N{B_} {H}x{W}x{wid} 3x3->{wid}->1x1->{cout}(+res)"
+    elif name == "mv_conv1x1_chain_fwd":
+        M, C, K, N2 = args[10:14]
+        flops = 2.0 * M * (C * K + K * N2)
+        byts = 2.0 * M * (C + 2 * K + N2)
+        shape = f"M{M} {C}->{K}(+res)->{N2}"
+    elif name == "mv_conv1x1_dual_chain_fwd":
+        M, C1, C2, K, N2 = args[10:15]
+        flops = 2.0 * M * ((C1 + C2) * K + K * N2)
+        byts = 2.0 * M * (C1 + C2 + K + N2)
+        shape = f"M{M} {C1}+{C2}->{K}->{N2}"
+    elif name == "mv_stem_conv_pool_fwd":
+        N, C, H, W, K, R, S, sh, sw, ph, pw, pk, ps, pp = args[5:19]
+        Ho, Wo = (H + 2 * ph - R) // sh + 1, (W + 2 * pw - S) // sw + 1
+        Po, Qo = (Ho + 2 * pp - pk) // ps + 1, (Wo + 2 * pp - pk) // ps + 1
+        flops = 2.0 * N * Ho * Wo * K * R * S * C
+        byts = ob(args[20]) * N * C * H * W + 2.0 * N * Po * Qo * K
+        shape = f"N{N} {C}x{H}x{W}->conv{Ho}x{Wo}->pool{Po}x{Qo}x{K}"
+    elif name in ("mv_conv2d_nchw_fwd", "mv_conv2d_nchw_split_fwd"):
+        o = 1 if name.endswith("split_fwd") else 0
+        N, C, H, W, K, R, S, sh, sw, ph, pw = args[5 + o:16 + o]
+        Ho = (H + 2 * ph - R) // sh + 1
+        Wo = (W + 2 * pw - S) // sw + 1
+        flops = 2.0 * N * Ho * Wo * K * R * S * C * (1 + o)
+        byts = 4.0 * N * C * H * W + 2.0 * N * Ho * Wo * K
+        shape = f"N{N} {C}x{H}x{W}->{Ho}x{Wo}x{K} k{R}s{sh}" + (" hi+lo" if o else "")
+    elif name in ("mv_mha_fwd", "mv_mha_heads_fwd"):
+        B, N, H, dh = args[3:7]
+        flops = 4.0 * B * H * N * N * dh
+        byts = 2.0 * B * N * H * dh * 4
+        shape = f"B{B} N{N} H{H} dh{dh}"
+    elif name == "mv_swin_window_attn_fwd":
+        B, Hf, Wf, C, heads, wh, ww = args[3:10]
+        flops = 4.0 * B * Hf * Wf * (wh * ww) * C
+        byts = 2.0 * B * Hf * Wf * C * 4
+        shape = f"B{B} {Hf}x{Wf}x{C} h{heads} w{wh}"
+    elif name == "mv_maxpool2d_nhwc_fwd":
+        N, H, W, C, kh, kw, sh, sw, ph, pw = args[2:12]
+        Ho = (H + 2 * ph - kh) // sh + 1
+        byts = 2.0 * N * C * (H * W + Ho * Ho)
+        shape = f"N{N} {H}x{W}x{C}"
+    elif name == "mv_layernorm_fwd":
+        M, C = args[4:6]
+        byts = float(M) * C * (ob(args[8]) + ob(args[9]))
+        shape = f"M{M} C{C}"
+    return flops, byts, shape
+
+
 def layer_table(compiled, path, steps=5):
-    """Replay the recorded launch list call by call with HIP events -> per-launch worksheet."""
+    """Replay the recorded launch list call by call with HIP events -> per-launch worksheet (every launch ALONE on the chip)."""
     from eqxvision_amd import _lib
     from eqxvision_amd._act import stream_ptr
     s = stream_ptr()
@@ -99,103 +214,7 @@ def layer_table(compiled, path, steps=5):
             _lib.call("mv_event_elapsed_ms", e0, e1, ctypes.byref(ms))
             ts.append(ms.value)
         us = 1e3 * float(np.median(ts))
-        flops = byts = 0.0
-        shape = ""
-        ob = lambda dt: 4.0 if dt == 0 else 2.0                   # bytes per element of an MV_F32 / MV_BF16 tensor
-        if name == "mv_conv2d_nhwc_fwd":
-            N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, g = args[6:20]
-            idt, odt = args[21], args[22]
-            Ho = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1
-            Wo = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
-            flops = 2.0 * N * Ho * Wo * K * R * S * C / g
-            byts = ob(idt) * (N * H * W * C + K * R * S * C / g) + ob(odt) * N * Ho * Wo * K * (2 if args[4] else 1)
-            shape = f"N{N} {H}x{W}x{C}->{Ho}x{Wo}x{K} k{R}s{sh}"
-        elif name == "mv_dwconv2d_nhwc_fwd":
-            N, H, W, C, R, S, sh, sw, ph, pw, dh, dw = args[5:17]
-            Ho = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1
-            Wo = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
-            flops = 2.0 * N * Ho * Wo * C * R * S
-            byts = 2.0 * N * C * (H * W + Ho * Wo)
-            shape = f"N{N} {H}x{W}x{C} dw k{R}s{sh}"
-        elif name == "mv_conv2d_nhwc_grouped64_fwd":
-            N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, g = args[6:20]
-            Ho = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1
-            Wo = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
-            flops = 2.0 * N * Ho * Wo * K * R * S * C / g                  # the grouped convolution's own FLOPs (not the padded tile's)
-            byts = 2.0 * (N * H * W * C + K * R * S * 64 + N * Ho * Wo * K)
-            shape = f"N{N} {H}x{W}x{C}->{Ho}x{Wo}x{K} k{R}s{sh} g{g}"
-        elif name in ("mv_linear_fwd", "mv_linear_split_fwd"):
-            M, N, K = args[6:9]
-            idt, odt = args[10], args[11]
-            split = 2 if name == "mv_linear_split_fwd" else 1
-            flops = 2.0 * M * N * K * split
-            byts = ob(idt) * (M * K + split * N * K) + ob(odt) * M * N * (2 if args[4] else 1)
-            shape = f"M{M} K{K} N{N}" + (" f32out" if odt == 0 else "") + (" +res" if args[4] else "") + (" hi+lo" if split == 2 else "")
-        elif name == "mv_ln_linear_fwd":
-            M, N, K = args[4:7]
-            flops = 2.0 * M * N * K
-            byts = ob(args[9]) * M * K + 2.0 * N * K + 2.0 * M * N
-            shape = f"M{M} K{K} N{N} LN-in" + (" f32in" if args[9] == 0 else "")
-        elif name == "mv_ln_mlp_fwd":
-            M, C, Hd = args[6:9]
-            flops = 4.0 * M * C * Hd
-            byts = 2.0 * ob(args[10]) * M * C + 4.0 * C * Hd
-            shape = f"M{M} C{C} hidden{Hd} LN+MLP+res"
-        elif name == "mv_linear_heads_fwd":
-            M, N, K = args[5:8]
-            flops = 2.0 * M * N * K
-            byts = 2.0 * (M * K + N * K + M * N)
-            shape = f"M{M} K{K} N{N} head-major"
-        elif name == "mv_conv1x1_dual_fwd":
-            N, Ho, Wo, C1, H2, W2, C2, s2, K = args[6:15]
-            M = N * Ho * Wo
-            flops = 2.0 * M * K * (C1 + C2)
-            byts = 2.0 * (M * C1 + M * C2 + K * (C1 + C2) + M * K)
-            shape = f"M{M} {C1}+{C2}(s{s2})->{K}"
-        elif name == "mv_conv1x1_chain_fwd":
-            M, C, K, N2 = args[10:14]
-            flops = 2.0 * M * (C * K + K * N2)
-            byts = 2.0 * M * (C + 2 * K + N2)
-            shape = f"M{M} {C}->{K}(+res)->{N2}"
-        elif name == "mv_conv1x1_dual_chain_fwd":
-            M, C1, C2, K, N2 = args[10:15]
-            flops = 2.0 * M * ((C1 + C2) * K + K * N2)
-            byts = 2.0 * M * (C1 + C2 + K + N2)
-            shape = f"M{M} {C1}+{C2}->{K}->{N2}"
-        elif name == "mv_stem_conv_pool_fwd":
-            N, C, H, W, K, R, S, sh, sw, ph, pw, pk, ps, pp = args[5:19]
-            Ho, Wo = (H + 2 * ph - R) // sh + 1, (W + 2 * pw - S) // sw + 1
-            Po, Qo = (Ho + 2 * pp - pk) // ps + 1, (Wo + 2 * pp - pk) // ps + 1
-            flops = 2.0 * N * Ho * Wo * K * R * S * C
-            byts = ob(args[20]) * N * C * H * W + 2.0 * N * Po * Qo * K
-            shape = f"N{N} {C}x{H}x{W}->conv{Ho}x{Wo}->pool{Po}x{Qo}x{K}"
-        elif name in ("mv_conv2d_nchw_fwd", "mv_conv2d_nchw_split_fwd"):
-            o = 1 if name.endswith("split_fwd") else 0
-            N, C, H, W, K, R, S, sh, sw, ph, pw = args[5 + o:16 + o]
-            Ho = (H + 2 * ph - R) // sh + 1
-            Wo = (W + 2 * pw - S) // sw + 1
-            flops = 2.0 * N * Ho * Wo * K * R * S * C * (1 + o)
-            byts = 4.0 * N * C * H * W + 2.0 * N * Ho * Wo * K
-            shape = f"N{N} {C}x{H}x{W}->{Ho}x{Wo}x{K} k{R}s{sh}" + (" hi+lo" if o else "")
-        elif name in ("mv_mha_fwd", "mv_mha_heads_fwd"):
-            B, N, H, dh = args[3:7]
-            flops = 4.0 * B * H * N * N * dh
-            byts = 2.0 * B * N * H * dh * 4
-            shape = f"B{B} N{N} H{H} dh{dh}"
-        elif name == "mv_swin_window_attn_fwd":
-            B, Hf, Wf, C, heads, wh, ww = args[3:10]
-            flops = 4.0 * B * Hf * Wf * (wh * ww) * C
-            byts = 2.0 * B * Hf * Wf * C * 4
-            shape = f"B{B} {Hf}x{Wf}x{C} h{heads} w{wh}"
-        elif name == "mv_maxpool2d_nhwc_fwd":
-            N, H, W, C, kh, kw, sh, sw, ph, pw = args[2:12]
-            Ho = (H + 2 * ph - kh) // sh + 1
-            byts = 2.0 * N * C * (H * W + Ho * Ho)
-            shape = f"N{N} {H}x{W}x{C}"
-        elif name == "mv_layernorm_fwd":
-            M, C = args[4:6]
-            byts = float(M) * C * (ob(args[8]) + ob(args[9]))
-            shape = f"M{M} C{C}"
+        flops, byts, shape = launch_meta(name, args)
         rows.append({"call": name, "kernel": kern, "shape": shape, "us": round(us, 2),
                      "tflops": round(flops / us / 1e6, 1) if us else 0, "gbs": round(byts / us / 1e3, 1) if us else 0,
                      "gflop": round(flops / 1e9, 3), "mb": round(byts / 1e6, 2)})
@@ -211,16 +230,84 @@ def layer_table(compiled, path, steps=5):
     return rows
 
 
+def insitu_rows(compiled, steps=6):
+    """Per-launch durations IN SITU: the recorded launch lists replayed eagerly the way the hipGraph runs them -- lane l on its own
+    stream, forked and joined once per step -- with every launch bracketed by two HIP events on the stream it is launched on.
+    This is the duration rocprofv3's kernel trace reports for the graph replays (two lanes share the chip, so a launch takes
+    longer than alone); with one lane it is the plain back-to-back duration."""
+    from eqxvision_amd import _lib
+    lanes = compiled.lane_calls or [compiled.calls]
+    main = torch.cuda.current_stream()
+    streams = [torch.cuda.Stream() for _ in lanes]
+    evs = [[(_ev(), _ev()) for _ in lc] for lc in lanes]
+    kern = [[""] * len(lc) for lc in lanes]
+    tot = [[0.0] * len(lc) for lc in lanes]
+    n = max(len(lc) for lc in lanes)
+    for st in range(steps + 1):                       # step 0 = warm-up (and kernel names)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for s_ in streams:
+            s_.wait_event(fork)
+        for i in range(n):
+            for l, lc in enumerate(lanes):
+                if i < len(lc):
+                    cfn, args, name = lc[i]
+                    sp = streams[l].cuda_stream
+                    _lib.call("mv_event_record", evs[l][i][0], sp)
+                    rc = cfn(*args[:-1], sp)
+                    if rc != 0:
+                        raise RuntimeError(f"in-situ replay of {name} failed (rc={rc})")
+                    if st == 0:
+                        kern[l][i] = _lib.last_kernel()
+                    _lib.call("mv_event_record", evs[l][i][1], sp)
+        for s_ in streams:
+            d = torch.cuda.Event()
+            d.record(s_)
+            main.wait_event(d)
+        torch.cuda.synchronize()
+        if st == 0:
+            continue
+        for l, lc in enumerate(lanes):
+            for i in range(len(lc)):
+                ms = ctypes.c_float()
+                _lib.call("mv_event_elapsed_ms", evs[l][i][0], evs[l][i][1], ctypes.byref(ms))
+                tot[l][i] += ms.value
+    rows = []
+    for l, lc in enumerate(lanes):
+        for i, (cfn, args, name) in enumerate(lc):
+            flops, byts, shape = launch_meta(name, args)
+            us = 1e3 * tot[l][i] / steps
+            rows.append({"call": name, "kernel": kern[l][i], "shape": shape, "us": round(us, 2), "lane": l,
+                         "tflops": round(flops / us / 1e6, 1) if us else 0, "gbs": round(byts / us / 1e3, 1) if us else 0,
+                         "gflop": round(flops / 1e9, 3), "mb": round(byts / 1e6, 2)})
+    return rows
+
+
+def dominant_family(rows):
+    """The GEMM-type kernel family with the largest summed duration in one forward -> (name, {us, gflop, mb, n})."""
+    fam = {}
+    for r_ in rows:
+        k = r_["kernel"].replace("_dense", "").replace("_conv", "")
+        d = fam.setdefault(k, {"us": 0.0, "gflop": 0.0, "mb": 0.0, "n": 0})
+        d["us"] += r_["us"]; d["gflop"] += r_["gflop"]; d["mb"] += r_["mb"]; d["n"] += 1
+    gemm = {k: v for k, v in fam.items() if v["gflop"] > 0}
+    return max((gemm or fam or {"n/a": {"us": 1, "gflop": 0, "mb": 0, "n": 1}}).items(), key=lambda kv: kv[1]["us"])
+
+
 def cpu_baseline(model_name, net, threads):
     """CPU restatement (port) of the same forward on the host cores; bounded sample."""
     import eqxvision_amd as eqv
     from oracle import torch_ref as TR
-    sd = eqv.utils.state_dict(net)
+    if model_name == "swin_t":              # the restatement reads torchvision's key names; same architecture, synthetic checkpoint
+        from oracle import state as S_
+        sd = S_.swin_state(1)
+    else:
+        sd = eqv.utils.state_dict(net)
     B = 32 if model_name != "vit_base" else 16
     reps = 4 if model_name != "vit_base" else 3
     x = np.random.Generator(np.random.PCG64(0)).random((B, 3, 224, 224), dtype=np.float32)
     fwd = {"resnet50": lambda: TR.resnet_forward(sd, x), "vit_base": lambda: TR.vit_forward(sd, x),
-           "alexnet": lambda: TR.alexnet_forward(sd, x)}.get(model_name)
+           "swin_t": lambda: TR.swin_forward(sd, x), "alexnet": lambda: TR.alexnet_forward(sd, x)}.get(model_name)
     if fwd is None:
         return None
     t_all = time.time()
@@ -292,49 +379,74 @@ def run_model(a, name, B, rank, world, soak_s):
     dev_ms_per_step = ms.value / a.steps
     dt = D.max_over_ranks(dt)
     compiled = fwd._entries()[0]
-    rows = layer_table(compiled, a.layers if name == a.model else None) if rank == 0 else []
     if rank != 0:
         return None, net
+    step_ms = 1e3 * dt / a.steps
     flop_per_launch = GFLOP_PER_IMG[name] * 1e9 * B
     achieved = flop_per_launch / (dev_ms_per_step * 1e-3) / 1e12
-    # dominant kernel = the kernel family with the largest summed duration in one forward.  `achieved` = its algorithmic
-    # FLOPs / its duration in the per-launch replay of the recorded launch list (every launch alone on the chip, HIP events
-    # on the launch stream).  Inside the graph two lanes overlap, so rocprofv3's in-situ AverageNs of the same kernel is
-    # longer: `rocprof` carries that figure from the committed profile of this command (profiles/).
-    fam = {}
-    for r_ in rows:
-        k = r_["kernel"].replace("_dense", "").replace("_conv", "")
-        d = fam.setdefault(k, {"us": 0.0, "gflop": 0.0, "mb": 0.0, "n": 0})
-        d["us"] += r_["us"]; d["gflop"] += r_["gflop"]; d["mb"] += r_["mb"]; d["n"] += 1
-    gemm = {k: v for k, v in fam.items() if v["gflop"] > 0}
-    dk, dv = max((gemm or fam or {"n/a": {"us": 1, "gflop": 0, "mb": 0, "n": 1}}).items(), key=lambda kv: kv[1]["us"])
+    # ---- roofline of the dominant kernel, measured live with HIP events on the launch streams (docstring) -----------------------
+    rows = insitu_rows(compiled)
+    dk, dv = dominant_family(rows)
     dom_tflops = dv["gflop"] / dv["us"] * 1e3 if dv["us"] else 0.0   # GFLOP/us = PFLOP/s
+    nl = len(compiled.lane_calls) if compiled.lane_calls else 1
+    alg_mb = sum(r_["mb"] for r_ in rows)
     bound_us = sum(max(r_["gflop"] * 1e3 / MFMA_PEAK_TFLOPS, r_["mb"] / HBM_PEAK_GBS * 1e3) for r_ in rows)
-    traffic = ref = None
-    tj = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per launch + rocprof averages, if collected
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per launch (separate --pmc passes), if collected
     if os.path.exists(tj) and world == 1:
         try:
             tjd = json.load(open(tj))
             if tjd.get("_batch", {}).get(name) == B:
                 traffic = tjd.get(name, {}).get(dk)
-                ref = tjd.get("_rocprof", {}).get(name, {}).get(dk)
         except Exception:  # noqa: BLE001
-            traffic = ref = None
+            traffic = None
     roof = {"bound": "mfma", "achieved": round(dom_tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(dom_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "kernel": dk, "launches_per_step": dv["n"],
             "avg_launch_us": round(dv["us"] / max(1, dv["n"]), 2),
-            "share_of_step": round(dv["us"] / max(1e-9, sum(r_["us"] for r_ in rows)), 3),
+            "how": f"in situ: eager replay of the {nl}-lane launch lists on {nl} stream(s), two HIP events around every launch on "
+                   "its own stream, 6 steps; = what rocprofv3 --kernel-trace reports for the graph replays of this command",
+            "share_of_kernel_time": round(dv["us"] / max(1e-9, sum(r_["us"] for r_ in rows)), 3),
             "flop_per_launch": round(dv["gflop"] * 1e9 / max(1, dv["n"])),
             "kernel_hbm_gbs": round(dv["mb"] / dv["us"] * 1e3, 1) if dv["us"] else 0.0,
             "whole_forward": {"achieved": round(achieved, 1), "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                               "graph_launch_ms": round(dev_ms_per_step, 4), "flop_per_launch": flop_per_launch,
+                              # algorithmic HBM bytes of one forward (sum over the launches; fused launches at what they have to
+                              # move) over the measured step, against 8 TB/s
+                              "algorithmic_mb": round(alg_mb, 1),
+                              "hbm_frac": round(alg_mb * 1e6 / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
                               # layer-wise speed of light: sum over launches of max(flops / MFMA peak, algorithmic bytes /
                               # HBM peak) over the measured step (1.0 = every launch on its own roofline, nothing overlapped)
                               "layerwise_bound_ms": round(bound_us / 1e3, 4),
                               "layerwise_bound_frac": round(bound_us / 1e3 / dev_ms_per_step, 4)}}
-    if ref:                                   # {"avg_launch_us": in-situ rocprofv3 average, "file": ...}
-        roof["rocprof"] = dict(ref, frac=round(dv["gflop"] / max(1, dv["n"]) / ref["avg_launch_us"] * 1e3 / MFMA_PEAK_TFLOPS, 4))
-    res = {"value": round(B * world * a.steps / dt, 1), "ms_per_step": round(1e3 * dt / a.steps, 4),
+    if nl > 1:
+        # lanes overlap in time, so the in-situ durations of the two lanes do not add up to the step; the same model traced as ONE
+        # launch list (full-batch launches back to back on one stream) gives per-kernel figures whose sum is comparable with a step
+        f1 = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k), use_graph=False, clone_outputs=False, lanes=1)
+        for _ in range(2):
+            f1(net, images, keys)
+        torch.cuda.synchronize()
+        e0_, e1_ = _ev(), _ev()
+        _lib.call("mv_event_record", e0_, stream_ptr())
+        for _ in range(5):
+            f1(net, images, keys)
+        _lib.call("mv_event_record", e1_, stream_ptr())
+        torch.cuda.synchronize()
+        ms1 = ctypes.c_float()
+        _lib.call("mv_event_elapsed_ms", e0_, e1_, ctypes.byref(ms1))
+        rows1 = insitu_rows(f1._entries()[0])
+        k1, v1 = dominant_family(rows1)
+        t1 = v1["gflop"] / v1["us"] * 1e3 if v1["us"] else 0.0
+        roof["lanes1"] = {"kernel": k1, "launches_per_step": v1["n"], "avg_launch_us": round(v1["us"] / max(1, v1["n"]), 2),
+                          "achieved": round(t1, 1), "frac": round(t1 / MFMA_PEAK_TFLOPS, 4),
+                          "sum_dominant_ms": round(v1["us"] / 1e3, 4), "sum_all_kernels_ms": round(sum(r_["us"] for r_ in rows1) / 1e3, 4),
+                          "ms_per_step_eager": round(ms1.value / 5, 4)}
+        f1._cache.clear()
+    if a.layers and name == a.model:                       # tuning worksheet: every launch ALONE on the chip
+        iso = layer_table(compiled, a.layers)
+        ik, iv = dominant_family(iso)
+        roof["isolated"] = {"kernel": ik, "avg_launch_us": round(iv["us"] / max(1, iv["n"]), 2),
+                            "frac": round(iv["gflop"] / iv["us"] * 1e3 / MFMA_PEAK_TFLOPS, 4) if iv["us"] else 0.0}
+    res = {"value": round(B * world * a.steps / dt, 1), "ms_per_step": round(step_ms, 4),
            "config": {"workload": f"{name} {a.dtype} forward, batch={B}/GPU, 3x224x224, 1000 classes",
                       "global_batch": B * world, "parallelism": f"dp{world}", "launches_per_step": len(compiled.calls),
                       "graph": compiled.graph is not None,
@@ -388,6 +500,9 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but {world} rank(s) joined (WORLD_SIZE={os.environ.get('WORLD_SIZE')}): "
                          "launch through torch.distributed.run or let bench.py spawn the ranks itself")
+    if world > 1 and not D._state["native"] and os.environ.get("EQV_DIST_COLLECTIVE", "rccl") == "rccl" and torch.cuda.is_available():
+        raise SystemExit("the logits all-gather is NOT on mv_allgather (RCCL): mv_comm_init failed and the run fell back to "
+                         "torch.distributed -- refusing to print a line (set EQV_DIST_COLLECTIVE=torch to measure that path on purpose)")
     if world > 1 and D._state["native"] and eqv._lib.load().mv_comm_size() != world:
         raise SystemExit(f"RCCL communicator has {eqv._lib.load().mv_comm_size()} ranks, expected {world}")
     torch.cuda.set_device(local)
@@ -401,7 +516,7 @@ def main():
     # CPU baseline FIRST (rank 0, 1 GPU only), so that the GPU phase is the tail of the run
     cpu = {}
     if world == 1 and not a.no_cpu:
-        for m in [a.model] + [e for e in extras if e in ("vit_base",)]:
+        for m in [a.model] + [e for e in extras if e in ("vit_base", "swin_t")]:
             try:
                 cpu[m] = cpu_baseline(m, build_model(m), torch.get_num_threads())
             except Exception as e:  # noqa: BLE001
