@@ -64,6 +64,8 @@ PROTOTYPES = {
     "mv_ln_linear_fwd": [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _i, _i, _vp],
     "mv_ln_mlp_supported": [_i64, _i, _i, _i],
     "mv_ln_mlp_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp],
+    "mv_ln_mlp_stream_supported": [_i64, _i, _i, _i],
+    "mv_ln_mlp_stream_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp],
     "mv_conv2d_nchw_split_fwd": [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_i, _i, _i, _vp],
     "mv_resize_bilinear_nhwc_fwd": [_vp, _vp] + [_i] * 6 + [_i, _i, _i, _vp],
     "mv_copy_rows": [_vp, _vp, _i64, _i64, _i64, _i64, _vp],

@@ -804,6 +804,8 @@ def ln_mlp(x: Act, ln, mlp) -> Optional[Act]:
     M = x.t.numel() // C
     xdt = _lib.F32 if x.t.dtype == torch.float32 else _lib.BF16
     if not _lib.load().mv_ln_mlp_supported(M, C, Hd, xdt):
+        if _lib.load().mv_ln_mlp_stream_supported(M, C, Hd, xdt):
+            return _ln_mlp_stream(x, ln, mlp, M, C, Hd, xdt)
         return None
     cache = mlp._cache()
     key = ("ln_mlp", id(ln.weight), id(ln.bias))
@@ -818,6 +820,33 @@ def ln_mlp(x: Act, ln, mlp) -> Optional[Act]:
         cache[key] = hit
     y = empty(tuple(x.t.shape), x.t.dtype)
     _lib.call("mv_ln_mlp_fwd", _ptr(x.t), _ptr(hit[0]), _ptr(hit[1]), _ptr(hit[2]), _ptr(hit[3]), _ptr(y), M, C, Hd,
+              float(ln.eps), xdt, stream_ptr())
+    return Act(y, x.kind, x.batched)
+
+
+def ln_mlp_fragments(w1: np.ndarray, w2: np.ndarray):
+    """fc1 [hidden][C] / fc2 [C][hidden] -> the fragment order of mv_ln_mlp_stream_fwd (header)."""
+    Hd, C = w1.shape
+    w1f = w1.reshape(Hd // 256, 8, 32, C // 16, 2, 8).transpose(0, 1, 3, 4, 2, 5)            # (chunk, wave, j, h, m, e)
+    w2f = w2.reshape(C // 32, 32, Hd // 256, 16, 2, 8).transpose(2, 0, 3, 4, 1, 5)           # (chunk, tile, j, h, m, e)
+    return np.ascontiguousarray(w1f), np.ascontiguousarray(w2f)
+
+
+def _ln_mlp_stream(x: Act, ln, mlp, M, C, Hd, xdt) -> Act:
+    """ln_mlp's wide-row variant: weights streamed from L2 in fragment order (LayerNorm affine folded into fc1 on the host)."""
+    fc1, fc2 = mlp.fc1, mlp.fc2
+    cache = mlp._cache()
+    key = ("ln_mlp_stream", id(ln.weight), id(ln.bias))
+    hit = cache.get(key)
+    if hit is None:
+        w1 = np.asarray(fc1.weight, np.float32)
+        g, b = np.asarray(ln.weight, np.float32).reshape(-1), np.asarray(ln.bias, np.float32).reshape(-1)
+        w1f, w2f = ln_mlp_fragments(w1 * g[None, :], np.asarray(fc2.weight, np.float32))
+        hit = (_dev(w1f, torch.bfloat16), _dev(np.asarray(fc1.bias, np.float32).reshape(-1) + w1 @ b, torch.float32),
+               _dev(w2f, torch.bfloat16), _dev(np.asarray(fc2.bias, np.float32).reshape(-1), torch.float32), ln)
+        cache[key] = hit
+    y = empty(tuple(x.t.shape), x.t.dtype)
+    _lib.call("mv_ln_mlp_stream_fwd", _ptr(x.t), _ptr(hit[0]), _ptr(hit[1]), _ptr(hit[2]), _ptr(hit[3]), _ptr(y), M, C, Hd,
               float(ln.eps), xdt, stream_ptr())
     return Act(y, x.kind, x.batched)
 

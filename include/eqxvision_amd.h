@@ -218,6 +218,17 @@ int mv_ln_mlp_supported(int64_t M, int C, int hidden, int x_dtype);
 int mv_ln_mlp_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int64_t M, int C,
                   int hidden, float eps, int x_dtype, mv_stream_t stream);
 
+/* The same MLP half for rows too wide for the weights to live in LDS (Swin stage 2: C = 384, hidden = 1536): both weight matrices
+ * are STREAMED from L2 straight into registers, 64 token rows per workgroup, the hidden activations pass through LDS in chunks
+ * of 256 units and never reach HBM.  Same formula and folding as mv_ln_mlp_fwd; the weights come in FRAGMENT ORDER (prepared once
+ * by the caller, eqxvision_amd/ops.py:ln_mlp): a wave fetches each k16-step of its 32 output units as one 1 KB piece,
+ *   w1f[chunk 0..hidden/256-1][wave 0..7][j 0..C/16-1][lane 0..63][e 0..7] = w1[u = 256*chunk + 32*wave + lane%32][c = 16*j + 8*(lane/32) + e]
+ *   w2f[chunk][tile 0..C/32-1][j 0..15][lane][e]                        = w2[c = 32*tile + lane%32][u = 256*chunk + 16*j + 8*(lane/32) + e]
+ * x, y: MV_F32 (the fp32 residual stream), not in place. */
+int mv_ln_mlp_stream_supported(int64_t M, int C, int hidden, int x_dtype);
+int mv_ln_mlp_stream_fwd(const void* x, const void* w1f, const float* b1, const void* w2f, const float* b2, void* y, int64_t M,
+                         int C, int hidden, float eps, int x_dtype, mv_stream_t stream);
+
 /* jax.image.resize(x, shape, method="bilinear") for up-sampling (segmentation/_utils.py:52-58: logits -> input resolution;
  * deeplabv3.py:66-72: the pooled ASPP branch back to the feature size): half-pixel centres, out-of-range taps dropped and the
  * rest renormalised (== clamped taps for the 2-tap kernel).  x NHWC [N,h,w,C]; y NHWC [N,H,W,C] or, with out_nchw, NCHW

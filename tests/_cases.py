@@ -799,8 +799,9 @@ def ln_mlp_case(M, stream="fp32", seed=0, C=96, Hd=384):
         w2 = (rng.standard_normal((C, Hd)) / np.sqrt(Hd)).astype(np.float32)
         b2 = (0.1 * rng.standard_normal(C)).astype(np.float32)
         xdt = 0 if stream == "fp32" else 1
-        if not L.load().mv_ln_mlp_supported(M, C, Hd, xdt):
-            return {"ok": False, "err": "mv_ln_mlp_supported says no"}
+        streamed = not L.load().mv_ln_mlp_supported(M, C, Hd, xdt)      # wide rows: the streamed-weights kernel (fragment order)
+        if streamed and not L.load().mv_ln_mlp_stream_supported(M, C, Hd, xdt):
+            return {"ok": False, "err": "neither mv_ln_mlp_supported nor mv_ln_mlp_stream_supported"}
         n = O.layernorm_rows(x, g, be, 1e-5).astype(np.float64)
         h = O.gelu_tanh(n @ w1.astype(np.float64).T + b1).astype(np.float64)
         ref = x.astype(np.float64) + h @ w2.astype(np.float64).T + b2
@@ -809,8 +810,15 @@ def ln_mlp_case(M, stream="fp32", seed=0, C=96, Hd=384):
         xd = dev(x, stream)
         w1d, b1d, w2d, b2d = dev(w1f, "bf16"), dev(b1f, "fp32"), dev(bf(w2), "bf16"), dev(b2, "fp32")
         y = torch.empty_like(xd)
-        L.call("mv_ln_mlp_fwd", xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), y.data_ptr(),
-               M, C, Hd, 1e-5, xdt, _stream())
+        if streamed:
+            w1fr = w1f.reshape(Hd // 256, 8, 32, C // 16, 2, 8).transpose(0, 1, 3, 4, 2, 5)
+            w2fr = bf(w2).reshape(C // 32, 32, Hd // 256, 16, 2, 8).transpose(2, 0, 3, 4, 1, 5)
+            w1s, w2s = dev(w1fr, "bf16"), dev(w2fr, "bf16")
+            L.call("mv_ln_mlp_stream_fwd", xd.data_ptr(), w1s.data_ptr(), b1d.data_ptr(), w2s.data_ptr(), b2d.data_ptr(), y.data_ptr(),
+                   M, C, Hd, 1e-5, xdt, _stream())
+        else:
+            L.call("mv_ln_mlp_fwd", xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), y.data_ptr(),
+                   M, C, Hd, 1e-5, xdt, _stream())
         kern = L.last_kernel()
         torch.cuda.synchronize()
         info = _cmp(host(y), ref, TOL_BF16)
@@ -1653,6 +1661,9 @@ def all_cases():
           ("ln_mlp/swin_stage0_f32stream", ln_mlp_case(8 * 56 * 56, "fp32", seed=520)),
           ("ln_mlp/bf16stream_ragged", ln_mlp_case(4096 + 77, "bf16", seed=521)),
           ("ln_mlp/f32stream_many_tiles", ln_mlp_case(70001, "fp32", seed=522)),
+          ("ln_mlp/stream_c384_swin_stage2_B8", ln_mlp_case(8 * 14 * 14, "fp32", seed=523, C=384, Hd=1536)),
+          ("ln_mlp/stream_c384_ragged", ln_mlp_case(64 * 9 + 37, "fp32", seed=524, C=384, Hd=1536)),
+          ("ln_mlp/stream_c384_many_tiles", ln_mlp_case(64 * 300 + 5, "fp32", seed=525, C=384, Hd=1536)),
           ("split/conv_swin_patch4", conv_nchw_split_case(3, 3, 224, 96, 4, 4, seed=514)),
           ("split/conv_odd_k3s2", conv_nchw_split_case(2, 3, 65, 40, 3, 2, seed=515)),
           ("chain/56x56_B4", chain_case(4 * 56 * 56, seed=1)),
