@@ -500,7 +500,7 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but {world} rank(s) joined (WORLD_SIZE={os.environ.get('WORLD_SIZE')}): "
                          "launch through torch.distributed.run or let bench.py spawn the ranks itself")
-    if world > 1 and not D._state["native"] and os.environ.get("EQV_DIST_COLLECTIVE", "rccl") == "rccl" and torch.cuda.is_available():
+    if world > 1 and not D._state["native"] and D._state["collective"] == "rccl":
         raise SystemExit("the logits all-gather is NOT on mv_allgather (RCCL): mv_comm_init failed and the run fell back to "
                          "torch.distributed -- refusing to print a line (set EQV_DIST_COLLECTIVE=torch to measure that path on purpose)")
     if world > 1 and D._state["native"] and eqv._lib.load().mv_comm_size() != world:

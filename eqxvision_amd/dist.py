@@ -24,7 +24,7 @@ import torch.distributed as dist
 
 from . import _lib
 
-_state = {"native": False, "group": None}
+_state = {"native": False, "group": None, "collective": None}   # collective: what init_from_env set out to use ("rccl" / "torch")
 
 
 def _rccl_path() -> Optional[str]:
@@ -73,6 +73,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         local = int(os.environ["EQV_DIST_DEVICE"])
     has_gpu = torch.cuda.is_available()
     collective = os.environ.get("EQV_DIST_COLLECTIVE") or ("rccl" if has_gpu and backend is None else "torch")
+    _state["collective"] = collective
     if has_gpu:
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():

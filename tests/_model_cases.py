@@ -931,6 +931,99 @@ def pth_reader_case():
     return run
 
 
+def _hot_model(name, sd):
+    """(factory-loaded inference model, torch-restatement forward) of one of the three full-size hot models on checkpoint `sd`."""
+    import warnings
+    import eqxvision_amd as eqv
+    if name == "resnet50":
+        return _load(eqv.models.resnet50, sd), lambda x: TR.resnet_forward(sd, x).numpy()
+    if name == "vit_base":
+        return _load(eqv.models.vit_base, sd, num_classes=1000), lambda x: TR.vit_forward(sd, x).numpy()
+    if name == "alexnet":
+        return _load(eqv.models.alexnet, sd), lambda x: TR.alexnet_forward(sd, x).numpy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return _load(eqv.models.swin_t, sd), lambda x: TR.swin_forward(sd, x).numpy()
+
+
+_HOT_STATE = {"resnet50": lambda: S.resnet_state(1), "vit_base": lambda: S.vit_state(1), "swin_t": lambda: S.swin_state(1),
+              "alexnet": lambda: S.alexnet_state(1, 1000)}
+_HEAD = {"resnet50": "fc", "vit_base": "fc", "swin_t": "head"}
+
+
+def committed_golden_case(name, dtype="bf16"):
+    """The HIP path against the COMMITTED vectors of tests/golden/hotpath_small.npz (generated by tests/golden/make_golden.py from
+    the torch restatement) -- not against an oracle regenerated in this process: first 16 logits and the L2 norm
+    of the logits of the full-size model at B = 2, 224 px."""
+    def run():
+        gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hotpath_small.npz"))
+        net, _ = _hot_model(name, _HOT_STATE[name]())
+        x = S.synthetic_images(2, 224, seed=0)
+        got = _run(net, x, dtype).cpu().numpy()
+        head, l2 = gold[f"{name}_224_logits_head16"], gold[f"{name}_224_logits_l2"]
+        tol = 1e-2 if dtype == "bf16" else 1e-3
+        info = _cmp(got[:, :16], head, tol)
+        l2err = float(np.abs(np.linalg.norm(got.astype(np.float64), axis=1) - l2).max())
+        info["l2_err"] = l2err
+        info["ok"] = bool(info["ok"] and l2err <= tol * np.sqrt(got.shape[1]))       # |  ||a|| - ||b||  | <= ||a - b|| <= tol * sqrt(classes)
+        return info
+    return run
+
+
+def committed_small_golden_case(dtype="bf16"):
+    """The reduced models of tests/golden/hotpath_small.npz (the same bottleneck / attention / window code at small sizes), HIP
+    path vs the committed logits."""
+    def run():
+        import warnings
+        import eqxvision_amd as eqv
+        gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hotpath_small.npz"))
+        tol = 1e-2 if dtype == "bf16" else 1e-3
+        R = eqv.models.classification.resnet
+        errs = {}
+        x64 = S.synthetic_images(2, 64, seed=0)
+        net = _load(lambda torch_weights=None, **kw: R._resnet(R._ResNetBottleneck, [1, 1, 1, 1], torch_weights, **kw),
+                    S.resnet_state(1, "bottleneck", (1, 1, 1, 1), 10), num_classes=10)
+        errs["resnet_bottleneck_1111_64px"] = float(np.abs(_run(net, x64, dtype).cpu().numpy() - gold["resnet_bottleneck_1111_64px"]).max())
+        net = _load(eqv.models.resnet18, S.resnet_state(1, "basic", (2, 2, 2, 2), 10), num_classes=10)
+        errs["resnet18_64px"] = float(np.abs(_run(net, x64, dtype).cpu().numpy() - gold["resnet18_64px"]).max())
+        fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(eqv.models.VisionTransformer(**kw), torch_weights)
+        net = _load(fac, S.vit_state(1, 32, 8, 64, 2, 2, 4, 10), img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=2, num_classes=10)
+        errs["vit_32px_p8_d64_h2_depth2"] = float(np.abs(_run(net, S.synthetic_images(3, 32, seed=0), dtype).cpu().numpy()
+                                                         - gold["vit_32px_p8_d64_h2_depth2"]).max())
+        fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(eqv.models.SwinTransformer(**kw), torch_weights)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            net = _load(fac, S.swin_state(1, (4, 4), 32, (2, 2), (2, 4), (7, 7), 4.0, 10), patch_size=[4, 4], embed_dim=32, depths=[2, 2],
+                        num_heads=[2, 4], window_size=[7, 7], num_classes=10)
+        errs["swin_56px_e32_d22"] = float(np.abs(_run(net, S.synthetic_images(2, 56, seed=0), dtype).cpu().numpy() - gold["swin_56px_e32_d22"]).max())
+        return {"ok": max(errs.values()) <= tol, "err": max(errs.values()), "lim": tol, "errs": errs}
+    return run
+
+
+def large_logit_case(name, target=15.0, B=2, dtype="bf16"):
+    """Logits at the scale of a TRAINED classifier (round-2 review, weak 2): the synthetic checkpoints give max|logit| of 0.6 - 2,
+    pretrained ones O(10).  The classifier head (weight and bias) of the synthetic checkpoint is scaled so that max|logit| of the
+    fp32 restatement is `target`; reports the absolute error and the error relative to max|logit|.  Passes on the RELATIVE
+    reading, 1e-2 * max(1, max|logit|) -- bf16 storage keeps 8 mantissa bits, so an absolute 1e-2 cannot hold at |logit| ~ 15 --
+    plus identical arg-max; the absolute figure is reported (DESIGN section 4 states which reading the build claims)."""
+    def run():
+        sd = _HOT_STATE[name]()
+        x = S.synthetic_images(B, 224, seed=0)
+        _, ref_fn = _hot_model(name, sd)
+        s = target / float(np.abs(ref_fn(x)).max())
+        h = _HEAD[name]
+        sd = type(sd)((k, (v * np.float32(s)).astype(np.float32) if k in (h + ".weight", h + ".bias") else v) for k, v in sd.items())
+        net, ref_fn = _hot_model(name, sd)
+        ref = ref_fn(x)
+        got = _run(net, x, dtype).cpu().numpy()
+        info = _cmp(got, ref, 1e-2 if dtype == "bf16" else 1e-3, scaled=True)
+        info["abs_err"] = info["err"]
+        info["head_scale"] = s
+        info["ok"] = bool(info["ok"] and info["argmax_match"])
+        return info
+    return run
+
+
 def all_cases(full=True):
     c = [("model/resnet_tiny_bottleneck", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2)),
          ("model/resnet18_64px", resnet_case("basic", (2, 2, 2, 2), 64, 2)),
@@ -1010,6 +1103,15 @@ def all_cases(full=True):
               ("model/fcn_resnet50_B2", segmentation_case("fcn", (3, 4, 6, 3), 224, 2, classes=21, full_ref="torch")),
               ("model/deeplabv3_resnet50_B2", segmentation_case("deeplabv3", (3, 4, 6, 3), 224, 2, classes=21, full_ref="torch")),
               ("model/swin_t_B1", swin_case(224, 96, (2, 2, 6, 2), (3, 6, 12, 24), 1, classes=1000, full_ref="torch")),
+              ("golden/committed_alexnet_224", committed_golden_case("alexnet")),
+              ("golden/committed_resnet50_224", committed_golden_case("resnet50")),
+              ("golden/committed_vit_base_224", committed_golden_case("vit_base")),
+              ("golden/committed_swin_t_224", committed_golden_case("swin_t")),
+              ("golden/committed_small_models", committed_small_golden_case()),
+              ("golden/committed_small_models_fp32", committed_small_golden_case("fp32")),
+              ("model/resnet50_logits_at_trained_scale", large_logit_case("resnet50")),
+              ("model/vit_base_logits_at_trained_scale", large_logit_case("vit_base")),
+              ("model/swin_t_logits_at_trained_scale", large_logit_case("swin_t")),
               ("model/resnet50_B256_full_config", full_batch_case("resnet50", 256)),
               ("model/vit_base_B256_full_config", full_batch_case("vit_base", 256)),
               ("model/swin_t_B128_full_config", full_batch_case("swin_t", 128))]

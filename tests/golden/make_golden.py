@@ -44,6 +44,15 @@ def main():
     lg = TR.resnet_forward(sd, x224).numpy()
     g["resnet50_224_logits_head16"] = lg[:, :16]
     g["resnet50_224_logits_l2"] = np.linalg.norm(lg, axis=1)
+    # full-size logits checksums (first 16 logits + L2 norm) for the other two hot models at B = 2
+    sd = S.vit_state(1)
+    lg = TR.vit_forward(sd, x224).numpy()
+    g["vit_base_224_logits_head16"] = lg[:, :16]
+    g["vit_base_224_logits_l2"] = np.linalg.norm(lg, axis=1)
+    sd = S.swin_state(1)
+    lg = TR.swin_forward(sd, x224).numpy()
+    g["swin_t_224_logits_head16"] = lg[:, :16]
+    g["swin_t_224_logits_l2"] = np.linalg.norm(lg, axis=1)
     np.savez_compressed(os.path.join(OUT, "hotpath_small.npz"), **{k: v.astype(np.float32) for k, v in g.items()})
     for k, v in g.items():
         print(k, v.shape, float(np.abs(v).max()))

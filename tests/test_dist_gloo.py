@@ -48,6 +48,42 @@ def test_sharded_forward_gloo(batch):
         np.testing.assert_array_equal(res[r], ref)
 
 
+def _worker8(rank, world, port, q):
+    """BASELINE config 4's collective shape on CPU: 8 ranks x 256 samples, fp32 logits [256, 1000] per rank -> [2048, 1000]."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from eqxvision_amd import dist as D
+    D.init_from_env("gloo")
+    B, classes = 2048, 1000
+    imgs = torch.arange(B, dtype=torch.float32).reshape(B, 1, 1, 1).expand(B, 3, 2, 2)      # sample i carries the value i
+
+    def forward(x):      # "logits" of sample i: i + class / 1000 (exact in fp32 for i < 2048): every row identifies its sample
+        assert x.shape[0] == B // world
+        return x[:, 0, 0, 0, None] + torch.arange(classes, dtype=torch.float32)[None, :] / 1024.0
+
+    out = D.sharded_forward(forward, imgs)
+    ok = out.shape == (B, classes) and bool((out[:, 0] == torch.arange(B, dtype=torch.float32)).all()) and \
+        bool((out[:, 999] == torch.arange(B, dtype=torch.float32) + 999.0 / 1024.0).all())
+    q.put((rank, ok, tuple(out.shape)))
+    torch.distributed.destroy_process_group()
+
+
+def test_sharded_forward_gloo_world8_config4():
+    """resnet50 batch 2048 over 8 ranks (BASELINE.json configs[3]): shard bounds, per-rank batch 256 and the all-gather of
+    f32[256, 1000] per rank into f32[2048, 1000] in rank order -- the same dist.py control flow the 8-GPU run takes, with gloo
+    standing in for RCCL."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=300) for _ in range(world)]
+    [p.join(60) for p in ps]
+    assert sorted(r for r, _, _ in res) == list(range(world))
+    assert all(ok and shape == (2048, 1000) for _, ok, shape in res), res
+
+
 def test_shard_bounds_cover_batch():
     from eqxvision_amd.dist import shard_bounds
     for B in (1, 7, 8, 2048):

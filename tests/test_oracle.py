@@ -132,6 +132,18 @@ def test_alexnet_golden_and_bf16_emulation_is_close():
     assert np.abs(emu - lg[:1]).max() <= 1e-2 * max(1.0, np.abs(lg).max())
 
 
+def test_full_size_vit_and_swin_checksums():
+    """the numpy oracle reproduces the committed full-size checksums (first 16 logits + L2 norm of the
+    logits, written by the torch restatement) of vit_base and swin_t -- first image of the B = 2 fixture."""
+    x = S.synthetic_images(2, 224, seed=0)[:1]
+    lg = O.vmap(lambda im: OM.vit_forward(S.vit_state(1), im))(x)
+    assert rel(lg[:, :16], GOLD["vit_base_224_logits_head16"][:1]) < 1e-4
+    assert rel(np.linalg.norm(lg, axis=1), GOLD["vit_base_224_logits_l2"][:1]) < 1e-5
+    lg = O.vmap(lambda im: OM.swin_forward(S.swin_state(1), im))(x)
+    assert rel(lg[:, :16], GOLD["swin_t_224_logits_head16"][:1]) < 1e-4
+    assert rel(np.linalg.norm(lg, axis=1), GOLD["swin_t_224_logits_l2"][:1]) < 1e-5
+
+
 def test_swin_shift_mask_and_window_edge_cases():
     r = rng(5)
     C, H, heads = 16, 14, 2
