@@ -160,7 +160,8 @@ class _SwinTransformerBlock(Module):
         mlp_live = isinstance(self.mlp, MlpProjection) and self.mlp._live()
         if (sd.inference or sd.p == 0.0) and not attn_live and not mlp_live:
             if type(self.attn) is _ShiftedWindowAttention and isinstance(self.norm1, nn.LayerNorm):
-                x = self.attn._forward(x, residual=x, norm=self.norm1)
+                y = ops.swin_block_attention(x, self.norm1, self.attn)     # the whole attention half, one workgroup per window
+                x = y if y is not None else self.attn._forward(x, residual=x, norm=self.norm1)
             else:
                 x = self.attn._forward(self.norm1(x), residual=x)
             if isinstance(self.mlp, MlpProjection):

@@ -992,6 +992,57 @@ def swin_window_attention(qkv: Act, bias: torch.Tensor, heads: int, window, shif
     return Act(out, "map", qkv.batched)
 
 
+def swin_block_attn_fragments(wqkv: np.ndarray, bqkv: np.ndarray, wp: np.ndarray, bias: np.ndarray):
+    """qkv weight [3C][C] (LayerNorm already folded) / bias [3C], proj weight [C][C], relative-position bias [heads][n][n] ->
+    the operand layouts of mv_swin_block_attn_fwd (header)."""
+    C = wp.shape[0]
+    heads = C // 32
+    G = heads // 4
+    rows = np.array([[(t // 4) * C + 32 * (4 * g + t % 4) for t in range(12)] for g in range(G)])                 # [G][12]
+    w = wqkv[(rows[:, :, None] + np.arange(32)[None, None, :])]                                                   # [G][12][32][C]
+    wf = w.reshape(G, 12, 32, C // 16, 2, 8).transpose(0, 1, 3, 4, 2, 5)                                           # (g, t, j, h, m, e)
+    bf_ = bqkv[(rows[:, :, None] + np.arange(32)[None, None, :])]                                                  # [G][12][32]
+    wpf = wp.reshape(C // 32, 32, C // 16, 2, 8).transpose(0, 2, 3, 1, 4)                                          # (t, j, h, m, e)
+    n = bias.shape[1]
+    b64 = np.zeros((heads, 64, 64), np.float32)
+    b64[:, :, n:] = -1e30
+    b64[:, :n, :n] = bias
+    return (np.ascontiguousarray(wf, np.float32), np.ascontiguousarray(bf_, np.float32), np.ascontiguousarray(wpf, np.float32), b64)
+
+
+def swin_block_attention(x: Act, norm, attn) -> Optional[Act]:
+    """x + attn(norm(x)) of a Swin block (swin.py:572-578, first line) in ONE launch where the library has the fused per-window
+    kernel (stage 2 of swin_t / swin_s), else None."""
+    from . import nn
+    if compute_dtype() != "bf16" or x.kind != "map" or x.t.dtype != torch.float32 or not isinstance(norm, nn.LayerNorm):
+        return None
+    if norm.weight is None or norm.bias is None or attn.qkv.bias is None or attn.proj.bias is None:
+        return None
+    B, Hf, Wf, C = x.t.shape
+    ws, sh = attn.window_size, list(attn.shift_size)
+    if ws[0] >= Hf:                                                   # reference :116-120: no shift when the window covers the map
+        sh[0] = 0
+    if ws[1] >= Wf:
+        sh[1] = 0
+    if attn.qkv.in_features != C or not _lib.load().mv_swin_block_attn_supported(Hf, Wf, C, attn.num_heads, ws[0], ws[1], _lib.F32):
+        return None
+    cache = attn._cache()
+    key = ("block_attn", id(norm.weight), id(norm.bias))
+    hit = cache.get(key)
+    if hit is None:
+        wq = np.asarray(attn.qkv.weight, np.float32)
+        g, b = np.asarray(norm.weight, np.float32).reshape(-1), np.asarray(norm.bias, np.float32).reshape(-1)
+        wf, bq, wpf, b64 = swin_block_attn_fragments(wq * g[None, :], np.asarray(attn.qkv.bias, np.float32).reshape(-1) + wq @ b,
+                                                     np.asarray(attn.proj.weight, np.float32), attn.get_relative_position_bias())
+        hit = (_dev(wf, torch.bfloat16), _dev(bq, torch.float32), _dev(wpf, torch.bfloat16),
+               _dev(np.asarray(attn.proj.bias, np.float32).reshape(-1), torch.float32), _dev(b64, torch.float32), norm)
+        cache[key] = hit
+    y = empty(tuple(x.t.shape), torch.float32)
+    _lib.call("mv_swin_block_attn_fwd", _ptr(x.t), _ptr(hit[0]), _ptr(hit[1]), _ptr(hit[2]), _ptr(hit[3]), _ptr(hit[4]), _ptr(y),
+              B, Hf, Wf, C, attn.num_heads, ws[0], ws[1], sh[0], sh[1], float(norm.eps), _lib.F32, stream_ptr())
+    return Act(y, "map", x.batched)
+
+
 def dropout_windows(x: Act, p: float, key, window, shift) -> Act:
     """`_func_dropout(x, dropout, key)` on the projection output of `_shifted_window_attention` (swin.py:233): the mask is drawn
     for the (num_windows, tokens, C) layout the reference holds there; x is the NHWC map of the same values."""

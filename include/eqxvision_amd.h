@@ -218,6 +218,22 @@ int mv_ln_mlp_supported(int64_t M, int C, int hidden, int x_dtype);
 int mv_ln_mlp_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int64_t M, int C,
                   int hidden, float eps, int x_dtype, mv_stream_t stream);
 
+/* The ATTENTION half of a Swin block in ONE launch, one workgroup per window (swin.py:572-578 first line, 90-255, 342-366:
+ * x + proj(shifted_window_attention(qkv(LayerNorm(x)))); inference, no dropout):
+ *   x, y: MV_F32 [B][Hf][Wf][C] (the fp32 residual stream), not in place.  Cyclic shift, window partition / reverse and the shift
+ *   mask (-100) are index arithmetic; q / k / v and the attention output never leave LDS.
+ * The caller folds the LayerNorm affine into the qkv weights (W . diag(gamma), b + W . beta) and hands the weights over in
+ * FRAGMENT ORDER (a wave fetches each k16-step of a 32-channel tile as one 1 KB piece; prepared by eqxvision_amd/ops.py):
+ *   wqkv_f[group g 0..heads/4-1][tile t 0..11][j 0..C/16-1][lane 0..63][e 0..7] = Wqkv'[row(g,t) + lane%32][16*j + 8*(lane/32) + e]
+ *       with row(g,t) = (t/4)*C + 32*(4*g + t%4): q, k, v of heads 4g..4g+3;   bqkv[g][t][0..31] = the matching bias slice
+ *   wp_f[tile t 0..C/32-1][j][lane][e] = Wproj[32*t + lane%32][16*j + 8*(lane/32) + e];   bp[C]
+ *   bias64[heads][64][64] fp32: relative-position bias bias[h][query][key] padded to 64 x 64, -1e30 on key columns >= 49
+ * Supported: C = 384, 12 heads of 32, 7 x 7 windows (swin_t / swin_s stage 2). */
+int mv_swin_block_attn_supported(int Hf, int Wf, int C, int heads, int wsh, int wsw, int x_dtype);
+int mv_swin_block_attn_fwd(const void* x, const void* wqkv_f, const float* bqkv, const void* wp_f, const float* bp,
+                           const float* bias64, void* y, int B, int Hf, int Wf, int C, int heads, int wsh, int wsw, int shh,
+                           int shw, float eps, int x_dtype, mv_stream_t stream);
+
 /* The same MLP half for rows too wide for the weights to live in LDS (Swin stage 2: C = 384, hidden = 1536): both weight matrices
  * are STREAMED from L2 straight into registers, 64 token rows per workgroup, the hidden activations pass through LDS in chunks
  * of 256 units and never reach HBM.  Same formula and folding as mv_ln_mlp_fwd; the weights come in FRAGMENT ORDER (prepared once

@@ -1185,6 +1185,64 @@ def swin_attn_case(B, Hf, C, heads, ws, shift, dtype="bf16", seed=0, generic=Fal
     return run
 
 
+def swin_block_attn_case(B, Hf, shift, seed=0, C=384, heads=12, ws=7):
+    """mv_swin_block_attn_fwd (LayerNorm -> qkv -> shifted-window attention -> proj -> + x, one launch, one workgroup per window;
+    swin.py:572-578 first line) vs the float64 restatement (LayerNorm, Linear, `_swin_core_ref`, Linear), and vs the library's own
+    four-launch sequence (which must not be closer to the reference by more than rounding noise)."""
+    def run():
+        from eqxvision_amd.ops import swin_block_attn_fragments
+        L = _lib()
+        rng = _rng(seed)
+        n = ws * ws
+        x = (rng.standard_normal((B, Hf, Hf, C)) * rng.uniform(0.5, 2.0, (B, Hf, Hf, 1)) + rng.uniform(-1, 1, (B, Hf, Hf, 1))).astype(np.float32)
+        g = rng.uniform(0.5, 1.5, C).astype(np.float32)
+        be = (0.1 * rng.standard_normal(C)).astype(np.float32)
+        wq = (rng.standard_normal((3 * C, C)) / np.sqrt(C)).astype(np.float32)
+        bq = (0.1 * rng.standard_normal(3 * C)).astype(np.float32)
+        wp = (rng.standard_normal((C, C)) / np.sqrt(C)).astype(np.float32)
+        bp = (0.1 * rng.standard_normal(C)).astype(np.float32)
+        bias = (0.5 * rng.standard_normal((heads, n, n))).astype(np.float32)
+        if not L.load().mv_swin_block_attn_supported(Hf, Hf, C, heads, ws, ws, 0):
+            return {"ok": False, "err": "mv_swin_block_attn_supported says no"}
+        nx = O.layernorm_rows(x.reshape(-1, C), g, be, 1e-5).astype(np.float64)
+        qkv = (nx @ wq.astype(np.float64).T + bq).reshape(B, Hf, Hf, 3 * C)
+        ref = np.empty((B, Hf, Hf, C))
+        for i in range(B):
+            a = _swin_core_ref(qkv[i].transpose(2, 0, 1).astype(np.float32), bias, ws, heads, shift, C).transpose(1, 2, 0)
+            ref[i] = x[i] + a.reshape(-1, C).astype(np.float64).dot(wp.astype(np.float64).T).reshape(Hf, Hf, C) + bp
+        wf, bqf, wpf, b64 = swin_block_attn_fragments(wq * g[None, :], bq + wq @ be, wp, bias)
+        xd = dev(x, "fp32")
+        d = [dev(bf(wf), "bf16"), dev(bqf, "fp32"), dev(bf(wpf), "bf16"), dev(bp, "fp32"), dev(b64, "fp32")]
+        y = torch.full_like(xd, -7.0)
+        L.call("mv_swin_block_attn_fwd", xd.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+               y.data_ptr(), B, Hf, Hf, C, heads, ws, ws, shift, shift, 1e-5, 0, _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, TOL_BF16)
+        info["kernel"] = kern
+        # the four launches it replaces
+        M = B * Hf * Hf
+        gd, bed = dev(g, "fp32"), dev(be, "fp32")
+        nb = torch.empty((M, C), dtype=torch.bfloat16, device="cuda")
+        L.call("mv_layernorm_fwd", xd.data_ptr(), gd.data_ptr(), bed.data_ptr(), nb.data_ptr(), M, C, 0, 1e-5, 0, 1, _stream())
+        qd = torch.empty((M, 3 * C), dtype=torch.bfloat16, device="cuda")
+        wqd, bqd = dev(bf(wq), "bf16"), dev(bq, "fp32")
+        L.call("mv_linear_fwd", nb.data_ptr(), wqd.data_ptr(), None, bqd.data_ptr(), None, qd.data_ptr(), M, 3 * C, C, 0, 1, 1, _stream())
+        ad = torch.empty((M, C), dtype=torch.bfloat16, device="cuda")
+        biasd = dev(bias, "fp32")
+        L.call("mv_swin_window_attn_fwd", qd.data_ptr(), biasd.data_ptr(), ad.data_ptr(), B, Hf, Hf, C, heads, ws, ws, shift, shift, 1,
+               _stream())
+        y4 = torch.empty_like(xd)
+        wpd, bpd = dev(bf(wp), "bf16"), dev(bp, "fp32")
+        L.call("mv_linear_fwd", ad.data_ptr(), wpd.data_ptr(), None, bpd.data_ptr(), xd.data_ptr(), y4.data_ptr(), M, C, C, 0, 1, 0, _stream())
+        torch.cuda.synchronize()
+        e4 = float(np.abs(host(y4).astype(np.float64) - ref).max())
+        info["err_four_launches"] = e4
+        info["ok"] = bool(info["ok"] and info["err"] <= 1.5 * e4 + 1e-3)
+        return info
+    return run
+
+
 def _swin_core_ref(qkv_chw, bias, ws, heads, shift, C):
     """oracle.shifted_window_attention with the qkv projection already applied: call it with
     x = qkv viewed as a 3C-channel map and identity weights of matching size, then undo proj."""
@@ -1661,6 +1719,9 @@ def all_cases():
           ("ln_mlp/swin_stage0_f32stream", ln_mlp_case(8 * 56 * 56, "fp32", seed=520)),
           ("ln_mlp/bf16stream_ragged", ln_mlp_case(4096 + 77, "bf16", seed=521)),
           ("ln_mlp/f32stream_many_tiles", ln_mlp_case(70001, "fp32", seed=522)),
+          ("swin_block_attn/c384_14x14_B3_noshift", swin_block_attn_case(3, 14, 0, seed=530)),
+          ("swin_block_attn/c384_14x14_B3_shift3", swin_block_attn_case(3, 14, 3, seed=531)),
+          ("swin_block_attn/c384_28x28_B2_shift3", swin_block_attn_case(2, 28, 3, seed=532)),
           ("ln_mlp/stream_c384_swin_stage2_B8", ln_mlp_case(8 * 14 * 14, "fp32", seed=523, C=384, Hd=1536)),
           ("ln_mlp/stream_c384_ragged", ln_mlp_case(64 * 9 + 37, "fp32", seed=524, C=384, Hd=1536)),
           ("ln_mlp/stream_c384_many_tiles", ln_mlp_case(64 * 300 + 5, "fp32", seed=525, C=384, Hd=1536)),

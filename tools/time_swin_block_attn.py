@@ -1,0 +1,47 @@
+"""Time mv_swin_block_attn_fwd (a Swin block's attention half in one launch, one workgroup per window) against the four launches it
+replaces (LayerNorm, qkv Linear, window attention, proj Linear + residual).  usage: time_swin_block_attn.py [B ...]  (stage 2)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from eqxvision_amd import _lib as L
+from eqxvision_amd.ops import swin_block_attn_fragments
+C, heads, Hf, ws, shift = 384, 12, 14, 7, 3
+s = torch.cuda.current_stream().cuda_stream
+
+def t(fn, n=30):
+    for _ in range(3): fn()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+rng = np.random.default_rng(0)
+wq = (rng.standard_normal((3 * C, C)) / C ** 0.5).astype(np.float32); bq = (0.1 * rng.standard_normal(3 * C)).astype(np.float32)
+wp = (rng.standard_normal((C, C)) / C ** 0.5).astype(np.float32); bp = (0.1 * rng.standard_normal(C)).astype(np.float32)
+bias = (0.5 * rng.standard_normal((heads, 49, 49))).astype(np.float32)
+wf, bqf, wpf, b64 = swin_block_attn_fragments(wq, bq, wp, bias)
+cu = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).cuda().to(dt)
+wfd, bqfd, wpfd, bpd, b64d = cu(wf, torch.bfloat16), cu(bqf), cu(wpf, torch.bfloat16), cu(bp), cu(b64)
+wqd, bqd, wpd, biasd = cu(wq, torch.bfloat16), cu(bq), cu(wp, torch.bfloat16), cu(bias)
+g, be = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+for B in [int(a) for a in sys.argv[1:]] or [64, 128]:
+    M = B * Hf * Hf
+    x = torch.randn(B, Hf, Hf, C, device="cuda")
+    y, y4 = torch.empty_like(x), torch.empty_like(x)
+    nb = torch.empty(M, C, device="cuda", dtype=torch.bfloat16); qd = torch.empty(M, 3 * C, device="cuda", dtype=torch.bfloat16)
+    ad = torch.empty(M, C, device="cuda", dtype=torch.bfloat16)
+
+    def fused():
+        L.call("mv_swin_block_attn_fwd", x.data_ptr(), wfd.data_ptr(), bqfd.data_ptr(), wpfd.data_ptr(), bpd.data_ptr(), b64d.data_ptr(),
+               y.data_ptr(), B, Hf, Hf, C, heads, ws, ws, shift, shift, 1e-5, 0, s)
+
+    def unfused():
+        L.call("mv_layernorm_fwd", x.data_ptr(), g.data_ptr(), be.data_ptr(), nb.data_ptr(), M, C, 0, 1e-5, 0, 1, s)
+        L.call("mv_linear_fwd", nb.data_ptr(), wqd.data_ptr(), None, bqd.data_ptr(), None, qd.data_ptr(), M, 3 * C, C, 0, 1, 1, s)
+        L.call("mv_swin_window_attn_fwd", qd.data_ptr(), biasd.data_ptr(), ad.data_ptr(), B, Hf, Hf, C, heads, ws, ws, shift, shift, 1, s)
+        L.call("mv_linear_fwd", ad.data_ptr(), wpd.data_ptr(), None, bpd.data_ptr(), x.data_ptr(), y4.data_ptr(), M, C, C, 0, 1, 0, s)
+
+    uf, uu = t(fused), t(unfused)
+    fused(); unfused(); torch.cuda.synchronize()
+    print(f"B={B} ({B * 4} windows): fused {uf:.1f} us   four launches {uu:.1f} us   max|diff| {(y - y4).abs().max().item():.4f}")
