@@ -1,13 +1,14 @@
 // The attention half of a Swin block in ONE launch, one workgroup per window (gfx950):
 //     y = x + proj(window_attention(qkv(LayerNorm(x))))          (swin.py:572-578 first line, 90-255, 342-366)
-// for C = 384 (stage 2 of swin_t / swin_s: 12 heads of 32, 7 x 7 windows, 14 x 14 maps -> 4 windows per image, one round of
-// 256 workgroups at 64 images).  The un-fused path is four launches (LayerNorm, qkv Linear, window attention, proj Linear +
+// for heads of 32 channels and 7 x 7 windows: C = 384 (stage 2 of swin_t / swin_s: 12 heads, one window per workgroup), C = 192
+// (stage 1: 6 heads, TWO windows per workgroup) and C = 96 (stage 0: 3 heads, FOUR windows per workgroup) -- windows x heads-per-
+// group = 4 in every case, so the same 24-MFMA-tile GEMM phases and the same 8 attention jobs fill the 8 waves.  The un-fused path is four launches (LayerNorm, qkv Linear, window attention, proj Linear +
 // residual) that move the 1152-channel qkv tensor and the attention output through HBM; here a window's 49 token rows are
 // gathered once (cyclic shift + window partition = index arithmetic), and q / k / v / the attention output live in LDS:
 //
 //   phase 0   LayerNorm of the 49 rows (fp32 statistics) -> bf16 rows in LDS (rows 49..63 zero; LayerNorm affine folded into
 //             the qkv weights by the host)
-//   3 x       heads in groups of four: [q | k | v] of the group = 12 channel tiles x 2 token blocks = 24 MFMA tiles, three per
+//   3 x       heads in groups of HG = 4 / windows: [q | k | v] of the group = 3 HG channel tiles x (2 x windows) token blocks = 24 MFMA tiles, three per
 //             wave (A = weights straight from L2 in fragment order, B = token rows from LDS, as ln_mlp_stream.hip);
 //             q, k go to LDS token-major, v TRANSPOSED element by element in the key order the P.V product wants;
 //             then attention, wave = (head of the group, query block of 32): S^T = K.Q^T puts one query per lane, scale +
@@ -26,8 +27,8 @@ namespace {
 
 struct SwinBAP {
     const float* x;        // [B][Hf][Wf][C] fp32 residual stream
-    const bf16_t* wqkv;    // [C/128 groups][12 tiles: q0..3 k0..3 v0..3][C/16][64][8]
-    const float* bqkv;     // [groups][12][32]
+    const bf16_t* wqkv;    // [3 groups][3 HG tiles: q heads, k heads, v heads of the group][C/16][64][8]
+    const float* bqkv;     // [groups][3 HG][32]
     const bf16_t* wp;      // [C/32 tiles][C/16][64][8]
     const float* bp;       // [C]
     const float* bias;     // [heads][64][64]: relative-position bias, -1e30 on padded keys
@@ -36,29 +37,37 @@ struct SwinBAP {
     float eps;
 };
 
-template <int C>
+template <int C, int NWIN>
 __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
-    constexpr int NH = C / 32, NG = NH / 4, KS = C / 16, NTOK = 49, WS = 7, D = 4;
-    static_assert(NH % 4 == 0 && C % 48 == 0 && KS % D == 0, "C = 384 layout");
-    constexpr int XROW = C * 2 + 16;                     // token rows of the normalised input / the attention output
+    constexpr int NH = C / 32, HG = 4 / NWIN, NG = NH / HG, KS = C / 16, NTOK = 49, WS = 7;
+    // k-loop: unrolled by U; weight fragments D steps ahead, token fragments 2 steps ahead in a ring of PB (all static indices)
+    constexpr int U = (KS % 4 == 0) ? 4 : 6, D = (KS % 4 == 0) ? 4 : 3, PB = (KS % 4 == 0) ? 4 : 3;
+    constexpr int NTB = 2 * NWIN, TR = 64 * NWIN, GT = 3 * HG, NCT = C / 32;      // token blocks / rows per workgroup; tiles per group
+    static_assert(NWIN * HG == 4 && NH % HG == 0 && C % 48 == 0 && KS % U == 0 && U % D == 0 && U % PB == 0 && GT * NTB == 24 && NCT * NTB == 24, "layout");
+    // token rows of the normalised input / the attention output: 2 C bytes + 16 of padding (conflict-free 16-byte fragment reads);
+    // C = 96: the padding would not fit -- 16 bytes after every FOURTH row do the same job (192-byte rows start 48 dwords apart)
+    constexpr int XBYTES = C == 96 ? TR * 192 + (TR / 4) * 16 : TR * (C * 2 + 16);
+    auto xoff = [](int r) -> int { return C == 96 ? r * 192 + (r >> 2) * 16 : r * (C * 2 + 16); };
     constexpr int QROW = 80, VROW = 144;                 // q, k rows: 32 dh (+ pad); v^T rows: 64 keys (+ pad)
     constexpr int LDS_NX = 0;
-    constexpr int LDS_Q = 64 * XROW;                     // [4 heads][64 tokens][QROW]
+    constexpr int LDS_Q = XBYTES;                        // [4 (head of group, window)][64 tokens][QROW]
     constexpr int LDS_K = LDS_Q + 4 * 64 * QROW;
-    constexpr int LDS_V = LDS_K + 4 * 64 * QROW;         // [4 heads][32 dh][VROW]
+    constexpr int LDS_V = LDS_K + 4 * 64 * QROW;         // [4][32 dh][VROW]
     constexpr int LDS_O = LDS_V + 4 * 32 * VROW;
-    constexpr int LDS_REG = LDS_O + 64 * XROW;           // int[64]: shift-mask region per token
+    constexpr int LDS_REG = LDS_O + XBYTES;              // int[NWIN][64]: shift-mask region per token
     constexpr int YROW = C * 4 + 16;
-    static_assert(64 * YROW <= LDS_O, "result tile must fit below the attention output");
+    static_assert(TR * YROW <= LDS_O && LDS_REG + NWIN * 256 <= 160 * 1024, "result tile must fit below the attention output");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
-    const int b = blockIdx.x / p.nW, wloc = blockIdx.x - b * p.nW;
-    const int wy = wloc / p.nWw, wx = wloc - wy * p.nWw;
+    const int wgs = p.nW / NWIN;                          // workgroups per image
+    const int b = blockIdx.x / wgs, wloc0 = (blockIdx.x - b * wgs) * NWIN;
     const bool shifted = (p.shh + p.shw) > 0;
-    auto tok_row = [&](int t) -> long long {            // token t of this window -> its row in x / y (un-rolled position)
+    auto tok_row = [&](int r) -> long long {            // row r = 64 * window + token -> its row in x / y (un-rolled position)
+        const int wloc = wloc0 + (r >> 6), t = r & 63;
+        const int wy = wloc / p.nWw, wx = wloc - wy * p.nWw;
         const int ty = t / WS, tx = t - ty * WS;
         int oy = wy * WS + ty + p.shh, ox = wx * WS + tx + p.shw;
         if (oy >= p.Hf) oy -= p.Hf;
@@ -66,26 +75,33 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
         return ((long long)b * p.Hf + oy) * p.Wf + ox;
     };
 
-    // ---------------- weight-fragment streams: two channel tiles per wave (units 3w .. 3w+2 of 12 tiles x 2 token blocks) ------
-    const int ta = (3 * wave) >> 1;                                    // first tile; the second is ta + 1
-    const bool odd = wave & 1;                                         // even: (ta,0) (ta,1) (ta+1,0); odd: (ta,1) (ta+1,0) (ta+1,1)
-    auto tile_base = [&](const bf16_t* w, int tile) -> const uint4* { return (const uint4*)w + (size_t)tile * KS * 64 + lane; };
+    // ---------------- weight-fragment streams: units 3w .. 3w+2 of (tiles x NTB token blocks) touch at most two channel tiles ------
+    const int ta = (3 * wave) / NTB;                                   // first tile; the second stream is tile ta + 1 (clamped)
+    const int u_tile[3] = {(3 * wave) / NTB, (3 * wave + 1) / NTB, (3 * wave + 2) / NTB};
+    const int u_tb[3] = {(3 * wave) % NTB, (3 * wave + 1) % NTB, (3 * wave + 2) % NTB};
+    const int pat = (u_tile[1] - ta) + 2 * (u_tile[2] - ta);           // which stream each unit multiplies with: 0 = 000, 2 = 001, 3 = 011
+    auto tile_base = [&](const bf16_t* w, int tile, int ntiles) -> const uint4* {
+        tile = tile < ntiles ? tile : ntiles - 1;
+        return (const uint4*)w + (size_t)tile * KS * 64 + lane;
+    };
     uint4 a0[D], a1[D];
     {
-        const uint4* s0 = tile_base(p.wqkv, ta);
-        const uint4* s1 = tile_base(p.wqkv, ta + 1);
+        const uint4* s0 = tile_base(p.wqkv, ta, GT);
+        const uint4* s1 = tile_base(p.wqkv, ta + 1, GT);
 #pragma unroll
         for (int d = 0; d < D; ++d) { a0[d] = s0[d * 64]; a1[d] = s1[d * 64]; }
     }
 
     // ---------------- phase 0: gather + LayerNorm -> LDS ----------------------------------------------------------------------
     {
-        constexpr int LPR = C / 12, RPP = 64 / LPR, NP = 8 / RPP;
+        constexpr int LPR = C / 12, RPP = 64 / LPR, RPW = TR / 8, NP = RPW / RPP;      // lanes per row (3 float4 each), rows per pass / wave
+        static_assert(NP * RPP == RPW, "whole passes");
         const int lr = lane / LPR, lq = lane % LPR;
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {
-            const int r = 8 * wave + ps * RPP + lr;
-            const float4* src = (const float4*)(p.x + tok_row(r < NTOK ? r : NTOK - 1) * C);
+            const int r = RPW * wave + ps * RPP + lr;
+            const bool real = (r & 63) < NTOK;
+            const float4* src = (const float4*)(p.x + tok_row(real ? r : (r & ~63)) * C);
             float4 v[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) v[i] = src[lq + LPR * i];
@@ -103,17 +119,19 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
             }
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
-            const float rstd = r < NTOK ? rsqrtf(q * (1.0f / C) + p.eps) : 0.f;        // padded rows: zeros
+            const float rstd = real ? rsqrtf(q * (1.0f / C) + p.eps) : 0.f;            // padded rows: zeros
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 uint2 u;
                 u.x = pack_bf2(v[i].x * rstd, v[i].y * rstd);
                 u.y = pack_bf2(v[i].z * rstd, v[i].w * rstd);
-                *(uint2*)(smem + LDS_NX + r * XROW + (lq + LPR * i) * 8) = u;
+                *(uint2*)(smem + LDS_NX + xoff(r) + (lq + LPR * i) * 8) = u;
             }
         }
-        if (tid < 64) {                                  // shift-mask region of every token (rolled coordinates, swin.py:190-209)
-            const int t = tid < NTOK ? tid : NTOK - 1;
+        if (tid < TR) {                                  // shift-mask region of every token (rolled coordinates, swin.py:190-209)
+            const int wloc = wloc0 + (tid >> 6);
+            const int wy = wloc / p.nWw, wx = wloc - wy * p.nWw;
+            const int t = (tid & 63) < NTOK ? (tid & 63) : NTOK - 1;
             const int ty = t / WS, tx = t - ty * WS;
             const int yy = wy * WS + ty, xx = wx * WS + tx;
             const int rh = (yy < p.Hf - WS) ? 0 : (yy < p.Hf - p.shh ? 1 : 2);
@@ -123,69 +141,73 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
     }
     __syncthreads();
 
-    // ---------------- the three-tiles-per-wave GEMM: acc[i] = unit i of this wave over K = C --------------------------------------
+    // ---------------- the three-units-per-wave GEMM: acc[i] = unit i of this wave over K = C ----------------------------------------
     f32x16 acc[3];
-    // src: LDS byte offset of the token rows (B operand); cur0 / cur1: this phase's two fragment streams; nx0 / nx1: the next phase's
-    auto gemm3 = [&](int src, const uint4* cur0, const uint4* cur1, const uint4* nx0, const uint4* nx1) {
+    // src: LDS byte offset of the token rows (B operand); cur0 / cur1: this phase's two fragment streams; nx0 / nx1: the next phase's.
+    // PAT: which stream each unit multiplies with (bit i-1 of PAT = unit i uses the second stream) -- a template value, chosen once
+    // per wave: no selects or branches inside the loop.
+    auto gemm3 = [&](auto patc, int src, const uint4* cur0, const uint4* cur1, const uint4* nx0, const uint4* nx1)
+        __attribute__((always_inline)) {        // (not inlined, the captured accumulators and fragment rings live in scratch: 18x slower)
+        constexpr int PAT = decltype(patc)::value;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-        const char* xb = smem + src + fr * XROW + fh * 16;
-        bf16x8 bq[4][2];
+        const char* xb[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xb[i] = smem + src + xoff(32 * u_tb[i] + fr) + fh * 16;
+        bf16x8 bq[PB][3];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) bq[t][tb] = *(const bf16x8*)(xb + tb * 32 * XROW + t * 32);
-        for (int j0 = 0; j0 < KS; j0 += D) {
+            for (int i = 0; i < 3; ++i) bq[t][i] = *(const bf16x8*)(xb[i] + t * 32);
+        for (int j0 = 0; j0 < KS; j0 += U) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
+            for (int d = 0; d < U; ++d) {
                 const int j = j0 + d;
                 const int jn = j + 2 < KS ? j + 2 : KS - 1;
                 const bool in = j + D < KS;
                 const uint4* n0 = in ? cur0 + (size_t)(j + D) * 64 : nx0 + (size_t)(j + D - KS) * 64;
                 const uint4* n1 = in ? cur1 + (size_t)(j + D) * 64 : nx1 + (size_t)(j + D - KS) * 64;
                 __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 f0 = __builtin_bit_cast(bf16x8, a0[d]);
-                const bf16x8 f1 = __builtin_bit_cast(bf16x8, a1[d]);
-                a0[d] = *n0;
-                a1[d] = *n1;
-                const bf16x8 b0 = bq[d][0], b1 = bq[d][1];
-                if (!odd) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, b0, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, b1, acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, b0, acc[2], 0, 0, 0);
-                } else {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, b1, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, b0, acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, b1, acc[2], 0, 0, 0);
-                }
+                const bf16x8 f0 = __builtin_bit_cast(bf16x8, a0[d % D]);
+                const bf16x8 f1 = __builtin_bit_cast(bf16x8, a1[d % D]);
+                a0[d % D] = *n0;
+                a1[d % D] = *n1;
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, bq[d % PB][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((PAT & 1) ? f1 : f0, bq[d % PB][1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((PAT & 2) ? f1 : f0, bq[d % PB][2], acc[2], 0, 0, 0);
 #pragma unroll
-                for (int tb = 0; tb < 2; ++tb) bq[(d + 2) % 4][tb] = *(const bf16x8*)(xb + tb * 32 * XROW + jn * 32);
+                for (int i = 0; i < 3; ++i) bq[(d + 2) % PB][i] = *(const bf16x8*)(xb[i] + jn * 32);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
-    // unit i of this wave -> (tile, token block)
-    auto unit_tile = [&](int i) -> int { return odd ? (i == 0 ? ta : ta + 1) : (i == 2 ? ta + 1 : ta); };
-    auto unit_tb = [&](int i) -> int { return odd ? (i == 1 ? 0 : 1) : (i == 1 ? 1 : 0); };
+    auto gemm = [&](int src, const uint4* cur0, const uint4* cur1, const uint4* nx0, const uint4* nx1) __attribute__((always_inline)) {
+        if (pat == 0) gemm3(std::integral_constant<int, 0>{}, src, cur0, cur1, nx0, nx1);
+        else if (pat == 2) gemm3(std::integral_constant<int, 2>{}, src, cur0, cur1, nx0, nx1);
+        else gemm3(std::integral_constant<int, 3>{}, src, cur0, cur1, nx0, nx1);
+    };
 
     const int* regl = (const int*)(smem + LDS_REG);
     const float scale = rsqrtf(32.0f);
 
     for (int g = 0; g < NG; ++g) {
-        // ---------------- q | k | v of heads 4g .. 4g+3 ----------------------------------------------------------------------------
-        const bf16_t* wg = p.wqkv + (size_t)g * 12 * KS * 64 * 8;
-        const bf16_t* wn = g + 1 < NG ? p.wqkv + (size_t)(g + 1) * 12 * KS * 64 * 8 : p.wp;      // next phase: next group, then proj
-        gemm3(LDS_NX, tile_base(wg, ta), tile_base(wg, ta + 1), tile_base(wn, ta), tile_base(wn, ta + 1));
+        // ---------------- q | k | v of heads HG g .. HG g + HG - 1, all windows of the workgroup -----------------------------------------
+        const bf16_t* wg = p.wqkv + (size_t)g * GT * KS * 64 * 8;
+        const bool last = g + 1 == NG;
+        const bf16_t* wn = last ? p.wp : wg + (size_t)GT * KS * 64 * 8;                 // next phase: next group, then proj
+        const int ntn = last ? NCT : GT;
+        gemm(LDS_NX, tile_base(wg, ta, GT), tile_base(wg, ta + 1, GT), tile_base(wn, ta, ntn), tile_base(wn, ta + 1, ntn));
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int tile = unit_tile(i), tb = unit_tb(i);
-            const int kind = tile >> 2, hl = tile & 3;                  // 0 q, 1 k, 2 v; head of the group
-            const float* bb = p.bqkv + ((size_t)g * 12 + tile) * 32 + 4 * fh;
-            const int tok = 32 * tb + fr;
+            const int tile = u_tile[i], tb = u_tb[i];
+            const int kind = tile / HG, hl = tile - kind * HG;          // 0 q, 1 k, 2 v; head of the group
+            const int win = tb >> 1, slotq = hl * NWIN + win;           // (head of group, window) slot of the q / k / v buffers
+            const float* bb = p.bqkv + ((size_t)g * GT + tile) * 32 + 4 * fh;
+            const int tok = 32 * (tb & 1) + fr;
             if (kind < 2) {
-                char* dst = smem + (kind == 0 ? LDS_Q : LDS_K) + (hl * 64 + tok) * QROW + 8 * fh;
+                char* dst = smem + (kind == 0 ? LDS_Q : LDS_K) + (slotq * 64 + tok) * QROW + 8 * fh;
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const float4 bv = *(const float4*)(bb + 8 * gq);
@@ -195,11 +217,11 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
                     *(uint2*)(dst + 16 * gq) = u;
                 }
             } else {
-                // v^T[dh][slot(key)]: the 8 keys a lane feeds to one P.V step sit next to each other (slot order (tile, pair of
-                // groups, lane half, group parity, r)) -- the lane's own position decides the slot of its token
+                // v^T[dh][slot(key)]: the 8 keys a lane feeds to one P.V step sit next to each other (slot order (token block, pair
+                // of groups, lane half, group parity, r)) -- the lane's own position decides the slot of its token
                 const int kg = fr >> 3, khh = (fr >> 2) & 1, kr = fr & 3;
-                const int slot = ((tb * 2 + (kg >> 1)) * 2 + khh) * 8 + (kg & 1) * 4 + kr;
-                char* dst = smem + LDS_V + hl * 32 * VROW + slot * 2;
+                const int slot = (((tb & 1) * 2 + (kg >> 1)) * 2 + khh) * 8 + (kg & 1) * 4 + kr;
+                char* dst = smem + LDS_V + slotq * 32 * VROW + slot * 2;
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const float4 bv = *(const float4*)(bb + 8 * gq);
@@ -211,12 +233,13 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
             }
         }
         __syncthreads();
-        // ---------------- attention: wave = (head hl of the group, query block qb) ------------------------------------------------
+        // ---------------- attention: wave = ((head of the group, window), query block qb) ------------------------------------------------
         {
-            const int hl = wave >> 1, qb = wave & 1, h = 4 * g + hl;
+            const int slotq = wave >> 1, qb = wave & 1;
+            const int hl = slotq / NWIN, win = slotq - hl * NWIN, h = HG * g + hl;
             const int qtok = 32 * qb + fr;
-            const char* qp = smem + LDS_Q + (hl * 64 + qtok) * QROW + fh * 16;
-            const char* kp = smem + LDS_K + (hl * 64 + fr) * QROW + fh * 16;
+            const char* qp = smem + LDS_Q + (slotq * 64 + qtok) * QROW + fh * 16;
+            const char* kp = smem + LDS_K + (slotq * 64 + fr) * QROW + fh * 16;
             bf16x8 qf[2], kf[2][2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -233,7 +256,8 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
                 for (int j = 0; j < 2; ++j) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][j], qf[j], s[kt], 0, 0, 0);
             }
             const float* brow = p.bias + ((size_t)h * 64 + qtok) * 64;
-            const int qreg = regl[qtok];
+            const int* rl = regl + 64 * win;
+            const int qreg = rl[qtok];
             float mx = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -241,7 +265,7 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
                 for (int gq = 0; gq < 4; ++gq) {
                     const int key0 = 32 * kt + 8 * gq + 4 * fh;
                     const float4 bv = *(const float4*)(brow + key0);
-                    const int4 kr = *(const int4*)(regl + key0);
+                    const int4 kr = *(const int4*)(rl + key0);
                     const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
                     const int rr[4] = {kr.x, kr.y, kr.z, kr.w};
 #pragma unroll
@@ -267,7 +291,7 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
             f32x16 o;
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[e] = 0.f;
-            const char* vp = smem + LDS_V + (hl * 32 + fr) * VROW + fh * 16;
+            const char* vp = smem + LDS_V + (slotq * 32 + fr) * VROW + fh * 16;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -280,7 +304,7 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
                     const bf16x8 vf = *(const bf16x8*)(vp + (kt * 2 + gp) * 32);
                     o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pf), o, 0, 0, 0);
                 }
-            char* od = smem + LDS_O + qtok * XROW + (32 * h + 4 * fh) * 2;
+            char* od = smem + LDS_O + xoff(64 * win + qtok) + (32 * h + 4 * fh) * 2;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 uint2 u;
@@ -293,10 +317,10 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
     }
 
     // ---------------- proj over the attention output ---------------------------------------------------------------------------------
-    gemm3(LDS_O, tile_base(p.wp, ta), tile_base(p.wp, ta + 1), tile_base(p.wp, ta), tile_base(p.wp, ta + 1));
+    gemm(LDS_O, tile_base(p.wp, ta, NCT), tile_base(p.wp, ta + 1, NCT), tile_base(p.wp, ta, NCT), tile_base(p.wp, ta + 1, NCT));
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int tile = unit_tile(i), tb = unit_tb(i);
+        const int tile = u_tile[i], tb = u_tb[i];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int ch = 32 * tile + 8 * gq + 4 * fh;
@@ -309,7 +333,7 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
     // ---------------- epilogue: whole rows, + residual, back to the tokens' own positions -----------------------------------------------
     {
         constexpr int QPR = C / 4;
-        constexpr int TOT = NTOK * QPR;
+        constexpr int TOT = NWIN * NTOK * QPR;
         constexpr int NIT = (TOT + 511) / 512;
         float4 xr[NIT];
         long long rows[NIT];
@@ -317,7 +341,8 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
         for (int i = 0; i < NIT; ++i) {
             int idx = tid + 512 * i;
             idx = idx < TOT ? idx : TOT - 1;
-            const int r = idx / QPR, q = idx - r * QPR;
+            const int rr = idx / QPR, q = idx - rr * QPR;                 // rr: real token index over the windows
+            const int r = 64 * (rr / NTOK) + rr % NTOK;
             rows[i] = tok_row(r) * C + 4 * q;
             xr[i] = *(const float4*)(p.x + rows[i]);
         }
@@ -325,7 +350,8 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
         for (int i = 0; i < NIT; ++i) {
             const int idx = tid + 512 * i;
             if (idx < TOT) {
-                const int r = idx / QPR, q = idx - r * QPR;
+                const int rr = idx / QPR, q = idx - rr * QPR;
+                const int r = 64 * (rr / NTOK) + rr % NTOK;
                 const float4 a = *(const float4*)(smem + r * YROW + q * 16);
                 *(float4*)(p.y + rows[i]) = make_float4(a.x + xr[i].x, a.y + xr[i].y, a.z + xr[i].z, a.w + xr[i].w);
             }
@@ -339,9 +365,14 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
 
 extern "C" {
 
+static int swin_block_attn_nwin(int C) { return C == 384 ? 1 : (C == 192 ? 2 : (C == 96 ? 4 : 0)); }
+
 int mv_swin_block_attn_supported(int Hf, int Wf, int C, int heads, int wsh, int wsw, int x_dtype) {
     if (mv::get_flag("no_swin_block_attn")) return 0;
-    return x_dtype == MV_F32 && C == 384 && heads == 12 && wsh == 7 && wsw == 7 && Hf % 7 == 0 && Wf % 7 == 0 && Hf >= 14 && Wf >= 14;
+    const int nwin = swin_block_attn_nwin(C);
+    if (!nwin || x_dtype != MV_F32 || heads * 32 != C || wsh != 7 || wsw != 7 || Hf % 7 || Wf % 7 || Hf < 14 || Wf < 14) return 0;
+    if (mv::get_flag("swin_block_attn_only") && mv::get_flag("swin_block_attn_only") != C) return 0;
+    return ((Hf / 7) * (Wf / 7)) % nwin == 0;
 }
 
 int mv_swin_block_attn_fwd(const void* x, const void* wqkv_f, const float* bqkv, const void* wp_f, const float* bp, const float* bias64,
@@ -359,11 +390,21 @@ int mv_swin_block_attn_fwd(const void* x, const void* wqkv_f, const float* bqkv,
     SwinBAP p;
     p.x = (const float*)x; p.wqkv = (const bf16_t*)wqkv_f; p.bqkv = bqkv; p.wp = (const bf16_t*)wp_f; p.bp = bp; p.bias = bias64;
     p.y = (float*)y; p.Hf = Hf; p.Wf = Wf; p.shh = shh; p.shw = shw; p.nWw = Wf / 7; p.nW = (Hf / 7) * (Wf / 7); p.eps = eps;
-    constexpr int SMEM = 2 * 64 * (384 * 2 + 16) + 2 * 4 * 64 * 80 + 4 * 32 * 144 + 256;
-    auto kern = swin_block_attn_kernel<384>;
-    MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    set_kernel_name("swin_block_attn_c384");
-    hipLaunchKernelGGL(kern, dim3((unsigned)(B * p.nW)), dim3(512), SMEM, stream, p);
+    const int nwin = swin_block_attn_nwin(C);
+    const int tr = 64 * nwin;
+    const int xbytes = C == 96 ? tr * 192 + (tr / 4) * 16 : tr * (C * 2 + 16);
+    const int smem = 2 * xbytes + 2 * 4 * 64 * 80 + 4 * 32 * 144 + nwin * 256;
+    const dim3 grid((unsigned)(B * (p.nW / nwin)));
+#define MV_SBA_GO(CC, NW)                                                                                            \
+    do {                                                                                                             \
+        auto kern = swin_block_attn_kernel<CC, NW>;                                                                  \
+        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));            \
+        hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p);                                                  \
+    } while (0)
+    if (C == 384) { set_kernel_name("swin_block_attn_c384"); MV_SBA_GO(384, 1); }
+    else if (C == 192) { set_kernel_name("swin_block_attn_c192"); MV_SBA_GO(192, 2); }
+    else { set_kernel_name("swin_block_attn_c96"); MV_SBA_GO(96, 4); }
+#undef MV_SBA_GO
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

@@ -997,11 +997,12 @@ def swin_block_attn_fragments(wqkv: np.ndarray, bqkv: np.ndarray, wp: np.ndarray
     the operand layouts of mv_swin_block_attn_fwd (header)."""
     C = wp.shape[0]
     heads = C // 32
-    G = heads // 4
-    rows = np.array([[(t // 4) * C + 32 * (4 * g + t % 4) for t in range(12)] for g in range(G)])                 # [G][12]
-    w = wqkv[(rows[:, :, None] + np.arange(32)[None, None, :])]                                                   # [G][12][32][C]
-    wf = w.reshape(G, 12, 32, C // 16, 2, 8).transpose(0, 1, 3, 4, 2, 5)                                           # (g, t, j, h, m, e)
-    bf_ = bqkv[(rows[:, :, None] + np.arange(32)[None, None, :])]                                                  # [G][12][32]
+    HG = {384: 4, 192: 2, 96: 1}[C]                       # heads per group (x windows per workgroup = 4)
+    G, GT = heads // HG, 3 * HG                            # always 3 groups; tiles per group: q heads, k heads, v heads
+    rows = np.array([[(t // HG) * C + 32 * (HG * g + t % HG) for t in range(GT)] for g in range(G)])              # [G][GT]
+    w = wqkv[(rows[:, :, None] + np.arange(32)[None, None, :])]                                                   # [G][GT][32][C]
+    wf = w.reshape(G, GT, 32, C // 16, 2, 8).transpose(0, 1, 3, 4, 2, 5)                                           # (g, t, j, h, m, e)
+    bf_ = bqkv[(rows[:, :, None] + np.arange(32)[None, None, :])]                                                  # [G][GT][32]
     wpf = wp.reshape(C // 32, 32, C // 16, 2, 8).transpose(0, 2, 3, 1, 4)                                          # (t, j, h, m, e)
     n = bias.shape[1]
     b64 = np.zeros((heads, 64, 64), np.float32)

@@ -224,11 +224,13 @@ int mv_ln_mlp_fwd(const void* x, const void* w1, const float* b1, const void* w2
  *   mask (-100) are index arithmetic; q / k / v and the attention output never leave LDS.
  * The caller folds the LayerNorm affine into the qkv weights (W . diag(gamma), b + W . beta) and hands the weights over in
  * FRAGMENT ORDER (a wave fetches each k16-step of a 32-channel tile as one 1 KB piece; prepared by eqxvision_amd/ops.py):
- *   wqkv_f[group g 0..heads/4-1][tile t 0..11][j 0..C/16-1][lane 0..63][e 0..7] = Wqkv'[row(g,t) + lane%32][16*j + 8*(lane/32) + e]
- *       with row(g,t) = (t/4)*C + 32*(4*g + t%4): q, k, v of heads 4g..4g+3;   bqkv[g][t][0..31] = the matching bias slice
+ *   wqkv_f[group g 0..2][tile t 0..3*HG-1][j 0..C/16-1][lane 0..63][e 0..7] = Wqkv'[row(g,t) + lane%32][16*j + 8*(lane/32) + e]
+ *       with HG = heads/3 heads per group and row(g,t) = (t/HG)*C + 32*(HG*g + t%HG): q, k, v of heads HG*g .. HG*g+HG-1;
+ *       bqkv[g][t][0..31] = the matching bias slice
  *   wp_f[tile t 0..C/32-1][j][lane][e] = Wproj[32*t + lane%32][16*j + 8*(lane/32) + e];   bp[C]
  *   bias64[heads][64][64] fp32: relative-position bias bias[h][query][key] padded to 64 x 64, -1e30 on key columns >= 49
- * Supported: C = 384, 12 heads of 32, 7 x 7 windows (swin_t / swin_s stage 2). */
+ * Supported: heads of 32 channels, 7 x 7 windows, C = 384 / 192 / 96 (swin_t / swin_s stages 2 / 1 / 0: one / two / four windows
+ * per workgroup; the windows of an image must divide by that). */
 int mv_swin_block_attn_supported(int Hf, int Wf, int C, int heads, int wsh, int wsw, int x_dtype);
 int mv_swin_block_attn_fwd(const void* x, const void* wqkv_f, const float* bqkv, const void* wp_f, const float* bp,
                            const float* bias64, void* y, int B, int Hf, int Wf, int C, int heads, int wsh, int wsw, int shh,

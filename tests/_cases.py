@@ -1722,6 +1722,12 @@ def all_cases():
           ("swin_block_attn/c384_14x14_B3_noshift", swin_block_attn_case(3, 14, 0, seed=530)),
           ("swin_block_attn/c384_14x14_B3_shift3", swin_block_attn_case(3, 14, 3, seed=531)),
           ("swin_block_attn/c384_28x28_B2_shift3", swin_block_attn_case(2, 28, 3, seed=532)),
+          ("swin_block_attn/c192_28x28_B2_noshift", swin_block_attn_case(2, 28, 0, seed=533, C=192, heads=6)),
+          ("swin_block_attn/c192_28x28_B3_shift3", swin_block_attn_case(3, 28, 3, seed=534, C=192, heads=6)),
+          ("swin_block_attn/c192_14x14_B2_shift3", swin_block_attn_case(2, 14, 3, seed=535, C=192, heads=6)),
+          ("swin_block_attn/c96_56x56_B1_noshift", swin_block_attn_case(1, 56, 0, seed=536, C=96, heads=3)),
+          ("swin_block_attn/c96_56x56_B2_shift3", swin_block_attn_case(2, 56, 3, seed=537, C=96, heads=3)),
+          ("swin_block_attn/c96_14x14_B3_shift3", swin_block_attn_case(3, 14, 3, seed=538, C=96, heads=3)),
           ("ln_mlp/stream_c384_swin_stage2_B8", ln_mlp_case(8 * 14 * 14, "fp32", seed=523, C=384, Hd=1536)),
           ("ln_mlp/stream_c384_ragged", ln_mlp_case(64 * 9 + 37, "fp32", seed=524, C=384, Hd=1536)),
           ("ln_mlp/stream_c384_many_tiles", ln_mlp_case(64 * 300 + 5, "fp32", seed=525, C=384, Hd=1536)),

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from eqxvision_amd import _lib as L
 from eqxvision_amd.ops import swin_block_attn_fragments
-C, heads, Hf, ws, shift = 384, 12, 14, 7, 3
+C = int(os.environ.get("SBA_C", "384")); heads = C // 32; Hf = {384: 14, 192: 28, 96: 56}[C]; ws, shift = 7, 3
 s = torch.cuda.current_stream().cuda_stream
 
 def t(fn, n=30):
@@ -44,4 +44,4 @@ for B in [int(a) for a in sys.argv[1:]] or [64, 128]:
 
     uf, uu = t(fused), t(unfused)
     fused(); unfused(); torch.cuda.synchronize()
-    print(f"B={B} ({B * 4} windows): fused {uf:.1f} us   four launches {uu:.1f} us   max|diff| {(y - y4).abs().max().item():.4f}")
+    print(f"C={C} B={B} ({B * (Hf // 7) ** 2} windows): fused {uf:.1f} us   four launches {uu:.1f} us   max|diff| {(y - y4).abs().max().item():.4f}")
