@@ -783,6 +783,65 @@ __global__ void patch_merge_vec_kernel(const uint4* __restrict__ x, uint4* __res
     }
 }
 
+// Swin patch merging (swin.py:23-31, 61-65): the 2 x 2 neighbourhood gather and the LayerNorm over its 4 C channels in ONE pass --
+// a wave per output row reads the four C-float segments straight from the fp32 map ([x[0::2,0::2], x[1::2,0::2], x[0::2,1::2],
+// x[1::2,1::2]] order), two-pass statistics in registers, bf16 (or fp32) rows out; the gathered 4C map is never materialised.
+// NV = float4 per lane (4C / 256 rounded up); H, W even.
+template <int NV, typename OutT>
+__global__ __launch_bounds__(256) void patch_merge_ln_kernel(const float* __restrict__ x, const float* __restrict__ gam,
+                                                             const float* __restrict__ bet, OutT* __restrict__ y, int B, int H, int W,
+                                                             int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int Ho = H / 2, Wo = W / 2, c4 = C / 4, q4 = 4 * c4;          // float4 per source pixel / per output row
+    const long long rows = (long long)B * Ho * Wo;
+    const long long w0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    float4 g[NV], bb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = lane + 64 * i;
+        g[i] = q < q4 ? ((const float4*)gam)[q] : make_float4(0, 0, 0, 0);
+        bb[i] = q < q4 ? ((const float4*)bet)[q] : make_float4(0, 0, 0, 0);
+    }
+    for (long long m = w0; m < rows; m += nw) {
+        const int wo = (int)(m % Wo);
+        const long long t = m / Wo;
+        const int ho = (int)(t % Ho), b = (int)(t / Ho);
+        float4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int q = lane + 64 * i;
+            const int seg = q / c4, c = q - seg * c4;                  // segment 0..3 -> pixel (2 ho + (seg & 1), 2 wo + (seg >> 1))
+            v[i] = make_float4(0, 0, 0, 0);
+            if (q < q4) v[i] = ((const float4*)x)[(((long long)b * H + 2 * ho + (seg & 1)) * W + 2 * wo + (seg >> 1)) * c4 + c];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)(4 * C);
+        float qq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (lane + 64 * i < q4) {
+                v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+                qq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
+        const float rstd = rsqrtf(qq / (float)(4 * C) + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int q = lane + 64 * i;
+            if (q < q4) {
+                const float4 o = make_float4(fmaf(v[i].x * rstd, g[i].x, bb[i].x), fmaf(v[i].y * rstd, g[i].y, bb[i].y),
+                                             fmaf(v[i].z * rstd, g[i].z, bb[i].z), fmaf(v[i].w * rstd, g[i].w, bb[i].w));
+                Out4<OutT>::st((void*)(y + m * 4 * C + 4 * q), o);
+            }
+        }
+    }
+}
+
 static inline int grid_for(long long n, int block = 256) {
     long long g = (n + block - 1) / block;
     if (g > 256 * 16) g = 256 * 16;
@@ -1341,6 +1400,40 @@ int mv_patch_merge_gather_nhwc(const void* x, void* y, int B, int H, int W, int 
     else
         hipLaunchKernelGGL(patch_merge_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, (float*)y,
                            B, H, W, C);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_patch_merge_ln_supported(int H, int W, int C, int x_dtype) {
+    return !get_flag("no_patch_merge_ln") && x_dtype == MV_F32 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && C <= 384 && C >= 16;
+}
+
+int mv_patch_merge_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, int B, int H, int W, int C, float eps,
+                          int x_dtype, int out_dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && gamma && beta && y && B > 0, "patch_merge_ln: bad args");
+    if (!mv_patch_merge_ln_supported(H, W, C, x_dtype)) {
+        set_error("mv_patch_merge_ln_fwd: unsupported %dx%dx%d (ask mv_patch_merge_ln_supported first)", H, W, C);
+        return MV_E_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)B * (H / 2) * (W / 2);
+    long long blocks = (rows + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const int nv = (C + 63) / 64;                       // float4 per lane: 4C / 4 / 64
+    set_kernel_name("patch_merge_ln_f32in");
+#define MV_PML(NVV)                                                                                                              \
+    do {                                                                                                                         \
+        if (out_dtype == MV_BF16)                                                                                                \
+            hipLaunchKernelGGL((patch_merge_ln_kernel<NVV, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, gamma, \
+                               beta, (bf16_t*)y, B, H, W, C, eps);                                                               \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((patch_merge_ln_kernel<NVV, float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, gamma,  \
+                               beta, (float*)y, B, H, W, C, eps);                                                                \
+    } while (0)
+    if (nv <= 2) MV_PML(2);
+    else if (nv <= 3) MV_PML(3);
+    else MV_PML(6);
+#undef MV_PML
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

@@ -43,8 +43,10 @@ class _PatchMerging(Module):
 
     @boundary
     def __call__(self, x, *, key=None):                                # reference :61-65
-        x = ops.patch_merge_gather(x)                                  # _patch_merging_pad (:23-31)
-        x = self.norm(x)
+        y = ops.patch_merge_ln(x, self.norm) if isinstance(self.norm, nn.LayerNorm) else None     # gather + LayerNorm, one pass
+        if y is None:
+            y = self.norm(ops.patch_merge_gather(x))                   # _patch_merging_pad (:23-31), then the norm
+        x = y
         if type(self.reduction) is Linear2d:      # produces the residual stream: split-precision weights (ops.linear_split)
             return ops.linear_split(ops.as_map(x), self.reduction, out_fp32=residual_fp32())
         return self.reduction(x)

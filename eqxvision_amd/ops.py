@@ -1220,6 +1220,22 @@ def drop_path(x: Act, p: float, mode: str, key) -> Act:
     return y if x.kind == "map" else Act(y.t.reshape(x.t.shape), x.kind, x.batched)
 
 
+def patch_merge_ln(x: Act, ln) -> Optional[Act]:
+    """norm(_patch_merging_pad(x)) (swin.py:61-65) in one pass over the fp32 map -- the gathered 4C map is never written; None when
+    the library has no such path (odd sizes, bf16 stream)."""
+    x = as_map(x)
+    B, H, W, C = x.t.shape
+    dt = compute_dtype()
+    if dt != "bf16" or x.t.dtype != torch.float32 or int(np.prod(ln.shape)) != 4 * C or ln.weight is None or ln.bias is None:
+        return None
+    if not _lib.load().mv_patch_merge_ln_supported(H, W, C, _lib.F32):
+        return None
+    y = empty((B, H // 2, W // 2, 4 * C), TORCH_DT[dt])
+    _lib.call("mv_patch_merge_ln_fwd", _ptr(x.t), _ptr(prep_f32(ln, "weight", ln.weight)), _ptr(prep_f32(ln, "bias", ln.bias)), _ptr(y),
+              B, H, W, C, float(ln.eps), _lib.F32, DT[dt], stream_ptr())
+    return Act(y, "map", x.batched)
+
+
 def patch_merge_gather(x: Act) -> Act:
     x = as_map(x)
     B, H, W, C = x.t.shape

@@ -329,6 +329,13 @@ int mv_dropout_windows_fwd(const void* x, const void* keys, void* y, int B, int 
  * [x(0::2,0::2) | x(1::2,0::2) | x(0::2,1::2) | x(1::2,1::2)], zero pad odd H/W. */
 int mv_patch_merge_gather_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, mv_stream_t stream);
 
+/* Swin patch merging's gather + its LayerNorm (swin.py:23-31, 61-65: `norm(_patch_merging_pad(x))`) in one pass: row (b, i, j) of y
+ * is the LayerNorm over the 4 C channels [x[2i,2j] | x[2i+1,2j] | x[2i,2j+1] | x[2i+1,2j+1]] of the fp32 NHWC map x; y [B][H/2][W/2][4C]
+ * in out_dtype.  H, W even, C % 4 == 0, C <= 384. */
+int mv_patch_merge_ln_supported(int H, int W, int C, int x_dtype);
+int mv_patch_merge_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, int B, int H, int W, int C, float eps,
+                          int x_dtype, int out_dtype, mv_stream_t stream);
+
 /* vit.py:269 row 0 of every image: tokens[b,0,:] = cls[:] + pos[0,:] (fp32 inputs). */
 int mv_vit_cls_pos_fwd(const float* cls, const float* pos, void* tokens, int B, int tok_stride, int D,
                        int dtype, mv_stream_t stream);

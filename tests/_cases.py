@@ -1185,6 +1185,30 @@ def swin_attn_case(B, Hf, C, heads, ws, shift, dtype="bf16", seed=0, generic=Fal
     return run
 
 
+def patch_merge_ln_case(B, H, C, out="bf16", seed=0):
+    """mv_patch_merge_ln_fwd (Swin patch merging's 2 x 2 gather + LayerNorm over the 4 C channels in one pass, swin.py:23-31, 61-65)
+    vs the numpy restatement: concatenate [x[0::2,0::2], x[1::2,0::2], x[0::2,1::2], x[1::2,1::2]] along channels, then LayerNorm."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        x = (rng.standard_normal((B, H, H, C)) * rng.uniform(0.5, 2.0, (B, H, H, 1)) + rng.uniform(-1, 1, (B, H, H, 1))).astype(np.float32)
+        g = rng.uniform(0.5, 1.5, 4 * C).astype(np.float32)
+        be = (0.1 * rng.standard_normal(4 * C)).astype(np.float32)
+        if not L.load().mv_patch_merge_ln_supported(H, H, C, 0):
+            return {"ok": False, "err": "mv_patch_merge_ln_supported says no"}
+        cat = np.concatenate([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], axis=-1)
+        ref = O.layernorm_rows(cat.reshape(-1, 4 * C), g, be, 1e-5).reshape(B, H // 2, H // 2, 4 * C)
+        xd, gd, bd = dev(x, "fp32"), dev(g, "fp32"), dev(be, "fp32")
+        y = torch.full((B, H // 2, H // 2, 4 * C), -7.0, dtype=torch.bfloat16 if out == "bf16" else torch.float32, device="cuda")
+        L.call("mv_patch_merge_ln_fwd", xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, H, H, C, 1e-5, 0, DT[out], _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, TOL_BF16 if out == "bf16" else TOL_F32)
+        info["kernel"] = kern
+        return info
+    return run
+
+
 def swin_block_attn_case(B, Hf, shift, seed=0, C=384, heads=12, ws=7):
     """mv_swin_block_attn_fwd (LayerNorm -> qkv -> shifted-window attention -> proj -> + x, one launch, one workgroup per window;
     swin.py:572-578 first line) vs the float64 restatement (LayerNorm, Linear, `_swin_core_ref`, Linear), and vs the library's own
@@ -1719,6 +1743,10 @@ def all_cases():
           ("ln_mlp/swin_stage0_f32stream", ln_mlp_case(8 * 56 * 56, "fp32", seed=520)),
           ("ln_mlp/bf16stream_ragged", ln_mlp_case(4096 + 77, "bf16", seed=521)),
           ("ln_mlp/f32stream_many_tiles", ln_mlp_case(70001, "fp32", seed=522)),
+          ("patch_merge_ln/c96_56_B2", patch_merge_ln_case(2, 56, 96, seed=540)),
+          ("patch_merge_ln/c192_28_B3", patch_merge_ln_case(3, 28, 192, seed=541)),
+          ("patch_merge_ln/c384_14_B5_f32out", patch_merge_ln_case(5, 14, 384, out="fp32", seed=542)),
+          ("patch_merge_ln/c32_10_B1", patch_merge_ln_case(1, 10, 32, seed=543)),
           ("swin_block_attn/c384_14x14_B3_noshift", swin_block_attn_case(3, 14, 0, seed=530)),
           ("swin_block_attn/c384_14x14_B3_shift3", swin_block_attn_case(3, 14, 3, seed=531)),
           ("swin_block_attn/c384_28x28_B2_shift3", swin_block_attn_case(2, 28, 3, seed=532)),

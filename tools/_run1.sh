@@ -1,6 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r3a
-timeout 900 python tools/gpu_check.py swin_block_attn model/swin > gpurun_out/r3a/check.log 2>&1
-(for c in 384 192 96; do SBA_C=$c timeout 300 python tools/time_swin_block_attn.py 64; done) > gpurun_out/r3a/time_sba.log 2>&1
-(LANES=2 timeout 300 python tools/ab_flag.py no_swin_block_attn swin_t 128 3) > gpurun_out/r3a/ab.log 2>&1
-grep -c PASS gpurun_out/r3a/check.log; grep "FAIL\|full_config" gpurun_out/r3a/check.log | cut -c1-300; cat gpurun_out/r3a/time_sba.log gpurun_out/r3a/ab.log
+timeout 900 python tools/gpu_check.py patch_merge_ln model/swin > gpurun_out/r3a/check.log 2>&1
+(LANES=2 timeout 300 python tools/ab_flag.py no_patch_merge_ln swin_t 128 3) > gpurun_out/r3a/ab.log 2>&1
+grep -c PASS gpurun_out/r3a/check.log; grep "FAIL\|full_config\|patch_merge" gpurun_out/r3a/check.log | cut -c1-260; cat gpurun_out/r3a/ab.log
