@@ -322,6 +322,207 @@ __global__ __launch_bounds__(512) void ln_mlp_stream_kernel(const LnMlpSP p) {
 #undef MV_LMS_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// C = 192 (Swin stage 1): 128 rows per block, so that the 6 output-channel tiles x 4 token blocks of fc2 are 24 MFMA tiles, three
+// per wave (the unit layout of swin_block_attn.hip), and every fc1 weight fragment feeds 4 MFMAs.  One chunk buffer (a second one
+// does not fit next to 128 normalised rows): two barriers per chunk, fc1 of the next chunk runs ahead of the first.
+template <int TM>
+__global__ __launch_bounds__(512) void ln_mlp_stream192_kernel(const LnMlpSP p) {
+    constexpr int C = 192, HID = 768, NCH = HID / 256, KS1 = C / 16, KS2 = 16, NTB = TM / 32, NCT = C / 32, D = 4, PB = 4;
+    static_assert(NTB == 4 && NCT * NTB == 24 && KS1 % D == 0 && KS2 % D == 0 && KS1 % PB == 0 && KS2 % PB == 0, "layout");
+    constexpr int XROW = C * 2 + 16, HROW = 256 * 2 + 16, LDS_H = TM * XROW, YROW = C * 4 + 16;
+    static_assert(TM * YROW <= TM * XROW + TM * HROW, "result tile must fit in the (dead) operand buffers");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const long long row0 = (long long)blockIdx.x * TM;
+
+    // fc2 units of this wave: 3w .. 3w+2 -> (tile = u / 4, token block = u % 4): at most two tiles
+    const int ta = (3 * wave) >> 2;
+    const int u_tile[3] = {(3 * wave) >> 2, (3 * wave + 1) >> 2, (3 * wave + 2) >> 2};
+    const int u_tb[3] = {(3 * wave) & 3, (3 * wave + 1) & 3, (3 * wave + 2) & 3};
+    const int pat = (u_tile[1] - ta) + 2 * (u_tile[2] - ta);
+    auto t2_base = [&](int c, int tile) -> const uint4* {
+        c = c < NCH ? c : NCH - 1;
+        tile = tile < NCT ? tile : NCT - 1;
+        return (const uint4*)p.w2f + ((size_t)(c * NCT + tile) * KS2) * 64 + lane;
+    };
+    const uint4* ap1 = (const uint4*)p.w1f + (size_t)wave * KS1 * 64 + lane;                 // + chunk * 8 * KS1 * 64
+    uint4 a1[D], a20[D], a21[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) a1[d] = ap1[d * 64];
+
+    // ---------------- LayerNorm of the tile -> LDS (bf16) ---------------------------------------------------------------------
+    {
+        constexpr int LPR = C / 12, RPP = 64 / LPR, RPW = TM / 8, NP = RPW / RPP;
+        const int lr = lane / LPR, lq = lane % LPR;
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int r = RPW * wave + ps * RPP + lr;
+            long long gr = row0 + r;
+            gr = gr < p.M ? gr : p.M - 1;
+            const float4* src = (const float4*)(p.x + gr * C);
+            float4 v[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[i] = src[lq + LPR * i];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float mean = s * (1.0f / C);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+                q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+            }
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            const float rstd = rsqrtf(q * (1.0f / C) + p.eps);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                uint2 u;
+                u.x = pack_bf2(v[i].x * rstd, v[i].y * rstd);
+                u.y = pack_bf2(v[i].z * rstd, v[i].w * rstd);
+                *(uint2*)(smem + r * XROW + (lq + LPR * i) * 8) = u;
+            }
+        }
+    }
+    {
+        const uint4* s0 = t2_base(0, ta);
+        const uint4* s1 = t2_base(0, ta + 1);
+#pragma unroll
+        for (int d = 0; d < D; ++d) { a20[d] = s0[d * 64]; a21[d] = s1[d * 64]; }
+    }
+    __syncthreads();
+
+    f32x16 acc2[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
+    f32x16 acc1[NTB];
+    float4 bia[4];
+    const char* xb = smem + fr * XROW + fh * 16;
+    char* hbuf = smem + LDS_H;
+
+    auto fc1 = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < NTB; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc1[b][e] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bia[g] = *(const float4*)(p.b1 + c * 256 + 32 * wave + 8 * g + 4 * fh);
+        const uint4* a1p = ap1 + (size_t)c * 8 * KS1 * 64;
+        const uint4* a1n = ap1 + (size_t)(c + 1 < NCH ? c + 1 : c) * 8 * KS1 * 64;
+        bf16x8 bq[PB][NTB];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int b = 0; b < NTB; ++b) bq[t][b] = *(const bf16x8*)(xb + b * 32 * XROW + t * 32);
+#pragma unroll
+        for (int j = 0; j < KS1; ++j) {
+            const int jn = j + 2 < KS1 ? j + 2 : KS1 - 1;
+            const uint4* an = (j + D < KS1) ? a1p + (size_t)(j + D) * 64 : a1n + (size_t)(j + D - KS1) * 64;
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 af = __builtin_bit_cast(bf16x8, a1[j % D]);
+            a1[j % D] = *an;
+#pragma unroll
+            for (int b = 0; b < NTB; ++b) {
+                acc1[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[j % PB][b], acc1[b], 0, 0, 0);
+                bq[(j + 2) % PB][b] = *(const bf16x8*)(xb + b * 32 * XROW + jn * 32);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto fc2 = [&](auto patc, int c) __attribute__((always_inline)) {
+        constexpr int PAT = decltype(patc)::value;
+        const uint4* cur0 = t2_base(c, ta);
+        const uint4* cur1 = t2_base(c, ta + 1);
+        const uint4* nx0 = t2_base(c + 1, ta);
+        const uint4* nx1 = t2_base(c + 1, ta + 1);
+        const char* hb[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) hb[i] = hbuf + (32 * u_tb[i] + fr) * HROW + fh * 16;
+        bf16x8 bq[PB][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) bq[t][i] = *(const bf16x8*)(hb[i] + t * 32);
+#pragma unroll
+        for (int j = 0; j < KS2; ++j) {
+            const int jn = j + 2 < KS2 ? j + 2 : KS2 - 1;
+            const bool in = j + D < KS2;
+            const uint4* n0 = in ? cur0 + (size_t)(j + D) * 64 : nx0 + (size_t)(j + D - KS2) * 64;
+            const uint4* n1 = in ? cur1 + (size_t)(j + D) * 64 : nx1 + (size_t)(j + D - KS2) * 64;
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 f0 = __builtin_bit_cast(bf16x8, a20[j % D]);
+            const bf16x8 f1 = __builtin_bit_cast(bf16x8, a21[j % D]);
+            a20[j % D] = *n0;
+            a21[j % D] = *n1;
+            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, bq[j % PB][0], acc2[0], 0, 0, 0);
+            acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((PAT & 1) ? f1 : f0, bq[j % PB][1], acc2[1], 0, 0, 0);
+            acc2[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((PAT & 2) ? f1 : f0, bq[j % PB][2], acc2[2], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) bq[(j + 2) % PB][i] = *(const bf16x8*)(hb[i] + jn * 32);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    for (int c = 0; c < NCH; ++c) {
+        fc1(c);
+        __syncthreads();                     // every wave has finished reading the chunk buffer (fc2 of chunk c - 1)
+#pragma unroll
+        for (int b = 0; b < NTB; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 u;
+                u.x = gelu_tanh_pack2(acc1[b][4 * g + 0] + bia[g].x, acc1[b][4 * g + 1] + bia[g].y);
+                u.y = gelu_tanh_pack2(acc1[b][4 * g + 2] + bia[g].z, acc1[b][4 * g + 3] + bia[g].w);
+                *(uint2*)(hbuf + (32 * b + fr) * HROW + (32 * wave + 8 * g + 4 * fh) * 2) = u;
+            }
+        __syncthreads();
+        if (pat == 0) fc2(std::integral_constant<int, 0>{}, c);
+        else if (pat == 2) fc2(std::integral_constant<int, 2>{}, c);
+        else fc2(std::integral_constant<int, 3>{}, c);
+    }
+
+    // ---------------- epilogue: accumulators -> LDS tile, then whole rows + bias + residual -----------------------------------------
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(float4*)(smem + (32 * u_tb[i] + fr) * YROW + (32 * u_tile[i] + 8 * g + 4 * fh) * 4) =
+                make_float4(acc2[i][4 * g + 0], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]);
+    __syncthreads();
+    {
+        constexpr int QPR = C / 4, NIT = TM * QPR / 512;
+        static_assert(TM * QPR % 512 == 0, "whole passes");
+        float4 xr[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + 512 * i;
+            const int r = idx / QPR, q = idx - r * QPR;
+            long long gr = row0 + r;
+            gr = gr < p.M ? gr : p.M - 1;
+            xr[i] = *(const float4*)(p.x + gr * C + 4 * q);
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + 512 * i;
+            const int r = idx / QPR, q = idx - r * QPR;
+            const float4 a = *(const float4*)(smem + r * YROW + q * 16);
+            const float4 b2 = *(const float4*)(p.b2 + 4 * q);
+            if (row0 + r < p.M)
+                *(float4*)(p.y + (row0 + r) * C + 4 * q) =
+                    make_float4(a.x + b2.x + xr[i].x, a.y + b2.y + xr[i].y, a.z + b2.z + xr[i].z, a.w + b2.w + xr[i].w);
+        }
+    }
+}
+
 }  // namespace
 
 }  // namespace mv
@@ -330,7 +531,7 @@ extern "C" {
 
 int mv_ln_mlp_stream_supported(int64_t M, int C, int hidden, int x_dtype) {
     if (mv::get_flag("no_ln_mlp_stream")) return 0;
-    return x_dtype == MV_F32 && C == 384 && hidden == 4 * C && M >= 64;
+    return x_dtype == MV_F32 && (C == 384 || C == 192) && hidden == 4 * C && M >= 128;
 }
 
 int mv_ln_mlp_stream_fwd(const void* x, const void* w1f, const float* b1, const void* w2f, const float* b2, void* y, int64_t M,
@@ -347,6 +548,16 @@ int mv_ln_mlp_stream_fwd(const void* x, const void* w1f, const float* b1, const 
     p.x = (const float*)x; p.w1f = (const bf16_t*)w1f; p.b1 = b1; p.w2f = (const bf16_t*)w2f; p.b2 = b2; p.y = (float*)y;
     p.M = M; p.eps = eps;
     p.prof = get_flag("lms_prof") ? (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo")) : nullptr;
+    if (C == 192) {
+        constexpr int TM = 128;
+        constexpr int SMEM = TM * (192 * 2 + 16) + TM * (256 * 2 + 16);
+        auto kern = ln_mlp_stream192_kernel<TM>;
+        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        set_kernel_name("ln_mlp_stream_c192_f32stream");
+        hipLaunchKernelGGL(kern, dim3((unsigned)((M + TM - 1) / TM)), dim3(512), SMEM, stream, p);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
     constexpr int TM = 64;
     constexpr int SMEM = TM * (384 * 2 + 16) + 2 * TM * (256 * 2 + 16);
     const int var = get_flag("lms_variant");                 // tuning: prefetch depths
@@ -358,7 +569,6 @@ int mv_ln_mlp_stream_fwd(const void* x, const void* w1f, const float* b1, const 
     } while (0)
     set_kernel_name("ln_mlp_stream_c384_f32stream");
     if (var == 1) MV_LMS_GO(4, 4);
-    else if (var == 2) MV_LMS_GO(6, 8);
     else MV_LMS_GO(8, 8);
 #undef MV_LMS_GO
     MV_LAUNCH_CHECK();

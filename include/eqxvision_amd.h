@@ -236,8 +236,8 @@ int mv_swin_block_attn_fwd(const void* x, const void* wqkv_f, const float* bqkv,
                            const float* bias64, void* y, int B, int Hf, int Wf, int C, int heads, int wsh, int wsw, int shh,
                            int shw, float eps, int x_dtype, mv_stream_t stream);
 
-/* The same MLP half for rows too wide for the weights to live in LDS (Swin stage 2: C = 384, hidden = 1536): both weight matrices
- * are STREAMED from L2 straight into registers, 64 token rows per workgroup, the hidden activations pass through LDS in chunks
+/* The same MLP half for rows too wide for the weights to live in LDS (Swin stages 1 / 2: C = 192 / 384, hidden = 4 C): both weight
+ * matrices are STREAMED from L2 straight into registers, 128 / 64 token rows per workgroup, the hidden activations pass through LDS in chunks
  * of 256 units and never reach HBM.  Same formula and folding as mv_ln_mlp_fwd; the weights come in FRAGMENT ORDER (prepared once
  * by the caller, eqxvision_amd/ops.py:ln_mlp): a wave fetches each k16-step of its 32 output units as one 1 KB piece,
  *   w1f[chunk 0..hidden/256-1][wave 0..7][j 0..C/16-1][lane 0..63][e 0..7] = w1[u = 256*chunk + 32*wave + lane%32][c = 16*j + 8*(lane/32) + e]

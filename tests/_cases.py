@@ -1759,6 +1759,9 @@ def all_cases():
           ("ln_mlp/stream_c384_swin_stage2_B8", ln_mlp_case(8 * 14 * 14, "fp32", seed=523, C=384, Hd=1536)),
           ("ln_mlp/stream_c384_ragged", ln_mlp_case(64 * 9 + 37, "fp32", seed=524, C=384, Hd=1536)),
           ("ln_mlp/stream_c384_many_tiles", ln_mlp_case(64 * 300 + 5, "fp32", seed=525, C=384, Hd=1536)),
+          ("ln_mlp/stream_c192_swin_stage1_B4", ln_mlp_case(4 * 28 * 28, "fp32", seed=526, C=192, Hd=768)),
+          ("ln_mlp/stream_c192_ragged", ln_mlp_case(128 * 5 + 77, "fp32", seed=527, C=192, Hd=768)),
+          ("ln_mlp/stream_c192_many_tiles", ln_mlp_case(128 * 300 + 9, "fp32", seed=528, C=192, Hd=768)),
           ("split/conv_swin_patch4", conv_nchw_split_case(3, 3, 224, 96, 4, 4, seed=514)),
           ("split/conv_odd_k3s2", conv_nchw_split_case(2, 3, 65, 40, 3, 2, seed=515)),
           ("chain/56x56_B4", chain_case(4 * 56 * 56, seed=1)),

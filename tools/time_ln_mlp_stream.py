@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from eqxvision_amd import _lib as L
 from eqxvision_amd.ops import ln_mlp_fragments
-C, Hd = 384, 1536
+C = int(os.environ.get('LMS_C', '384')); Hd = 4 * C
 s = torch.cuda.current_stream().cuda_stream
 
 def t(fn, n=30):
@@ -16,7 +16,7 @@ def t(fn, n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-for M in [int(a) for a in sys.argv[1:]] or [64 * 196, 128 * 196]:
+for M in [int(a) for a in sys.argv[1:]] or ([64 * 196, 128 * 196] if C == 384 else [64 * 784]):
     x = torch.randn(M, C, device="cuda")
     w1 = (np.random.randn(Hd, C) / C ** 0.5).astype(np.float32); w2 = (np.random.randn(C, Hd) / Hd ** 0.5).astype(np.float32)
     w1f, w2f = ln_mlp_fragments(w1, w2)
@@ -40,7 +40,7 @@ for M in [int(a) for a in sys.argv[1:]] or [64 * 196, 128 * 196]:
     d = (y - y3).abs().max().item()
     for var in (1, 2):
         L.set_flag("lms_variant", var); tv = t(fused); fused(); torch.cuda.synchronize(); print(f"   variant {var}: {tv:.1f} us   max|diff| {(y - y3).abs().max().item() if False else 0:.4f}"); L.set_flag("lms_variant", 0)
-    print(f"M={M}: fused {uf:.1f} us ({fl/uf/1e6:.0f} TFLOP/s, weights {M/64*2.36e6/uf/1e6:.1f} TB/s from L2)   three launches {uu:.1f} us ({fl/uu/1e6:.0f} TFLOP/s)   max|diff| {d:.4f}")
+    print(f"M={M}: fused {uf:.1f} us ({fl/uf/1e6:.0f} TFLOP/s, C={C})   three launches {uu:.1f} us ({fl/uu/1e6:.0f} TFLOP/s)   max|diff| {d:.4f}")
 
     if os.environ.get("LMS_PROF"):
         nb_ = (M + 63) // 64
