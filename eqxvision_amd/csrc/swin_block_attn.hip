@@ -35,25 +35,30 @@ struct SwinBAP {
     float* y;
     int Hf, Wf, shh, shw, nWw, nW;
     float eps;
+    long long* prof;       // experiments only (tools/time_swin_block_attn.py): per-wave wall-clock stamps at the phase boundaries
 };
 
-template <int C, int NWIN>
-__global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
-    constexpr int NH = C / 32, HG = 4 / NWIN, NG = NH / HG, KS = C / 16, NTOK = 49, WS = 7;
+// NWV = waves per workgroup: 8, or 4 for C = 96 (two windows, one head at a time: half the LDS, so that TWO workgroups share a CU --
+// a stage-0 workgroup has 1.5 us of matrix work and ~22 us of dependent latencies: gather, 7 barriers, bias loads, epilogue)
+template <int C, int NWIN, int NWV>
+__global__ __launch_bounds__(NWV * 64) void swin_block_attn_kernel(const SwinBAP p) {
+    constexpr int NT = NWV * 64, NSLOT = NWV / 2;            // threads; (head of group, window) slots = attention jobs / 2
+    constexpr int NH = C / 32, HG = NSLOT / NWIN, NG = NH / HG, KS = C / 16, NTOK = 49, WS = 7;
     // k-loop: unrolled by U; weight fragments D steps ahead, token fragments 2 steps ahead in a ring of PB (all static indices)
     constexpr int U = (KS % 4 == 0) ? 4 : 6, D = (KS % 4 == 0) ? 4 : 3, PB = (KS % 4 == 0) ? 4 : 3;
     constexpr int NTB = 2 * NWIN, TR = 64 * NWIN, GT = 3 * HG, NCT = C / 32;      // token blocks / rows per workgroup; tiles per group
-    static_assert(NWIN * HG == 4 && NH % HG == 0 && C % 48 == 0 && KS % U == 0 && U % D == 0 && U % PB == 0 && GT * NTB == 24 && NCT * NTB == 24, "layout");
+    static_assert(NWIN * HG == NSLOT && NH % HG == 0 && C % 48 == 0 && KS % U == 0 && U % D == 0 && U % PB == 0 && GT * NTB == 3 * NWV &&
+                  NCT * NTB == 3 * NWV, "layout");
     // token rows of the normalised input / the attention output: 2 C bytes + 16 of padding (conflict-free 16-byte fragment reads);
     // C = 96: the padding would not fit -- 16 bytes after every FOURTH row do the same job (192-byte rows start 48 dwords apart)
     constexpr int XBYTES = C == 96 ? TR * 192 + (TR / 4) * 16 : TR * (C * 2 + 16);
     auto xoff = [](int r) -> int { return C == 96 ? r * 192 + (r >> 2) * 16 : r * (C * 2 + 16); };
     constexpr int QROW = 80, VROW = 144;                 // q, k rows: 32 dh (+ pad); v^T rows: 64 keys (+ pad)
     constexpr int LDS_NX = 0;
-    constexpr int LDS_Q = XBYTES;                        // [4 (head of group, window)][64 tokens][QROW]
-    constexpr int LDS_K = LDS_Q + 4 * 64 * QROW;
-    constexpr int LDS_V = LDS_K + 4 * 64 * QROW;         // [4][32 dh][VROW]
-    constexpr int LDS_O = LDS_V + 4 * 32 * VROW;
+    constexpr int LDS_Q = XBYTES;                        // [NSLOT (head of group, window)][64 tokens][QROW]
+    constexpr int LDS_K = LDS_Q + NSLOT * 64 * QROW;
+    constexpr int LDS_V = LDS_K + NSLOT * 64 * QROW;     // [NSLOT][32 dh][VROW]
+    constexpr int LDS_O = LDS_V + NSLOT * 32 * VROW;
     constexpr int LDS_REG = LDS_O + XBYTES;              // int[NWIN][64]: shift-mask region per token
     constexpr int YROW = C * 4 + 16;
     static_assert(TR * YROW <= LDS_O && LDS_REG + NWIN * 256 <= 160 * 1024, "result tile must fit below the attention output");
@@ -64,6 +69,10 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
     const int fr = lane & 31, fh = lane >> 5;
     const int wgs = p.nW / NWIN;                          // workgroups per image
     const int b = blockIdx.x / wgs, wloc0 = (blockIdx.x - b * wgs) * NWIN;
+    long long st_w[8];
+    int nst = 0;
+#define MV_SBA_STAMP() do { if (p.prof && nst < 8) st_w[nst++] = wall_clock64(); } while (0)
+    MV_SBA_STAMP();                                       // 0: start
     const bool shifted = (p.shh + p.shw) > 0;
     auto tok_row = [&](int r) -> long long {            // row r = 64 * window + token -> its row in x / y (un-rolled position)
         const int wloc = wloc0 + (r >> 6), t = r & 63;
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
 
     // ---------------- phase 0: gather + LayerNorm -> LDS ----------------------------------------------------------------------
     {
-        constexpr int LPR = C / 12, RPP = 64 / LPR, RPW = TR / 8, NP = RPW / RPP;      // lanes per row (3 float4 each), rows per pass / wave
+        constexpr int LPR = C / 12, RPP = 64 / LPR, RPW = TR / NWV, NP = RPW / RPP;      // lanes per row (3 float4 each), rows per pass / wave
         static_assert(NP * RPP == RPW, "whole passes");
         const int lr = lane / LPR, lq = lane % LPR;
 #pragma unroll
@@ -140,6 +149,7 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
         }
     }
     __syncthreads();
+    MV_SBA_STAMP();                                       // 1: LayerNorm + barrier
 
     // ---------------- the three-units-per-wave GEMM: acc[i] = unit i of this wave over K = C ----------------------------------------
     f32x16 acc[3];
@@ -199,6 +209,7 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
         const bf16_t* wn = last ? p.wp : wg + (size_t)GT * KS * 64 * 8;                 // next phase: next group, then proj
         const int ntn = last ? NCT : GT;
         gemm(LDS_NX, tile_base(wg, ta, GT), tile_base(wg, ta + 1, GT), tile_base(wn, ta, ntn), tile_base(wn, ta + 1, ntn));
+        if (g == 0) MV_SBA_STAMP();                       // 2: qkv GEMM of group 0
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int tile = u_tile[i], tb = u_tb[i];
@@ -233,6 +244,7 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
             }
         }
         __syncthreads();
+        if (g == 0) MV_SBA_STAMP();                       // 3: q / k / v stores + barrier
         // ---------------- attention: wave = ((head of the group, window), query block qb) ------------------------------------------------
         {
             const int slotq = wave >> 1, qb = wave & 1;
@@ -313,8 +325,11 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
                 *(uint2*)(od + 16 * gq) = u;
             }
         }
+        if (g == 0) MV_SBA_STAMP();                       // 4: attention of group 0
         __syncthreads();
+        if (g == 0) MV_SBA_STAMP();                       // 5: barrier
     }
+    MV_SBA_STAMP();                                       // 6: groups 1, 2
 
     // ---------------- proj over the attention output ---------------------------------------------------------------------------------
     gemm(LDS_O, tile_base(p.wp, ta, NCT), tile_base(p.wp, ta + 1, NCT), tile_base(p.wp, ta, NCT), tile_base(p.wp, ta + 1, NCT));
@@ -330,16 +345,17 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
         }
     }
     __syncthreads();
+    MV_SBA_STAMP();                                       // 7: proj + staging + barrier
     // ---------------- epilogue: whole rows, + residual, back to the tokens' own positions -----------------------------------------------
     {
         constexpr int QPR = C / 4;
         constexpr int TOT = NWIN * NTOK * QPR;
-        constexpr int NIT = (TOT + 511) / 512;
+        constexpr int NIT = (TOT + NT - 1) / NT;
         float4 xr[NIT];
         long long rows[NIT];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            int idx = tid + 512 * i;
+            int idx = tid + NT * i;
             idx = idx < TOT ? idx : TOT - 1;
             const int rr = idx / QPR, q = idx - rr * QPR;                 // rr: real token index over the windows
             const int r = 64 * (rr / NTOK) + rr % NTOK;
@@ -348,7 +364,7 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
         }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int idx = tid + 512 * i;
+            const int idx = tid + NT * i;
             if (idx < TOT) {
                 const int rr = idx / QPR, q = idx - rr * QPR;
                 const int r = 64 * (rr / NTOK) + rr % NTOK;
@@ -357,6 +373,15 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
             }
         }
     }
+    if (p.prof) {
+        const long long tend = wall_clock64();
+        if (lane == 0) {
+            long long* o = p.prof + ((size_t)blockIdx.x * NWV + wave) * 9;
+            for (int i = 0; i < 8; ++i) o[i] = st_w[i];
+            o[8] = tend;
+        }
+    }
+#undef MV_SBA_STAMP
 }
 
 }  // namespace
@@ -365,13 +390,12 @@ __global__ __launch_bounds__(512) void swin_block_attn_kernel(const SwinBAP p) {
 
 extern "C" {
 
-static int swin_block_attn_nwin(int C) { return C == 384 ? 1 : (C == 192 ? 2 : (C == 96 ? 4 : 0)); }
+static int swin_block_attn_nwin(int C) { return C == 384 ? 1 : (C == 192 ? 2 : (C == 96 ? (mv::get_flag("swin_c96_8w") ? 4 : 2) : 0)); }
 
 int mv_swin_block_attn_supported(int Hf, int Wf, int C, int heads, int wsh, int wsw, int x_dtype) {
     if (mv::get_flag("no_swin_block_attn")) return 0;
     const int nwin = swin_block_attn_nwin(C);
     if (!nwin || x_dtype != MV_F32 || heads * 32 != C || wsh != 7 || wsw != 7 || Hf % 7 || Wf % 7 || Hf < 14 || Wf < 14) return 0;
-    if (mv::get_flag("swin_block_attn_only") && mv::get_flag("swin_block_attn_only") != C) return 0;
     return ((Hf / 7) * (Wf / 7)) % nwin == 0;
 }
 
@@ -390,20 +414,23 @@ int mv_swin_block_attn_fwd(const void* x, const void* wqkv_f, const float* bqkv,
     SwinBAP p;
     p.x = (const float*)x; p.wqkv = (const bf16_t*)wqkv_f; p.bqkv = bqkv; p.wp = (const bf16_t*)wp_f; p.bp = bp; p.bias = bias64;
     p.y = (float*)y; p.Hf = Hf; p.Wf = Wf; p.shh = shh; p.shw = shw; p.nWw = Wf / 7; p.nW = (Hf / 7) * (Wf / 7); p.eps = eps;
+    p.prof = get_flag("sba_prof") ? (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo")) : nullptr;
     const int nwin = swin_block_attn_nwin(C);
-    const int tr = 64 * nwin;
+    const int nwv = (C == 96 && nwin == 2) ? 4 : 8;
+    const int tr = 64 * nwin, nslot = nwv / 2;
     const int xbytes = C == 96 ? tr * 192 + (tr / 4) * 16 : tr * (C * 2 + 16);
-    const int smem = 2 * xbytes + 2 * 4 * 64 * 80 + 4 * 32 * 144 + nwin * 256;
+    const int smem = 2 * xbytes + 2 * nslot * 64 * 80 + nslot * 32 * 144 + nwin * 256;
     const dim3 grid((unsigned)(B * (p.nW / nwin)));
-#define MV_SBA_GO(CC, NW)                                                                                            \
+#define MV_SBA_GO(CC, NW, WV)                                                                                        \
     do {                                                                                                             \
-        auto kern = swin_block_attn_kernel<CC, NW>;                                                                  \
+        auto kern = swin_block_attn_kernel<CC, NW, WV>;                                                              \
         MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));            \
-        hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p);                                                  \
+        hipLaunchKernelGGL(kern, grid, dim3(WV * 64), smem, stream, p);                                              \
     } while (0)
-    if (C == 384) { set_kernel_name("swin_block_attn_c384"); MV_SBA_GO(384, 1); }
-    else if (C == 192) { set_kernel_name("swin_block_attn_c192"); MV_SBA_GO(192, 2); }
-    else { set_kernel_name("swin_block_attn_c96"); MV_SBA_GO(96, 4); }
+    if (C == 384) { set_kernel_name("swin_block_attn_c384"); MV_SBA_GO(384, 1, 8); }
+    else if (C == 192) { set_kernel_name("swin_block_attn_c192"); MV_SBA_GO(192, 2, 8); }
+    else if (nwv == 8) { set_kernel_name("swin_block_attn_c96_8w"); MV_SBA_GO(96, 4, 8); }
+    else { set_kernel_name("swin_block_attn_c96"); MV_SBA_GO(96, 2, 4); }
 #undef MV_SBA_GO
     MV_LAUNCH_CHECK();
     return MV_OK;

@@ -45,3 +45,22 @@ for B in [int(a) for a in sys.argv[1:]] or [64, 128]:
     uf, uu = t(fused), t(unfused)
     fused(); unfused(); torch.cuda.synchronize()
     print(f"C={C} B={B} ({B * (Hf // 7) ** 2} windows): fused {uf:.1f} us   four launches {uu:.1f} us   max|diff| {(y - y4).abs().max().item():.4f}")
+
+    if os.environ.get("SBA_PROF"):
+        nwin = {384: 1, 192: 2, 96: 2}[C]; nwv = 4 if C == 96 else 8
+        nwg = B * (Hf // 7) ** 2 // nwin
+        prof = torch.zeros(nwg * nwv * 9, dtype=torch.int64, device="cuda")
+        pp = prof.data_ptr(); lo = pp & 0xffffffff
+        if lo >= 1 << 31: lo -= 1 << 32
+        L.set_flag("prof_hi", pp >> 32); L.set_flag("prof_lo", lo); L.set_flag("sba_prof", 1)
+        fused(); torch.cuda.synchronize()
+        L.set_flag("sba_prof", 0); L.set_flag("prof_lo", 0); L.set_flag("prof_hi", 0)
+        a = prof.cpu().numpy().reshape(nwg, nwv, 9).astype(np.float64) / 100.0
+        t0 = a[:, :, 0].min()
+        names = ["gather + LayerNorm + barrier", "qkv GEMM (group 0)", "q/k/v stores + barrier", "attention (group 0)", "barrier", "groups 1, 2", "proj + staging + barrier", "epilogue"]
+        print(f"  kernel span {a[:, :, 8].max() - t0:.1f} us; {nwg} workgroups; start times: median {np.median(a[:, 0, 0]) - t0:.1f} us, last {a[:, 0, 0].max() - t0:.1f} us; per-wave mean (min..max) us")
+        for i, nm in enumerate(names):
+            d = a[:, :, i + 1] - a[:, :, i]
+            print(f"    {nm:30s} {d.mean():7.2f} ({d.min():6.2f} .. {d.max():6.2f})")
+        d = a[:, :, 8] - a[:, :, 0]
+        print(f"    {'workgroup total':30s} {d.mean():7.2f} ({d.min():6.2f} .. {d.max():6.2f})")
