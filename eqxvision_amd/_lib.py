@@ -91,6 +91,8 @@ PROTOTYPES = {
     "mv_mha_dropout_fwd": [_vp, _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _f, _i, _vp],
     "mv_swin_window_attn_fwd": [_vp, _vp, _vp] + [_i] * 9 + [_i, _vp],
     "mv_patch_merge_gather_nhwc": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mv_patch4_ln_supported": [_i] * 5,
+    "mv_patch4_ln_fwd": [_vp] * 7 + [_i] * 5 + [_f, _i, _vp],
     "mv_patch_merge_ln_supported": [_i] * 4,
     "mv_patch_merge_ln_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "mv_vit_cls_pos_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -236,9 +236,13 @@ class SwinTransformer(Module):
         first = L[0]
         if (residual_fp32() and isinstance(first, nn.Sequential) and len(first) == 2
                 and type(first.layers[0]) is nn.Conv2d and isinstance(first.layers[1], nn.LayerNorm)):
-            y = ops.conv2d_entry_split(x, first.layers[0])          # patch embedding: split-precision weights
-            x = y if y is not None else ops.conv2d(x, first.layers[0])
-            x = ops.layernorm(x, first.layers[1], out_fp32=True)
+            y = ops.patch4_ln(x, first.layers[0], first.layers[1])  # patch embedding + its norm, one launch, fp32 throughout
+            if y is not None:
+                x = y
+            else:
+                y = ops.conv2d_entry_split(x, first.layers[0])      # patch embedding: split-precision weights
+                x = y if y is not None else ops.conv2d(x, first.layers[0])
+                x = ops.layernorm(x, first.layers[1], out_fp32=True)
             for layer, k in zip(L[1:], ks[1:]):
                 x = layer(x, key=k)
             return x

@@ -707,6 +707,27 @@ def conv2d_entry_split(x: Act, conv) -> Optional[Act]:
     return Act(y, "map", x.batched)
 
 
+def patch4_ln(x: Act, conv, ln) -> Optional[Act]:
+    """LayerNorm2d(Conv2d(3, K, 4, 4)(x)) -- Swin's patch embedding and its norm (swin.py:705-711) -- in one launch from the raw
+    NCHW image to the fp32 NHWC residual stream, split-precision weights; None when the library has no such path."""
+    if compute_dtype() != "bf16" or x.kind != "img" or x.t.dtype != torch.float32 or conv.groups != 1 or ln.weight is None or ln.bias is None:
+        return None
+    B, C, H, W = x.t.shape
+    K = conv.out_channels
+    if tuple(conv.kernel_size) != (4, 4) or tuple(conv.stride) != (4, 4) or tuple(conv.padding) != (0, 0) or tuple(conv.dilation) != (1, 1) \
+            or conv.in_channels != C or int(np.prod(ln.shape)) != K:
+        return None
+    if not _lib.load().mv_patch4_ln_supported(C, H, W, K, _lib.F32):
+        return None
+    hi, lo, b = prep_conv_split(conv)
+    if not split_weights():
+        lo = None
+    y = empty((B, H // 4, W // 4, K), torch.float32)
+    _lib.call("mv_patch4_ln_fwd", _ptr(x.t), _ptr(hi), _ptr(lo), _ptr(b), _ptr(prep_f32(ln, "weight", ln.weight)),
+              _ptr(prep_f32(ln, "bias", ln.bias)), _ptr(y), B, C, H, W, K, float(ln.eps), _lib.F32, stream_ptr())
+    return Act(y, "map", x.batched)
+
+
 def patch_embed_tokens(x: Act, conv, cls: Optional[torch.Tensor], pos: Optional[torch.Tensor], n_extra: int) -> Act:
     """PatchEmbed conv (k = s = patch) straight from the NCHW image into token rows
     [B, n_extra + P, D]; with `pos` the position embedding is added in the epilogue and row 0 gets

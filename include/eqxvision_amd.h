@@ -329,6 +329,13 @@ int mv_dropout_windows_fwd(const void* x, const void* keys, void* y, int B, int 
  * [x(0::2,0::2) | x(1::2,0::2) | x(0::2,1::2) | x(1::2,1::2)], zero pad odd H/W. */
 int mv_patch_merge_gather_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, mv_stream_t stream);
 
+/* Swin patch embedding + its LayerNorm in one launch (swin.py:705-711: LayerNorm2d(Conv2d(3, K, kernel 4, stride 4)(x))): x MV_F32
+ * NCHW [B][3][H][W] -> y MV_F32 NHWC [B][H/4][W/4][K] (the fp32 residual stream).  w_hi [K][48] bf16 (OIHW flattened), w_lo = the low
+ * halves of split-precision weights (hi + lo ~ the fp32 weight) or NULL, bias [K] or NULL.  K = 96 or 128; H, W multiples of 4. */
+int mv_patch4_ln_supported(int C, int H, int W, int K, int x_dtype);
+int mv_patch4_ln_fwd(const void* x, const void* w_hi, const void* w_lo, const float* bias, const float* gamma, const float* beta,
+                     void* y, int B, int C, int H, int W, int K, float eps, int x_dtype, mv_stream_t stream);
+
 /* Swin patch merging's gather + its LayerNorm (swin.py:23-31, 61-65: `norm(_patch_merging_pad(x))`) in one pass: row (b, i, j) of y
  * is the LayerNorm over the 4 C channels [x[2i,2j] | x[2i+1,2j] | x[2i,2j+1] | x[2i+1,2j+1]] of the fp32 NHWC map x; y [B][H/2][W/2][4C]
  * in out_dtype.  H, W even, C % 4 == 0, C <= 384. */

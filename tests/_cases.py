@@ -1185,6 +1185,40 @@ def swin_attn_case(B, Hf, C, heads, ws, shift, dtype="bf16", seed=0, generic=Fal
     return run
 
 
+def patch4_ln_case(B, H, K=96, split=True, seed=0):
+    """mv_patch4_ln_fwd (Swin patch embedding conv 4x4 / 4 + LayerNorm2d in one launch, swin.py:705-711) vs the numpy restatement;
+    fp32 output, split-precision weights (hi + lo bf16 terms): the input is the only bf16 rounding, so the fp32 tolerance applies
+    to the image-rounded reference."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        x = rng.random((B, 3, H, H), dtype=np.float32)
+        w = (rng.standard_normal((K, 3, 4, 4)) / np.sqrt(48)).astype(np.float32)
+        b = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        g = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        be = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        if not L.load().mv_patch4_ln_supported(3, H, H, K, 0):
+            return {"ok": False, "err": "mv_patch4_ln_supported says no"}
+        hi = bf(w)
+        lo = bf(w - hi)
+        weff = (hi + lo) if split else hi
+        conv = np.stack([O.conv2d(bf(x[i]), weff, b.reshape(-1, 1, 1), 4, 0) for i in range(B)])          # [B][K][H/4][W/4]
+        rows = conv.transpose(0, 2, 3, 1).reshape(-1, K)
+        ref = O.layernorm_rows(rows, g, be, 1e-5).reshape(B, H // 4, H // 4, K)
+        xd = dev(x, "fp32")
+        hid, lod = dev(hi.reshape(K, 48), "bf16"), dev(lo.reshape(K, 48), "bf16")
+        bd, gd, bed = dev(b, "fp32"), dev(g, "fp32"), dev(be, "fp32")
+        y = torch.full((B, H // 4, H // 4, K), -7.0, dtype=torch.float32, device="cuda")
+        L.call("mv_patch4_ln_fwd", xd.data_ptr(), hid.data_ptr(), lod.data_ptr() if split else None, bd.data_ptr(), gd.data_ptr(),
+               bed.data_ptr(), y.data_ptr(), B, 3, H, H, K, 1e-5, 0, _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(y), ref, TOL_F32)
+        info["kernel"] = kern
+        return info
+    return run
+
+
 def patch_merge_ln_case(B, H, C, out="bf16", seed=0):
     """mv_patch_merge_ln_fwd (Swin patch merging's 2 x 2 gather + LayerNorm over the 4 C channels in one pass, swin.py:23-31, 61-65)
     vs the numpy restatement: concatenate [x[0::2,0::2], x[1::2,0::2], x[0::2,1::2], x[1::2,1::2]] along channels, then LayerNorm."""
@@ -1743,6 +1777,9 @@ def all_cases():
           ("ln_mlp/swin_stage0_f32stream", ln_mlp_case(8 * 56 * 56, "fp32", seed=520)),
           ("ln_mlp/bf16stream_ragged", ln_mlp_case(4096 + 77, "bf16", seed=521)),
           ("ln_mlp/f32stream_many_tiles", ln_mlp_case(70001, "fp32", seed=522)),
+          ("patch4_ln/k96_224_B2_split", patch4_ln_case(2, 224, seed=545)),
+          ("patch4_ln/k96_56_B5_nosplit_ragged", patch4_ln_case(5, 56, split=False, seed=546)),
+          ("patch4_ln/k128_112_B3_split", patch4_ln_case(3, 112, K=128, seed=547)),
           ("patch_merge_ln/c96_56_B2", patch_merge_ln_case(2, 56, 96, seed=540)),
           ("patch_merge_ln/c192_28_B3", patch_merge_ln_case(3, 28, 192, seed=541)),
           ("patch_merge_ln/c384_14_B5_f32out", patch_merge_ln_case(5, 14, 384, out="fp32", seed=542)),
