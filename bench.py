@@ -131,6 +131,27 @@ def launch_meta(name, args):
         flops = 4.0 * M * C * Hd
         byts = 2.0 * ob(args[10]) * M * C + 4.0 * C * Hd
         shape = f"M{M} C{C} hidden{Hd} LN+MLP+res"
+    elif name == "mv_ln_mlp_stream_fwd":
+        M, C, Hd = args[6:9]
+        flops = 4.0 * M * C * Hd
+        byts = 2.0 * ob(args[10]) * M * C + 4.0 * C * Hd
+        shape = f"M{M} C{C} hidden{Hd} LN+MLP+res (streamed weights)"
+    elif name == "mv_swin_block_attn_fwd":
+        B_, Hf, Wf, C, heads, wsh, wsw = args[7:14]
+        M = B_ * Hf * Wf
+        flops = M * (8.0 * C * C + 4.0 * wsh * wsw * C)            # qkv + proj Linears, Q.K^T and P.V inside a window
+        byts = 2.0 * ob(args[17]) * M * C + 2.0 * 4 * C * C
+        shape = f"B{B_} {Hf}x{Wf}x{C} h{heads} w{wsh} LN+qkv+attn+proj+res"
+    elif name == "mv_patch_merge_ln_fwd":
+        B_, H, W, C = args[4:8]
+        byts = ob(args[9]) * B_ * H * W * C + ob(args[10]) * B_ * H * W * C
+        shape = f"B{B_} {H}x{W}x{C} -> {H // 2}x{W // 2}x{4 * C} gather+LN"
+    elif name == "mv_patch4_ln_fwd":
+        B_, C, H, W, K = args[7:12]
+        M = B_ * (H // 4) * (W // 4)
+        flops = 2.0 * M * 16 * C * K * (2 if args[2] else 1)
+        byts = 4.0 * B_ * C * H * W + 4.0 * M * K
+        shape = f"B{B_} {C}x{H}x{W} -> {H // 4}x{W // 4}x{K} conv4s4+LN" + (" hi+lo" if args[2] else "")
     elif name == "mv_linear_heads_fwd":
         M, N, K = args[5:8]
         flops = 2.0 * M * N * K
@@ -230,7 +251,7 @@ def layer_table(compiled, path, steps=5):
     return rows
 
 
-def insitu_rows(compiled, steps=6):
+def insitu_rows(compiled, steps=6, only=None):
     """Per-launch durations IN SITU: the recorded launch lists replayed eagerly the way the hipGraph runs them -- lane l on its own
     stream, forked and joined once per step -- with every launch bracketed by two HIP events on the stream it is launched on.
     This is the duration rocprofv3's kernel trace reports for the graph replays (two lanes share the chip, so a launch takes
@@ -253,13 +274,16 @@ def insitu_rows(compiled, steps=6):
                 if i < len(lc):
                     cfn, args, name = lc[i]
                     sp = streams[l].cuda_stream
-                    _lib.call("mv_event_record", evs[l][i][0], sp)
+                    timed = only is None or (l, i) in only
+                    if timed:
+                        _lib.call("mv_event_record", evs[l][i][0], sp)
                     rc = cfn(*args[:-1], sp)
                     if rc != 0:
                         raise RuntimeError(f"in-situ replay of {name} failed (rc={rc})")
                     if st == 0:
                         kern[l][i] = _lib.last_kernel()
-                    _lib.call("mv_event_record", evs[l][i][1], sp)
+                    if timed:
+                        _lib.call("mv_event_record", evs[l][i][1], sp)
         for s_ in streams:
             d = torch.cuda.Event()
             d.record(s_)
@@ -269,6 +293,8 @@ def insitu_rows(compiled, steps=6):
             continue
         for l, lc in enumerate(lanes):
             for i in range(len(lc)):
+                if only is not None and (l, i) not in only:
+                    continue
                 ms = ctypes.c_float()
                 _lib.call("mv_event_elapsed_ms", evs[l][i][0], evs[l][i][1], ctypes.byref(ms))
                 tot[l][i] += ms.value
@@ -277,10 +303,11 @@ def insitu_rows(compiled, steps=6):
         for i, (cfn, args, name) in enumerate(lc):
             flops, byts, shape = launch_meta(name, args)
             us = 1e3 * tot[l][i] / steps
-            rows.append({"call": name, "kernel": kern[l][i], "shape": shape, "us": round(us, 2), "lane": l,
+            rows.append({"call": name, "kernel": kern[l][i], "shape": shape, "us": round(us, 2), "lane": l, "index": i,
                          "tflops": round(flops / us / 1e6, 1) if us else 0, "gbs": round(byts / us / 1e3, 1) if us else 0,
                          "gflop": round(flops / 1e9, 3), "mb": round(byts / 1e6, 2)})
     return rows
+
 
 
 def dominant_family(rows):
@@ -404,7 +431,8 @@ def run_model(a, name, B, rank, world, soak_s):
             "frac": round(dom_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "kernel": dk, "launches_per_step": dv["n"],
             "avg_launch_us": round(dv["us"] / max(1, dv["n"]), 2),
             "how": f"in situ: eager replay of the {nl}-lane launch lists on {nl} stream(s), two HIP events around every launch on "
-                   "its own stream, 6 steps; = what rocprofv3 --kernel-trace reports for the graph replays of this command",
+                   "its own stream, 6 steps; compare rocprofv3 --kernel-trace of this command (graph replays; the lanes' overlap "
+                   "pattern in a graph replay is not identical to the eager one, profiles/r03/README.md)",
             "share_of_kernel_time": round(dv["us"] / max(1e-9, sum(r_["us"] for r_ in rows)), 3),
             "flop_per_launch": round(dv["gflop"] * 1e9 / max(1, dv["n"])),
             "kernel_hbm_gbs": round(dv["mb"] / dv["us"] * 1e3, 1) if dv["us"] else 0.0,
@@ -418,7 +446,7 @@ def run_model(a, name, B, rank, world, soak_s):
                               # HBM peak) over the measured step (1.0 = every launch on its own roofline, nothing overlapped)
                               "layerwise_bound_ms": round(bound_us / 1e3, 4),
                               "layerwise_bound_frac": round(bound_us / 1e3 / dev_ms_per_step, 4)}}
-    if nl > 1:
+    if nl > 1 and not a.no_lanes1:
         # lanes overlap in time, so the in-situ durations of the two lanes do not add up to the step; the same model traced as ONE
         # launch list (full-batch launches back to back on one stream) gives per-kernel figures whose sum is comparable with a step
         f1 = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k), use_graph=False, clone_outputs=False, lanes=1)
@@ -486,6 +514,8 @@ def main():
                                                              "(default 5 at 1 GPU, 2 otherwise)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-lanes1", action="store_true", help="skip the single-launch-list pass behind roofline.lanes1 (profile runs: "
+                                                             "keeps full-batch launches of the same kernels out of the trace)")
     ap.add_argument("--lanes", type=int, default=2,
                     help="sub-batches captured as parallel hipGraph branches (fills the last, partial round of CUs of "
                          "one kernel with the other lane's next kernel); 1 = a single launch list")

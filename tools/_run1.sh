@@ -1,5 +1,10 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3a
-timeout 900 python tools/gpu_check.py patch4_ln model/swin golden/committed_swin golden/committed_small > gpurun_out/r3a/check.log 2>&1
-(LANES=2 timeout 300 python tools/ab_flag.py no_patch4_ln swin_t 128 3) > gpurun_out/r3a/ab.log 2>&1
-grep -c PASS gpurun_out/r3a/check.log; grep "FAIL\|full_config\|patch4\|golden" gpurun_out/r3a/check.log | cut -c1-300; cat gpurun_out/r3a/ab.log
+O=gpurun_out/r3b; mkdir -p $O
+for ord in lane interleave; do
+for spec in swin_t:128 vit_base:256; do
+  M=${spec%%:*}; B=${spec##*:}
+  EQV_INSITU_ORDER=$ord timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${M}_$ord -o t -- python bench.py --model $M --batch $B --steps 20 --warmup 5 --no-cpu --extra none --soak 1 --no-lanes1 > $O/${M}_$ord.log 2>&1
+  grep '^{' $O/${M}_$ord.log | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read())['roofline']; print('$M $ord', r['kernel'], r['avg_launch_us'], r['avg_launch_us_eager_all_events'])"
+  t=$(find $O/${M}_$ord -name "*kernel_trace.csv" | head -1); python tools/rocprof_trim.py $t $O/${M}_${ord}_warm.txt; head -8 $O/${M}_${ord}_warm.txt | cut -c1-130
+done; done
+find $O -size +3M -delete

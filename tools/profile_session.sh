@@ -1,17 +1,25 @@
 #!/bin/bash
 # Round profiles: rocprofv3 kernel statistics of the bench command per model (in-situ durations, two graph lanes), HBM traffic
 # per launch from separate --pmc passes (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE), and an SQ pass with the
-# matrix-pipe busy counter.  usage: tools/profile_session.sh TAG  ->  gpurun_out/TAG/{MODEL}_*  (copy what matters to profiles/)
-TAG=${1:-prof}
+# matrix-pipe busy counter.  usage: tools/profile_session.sh TAG [ROUND]  ->  gpurun_out/TAG/{MODEL}_*  (copy what matters to profiles/ROUND)
+TAG=${1:-prof}; export ROUND=${2:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
 for spec in resnet50:256 vit_base:256 swin_t:128; do
   M=${spec%%:*}; B=${spec##*:}
-  CMD="python bench.py --model $M --batch $B --steps 20 --warmup 5 --no-cpu --extra none --soak 1"
-  timeout 400 $CMD --layers $O/${M}_per_launch.txt > $O/${M}_bench.json 2> $O/${M}_bench.err
+  CMD="python bench.py --model $M --batch $B --steps 20 --warmup 5 --no-cpu --extra none --soak 1 --no-lanes1"
+  timeout 400 $CMD --layers $O/${M}_per_launch.txt > $O/${M}_bench_layers.json 2> $O/${M}_bench.err
+  # THE profiled command (its own JSON line is what roofline.frac is checked against): no --layers, no lanes1 pass -> the trace
+  # holds only the two-lane launches (graph replays + the in-situ event pass)
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${M}_trace -o t -- $CMD > $O/${M}_trace.log 2>&1
+  grep '^{' $O/${M}_trace.log | tail -1 > $O/${M}_bench.json
   t=$(find $O/${M}_trace -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/rocprof_trim.py $t $O/${M}_rocprofv3_warm_stats.txt
   s=$(find $O/${M}_trace -name "*kernel_stats.csv" | head -1); [ -n "$s" ] && cp $s $O/${M}_rocprofv3_kernel_stats.csv
+  # the same model as ONE launch list (--lanes 1): per-kernel durations whose sum compares with a step
+  CMD1="python bench.py --model $M --batch $B --steps 20 --warmup 5 --no-cpu --extra none --soak 1 --lanes 1"
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${M}_trace1 -o t -- $CMD1 > $O/${M}_trace1.log 2>&1
+  grep '^{' $O/${M}_trace1.log | tail -1 > $O/${M}_lanes1_bench.json
+  t=$(find $O/${M}_trace1 -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/rocprof_trim.py $t $O/${M}_lanes1_rocprofv3_warm_stats.txt
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/${M}_$C -o t -- python bench.py --model $M --batch $B --steps 3 --warmup 2 --no-cpu --extra none --soak 0 > $O/${M}_$C.log 2>&1
   done
@@ -34,7 +42,10 @@ def fam(name):
                    ("chain1x1_kernel<128", "chain1x1_bf16_64_256_128"), ("chain1x1_kernel<64, 6, true", "chain1x1_dual_bf16_64+64_256_64"), ("chain_stream_kernel", "chain_stream_bf16_128_512_128"),
                    ("conv3x3c64_v2_kernel", "conv3x3c64_halo"), ("stem_pool_kernel", "stem_pool_mfma_f32in"),
                    ("patch_embed_kernel", "patch_embed_mfma_f32in"), ("mha_mfma_kernel", "mha_mfma_dh64_hm"),
-                   ("layernorm_vec_kernel", "layernorm_vec"), ("ln_mlp96_kernel", "ln_mlp96_f32stream"), ("swin_attn_mfma", "swin_attn_mfma"), ("skinny_f32_kernel", "skinny_linear_f32_mfma")):
+                   ("layernorm_vec_kernel", "layernorm_vec"), ("ln_mlp96_kernel", "ln_mlp96_f32stream"), ("swin_attn_mfma", "swin_attn_mfma"), ("skinny_f32_kernel", "skinny_linear_f32_mfma"),
+                   ("bneck_tail_kernel", "bneck_tail_bf16_14x14_256_1024"), ("ln_mlp_stream_kernel", "ln_mlp_stream_c384_f32stream"), ("ln_mlp_stream192_kernel", "ln_mlp_stream_c192_f32stream"),
+                   ("swin_block_attn_kernel<384", "swin_block_attn_c384"), ("swin_block_attn_kernel<192", "swin_block_attn_c192"), ("swin_block_attn_kernel<96", "swin_block_attn_c96"),
+                   ("patch_merge_ln_kernel", "patch_merge_ln_f32in"), ("swin_stem_ln_kernel", "swin_stem_ln_k96")):
         if sub in n: return f
     return None
 out = {"_batch": {}, "_rocprof": {}}
@@ -66,7 +77,7 @@ for M, B in (("resnet50", 256), ("vit_base", 256), ("swin_t", 128)):
     out["_rocprof"][M] = {}
     for k, v in rp.items():
         w = sorted(v)[: max(1, len(v) - max(1, len(v) // 50))]
-        out["_rocprof"][M][k] = {"avg_launch_us": round(sum(w) / len(w), 2), "calls": len(v), "file": f"profiles/r02/{M}_rocprofv3_warm_stats.txt"}
+        out["_rocprof"][M][k] = {"avg_launch_us": round(sum(w) / len(w), 2), "calls": len(v), "file": f"profiles/{os.environ.get('ROUND', 'r03')}/{M}_rocprofv3_warm_stats.txt"}
     # SQ pass: MFMA busy fraction per family (busy cycles per SIMD / kernel cycles)
     sq = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{O}/{M}_SQ/**/*counter_collection.csv", recursive=True):
@@ -81,6 +92,18 @@ for M, B in (("resnet50", 256), ("vit_base", 256), ("swin_t", 128)):
             frac = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024.0 / dur if dur else 0
             g.write(f"{k:34s} n={len(next(iter(d.values()))):4d} mfma_busy_frac {frac:5.3f}  kernel_cycles {dur:12.0f}  " +
                     "  ".join(f"{c}={m[c]:.3g}" for c in sorted(m)) + "\n")
+# bench.py's live roofline figure against the trace of the same command
+agree = ["# roofline.avg_launch_us printed by bench.py (HIP events, live) vs the rocprofv3 kernel trace of the SAME command (warm average)"]
+for M in ("resnet50", "vit_base", "swin_t"):
+    try:
+        r = json.load(open(f"{O}/{M}_bench.json"))["roofline"]
+        rp = out["_rocprof"][M][r["kernel"]]
+        agree.append(f"{M:9s} {r['kernel']:30s} bench {r['avg_launch_us']:8.2f} us  rocprofv3 {rp['avg_launch_us']:8.2f} us ({rp['calls']} calls)  "
+                     f"ratio {r['avg_launch_us'] / rp['avg_launch_us']:.3f}   frac {r['frac']}")
+    except Exception as e:
+        agree.append(f"{M}: {type(e).__name__} {e}")
+open(f"{O}/roofline_vs_rocprof.txt", "w").write("\n".join(agree) + "\n")
+print("\n".join(agree))
 json.dump(out, open(f"{O}/traffic.json", "w"), indent=1)
 open(f"{O}/hbm_traffic_pmc.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
