@@ -560,17 +560,10 @@ int mv_ln_mlp_stream_fwd(const void* x, const void* w1f, const float* b1, const 
     }
     constexpr int TM = 64;
     constexpr int SMEM = TM * (384 * 2 + 16) + 2 * TM * (256 * 2 + 16);
-    const int var = get_flag("lms_variant");                 // tuning: prefetch depths
-#define MV_LMS_GO(A, B)                                                                                              \
-    do {                                                                                                             \
-        auto kern = ln_mlp_stream_kernel<384, TM, A, B>;                                                             \
-        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));            \
-        hipLaunchKernelGGL(kern, dim3((unsigned)((M + TM - 1) / TM)), dim3(512), SMEM, stream, p);                   \
-    } while (0)
+    auto kern = ln_mlp_stream_kernel<384, TM, 8, 8>;         // prefetch depths: (4, 4), (6, 6), (8, 4) measured equal or slower
+    MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     set_kernel_name("ln_mlp_stream_c384_f32stream");
-    if (var == 1) MV_LMS_GO(4, 4);
-    else MV_LMS_GO(8, 8);
-#undef MV_LMS_GO
+    hipLaunchKernelGGL(kern, dim3((unsigned)((M + TM - 1) / TM)), dim3(512), SMEM, stream, p);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

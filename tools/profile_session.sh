@@ -21,9 +21,9 @@ for spec in resnet50:256 vit_base:256 swin_t:128; do
   grep '^{' $O/${M}_trace1.log | tail -1 > $O/${M}_lanes1_bench.json
   t=$(find $O/${M}_trace1 -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/rocprof_trim.py $t $O/${M}_lanes1_rocprofv3_warm_stats.txt
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/${M}_$C -o t -- python bench.py --model $M --batch $B --steps 3 --warmup 2 --no-cpu --extra none --soak 0 > $O/${M}_$C.log 2>&1
+    timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/${M}_$C -o t -- python bench.py --model $M --batch $B --steps 3 --warmup 2 --no-cpu --extra none --soak 0 --no-lanes1 > $O/${M}_$C.log 2>&1
   done
-  timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/${M}_SQ -o t -- python bench.py --model $M --batch $B --steps 2 --warmup 2 --no-cpu --extra none --soak 0 --no-graph > $O/${M}_SQ.log 2>&1
+  timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/${M}_SQ -o t -- python bench.py --model $M --batch $B --steps 2 --warmup 2 --no-cpu --extra none --soak 0 --no-graph --no-lanes1 > $O/${M}_SQ.log 2>&1
 done
 find $O -name "*.db" -delete
 O=$O python - <<'PY'

@@ -38,8 +38,6 @@ for M in [int(a) for a in sys.argv[1:]] or ([64 * 196, 128 * 196] if C == 384 el
     uf = t(fused); uu = t(unfused)
     fused(); unfused(); torch.cuda.synchronize()
     d = (y - y3).abs().max().item()
-    for var in (1, 2):
-        L.set_flag("lms_variant", var); tv = t(fused); fused(); torch.cuda.synchronize(); print(f"   variant {var}: {tv:.1f} us   max|diff| {(y - y3).abs().max().item() if False else 0:.4f}"); L.set_flag("lms_variant", 0)
     print(f"M={M}: fused {uf:.1f} us ({fl/uf/1e6:.0f} TFLOP/s, C={C})   three launches {uu:.1f} us ({fl/uu/1e6:.0f} TFLOP/s)   max|diff| {d:.4f}")
 
     if os.environ.get("LMS_PROF"):
