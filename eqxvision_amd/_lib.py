@@ -10,6 +10,8 @@ import ctypes as C
 import os
 import threading
 
+from . import _trace
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libeqxvision_amd.so")
 
@@ -163,7 +165,14 @@ def set_recording(rec):
 def call(name, *args):
     lib = load()
     fn = getattr(lib, name)
-    rc = fn(*args)
+    if _trace.enabled:
+        _trace.push(name)
+        try:
+            rc = fn(*args)
+        finally:
+            _trace.pop()
+    else:
+        rc = fn(*args)
     if rc != 0:
         msg = lib.mv_last_error()
         raise MVError(f"{name} failed (rc={rc}): {msg.decode() if msg else ''}")

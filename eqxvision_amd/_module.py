@@ -70,6 +70,10 @@ class StateIndex:
 
 class _ModuleMeta(type):
     def __new__(mcls, name, bases, ns):
+        if "__call__" in ns and callable(ns["__call__"]):
+            from . import _trace
+            ns = dict(ns)
+            ns["__call__"] = _trace.wrap_call(name, ns["__call__"])    # roctx range per module call when EQV_ROCTX=1
         cls = super().__new__(mcls, name, bases, ns)
         fields: List[str] = []
         for klass in reversed(cls.__mro__):

@@ -312,8 +312,13 @@ static int launch_tile(IgemmP& p, bool dense, bool out_f32, hipStream_t st) {
 // in total), rules kept; vit_base B=256, two lanes -- three shapes, +3.5% together:
 struct TunedTile { const char* kind; int M, a, b, R, S, sh, choice; };
 // Round 2: the three ViT-B rows of round 1 are gone -- igemm8 (choice 10, now the rule for those shapes) beats all of them.
+// Round 3 (gpurun_out/r3d/tune_resnet50.log; after bneck_tail changed the mix): resnet50 B=256, two lanes -- two shapes, +2.2% and +1.6%
+// (three more "wins" of that log are the rule's own kernel re-measured: drift)
+// (inside the laned graph the other lane fills the idle CUs, so the per-FLOP cheaper 256-row tile wins although it leaves
+// fewer tiles than CUs); swin_t B=128: nothing above the drift.
 static const TunedTile kTuned[] = {
-    {"none", 0, 0, 0, 0, 0, 0, 0},
+    {"ov", 25088, 1024, 256, 1, 1, 1, 10},    // layer-3 conv1 1x1 1024 -> 256 at 128 images: igemm8 256x256 (98 tiles) over 128x256 (196)
+    {"ov", 6272, 512, 512, 3, 3, 1, 12},      // layer-4 conv2 3x3 at 128 images: igemm8 256x128
 };
 int tile_override(const char* kind, long long M, int a, int b, int R, int S, int sh) {
     char key[96];

@@ -436,3 +436,40 @@ def test_pth_reader_rejects_views_outside_the_storage():
     for off, size, stride in ((0, (4, 4), (4, 1)), (11, (2,), (1,)), (-1, (2,), (1,)), (0, (2, 2), (-1, 1)), (0, (3,), (1000,))):
         with pytest.raises(pickle.UnpicklingError):
             pth._rebuild_tensor_v2(st, off, size, stride)
+
+
+def test_roctx_ranges_bracket_module_calls():
+    """SURVEY section 5, tracing row: with tracing on, every Module.__call__ opens and closes a roctx range (nested per sub-module)."""
+    from eqxvision_amd import _trace
+
+    class Inner(eqv.Module):
+        k: int
+
+        def __init__(self):
+            self.k = 1
+
+        def __call__(self, x, *, key=None):
+            return x + _trace.depth
+
+    class Outer(eqv.Module):
+        inner: Inner
+
+        def __init__(self):
+            self.inner = Inner()
+
+        def __call__(self, x, *, key=None):
+            return self.inner(x) * 10 + _trace.depth
+
+    m = Outer()
+    assert m(0) == 0                              # off: no ranges
+    old, before = _trace.enabled, _trace.pushed
+    _trace.enabled = True
+    try:
+        try:
+            _trace._load()
+        except RuntimeError:
+            pytest.skip("libroctx64.so not loadable here")
+        assert m(0) == 21                         # inner saw depth 2, outer depth 1
+        assert _trace.pushed == before + 2 and _trace.depth == 0
+    finally:
+        _trace.enabled = old

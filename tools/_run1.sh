@@ -1,10 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3b; mkdir -p $O
-for ord in lane interleave; do
-for spec in swin_t:128 vit_base:256; do
-  M=${spec%%:*}; B=${spec##*:}
-  EQV_INSITU_ORDER=$ord timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${M}_$ord -o t -- python bench.py --model $M --batch $B --steps 20 --warmup 5 --no-cpu --extra none --soak 1 --no-lanes1 > $O/${M}_$ord.log 2>&1
-  grep '^{' $O/${M}_$ord.log | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read())['roofline']; print('$M $ord', r['kernel'], r['avg_launch_us'], r['avg_launch_us_eager_all_events'])"
-  t=$(find $O/${M}_$ord -name "*kernel_trace.csv" | head -1); python tools/rocprof_trim.py $t $O/${M}_${ord}_warm.txt; head -8 $O/${M}_${ord}_warm.txt | cut -c1-130
-done; done
-find $O -size +3M -delete
+mkdir -p gpurun_out/r3e
+(LANES=2 timeout 300 python tools/ab_flag.py no_tuned resnet50 256 4) > gpurun_out/r3e/ab_tuned.log 2>&1
+timeout 600 python tools/gpu_check.py model/resnet50 golden/committed > gpurun_out/r3e/check.log 2>&1
+grep -c PASS gpurun_out/r3e/check.log; grep "FAIL" gpurun_out/r3e/check.log | cut -c1-300; cat gpurun_out/r3e/ab_tuned.log | tail -12
