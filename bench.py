@@ -14,8 +14,9 @@ Extra objects in the line:
   roofline     the dominant kernel = the GEMM-type kernel family with the largest summed duration in one forward.
                `achieved` = its algorithmic FLOPs per launch (2 x MACs, `flop_per_launch`) / its average launch duration
                (`avg_launch_us`) measured IN SITU with HIP events on the stream each launch runs on (an eager replay of the
-               lanes' launch lists on their own streams, right after the timed region) -- the duration rocprofv3's kernel
-               trace of this command reports for the same kernel (profiles/r03/<model>_rocprofv3_warm_stats.txt);
+               lanes' launch lists on their own streams, right after the timed region; the last rows of a rocprofv3 kernel
+               trace of this command ARE that pass -- profiles/r03/roofline_vs_rocprof.txt checks the two clocks against each
+               other; the graph replays themselves run with less lane overlap under the profiler, see profiles/r03/README.md);
                `frac` = achieved / 2.5 PFLOP/s (dense bf16 MFMA peak).  `lanes1`: the same model as ONE launch list (lanes
                overlap in time, so only there does the sum over the dominant kernel's launches compare with a step);
                `isolated` (with --layers): every launch alone on the chip.  `whole_forward`: SURVEY section 8d's FLOPs per
@@ -431,8 +432,8 @@ def run_model(a, name, B, rank, world, soak_s):
             "frac": round(dom_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "kernel": dk, "launches_per_step": dv["n"],
             "avg_launch_us": round(dv["us"] / max(1, dv["n"]), 2),
             "how": f"in situ: eager replay of the {nl}-lane launch lists on {nl} stream(s), two HIP events around every launch on "
-                   "its own stream, 6 steps; compare rocprofv3 --kernel-trace of this command (graph replays; the lanes' overlap "
-                   "pattern in a graph replay is not identical to the eager one, profiles/r03/README.md)",
+                   "its own stream, 6 steps (the LAST 6 x launches_per_step rows of a rocprofv3 --kernel-trace of this command are "
+                   "this pass: profiles/r03/roofline_vs_rocprof.txt compares the two clocks)",
             "share_of_kernel_time": round(dv["us"] / max(1e-9, sum(r_["us"] for r_ in rows)), 3),
             "flop_per_launch": round(dv["gflop"] * 1e9 / max(1, dv["n"])),
             "kernel_hbm_gbs": round(dv["mb"] / dv["us"] * 1e3, 1) if dv["us"] else 0.0,

@@ -1,5 +1,11 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3e
-(LANES=2 timeout 300 python tools/ab_flag.py no_tuned resnet50 256 4) > gpurun_out/r3e/ab_tuned.log 2>&1
-timeout 600 python tools/gpu_check.py model/resnet50 golden/committed > gpurun_out/r3e/check.log 2>&1
-grep -c PASS gpurun_out/r3e/check.log; grep "FAIL" gpurun_out/r3e/check.log | cut -c1-300; cat gpurun_out/r3e/ab_tuned.log | tail -12
+O=gpurun_out/r3h; mkdir -p $O
+for spec in swin_t:128:88 resnet50:256:82; do
+  M=${spec%%:*}; r=${spec#*:}; B=${r%%:*}; N=${r##*:}
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/${M}_t -o t -- python bench.py --model $M --batch $B --steps 4 --warmup 1 --no-cpu --extra none --soak 0 --no-lanes1 > $O/$M.log 2>&1
+  t=$(find $O/${M}_t -name "*kernel_trace.csv" | head -1)
+  python tools/graph_timeline.py $t $N 7 > $O/${M}_timeline.txt
+  python tools/graph_timeline.py $t $N 0 > $O/${M}_timeline_eager.txt
+  head -3 $O/${M}_timeline.txt
+done
+find $O -size +3M -delete
