@@ -132,6 +132,11 @@ def launch_meta(name, args):
         flops = 4.0 * M * C * Hd
         byts = 2.0 * ob(args[10]) * M * C + 4.0 * C * Hd
         shape = f"M{M} C{C} hidden{Hd} LN+MLP+res"
+    elif name == "mv_fc_stream_fwd":
+        M, N, K = args[6:9]
+        flops = 2.0 * M * N * K
+        byts = 2.0 * (M * K + N * K) + ob(args[11]) * M * N
+        shape = f"M{M} K{K} N{N} fc (fragment-ordered weights, split-K)" + (" f32out" if args[11] == 0 else "")
     elif name == "mv_ln_mlp_stream_fwd":
         M, C, Hd = args[6:9]
         flops = 4.0 * M * C * Hd

@@ -68,6 +68,9 @@ PROTOTYPES = {
     "mv_ln_mlp_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp],
     "mv_swin_block_attn_supported": [_i] * 7,
     "mv_swin_block_attn_fwd": [_vp] * 7 + [_i] * 9 + [_f, _i, _vp],
+    "mv_fc_stream_supported": [_i64, _i, _i, _i, _i],
+    "mv_fc_stream_workspace": [_i64, _i, _i],
+    "mv_fc_stream_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp],
     "mv_ln_mlp_stream_supported": [_i64, _i, _i, _i],
     "mv_ln_mlp_stream_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp],
     "mv_conv2d_nchw_split_fwd": [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_i, _i, _i, _vp],
@@ -114,7 +117,7 @@ PROTOTYPES = {
     "mv_event_elapsed_ms": [_vp, _vp, C.POINTER(_f)],
     "mv_event_destroy": [_vp],
 }
-_RESTYPES = {"mv_last_error": C.c_char_p, "mv_last_kernel": C.c_char_p}
+_RESTYPES = {"mv_last_error": C.c_char_p, "mv_last_kernel": C.c_char_p, "mv_fc_stream_workspace": _i64}
 
 _lib = None
 _lock = threading.Lock()

@@ -189,7 +189,7 @@ int skinny_launch(const void* x, const void* w, const float* scale, const float*
                   int act, int out_dtype, hipStream_t stream);
 int stem_pool_supported(int C, int K, int R, int S, int sh, int sw, int ph, int pw, int pk, int ps, int pp, int act,
                         int x_dtype, int out_dtype, long long in_elems);
-int stem_pool_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H, int W,
+int stem_pool_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H, int W, int R,
                      int x_dtype, hipStream_t stream);
 int mha_mfma_supported(int N, int dh, int dtype);
 int mha_mfma_launch(const void* qkv, int head_major, void* out, float* probs, int B, int N, int H, int dh, float scale,

@@ -933,8 +933,8 @@ int mv_stem_conv_pool_fwd(const void* x, const void* w, const float* scale, cons
         return MV_E_UNSUPPORTED;
     }
     const int Ho = (H + 2 * ph - R) / sh + 1, Wo = (W + 2 * pw - S) / sw + 1;
-    MV_CHECK_ARG(Ho >= pool_k - pool_p && Wo >= pool_k - pool_p, "stem_conv_pool: image too small");
-    return stem_pool_launch(x, w, scale, shift, y, N, H, W, x_dtype, (hipStream_t)stream);
+    MV_CHECK_ARG(Ho >= pool_k - pool_p && Wo >= pool_k - pool_p && Ho + 2 * pool_p >= pool_k && Wo + 2 * pool_p >= pool_k, "stem_conv_pool: image too small");
+    return stem_pool_launch(x, w, scale, shift, y, N, H, W, R, x_dtype, (hipStream_t)stream);
 }
 
 int mv_conv1x1_chain_supported(int64_t M, int C, int K, int N2, int dtype) {

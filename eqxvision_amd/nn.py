@@ -328,6 +328,12 @@ class Sequential(Module):
                 if j < len(L) and isinstance(L[j], Lambda) and act_name(L[j].fn):
                     a = act_name(L[j].fn)
                     j += 1
+                if x.kind == "img" and a == "relu" and j < len(L) and type(L[j]) is MaxPool2d:
+                    # network entry from the raw image followed by a max-pool (alexnet.py:44-46): one launch where the
+                    # library has the fused kernel for this configuration (ops.stem_conv_pool falls back to the pair)
+                    x = ops.stem_conv_pool(x, layer, bn, a, L[j])
+                    i = j + 1
+                    continue
                 x = ops.conv2d(x, layer, bn, a)
                 i = j
                 continue

@@ -645,9 +645,35 @@ def linear(x: Act, lin, act=None, residual: Optional[Act] = None, out_fp32: bool
         if tuple(residual.t.shape) != tuple(y.shape) or residual.t.dtype != odt:
             raise ValueError(f"residual shape/dtype mismatch in linear: {residual} vs {tuple(y.shape)} {odt}")
         res = residual.t
+    odc = _lib.F32 if out_fp32 else DT[dt]
+    if res is None and dt == "bf16" and _lib.load().mv_fc_stream_supported(M, N, K, DT[dt], odc):
+        # few rows, a big weight matrix (AlexNet / VGG classifiers): the layer is bound by streaming W -- fragment-ordered weights,
+        # split-K over the CUs, fixed-order reduction (csrc/fc_stream.hip)
+        wf = fc_fragments(lin)
+        nbytes = int(_lib.load().mv_fc_stream_workspace(M, N, K))
+        ws = empty((nbytes // 4,), torch.float32)
+        _lib.call("mv_fc_stream_fwd", _ptr(x.t), _ptr(wf), _ptr(b), _ptr(y), _ptr(ws), nbytes, M, N, K, ACT[act], DT[dt], odc, stream_ptr())
+        return Act(y, x.kind, x.batched)
     _lib.call("mv_linear_fwd", _ptr(x.t), _ptr(w), None, _ptr(b), _ptr(res), _ptr(y), M, N, K, ACT[act],
-              DT[dt], _lib.F32 if out_fp32 else DT[dt], stream_ptr())
+              DT[dt], odc, stream_ptr())
     return Act(y, x.kind, x.batched)
+
+
+def fc_fragments(lin) -> torch.Tensor:
+    """Linear weight [N][K] in MFMA fragment order for csrc/fc_stream.hip: [N / 32 tiles][K / 16 steps][64 lanes][8] bf16, lane
+    (n = l % 32, h = l / 32) holds W[32 tile + n][16 step + 8 h .. + 7]; N is padded to a multiple of 32 with zero rows (cached)."""
+    cache = lin._cache()
+    hit = cache.get("fc_frag")
+    if hit is None:
+        w = torch.from_numpy(np.ascontiguousarray(np.asarray(lin.weight, np.float32))).to(torch.bfloat16)
+        N, K = w.shape
+        NT = (N + 31) // 32
+        if NT * 32 != N:
+            w = torch.cat([w, torch.zeros((NT * 32 - N, K), dtype=torch.bfloat16)], dim=0)
+        # [NT][32 n][K/16][2 h][8] -> [NT][K/16][2 h][32 n][8]
+        hit = w.view(NT, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().to(device())
+        cache["fc_frag"] = hit
+    return hit
 
 
 def linear_head(x: Act, lin) -> Act:

@@ -247,6 +247,18 @@ int mv_ln_mlp_stream_supported(int64_t M, int C, int hidden, int x_dtype);
 int mv_ln_mlp_stream_fwd(const void* x, const void* w1f, const float* b1, const void* w2f, const float* b2, void* y, int64_t M,
                          int C, int hidden, float eps, int x_dtype, mv_stream_t stream);
 
+/* eqx.nn.Linear over FEW rows with a big weight matrix -- the AlexNet / VGG classifiers (alexnet.py:62-70: Linear(9216, 4096),
+ * Linear(4096, 4096), Linear(4096, classes), each behind `jax.vmap` = M rows) -- y[M][N] = act(x[M][K] . w^T + bias).  The layer is
+ * bound by streaming w: w_frag is w in MFMA fragment order, prepared once by the caller (eqxvision_amd/ops.py:fc_fragments),
+ *   w_frag[tile 0..ceil(N/32)-1][step 0..K/16-1][lane 0..63][e 0..7] = w[32*tile + lane%32][16*step + 8*(lane/32) + e]  (zero rows past N);
+ * the reduction is split over the CUs and the fp32 partial sums are added in a fixed order (bit-reproducible) by a second launch.
+ * x: MV_BF16 [M][K]; y: MV_BF16 or MV_F32 [M][N]; bias fp32 [N] or NULL; workspace: device memory of at least
+ * mv_fc_stream_workspace(M, N, K) bytes, owned by the caller, free again when the call has completed on `stream`. */
+int mv_fc_stream_supported(int64_t M, int N, int K, int in_dtype, int out_dtype);
+int64_t mv_fc_stream_workspace(int64_t M, int N, int K);
+int mv_fc_stream_fwd(const void* x, const void* w_frag, const float* bias, void* y, void* workspace, int64_t workspace_bytes, int64_t M,
+                     int N, int K, int act, int in_dtype, int out_dtype, mv_stream_t stream);
+
 /* jax.image.resize(x, shape, method="bilinear") for up-sampling (segmentation/_utils.py:52-58: logits -> input resolution;
  * deeplabv3.py:66-72: the pooled ASPP branch back to the feature size): half-pixel centres, out-of-range taps dropped and the
  * rest renormalised (== clamped taps for the 2-tap kernel).  x NHWC [N,h,w,C]; y NHWC [N,H,W,C] or, with out_nchw, NCHW

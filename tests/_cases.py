@@ -905,13 +905,54 @@ def avgpool_case(N, H, W, C, oh, ow, dtype="bf16", seed=0):
     return run
 
 
-def stem_pool_case(N, H, W, xdtype="fp32", seed=0, neg_scale=False):
-    """mv_stem_conv_pool_fwd (conv 7x7/2 + BN + ReLU + maxpool 3/2/1, one launch) vs the oracle chain
-    conv2d -> scale/shift -> relu -> (bf16 rounding) -> maxpool2d (reference resnet.py:243-254)."""
+def fc_stream_case(M, K, N, act=0, out="bf16", bias=True, seed=0):
+    """mv_fc_stream_fwd (few rows x a big weight matrix: the AlexNet / VGG classifier Linears, alexnet.py:62-70): fragment-ordered
+    weights, split-K + fixed-order reduction vs float64; two runs are bit-identical; also against mv_linear_fwd's kernel."""
     def run():
         L = _lib()
         rng = _rng(seed)
-        C, K, R = 3, 64, 7
+        x = bf(rng.standard_normal((M, K)))
+        w = bf(rng.standard_normal((N, K)) / np.sqrt(K))
+        b = (0.1 * rng.standard_normal(N)).astype(np.float32) if bias else None
+        ref = x.astype(np.float64) @ w.astype(np.float64).T + (0 if b is None else b)
+        if act == 1:
+            ref = O.relu(ref)
+        odc = 1 if out == "bf16" else 0
+        if not L.load().mv_fc_stream_supported(M, N, K, 1, odc):
+            return {"ok": False, "err": "mv_fc_stream_supported says no"}
+        NT = (N + 31) // 32
+        wp = np.zeros((NT * 32, K), np.float32)
+        wp[:N] = w
+        wf = np.ascontiguousarray(wp.reshape(NT, 32, K // 16, 2, 8).transpose(0, 2, 3, 1, 4))       # [tile][step][h][n][e]
+        xd, wd = dev(x, "bf16"), dev(wf, "bf16")
+        bd = None if b is None else dev(b, "fp32")
+        nbytes = int(L.load().mv_fc_stream_workspace(M, N, K))
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device="cuda")
+        ys = []
+        for _ in range(2):
+            y = torch.full((M, N), -7.0, dtype=torch.bfloat16 if out == "bf16" else torch.float32, device="cuda")
+            L.call("mv_fc_stream_fwd", xd.data_ptr(), wd.data_ptr(), None if bd is None else bd.data_ptr(), y.data_ptr(), ws.data_ptr(), nbytes,
+                   M, N, K, act, 1, odc, _stream())
+            ys.append(y)
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        info = _cmp(host(ys[0]), ref, TOL_BF16 if out == "bf16" else TOL_F32 * 10)      # bf16 operands: the fp32 result carries their rounding
+        info["kernel"] = kern
+        info["reproducible"] = bool(torch.equal(ys[0], ys[1]))
+        info["ok"] = info["ok"] and info["reproducible"]
+        return info
+    return run
+
+
+def stem_pool_case(N, H, W, xdtype="fp32", seed=0, neg_scale=False, alexnet=False):
+    """mv_stem_conv_pool_fwd (conv 7x7/2 + BN + ReLU + maxpool 3/2/1, one launch) vs the oracle chain
+    conv2d -> scale/shift -> relu -> (bf16 rounding) -> maxpool2d (reference resnet.py:243-254); `alexnet`: the same entry for
+    conv 11x11/4 pad 2 + bias + ReLU + maxpool 3/2 (reference alexnet.py:44-46; scale = NULL, shift = the bias)."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        C, K = 3, 64
+        R, st, pad, pp = (11, 4, 2, 0) if alexnet else (7, 2, 3, 1)
         x = rng.random((N, C, H, W), dtype=np.float32) * 2 - 0.7
         if xdtype == "bf16":
             x = bf(x)
@@ -919,24 +960,29 @@ def stem_pool_case(N, H, W, xdtype="fp32", seed=0, neg_scale=False):
         sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
         if neg_scale:
             sc[::3] *= -1.0            # BN gamma may be negative: scale/shift must be applied BEFORE the max
+        if alexnet:
+            sc[:] = 1.0
         sf = (0.1 * rng.standard_normal(K)).astype(np.float32)
-        if not L.load().mv_stem_conv_pool_supported(C, K, R, R, 2, 2, 3, 3, 3, 2, 1, 1, DT[xdtype], 1, N * C * H * W):
+        if not L.load().mv_stem_conv_pool_supported(C, K, R, R, st, st, pad, pad, 3, 2, pp, 1, DT[xdtype], 1, N * C * H * W):
             return {"ok": False, "err": "mv_stem_conv_pool_supported says no"}
         xr = bf(x)
-        conv = np.stack([O.conv2d(xr[i], w, None, 2, 3) for i in range(N)]) * sc[None, :, None, None] + sf[None, :, None, None]
+        conv = np.stack([O.conv2d(xr[i], w, None, st, pad) for i in range(N)]) * sc[None, :, None, None] + sf[None, :, None, None]
         conv = bf(O.relu(conv))
-        ref = np.stack([O.maxpool2d(conv[i], 3, 2, 1) for i in range(N)])          # [N, K, Po, Qo]
+        ref = np.stack([O.maxpool2d(conv[i], 3, 2, pp) for i in range(N)])          # [N, K, Po, Qo]
         Po, Qo = ref.shape[2], ref.shape[3]
         ref = ref.transpose(0, 2, 3, 1)
         xd, wd = dev(x, xdtype), dev(w, "bf16")
         scd, sfd = dev(sc, "fp32"), dev(sf, "fp32")
         y = torch.full((N, Po, Qo, K), -7.0, dtype=torch.bfloat16, device="cuda")
-        L.call("mv_stem_conv_pool_fwd", xd.data_ptr(), wd.data_ptr(), scd.data_ptr(), sfd.data_ptr(), y.data_ptr(),
-               N, C, H, W, K, R, R, 2, 2, 3, 3, 3, 2, 1, 1, DT[xdtype], 1, _stream())
+        L.call("mv_stem_conv_pool_fwd", xd.data_ptr(), wd.data_ptr(), None if alexnet else scd.data_ptr(), sfd.data_ptr(), y.data_ptr(),
+               N, C, H, W, K, R, R, st, st, pad, pad, 3, 2, pp, 1, DT[xdtype], 1, _stream())
         kern = L.last_kernel()
         torch.cuda.synchronize()
         info = _cmp(host(y), ref, TOL_BF16)
         info["kernel"] = kern
+        if alexnet and not kern.startswith("stem_pool11"):
+            info["ok"] = False
+            info["err_msg"] = f"expected the fused 11x11 entry kernel, ran {kern}"
         return info
     return run
 
@@ -1868,6 +1914,18 @@ def all_cases():
           ("stem/pool_fused_many_tiles", stem_pool_case(40, 128, 128, seed=10)),
           ("stem/pool_fused_odd_bf16in_61x70", stem_pool_case(3, 61, 70, xdtype="bf16", seed=11)),
           ("stem/pool_fused_w228_h30", stem_pool_case(2, 30, 228, seed=12)),
+          ("fc_stream/alexnet_fc1_M128", fc_stream_case(128, 9216, 4096, act=1, seed=1)),
+          ("fc_stream/alexnet_fc2_M128", fc_stream_case(128, 4096, 4096, act=1, seed=2)),
+          ("fc_stream/alexnet_fc3_M128_f32out_N1000", fc_stream_case(128, 4096, 1000, out="fp32", seed=3)),
+          ("fc_stream/M3_small", fc_stream_case(3, 1024, 4096, act=1, seed=4)),
+          ("fc_stream/M200_two_row_blocks_N512", fc_stream_case(200, 1152, 2048, seed=5)),
+          ("fc_stream/M130_N260_K640_nobias", fc_stream_case(130, 8192, 260, bias=False, seed=6)),
+          ("fc_stream/M256_vgg_fc1_K25088", fc_stream_case(256, 25088, 4096, act=1, seed=7)),
+          ("stem/pool11_fused_224", stem_pool_case(3, 224, 224, seed=13, alexnet=True)),
+          ("stem/pool11_fused_67_bf16in", stem_pool_case(2, 67, 67, xdtype="bf16", seed=14, alexnet=True)),
+          ("stem/pool11_fused_odd_131x95", stem_pool_case(2, 131, 95, seed=15, alexnet=True)),
+          ("stem/pool11_fused_many_tiles", stem_pool_case(20, 160, 160, seed=16, alexnet=True)),
+          ("stem/pool11_fused_w228_h43", stem_pool_case(2, 43, 228, seed=17, alexnet=True)),
           ("stem/vit_224_bf16in", conv_nchw_case(2, 3, 224, 224, 768, 16, 16, 16, 0, tokens=True, xdtype="bf16")),
           ("stem/patch8_notokens", conv_nchw_case(3, 3, 40, 48, 192, 8, 8, 8, 0)),
           ("stem/odd_size_7x7", conv_nchw_case(1, 3, 61, 75, 32, 7, 7, 2, 3, act=1))]
