@@ -4,8 +4,8 @@ resnet50 bf16 forward, batch 256 per MI355X; `--model vit_base` = configs[2]).
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched through
 `torch.distributed.run` (one rank per GPU, RCCL) -- or spawns those ranks itself when WORLD_SIZE is unset.
-At 1 GPU the same invocation also times vit_base (B=256, the other half of the headline metric) and swin_t (B=128)
-and reports them under "extra".  A step = one forward of the per-GPU batch through the
+At 1 GPU the same invocation also times vit_base (B=256, the other half of the headline metric), swin_t (B=128) and
+alexnet (B=256, configs[0]'s model) and reports them under "extra".  A step = one forward of the per-GPU batch through the
 HIP path (hipGraph replay of the recorded launch list) + the all-gather of the fp32 logits; images are
 already resident in HBM.  W untimed warm-up steps, then exactly K timed steps bracketed by
 barrier + synchronize; MAX over ranks; rank 0 prints ONE JSON line.
@@ -515,7 +515,7 @@ def main():
     ap.add_argument("--layers", default=None, help="write a per-launch worksheet of --model to this file")
     ap.add_argument("--extra", default=None,
                     help="comma list of further models timed in the same invocation and reported under \"extra\" "
-                         "(default at 1 GPU for the headline model: vit_base,swin_t; 'none' = only --model)")
+                         "(default at 1 GPU for the headline model: vit_base,swin_t,alexnet; 'none' = only --model)")
     ap.add_argument("--soak", type=float, default=None, help="seconds of untimed graph replays before the warm-up steps "
                                                              "(default 5 at 1 GPU, 2 otherwise)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -546,13 +546,13 @@ def main():
     default_batch = {"swin_t": 128}
     extras = []
     if world == 1 and a.extra != "none":
-        extras = [m for m in (a.extra.split(",") if a.extra else (["vit_base", "swin_t"] if a.model == "resnet50" else [])) if m]
+        extras = [m for m in (a.extra.split(",") if a.extra else (["vit_base", "swin_t", "alexnet"] if a.model == "resnet50" else [])) if m]
     soak = a.soak if a.soak is not None else (5.0 if world == 1 else 2.0)
 
     # CPU baseline FIRST (rank 0, 1 GPU only), so that the GPU phase is the tail of the run
     cpu = {}
     if world == 1 and not a.no_cpu:
-        for m in [a.model] + [e for e in extras if e in ("vit_base", "swin_t")]:
+        for m in [a.model] + [e for e in extras if e in ("vit_base", "swin_t", "alexnet")]:
             try:
                 cpu[m] = cpu_baseline(m, build_model(m), torch.get_num_threads())
             except Exception as e:  # noqa: BLE001

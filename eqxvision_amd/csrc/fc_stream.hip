@@ -153,6 +153,7 @@ static int fc_splits(long long M, int N, int K) {
     const int nb = (N + 127) / 128, nc = K / FC_CH, mb = (int)((M + FC_MB - 1) / FC_MB);
     int s = 512 / (nb * mb);                                     // ~two workgroups per CU (70 KB of LDS each)
     if (s > nc) s = nc;
+    if (s > K / 512) s = K / 512;                                // partial sums written + read (8 S bytes per output of 128 rows) <= the weight bytes
     if (s > 32) s = 32;
     return s < 1 ? 1 : s;
 }

@@ -319,6 +319,7 @@ struct TunedTile { const char* kind; int M, a, b, R, S, sh, choice; };
 static const TunedTile kTuned[] = {
     {"ov", 25088, 1024, 256, 1, 1, 1, 10},    // layer-3 conv1 1x1 1024 -> 256 at 128 images: igemm8 256x256 (98 tiles) over 128x256 (196)
     {"ov", 6272, 512, 512, 3, 3, 1, 12},      // layer-4 conv2 3x3 at 128 images: igemm8 256x128
+    {"ov", 21632, 192, 384, 3, 3, 1, 12},     // alexnet conv3 (13 x 13, 192 -> 384) at 128 images: igemm8 256x128 (+0.9%, gpurun_out/r3l/tune_alexnet.log)
 };
 int tile_override(const char* kind, long long M, int a, int b, int R, int S, int sh) {
     char key[96];

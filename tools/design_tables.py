@@ -8,7 +8,7 @@ tj = json.load(open(os.path.join(P, "traffic.json")))
 _out = []
 def print(*a):                                                  # noqa: A001 -- collect, then patch DESIGN.md between its markers
     _out.append(" ".join(str(x) for x in a))
-for M in ("resnet50", "vit_base", "swin_t"):
+for M in ("resnet50", "vit_base", "swin_t", "alexnet"):
     b = json.load(open(f"{P}/{R}/{M}_bench_layers.json"))
     bp = json.load(open(f"{P}/{R}/{M}_bench.json"))
     b1 = json.load(open(f"{P}/{R}/{M}_lanes1_bench.json"))

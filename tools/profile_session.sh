@@ -5,7 +5,7 @@
 TAG=${1:-prof}; export ROUND=${2:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
-for spec in resnet50:256 vit_base:256 swin_t:128; do
+for spec in resnet50:256 vit_base:256 swin_t:128 alexnet:256; do
   M=${spec%%:*}; B=${spec##*:}
   CMD="python bench.py --model $M --batch $B --steps 20 --warmup 5 --no-cpu --extra none --soak 1 --no-lanes1"
   timeout 400 $CMD --layers $O/${M}_per_launch.txt > $O/${M}_bench_layers.json 2> $O/${M}_bench.err
@@ -25,7 +25,7 @@ for spec in resnet50:256 vit_base:256 swin_t:128; do
   done
   timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/${M}_SQ -o t -- python bench.py --model $M --batch $B --steps 2 --warmup 2 --no-cpu --extra none --soak 0 --no-graph --no-lanes1 > $O/${M}_SQ.log 2>&1
 done
-for spec in resnet50 vit_base swin_t; do
+for spec in resnet50 vit_base swin_t alexnet; do
   t=$(find $O/${spec}_trace -name "*kernel_trace.csv" | head -1)
   n=$(python -c "import json; print(json.load(open('$O/${spec}_bench.json'))['config']['launches_per_step'])")
   [ -n "$t" ] && python tools/graph_timeline.py $t $n 7 > $O/${spec}_graph_timeline_under_rocprofv3.txt
@@ -45,17 +45,18 @@ def fam(name):
                    ("igemm_bf16_kernel<128, 128", "igemm_bf16_128x128"), ("igemm_bf16_kernel<128, 64", "igemm_bf16_128x64"),
                    ("stream1x1_kernel", "stream1x1"), ("chain1x1_kernel<64, 8, false", "chain1x1_bf16_64_256_64"),
                    ("chain1x1_kernel<128", "chain1x1_bf16_64_256_128"), ("chain1x1_kernel<64, 6, true", "chain1x1_dual_bf16_64+64_256_64"), ("chain_stream_kernel", "chain_stream_bf16_128_512_128"),
-                   ("conv3x3c64_v2_kernel", "conv3x3c64_halo"), ("stem_pool_kernel", "stem_pool_mfma_f32in"),
+                   ("conv3x3c64_v2_kernel", "conv3x3c64_halo"), ("stem_pool_kernel<float, true, 11", "stem_pool11_mfma_f32in"), ("stem_pool_kernel", "stem_pool_mfma_f32in"),
                    ("patch_embed_kernel", "patch_embed_mfma_f32in"), ("mha_mfma_kernel", "mha_mfma_dh64_hm"),
                    ("layernorm_vec_kernel", "layernorm_vec"), ("ln_mlp96_kernel", "ln_mlp96_f32stream"), ("swin_attn_mfma", "swin_attn_mfma"), ("skinny_f32_kernel", "skinny_linear_f32_mfma"),
                    ("bneck_tail_kernel", "bneck_tail_bf16_14x14_256_1024"), ("ln_mlp_stream_kernel", "ln_mlp_stream_c384_f32stream"), ("ln_mlp_stream192_kernel", "ln_mlp_stream_c192_f32stream"),
                    ("swin_block_attn_kernel<384", "swin_block_attn_c384"), ("swin_block_attn_kernel<192", "swin_block_attn_c192"), ("swin_block_attn_kernel<96", "swin_block_attn_c96"),
-                   ("patch_merge_ln_kernel", "patch_merge_ln_f32in"), ("swin_stem_ln_kernel", "swin_stem_ln_k96")):
+                   ("patch_merge_ln_kernel", "patch_merge_ln_f32in"), ("swin_stem_ln_kernel", "swin_stem_ln_k96"),
+                   ("fc_stream_kernel", "fc_stream_bf16"), ("maxpool_nhwc_bf16x8_kernel", "maxpool_nhwc_bf16x8")):
         if sub in n: return f
     return None
 out = {"_batch": {}, "_rocprof": {}}
 lines = []
-for M, B in (("resnet50", 256), ("vit_base", 256), ("swin_t", 128)):
+for M, B in (("resnet50", 256), ("vit_base", 256), ("swin_t", 128), ("alexnet", 256)):
     acc = {"FETCH_SIZE": collections.defaultdict(list), "WRITE_SIZE": collections.defaultdict(list)}
     for C in acc:
         for f in glob.glob(f"{O}/{M}_{C}/**/*counter_collection.csv", recursive=True):
@@ -103,7 +104,7 @@ for M, B in (("resnet50", 256), ("vit_base", 256), ("swin_t", 128)):
 # so slowly that the second lane starts when the first is half done (<model>_graph_timeline_under_rocprofv3.txt).
 agree = ["# roofline.avg_launch_us printed by bench.py (HIP events, live) vs the rocprofv3 kernel trace of the SAME command:",
          "# 'same pass' = the trace rows of bench.py's own in-situ pass (last 6 eager replays); 'graph replays' = warm average over the whole trace"]
-for M in ("resnet50", "vit_base", "swin_t"):
+for M in ("resnet50", "vit_base", "swin_t", "alexnet"):
     try:
         bj = json.load(open(f"{O}/{M}_bench.json"))
         r = bj["roofline"]
