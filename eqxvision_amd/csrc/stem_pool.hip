@@ -344,7 +344,8 @@ int stem_pool_launch(const void* x, const void* w, const float* scale, const flo
     StemPoolP p;
     p.x = x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.y = (bf16_t*)y;
     p.N = N; p.H = H; p.W = W;
-    if (R == 11)                                          // 145 KB of LDS: one block per CU
+    if (R == 11)                                          // 145 KB of LDS: one block per CU; two pixel tiles per wave at once (+1.5 % on the model;
+                                                          // the same on the ResNet entry is 2.7 % SLOWER: it costs the second block per CU its slack)
         return stem_pool_go<11, 4, 2, 0, 84, 2>(p, x_dtype, 1, "stem_pool11_mfma_f32in", "stem_pool11_mfma_bf16in", st);
     return stem_pool_go<7, 2, 3, 1, 48, 1>(p, x_dtype, 2, "stem_pool_mfma_f32in", "stem_pool_mfma_bf16in", st);   // two blocks per CU
 }
