@@ -115,6 +115,11 @@ for M in ("resnet50", "vit_base", "swin_t", "alexnet"):
             for x in csv.DictReader(open(f)):
                 rows.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), x["Kernel_Name"]))
         rows.sort()
+        names = [k for _, _, k in rows]
+        for P in range(N, 4 * N):                       # kernels per replay: a C-ABI call may launch more than one kernel
+            if names[-P:] == names[-2 * P:-P] and sorted(names[-P:]) == sorted(names[-3 * P:-2 * P]):
+                N = P
+                break
         win = [(e - s) / 1e3 for s, e, k in rows[-6 * N:] if fam(k) == r["kernel"]]
         same = sum(win) / max(1, len(win))
         ok = len(win) == 6 * r["launches_per_step"]
