@@ -68,6 +68,8 @@ PROTOTYPES = {
     "mv_ln_mlp_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp],
     "mv_swin_block_attn_supported": [_i] * 7,
     "mv_swin_block_attn_fwd": [_vp] * 7 + [_i] * 9 + [_f, _i, _vp],
+    "mv_conv2d_nchw_f32out_supported": [_i] * 11,
+    "mv_conv2d_nchw_f32out_fwd": [_vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_i, _i, _i, _i, _vp, _vp],
     "mv_fc_stream_supported": [_i64, _i, _i, _i, _i],
     "mv_fc_stream_workspace": [_i64, _i, _i],
     "mv_fc_stream_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp],

@@ -915,6 +915,27 @@ int mv_conv2d_nchw_fwd(const void* x, const void* w, const float* scale, const f
     return conv_generic_dispatch(x, w, scale, shift, nullptr, y, pos, p, x_dtype, out_dtype, out_dtype, st);
 }
 
+int mv_conv2d_nchw_f32out_supported(int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int x_dtype) {
+    return !get_flag("force_generic") && stem_supported(C, K, R, S, x_dtype, MV_BF16) &&
+           stem_f32out_supported(C, H, W, K, R, S, sh, sw, ph, pw, x_dtype);
+}
+
+int mv_conv2d_nchw_f32out_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
+                              int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act, int x_dtype,
+                              int tok_stride, int tok_offset, const float* pos, mv_stream_t stream) {
+    MV_CHECK_ARG(act >= MV_ACT_NONE && act <= MV_ACT_SILU, "conv2d_nchw_f32out: unknown activation %d", act);
+    MV_CHECK_ARG(x && w && y, "conv2d_nchw_f32out: NULL pointer");
+    MV_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0, "conv2d_nchw_f32out: non-positive dims");
+    if (!mv_conv2d_nchw_f32out_supported(C, H, W, K, R, S, sh, sw, ph, pw, x_dtype)) {
+        set_error("conv2d_nchw_f32out: unsupported configuration (ask mv_conv2d_nchw_f32out_supported first)");
+        return MV_E_UNSUPPORTED;
+    }
+    const int Ho = (H - R) / sh + 1, Wo = (W - S) / sw + 1;
+    MV_CHECK_ARG(tok_stride == 0 || tok_stride >= tok_offset + Ho * Wo, "conv2d_nchw_f32out: tok_stride too small");
+    return stem_launch(x, w, scale, shift, y, N, C, H, W, K, R, S, sh, sw, ph, pw, act, x_dtype, MV_F32, tok_stride, tok_offset, pos,
+                       (hipStream_t)stream);
+}
+
 int mv_stem_conv_pool_supported(int C, int K, int R, int S, int sh, int sw, int ph, int pw, int pool_k, int pool_s,
                                 int pool_p, int act, int x_dtype, int out_dtype, int64_t in_elems) {
     return !get_flag("force_generic") && !get_flag("no_stem_pool") &&

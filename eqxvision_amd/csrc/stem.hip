@@ -470,7 +470,7 @@ struct PatchP {
     const float* scale;
     const float* shift;
     const float* pos;
-    bf16_t* y;
+    void* y;               // bf16, or fp32 (ViT tokens entering the fp32 residual stream un-rounded)
     const bf16_t* zero;
     int N, C, H, W, K, R, S, Ho, Wo;
     int CRS, M, tiles_m, tiles_n, act, tok_stride, tok_offset;
@@ -490,7 +490,7 @@ template <> struct Frag8<bf16_t> {
     __device__ __forceinline__ uint4 bf() const { return v; }
 };
 
-template <typename TX>
+template <typename TX, typename OutT>
 __global__ __launch_bounds__(256) void patch_embed_kernel(const PatchP p) {
     constexpr int BN = 128, ROWB = 128, TN = 4, WI = BN / 32;
     constexpr int STAGE = BN * ROWB;                       // 16 KB weight tile per stage
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const PatchP p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = apply_act_rt(v[e], p.act);
                 }
-                Out8<bf16_t>::st(p.y + orow * p.K + n, v);
+                Out8<OutT>::st((OutT*)p.y + orow * p.K + n, v);
             }
         }
     }
@@ -644,10 +644,10 @@ static bool patch_v2_ok(int C, int H, int W, int K, int R, int S, int sh, int sw
 }
 
 static int patch_v2_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
-                           int H, int W, int K, int R, int S, int act, int x_dtype, int tok_stride, int tok_offset,
+                           int H, int W, int K, int R, int S, int act, int x_dtype, int out_dtype, int tok_stride, int tok_offset,
                            const float* pos, hipStream_t st) {
     PatchP p;
-    p.x = x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.pos = pos; p.y = (bf16_t*)y;
+    p.x = x; p.w = (const bf16_t*)w; p.scale = scale; p.shift = shift; p.pos = pos; p.y = y;
     p.zero = (const bf16_t*)zero_page(st);
     if (!p.zero) {
         set_error("patch_embed: zero page allocation failed");
@@ -667,11 +667,20 @@ static int patch_v2_launch(const void* x, const void* w, const float* scale, con
     p.tiles_n = (K + 127) / 128;
     p.act = act; p.tok_stride = tok_stride; p.tok_offset = tok_offset;
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
+    if (out_dtype == MV_F32) {
+        set_kernel_name(x_dtype == MV_F32 ? "patch_embed_mfma_f32in_f32out" : "patch_embed_mfma_bf16in_f32out");
+        if (x_dtype == MV_F32)
+            hipLaunchKernelGGL((patch_embed_kernel<float, float>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((patch_embed_kernel<bf16_t, float>), grid, block, 0, st, p);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
     set_kernel_name(x_dtype == MV_F32 ? "patch_embed_mfma_f32in" : "patch_embed_mfma_bf16in");
     if (x_dtype == MV_F32)
-        hipLaunchKernelGGL(patch_embed_kernel<float>, grid, block, 0, st, p);
+        hipLaunchKernelGGL((patch_embed_kernel<float, bf16_t>), grid, block, 0, st, p);
     else
-        hipLaunchKernelGGL(patch_embed_kernel<bf16_t>, grid, block, 0, st, p);
+        hipLaunchKernelGGL((patch_embed_kernel<bf16_t, bf16_t>), grid, block, 0, st, p);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }
@@ -683,12 +692,21 @@ int stem_supported(int C, int K, int R, int S, int x_dtype, int out_dtype) {
            R < 256 && S < 256;
 }
 
+// fp32 result (the ViT token rows that START the fp32 residual stream): only the non-overlapping-patch GEMM writes it
+int stem_f32out_supported(int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int x_dtype) {
+    return (x_dtype == MV_F32 || x_dtype == MV_BF16) && patch_v2_ok(C, H, W, K, R, S, sh, sw, ph, pw, x_dtype) && !get_flag("stem_v0") &&
+           !get_flag("no_patch_f32out");
+}
+
 int stem_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C, int H,
                 int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act, int x_dtype, int out_dtype,
                 int tok_stride, int tok_offset, const float* pos, hipStream_t st, const void* w_lo) {
-    (void)out_dtype;
     if (!w_lo && patch_v2_ok(C, H, W, K, R, S, sh, sw, ph, pw, x_dtype) && !get_flag("stem_v0"))
-        return patch_v2_launch(x, w, scale, shift, y, N, C, H, W, K, R, S, act, x_dtype, tok_stride, tok_offset, pos, st);
+        return patch_v2_launch(x, w, scale, shift, y, N, C, H, W, K, R, S, act, x_dtype, out_dtype, tok_stride, tok_offset, pos, st);
+    if (out_dtype != MV_BF16) {
+        set_error("stem conv: fp32 output only from the non-overlapping patch kernel");
+        return MV_E_UNSUPPORTED;
+    }
     if (!w_lo && stem_v1_ok(C, K, R, S, sw, tok_stride) && !get_flag("stem_v0"))
         return stem_v1_launch(x, w, scale, shift, y, N, C, H, W, K, R, S, sh, sw, ph, pw, act, x_dtype, st);
     StemP p;

@@ -163,8 +163,8 @@ class VisionTransformer(Module):
             pe._check(x)
             cls = ops.prep_f32(self, "cls_token", self.cls_token.reshape(-1))
             pos = ops.prep_f32(self, "pos_embed", self.pos_embed)
-            t = ops.patch_embed_tokens(x, pe.proj, cls, pos, 1)
-            return ops.cast(t, "fp32") if residual_fp32() else t
+            t = ops.patch_embed_tokens(x, pe.proj, cls, pos, 1, out_fp32=residual_fp32())
+            return ops.cast(t, "fp32") if residual_fp32() else t         # no-op when the rows were written in fp32
         raise NotImplementedError("VisionTransformer expects a raw (C,H,W) image and the default PatchEmbed")
 
     def _head(self, x: Act) -> Act:

@@ -754,10 +754,11 @@ def patch4_ln(x: Act, conv, ln) -> Optional[Act]:
     return Act(y, "map", x.batched)
 
 
-def patch_embed_tokens(x: Act, conv, cls: Optional[torch.Tensor], pos: Optional[torch.Tensor], n_extra: int) -> Act:
+def patch_embed_tokens(x: Act, conv, cls: Optional[torch.Tensor], pos: Optional[torch.Tensor], n_extra: int, out_fp32: bool = False) -> Act:
     """PatchEmbed conv (k = s = patch) straight from the NCHW image into token rows
     [B, n_extra + P, D]; with `pos` the position embedding is added in the epilogue and row 0 gets
-    cls + pos[0] (vit.py:268-269)."""
+    cls + pos[0] (vit.py:268-269).  `out_fp32` (bf16 mode with the fp32 residual stream): the rows are written in fp32 where the
+    library has that epilogue, else in the compute dtype (the caller casts)."""
     dt = compute_dtype()
     if x.kind != "img":
         raise ValueError("patch_embed expects a raw (C,H,W) image")
@@ -770,6 +771,13 @@ def patch_embed_tokens(x: Act, conv, cls: Optional[torch.Tensor], pos: Optional[
     Ho = (H + 2 * ph - kh) // sh + 1
     Wo = (W + 2 * pw - kw) // sw + 1
     T = n_extra + Ho * Wo
+    if out_fp32 and dt == "bf16" and _lib.load().mv_conv2d_nchw_f32out_supported(C, H, W, K, kh, kw, sh, sw, ph, pw, x.dt):
+        y = empty((B, T, K), torch.float32)
+        _lib.call("mv_conv2d_nchw_f32out_fwd", _ptr(x.t), _ptr(w), _ptr(scale), _ptr(shift), _ptr(y),
+                  B, C, H, W, K, kh, kw, sh, sw, ph, pw, _lib.ACT_NONE, x.dt, T, n_extra, _ptr(pos), stream_ptr())
+        if n_extra:
+            _lib.call("mv_vit_cls_pos_fwd", _ptr(cls), _ptr(pos), _ptr(y), B, T, K, _lib.F32, stream_ptr())
+        return Act(y, "seq", x.batched)
     y = empty((B, T, K), TORCH_DT[dt])
     _lib.call("mv_conv2d_nchw_fwd", _ptr(x.t), _ptr(w), _ptr(scale), _ptr(shift), _ptr(y),
               B, C, H, W, K, kh, kw, sh, sw, ph, pw, _lib.ACT_NONE, x.dt, DT[dt], T, n_extra, _ptr(pos), stream_ptr())

@@ -79,6 +79,14 @@ int mv_conv2d_nchw_fwd(const void* x, const void* w, const float* scale, const f
                        int sh, int sw, int ph, int pw, int act, int x_dtype, int out_dtype,
                        int tok_stride, int tok_offset, const float* pos, mv_stream_t stream);
 
+/* The same entry with bf16 operands and an fp32 result: the ViT patch embedding (patch_embed.py:60-62, vit.py:268-269) whose token
+ * rows START the fp32 residual stream -- they are not rounded to bf16 on the way (and the cast pass disappears).  w OIHW bf16, y
+ * fp32 rows; non-overlapping patches only (stride = kernel, no padding, S % 8 == 0): ask the _supported entry. */
+int mv_conv2d_nchw_f32out_supported(int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int x_dtype);
+int mv_conv2d_nchw_f32out_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,
+                              int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int act, int x_dtype,
+                              int tok_stride, int tok_offset, const float* pos, mv_stream_t stream);
+
 /* The ResNet network entry in one launch (resnet.py:243-254: conv1 -> bn1 -> relu -> maxpool):
  * x NCHW [N,C,H,W] of x_dtype, w OIHW, folded BN scale/shift, y NHWC [N][Po][Qo][K] with
  * (Ho, Wo) the convolution's and (Po, Qo) the MaxPool2d(pool_k, pool_s, pool_p) output size.  The conv map

@@ -285,7 +285,9 @@ def dual_case(N, Ho, Wo, C1, C2, K, stride, act=1, seed=0, flags=()):
 
 
 def conv_nchw_case(N, C, H, W, K, R, S, stride, pad, act=0, xdtype="fp32", tokens=False, generic=False, seed=0,
-                   v0=False):
+                   v0=False, f32out=False):
+    """`f32out`: mv_conv2d_nchw_f32out_fwd -- bf16 operands, fp32 rows (the ViT tokens that start the fp32 residual stream): the
+    result must match the exact product of the bf16 operands to fp32 accuracy, i.e. it was NOT rounded to bf16."""
     def run():
         L = _lib()
         rng = _rng(seed)
@@ -311,15 +313,25 @@ def conv_nchw_case(N, C, H, W, K, R, S, stride, pad, act=0, xdtype="fp32", token
             T = P + 1
             pos = rng.standard_normal((T, K)).astype(np.float32)
             posd = dev(pos, "fp32")
-            y = torch.zeros((N, T, K), dtype=torch.bfloat16, device="cuda")
+            y = torch.zeros((N, T, K), dtype=torch.float32 if f32out else torch.bfloat16, device="cuda")
             ref = np.concatenate([np.zeros((N, 1, K), np.float32), ref + pos[None, 1:]], 1)
             targs = (T, 1, posd.data_ptr())
         else:
-            y = torch.empty((N, P, K), dtype=torch.bfloat16, device="cuda")
+            y = torch.empty((N, P, K), dtype=torch.float32 if f32out else torch.bfloat16, device="cuda")
             targs = (0, 0, None)
         L.set_flag("force_generic", 1 if generic else 0)
         L.set_flag("stem_v0", 1 if v0 else 0)
         try:
+            if f32out:
+                if not L.load().mv_conv2d_nchw_f32out_supported(C, H, W, K, R, S, stride, stride, pad, pad, DT[xdtype]):
+                    return {"ok": False, "err": "mv_conv2d_nchw_f32out_supported says no"}
+                L.call("mv_conv2d_nchw_f32out_fwd", xd.data_ptr(), wd.data_ptr(), scd.data_ptr(), sfd.data_ptr(), y.data_ptr(),
+                       N, C, H, W, K, R, S, stride, stride, pad, pad, act, DT[xdtype], *targs, _stream())
+                kern = L.last_kernel()
+                torch.cuda.synchronize()
+                info = _cmp(host(y), ref, TOL_F32)                  # bf16 operands, exact products, fp32 accumulation and store
+                info["kernel"] = kern
+                return info
             L.call("mv_conv2d_nchw_fwd", xd.data_ptr(), wd.data_ptr(), scd.data_ptr(), sfd.data_ptr(), y.data_ptr(),
                    N, C, H, W, K, R, S, stride, stride, pad, pad, act, DT[xdtype], 1, *targs, _stream())
             kern = L.last_kernel()
@@ -1927,6 +1939,9 @@ def all_cases():
           ("stem/pool11_fused_many_tiles", stem_pool_case(20, 160, 160, seed=16, alexnet=True)),
           ("stem/pool11_fused_w228_h43", stem_pool_case(2, 43, 228, seed=17, alexnet=True)),
           ("stem/vit_224_bf16in", conv_nchw_case(2, 3, 224, 224, 768, 16, 16, 16, 0, tokens=True, xdtype="bf16")),
+          ("stem/vit_patch16_tokens_f32out", conv_nchw_case(2, 3, 64, 64, 768, 16, 16, 16, 0, tokens=True, f32out=True)),
+          ("stem/vit_224_f32out", conv_nchw_case(3, 3, 224, 224, 768, 16, 16, 16, 0, tokens=True, f32out=True, seed=3)),
+          ("stem/vit_224_bf16in_f32out_no_tokens", conv_nchw_case(2, 3, 224, 224, 384, 16, 16, 16, 0, xdtype="bf16", f32out=True, seed=4)),
           ("stem/patch8_notokens", conv_nchw_case(3, 3, 40, 48, 192, 8, 8, 8, 0)),
           ("stem/odd_size_7x7", conv_nchw_case(1, 3, 61, 75, 32, 7, 7, 2, 3, act=1))]
     c += [("maxpool/3_2_1", maxpool_case(2, 112, 112, 64, 3, 2, 1)),
