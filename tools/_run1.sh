@@ -1,3 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 300 python tools/lane_offset.py swin_t 128 2>&1 | tail -6
-timeout 300 python tools/lane_offset.py alexnet 256 2>&1 | tail -6
+for m in resnet50:256 swin_t:128 alexnet:256 vit_base:256; do
+  M=${m%%:*}; B=${m##*:}
+  timeout 600 python bench.py --model $M --batch $B --steps 1500 --warmup 20 --no-cpu --extra none --soak 2 --no-lanes1 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$M', d['value'], d['ms_per_step'], d['steps'])"
+done
+rocm-smi --showmeminfo vram 2>/dev/null | grep -i "used" | head -2
