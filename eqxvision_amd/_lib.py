@@ -13,7 +13,7 @@ import threading
 from . import _trace
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libeqxvision_amd.so")
+LIB_PATH = os.environ.get("EQV_LIB") or os.path.join(_HERE, "csrc", "libeqxvision_amd.so")   # EQV_LIB: tools only (debug build)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU_TANH = 0, 1, 2

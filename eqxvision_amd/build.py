@@ -13,8 +13,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libeqxvision_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-if os.environ.get("EQV_PROF"):          # debug build: per-block / per-barrier time stamps in igemm2 / igemm8 (tools/phase_prof.py)
-    FLAGS.append("-DMV_I8_PROF")
+PROF = bool(os.environ.get("EQV_PROF"))
+if PROF:          # debug build: per-block / per-barrier time stamps in igemm2 / igemm8 (tools/phase_prof.py); its own library and
+    FLAGS.append("-DMV_I8_PROF")      # object directory, loaded with EQV_LIB=<path> -- the product library is never a debug build
+    LIB = os.path.join(CSRC, "libeqxvision_amd_prof.so")
 
 
 def _newer(src, dst):
@@ -24,7 +26,7 @@ def _newer(src, dst):
 def build(force: bool = False, verbose: bool = True) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build_prof" if PROF else "build")
     os.makedirs(objdir, exist_ok=True)
     newest_hdr = max(os.path.getmtime(h) for h in hdrs)
     jobs = []

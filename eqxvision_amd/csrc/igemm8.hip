@@ -178,6 +178,13 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
 #else
 #define MV_I8_STAMP() do {} while (0)
 #endif
+    if (p.skew > 0 && blockIdx.x < 256) {          // experiment (i8_skew): de-phase the first round of workgroups by quarters
+        const int q = (blockIdx.x >> 3) & 3;
+        if (q) {
+            const long long t_end = wall_clock64() + (long long)q * p.skew;
+            while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     int tile_m, tile_n;
     tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n, p.gm);
@@ -245,7 +252,13 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
     }
 
     // ---------------- epilogue constants (older than every DMA: vmcnt retires in order) ------------------
+#ifdef MV_I8_PROF
+    const OutT* res = (p.dbg & 8) ? nullptr : (const OutT*)p.residual;       // ablation: no residual loads
+    const bool do_store = !(p.dbg & 4);                                       // ablation: no global stores
+#else
     const OutT* res = (const OutT*)p.residual;
+    constexpr bool do_store = true;
+#endif
     ScaleShift8 ss;
     ss.load(p.scale, p.shift, n0 + 64 * wc + (lane & 7) * 8, p.K);
 
@@ -413,7 +426,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
             const int n = n0 + wrow0 + c8 * 8;
             const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
             const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
-            if (m < p.M && n < p.K) {
+            if (m < p.M && n < p.K && do_store) {
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 ss.apply(v);
                 if (res) late[b & 1][pass].add_to(v);
@@ -722,6 +735,7 @@ static int igemm8_go(Igemm2P& p, bool dual, bool out_f32, int tile, hipStream_t 
     p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = (p.K + bn - 1) / bn;
     p.gm = get_flag("i8_gm") ? get_flag("i8_gm") : 8;
+    p.skew = get_flag("i8_skew");
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(512);
 #define GO(KERN, SMEM)                                                                                            \
     do {                                                                                                          \

@@ -20,6 +20,7 @@ struct Igemm2P {
     const bf16_t* x2;               // igemm2 DUAL: second reduction source, NHWC [N][H2][W2][C2], read at pixel stride s2
     int C2, H2, W2, s2;
     int gm;                         // igemm8: pixel tiles per group of the tile order (mfma_common.h: tile_coords)
+    int skew;                       // igemm8 experiment: start delay of the first-round workgroups, (block / 8 & 3) x skew x 10 ns
     int tok;                        // > 0: head-major output y[b][n/64][t][n%64], rows m = b*tok + t (qkv projection)
 };
 

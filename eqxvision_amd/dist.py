@@ -87,10 +87,16 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         try:
             native_comm_init(rank, world)
         except _lib.MVError as e:
-            # The library's own RCCL binding could not come up (e.g. librccl not loadable): keep the run alive on PyTorch's
-            # binding of the SAME library -- a second process group with backend nccl (== RCCL); never a host-staged gather.
+            # The library's own RCCL binding could not come up (e.g. librccl not loadable).  DESIGN.md section 6 promises ONE
+            # collective, `mv_allgather` on the launch stream; a different backend is never chosen silently.  Opt in with
+            # EQV_DIST_ALLOW_TORCH=1 to keep a run alive on PyTorch's binding of the same library (a second process group,
+            # backend nccl == RCCL; never a host-staged gather).
+            if os.environ.get("EQV_DIST_ALLOW_TORCH") != "1":
+                raise _lib.MVError(
+                    f"mv_comm_init failed ({e}); the sharded forward needs the native RCCL communicator. "
+                    "Set EQV_DIST_ALLOW_TORCH=1 to route the logits all-gather through torch.distributed (nccl) instead.") from e
             import warnings
-            warnings.warn(f"mv_comm_init failed ({e}); routing the logits all-gather through torch.distributed (nccl)")
+            warnings.warn(f"mv_comm_init failed ({e}); EQV_DIST_ALLOW_TORCH=1: the logits all-gather goes through torch.distributed (nccl)")
             _state["group"] = dist.new_group(backend="nccl")
     return rank, world, local
 

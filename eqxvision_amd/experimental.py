@@ -2,6 +2,7 @@
 
     getter = intermediate_layer_getter(model, get_target_layers)
     out, feats = getter(x, key=key)          # feats: outputs of the target layers, in the order get_target_layers listed them
+                                             # (for an `nn.Sequential` model: in LAYER order, as the reference hands its wrappers out)
 
 `get_target_layers(model)` returns the target sub-modules (or, for an `nn.Sequential`, their indices); a layer that runs several
 times in one forward reports its LAST output.
@@ -67,9 +68,32 @@ class LayerGetter(Module):
         out = self.model(x, key=key)
         return out, self._frame.take()
 
+    def aux(self) -> List[AuxData]:
+        """The last call's captures as the reference's `AuxData` holders."""
+        out = []
+        for v in self._frame.take():
+            a = AuxData()
+            a.update(v)
+            out.append(a)
+        return out
+
+
+class AuxData:
+    """Public name kept for API parity with the reference (experimental.py:8-21: one mutable `.data` holder per target layer).
+    The getter here keeps its captures in one `_Capture` frame; this holder is what `LayerGetter.aux()` hands out."""
+
+    def __init__(self):
+        self.data = None
+
+    def update(self, x):
+        self.data = x
+
 
 def _tap_sequential(seq: nn.Sequential, indices: Sequence[int], frame: _Capture) -> nn.Sequential:
-    order = {int(i): k for k, i in enumerate(indices)}           # layer index -> slot, in the caller's order
+    # the reference walks the layers and gives the next unused wrapper to every layer whose index is a target
+    # (experimental.py:60-68): slots follow LAYER order whatever order the indices were listed in, and a repeated index
+    # leaves the surplus slots at the end empty (None)
+    order = {i: k for k, i in enumerate(sorted({int(i) for i in indices}))}
     return nn.Sequential([_Tap(layer, order[i], frame) if i in order else layer for i, layer in enumerate(seq.layers)])
 
 
