@@ -88,6 +88,8 @@ PROTOTYPES = {
     "mv_conv1x1_chain_fwd": [_vp] * 10 + [_i64, _i, _i, _i, _i, _vp],
     "mv_bottleneck_tail_supported": [_i] * 5,
     "mv_bottleneck_tail_fwd": [_vp] * 9 + [_i] * 6 + [_vp],
+    "mv_bottleneck_strip_supported": [_i] * 7,
+    "mv_bottleneck_strip_fwd": [_vp] * 11 + [_i] * 8 + [_vp],
     "mv_conv1x1_dual_supported": [_i64, _i, _i, _i, _i],
     "mv_conv1x1_dual_fwd": [_vp] * 6 + [_i] * 11 + [_vp],
     "mv_conv1x1_dual_chain_supported": [_i64, _i, _i, _i, _i, _i],

@@ -105,11 +105,19 @@ class _ResNetBottleneck(Module):
         conv1 output attached to its input."""
         pre = x.pre if ops.is_act(x) else None
         x = ops.as_map(x)
+        ds = self.downsample
+        conv_ds = isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d) and \
+            isinstance(ds[1], nn.BatchNorm)
+        if pre is None and (isinstance(ds, nn.Identity) or conv_ds):
+            # the whole block in one launch, t1 / t2 on the CU, the input read once as operand and identity
+            # (ops.bottleneck_strip; None when the library has no such path for the shapes: everything but the 56x56 stage)
+            y = ops.bottleneck_strip(x, self, (ds[0], ds[1]) if conv_ds else None)
+            if y is not None:
+                return y
         if pre is not None and pre[0] is self.conv1:
             out = pre[1]
         else:
             out = ops.conv2d(x, self.conv1, self.bn1, "relu")
-        ds = self.downsample
         if isinstance(ds, nn.Identity):
             # identity block on a map that fits a CU: conv2 + conv3 + identity in one launch, the `width`-channel intermediate
             # stays in LDS (ops.bottleneck_tail; None when the library has no such path for the shapes)
@@ -117,8 +125,6 @@ class _ResNetBottleneck(Module):
             if y is not None:
                 return y
         out = ops.conv2d(out, self.conv2, self.bn2, "relu")
-        conv_ds = isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d) and \
-            isinstance(ds[1], nn.BatchNorm)
         if conv_ds:
             # identity = BN(conv1x1(x)) (resnet.py:295-303): it and conv3 add into one output -> one GEMM over the
             # concatenated reduction [out | x]; the identity map is never materialised

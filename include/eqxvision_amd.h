@@ -130,6 +130,26 @@ int mv_bottleneck_tail_fwd(const void* t1, const void* w2f, const float* scale2,
                            const float* scale3, const float* shift3, const void* residual, void* y, int B, int H, int W,
                            int width, int cout, int dtype, mv_stream_t stream);
 
+/* A WHOLE ResNet bottleneck of the 56x56 stage in one launch, row-strip tiled (resnet.py:144-162; first block of the stage:
+ * + the downsample branch, resnet.py:295-303):
+ *   t1 = relu(scale1 * conv1x1(x, w1) + shift1)            (64 channels, stays in LDS with a recomputed one-row halo, bf16)
+ *   t2 = relu(scale2 * conv3x3_pad1(t1, w2) + shift2)      (64 channels, stays in registers, bf16)
+ *   dual = 0:  y = relu(scale3 * (t2 . w3^T) + shift3 + x)                        x[B,56,56,256] is read ONCE: operand and identity
+ *   dual = 1:  y = relu((t2 . w3s^T + x . wds^T) + shift3)                        x[B,56,56,64]; w3s = scale3 * w3, wds = scale_d * w_d
+ *                                                                                   (rows folded by the caller), shift3 = shift3 + shift_d,
+ *                                                                                   scale3 = ones
+ * One workgroup = 8 rows x 56 columns of one image.  Weights in FRAGMENT ORDER (eqxvision_amd/ops.py:prep_bneck_strip),
+ * lane = 32 * (k-half) + (output channel % 32), e = 8 consecutive input channels:
+ *   w1f[a 0..1][j 0..cin/16-1][lane][e]       = w1[k = 32 a + lane%32][c = 16 j + 8 (lane/32) + e]
+ *   w2f[a 0..1][tap r*3+s][j 0..3][lane][e]   = w2[k = 32 a + lane%32][r][s][c = 16 j + 8 (lane/32) + e]         (KRSC)
+ *   w3f[a 0..7][j 0..3 (dual: 0..7)][lane][e] = wcat[k = 32 a + lane%32][c = 16 j + 8 (lane/32) + e],  wcat = w3 or [w3s | wds]
+ * Supported: bf16, 56x56, width 64, cout 256, cin 256 (dual 0) or 64 (dual 1): ResNet-50/101/152 layer1.  y must not alias x. */
+int mv_bottleneck_strip_supported(int H, int W, int cin, int width, int cout, int dual, int dtype);
+int mv_bottleneck_strip_fwd(const void* x, const void* w1f, const float* scale1, const float* shift1, const void* w2f,
+                            const float* scale2, const float* shift2, const void* w3f, const float* scale3,
+                            const float* shift3, void* y, int B, int H, int W, int cin, int width, int cout, int dual,
+                            int dtype, mv_stream_t stream);
+
 /* conv3 + BN and the downsample conv + BN of a stage's first bottleneck (resnet.py:144-162, 295-303) as ONE GEMM over
  * the concatenated reduction: both add into the same output, so
  *   y[N,Ho,Wo,K] = act(scale[k] * (x[N,Ho,Wo,C1] . wcat[k, 0:C1] + x2[N, s*ho, s*wo, C2] . wcat[k, C1:C1+C2]) + shift[k])

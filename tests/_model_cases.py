@@ -931,6 +931,35 @@ def pth_reader_case():
     return run
 
 
+def strip_vs_unfused_case(B=3):
+    """resnet50 with layer 1 on the whole-bottleneck strip kernel (mv_bottleneck_strip_fwd: t1 / t2 on the CU, input read once)
+    against the SAME model on the default un-fused launches (conv3x3c64 + chain1x1 trio): the two paths round at the
+    same places, so the logits must agree far inside the bf16 tolerance; `bit_identical` says whether they agree exactly."""
+    def run():
+        import eqxvision_amd as eqv
+        from eqxvision_amd import _lib as L
+        sd = S.resnet_state(1, "bottleneck", (3, 4, 6, 3), 1000)
+        net = _load(eqv.models.resnet50, sd, num_classes=1000)
+        x = S.synthetic_images(B, 224, seed=5)
+        L.set_flag("bneck_strip", 1)                 # the strip kernel is opt-in (ops.bottleneck_strip)
+        rec = []
+        old = L.set_recording(rec)
+        try:
+            got = _run(net, x, "bf16").float().cpu().numpy()
+        finally:
+            L.set_recording(old)
+            L.set_flag("bneck_strip", 0)
+        n_strip = sum(1 for r in rec if r[2] == "mv_bottleneck_strip_fwd")
+        base = _run(net, x, "bf16").float().cpu().numpy()
+        ref = TR.resnet_forward(sd, x, "bottleneck", (3, 4, 6, 3)).numpy()
+        out = _cmp(got, base, 2e-3, {"bit_identical": bool((got == base).all()), "err_vs_oracle": float(np.abs(got - ref).max()),
+                                     "unfused_err_vs_oracle": float(np.abs(base - ref).max())})
+        out["strip_launches"] = n_strip
+        out["ok"] = out["ok"] and out["err_vs_oracle"] <= 1e-2 and n_strip == 3           # all three blocks of layer 1
+        return out
+    return run
+
+
 def _hot_model(name, sd):
     """(factory-loaded inference model, torch-restatement forward) of one of the three full-size hot models on checkpoint `sd`."""
     import warnings
@@ -1083,6 +1112,7 @@ def all_cases(full=True):
               ("model/alexnet_B4_fp32", alexnet_case(4, dtype="fp32")),
               ("model/resnet50_B2", resnet_case("bottleneck", (3, 4, 6, 3), 224, 2, classes=1000, full_ref="torch")),
               ("model/resnet50_B3_chained_tail_head", resnet_case("bottleneck", (3, 4, 6, 3), 224, 3, classes=1000, full_ref="torch")),
+              ("model/resnet50_strip_vs_unfused_layer1", strip_vs_unfused_case(3)),
               ("model/resnet50_B5_odd_200px", resnet_case("bottleneck", (3, 4, 6, 3), 200, 5, classes=1000, full_ref="torch")),
               ("model/resnet_2111_160px_B7_mixed_paths", resnet_case("bottleneck", (2, 1, 1, 1), 160, 7, classes=10, full_ref="torch")),
               ("model/resnet_1211_128px_B16_mixed_paths", resnet_case("bottleneck", (1, 2, 1, 1), 128, 16, classes=10, full_ref="torch")),
