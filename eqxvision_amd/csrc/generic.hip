@@ -579,6 +579,45 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const TI* __restrict
     }
 }
 
+// The same LayerNorm on <= 64 VGPRs and no LDS (fp32 rows in, bf16 out, C = 256 * CHUNKS <= 1024): one wave per row, the row in
+// CHUNKS x 4 registers, no second row in flight.  Alone it is slower than the kernel above; its point is WHERE it can run: a
+// Linear-layer igemm8 workgroup (igemm8.hip, LIN) takes 8 waves x 224 VGPRs of a CU, which leaves 64 registers per SIMD lane --
+// room for exactly one such wave per SIMD.  With two graph lanes the LayerNorm of one lane then runs UNDER the other lane's GEMM
+// main loop (whose memory pipe is idle) instead of time-slicing the CUs with it.
+template <int CHUNKS>
+__global__ __launch_bounds__(256) void layernorm_slim_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, bf16_t* __restrict__ y, long long M,
+                                                             float eps) {
+    constexpr int C = 256 * CHUNKS;
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * 4;
+    for (long long row = gw; row < M; row += nw) {
+        const float* xr = x + row * C + lane * 4;
+        float4 v[CHUNKS];
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) v[i] = *(const float4*)(xr + 256 * i);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = group_sum<64>(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+        const float rstd = rsqrtf(group_sum<64>(q) * (1.0f / C) + eps);
+        bf16_t* yr = y + row * C + lane * 4;
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) {
+            const float4 g = *(const float4*)(gamma + 256 * i + lane * 4), b = *(const float4*)(beta + 256 * i + lane * 4);
+            *(uint2*)(yr + 256 * i) = make_uint2(pack_bf2(v[i].x * rstd * g.x + b.x, v[i].y * rstd * g.y + b.y),
+                                                 pack_bf2(v[i].z * rstd * g.z + b.z, v[i].w * rstd * g.w + b.w));
+        }
+    }
+}
+
 template <typename T>
 __global__ void eltwise_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, int act) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -1231,6 +1270,21 @@ int mv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void*
     dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block)), block(64 * rows_per_block);
     const int epc = in_dtype == MV_BF16 ? 8 : 4;          // elements per 16-byte chunk of the input
     const int nch = C / epc;
+    if (!get_flag("no_ln_slim") && in_dtype == MV_F32 && out_dtype == MV_BF16 && gamma && beta && xs == C && C % 256 == 0 && C <= 768 &&
+        !get_flag("force_generic")) {
+        set_kernel_name("layernorm_slim");
+        long long nb = (M + 3) / 4;
+        if (nb > 2048) nb = 2048;
+        dim3 sgrid((unsigned)nb), sblock(256);
+#define GOS(CH) hipLaunchKernelGGL((layernorm_slim_kernel<CH>), sgrid, sblock, 0, st, (const float*)x, gamma, beta, (bf16_t*)y, (long long)M, eps)
+        if (C == 256) GOS(1);
+        else if (C == 512) GOS(2);
+        else if (C == 768) GOS(3);
+        else GOS(4);
+#undef GOS
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
     if (C % epc == 0 && xs % epc == 0 && nch <= 64 * 8 && !get_flag("force_generic")) {
         set_kernel_name("layernorm_vec");
         const int width = nch <= 16 ? 16 : (nch <= 32 ? 32 : 64);

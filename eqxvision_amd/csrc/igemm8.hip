@@ -150,8 +150,18 @@ __device__ __forceinline__ void row_setup(const Igemm2P& p, const RowBase& rb, i
     mask = mk;
 }
 
-template <typename OutT, bool DUAL>
+// LIN: a Linear layer (dense 1x1 rows, no per-channel scale, one source).  The tap masks and the scale registers go away, which
+// takes the kernel from 235 to <= 224 VGPRs: two of its waves then leave 64 registers per SIMD lane free, exactly one wave of the
+// 64-register streaming kernels (LayerNorm, element-wise) -- with two graph lanes those run UNDER this kernel's main loop, whose
+// memory pipe is idle, instead of time-slicing the CUs with it.
+//
+// MODE 0: any convolution.  MODE 1 (DENSE): a dense 1x1 layer, one source -- no tap masks, the k-tile advance is two additions
+// (measured on the ViT qkv shape: 114.6 -> 101.4 us, the DMA issue path loses its per-piece mask test).  MODE 2 (LIN) = DENSE
+// without the per-channel scale (Linear layers).
+template <typename OutT, bool DUAL, int MODE = 0>
 __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
+    constexpr bool DENSE = MODE >= 1, LIN = MODE == 2;
+    static_assert(!(DUAL && DENSE), "DENSE is single-source");
     constexpr int BM = 256, BN = 256;
     constexpr int ROWB = 128;
     constexpr int EPITCH = 64 * 4 + 16;
@@ -220,11 +230,17 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * (8 * ROWB));
 
+    auto tap_adv = [&](TapState& s, int tile) {
+        if constexpr (DENSE) { s.woff += 128u; s.xoff += 128u; }     // the next 64 channels of both operands
+        else tap_next<DUAL>(p, s, tile, nk1);
+    };
     // the pieces of one k-tile: W x4, Xtop x2 (group 0 rows, group 1 rows), Xbot x2; BUF compile-time
     auto x_piece = [&](int q, const TapState& s, int tile, auto loff) {
         constexpr int LOFF = decltype(loff)::value;
         if (DUAL && tile >= nk1) {
             if constexpr (DUAL) dma16<LOFF>(ldsw, xvo2[q], rx2, s.xoff);
+        } else if constexpr (DENSE) {
+            dma16<LOFF>(ldsw, xvo[q], rx, s.xoff);        // rows past M carry OOB themselves; no taps
         } else {
             const unsigned vo = (xmask[q] & s.bit) ? xvo[q] : OOB;
             dma16<LOFF>(ldsw, vo, rx, s.xoff);
@@ -260,7 +276,8 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
     constexpr bool do_store = true;
 #endif
     ScaleShift8 ss;
-    ss.load(p.scale, p.shift, n0 + 64 * wc + (lane & 7) * 8, p.K);
+    if constexpr (LIN) ss.load_shift(p.shift, n0 + 64 * wc + (lane & 7) * 8, p.K);
+    else ss.load(p.scale, p.shift, n0 + 64 * wc + (lane & 7) * 8, p.K);
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -279,7 +296,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
     MV_I8_X(0, 2, sb, 0);
     MV_I8_X(0, 3, sb, 0);
     if (nk > 1) {
-        tap_next<DUAL>(p, sa, 1, nk1);
+        tap_adv(sa, 1);
         MV_I8_W(1, sa);
         MV_I8_X(1, 0, sa, 1);
         wait_vm<7>();
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
         if (!do_dma) {
             wait_vm_lgkm0<0>();
         } else if (it + 1 < nk) {
-            tap_next<DUAL>(p, sb, it + 1, nk1);
+            tap_adv(sb, it + 1);
             MV_I8_X(BUF ^ 1, 1, sb, it + 1);
             MV_I8_X(BUF ^ 1, 2, sb, it + 1);
             MV_I8_X(BUF ^ 1, 3, sb, it + 1);
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
         if (!do_dma) {
             wait_vm_lgkm0<0>();
         } else if (it + 2 < nk) {
-            tap_next<DUAL>(p, sa, it + 2, nk1);
+            tap_adv(sa, it + 2);
             MV_I8_W(BUF, sa);
             MV_I8_X(BUF, 0, sa, it + 2);
             wait_vm_lgkm0<7>();          // W and both Xtop pieces of tile it+1 have landed
@@ -428,7 +445,8 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
             const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
             if (m < p.M && n < p.K && do_store) {
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                ss.apply(v);
+                if constexpr (LIN) ss.apply_shift(v);
+                else ss.apply(v);
                 if (res) late[b & 1][pass].add_to(v);
                 if (p.act == MV_ACT_RELU) {
 #pragma unroll
@@ -484,8 +502,9 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
 //   ARR = 1: block = 256 pixels x 128 channels (group g: pixel rows 128 g ..; its waves 2 (pixels) x 2 (channels)) -- layers
 //            with 128 output channels (ResNet layer2).
 // Per FLOP it stages 1.5x the bytes of the 256 x 256 tile, so it is the slower kernel wherever both fill the chip.
-template <typename OutT, int ARR, bool DUAL>
+template <typename OutT, int ARR, bool DUAL, bool DENSE = false>
 __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
+    static_assert(!(DUAL && DENSE), "DENSE is single-source");
     constexpr int BM = ARR == 0 ? 128 : 256, BN = ARR == 0 ? 256 : 128;
     constexpr int ROWB = 128;
     constexpr int XI = BM / 64, WI = BN / 64;              // DMA pieces per thread per k-tile
@@ -530,6 +549,10 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * (8 * ROWB));
 
+    auto tap_adv = [&](TapState& s, int tile) {
+        if constexpr (DENSE) { s.woff += 128u; s.xoff += 128u; }
+        else tap_next<DUAL>(p, s, tile, nk1);
+    };
     auto stage = [&](const TapState& st, int tile, auto slotc) {
         constexpr int BASE = decltype(slotc)::value * SLOT;
         const bool second = DUAL && tile >= nk1;
@@ -541,6 +564,13 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
                     dma16<BASE + 2 * 8192>(ldsw, xvo2[2], rx2, st.xoff);
                     dma16<BASE + 3 * 8192>(ldsw, xvo2[3], rx2, st.xoff);
                 }
+            }
+        } else if constexpr (DENSE) {
+            dma16<BASE + 0 * 8192>(ldsw, xvo[0], rx, st.xoff);
+            dma16<BASE + 1 * 8192>(ldsw, xvo[1], rx, st.xoff);
+            if constexpr (XI == 4) {
+                dma16<BASE + 2 * 8192>(ldsw, xvo[2], rx, st.xoff);
+                dma16<BASE + 3 * 8192>(ldsw, xvo[3], rx, st.xoff);
             }
         } else {
             dma16<BASE + 0 * 8192>(ldsw, (xmask[0] & st.bit) ? xvo[0] : OOB, rx, st.xoff);
@@ -585,7 +615,7 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
     TapState st = tap_first();
     stage(st, 0, std::integral_constant<int, 0>{});
     if (nk > 1) {
-        tap_next<DUAL>(p, st, 1, nk1);
+        tap_adv(st, 1);
         stage(st, 1, std::integral_constant<int, 1>{});
         wait_vm<6>();
     } else {
@@ -606,7 +636,7 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
             lds_read16<OFF + 32 * ROWB>(xf[1][kk], SL == 2 ? xaddr2[kk] : xaddr[kk]);
         }
         if (it + 2 < nk) {                                   // tile it+2 goes where tile it-1 was (last read a phase ago)
-            tap_next<DUAL>(p, st, it + 2, nk1);
+            tap_adv(st, it + 2);
             stage(st, it + 2, std::integral_constant<int, (SL + 2) % 3>{});
             wait_vm_lgkm0<6>();                              // tile it+1 has landed
         } else {
@@ -753,12 +783,27 @@ static int igemm8_go(Igemm2P& p, bool dual, bool out_f32, int tile, hipStream_t 
             else GO((NAME<bf16_t, ##__VA_ARGS__, false>), SMEM);              \
         }                                                                     \
     } while (0)
-    if (tile == 1) GO4(igemm8s_kernel, 3 * 384 * 128, 0);
+    const bool dense1 = !dual && p.R == 1 && p.S == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0 && !get_flag("no_i8_lin");
+    if (tile == 1 && dense1) {
+        if (out_f32) GO((igemm8s_kernel<float, 0, false, true>), 3 * 384 * 128);
+        else GO((igemm8s_kernel<bf16_t, 0, false, true>), 3 * 384 * 128);
+    } else if (tile == 2 && dense1) {
+        if (out_f32) GO((igemm8s_kernel<float, 1, false, true>), 3 * 384 * 128);
+        else GO((igemm8s_kernel<bf16_t, 1, false, true>), 3 * 384 * 128);
+    } else if (tile == 1) GO4(igemm8s_kernel, 3 * 384 * 128, 0);
     else if (tile == 2) GO4(igemm8s_kernel, 3 * 384 * 128, 1);
 #ifdef MV_I8_PROF
     else GO4(igemm8_kernel, LDS_TOTAL + 4096);
 #else
-    else GO4(igemm8_kernel, LDS_TOTAL);
+    else if (!dual && p.R == 1 && p.S == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0 && !get_flag("no_i8_lin")) {
+        if (p.scale) {
+            if (out_f32) GO((igemm8_kernel<float, false, 1>), LDS_TOTAL);
+            else GO((igemm8_kernel<bf16_t, false, 1>), LDS_TOTAL);
+        } else {
+            if (out_f32) GO((igemm8_kernel<float, false, 2>), LDS_TOTAL);
+            else GO((igemm8_kernel<bf16_t, false, 2>), LDS_TOTAL);
+        }
+    } else GO4(igemm8_kernel, LDS_TOTAL);
 #endif
 #undef GO4
 #undef GO

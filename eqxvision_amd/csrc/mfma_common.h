@@ -94,6 +94,17 @@ struct ScaleShift8 {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
     }
+    // Linear layers (no per-channel scale): only the 8 shift registers are ever written or read
+    __device__ __forceinline__ void load_shift(const float* shift, int n, int N) {
+        const int nn = (n + 8 <= N) ? n : 0;
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f), d = c;
+        if (shift) { c = *(const float4*)(shift + nn); d = *(const float4*)(shift + nn + 4); }
+        sh[0] = c.x; sh[1] = c.y; sh[2] = c.z; sh[3] = c.w; sh[4] = d.x; sh[5] = d.y; sh[6] = d.z; sh[7] = d.w;
+    }
+    __device__ __forceinline__ void apply_shift(float* v) const {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += sh[e];
+    }
 };
 
 }  // namespace mv
