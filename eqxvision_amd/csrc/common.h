@@ -171,9 +171,6 @@ int igemm8_launch(const void* x, const void* w, const float* scale, const float*
 int igemm8_dual_launch(const void* x, const void* x2, const void* w, const float* scale, const float* shift,
                        const void* residual, void* y, int N, int Ho, int Wo, int C1, int H2, int W2, int C2, int s2, int K,
                        int act, int out_dtype, int tile, hipStream_t st);
-int igemm8h_supported(long long M, int C, int K, long long x_bytes, long long w_bytes);
-int igemm8h_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y, long long M,
-                   int C, int K, int act, int out_dtype, int tok, hipStream_t st);
 int stem_supported(int C, int K, int R, int S, int x_dtype, int out_dtype);
 int stem_f32out_supported(int C, int H, int W, int K, int R, int S, int sh, int sw, int ph, int pw, int x_dtype);
 int stem_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int C,

@@ -835,10 +835,6 @@ int igemm8_launch(const void* x, const void* w, const float* scale, const float*
     p.dbg = get_flag("i8_ablate");
 #endif
     const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
-    // two workgroups per CU (igemm8h.hip): flag i8h = 1: every dense layer this entry gets; 2: only where the big tile was chosen
-    if (dense && (tile == 1 || tile == 2) && get_flag("i8h") && (get_flag("i8h") == 1 || tile == 1) &&
-        igemm8h_supported(M, C, K, 2LL * M * C, 2LL * K * C))
-        return igemm8h_launch(x, w, scale, shift, residual, y, M, C, K, act, out_dtype, tok, st);
     if (tile == 2) set_kernel_name(dense ? "igemm8_bf16_128x256_dense" : "igemm8_bf16_128x256_conv");
     else if (tile == 3) set_kernel_name(dense ? "igemm8_bf16_256x128_dense" : "igemm8_bf16_256x128_conv");
     else set_kernel_name(dense ? "igemm8_bf16_256x256_dense" : "igemm8_bf16_256x256_conv");
