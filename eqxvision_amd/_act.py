@@ -134,7 +134,7 @@ def on_replay(fn) -> None:
 
 
 class Act:
-    __slots__ = ("t", "kind", "batched", "pre")
+    __slots__ = ("t", "kind", "batched", "pre", "node")
 
     def __init__(self, t: torch.Tensor, kind: str, batched: bool):
         self.t = t
@@ -142,6 +142,7 @@ class Act:
         self.batched = batched
         self.pre = None     # (module, Act): the result of applying `module` (+ its norm + relu) to this activation was
                             # already produced by the launch that produced it (ops.conv1x1_chain)
+        self.node = None    # under filter_value_and_grad: the autograd node that produced this activation (grad.py)
 
     @property
     def B(self) -> int:

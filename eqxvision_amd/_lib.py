@@ -112,6 +112,18 @@ PROTOTYPES = {
     "mv_nchw_to_nhwc": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mv_nhwc_to_nchw": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mv_cast": [_vp, _vp, _i64, _i, _i, _vp],
+    "mv_conv2d_dgrad_nhwc_f32": [_vp, _vp, _vp] + [_i] * 13 + [_vp],
+    "mv_conv2d_wgrad_nhwc_f32": [_vp, _vp, _vp] + [_i] * 13 + [_vp],
+    "mv_act_bwd_f32": [_vp, _vp, _vp, _i64, _i, _vp],
+    "mv_maxpool2d_bwd_nhwc_f32": [_vp, _vp, _vp] + [_i] * 10 + [_vp],
+    "mv_avgpool_global_bwd_nhwc_f32": [_vp, _vp, _i, _i, _i, _vp],
+    "mv_colsum_f32": [_vp, _vp, _vp, _i64, _i, _vp],
+    "mv_bn_dgamma_f32": [_vp, _vp, _vp, _vp, _f, _vp, _i, _vp],
+    "mv_layernorm_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp],
+    "mv_softmax_bwd_f32": [_vp, _vp, _vp, _i64, _i, _f, _vp],
+    "mv_softmax_xent_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "mv_adam_step_f32": [_vp, _vp, _vp, _vp, _i64] + [_f] * 6 + [_vp],
+    "mv_transpose2d_f32": [_vp, _vp, _i, _i, _i64, _vp],
     "mv_graph_begin_capture": [_vp],
     "mv_graph_end_capture": [_vp, C.POINTER(_vp)],
     "mv_graph_launch": [_vp, _vp],
@@ -169,8 +181,13 @@ def set_recording(rec):
     return old
 
 
+_grad_guard = None      # set by eqxvision_amd.grad: refuses launches of un-differentiable ops inside filter_value_and_grad
+
+
 def call(name, *args):
     lib = load()
+    if _grad_guard is not None:
+        _grad_guard(name)
     fn = getattr(lib, name)
     if _trace.enabled:
         _trace.push(name)

@@ -1,0 +1,374 @@
+// Backward half of a training step (reference tests/test_grads.py:35-47: eqx.filter_value_and_grad +
+// optax.adam on the classification models): the gradient kernels that have no forward twin, all fp32.  The contractions that
+// ARE a forward contraction with other operands (Linear dgrad / wgrad, attention's four products) go through the forward
+// entries (mv_linear_fwd on transposed operands, eqxvision_amd/grad.py); what lives here:
+//   * Conv2d dgrad / wgrad for any filter, stride, padding, dilation (groups = 1), NHWC maps, KRSC filters;
+//   * activation (ReLU / GELU-tanh), max-pool and global-average-pool backward;
+//   * column reductions (bias, BatchNorm / LayerNorm gamma and beta gradients), the BatchNorm gamma gradient for a normalisation
+//     with RUNNING statistics (the reference's training branch normalises with the updated running statistics, which the
+//     gradient treats as constants: eqx.experimental.BatchNorm keeps its state outside the differentiated pytree);
+//   * LayerNorm and softmax backward, softmax cross-entropy with its gradient, the Adam update, a 2-D transpose.
+// Minimum slice: correctness first (one thread per output element, VALU); the matrix-core versions are future work.
+#include "common.h"
+
+namespace mv {
+
+namespace {
+
+__global__ void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int H,
+                                  int W, int C, int K, int R, int S, int Ho, int Wo, int sh, int sw, int ph, int pw, int dh,
+                                  int dw) {
+    const long long pix = blockIdx.x;                       // (n, hi, wi)
+    const int wi = (int)(pix % W), hi = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const int th = hi + ph - r * dh;
+            if (th < 0 || th % sh) continue;
+            const int ho = th / sh;
+            if (ho >= Ho) continue;
+            for (int s = 0; s < S; ++s) {
+                const int tw = wi + pw - s * dw;
+                if (tw < 0 || tw % sw) continue;
+                const int wo = tw / sw;
+                if (wo >= Wo) continue;
+                const float* dyp = dy + (((long long)n * Ho + ho) * Wo + wo) * K;
+                const float* wp = w + ((long long)r * S + s) * C + c;
+                for (int k = 0; k < K; ++k) acc = fmaf(dyp[k], wp[(long long)k * R * S * C], acc);
+            }
+        }
+        dx[pix * C + c] = acc;
+    }
+}
+
+// one block per (k, r, s); threads over c; the block's threads walk the output positions together
+__global__ void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dwt, int N, int H,
+                                  int W, int C, int K, int R, int S, int Ho, int Wo, int sh, int sw, int ph, int pw, int dh,
+                                  int dw) {
+    const int krs = blockIdx.x;
+    const int s = krs % S, r = (krs / S) % R, k = krs / (R * S);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n)
+            for (int ho = 0; ho < Ho; ++ho) {
+                const int hi = ho * sh - ph + r * dh;
+                if ((unsigned)hi >= (unsigned)H) continue;
+                for (int wo = 0; wo < Wo; ++wo) {
+                    const int wi = wo * sw - pw + s * dw;
+                    if ((unsigned)wi >= (unsigned)W) continue;
+                    acc = fmaf(dy[(((long long)n * Ho + ho) * Wo + wo) * K + k], x[(((long long)n * H + hi) * W + wi) * C + c], acc);
+                }
+            }
+        dwt[(long long)krs * C + c] = acc;
+    }
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ref, float* __restrict__ dx, long long n,
+                               int act) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float g = dy[i], v = ref[i];
+        float d = g;
+        if (act == MV_ACT_RELU) {
+            d = v > 0.f ? g : 0.f;
+        } else if (act == MV_ACT_GELU_TANH) {                // d/dx [0.5 x (1 + tanh(u))], u = c (x + 0.044715 x^3)
+            const float c0 = 0.7978845608028654f, c1 = 0.044715f;
+            const float u = c0 * (v + c1 * v * v * v);
+            const float t = tanhf(u);
+            d = g * (0.5f * (1.f + t) + 0.5f * v * (1.f - t * t) * c0 * (1.f + 3.f * c1 * v * v));
+        }
+        dx[i] = d;
+    }
+}
+
+// gather form: an input element receives dy of every window in which it is the FIRST maximum (row-major scan of the window,
+// like the forward's max); no atomics, deterministic
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int N, int H,
+                                   int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int Ho, int Wo) {
+    const long long pix = blockIdx.x;
+    const int wi = (int)(pix % W), hi = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float me = x[pix * C + c];
+        float acc = 0.f;
+        for (int ho = 0; ho < Ho; ++ho) {
+            const int h0 = ho * sh - ph;
+            if (hi < h0 || hi >= h0 + kh) continue;
+            for (int wo = 0; wo < Wo; ++wo) {
+                const int w0 = wo * sw - pw;
+                if (wi < w0 || wi >= w0 + kw) continue;
+                bool first = true;                            // am I the first maximum of window (ho, wo)?
+                for (int r = 0; r < kh && first; ++r)
+                    for (int s = 0; s < kw; ++s) {
+                        const int a = h0 + r, b = w0 + s;
+                        if ((unsigned)a >= (unsigned)H || (unsigned)b >= (unsigned)W) continue;
+                        const float v = x[(((long long)n * H + a) * W + b) * C + c];
+                        const bool before = a < hi || (a == hi && b < wi);
+                        if (v > me || (before && v == me)) { first = false; break; }
+                    }
+                if (first) acc += dy[(((long long)n * Ho + ho) * Wo + wo) * C + c];
+            }
+        }
+        dx[pix * C + c] = acc;
+    }
+}
+
+__global__ void avgpool_global_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int HW, int C, long long n) {
+    const float inv = 1.0f / (float)HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long b = i / ((long long)C * HW);
+        dx[i] = dy[b * C + c] * inv;
+    }
+}
+
+// out[c] = sum_m a[m, c] * (b ? b[m, c] : 1): one block per 64 columns, 4 row groups reduced through LDS
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                      long long M, int C) {
+    __shared__ float part[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float acc = 0.f;
+    if (c < C)
+        for (long long m = rg; m < M; m += 4) acc += b ? a[m * C + c] * b[m * C + c] : a[m * C + c];
+    part[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < C) out[c] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+}
+
+__global__ void bn_dgamma_kernel(const float* __restrict__ dyz, const float* __restrict__ dys, const float* __restrict__ mean,
+                                 const float* __restrict__ var, float eps, float* __restrict__ dgamma, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) dgamma[c] = (dyz[c] - mean[c] * dys[c]) * rsqrtf(var[c] + eps);        // sum dy (z - mean) rstd
+}
+
+// one wave per row: dx = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)); dyxhat = dy xhat (its column sums are dgamma)
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ dy, float* __restrict__ dx,
+                                                             float* __restrict__ dyxhat, long long M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * C;
+    const float* gr = dy + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    float a = 0.f, b = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, gd = (gamma ? gamma[c] : 1.f) * gr[c];
+        a += gd; b += gd * xh;
+    }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    a /= (float)C; b /= (float)C;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, gd = (gamma ? gamma[c] : 1.f) * gr[c];
+        dx[row * C + c] = rstd * (gd - a - xh * b);
+        dyxhat[row * C + c] = gr[c] * xh;
+    }
+}
+
+// ds = scale * p * (dp - sum_j dp p)  (the softmax of scale * s, one wave per row)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                                           float* __restrict__ ds, long long rows, int cols, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += p[row * cols + c] * dp[row * cols + c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    for (int c = lane; c < cols; c += 64) ds[row * cols + c] = scale * p[row * cols + c] * (dp[row * cols + c] - s);
+}
+
+// optax.softmax_cross_entropy(logits, onehot).mean(): loss = mean_b (logsumexp(l_b) - sum_k t_bk l_bk); dlogits = (softmax - t) / B
+__global__ __launch_bounds__(64) void softmax_xent_kernel(const float* __restrict__ logits, const float* __restrict__ target,
+                                                           float* __restrict__ loss_rows, float* __restrict__ dlogits, int B, int K) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* l = logits + (long long)b * K;
+    const float* t = target + (long long)b * K;
+    float mx = -3.0e38f;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, l[k]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float se = 0.f, tl = 0.f, ts = 0.f;
+    for (int k = lane; k < K; k += 64) { se += expf(l[k] - mx); tl += t[k] * l[k]; ts += t[k]; }
+    for (int o = 32; o > 0; o >>= 1) { se += __shfl_xor(se, o); tl += __shfl_xor(tl, o); ts += __shfl_xor(ts, o); }
+    const float lse = mx + logf(se);
+    if (lane == 0) loss_rows[b] = ts * lse - tl;                       // -sum_k t_k log_softmax_k
+    const float invB = 1.0f / (float)B;
+    for (int k = lane; k < K; k += 64) dlogits[(long long)b * K + k] = (ts * expf(l[k] - lse) - t[k]) * invB;
+}
+
+__global__ void mean_kernel(const float* __restrict__ v, float* __restrict__ out, int n) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += v[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+
+// optax.adam: m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; update = -lr (m / bc1) / (sqrt(v / bc2) + eps)
+__global__ void adam_kernel(const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, float* __restrict__ upd,
+                            long long n, float lr, float b1, float b2, float eps, float bc1, float bc2) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        upd[i] = -lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    }
+}
+
+__global__ void transpose2d_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int C, long long xs) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        tile[j][threadIdx.x] = (r < R && c < C) ? x[(long long)r * xs + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (c < C && r < R) y[(long long)c * R + r] = tile[threadIdx.x][j];
+    }
+}
+
+inline unsigned blocks_for(long long n, int per) {
+    long long b = (n + per - 1) / per;
+    return (unsigned)(b < 1 ? 1 : (b > 65535 * 16 ? 65535 * 16 : b));
+}
+
+}  // namespace
+
+}  // namespace mv
+
+extern "C" {
+
+using namespace mv;
+
+int mv_conv2d_dgrad_nhwc_f32(const float* dy, const float* w_krsc, float* dx, int N, int H, int W, int C, int K, int R, int S, int sh,
+                             int sw, int ph, int pw, int dh, int dw, mv_stream_t stream) {
+    MV_CHECK_ARG(dy && w_krsc && dx && N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0,
+                 "conv2d_dgrad: bad arguments");
+    const int Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
+    MV_CHECK_ARG(Ho > 0 && Wo > 0 && (long long)N * H * W < (1LL << 31), "conv2d_dgrad: bad dims");
+    set_kernel_name("conv_dgrad_f32");
+    hipLaunchKernelGGL(conv_dgrad_kernel, dim3((unsigned)((long long)N * H * W)), dim3(C >= 256 ? 256 : (C > 64 ? 128 : 64)), 0,
+                       (hipStream_t)stream, dy, w_krsc, dx, N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw_krsc, int N, int H, int W, int C, int K, int R, int S, int sh,
+                             int sw, int ph, int pw, int dh, int dw, mv_stream_t stream) {
+    MV_CHECK_ARG(x && dy && dw_krsc && N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0,
+                 "conv2d_wgrad: bad arguments");
+    const int Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
+    MV_CHECK_ARG(Ho > 0 && Wo > 0 && (long long)K * R * S < (1LL << 31), "conv2d_wgrad: bad dims");
+    set_kernel_name("conv_wgrad_f32");
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(K * R * S)), dim3(C >= 256 ? 256 : (C > 64 ? 128 : 64)), 0,
+                       (hipStream_t)stream, x, dy, dw_krsc, N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_act_bwd_f32(const float* dy, const float* ref, float* dx, int64_t n, int act, mv_stream_t stream) {
+    MV_CHECK_ARG(dy && ref && dx && n > 0, "act_bwd: bad arguments");
+    MV_CHECK_ARG(act == MV_ACT_NONE || act == MV_ACT_RELU || act == MV_ACT_GELU_TANH, "act_bwd: activation %d has no backward here", act);
+    set_kernel_name("act_bwd_f32");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, ref, dx, (long long)n, act);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_maxpool2d_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
+                              int ph, int pw, mv_stream_t stream) {
+    MV_CHECK_ARG(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0, "maxpool2d_bwd: bad arguments");
+    const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+    MV_CHECK_ARG(Ho > 0 && Wo > 0 && (long long)N * H * W < (1LL << 31), "maxpool2d_bwd: bad dims");
+    set_kernel_name("maxpool_bwd_f32");
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((long long)N * H * W)), dim3(C >= 256 ? 256 : 64), 0, (hipStream_t)stream, x,
+                       dy, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, Ho, Wo);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_avgpool_global_bwd_nhwc_f32(const float* dy, float* dx, int N, int HW, int C, mv_stream_t stream) {
+    MV_CHECK_ARG(dy && dx && N > 0 && HW > 0 && C > 0, "avgpool_global_bwd: bad arguments");
+    const long long n = (long long)N * HW * C;
+    set_kernel_name("avgpool_global_bwd_f32");
+    hipLaunchKernelGGL(avgpool_global_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, HW, C, n);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_colsum_f32(const float* a, const float* b, float* out, int64_t M, int C, mv_stream_t stream) {
+    MV_CHECK_ARG(a && out && M > 0 && C > 0, "colsum: bad arguments");
+    set_kernel_name("colsum_f32");
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)M, C);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_bn_dgamma_f32(const float* sum_dy_z, const float* sum_dy, const float* mean, const float* var, float eps, float* dgamma, int C,
+                     mv_stream_t stream) {
+    MV_CHECK_ARG(sum_dy_z && sum_dy && mean && var && dgamma && C > 0, "bn_dgamma: bad arguments");
+    set_kernel_name("bn_dgamma_f32");
+    hipLaunchKernelGGL(bn_dgamma_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sum_dy_z, sum_dy, mean,
+                       var, eps, dgamma, C);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, float* dx, float* dy_xhat, int64_t M, int C, float eps,
+                         mv_stream_t stream) {
+    MV_CHECK_ARG(x && dy && dx && dy_xhat && M > 0 && C > 0, "layernorm_bwd: bad arguments");
+    set_kernel_name("layernorm_bwd_f32");
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dx, dy_xhat,
+                       (long long)M, C, eps);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_softmax_bwd_f32(const float* p, const float* dp, float* ds, int64_t rows, int cols, float scale, mv_stream_t stream) {
+    MV_CHECK_ARG(p && dp && ds && rows > 0 && cols > 0, "softmax_bwd: bad arguments");
+    set_kernel_name("softmax_bwd_f32");
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, dp, ds,
+                       (long long)rows, cols, scale);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_softmax_xent_f32(const float* logits, const float* target, float* loss_rows, float* loss_mean, float* dlogits, int B, int K,
+                        mv_stream_t stream) {
+    MV_CHECK_ARG(logits && target && loss_rows && loss_mean && dlogits && B > 0 && K > 0, "softmax_xent: bad arguments");
+    set_kernel_name("softmax_xent_f32");
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, logits, target, loss_rows, dlogits, B, K);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_rows, loss_mean, B);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_adam_step_f32(const float* grad, float* m, float* v, float* update, int64_t n, float lr, float b1, float b2, float eps,
+                     float bias_corr1, float bias_corr2, mv_stream_t stream) {
+    MV_CHECK_ARG(grad && m && v && update && n > 0 && bias_corr1 > 0.f && bias_corr2 > 0.f, "adam_step: bad arguments");
+    set_kernel_name("adam_step_f32");
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, grad, m, v, update, (long long)n, lr, b1,
+                       b2, eps, bias_corr1, bias_corr2);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_transpose2d_f32(const float* x, float* y, int R, int C, int64_t x_row_stride, mv_stream_t stream) {
+    MV_CHECK_ARG(x && y && R > 0 && C > 0, "transpose2d: bad arguments");
+    const long long xs = x_row_stride ? (long long)x_row_stride : (long long)C;
+    MV_CHECK_ARG(xs >= C && (R + 31) / 32 <= 65535, "transpose2d: bad dims");
+    set_kernel_name("transpose2d_f32");
+    hipLaunchKernelGGL(transpose2d_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32)), dim3(32, 8), 0, (hipStream_t)stream,
+                       x, y, R, C, xs);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+}  // extern "C"

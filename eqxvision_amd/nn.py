@@ -22,6 +22,10 @@ from ._module import Module, StateIndex
 
 # ------------------------------------------------------------------ boundary handling
 def _unwrap(out, batched: bool):
+    if isinstance(out, Act) and out.node is not None:
+        from . import grad as _grad
+        if _grad.active():          # inside filter_value_and_grad: the result stays on the tape (grad.GTensor)
+            return _grad.GTensor(out)
     if isinstance(out, Act):
         t = ops.to_user(out) if out.kind != "raw" else (out.t if out.batched else out.t[0])
         return t

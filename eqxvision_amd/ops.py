@@ -1406,3 +1406,12 @@ def first_row(x: Act) -> Act:
     for b in range(B):
         _lib.call("mv_cast", x.t[b].data_ptr(), y[b].data_ptr(), D, x.dt, x.dt, stream_ptr())
     return Act(y, "vec", x.batched)
+
+
+# ------------------------------------------------------------------ gradients (eqxvision_amd/grad.py)
+# Under `filter_value_and_grad` the entry points below run their differentiable fp32 twins; everywhere else they are untouched.
+from . import grad as _grad  # noqa: E402
+
+for _name in _grad.HOOKED:
+    globals()[_name] = _grad.hook(_name, globals()[_name])
+del _name

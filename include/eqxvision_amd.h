@@ -403,6 +403,44 @@ int mv_nchw_to_nhwc(const void* x, void* y, int N, int C, int H, int W, int in_d
 int mv_nhwc_to_nchw(const void* x, void* y, int N, int C, int H, int W, int in_dtype, int out_dtype, mv_stream_t stream);
 int mv_cast(const void* x, void* y, int64_t n, int in_dtype, int out_dtype, mv_stream_t stream);
 
+/* ---- backward half of a training step (reference tests/test_grads.py:35-47: eqx.filter_value_and_grad +
+ * optax.adam + eqx.apply_updates on the classification models).  fp32 throughout.  The contractions that are a forward
+ * contraction on other operands (Linear dgrad / wgrad, the four products of attention's backward) go through mv_linear_fwd on
+ * operands transposed with mv_transpose2d_f32 (eqxvision_amd/grad.py); these entries are the gradient kernels with no forward twin. */
+/* Conv2d (eqx.nn.Conv2d, groups = 1): dx[N,H,W,C] from dy[N,Ho,Wo,K] and w KRSC; dw KRSC from x and dy. */
+int mv_conv2d_dgrad_nhwc_f32(const float* dy, const float* w_krsc, float* dx, int N, int H, int W, int C, int K, int R, int S,
+                             int sh, int sw, int ph, int pw, int dh, int dw, mv_stream_t stream);
+int mv_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw_krsc, int N, int H, int W, int C, int K, int R, int S,
+                             int sh, int sw, int ph, int pw, int dh, int dw, mv_stream_t stream);
+/* dx = dy * act'(ref): MV_ACT_RELU (ref = the layer's input or output: same sign test), MV_ACT_GELU_TANH (ref = the input), NONE. */
+int mv_act_bwd_f32(const float* dy, const float* ref, float* dx, int64_t n, int act, mv_stream_t stream);
+/* eqx.nn.MaxPool2d backward: dy goes to the first maximum of each window (x = the forward input). */
+int mv_maxpool2d_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
+                              int ph, int pw, mv_stream_t stream);
+/* AdaptiveAvgPool2d((1,1)) backward: dx[n,h,w,c] = dy[n,c] / (H W). */
+int mv_avgpool_global_bwd_nhwc_f32(const float* dy, float* dx, int N, int HW, int C, mv_stream_t stream);
+/* out[c] = sum over the M rows of a[m,c] * (b ? b[m,c] : 1): bias / beta gradients (b = NULL), gamma gradients (b = x_hat). */
+int mv_colsum_f32(const float* a, const float* b, float* out, int64_t M, int C, mv_stream_t stream);
+/* BatchNorm gamma gradient when the normalisation used the RUNNING statistics (the reference's training branch; the state is not
+ * differentiated): dgamma[c] = (sum dy z - mean[c] sum dy) / sqrt(var[c] + eps), from the two column sums. */
+int mv_bn_dgamma_f32(const float* sum_dy_z, const float* sum_dy, const float* mean, const float* var, float eps, float* dgamma, int C,
+                     mv_stream_t stream);
+/* eqx.nn.LayerNorm backward over M rows of C (x = the forward input): dx, and dy_xhat = dy * x_hat (its column sums = dgamma;
+ * the column sums of dy = dbeta). */
+int mv_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, float* dx, float* dy_xhat, int64_t M, int C, float eps,
+                         mv_stream_t stream);
+/* softmax backward for p = softmax(scale * s) row-wise: ds = scale * p * (dp - sum_j dp_j p_j). */
+int mv_softmax_bwd_f32(const float* p, const float* dp, float* ds, int64_t rows, int cols, float scale, mv_stream_t stream);
+/* optax.softmax_cross_entropy(logits, target).mean() (tests/test_grads.py:41): loss_rows[B], loss_mean[1], dlogits = d mean / d logits. */
+int mv_softmax_xent_f32(const float* logits, const float* target, float* loss_rows, float* loss_mean, float* dlogits, int B, int K,
+                        mv_stream_t stream);
+/* optax.adam (tests/test_grads.py:52): m, v updated in place, update = -lr * (m / bias_corr1) / (sqrt(v / bias_corr2) + eps) with
+ * bias_corr = 1 - beta^t computed by the caller; eqx.apply_updates adds `update` to the parameter (mv_add_fwd). */
+int mv_adam_step_f32(const float* grad, float* m, float* v, float* update, int64_t n, float lr, float b1, float b2, float eps,
+                     float bias_corr1, float bias_corr2, mv_stream_t stream);
+/* y[C][R] = x[R][C]^T, rows of x x_row_stride elements apart (0 = dense). */
+int mv_transpose2d_f32(const float* x, float* y, int R, int C, int64_t x_row_stride, mv_stream_t stream);
+
 /* hipGraph capture of a whole forward (replaces the reference's eqx.filter_jit executable) */
 int mv_graph_begin_capture(mv_stream_t stream);
 int mv_graph_end_capture(mv_stream_t stream, void** graph_exec);

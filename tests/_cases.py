@@ -265,6 +265,137 @@ def bneck_strip_case(B, dual=False, seed=0, big=False, neg=True):
     return run
 
 
+# ---- backward kernels (csrc/train_bwd.hip) vs torch.autograd on the CPU (fp32 both sides)
+def _ag(fn, *inputs):
+    """torch.autograd of sum(fn(*inputs) * seed) for a fixed random seed tensor -> (output, seed, grads of the inputs)."""
+    ts = [torch.from_numpy(np.ascontiguousarray(a)).clone().requires_grad_(True) for a in inputs]
+    y = fn(*ts)
+    g = torch.from_numpy(np.random.Generator(np.random.PCG64(99)).standard_normal(tuple(y.shape)).astype(np.float32))
+    (y * g).sum().backward()
+    return y.detach().numpy(), g.numpy(), [t.grad.numpy() for t in ts]
+
+
+def conv_bwd_case(N, H, W, C, K, R, stride=1, pad=0, dil=1, seed=0):
+    def run():
+        import torch.nn.functional as F
+        L = _lib()
+        rng = _rng(seed)
+        x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        w = (rng.standard_normal((K, C, R, R)) / np.sqrt(C * R * R)).astype(np.float32)
+        y, g, (dx_ref, dw_ref) = _ag(lambda a, b: F.conv2d(a, b, None, stride, pad, dil), x, w)
+        d = {k: dev(v, "fp32") for k, v in dict(x=x.transpose(0, 2, 3, 1), w=w.transpose(0, 2, 3, 1), g=g.transpose(0, 2, 3, 1)).items()}
+        dx = torch.full((N, H, W, C), -7.0, device="cuda")
+        dw = torch.full((K, R, R, C), -7.0, device="cuda")
+        L.call("mv_conv2d_dgrad_nhwc_f32", d["g"].data_ptr(), d["w"].data_ptr(), dx.data_ptr(), N, H, W, C, K, R, R, stride, stride, pad, pad,
+               dil, dil, _stream())
+        L.call("mv_conv2d_wgrad_nhwc_f32", d["x"].data_ptr(), d["g"].data_ptr(), dw.data_ptr(), N, H, W, C, K, R, R, stride, stride, pad, pad,
+               dil, dil, _stream())
+        torch.cuda.synchronize()
+        a = _cmp(host(dx).transpose(0, 3, 1, 2), dx_ref, TOL_F32)
+        b = _cmp(host(dw).transpose(0, 3, 1, 2), dw_ref, TOL_F32)
+        return {"ok": a["ok"] and b["ok"], "err": max(a["err"], b["err"]) if isinstance(a["err"], float) and isinstance(b["err"], float) else (a["err"], b["err"]),
+                "dx": a, "dw": b}
+    return run
+
+
+def maxpool_bwd_case(N, H, W, C, k, s, p, seed=0, relu=False):
+    def run():
+        import torch.nn.functional as F
+        L = _lib()
+        rng = _rng(seed)
+        x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        if relu:
+            x = np.maximum(x, 0)                      # many exact ties at zero
+        y, g, (dx_ref,) = _ag(lambda a: F.max_pool2d(a, k, s, p), x)
+        xd, gd = dev(x.transpose(0, 2, 3, 1), "fp32"), dev(g.transpose(0, 2, 3, 1), "fp32")
+        dx = torch.full((N, H, W, C), -7.0, device="cuda")
+        L.call("mv_maxpool2d_bwd_nhwc_f32", xd.data_ptr(), gd.data_ptr(), dx.data_ptr(), N, H, W, C, k, k, s, s, p, p, _stream())
+        torch.cuda.synchronize()
+        got = host(dx).transpose(0, 3, 1, 2)
+        info = _cmp(got, dx_ref, TOL_F32)
+        info["sum_err"] = float(abs(got.sum() - dx_ref.sum()))           # with ties only the total is defined by the maths
+        return info
+    return run
+
+
+def rowwise_bwd_case(kind, M, C, seed=0):
+    """layernorm / softmax / act backward and the column sums vs torch.autograd."""
+    def run():
+        import torch.nn.functional as F
+        L = _lib()
+        rng = _rng(seed)
+        x = rng.standard_normal((M, C)).astype(np.float32) * 1.5
+        if kind == "layernorm":
+            gam = rng.uniform(0.5, 1.5, C).astype(np.float32)
+            bet = (0.1 * rng.standard_normal(C)).astype(np.float32)
+            y, g, (dx_ref, dg_ref, db_ref) = _ag(lambda a, b, c: F.layer_norm(a, (C,), b, c, 1e-5), x, gam, bet)
+            xd, gd, gm = dev(x, "fp32"), dev(g, "fp32"), dev(gam, "fp32")
+            dx, gx = torch.empty(M, C, device="cuda"), torch.empty(M, C, device="cuda")
+            dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+            L.call("mv_layernorm_bwd_f32", xd.data_ptr(), gm.data_ptr(), gd.data_ptr(), dx.data_ptr(), gx.data_ptr(), M, C, 1e-5, _stream())
+            L.call("mv_colsum_f32", gx.data_ptr(), None, dg.data_ptr(), M, C, _stream())
+            L.call("mv_colsum_f32", gd.data_ptr(), None, db.data_ptr(), M, C, _stream())
+            torch.cuda.synchronize()
+            parts = [_cmp(host(dx), dx_ref, TOL_F32), _cmp(host(dg), dg_ref, TOL_F32), _cmp(host(db), db_ref, TOL_F32)]
+        elif kind == "softmax":
+            scale = 0.37
+            y, g, (ds_ref,) = _ag(lambda a: torch.softmax(a * scale, -1), x)
+            pd, gd = dev(y, "fp32"), dev(g, "fp32")
+            ds = torch.empty(M, C, device="cuda")
+            L.call("mv_softmax_bwd_f32", pd.data_ptr(), gd.data_ptr(), ds.data_ptr(), M, C, scale, _stream())
+            torch.cuda.synchronize()
+            parts = [_cmp(host(ds), ds_ref, TOL_F32)]
+        else:                                         # relu / gelu
+            act = {"relu": 1, "gelu": 2}[kind]
+            f = F.relu if kind == "relu" else (lambda a: F.gelu(a, approximate="tanh"))
+            y, g, (dx_ref,) = _ag(f, x)
+            xd, gd = dev(x, "fp32"), dev(g, "fp32")
+            dx = torch.empty(M, C, device="cuda")
+            L.call("mv_act_bwd_f32", gd.data_ptr(), xd.data_ptr(), dx.data_ptr(), M * C, act, _stream())
+            torch.cuda.synchronize()
+            parts = [_cmp(host(dx), dx_ref, TOL_F32)]
+        return {"ok": all(p["ok"] for p in parts), "err": max(p["err"] for p in parts), "parts": parts}
+    return run
+
+
+def xent_adam_case(B, K, seed=0):
+    def run():
+        import torch.nn.functional as F
+        L = _lib()
+        rng = _rng(seed)
+        logits = (3 * rng.standard_normal((B, K))).astype(np.float32)
+        lab = rng.integers(0, K, B)
+        tl = torch.from_numpy(logits).clone().requires_grad_(True)
+        loss = F.cross_entropy(tl, torch.from_numpy(lab), reduction="mean")
+        loss.backward()
+        oh = np.zeros((B, K), np.float32)
+        oh[np.arange(B), lab] = 1
+        ld, od = dev(logits, "fp32"), dev(oh, "fp32")
+        rows, mean, dl = torch.empty(B, device="cuda"), torch.empty(1, device="cuda"), torch.empty(B, K, device="cuda")
+        L.call("mv_softmax_xent_f32", ld.data_ptr(), od.data_ptr(), rows.data_ptr(), mean.data_ptr(), dl.data_ptr(), B, K, _stream())
+        # three Adam steps on the gradient tensor against torch.optim.Adam (optax.adam's update rule)
+        p0 = rng.standard_normal((B, K)).astype(np.float32)
+        tp = torch.from_numpy(p0).clone().requires_grad_(True)
+        opt = torch.optim.Adam([tp], lr=0.01, betas=(0.9, 0.999), eps=1e-8)
+        pd = dev(p0, "fp32")
+        m, v, u = torch.zeros(B * K, device="cuda"), torch.zeros(B * K, device="cuda"), torch.empty(B * K, device="cuda")
+        for step in range(1, 4):
+            gstep = (rng.standard_normal((B, K)) * 0.3).astype(np.float32)
+            tp.grad = torch.from_numpy(gstep)
+            opt.step()
+            gd = dev(gstep, "fp32")
+            L.call("mv_adam_step_f32", gd.data_ptr(), m.data_ptr(), v.data_ptr(), u.data_ptr(), B * K, 0.01, 0.9, 0.999, 1e-8,
+                   1 - 0.9 ** step, 1 - 0.999 ** step, _stream())
+            new = torch.empty_like(pd)
+            L.call("mv_add_fwd", pd.data_ptr(), u.data_ptr(), new.data_ptr(), B * K, 0, 0, _stream())
+            pd = new
+        torch.cuda.synchronize()
+        parts = [_cmp(host(dl), tl.grad.numpy(), TOL_F32), _cmp(host(mean), np.asarray([float(loss)]), TOL_F32),
+                 _cmp(host(pd), tp.detach().numpy(), TOL_F32)]
+        return {"ok": all(p["ok"] for p in parts), "err": max(p["err"] for p in parts), "parts": parts}
+    return run
+
+
 def dual_chain_case(M, seed=0):
     """mv_conv1x1_dual_chain_fwd: conv3 + BN and the downsample conv + BN as one GEMM over [t2 | x] (scales folded into
     the bf16 weight rows, as ops.conv1x1_dual_chain does), ReLU, then the next block's conv1 + BN + ReLU -- vs the oracle
@@ -1938,6 +2069,24 @@ def all_cases():
           ("bneck_strip/identity_B3_big", bneck_strip_case(3, seed=22, big=True)),
           ("bneck_strip/dual_B1", bneck_strip_case(1, dual=True, seed=23)),
           ("bneck_strip/dual_B2_big", bneck_strip_case(2, dual=True, seed=24, big=True)),
+          ("bwd/conv3x3_s1_p1", conv_bwd_case(2, 14, 14, 64, 96, 3, 1, 1, seed=31)),
+          ("bwd/conv3x3_s2_p1_odd", conv_bwd_case(2, 15, 13, 24, 40, 3, 2, 1, seed=32)),
+          ("bwd/conv7x7_s2_p3_stem", conv_bwd_case(1, 32, 32, 3, 16, 7, 2, 3, seed=33)),
+          ("bwd/conv11x11_s4_p2", conv_bwd_case(1, 67, 67, 3, 8, 11, 4, 2, seed=34)),
+          ("bwd/conv1x1_s2_downsample", conv_bwd_case(2, 14, 14, 128, 256, 1, 2, 0, seed=35)),
+          ("bwd/conv16x16_s16_patch", conv_bwd_case(2, 32, 32, 3, 48, 16, 16, 0, seed=36)),
+          ("bwd/conv3x3_dil2", conv_bwd_case(1, 12, 12, 16, 16, 3, 1, 2, 2, seed=37)),
+          ("bwd/conv3x3_c256_k512_28", conv_bwd_case(1, 28, 28, 256, 512, 3, 1, 1, seed=38)),
+          ("bwd/maxpool_3x3_s2", maxpool_bwd_case(2, 27, 27, 64, 3, 2, 0, seed=41)),
+          ("bwd/maxpool_3x3_s2_p1", maxpool_bwd_case(2, 28, 28, 64, 3, 2, 1, seed=42)),
+          ("bwd/maxpool_2x2_s2", maxpool_bwd_case(1, 56, 56, 256, 2, 2, 0, seed=43)),
+          ("bwd/maxpool_2x2_s2_relu_ties", maxpool_bwd_case(1, 56, 56, 256, 2, 2, 0, seed=44, relu=True)),
+          ("bwd/layernorm_197x192", rowwise_bwd_case("layernorm", 394, 192, seed=45)),
+          ("bwd/layernorm_odd_70", rowwise_bwd_case("layernorm", 33, 70, seed=46)),
+          ("bwd/softmax_197", rowwise_bwd_case("softmax", 197, 197, seed=47)),
+          ("bwd/relu", rowwise_bwd_case("relu", 100, 333, seed=48)),
+          ("bwd/gelu_tanh", rowwise_bwd_case("gelu", 100, 333, seed=49)),
+          ("bwd/softmax_xent_adam", xent_adam_case(7, 10, seed=50)),
           ("chain/dual_56x56_B4", dual_chain_case(4 * 56 * 56, seed=6)),
           ("chain/dual_ragged_many", dual_chain_case(29 * 56 * 56 + 13, seed=7)),
           ("chain/n128_56x56_B4", chain_case(4 * 56 * 56, seed=4, N2=128)),

@@ -1,0 +1,117 @@
+"""GPU cases of the backward half: gradients of the HIP path (eqxvision_amd.filter_value_and_grad) vs
+torch.autograd on the CPU restatement (oracle/torch_grad.py) on the same synthetic checkpoint and images, and the reference's own
+training-step test (reference tests/test_grads.py:35-47: value_and_grad + optax.adam + apply_updates in TRAINING mode, one image,
+"loss is not NaN").  fp32 on both sides: every gradient tensor within 1e-3 of its own max |.|."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import state as S
+from oracle import torch_grad as TG
+from tests._model_cases import _keys, _load
+
+
+def _loss_fn(keys, classes):
+    import eqxvision_amd as eqv
+
+    @eqv.filter_value_and_grad
+    def compute_loss(model, x, y):
+        out = eqv.vmap(model, axis_name="batch")(x, key=keys)
+        return eqv.optim.softmax_cross_entropy(out, eqv.optim.one_hot(y, classes)).mean()
+    return compute_loss
+
+
+def grad_parity_case(model, B=2, size=224, classes=10, lim=1e-3):
+    """Every gradient tensor of the HIP path within `lim` x its own max |.| of torch.autograd in fp32 (the same arithmetic, so the
+    ReLU / max-pool branches coincide; vgg11's eight-deep ReLU + 2x2-pool stack still flips a few: its limit is 1e-2, and the
+    relative L2 error over all parameters is reported next to it)."""
+    def run():
+        import eqxvision_amd as eqv
+        x = S.synthetic_images(B, size, seed=11)
+        labels = np.arange(B) % classes
+        if model == "alexnet":
+            sd = S.alexnet_state(1, classes)
+            net = _load(eqv.models.alexnet, sd, num_classes=classes)
+            ref_loss, ref = TG.alexnet(sd, x, labels)
+        elif model == "resnet18":
+            sd = S.resnet_state(1, "basic", (2, 2, 2, 2), classes)
+            net = _load(eqv.models.resnet18, sd, num_classes=classes)
+            ref_loss, ref = TG.resnet(sd, x, labels, "basic", (2, 2, 2, 2))
+        elif model == "resnet50":
+            sd = S.resnet_state(1, "bottleneck", (3, 4, 6, 3), classes)
+            net = _load(eqv.models.resnet50, sd, num_classes=classes)
+            ref_loss, ref = TG.resnet(sd, x, labels, "bottleneck", (3, 4, 6, 3))
+        elif model == "vgg11":
+            sd = S.vgg_state(1, "A", False, classes)
+            net = _load(eqv.models.vgg11, sd, num_classes=classes)
+            ref_loss, ref = TG.vgg(sd, x, labels, "A")
+        else:
+            sd = S.vit_state(1, size, 16, 192, 12, 3, 4, classes)
+            net = _load(eqv.models.vit_tiny, sd, num_classes=classes)
+            ref_loss, ref = TG.vit(sd, x, labels, 16, 3, 12)
+        # `_load` returns the model in inference mode: Dropout off, BatchNorm on its stored statistics (constants, as in the oracle)
+        loss, grads = _loss_fn(_keys(B), classes)(net, x, labels)
+        got = eqv.utils.state_dict(grads)
+        # the two sides list the same parameters in the same order (the load_torch_weights contract); names differ where the
+        # reference's module tree does (its VGG classifier has one ReLU less than torchvision's: other Sequential indices)
+        got_l = [(k, v) for k, v in got.items() if "running" not in k]
+        ref_l = [(k, sd[k]) for k in sd if k in ref]
+        if len(got_l) != len(ref_l):
+            return {"ok": False, "err": f"{len(got_l)} gradient leaves vs {len(ref_l)} parameters"}
+        errs = []
+        for (gn, a), (name, _) in zip(got_l, ref_l):
+            a = np.asarray(a, np.float64).reshape(-1)
+            b = np.asarray(ref[name], np.float64).reshape(-1)
+            if a.shape != b.shape:
+                return {"ok": False, "err": f"{name} / {gn}: shape {a.shape} vs {b.shape}"}
+            if not np.isfinite(a).all():
+                return {"ok": False, "err": f"{name}: non-finite gradient"}
+            errs.append((float(np.abs(a - b).max() / max(1e-12, np.abs(b).max())), name))
+        errs.sort(reverse=True)
+        worst, worst_name = errs[0]
+        ga = np.concatenate([np.asarray(a, np.float64).reshape(-1) for _, a in got_l])
+        gb = np.concatenate([np.asarray(ref[n], np.float64).reshape(-1) for n, _ in ref_l])
+        l2 = float(np.linalg.norm(ga - gb) / max(1e-30, np.linalg.norm(gb)))
+        return {"ok": worst <= lim and l2 <= lim and abs(loss - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss)), "err": worst, "rel_l2": l2,
+                "lim": lim, "worst": worst_name, "loss": loss, "ref_loss": ref_loss, "tensors": len(ref), "top": errs[:6], "all": sorted((n, round(e, 7)) for e, n in errs) if worst > 1e-3 else None}
+    return run
+
+
+def train_step_case(model, classes=3, steps=2, **model_kw):
+    """The reference's test body: model in TRAINING mode (fresh init), one 224 x 224 image, label 1, adam(0.01)."""
+    def run():
+        import eqxvision_amd as eqv
+        key = eqv.random.PRNGKey(0)
+        net = getattr(eqv.models, model)(num_classes=classes, key=key, **model_kw)
+        x = S.synthetic_images(1, 224, seed=0)
+        y = np.asarray([1])
+        opt = eqv.optim.adam(learning_rate=0.01)
+        st = opt.init(eqv.filter(net, eqv.is_array))
+        keys = eqv.random.split(eqv.random.PRNGKey(1), 1)
+        fn = _loss_fn(keys, classes)
+        losses = []
+        before = [np.array(l, copy=True) for l in eqv.tree_leaves(net) if isinstance(l, np.ndarray) and l.dtype.kind == "f"]
+        for _ in range(steps):
+            loss, grads = fn(net, x, y)
+            updates, st = opt.update(grads, st)
+            net = eqv.apply_updates(net, updates)
+            losses.append(loss)
+        after = [l for l in eqv.tree_leaves(net) if isinstance(l, np.ndarray) and l.dtype.kind == "f"]
+        moved = sum(1 for a, b in zip(before, after) if not np.array_equal(a, b))
+        ok = all(np.isfinite(l) for l in losses) and moved >= len(before) * 0.9 and all(np.isfinite(a).all() for a in after)
+        return {"ok": bool(ok), "err": 0.0, "losses": losses, "leaves": len(before), "leaves_moved": moved}
+    return run
+
+
+def all_cases():
+    return [("grad/alexnet_B2_vs_autograd", grad_parity_case("alexnet", 2)),
+            ("grad/resnet18_B2_vs_autograd", grad_parity_case("resnet18", 2)),
+            ("grad/vit_tiny_B2_vs_autograd", grad_parity_case("vit_tiny", 2)),
+            ("grad/resnet50_B1_vs_autograd", grad_parity_case("resnet50", 1)),
+            ("grad/vgg11_B1_vs_autograd", grad_parity_case("vgg11", 1, lim=1e-2)),
+            ("grad/step_alexnet_training_mode", train_step_case("alexnet")),
+            ("grad/step_resnet18_training_mode", train_step_case("resnet18")),
+            ("grad/step_vit_tiny_training_mode", train_step_case("vit_tiny")),
+            ("grad/step_vit_tiny_drop_path_0.1", train_step_case("vit_tiny", drop_path_rate=0.1)),
+            ("grad/step_vgg11_bn_training_mode", train_step_case("vgg11_bn"))]

@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from tests import _cases, _model_cases
+from tests import _cases, _grad_cases, _model_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -22,5 +22,11 @@ def test_op(name, fn):
 
 @pytest.mark.parametrize("name,fn", _model_cases.all_cases(), ids=[n for n, _ in _model_cases.all_cases()])
 def test_model(name, fn):
+    info = fn()
+    assert info["ok"], f"{name}: {info}"
+
+
+@pytest.mark.parametrize("name,fn", _grad_cases.all_cases(), ids=[n for n, _ in _grad_cases.all_cases()])
+def test_grad(name, fn):
     info = fn()
     assert info["ok"], f"{name}: {info}"

@@ -239,3 +239,20 @@ def test_oracle_jax_random_known_answers():
     per_row = (l.reshape(3, -1) != 0).all(1) | (l.reshape(3, -1) == 0).all(1)      # whole first-axis slices are kept or dropped
     assert per_row.all()
 
+
+
+def test_gradient_oracle_against_finite_differences():
+    """oracle/torch_grad.py (the reference of the GPU gradient cases) checked against central differences of its own loss on a
+    small ViT (32 px, patch 16, width 32, 2 blocks): a few entries of different parameter kinds."""
+    from oracle import torch_grad as TG
+    sd = S.vit_state(3, 32, 16, 32, 2, 4, 4, 5)
+    x = S.synthetic_images(3, 32, seed=4)
+    labels = [0, 3, 1]
+    fn = lambda sd_, x_, y_: TG.vit(sd_, x_, y_, 16, 4, 2, dtype=torch.float64)
+    loss, grads = fn(sd, x, labels)
+    assert np.isfinite(loss)
+    for name, idx in (("fc.bias", 2), ("blocks.1.mlp.fc1.weight", 17), ("blocks.0.attn.qkv.weight", 40), ("pos_embed", 9),
+                      ("patch_embed.proj.weight", 100), ("blocks.0.norm1.weight", 3)):
+        fd = TG.finite_difference(fn, sd, x, labels, name, idx)
+        g = float(np.asarray(grads[name]).reshape(-1)[idx])
+        assert abs(fd - g) <= 2e-3 * max(1.0, abs(g)) + 2e-3, (name, fd, g)

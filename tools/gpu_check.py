@@ -9,14 +9,14 @@ import time
 import traceback
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests import _cases, _model_cases  # noqa: E402
+from tests import _cases, _grad_cases, _model_cases  # noqa: E402
 
 
 def main():
     only = sys.argv[1:]                       # substrings; a case runs if it contains any of them
     results = []
     nfail = 0
-    for name, fn in _cases.all_cases() + _model_cases.all_cases():
+    for name, fn in _cases.all_cases() + _model_cases.all_cases() + _grad_cases.all_cases():
         if only and not any(o in name for o in only):
             continue
         t = time.time()
