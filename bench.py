@@ -11,13 +11,15 @@ already resident in HBM.  W untimed warm-up steps, then exactly K timed steps br
 barrier + synchronize; MAX over ranks; rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     the dominant kernel = the GEMM-type kernel family with the largest summed duration in one forward.
+  roofline     the dominant kernel = the GEMM-type kernel (one name per kernel symbol) with the largest summed duration in one forward.
                `achieved` = its algorithmic FLOPs per launch (2 x MACs, `flop_per_launch`) / its average launch duration
                (`avg_launch_us`) measured IN SITU with HIP events on the stream each launch runs on (an eager replay of the
                lanes' launch lists on their own streams, right after the timed region; the last rows of a rocprofv3 kernel
                trace of this command ARE that pass -- profiles/r03/roofline_vs_rocprof.txt checks the two clocks against each
                other; the graph replays themselves run with less lane overlap under the profiler, see profiles/r03/README.md);
-               `frac` = achieved / 2.5 PFLOP/s (dense bf16 MFMA peak).  `lanes1`: the same model as ONE launch list (lanes
+               `frac` = achieved / 2.5 PFLOP/s (dense bf16 MFMA peak).  `rocprof`: the same kernel's warm average in the committed
+               rocprofv3 summary (profiles/traffic.json -> profiles/r04/<model>_rocprofv3_warm_stats.txt) and the fraction that
+               follows from it.  `alone_frac` / `lanes1`: the same model as ONE launch list (lanes
                overlap in time, so only there does the sum over the dominant kernel's launches compare with a step);
                `isolated` (with --layers): every launch alone on the chip.  `whole_forward`: SURVEY section 8d's FLOPs per
                image x batch / the step (`frac`), algorithmic HBM bytes / the step / 8 TB/s (`hbm_frac`).
@@ -316,13 +318,15 @@ def insitu_rows(compiled, steps=6, only=None):
 
 
 
-def dominant_family(rows):
-    """The GEMM-type kernel family with the largest summed duration in one forward -> (name, {us, gflop, mb, n})."""
+def dominant_family(rows, name=None):
+    """The GEMM-type kernel (one name = one kernel symbol, so a rocprofv3 summary row covers the same launches) with the largest
+    summed duration in one forward -- or the kernel called `name` -- -> (name, {us, gflop, mb, n})."""
     fam = {}
     for r_ in rows:
-        k = r_["kernel"].replace("_dense", "").replace("_conv", "")
-        d = fam.setdefault(k, {"us": 0.0, "gflop": 0.0, "mb": 0.0, "n": 0})
+        d = fam.setdefault(r_["kernel"], {"us": 0.0, "gflop": 0.0, "mb": 0.0, "n": 0})
         d["us"] += r_["us"]; d["gflop"] += r_["gflop"]; d["mb"] += r_["mb"]; d["n"] += 1
+    if name is not None and name in fam:
+        return name, fam[name]
     gemm = {k: v for k, v in fam.items() if v["gflop"] > 0}
     return max((gemm or fam or {"n/a": {"us": 1, "gflop": 0, "mb": 0, "n": 1}}).items(), key=lambda kv: kv[1]["us"])
 
@@ -424,21 +428,29 @@ def run_model(a, name, B, rank, world, soak_s):
     nl = len(compiled.lane_calls) if compiled.lane_calls else 1
     alg_mb = sum(r_["mb"] for r_ in rows)
     bound_us = sum(max(r_["gflop"] * 1e3 / MFMA_PEAK_TFLOPS, r_["mb"] / HBM_PEAK_GBS * 1e3) for r_ in rows)
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per launch (separate --pmc passes), if collected
-    if os.path.exists(tj) and world == 1:
+    traffic, rocprof = None, None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per launch (separate --pmc passes) and the
+    if os.path.exists(tj) and world == 1:                      # committed rocprofv3 summary's duration of the same kernel, if collected
         try:
             tjd = json.load(open(tj))
             if tjd.get("_batch", {}).get(name) == B:
                 traffic = tjd.get(name, {}).get(dk)
+                rp = tjd.get("_rocprof", {}).get(name, {}).get(dk)
+                if rp and dv["n"]:
+                    fl = dv["gflop"] / dv["n"]              # GFLOP per launch
+                    rocprof = {"file": rp.get("file"), "avg_us_warm": rp["avg_launch_us"], "calls": rp.get("calls"),
+                               "frac": round(fl / rp["avg_launch_us"] * 1e3 / MFMA_PEAK_TFLOPS, 4),
+                               "note": "the committed rocprofv3 --kernel-trace summary of this command (two lanes), same kernel symbol; "
+                                       "frac = flop_per_launch / avg_us_warm / peak"}
         except Exception:  # noqa: BLE001
             traffic = None
     roof = {"bound": "mfma", "achieved": round(dom_tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(dom_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "kernel": dk, "launches_per_step": dv["n"],
+            "rocprof": rocprof,
             "avg_launch_us": round(dv["us"] / max(1, dv["n"]), 2),
             "how": f"in situ: eager replay of the {nl}-lane launch lists on {nl} stream(s), two HIP events around every launch on "
                    "its own stream, 6 steps (the LAST 6 x launches_per_step rows of a rocprofv3 --kernel-trace of this command are "
-                   "this pass: profiles/r03/roofline_vs_rocprof.txt compares the two clocks)",
+                   "this pass: profiles/r04/roofline_vs_rocprof.txt compares the two clocks)",
             "share_of_kernel_time": round(dv["us"] / max(1e-9, sum(r_["us"] for r_ in rows)), 3),
             "flop_per_launch": round(dv["gflop"] * 1e9 / max(1, dv["n"])),
             "kernel_hbm_gbs": round(dv["mb"] / dv["us"] * 1e3, 1) if dv["us"] else 0.0,
@@ -468,8 +480,10 @@ def run_model(a, name, B, rank, world, soak_s):
         ms1 = ctypes.c_float()
         _lib.call("mv_event_elapsed_ms", e0_, e1_, ctypes.byref(ms1))
         rows1 = insitu_rows(f1._entries()[0])
-        k1, v1 = dominant_family(rows1)
+        k1, v1 = dominant_family(rows1, dk)                    # the SAME kernel as the headline figure where the one-lane list has it
         t1 = v1["gflop"] / v1["us"] * 1e3 if v1["us"] else 0.0
+        # the only per-kernel figure whose durations add up to a step (no second lane sharing the chip): the dominant kernel ALONE
+        roof["alone_frac"] = round(t1 / MFMA_PEAK_TFLOPS, 4)
         roof["lanes1"] = {"kernel": k1, "launches_per_step": v1["n"], "avg_launch_us": round(v1["us"] / max(1, v1["n"]), 2),
                           "achieved": round(t1, 1), "frac": round(t1 / MFMA_PEAK_TFLOPS, 4),
                           "sum_dominant_ms": round(v1["us"] / 1e3, 4), "sum_all_kernels_ms": round(sum(r_["us"] for r_ in rows1) / 1e3, 4),

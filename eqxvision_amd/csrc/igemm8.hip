@@ -835,9 +835,15 @@ int igemm8_launch(const void* x, const void* w, const float* scale, const float*
     p.dbg = get_flag("i8_ablate");
 #endif
     const bool dense = (R == 1 && S == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0);
-    if (tile == 2) set_kernel_name(dense ? "igemm8_bf16_128x256_dense" : "igemm8_bf16_128x256_conv");
-    else if (tile == 3) set_kernel_name(dense ? "igemm8_bf16_256x128_dense" : "igemm8_bf16_256x128_conv");
-    else set_kernel_name(dense ? "igemm8_bf16_256x256_dense" : "igemm8_bf16_256x256_conv");
+    {   // one name per kernel SYMBOL (template instance), so that a rocprofv3 summary row and a bench row are the same launches:
+        // <tile>_{conv | dense | lin}[_f32out]  <->  igemm8_kernel<OutT, false, MODE> / igemm8s_kernel<OutT, ARR, false, DENSE>
+        const bool fast = dense && !get_flag("no_i8_lin");
+        const char* mode = !fast ? (dense ? "dense0" : "conv") : ((tile == 1 && !scale) ? "lin" : "dense");
+        static thread_local char nm[64];
+        snprintf(nm, sizeof(nm), "igemm8_bf16_%s_%s%s", tile == 2 ? "128x256" : (tile == 3 ? "256x128" : "256x256"), mode,
+                 out_dtype == MV_F32 ? "_f32out" : "");
+        set_kernel_name(nm);
+    }
     return igemm8_go(p, false, out_dtype == MV_F32, tile - 1, st);
 }
 
@@ -860,7 +866,12 @@ int igemm8_dual_launch(const void* x, const void* x2, const void* w, const float
     }
     p.M = (int)M;
     p.act = act;
-    set_kernel_name(tile == 2 ? "igemm8_dual_bf16_128x256" : (tile == 3 ? "igemm8_dual_bf16_256x128" : "igemm8_dual_bf16_256x256"));
+    {
+        static thread_local char nm[64];
+        snprintf(nm, sizeof(nm), "igemm8_dual_bf16_%s%s", tile == 2 ? "128x256" : (tile == 3 ? "256x128" : "256x256"),
+                 out_dtype == MV_F32 ? "_f32out" : "");
+        set_kernel_name(nm);
+    }
     return igemm8_go(p, true, out_dtype == MV_F32, tile - 1, st);
 }
 

@@ -390,7 +390,7 @@ def xent_adam_case(B, K, seed=0):
             L.call("mv_add_fwd", pd.data_ptr(), u.data_ptr(), new.data_ptr(), B * K, 0, 0, _stream())
             pd = new
         torch.cuda.synchronize()
-        parts = [_cmp(host(dl), tl.grad.numpy(), TOL_F32), _cmp(host(mean), np.asarray([float(loss)]), TOL_F32),
+        parts = [_cmp(host(dl), tl.grad.numpy(), TOL_F32), _cmp(host(mean), np.asarray([float(loss.detach())]), TOL_F32),
                  _cmp(host(pd), tp.detach().numpy(), TOL_F32)]
         return {"ok": all(p["ok"] for p in parts), "err": max(p["err"] for p in parts), "parts": parts}
     return run

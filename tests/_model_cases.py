@@ -765,7 +765,7 @@ def fresh_inputs_case():
     return run
 
 
-def full_batch_case(model, B, lanes=2):
+def full_batch_case(model, B, lanes=2, guard=None):
     """BASELINE.json's full configuration (resnet50 / vit_base B=256, swin_t B=128) on the bench path -- filter_jit, hipGraph
     replay, graph lanes -- checked through a size-independent property: the batch is 8 distinct images tiled B/8 times, so
     (a) rows 0..7 must match the fp32 torch restatement of the same 8 images within the bf16 tolerance and (b) every
@@ -802,6 +802,9 @@ def full_batch_case(model, B, lanes=2):
         out["replica_max_diff"] = float(rep)
         out["replicas_bit_identical"] = bool(rep == 0.0)
         out["ok"] = bool(out["ok"] and rep <= out["lim"])
+        if guard is not None:          # a margin under the 1e-2 bar: a new bf16 fusion must not eat it silently (swin_t sits at 8.3e-3)
+            out["guard"] = guard
+            out["ok"] = bool(out["ok"] and out["err"] <= guard)
         return out
     return run
 
@@ -1144,5 +1147,5 @@ def all_cases(full=True):
               ("model/swin_t_logits_at_trained_scale", large_logit_case("swin_t")),
               ("model/resnet50_B256_full_config", full_batch_case("resnet50", 256)),
               ("model/vit_base_B256_full_config", full_batch_case("vit_base", 256)),
-              ("model/swin_t_B128_full_config", full_batch_case("swin_t", 128))]
+              ("model/swin_t_B128_full_config", full_batch_case("swin_t", 128, guard=9e-3))]
     return c

@@ -2,7 +2,7 @@
 duration alone / in situ, achieved TFLOP/s and GB/s (alone), algorithmic vs PMC-counted HBM bytes and the matrix-pipe-busy fraction.
 usage: design_tables.py [ROUND=r03]"""
 import json, os, re, sys, collections
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 tj = json.load(open(os.path.join(P, "traffic.json")))
 _out = []
@@ -17,8 +17,8 @@ for M in ("resnet50", "vit_base", "swin_t", "alexnet"):
     for line in open(f"{P}/{R}/{M}_per_launch.txt"):
         if line.startswith("#") or line.startswith("kernel"):
             continue
-        k = line[:34].strip().replace("_dense", "").replace("_conv", "")
-        us, tf, gbs, gf, mb, pct = [float(x) for x in line[74:].split()[-6:]]
+        k = line.split()[0]                                     # one row per kernel name = one kernel symbol
+        us, tf, gbs, gf, mb, pct = [float(x) for x in line.split()[-6:]]
         d = fam.setdefault(k, dict(n=0, us=0.0, gf=0.0, mb=0.0))
         d["n"] += 1; d["us"] += us; d["gf"] += gf; d["mb"] += mb
     sq = {}
@@ -32,7 +32,7 @@ for M in ("resnet50", "vit_base", "swin_t", "alexnet"):
           f"one lane: {b1['value'] / 1e3:.1f} k; under rocprofv3: {bp['value'] / 1e3:.1f} k.\n")
     print("| kernel family | launches / step | share of kernel time | us alone | us in situ (rocprofv3) | TFLOP/s alone (frac of 2500) | GB/s alone (frac of 8000) | algorithmic MB | PMC MB (ratio) | matrix pipe busy |")
     print("|---|---|---|---|---|---|---|---|---|---|")
-    for k, d in sorted(fam.items(), key=lambda kv: -kv[1]["us"])[:7]:
+    for k, d in sorted(fam.items(), key=lambda kv: -kv[1]["us"])[:8]:
         a = d["us"] / d["n"]
         ins = rp.get(k, {}).get("avg_launch_us")
         pm = tj.get(M, {}).get(k)
