@@ -11,12 +11,14 @@ already resident in HBM.  W untimed warm-up steps, then exactly K timed steps br
 barrier + synchronize; MAX over ranks; rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     the dominant kernel = the GEMM-type kernel (one name per kernel symbol) with the largest summed duration in one forward.
-               `achieved` = its algorithmic FLOPs per launch (2 x MACs, `flop_per_launch`) / its average launch duration
-               (`avg_launch_us`) measured IN SITU with HIP events on the stream each launch runs on (an eager replay of the
-               lanes' launch lists on their own streams, right after the timed region; the last rows of a rocprofv3 kernel
-               trace of this command ARE that pass -- profiles/r03/roofline_vs_rocprof.txt checks the two clocks against each
-               other; the graph replays themselves run with less lane overlap under the profiler, see profiles/r03/README.md);
+  roofline     the dominant kernel = the GEMM-type kernel (one name per kernel symbol) with the largest summed duration in the
+               model traced as ONE launch list (the only setting in which per-kernel durations add up to a step and in which HIP
+               events and rocprofv3 agree to 1-3 %).  `achieved` = its algorithmic FLOPs per launch (2 x MACs, `flop_per_launch`) /
+               its average launch duration (`avg_launch_us`), measured live with HIP events on the launch stream right after the
+               timed region; `rocprof` = the same kernel's `avg_us_warm` in the committed summary of `bench.py --lanes 1`
+               (profiles/r04/<model>_lanes1_rocprofv3_warm_stats.txt) and the fraction that follows from it.  `two_lanes`: the same
+               measurement IN SITU in the two-lane graph's launch lists (eager two-stream replay; a launch then shares the chip with
+               the other lane's kernel, and a profiler changes that overlap: profiles/r04/README.md);
                `frac` = achieved / 2.5 PFLOP/s (dense bf16 MFMA peak).  `rocprof`: the same kernel's warm average in the committed
                rocprofv3 summary (profiles/traffic.json -> profiles/r04/<model>_rocprofv3_warm_stats.txt) and the fraction that
                follows from it.  `alone_frac` / `lanes1`: the same model as ONE launch list (lanes
@@ -480,10 +482,36 @@ def run_model(a, name, B, rank, world, soak_s):
         ms1 = ctypes.c_float()
         _lib.call("mv_event_elapsed_ms", e0_, e1_, ctypes.byref(ms1))
         rows1 = insitu_rows(f1._entries()[0])
-        k1, v1 = dominant_family(rows1, dk)                    # the SAME kernel as the headline figure where the one-lane list has it
+        k1, v1 = dominant_family(rows1)
         t1 = v1["gflop"] / v1["us"] * 1e3 if v1["us"] else 0.0
-        # the only per-kernel figure whose durations add up to a step (no second lane sharing the chip): the dominant kernel ALONE
-        roof["alone_frac"] = round(t1 / MFMA_PEAK_TFLOPS, 4)
+        two = {k: roof[k] for k in ("kernel", "achieved", "frac", "launches_per_step", "avg_launch_us", "how", "share_of_kernel_time",
+                                     "flop_per_launch", "kernel_hbm_gbs", "rocprof")}
+        # THE headline figure: the dominant kernel of the ONE-lane list.  Only there do the per-kernel durations add up to a step
+        # (sum_all_kernels_ms ~ ms_per_step_eager) and only there do HIP events and a rocprofv3 trace of `bench.py --lanes 1` agree
+        # (1-3 %): with two lanes a launch shares the chip with the other lane's kernel, and rocprofv3 itself changes how much the
+        # lanes overlap (profiles/r04/README.md), so the two-lane in-situ figure (`roofline.two_lanes`) has no second clock.
+        rp1 = None
+        try:
+            tjd = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            rp = tjd.get("_rocprof_lanes1", {}).get(name, {}).get(k1) if tjd.get("_batch", {}).get(name) == B and world == 1 else None
+            if rp and v1["n"]:
+                rp1 = {"file": rp.get("file"), "avg_us_warm": rp["avg_launch_us"], "calls": rp.get("calls"),
+                       "frac": round(v1["gflop"] / v1["n"] / rp["avg_launch_us"] * 1e3 / MFMA_PEAK_TFLOPS, 4),
+                       "note": "committed rocprofv3 --kernel-trace summary of `bench.py --lanes 1` (same kernel symbol): "
+                               "frac = flop_per_launch / avg_us_warm / peak"}
+        except Exception:  # noqa: BLE001
+            rp1 = None
+        roof.update({"kernel": k1, "achieved": round(t1, 1), "frac": round(t1 / MFMA_PEAK_TFLOPS, 4), "alone_frac": round(t1 / MFMA_PEAK_TFLOPS, 4),
+                     "launches_per_step": v1["n"], "avg_launch_us": round(v1["us"] / max(1, v1["n"]), 2),
+                     "flop_per_launch": round(v1["gflop"] * 1e9 / max(1, v1["n"])),
+                     "kernel_hbm_gbs": round(v1["mb"] / v1["us"] * 1e3, 1) if v1["us"] else 0.0,
+                     "share_of_kernel_time": round(v1["us"] / max(1e-9, sum(r_["us"] for r_ in rows1)), 3),
+                     "how": "one lane: the model traced as ONE launch list (full-batch launches back to back on one stream), two HIP "
+                            "events around every launch, 6 eager replays; the dominant kernel = largest summed duration among the "
+                            "GEMM-type kernels (one name per kernel symbol)",
+                     "rocprof": rp1, "two_lanes": two})
+        if traffic is not None and two["kernel"] != k1:
+            roof["traffic"] = None
         roof["lanes1"] = {"kernel": k1, "launches_per_step": v1["n"], "avg_launch_us": round(v1["us"] / max(1, v1["n"]), 2),
                           "achieved": round(t1, 1), "frac": round(t1 / MFMA_PEAK_TFLOPS, 4),
                           "sum_dominant_ms": round(v1["us"] / 1e3, 4), "sum_all_kernels_ms": round(sum(r_["us"] for r_ in rows1) / 1e3, 4),

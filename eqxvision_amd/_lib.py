@@ -112,8 +112,9 @@ PROTOTYPES = {
     "mv_nchw_to_nhwc": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mv_nhwc_to_nchw": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mv_cast": [_vp, _vp, _i64, _i, _i, _vp],
-    "mv_conv2d_dgrad_nhwc_f32": [_vp, _vp, _vp] + [_i] * 13 + [_vp],
-    "mv_conv2d_wgrad_nhwc_f32": [_vp, _vp, _vp] + [_i] * 13 + [_vp],
+    "mv_conv2d_dgrad_nhwc_f32": [_vp, _vp, _vp] + [_i] * 14 + [_vp],
+    "mv_conv2d_wgrad_nhwc_f32": [_vp, _vp, _vp] + [_i] * 14 + [_vp],
+    "mv_channel_scale_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mv_act_bwd_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "mv_maxpool2d_bwd_nhwc_f32": [_vp, _vp, _vp] + [_i] * 10 + [_vp],
     "mv_avgpool_global_bwd_nhwc_f32": [_vp, _vp, _i, _i, _i, _vp],

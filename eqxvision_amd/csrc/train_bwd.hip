@@ -15,9 +15,11 @@ namespace mv {
 
 namespace {
 
+// groups: input channel c belongs to group c / (C / groups), whose K / groups filters hold C / groups channels each (KRSC rows)
 __global__ void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int H,
                                   int W, int C, int K, int R, int S, int Ho, int Wo, int sh, int sw, int ph, int pw, int dh,
-                                  int dw) {
+                                  int dw, int groups) {
+    const int Cg = C / groups, Kg = K / groups;
     const long long pix = blockIdx.x;                       // (n, hi, wi)
     const int wi = (int)(pix % W), hi = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -32,9 +34,10 @@ __global__ void conv_dgrad_kernel(const float* __restrict__ dy, const float* __r
                 if (tw < 0 || tw % sw) continue;
                 const int wo = tw / sw;
                 if (wo >= Wo) continue;
-                const float* dyp = dy + (((long long)n * Ho + ho) * Wo + wo) * K;
-                const float* wp = w + ((long long)r * S + s) * C + c;
-                for (int k = 0; k < K; ++k) acc = fmaf(dyp[k], wp[(long long)k * R * S * C], acc);
+                const int gi = c / Cg;
+                const float* dyp = dy + (((long long)n * Ho + ho) * Wo + wo) * K + gi * Kg;
+                const float* wp = w + ((long long)gi * Kg * R * S + (long long)r * S + s) * Cg + (c - gi * Cg);
+                for (int k = 0; k < Kg; ++k) acc = fmaf(dyp[k], wp[(long long)k * R * S * Cg], acc);
             }
         }
         dx[pix * C + c] = acc;
@@ -43,10 +46,13 @@ __global__ void conv_dgrad_kernel(const float* __restrict__ dy, const float* __r
 
 // one block per (k, r, s); threads over c; the block's threads walk the output positions together
 __global__ void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dwt, int N, int H,
-                                  int W, int C, int K, int R, int S, int Ho, int Wo, int sh, int sw, int ph, int pw, int dh,
-                                  int dw) {
+                                  int W, int Cfull, int K, int R, int S, int Ho, int Wo, int sh, int sw, int ph, int pw, int dh,
+                                  int dw, int groups) {
     const int krs = blockIdx.x;
     const int s = krs % S, r = (krs / S) % R, k = krs / (R * S);
+    const int C = Cfull / groups;                          // channels per filter; the filter's group starts at channel c0
+    const int c0 = (k / (K / groups)) * C;
+    x += c0;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float acc = 0.f;
         for (int n = 0; n < N; ++n)
@@ -56,7 +62,7 @@ __global__ void conv_wgrad_kernel(const float* __restrict__ x, const float* __re
                 for (int wo = 0; wo < Wo; ++wo) {
                     const int wi = wo * sw - pw + s * dw;
                     if ((unsigned)wi >= (unsigned)W) continue;
-                    acc = fmaf(dy[(((long long)n * Ho + ho) * Wo + wo) * K + k], x[(((long long)n * H + hi) * W + wi) * C + c], acc);
+                    acc = fmaf(dy[(((long long)n * Ho + ho) * Wo + wo) * K + k], x[(((long long)n * H + hi) * W + wi) * Cfull + c], acc);
                 }
             }
         dwt[(long long)krs * C + c] = acc;
@@ -75,6 +81,13 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
             const float u = c0 * (v + c1 * v * v * v);
             const float t = tanhf(u);
             d = g * (0.5f * (1.f + t) + 0.5f * v * (1.f - t * t) * c0 * (1.f + 3.f * c1 * v * v));
+        } else if (act == MV_ACT_HARD_SIGMOID) {             // clip(x + 3, 0, 6) / 6
+            d = (v > -3.f && v < 3.f) ? g * (1.0f / 6.0f) : 0.f;
+        } else if (act == MV_ACT_HARD_SWISH) {               // x clip(x + 3, 0, 6) / 6
+            d = v <= -3.f ? 0.f : (v >= 3.f ? g : g * (2.f * v + 3.f) * (1.0f / 6.0f));
+        } else if (act == MV_ACT_SIGMOID || act == MV_ACT_SILU) {
+            const float sg = 1.0f / (1.0f + expf(-v));
+            d = act == MV_ACT_SIGMOID ? g * sg * (1.f - sg) : g * sg * (1.f + v * (1.f - sg));
         }
         dx[i] = d;
     }
@@ -132,6 +145,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
     part[rg][cl] = acc;
     __syncthreads();
     if (rg == 0 && c < C) out[c] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+}
+
+// ds[b, c] = sum over the HW positions of image b of g[b, p, c] * x[b, p, c]  (the scale's gradient of y = x * s[b, c])
+__global__ __launch_bounds__(256) void channel_scale_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                 float* __restrict__ ds, int HW, int C) {
+    __shared__ float part[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+    float acc = 0.f;
+    if (c < C)
+        for (int p = rg; p < HW; p += 4) acc = fmaf(g[((long long)b * HW + p) * C + c], x[((long long)b * HW + p) * C + c], acc);
+    part[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < C) ds[(long long)b * C + c] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
 }
 
 __global__ void bn_dgamma_kernel(const float* __restrict__ dyz, const float* __restrict__ dys, const float* __restrict__ mean,
@@ -248,34 +275,37 @@ extern "C" {
 using namespace mv;
 
 int mv_conv2d_dgrad_nhwc_f32(const float* dy, const float* w_krsc, float* dx, int N, int H, int W, int C, int K, int R, int S, int sh,
-                             int sw, int ph, int pw, int dh, int dw, mv_stream_t stream) {
+                             int sw, int ph, int pw, int dh, int dw, int groups, mv_stream_t stream) {
     MV_CHECK_ARG(dy && w_krsc && dx && N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0,
                  "conv2d_dgrad: bad arguments");
+    MV_CHECK_ARG(groups > 0 && C % groups == 0 && K % groups == 0, "conv2d_dgrad: groups = %d does not divide C = %d, K = %d", groups, C, K);
     const int Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
     MV_CHECK_ARG(Ho > 0 && Wo > 0 && (long long)N * H * W < (1LL << 31), "conv2d_dgrad: bad dims");
     set_kernel_name("conv_dgrad_f32");
     hipLaunchKernelGGL(conv_dgrad_kernel, dim3((unsigned)((long long)N * H * W)), dim3(C >= 256 ? 256 : (C > 64 ? 128 : 64)), 0,
-                       (hipStream_t)stream, dy, w_krsc, dx, N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw);
+                       (hipStream_t)stream, dy, w_krsc, dx, N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw, groups);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }
 
 int mv_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw_krsc, int N, int H, int W, int C, int K, int R, int S, int sh,
-                             int sw, int ph, int pw, int dh, int dw, mv_stream_t stream) {
+                             int sw, int ph, int pw, int dh, int dw, int groups, mv_stream_t stream) {
     MV_CHECK_ARG(x && dy && dw_krsc && N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0,
                  "conv2d_wgrad: bad arguments");
+    MV_CHECK_ARG(groups > 0 && C % groups == 0 && K % groups == 0, "conv2d_wgrad: groups = %d does not divide C = %d, K = %d", groups, C, K);
     const int Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
     MV_CHECK_ARG(Ho > 0 && Wo > 0 && (long long)K * R * S < (1LL << 31), "conv2d_wgrad: bad dims");
     set_kernel_name("conv_wgrad_f32");
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(K * R * S)), dim3(C >= 256 ? 256 : (C > 64 ? 128 : 64)), 0,
-                       (hipStream_t)stream, x, dy, dw_krsc, N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw);
+    const int cg = C / groups;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(K * R * S)), dim3(cg >= 256 ? 256 : (cg > 64 ? 128 : 64)), 0,
+                       (hipStream_t)stream, x, dy, dw_krsc, N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw, groups);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }
 
 int mv_act_bwd_f32(const float* dy, const float* ref, float* dx, int64_t n, int act, mv_stream_t stream) {
     MV_CHECK_ARG(dy && ref && dx && n > 0, "act_bwd: bad arguments");
-    MV_CHECK_ARG(act == MV_ACT_NONE || act == MV_ACT_RELU || act == MV_ACT_GELU_TANH, "act_bwd: activation %d has no backward here", act);
+    MV_CHECK_ARG(act >= MV_ACT_NONE && act <= MV_ACT_SILU, "act_bwd: unknown activation %d", act);
     set_kernel_name("act_bwd_f32");
     hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, ref, dx, (long long)n, act);
     MV_LAUNCH_CHECK();
@@ -307,6 +337,15 @@ int mv_colsum_f32(const float* a, const float* b, float* out, int64_t M, int C, 
     MV_CHECK_ARG(a && out && M > 0 && C > 0, "colsum: bad arguments");
     set_kernel_name("colsum_f32");
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)M, C);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_channel_scale_bwd_f32(const float* g, const float* x, float* ds, int B, int HW, int C, mv_stream_t stream) {
+    MV_CHECK_ARG(g && x && ds && B > 0 && B <= 65535 && HW > 0 && C > 0, "channel_scale_bwd: bad arguments");
+    set_kernel_name("channel_scale_bwd_f32");
+    hipLaunchKernelGGL(channel_scale_bwd_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0, (hipStream_t)stream, g, x, ds,
+                       HW, C);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

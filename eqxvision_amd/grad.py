@@ -21,9 +21,10 @@ left out of the gradient.
 BatchNorm.  The reference's training branch normalises with the UPDATED RUNNING statistics, and eqx.experimental.BatchNorm keeps
 that state outside the differentiated pytree: the gradient treats the statistics as constants (a per-channel affine).
 
-Scope: the layers of alexnet / vgg / resnet (basic and bottleneck, un-fused) / vit (Conv2d groups = 1, Linear, BatchNorm,
-LayerNorm, ReLU / GELU, MaxPool2d, AdaptiveAvgPool2d to (1,1) or to the input size, Dropout, DropPath, attention, cls / position
-embeddings).  Swin, grouped / depthwise convolutions and squeeze-excitation have no backward yet and raise."""
+Scope: the layers of alexnet / vgg / resnet / resnext (basic and bottleneck, un-fused) / mobilenet v2 + v3 / efficientnet / regnet /
+vit: Conv2d (any groups), Linear, BatchNorm, LayerNorm, every MV_ACT_* activation, MaxPool2d, AdaptiveAvgPool2d to (1,1) or to the
+input size, Dropout, DropPath, SqueezeExcitation (un-fused: pool, two pointwise convolutions, channel scale), attention, cls /
+position embeddings.  Swin's shifted-window attention has no backward yet and raises."""
 from __future__ import annotations
 
 import functools
@@ -40,7 +41,8 @@ from ._module import Module, tree_map
 
 _tls = threading.local()
 F32 = _lib.F32
-ACTS = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "gelu": _lib.ACT_GELU_TANH}
+ACTS = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "gelu": _lib.ACT_GELU_TANH,
+        "hard_swish": _lib.ACT_HARD_SWISH, "hard_sigmoid": _lib.ACT_HARD_SIGMOID, "sigmoid": _lib.ACT_SIGMOID, "silu": _lib.ACT_SILU}
 
 
 # ------------------------------------------------------------------------------------------------------------ the tape
@@ -186,7 +188,7 @@ def _mk(t: torch.Tensor, kind: str, batched: bool, parents, backward) -> Act:
 
 def _check_act(act):
     if act not in ACTS:
-        raise NotImplementedError(f"activation {act!r} has no backward (relu / gelu only)")
+        raise NotImplementedError(f"activation {act!r} has no backward")
 
 
 # ------------------------------------------------------------------------------------------------------------ layout
@@ -322,6 +324,28 @@ def g_drop_path(x: Act, p: float, mode: str, key) -> Act:
     return _mk(scale(x.t), x.kind, x.batched, [_node(x)], lambda g: (scale(g),))
 
 
+@_op
+def g_channel_scale(x: Act, s: Act) -> Act:
+    """x * s, s one value per (image, channel) (SqueezeExcitation, layers/squeeze.py:60): dx = g * s, ds = sum_hw g * x."""
+    x = g_as_map.__wrapped__(x)
+    B, H, W, C = x.t.shape
+    st = s.t.reshape(B, -1)
+    if st.shape[1] != C or not st.is_contiguous():
+        raise ValueError(f"channel_scale: scale {tuple(s.t.shape)} does not fit the map {tuple(x.t.shape)}")
+    xin, sshape = x.t, tuple(s.t.shape)
+
+    def scale(src):
+        y = _new(src.shape)
+        _call("mv_channel_scale_nhwc_fwd", _p(src), _p(st), _p(y), B, H * W, C, F32, _S())
+        return y
+
+    def backward(g):
+        ds = _new((B, C))
+        _call("mv_channel_scale_bwd_f32", _p(g), _p(xin), _p(ds), B, H * W, C, _S())
+        return (scale(g), ds.reshape(sshape))
+    return _mk(scale(x.t), "map", x.batched, [_node(x), _node(s)], backward)
+
+
 # ------------------------------------------------------------------------------------------------------------ pooling
 @_op
 def g_maxpool2d(x: Act, kernel_size, stride, padding) -> Act:
@@ -423,7 +447,7 @@ def g_batchnorm(x: Act, bn, act=None) -> Act:
 
 # ------------------------------------------------------------------------------------------------------------ convolution
 def _conv_w(conv) -> torch.Tensor:
-    K, C = conv.out_channels, conv.in_channels
+    K, C = conv.out_channels, conv.in_channels // conv.groups
     R, S = conv.kernel_size
 
     def make(raw):
@@ -436,8 +460,7 @@ def _conv_w(conv) -> torch.Tensor:
 @_op
 def g_conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> Act:
     _check_act(act)
-    if conv.groups != 1:
-        raise NotImplementedError("grouped / depthwise Conv2d has no backward yet")
+    G = conv.groups
     x = g_as_map.__wrapped__(x)
     B, H, W, C = x.t.shape
     kh, kw = conv.kernel_size
@@ -451,7 +474,7 @@ def g_conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) ->
     w = _conv_w(conv)
     bias = _leaf_dev(conv.bias).reshape(-1) if conv.bias is not None else None
     z = _new((B, Ho, Wo, K))
-    _call("mv_conv2d_nhwc_fwd", _p(x.t), _p(w), None, _p(bias), None, _p(z), B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, 1,
+    _call("mv_conv2d_nhwc_fwd", _p(x.t), _p(w), None, _p(bias), None, _p(z), B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, G,
           _lib.ACT_NONE, F32, F32, _S())
     y1, saved = (z, None) if bn is None else _bn_forward(bn, z, "map", x.batched)
     r = None
@@ -471,15 +494,15 @@ def g_conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) ->
         dz = g2 if bn is None else _bn_backward(bn, z, g2, saved)
         if conv.bias is not None:
             _acc_param(conv.bias, _colsum(dz, None, K))
-        dwk = _new((K, kh, kw, C))
-        _call("mv_conv2d_wgrad_nhwc_f32", _p(xin), _p(dz), _p(dwk), B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, _S())
-        dwo = _new((K, C, kh, kw))
-        _call("mv_nhwc_to_nchw", _p(dwk), _p(dwo), K, C, kh, kw, F32, F32, _S())   # KRSC -> OIHW, the leaf's layout
+        dwk = _new((K, kh, kw, C // G))
+        _call("mv_conv2d_wgrad_nhwc_f32", _p(xin), _p(dz), _p(dwk), B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, G, _S())
+        dwo = _new((K, C // G, kh, kw))
+        _call("mv_nhwc_to_nchw", _p(dwk), _p(dwo), K, C // G, kh, kw, F32, F32, _S())   # KRSC -> OIHW, the leaf's layout
         _acc_param(conv.weight, dwo)
         dx = None
         if need_dx:
             dx = _new((B, H, W, C))
-            _call("mv_conv2d_dgrad_nhwc_f32", _p(dz), _p(w), _p(dx), B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, _S())
+            _call("mv_conv2d_dgrad_nhwc_f32", _p(dz), _p(w), _p(dx), B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, G, _S())
         return (dx, g2 if r is not None else None)
     return _mk(y, "map", x.batched, [_node(x), _node(r)], backward)
 
@@ -658,7 +681,7 @@ def g_qkv_attention(x: Act, lin, heads: int, scale: float, need_probs: bool, dro
 
 
 # ------------------------------------------------------------------------------------------------------------ the transform
-HOOKED = ("as_map", "as_rows", "cast", "flatten", "first_row", "eltwise", "add", "dropout", "drop_path", "maxpool2d",
+HOOKED = ("as_map", "as_rows", "cast", "flatten", "first_row", "eltwise", "add", "dropout", "drop_path", "channel_scale", "maxpool2d",
           "adaptive_avgpool2d", "batchnorm", "conv2d", "stem_conv_pool", "linear", "linear_head", "layernorm", "ln_linear",
           "layernorm_first_row", "prep_f32", "patch_embed_tokens", "qkv_attention")
 

@@ -352,7 +352,10 @@ class Sequential(Module):
                 continue
             if hasattr(layer, "call_chained") and is_act(x):
                 # consecutive residual blocks (resnet.py:330-333): the block may fuse its tail with the next one's head
-                x = layer.call_chained(x, L[i + 1] if i + 1 < len(L) else nxt)
+                nx = L[i + 1] if i + 1 < len(L) else nxt
+                # a nested Sequential (a stage of blocks) takes its share of the key like any other layer (training-mode
+                # Dropout / DropPath inside it); a residual block's call_chained has no stochastic layers of its own
+                x = layer.call_chained(x, nx, key=keys[i]) if isinstance(layer, Sequential) else layer.call_chained(x, nx)
                 i += 1
                 continue
             x = layer(x, key=keys[i])

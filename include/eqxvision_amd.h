@@ -407,12 +407,13 @@ int mv_cast(const void* x, void* y, int64_t n, int in_dtype, int out_dtype, mv_s
  * optax.adam + eqx.apply_updates on the classification models).  fp32 throughout.  The contractions that are a forward
  * contraction on other operands (Linear dgrad / wgrad, the four products of attention's backward) go through mv_linear_fwd on
  * operands transposed with mv_transpose2d_f32 (eqxvision_amd/grad.py); these entries are the gradient kernels with no forward twin. */
-/* Conv2d (eqx.nn.Conv2d, groups = 1): dx[N,H,W,C] from dy[N,Ho,Wo,K] and w KRSC; dw KRSC from x and dy. */
+/* Conv2d (eqx.nn.Conv2d incl. grouped / depthwise): dx[N,H,W,C] from dy[N,Ho,Wo,K] and w [K][R][S][C/groups]; dw in the same
+ * layout from x and dy. */
 int mv_conv2d_dgrad_nhwc_f32(const float* dy, const float* w_krsc, float* dx, int N, int H, int W, int C, int K, int R, int S,
-                             int sh, int sw, int ph, int pw, int dh, int dw, mv_stream_t stream);
+                             int sh, int sw, int ph, int pw, int dh, int dw, int groups, mv_stream_t stream);
 int mv_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw_krsc, int N, int H, int W, int C, int K, int R, int S,
-                             int sh, int sw, int ph, int pw, int dh, int dw, mv_stream_t stream);
-/* dx = dy * act'(ref): MV_ACT_RELU (ref = the layer's input or output: same sign test), MV_ACT_GELU_TANH (ref = the input), NONE. */
+                             int sh, int sw, int ph, int pw, int dh, int dw, int groups, mv_stream_t stream);
+/* dx = dy * act'(ref), ref = the activation's INPUT: every MV_ACT_* (relu, gelu-tanh, hard_swish, hard_sigmoid, sigmoid, silu). */
 int mv_act_bwd_f32(const float* dy, const float* ref, float* dx, int64_t n, int act, mv_stream_t stream);
 /* eqx.nn.MaxPool2d backward: dy goes to the first maximum of each window (x = the forward input). */
 int mv_maxpool2d_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
@@ -421,6 +422,9 @@ int mv_maxpool2d_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int N,
 int mv_avgpool_global_bwd_nhwc_f32(const float* dy, float* dx, int N, int HW, int C, mv_stream_t stream);
 /* out[c] = sum over the M rows of a[m,c] * (b ? b[m,c] : 1): bias / beta gradients (b = NULL), gamma gradients (b = x_hat). */
 int mv_colsum_f32(const float* a, const float* b, float* out, int64_t M, int C, mv_stream_t stream);
+/* y = x * s[b, c] (SqueezeExcitation's multiply, DropPath): ds[b, c] = sum over the image's HW positions of g * x; dx is the
+ * forward multiply applied to g (mv_channel_scale_nhwc_fwd). */
+int mv_channel_scale_bwd_f32(const float* g, const float* x, float* ds, int B, int HW, int C, mv_stream_t stream);
 /* BatchNorm gamma gradient when the normalisation used the RUNNING statistics (the reference's training branch; the state is not
  * differentiated): dgamma[c] = (sum dy z - mean[c] sum dy) / sqrt(var[c] + eps), from the two column sums. */
 int mv_bn_dgamma_f32(const float* sum_dy_z, const float* sum_dy, const float* mean, const float* var, float eps, float* dgamma, int C,

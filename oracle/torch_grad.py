@@ -80,6 +80,14 @@ def vgg(sd, x, labels, plan="A", batch_norm=False, dtype=torch.float32):
     return _finish(logits, labels, P)
 
 
+def mobilenet_v2(sd, x, labels, setting=None, dtype=torch.float32):
+    """Depthwise / pointwise inverted residuals (mobilenetv2.py): exercises the grouped-convolution gradients."""
+    from .state import MBV2_SETTING
+    P = _params(sd, dtype)
+    logits = TR.mobilenet_v2_forward.__wrapped__(P, torch.as_tensor(x).to(dtype), setting if setting is not None else MBV2_SETTING)
+    return _finish(logits, labels, P)
+
+
 def finite_difference(fn, sd, x, labels, name, index, h=1e-3):
     """Central difference of the loss w.r.t. element `index` (flat) of parameter `name` in fp64-ish steps: checks the autograd
     oracle itself (tests/test_oracle.py)."""

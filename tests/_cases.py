@@ -275,21 +275,21 @@ def _ag(fn, *inputs):
     return y.detach().numpy(), g.numpy(), [t.grad.numpy() for t in ts]
 
 
-def conv_bwd_case(N, H, W, C, K, R, stride=1, pad=0, dil=1, seed=0):
+def conv_bwd_case(N, H, W, C, K, R, stride=1, pad=0, dil=1, seed=0, groups=1):
     def run():
         import torch.nn.functional as F
         L = _lib()
         rng = _rng(seed)
         x = rng.standard_normal((N, C, H, W)).astype(np.float32)
-        w = (rng.standard_normal((K, C, R, R)) / np.sqrt(C * R * R)).astype(np.float32)
-        y, g, (dx_ref, dw_ref) = _ag(lambda a, b: F.conv2d(a, b, None, stride, pad, dil), x, w)
+        w = (rng.standard_normal((K, C // groups, R, R)) / np.sqrt(C // groups * R * R)).astype(np.float32)
+        y, g, (dx_ref, dw_ref) = _ag(lambda a, b: F.conv2d(a, b, None, stride, pad, dil, groups), x, w)
         d = {k: dev(v, "fp32") for k, v in dict(x=x.transpose(0, 2, 3, 1), w=w.transpose(0, 2, 3, 1), g=g.transpose(0, 2, 3, 1)).items()}
         dx = torch.full((N, H, W, C), -7.0, device="cuda")
-        dw = torch.full((K, R, R, C), -7.0, device="cuda")
+        dw = torch.full((K, R, R, C // groups), -7.0, device="cuda")
         L.call("mv_conv2d_dgrad_nhwc_f32", d["g"].data_ptr(), d["w"].data_ptr(), dx.data_ptr(), N, H, W, C, K, R, R, stride, stride, pad, pad,
-               dil, dil, _stream())
+               dil, dil, groups, _stream())
         L.call("mv_conv2d_wgrad_nhwc_f32", d["x"].data_ptr(), d["g"].data_ptr(), dw.data_ptr(), N, H, W, C, K, R, R, stride, stride, pad, pad,
-               dil, dil, _stream())
+               dil, dil, groups, _stream())
         torch.cuda.synchronize()
         a = _cmp(host(dx).transpose(0, 3, 1, 2), dx_ref, TOL_F32)
         b = _cmp(host(dw).transpose(0, 3, 1, 2), dw_ref, TOL_F32)
@@ -345,9 +345,11 @@ def rowwise_bwd_case(kind, M, C, seed=0):
             L.call("mv_softmax_bwd_f32", pd.data_ptr(), gd.data_ptr(), ds.data_ptr(), M, C, scale, _stream())
             torch.cuda.synchronize()
             parts = [_cmp(host(ds), ds_ref, TOL_F32)]
-        else:                                         # relu / gelu
-            act = {"relu": 1, "gelu": 2}[kind]
-            f = F.relu if kind == "relu" else (lambda a: F.gelu(a, approximate="tanh"))
+        else:                                         # an activation
+            act = {"relu": 1, "gelu": 2, "hard_swish": 3, "hard_sigmoid": 4, "sigmoid": 5, "silu": 6}[kind]
+            f = {"relu": F.relu, "gelu": lambda a: F.gelu(a, approximate="tanh"), "hard_swish": F.hardswish, "hard_sigmoid": F.hardsigmoid,
+                 "sigmoid": torch.sigmoid, "silu": F.silu}[kind]
+            x = x * 2.5                                # reach both saturated ends of the hard_* functions
             y, g, (dx_ref,) = _ag(f, x)
             xd, gd = dev(x, "fp32"), dev(g, "fp32")
             dx = torch.empty(M, C, device="cuda")
@@ -2077,6 +2079,9 @@ def all_cases():
           ("bwd/conv16x16_s16_patch", conv_bwd_case(2, 32, 32, 3, 48, 16, 16, 0, seed=36)),
           ("bwd/conv3x3_dil2", conv_bwd_case(1, 12, 12, 16, 16, 3, 1, 2, 2, seed=37)),
           ("bwd/conv3x3_c256_k512_28", conv_bwd_case(1, 28, 28, 256, 512, 3, 1, 1, seed=38)),
+          ("bwd/conv3x3_depthwise_s2", conv_bwd_case(2, 14, 14, 48, 48, 3, 2, 1, seed=39, groups=48)),
+          ("bwd/conv3x3_groups4", conv_bwd_case(2, 12, 12, 32, 64, 3, 1, 1, seed=40, groups=4)),
+          ("bwd/conv5x5_depthwise", conv_bwd_case(1, 14, 14, 40, 40, 5, 1, 2, seed=51, groups=40)),
           ("bwd/maxpool_3x3_s2", maxpool_bwd_case(2, 27, 27, 64, 3, 2, 0, seed=41)),
           ("bwd/maxpool_3x3_s2_p1", maxpool_bwd_case(2, 28, 28, 64, 3, 2, 1, seed=42)),
           ("bwd/maxpool_2x2_s2", maxpool_bwd_case(1, 56, 56, 256, 2, 2, 0, seed=43)),
@@ -2086,6 +2091,10 @@ def all_cases():
           ("bwd/softmax_197", rowwise_bwd_case("softmax", 197, 197, seed=47)),
           ("bwd/relu", rowwise_bwd_case("relu", 100, 333, seed=48)),
           ("bwd/gelu_tanh", rowwise_bwd_case("gelu", 100, 333, seed=49)),
+          ("bwd/hard_swish", rowwise_bwd_case("hard_swish", 64, 200, seed=52)),
+          ("bwd/hard_sigmoid", rowwise_bwd_case("hard_sigmoid", 64, 200, seed=53)),
+          ("bwd/sigmoid", rowwise_bwd_case("sigmoid", 64, 200, seed=54)),
+          ("bwd/silu", rowwise_bwd_case("silu", 64, 200, seed=55)),
           ("bwd/softmax_xent_adam", xent_adam_case(7, 10, seed=50)),
           ("chain/dual_56x56_B4", dual_chain_case(4 * 56 * 56, seed=6)),
           ("chain/dual_ragged_many", dual_chain_case(29 * 56 * 56 + 13, seed=7)),

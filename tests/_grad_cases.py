@@ -42,6 +42,10 @@ def grad_parity_case(model, B=2, size=224, classes=10, lim=1e-3):
             sd = S.resnet_state(1, "bottleneck", (3, 4, 6, 3), classes)
             net = _load(eqv.models.resnet50, sd, num_classes=classes)
             ref_loss, ref = TG.resnet(sd, x, labels, "bottleneck", (3, 4, 6, 3))
+        elif model == "mobilenet_v2":
+            sd = S.mobilenet_v2_state(1, classes, S.MBV2_SETTING)
+            net = _load(eqv.models.mobilenet_v2, sd, num_classes=classes)
+            ref_loss, ref = TG.mobilenet_v2(sd, x, labels)
         elif model == "vgg11":
             sd = S.vgg_state(1, "A", False, classes)
             net = _load(eqv.models.vgg11, sd, num_classes=classes)
@@ -110,8 +114,14 @@ def all_cases():
             ("grad/vit_tiny_B2_vs_autograd", grad_parity_case("vit_tiny", 2)),
             ("grad/resnet50_B1_vs_autograd", grad_parity_case("resnet50", 1)),
             ("grad/vgg11_B1_vs_autograd", grad_parity_case("vgg11", 1, lim=1e-2)),
+            ("grad/mobilenet_v2_B2_vs_autograd", grad_parity_case("mobilenet_v2", 2)),
             ("grad/step_alexnet_training_mode", train_step_case("alexnet")),
             ("grad/step_resnet18_training_mode", train_step_case("resnet18")),
             ("grad/step_vit_tiny_training_mode", train_step_case("vit_tiny")),
             ("grad/step_vit_tiny_drop_path_0.1", train_step_case("vit_tiny", drop_path_rate=0.1)),
-            ("grad/step_vgg11_bn_training_mode", train_step_case("vgg11_bn"))]
+            ("grad/step_vgg11_bn_training_mode", train_step_case("vgg11_bn")),
+            ("grad/step_mobilenet_v2_training_mode", train_step_case("mobilenet_v2")),
+            ("grad/step_mobilenet_v3_small_training_mode", train_step_case("mobilenet_v3_small")),
+            ("grad/step_efficientnet_b0_training_mode", train_step_case("efficientnet_b0")),
+            ("grad/step_regnet_x_400mf_training_mode", train_step_case("regnet_x_400mf")),
+            ("grad/step_resnext50_32x4d_training_mode", train_step_case("resnext50_32x4d"))]

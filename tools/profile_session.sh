@@ -61,7 +61,7 @@ def fam(name):
                    ("fc_stream_kernel", "fc_stream_bf16"), ("maxpool_nhwc_bf16x8_kernel", "maxpool_nhwc_bf16x8")):
         if sub in n: return f
     return None
-out = {"_batch": {}, "_rocprof": {}}
+out = {"_batch": {}, "_rocprof": {}, "_rocprof_lanes1": {}}
 lines = []
 for M, B in (("resnet50", 256), ("vit_base", 256), ("swin_t", 128), ("alexnet", 256)):
     acc = {"FETCH_SIZE": collections.defaultdict(list), "WRITE_SIZE": collections.defaultdict(list)}
@@ -91,6 +91,17 @@ for M, B in (("resnet50", 256), ("vit_base", 256), ("swin_t", 128), ("alexnet", 
     for k, v in rp.items():
         w = sorted(v)[: max(1, len(v) - max(1, len(v) // 50))]
         out["_rocprof"][M][k] = {"avg_launch_us": round(sum(w) / len(w), 2), "calls": len(v), "file": f"profiles/{os.environ.get('ROUND', 'r03')}/{M}_rocprofv3_warm_stats.txt"}
+    # the same for the ONE-lane command (full-batch launches back to back): what bench.py's headline roofline is compared with
+    rp1 = collections.defaultdict(list)
+    for f in glob.glob(f"{O}/{M}_trace1/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = fam(r["Kernel_Name"])
+            if k: rp1[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    out["_rocprof_lanes1"][M] = {}
+    for k, v in rp1.items():
+        w = sorted(v)[: max(1, len(v) - max(1, len(v) // 50))]
+        out["_rocprof_lanes1"][M][k] = {"avg_launch_us": round(sum(w) / len(w), 2), "calls": len(v),
+                                        "file": f"profiles/{os.environ.get('ROUND', 'r04')}/{M}_lanes1_rocprofv3_warm_stats.txt"}
     # SQ pass: MFMA busy fraction per family (busy cycles per SIMD / kernel cycles)
     sq = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{O}/{M}_SQ/**/*counter_collection.csv", recursive=True):
@@ -134,6 +145,17 @@ for M in ("resnet50", "vit_base", "swin_t", "alexnet"):
                      f"ratio {r['avg_launch_us'] / same if same else 0:.3f} | graph replays {rp['avg_launch_us']:8.2f} us ({rp['calls']} calls)   frac {r['frac']}")
     except Exception as e:
         agree.append(f"{M}: {type(e).__name__} {e}")
+agree.append("# headline roofline (one lane): bench.py --lanes 1 under rocprofv3, its own avg_launch_us (HIP events) vs the trace's warm average of the same kernel")
+for M in ("resnet50", "vit_base", "swin_t", "alexnet"):
+    try:
+        bj = json.load(open(f"{O}/{M}_lanes1_bench.json"))
+        r = bj["roofline"]
+        rp = out["_rocprof_lanes1"][M][r["kernel"]]
+        fl = r["flop_per_launch"]
+        agree.append(f"{M:9s} {r['kernel']:34s} events {r['avg_launch_us']:8.2f} us (frac {r['frac']}) | rocprofv3 {rp['avg_launch_us']:8.2f} us "
+                     f"({rp['calls']} calls, frac {fl / rp['avg_launch_us'] / 1e6 / 2500:.4f}) ratio {r['avg_launch_us'] / rp['avg_launch_us']:.3f}")
+    except Exception as e:
+        agree.append(f"{M} lanes1: {type(e).__name__} {e}")
 open(f"{O}/roofline_vs_rocprof.txt", "w").write("\n".join(agree) + "\n")
 print("\n".join(agree))
 json.dump(out, open(f"{O}/traffic.json", "w"), indent=1)
