@@ -125,6 +125,9 @@ PROTOTYPES = {
     "mv_softmax_xent_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "mv_adam_step_f32": [_vp, _vp, _vp, _vp, _i64] + [_f] * 6 + [_vp],
     "mv_transpose2d_f32": [_vp, _vp, _i, _i, _i64, _vp],
+    "mv_swin_window_attn_bwd_f32": [_vp] * 5 + [_i] * 9 + [_vp],
+    "mv_scatter_rows_sum_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "mv_patch_merge_gather_bwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp],
     "mv_graph_begin_capture": [_vp],
     "mv_graph_end_capture": [_vp, C.POINTER(_vp)],
     "mv_graph_launch": [_vp, _vp],

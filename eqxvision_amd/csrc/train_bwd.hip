@@ -247,6 +247,133 @@ __global__ void adam_kernel(const float* __restrict__ g, float* __restrict__ m, 
     }
 }
 
+
+// Swin shifted-window attention backward (swin.py:123-250), one workgroup per (window, head, image), one thread per token.
+// qkv NHWC [B,Hf,Wf,3C] ([q|k|v][head][dh]); roll / partition / mask are the forward's index arithmetic (generic.hip:
+// swin_attn_generic_kernel).  With s = (q / sqrt(dh)) . k + bias + mask, p = softmax(s), o = p v:
+//   g = p * (dp - sum_j dp p), dp = do . v^T;  dq = g k / sqrt(dh);  dk = g^T (q / sqrt(dh));  dv = p^T do;  dbias += g.
+// g is also written out per window ([B * windows][heads][n * n]) so that the bias gradient is a deterministic column sum.
+__global__ __launch_bounds__(64) void swin_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                            const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                            float* __restrict__ gall, int B, int Hf, int Wf, int C, int heads, int wsh,
+                                                            int wsw, int shh, int shw) {
+    extern __shared__ float sm[];
+    const int n = wsh * wsw, dh = C / heads;
+    float* q = sm;                  // [n][dh] (scaled)
+    float* k = q + n * dh;
+    float* v = k + n * dh;
+    float* go = v + n * dh;         // dout rows
+    float* P = go + n * dh;         // [n][n]
+    float* G = P + n * n;
+    const int nWw = Wf / wsw;
+    const int win = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int wy = win / nWw, wx = win % nWw;
+    const int t = threadIdx.x;
+    const float scale = rsqrtf((float)dh);
+    const bool shifted = (shh + shw) > 0;
+    auto region = [&](int y, int x) {
+        const int rh = (y < Hf - wsh) ? 0 : (y < Hf - shh ? 1 : 2);
+        const int rw = (x < Wf - wsw) ? 0 : (x < Wf - shw ? 1 : 2);
+        return rh * 3 + rw;
+    };
+    long long pos = 0;
+    int myreg = 0;
+    if (t < n) {
+        const int ty = wy * wsh + t / wsw, tx = wx * wsw + t % wsw;          // rolled coordinates
+        myreg = region(ty, tx);
+        pos = ((long long)b * Hf + (ty + shh) % Hf) * Wf + (tx + shw) % Wf;
+        const float* r = qkv + pos * 3 * C + h * dh;
+        for (int d = 0; d < dh; ++d) {
+            q[t * dh + d] = r[d] * scale;
+            k[t * dh + d] = r[C + d];
+            v[t * dh + d] = r[2 * C + d];
+            go[t * dh + d] = dout[pos * C + h * dh + d];
+        }
+    }
+    __shared__ int reg[64];
+    if (t < 64) reg[t] = myreg;
+    __syncthreads();
+    if (t < n) {
+        float mx = -INFINITY;
+        for (int j = 0; j < n; ++j) {
+            float s = 0.f;
+            for (int d = 0; d < dh; ++d) s = fmaf(q[t * dh + d], k[j * dh + d], s);
+            s += bias[((long long)h * n + t) * n + j];
+            if (shifted && reg[j] != myreg) s += -100.0f;
+            P[t * n + j] = s;
+            mx = fmaxf(mx, s);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < n; ++j) { const float e = __expf(P[t * n + j] - mx); P[t * n + j] = e; sum += e; }
+        const float inv = 1.f / sum;
+        float rs = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float pj = P[t * n + j] * inv;
+            float dp = 0.f;
+            for (int d = 0; d < dh; ++d) dp = fmaf(go[t * dh + d], v[j * dh + d], dp);
+            P[t * n + j] = pj;
+            G[t * n + j] = dp;
+            rs = fmaf(dp, pj, rs);
+        }
+        float* gw = gall + (((long long)b * gridDim.x + win) * heads + h) * n * n + (long long)t * n;
+        for (int j = 0; j < n; ++j) {
+            const float g = P[t * n + j] * (G[t * n + j] - rs);
+            G[t * n + j] = g;
+            gw[j] = g;
+        }
+        float* dq = dqkv + pos * 3 * C + h * dh;
+        for (int d = 0; d < dh; ++d) {
+            float a = 0.f;
+            for (int j = 0; j < n; ++j) a = fmaf(G[t * n + j], k[j * dh + d], a);
+            dq[d] = a * scale;
+        }
+    }
+    __syncthreads();
+    if (t < n) {
+        float* dk = dqkv + pos * 3 * C + C + h * dh;
+        float* dv = dqkv + pos * 3 * C + 2 * C + h * dh;
+        for (int d = 0; d < dh; ++d) {
+            float a = 0.f, c = 0.f;
+            for (int i = 0; i < n; ++i) {
+                a = fmaf(G[i * n + t], q[i * dh + d], a);          // q is already scaled
+                c = fmaf(P[i * n + t], go[i * dh + d], c);
+            }
+            dk[d] = a;
+            dv[d] = c;
+        }
+    }
+}
+
+// out[t][c] = sum over the rows m with idx[m] == t of src[m][c]  (relative_position_bias_table gradient: rows = the n * n
+// (query, key) pairs, columns = heads); one block per table row, fixed summation order
+__global__ void scatter_rows_sum_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ out, int M,
+                                        int Ccols) {
+    const int t = blockIdx.x;
+    for (int c = threadIdx.x; c < Ccols; c += blockDim.x) {
+        float a = 0.f;
+        for (int m = 0; m < M; ++m)
+            if (idx[m] == t) a += src[(long long)m * Ccols + c];
+        out[(long long)t * Ccols + c] = a;
+    }
+}
+
+// inverse of the 2 x 2 neighbourhood gather of Swin's patch merging (swin.py:23-31): dx[b, 2 ho + (q & 1), 2 wo + (q >> 1), c] =
+// dy[b, ho, wo, q C + c]
+__global__ void patch_merge_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int H, int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long n = (long long)B * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long m = i / C;
+        const int wi = (int)(m % W);
+        m /= W;
+        const int hi = (int)(m % H);
+        const int b = (int)(m / H);
+        const int q = (hi & 1) + 2 * (wi & 1);
+        dx[i] = dy[(((long long)b * Ho + (hi >> 1)) * Wo + (wi >> 1)) * 4 * C + q * C + c];
+    }
+}
+
 __global__ void transpose2d_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int C, long long xs) {
     __shared__ float tile[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -395,6 +522,43 @@ int mv_adam_step_f32(const float* grad, float* m, float* v, float* update, int64
     set_kernel_name("adam_step_f32");
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, grad, m, v, update, (long long)n, lr, b1,
                        b2, eps, bias_corr1, bias_corr2);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_swin_window_attn_bwd_f32(const float* qkv, const float* bias, const float* dout, float* dqkv, float* g_windows, int B, int Hf,
+                                int Wf, int C, int heads, int ws_h, int ws_w, int shift_h, int shift_w, mv_stream_t stream) {
+    MV_CHECK_ARG(qkv && bias && dout && dqkv && g_windows && B > 0 && Hf > 0 && Wf > 0 && C > 0 && heads > 0, "swin_attn_bwd: bad args");
+    MV_CHECK_ARG(C % heads == 0 && ws_h > 0 && ws_w > 0 && Hf % ws_h == 0 && Wf % ws_w == 0 && ws_h * ws_w <= 64,
+                 "swin_attn_bwd: map %dx%d / window %dx%d (<= 64 tokens) / %d heads", Hf, Wf, ws_h, ws_w, heads);
+    MV_CHECK_ARG(shift_h >= 0 && shift_w >= 0 && shift_h < ws_h && shift_w < ws_w && heads <= 65535 && B <= 65535, "swin_attn_bwd: bad shift / grid");
+    if (ws_h >= Hf) shift_h = 0;  // swin.py:116-120
+    if (ws_w >= Wf) shift_w = 0;
+    const int n = ws_h * ws_w, dh = C / heads;
+    const size_t smem = (size_t)(4 * n * dh + 2 * n * n) * sizeof(float);
+    MV_CHECK_ARG(smem <= 150 * 1024, "swin_attn_bwd: head width %d too large", dh);
+    auto kern = swin_attn_bwd_kernel;
+    MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    set_kernel_name("swin_attn_bwd_f32");
+    hipLaunchKernelGGL(kern, dim3((unsigned)((Hf / ws_h) * (Wf / ws_w)), (unsigned)heads, (unsigned)B), dim3(64), smem, (hipStream_t)stream,
+                       qkv, bias, dout, dqkv, g_windows, B, Hf, Wf, C, heads, ws_h, ws_w, shift_h, shift_w);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_scatter_rows_sum_f32(const float* src, const int* index, float* out, int M, int C, int T, mv_stream_t stream) {
+    MV_CHECK_ARG(src && index && out && M > 0 && C > 0 && T > 0, "scatter_rows_sum: bad arguments");
+    set_kernel_name("scatter_rows_sum_f32");
+    hipLaunchKernelGGL(scatter_rows_sum_kernel, dim3((unsigned)T), dim3(64), 0, (hipStream_t)stream, src, index, out, M, C);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_patch_merge_gather_bwd_f32(const float* dy, float* dx, int B, int H, int W, int C, mv_stream_t stream) {
+    MV_CHECK_ARG(dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "patch_merge_bwd: bad arguments");
+    const long long n = (long long)B * H * W * C;
+    set_kernel_name("patch_merge_bwd_f32");
+    hipLaunchKernelGGL(patch_merge_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, H, W, C);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

@@ -24,7 +24,7 @@ that state outside the differentiated pytree: the gradient treats the statistics
 Scope: the layers of alexnet / vgg / resnet / resnext (basic and bottleneck, un-fused) / mobilenet v2 + v3 / efficientnet / regnet /
 vit: Conv2d (any groups), Linear, BatchNorm, LayerNorm, every MV_ACT_* activation, MaxPool2d, AdaptiveAvgPool2d to (1,1) or to the
 input size, Dropout, DropPath, SqueezeExcitation (un-fused: pool, two pointwise convolutions, channel scale), attention, cls /
-position embeddings.  Swin's shifted-window attention has no backward yet and raises."""
+position embeddings, Swin's shifted-window attention (with the relative-position bias table's gradient) and patch merging."""
 from __future__ import annotations
 
 import functools
@@ -680,10 +680,73 @@ def g_qkv_attention(x: Act, lin, heads: int, scale: float, need_probs: bool, dro
     return y, (probs if need_probs else None)
 
 
+# ------------------------------------------------------------------------------------------------------------ Swin pieces
+@_op
+def g_swin_rel_bias(attn) -> torch.Tensor:
+    """table[index] -> [heads][n][n] on the device; the tape remembers which table leaf (and which index) it came from."""
+    t = tape()
+    table = attn.relative_position_bias_table
+    key = (id(table), "relbias")
+    hit = t.dev.get(key)
+    if hit is None:
+        t.leaves[id(table)] = table
+        hit = _upload(attn.get_relative_position_bias())
+        T = int(np.shape(table)[0])
+        idx = (np.asarray(attn.relative_position_index).reshape(-1).astype(np.int64) % T).astype(np.int32)   # negative indices wrap
+        t.dev[key] = hit
+        t.leaf_of[hit.data_ptr()] = (table, torch.from_numpy(idx).to(device()), T)
+    return hit
+
+
+@_op
+def g_swin_window_attention(qkv: Act, bias: torch.Tensor, heads: int, window, shift, drop=None) -> Act:
+    if drop is not None:
+        raise NotImplementedError("Swin attention dropout has no backward yet")
+    B, Hf, Wf, C3 = qkv.t.shape
+    C = C3 // 3
+    wh, ww, sh, sw = int(window[0]), int(window[1]), int(shift[0]), int(shift[1])
+    out = _new((B, Hf, Wf, C))
+    _call("mv_swin_window_attn_fwd", _p(qkv.t), _p(bias), _p(out), B, Hf, Wf, C, heads, wh, ww, sh, sw, F32, _S())
+    qt = qkv.t
+    info = tape().leaf_of.get(bias.data_ptr())
+
+    def backward(g):
+        n, nW = wh * ww, (Hf // wh) * (Wf // ww)
+        dqkv = _new((B, Hf, Wf, C3))
+        gw = _new((B * nW, heads * n * n))
+        _call("mv_swin_window_attn_bwd_f32", _p(qt), _p(bias), _p(g), _p(dqkv), _p(gw), B, Hf, Wf, C, heads, wh, ww, sh, sw, _S())
+        if info is not None:
+            table, idx, T = info
+            db = _colsum(gw, None, heads * n * n)                         # [heads][n * n]: summed over images and windows
+            dbt = _transpose(db, heads, n * n)                            # [n * n][heads]
+            dt = _new((T, heads))
+            _call("mv_scatter_rows_sum_f32", _p(dbt), _p(idx), _p(dt), n * n, heads, T, _S())
+            _acc_param(table, dt)
+        return (dqkv,)
+    return _mk(out, "map", qkv.batched, [_node(qkv)], backward)
+
+
+@_op
+def g_patch_merge_gather(x: Act) -> Act:
+    x = g_as_map.__wrapped__(x)
+    B, H, W, C = x.t.shape
+    if H % 2 or W % 2:
+        raise NotImplementedError("patch merging of an odd-sized map has no backward yet")
+    y = _new((B, H // 2, W // 2, 4 * C))
+    _call("mv_patch_merge_gather_nhwc", _p(x.t), _p(y), B, H, W, C, F32, _S())
+
+    def backward(g):
+        dx = _new((B, H, W, C))
+        _call("mv_patch_merge_gather_bwd_f32", _p(g), _p(dx), B, H, W, C, _S())
+        return (dx,)
+    return _mk(y, "map", x.batched, [_node(x)], backward)
+
+
 # ------------------------------------------------------------------------------------------------------------ the transform
 HOOKED = ("as_map", "as_rows", "cast", "flatten", "first_row", "eltwise", "add", "dropout", "drop_path", "channel_scale", "maxpool2d",
           "adaptive_avgpool2d", "batchnorm", "conv2d", "stem_conv_pool", "linear", "linear_head", "layernorm", "ln_linear",
-          "layernorm_first_row", "prep_f32", "patch_embed_tokens", "qkv_attention")
+          "layernorm_first_row", "prep_f32", "patch_embed_tokens", "qkv_attention", "swin_rel_bias", "swin_window_attention",
+          "patch_merge_gather")
 
 
 def hook(name: str, orig: Callable) -> Callable:

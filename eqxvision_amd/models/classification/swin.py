@@ -97,12 +97,7 @@ class _ShiftedWindowAttention(Module):
                                            self.window_size)
 
     def _bias_dev(self):
-        cache = self._cache()
-        b = cache.get("bias")
-        if b is None:
-            b = ops._dev(self.get_relative_position_bias(), __import__("torch").float32)
-            cache["bias"] = b
-        return b
+        return ops.swin_rel_bias(self)
 
     def _live(self) -> bool:
         """The reference's `_func_dropout` (swin.py:17-20, 227, 233) has no inference switch: a non-zero rate drops in EVERY mode."""

@@ -1106,6 +1106,17 @@ def qkv_attention(x: Act, lin, heads: int, scale: float, need_probs: bool, drop=
     return Act(out, "seq", x.batched), probs
 
 
+def swin_rel_bias(attn) -> torch.Tensor:
+    """The relative-position bias [heads][n][n] of a _ShiftedWindowAttention on the device: table[index] gathered on the host
+    (swin.py:34-43), cached on the module."""
+    cache = attn._cache()
+    b = cache.get("bias")
+    if b is None:
+        b = _dev(attn.get_relative_position_bias(), torch.float32)
+        cache["bias"] = b
+    return b
+
+
 def swin_window_attention(qkv: Act, bias: torch.Tensor, heads: int, window, shift, drop=None) -> Act:
     """`drop` = (p, per-sample keys): the reference's `_func_dropout(attn, attention_dropout, key)` (swin.py:227) inside the kernel."""
     B, Hf, Wf, C3 = qkv.t.shape

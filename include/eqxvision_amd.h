@@ -442,6 +442,16 @@ int mv_softmax_xent_f32(const float* logits, const float* target, float* loss_ro
  * bias_corr = 1 - beta^t computed by the caller; eqx.apply_updates adds `update` to the parameter (mv_add_fwd). */
 int mv_adam_step_f32(const float* grad, float* m, float* v, float* update, int64_t n, float lr, float b1, float b2, float eps,
                      float bias_corr1, float bias_corr2, mv_stream_t stream);
+/* Backward of mv_swin_window_attn_fwd (swin.py:123-250), fp32: dqkv[B,Hf,Wf,3C] from qkv, the relative-position bias
+ * [heads][n][n] and dout[B,Hf,Wf,C]; g_windows [B * windows][heads][n * n] receives the gradient w.r.t. the attention logits of
+ * every window (its column sum over the windows = the bias gradient).  Windows of <= 64 tokens. */
+int mv_swin_window_attn_bwd_f32(const float* qkv, const float* bias, const float* dout, float* dqkv, float* g_windows, int B, int Hf,
+                                int Wf, int C, int heads, int ws_h, int ws_w, int shift_h, int shift_w, mv_stream_t stream);
+/* out[t][c] = sum of src[m][c] over the rows m with index[m] == t (t < T): the gradient of a table gathered by `index`
+ * (swin.py:34-43: relative_position_bias_table[relative_position_index]). */
+int mv_scatter_rows_sum_f32(const float* src, const int* index, float* out, int M, int C, int T, mv_stream_t stream);
+/* Backward of mv_patch_merge_gather_nhwc (swin.py:23-31) for even H, W: dx[B,H,W,C] from dy[B,H/2,W/2,4C]. */
+int mv_patch_merge_gather_bwd_f32(const float* dy, float* dx, int B, int H, int W, int C, mv_stream_t stream);
 /* y[C][R] = x[R][C]^T, rows of x x_row_stride elements apart (0 = dense). */
 int mv_transpose2d_f32(const float* x, float* y, int R, int C, int64_t x_row_stride, mv_stream_t stream);
 

@@ -88,6 +88,12 @@ def mobilenet_v2(sd, x, labels, setting=None, dtype=torch.float32):
     return _finish(logits, labels, P)
 
 
+def swin(sd, x, labels, dtype=torch.float32, **kw):
+    """Shifted-window attention with the relative-position bias table, patch merging, LayerNorm2d (swin.py)."""
+    P = _params(sd, dtype)
+    return _finish(TR.swin_forward.__wrapped__(P, torch.as_tensor(x).to(dtype), **kw), labels, P)
+
+
 def finite_difference(fn, sd, x, labels, name, index, h=1e-3):
     """Central difference of the loss w.r.t. element `index` (flat) of parameter `name` in fp64-ish steps: checks the autograd
     oracle itself (tests/test_oracle.py)."""

@@ -360,6 +360,78 @@ def rowwise_bwd_case(kind, M, C, seed=0):
     return run
 
 
+def swin_bwd_case(B, Hf, C, heads, shift, seed=0, ws=7):
+    """mv_swin_window_attn_bwd_f32 (+ the bias-table gradient through mv_colsum_f32 / mv_scatter_rows_sum_f32) vs torch.autograd of
+    the torchvision-style shifted-window attention core (roll, partition, bias, -100 mask, softmax, reverse)."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        n, dh, T = ws * ws, C // heads, (2 * ws - 1) ** 2
+        qkv = rng.standard_normal((B, Hf, Hf, 3 * C)).astype(np.float32)
+        table = (0.5 * rng.standard_normal((T, heads))).astype(np.float32)
+        coords = np.stack(np.meshgrid(np.arange(ws), np.arange(ws), indexing="ij")).reshape(2, -1)
+        rel = coords[:, :, None] - coords[:, None, :] + (ws - 1)
+        index = (rel[0] * (2 * ws - 1) + rel[1]).reshape(-1).astype(np.int64)
+        sh = [shift, shift] if Hf > ws else [0, 0]
+
+        def core(qkv_t, table_t):
+            x = qkv_t
+            if sum(sh) > 0:
+                x = torch.roll(x, (-sh[0], -sh[1]), (1, 2))
+            nW = (Hf // ws) ** 2
+            x = x.view(B, Hf // ws, ws, Hf // ws, ws, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(B * nW, n, 3, heads, dh).permute(2, 0, 3, 1, 4)
+            q, k, v = x[0] * dh ** -0.5, x[1], x[2]
+            attn = q @ k.transpose(-2, -1) + table_t[torch.from_numpy(index)].view(n, n, heads).permute(2, 0, 1)[None]
+            if sum(sh) > 0:
+                m = qkv_t.new_zeros((Hf, Hf))
+                hs = ((0, -ws), (-ws, -sh[0]), (-sh[0], None))
+                c = 0
+                for hh in hs:
+                    for ww in hs:
+                        m[hh[0]:hh[1], ww[0]:ww[1]] = c
+                        c += 1
+                m = m.view(Hf // ws, ws, Hf // ws, ws).permute(0, 2, 1, 3).reshape(nW, n)
+                m = m.unsqueeze(1) - m.unsqueeze(2)
+                m = m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
+                attn = (attn.view(B, nW, heads, n, n) + m[None, :, None]).view(-1, heads, n, n)
+            y = (attn.softmax(-1) @ v).transpose(1, 2).reshape(B * nW, n, C)
+            y = y.view(B, Hf // ws, Hf // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hf, Hf, C)
+            return torch.roll(y, (sh[0], sh[1]), (1, 2)) if sum(sh) > 0 else y
+        y, g, (dq_ref, dt_ref) = _ag(core, qkv, table)
+        bias = table[index].reshape(n, n, heads).transpose(2, 0, 1)
+        qd, bd, gd = dev(qkv, "fp32"), dev(np.ascontiguousarray(bias), "fp32"), dev(g, "fp32")
+        nW = (Hf // ws) ** 2
+        out = torch.empty(B, Hf, Hf, C, device="cuda")
+        L.call("mv_swin_window_attn_fwd", qd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, Hf, Hf, C, heads, ws, ws, sh[0], sh[1], 0, _stream())
+        dq, gw = torch.full((B, Hf, Hf, 3 * C), -7.0, device="cuda"), torch.empty(B * nW, heads * n * n, device="cuda")
+        L.call("mv_swin_window_attn_bwd_f32", qd.data_ptr(), bd.data_ptr(), gd.data_ptr(), dq.data_ptr(), gw.data_ptr(), B, Hf, Hf, C, heads,
+               ws, ws, sh[0], sh[1], _stream())
+        db, dbt, dt = torch.empty(heads * n * n, device="cuda"), torch.empty(n * n, heads, device="cuda"), torch.empty(T, heads, device="cuda")
+        L.call("mv_colsum_f32", gw.data_ptr(), None, db.data_ptr(), B * nW, heads * n * n, _stream())
+        L.call("mv_transpose2d_f32", db.data_ptr(), dbt.data_ptr(), heads, n * n, 0, _stream())
+        idx = torch.from_numpy(index.astype(np.int32)).cuda()
+        L.call("mv_scatter_rows_sum_f32", dbt.data_ptr(), idx.data_ptr(), dt.data_ptr(), n * n, heads, T, _stream())
+        torch.cuda.synchronize()
+        parts = [_cmp(host(out), y, TOL_F32), _cmp(host(dq), dq_ref, TOL_F32), _cmp(host(dt), dt_ref, TOL_F32)]
+        return {"ok": all(p_["ok"] for p_ in parts), "err": max(p_["err"] for p_ in parts), "parts": parts}
+    return run
+
+
+def patch_merge_bwd_case(B, H, C, seed=0):
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        x = rng.standard_normal((B, H, H, C)).astype(np.float32)
+        f = lambda a: torch.cat([a[:, 0::2, 0::2], a[:, 1::2, 0::2], a[:, 0::2, 1::2], a[:, 1::2, 1::2]], -1)
+        y, g, (dx_ref,) = _ag(f, x)
+        gd = dev(g, "fp32")
+        dx = torch.full((B, H, H, C), -7.0, device="cuda")
+        L.call("mv_patch_merge_gather_bwd_f32", gd.data_ptr(), dx.data_ptr(), B, H, H, C, _stream())
+        torch.cuda.synchronize()
+        return _cmp(host(dx), dx_ref, TOL_F32)
+    return run
+
+
 def xent_adam_case(B, K, seed=0):
     def run():
         import torch.nn.functional as F
@@ -2096,6 +2168,11 @@ def all_cases():
           ("bwd/sigmoid", rowwise_bwd_case("sigmoid", 64, 200, seed=54)),
           ("bwd/silu", rowwise_bwd_case("silu", 64, 200, seed=55)),
           ("bwd/softmax_xent_adam", xent_adam_case(7, 10, seed=50)),
+          ("bwd/swin_attn_unshifted_56_c96", swin_bwd_case(2, 14, 96, 3, 0, seed=56)),
+          ("bwd/swin_attn_shifted_c96", swin_bwd_case(2, 14, 96, 3, 3, seed=57)),
+          ("bwd/swin_attn_shifted_c192_28", swin_bwd_case(1, 28, 192, 6, 3, seed=58)),
+          ("bwd/swin_attn_one_window_c768", swin_bwd_case(2, 7, 768, 24, 3, seed=59)),
+          ("bwd/patch_merge", patch_merge_bwd_case(2, 14, 96, seed=60)),
           ("chain/dual_56x56_B4", dual_chain_case(4 * 56 * 56, seed=6)),
           ("chain/dual_ragged_many", dual_chain_case(29 * 56 * 56 + 13, seed=7)),
           ("chain/n128_56x56_B4", chain_case(4 * 56 * 56, seed=4, N2=128)),

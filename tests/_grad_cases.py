@@ -46,6 +46,13 @@ def grad_parity_case(model, B=2, size=224, classes=10, lim=1e-3):
             sd = S.mobilenet_v2_state(1, classes, S.MBV2_SETTING)
             net = _load(eqv.models.mobilenet_v2, sd, num_classes=classes)
             ref_loss, ref = TG.mobilenet_v2(sd, x, labels)
+        elif model == "swin_t":
+            import warnings
+            sd = S.swin_state(1, (4, 4), 96, (2, 2, 6, 2), (3, 6, 12, 24), (7, 7), 4.0, classes)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                net = _load(eqv.models.swin_t, sd, num_classes=classes)
+            ref_loss, ref = TG.swin(sd, x, labels)
         elif model == "vgg11":
             sd = S.vgg_state(1, "A", False, classes)
             net = _load(eqv.models.vgg11, sd, num_classes=classes)
@@ -59,7 +66,7 @@ def grad_parity_case(model, B=2, size=224, classes=10, lim=1e-3):
         got = eqv.utils.state_dict(grads)
         # the two sides list the same parameters in the same order (the load_torch_weights contract); names differ where the
         # reference's module tree does (its VGG classifier has one ReLU less than torchvision's: other Sequential indices)
-        got_l = [(k, v) for k, v in got.items() if "running" not in k]
+        got_l = [(k, v) for k, v in got.items() if "running" not in k and np.asarray(v).dtype.kind == "f"]
         ref_l = [(k, sd[k]) for k in sd if k in ref]
         if len(got_l) != len(ref_l):
             return {"ok": False, "err": f"{len(got_l)} gradient leaves vs {len(ref_l)} parameters"}
@@ -115,6 +122,7 @@ def all_cases():
             ("grad/resnet50_B1_vs_autograd", grad_parity_case("resnet50", 1)),
             ("grad/vgg11_B1_vs_autograd", grad_parity_case("vgg11", 1, lim=1e-2)),
             ("grad/mobilenet_v2_B2_vs_autograd", grad_parity_case("mobilenet_v2", 2)),
+            ("grad/swin_t_B2_vs_autograd", grad_parity_case("swin_t", 2)),
             ("grad/step_alexnet_training_mode", train_step_case("alexnet")),
             ("grad/step_resnet18_training_mode", train_step_case("resnet18")),
             ("grad/step_vit_tiny_training_mode", train_step_case("vit_tiny")),
@@ -124,4 +132,5 @@ def all_cases():
             ("grad/step_mobilenet_v3_small_training_mode", train_step_case("mobilenet_v3_small")),
             ("grad/step_efficientnet_b0_training_mode", train_step_case("efficientnet_b0")),
             ("grad/step_regnet_x_400mf_training_mode", train_step_case("regnet_x_400mf")),
-            ("grad/step_resnext50_32x4d_training_mode", train_step_case("resnext50_32x4d"))]
+            ("grad/step_resnext50_32x4d_training_mode", train_step_case("resnext50_32x4d")),
+            ("grad/step_swin_t_training_mode", train_step_case("swin_t"))]
