@@ -43,12 +43,14 @@ class StateIndex:
             # a recorded training-mode step has the ADDRESSES of the device copy baked in (transforms: 'state-rw' signature):
             # refresh those tensors in place instead of dropping them, or the replay would keep updating the old statistics and
             # its hook would hand them back over the values set here (round-2 advice)
-            try:
-                import torch
-                for t, a in zip(self._dev, v):
-                    t.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(a, np.float32)).reshape(tuple(t.shape))))
-            except Exception:
-                self._dev = None
+            import torch
+            if len(v) != len(self._dev) or any(int(np.size(a)) != t.numel() for t, a in zip(self._dev, v)):
+                # a recorded training step has the old tensors' ADDRESSES baked in: a value of another shape cannot be refreshed in
+                # place, and silently dropping the device copy would leave that recording updating stale statistics
+                raise ValueError("StateIndex.value: the new statistics do not match the shape of the device copy a recorded "
+                                 "training step may hold; build a fresh module (or clear filter_jit's cache) instead")
+            for t, a in zip(self._dev, v):
+                t.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(a, np.float32)).reshape(tuple(t.shape))))
         else:
             self._dev = None
         self._dev_newer = False

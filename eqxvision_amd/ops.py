@@ -479,7 +479,7 @@ def prep_bneck_tail(conv2, bn2, conv3, bn3):
         s2, h2 = _fold(conv2, bn2)
         s3, h3 = _fold(conv3, bn3)
         hit = (_dev(w2f, torch.bfloat16), _dev(s2, torch.float32), _dev(h2, torch.float32),
-               _dev(w3f, torch.bfloat16), _dev(s3, torch.float32), _dev(h3, torch.float32))
+               _dev(w3f, torch.bfloat16), _dev(s3, torch.float32), _dev(h3, torch.float32), conv3)   # conv3: keeps the id() in the key alive
         cache[key] = hit
     return hit
 
@@ -502,7 +502,7 @@ def bottleneck_tail(t1: Act, conv2, bn2, conv3, bn3, identity: Act) -> Optional[
         return None
     if not _lib.load().mv_bottleneck_tail_supported(H, W, C, K, DT[dt]):
         return None
-    w2f, s2, h2, w3f, s3, h3 = prep_bneck_tail(conv2, bn2, conv3, bn3)
+    w2f, s2, h2, w3f, s3, h3, _ = prep_bneck_tail(conv2, bn2, conv3, bn3)
     y = empty((B, H, W, K), torch.bfloat16)
     _lib.call("mv_bottleneck_tail_fwd", _ptr(t1.t), _ptr(w2f), _ptr(s2), _ptr(h2), _ptr(w3f), _ptr(s3), _ptr(h3),
               _ptr(identity.t), _ptr(y), B, H, W, C, K, DT[dt], stream_ptr())
@@ -707,7 +707,6 @@ def linear(x: Act, lin, act=None, residual: Optional[Act] = None, out_fp32: bool
     x = as_map(x) if x.kind in ("img", "map") else as_rows(x)
     if x.t.dtype != TORCH_DT[dt]:
         x = cast(x, dt)
-    w, b = prep_linear(lin, dt)
     N, K = lin.out_features, lin.in_features
     if x.t.shape[-1] != K:
         raise ValueError(f"Linear expected {K} input features, got {x.t.shape[-1]}")
@@ -725,14 +724,35 @@ def linear(x: Act, lin, act=None, residual: Optional[Act] = None, out_fp32: bool
     if res is None and dt == "bf16" and _lib.load().mv_fc_stream_supported(M, N, K, DT[dt], odc):
         # few rows, a big weight matrix (AlexNet / VGG classifiers): the layer is bound by streaming W -- fragment-ordered weights,
         # split-K over the CUs, fixed-order reduction (csrc/fc_stream.hip)
+        # (decided BEFORE prep_linear: the row-major bf16 copy of a 9216 x 4096 weight would only double the device memory)
         wf = fc_fragments(lin)
+        b = prep_f32(lin, "bias", None if lin.bias is None else np.asarray(lin.bias, np.float32).reshape(-1))
         nbytes = int(_lib.load().mv_fc_stream_workspace(M, N, K))
-        ws = empty((nbytes // 4,), torch.float32)
+        ws = _fc_workspace(nbytes)
         _lib.call("mv_fc_stream_fwd", _ptr(x.t), _ptr(wf), _ptr(b), _ptr(y), _ptr(ws), nbytes, M, N, K, ACT[act], DT[dt], odc, stream_ptr())
         return Act(y, x.kind, x.batched)
+    w, b = prep_linear(lin, dt)
     _lib.call("mv_linear_fwd", _ptr(x.t), _ptr(w), None, _ptr(b), _ptr(res), _ptr(y), M, N, K, ACT[act],
               DT[dt], odc, stream_ptr())
     return Act(y, x.kind, x.batched)
+
+
+_FC_WS = {}
+
+
+def _fc_workspace(nbytes: int) -> torch.Tensor:
+    """The split-K workspace of an eager call: ONE per stream instead of a fresh allocation per call (launches on a stream are
+    ordered, so consecutive layers share it).  While a forward is being RECORDED every call keeps its own: the lanes of a recording
+    become parallel branches of the hipGraph, and two branches must not share scratch memory."""
+    from . import _act
+    if getattr(_act._tls, "keep", None) is not None:
+        return empty(((nbytes + 3) // 4,), torch.float32)
+    key = (stream_ptr(), torch.cuda.current_device())
+    ws = _FC_WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(((nbytes + 3) // 4,), dtype=torch.float32, device=device())
+        _FC_WS[key] = ws
+    return ws
 
 
 def fc_fragments(lin) -> torch.Tensor:
@@ -1139,6 +1159,8 @@ def swin_block_attn_fragments(wqkv: np.ndarray, bqkv: np.ndarray, wp: np.ndarray
     the operand layouts of mv_swin_block_attn_fwd (header)."""
     C = wp.shape[0]
     heads = C // 32
+    if C not in (384, 192, 96):                           # the widths the kernel is instantiated for (NWIN / NWV templates)
+        raise ValueError(f"swin_block_attn_fragments: width {C} has no fused kernel (96 / 192 / 384)")
     HG = {384: 4, 192: 2, 96: 1}[C]                       # heads per group (x windows per workgroup = 4)
     G, GT = heads // HG, 3 * HG                            # always 3 groups; tiles per group: q heads, k heads, v heads
     rows = np.array([[(t // HG) * C + 32 * (HG * g + t % HG) for t in range(GT)] for g in range(G)])              # [G][GT]
