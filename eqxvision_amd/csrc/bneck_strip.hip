@@ -80,16 +80,15 @@ __global__ __launch_bounds__(512) void bneck_strip_kernel(const StripP p) {
 #else
 #define MV_BS_STAMP(i) do {} while (0)
 #endif
-    // Every workgroup is load-bound in phase A, matrix-bound in phase B and store-bound in phase C, and they all last the same
-    // time: started together, all CUs would hit HBM in the same phases and leave it idle in between.  The first round is
-    // staggered by quarters of a workgroup's duration; later rounds inherit the offsets.
-    if (p.skew > 0 && blockIdx.x < 256) {
+#ifdef MV_I8_PROF                                    // the stagger experiment (debug build): phase A stays ~21 us per workgroup with it --
+    if (p.skew > 0 && blockIdx.x < 256) {            // a CU's memory pipe, not chip-wide contention, is what bounds it
         const int q = (blockIdx.x >> 3) & 3;
         if (q) {
             const long long t_end = wall_clock64() + (long long)q * p.skew;
             while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(32);
         }
     }
+#endif
     MV_BS_STAMP(0);
 
     // ---------------- zero border of the t1 map ---------------------------------------------------------------------------
@@ -360,8 +359,9 @@ int mv_bottleneck_strip_fwd(const void* x, const void* w1f, const float* scale1,
     p.w2f = (const bf16_t*)w2f; p.s2 = scale2; p.h2 = shift2;
     p.w3f = (const bf16_t*)w3f; p.s3 = scale3; p.h3 = shift3; p.y = (bf16_t*)y;
     p.prof = nullptr;
-    p.skew = get_flag("strip_skew");
+    p.skew = 0;
 #ifdef MV_I8_PROF
+    p.skew = get_flag("strip_skew");
     if (get_flag("bneck_prof"))
         p.prof = (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo"));
 #endif

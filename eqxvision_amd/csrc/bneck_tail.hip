@@ -344,12 +344,20 @@ int mv_bottleneck_tail_fwd(const void* t1, const void* w2f, const float* scale2,
     BneckP p;
     p.t1 = (const bf16_t*)t1; p.w2f = (const bf16_t*)w2f; p.s2 = scale2; p.h2 = shift2;
     p.w3f = (const bf16_t*)w3f; p.s3 = scale3; p.h3 = shift3; p.res = (const bf16_t*)residual; p.y = (bf16_t*)y;
-    p.skew = get_flag("bneck_skew");
-    p.prof = get_flag("bneck_prof") ? (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo")) : nullptr;
+    p.skew = 0;                 // the skewed two-half schedule measured +0 / -2 %: the switch is gone
+    p.prof = nullptr;
+#ifdef MV_I8_PROF              // debug build only (EQV_PROF=1): the production library never turns a flag into a device address
+    if (get_flag("bneck_prof"))
+        p.prof = (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo"));
+#endif
     constexpr int SMEM = 7 * 32 * 512 + 8 * 32 * 144;        // t2 + the 8 epilogue patches (>= the zero-bordered t1 map)
     static_assert(SMEM >= (7 * 32 + 34) * 512, "t1 map must fit");
     auto kern = bneck_tail_kernel<256, 1024, 14>;
-    MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    static bool attr_set = false;
+    if (!attr_set) {
+        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
     set_kernel_name("bneck_tail_bf16_14x14_256_1024");
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(512), SMEM, stream, p);
     MV_LAUNCH_CHECK();

@@ -188,13 +188,15 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
 #else
 #define MV_I8_STAMP() do {} while (0)
 #endif
-    if (p.skew > 0 && blockIdx.x < 256) {          // experiment (i8_skew): de-phase the first round of workgroups by quarters
+#ifdef MV_I8_PROF
+    if (p.skew > 0 && blockIdx.x < 256) {          // experiment (i8_skew, debug build): de-phase the first round of workgroups by quarters
         const int q = (blockIdx.x >> 3) & 3;
         if (q) {
             const long long t_end = wall_clock64() + (long long)q * p.skew;
             while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16);
         }
     }
+#endif
     const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     int tile_m, tile_n;
     tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n, p.gm);
@@ -765,7 +767,9 @@ static int igemm8_go(Igemm2P& p, bool dual, bool out_f32, int tile, hipStream_t 
     p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = (p.K + bn - 1) / bn;
     p.gm = get_flag("i8_gm") ? get_flag("i8_gm") : 8;
-    p.skew = get_flag("i8_skew");
+#ifdef MV_I8_PROF
+    p.skew = get_flag("i8_skew");                    // measured -3.6 % on vit_base (profiles/r04/vit_ab_i8_skew_4.6us.txt)
+#endif
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(512);
 #define GO(KERN, SMEM)                                                                                            \
     do {                                                                                                          \

@@ -547,7 +547,11 @@ int mv_ln_mlp_stream_fwd(const void* x, const void* w1f, const float* b1, const 
     LnMlpSP p;
     p.x = (const float*)x; p.w1f = (const bf16_t*)w1f; p.b1 = b1; p.w2f = (const bf16_t*)w2f; p.b2 = b2; p.y = (float*)y;
     p.M = M; p.eps = eps;
-    p.prof = get_flag("lms_prof") ? (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo")) : nullptr;
+    p.prof = nullptr;
+#ifdef MV_I8_PROF              // debug build only
+    if (get_flag("lms_prof"))
+        p.prof = (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo"));
+#endif
     if (C == 192) {
         constexpr int TM = 128;
         constexpr int SMEM = TM * (192 * 2 + 16) + TM * (256 * 2 + 16);

@@ -390,7 +390,8 @@ __global__ __launch_bounds__(NWV * 64) void swin_block_attn_kernel(const SwinBAP
 
 extern "C" {
 
-static int swin_block_attn_nwin(int C) { return C == 384 ? 1 : (C == 192 ? 2 : (C == 96 ? (mv::get_flag("swin_c96_8w") ? 4 : 2) : 0)); }
+// windows per workgroup.  (C = 96 also ran as 4 windows / 8 waves, one workgroup per CU: -4 % on swin_t, removed in round 4.)
+static int swin_block_attn_nwin(int C) { return C == 384 ? 1 : (C == 192 ? 2 : (C == 96 ? 2 : 0)); }
 
 int mv_swin_block_attn_supported(int Hf, int Wf, int C, int heads, int wsh, int wsw, int x_dtype) {
     if (mv::get_flag("no_swin_block_attn")) return 0;
@@ -414,9 +415,13 @@ int mv_swin_block_attn_fwd(const void* x, const void* wqkv_f, const float* bqkv,
     SwinBAP p;
     p.x = (const float*)x; p.wqkv = (const bf16_t*)wqkv_f; p.bqkv = bqkv; p.wp = (const bf16_t*)wp_f; p.bp = bp; p.bias = bias64;
     p.y = (float*)y; p.Hf = Hf; p.Wf = Wf; p.shh = shh; p.shw = shw; p.nWw = Wf / 7; p.nW = (Hf / 7) * (Wf / 7); p.eps = eps;
-    p.prof = get_flag("sba_prof") ? (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo")) : nullptr;
+    p.prof = nullptr;
+#ifdef MV_I8_PROF              // debug build only
+    if (get_flag("sba_prof"))
+        p.prof = (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo"));
+#endif
     const int nwin = swin_block_attn_nwin(C);
-    const int nwv = (C == 96 && nwin == 2) ? 4 : 8;
+    const int nwv = C == 96 ? 4 : 8;
     const int tr = 64 * nwin, nslot = nwv / 2;
     const int xbytes = C == 96 ? tr * 192 + (tr / 4) * 16 : tr * (C * 2 + 16);
     const int smem = 2 * xbytes + 2 * nslot * 64 * 80 + nslot * 32 * 144 + nwin * 256;
@@ -424,12 +429,15 @@ int mv_swin_block_attn_fwd(const void* x, const void* wqkv_f, const float* bqkv,
 #define MV_SBA_GO(CC, NW, WV)                                                                                        \
     do {                                                                                                             \
         auto kern = swin_block_attn_kernel<CC, NW, WV>;                                                              \
-        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));            \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
         hipLaunchKernelGGL(kern, grid, dim3(WV * 64), smem, stream, p);                                              \
     } while (0)
     if (C == 384) { set_kernel_name("swin_block_attn_c384"); MV_SBA_GO(384, 1, 8); }
     else if (C == 192) { set_kernel_name("swin_block_attn_c192"); MV_SBA_GO(192, 2, 8); }
-    else if (nwv == 8) { set_kernel_name("swin_block_attn_c96_8w"); MV_SBA_GO(96, 4, 8); }
     else { set_kernel_name("swin_block_attn_c96"); MV_SBA_GO(96, 2, 4); }
 #undef MV_SBA_GO
     MV_LAUNCH_CHECK();

@@ -1,4 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04_s10; mkdir -p $O
-timeout 1500 python tools/gpu_check.py grad/swin > $O/check.log 2>&1; grep -E "PASS|FAIL|passed" $O/check.log | cut -c1-420
-timeout 600 python -m pytest tests/test_c_host.py -m gpu -x -q 2>&1 | tail -25
+bash tools/profile_session.sh r4prof r04 > gpurun_out/r4prof.log 2>&1
+tail -12 gpurun_out/r4prof.log | cut -c1-300
+cat gpurun_out/r4prof/roofline_vs_rocprof.txt
+timeout 600 python tools/gpu_check.py alexnet fc_stream > gpurun_out/r4prof/check_alex.log 2>&1; grep -c PASS gpurun_out/r4prof/check_alex.log; grep FAIL gpurun_out/r4prof/check_alex.log | cut -c1-300
+timeout 400 python bench.py > gpurun_out/r4prof/bench_default_line.json 2> gpurun_out/r4prof/bench_default.err; cut -c1-1500 gpurun_out/r4prof/bench_default_line.json

@@ -16,8 +16,6 @@ def t(fn, n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-if os.environ.get("BNECK_SKEW"):
-    L.set_flag("bneck_skew", int(os.environ["BNECK_SKEW"])); print("bneck_skew =", os.environ["BNECK_SKEW"])
 for B in [int(a) for a in sys.argv[1:]] or [128, 256]:
     t1, r = bf(B, HW, HW, WID).relu(), bf(B, HW, HW, COUT)
     w2 = (torch.randn(WID, 3, 3, WID, device="cuda") / (9 * WID) ** 0.5).bfloat16()          # KRSC
