@@ -72,6 +72,8 @@ PROTOTYPES = {
     "mv_conv2d_nchw_f32out_fwd": [_vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_i, _i, _i, _i, _vp, _vp],
     "mv_fc_stream_supported": [_i64, _i, _i, _i, _i],
     "mv_fc_stream_workspace": [_i64, _i, _i],
+    "mv_set_scratch": [_vp, C.c_size_t, _vp],
+    "mv_splitk_scratch_bytes": [_i64, _i64, _i64],
     "mv_fc_stream_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp],
     "mv_ln_mlp_stream_supported": [_i64, _i, _i, _i],
     "mv_ln_mlp_stream_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _vp],
@@ -137,7 +139,8 @@ PROTOTYPES = {
     "mv_event_elapsed_ms": [_vp, _vp, C.POINTER(_f)],
     "mv_event_destroy": [_vp],
 }
-_RESTYPES = {"mv_last_error": C.c_char_p, "mv_last_kernel": C.c_char_p, "mv_fc_stream_workspace": _i64}
+_RESTYPES = {"mv_last_error": C.c_char_p, "mv_last_kernel": C.c_char_p, "mv_fc_stream_workspace": _i64,
+             "mv_splitk_scratch_bytes": C.c_size_t}
 
 _lib = None
 _lock = threading.Lock()
@@ -206,8 +209,25 @@ def call(name, *args):
         raise MVError(f"{name} failed (rc={rc}): {msg.decode() if msg else ''}")
     rec = getattr(_tls, "rec", None)
     if rec is not None and not name.startswith(_NOT_RECORDED):
+        if name == "mv_set_scratch":                   # not a launch: it travels with the launch it was set for
+            _tls.pending_scratch = args[:2]
+            return rc
+        ps = getattr(_tls, "pending_scratch", None)
+        if ps is not None:
+            _tls.pending_scratch = None
+            fn = _with_scratch(lib.mv_set_scratch, ps, fn)
         rec.append((fn, args, name))
     return rc
+
+
+def _with_scratch(setter, scratch, fn):
+    """A recorded launch that was handed scratch memory: every replay hands it over again, on the stream it is replayed on."""
+    ptr, nbytes = scratch
+
+    def launch(*a):
+        setter(ptr, nbytes, a[-1])
+        return fn(*a)
+    return launch
 
 
 def last_kernel() -> str:

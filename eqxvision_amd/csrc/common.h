@@ -80,7 +80,12 @@ __device__ __forceinline__ float apply_act_rt(float v, int act) {
 // ---- host side ------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 void set_kernel_name(const char* name);
+void append_kernel_name(const char* suffix);
 int get_flag(const char* name);
+// the scratch the host handed over with mv_set_scratch for the next launch on `stream`: returned (and forgotten) if it holds
+// at least `need` bytes, else nullptr
+void* take_scratch(hipStream_t stream, size_t need);
+size_t splitk_scratch_bytes(long long M, long long N, long long kred);       // igemm8.hip
 const void* zero_page(hipStream_t stream);  // >= 4 KiB of device zeros for the current device
 
 inline size_t dsize(int dt) { return dt == MV_BF16 ? 2 : 4; }

@@ -95,6 +95,23 @@ template <bool DUAL> __device__ __forceinline__ void tap_next(const Igemm2P& p, 
     s.xoff = 2u * (unsigned)(((s.r * p.dh) * p.W + s.s * p.dw) * p.C + s.c0);
 }
 
+// -> state of k-tile `tile` from scratch (a split-K block starts in the middle of the reduction)
+template <bool DUAL> __device__ __forceinline__ TapState tap_at(const Igemm2P& p, int tile, int nk1) {
+    TapState s = tap_first();
+    s.woff = 128u * (unsigned)tile;
+    if (DUAL && tile >= nk1) {
+        s.xoff = 128u * (unsigned)(tile - nk1);
+        return s;
+    }
+    const int cpt = p.C >> 6, tap = tile / cpt;
+    s.c0 = (tile - tap * cpt) * 64;
+    s.r = tap / p.S;
+    s.s = tap - s.r * p.S;
+    s.bit = 1u << tap;
+    s.xoff = 2u * (unsigned)(((s.r * p.dh) * p.W + s.s * p.dw) * p.C + s.c0);
+    return s;
+}
+
 // Per-lane DMA source of one staged pixel row: byte offset of its tap-(0,0) / channel-0 element (+ the lane's swizzled
 // 16-byte chunk) from the x descriptor base, the bit mask of the filter taps that fall inside the image, and (DUAL) the
 // offset of the same output pixel in the second, strided source.  Block-uniform part (b0, ho0, wo0) done once by the caller.
@@ -521,7 +538,16 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
     const int grp = wave >> 2;
     const int xrow0 = ARR == 0 ? 64 * grp : 128 * grp + 64 * (wave & 1);
     const int wrow0 = ARR == 0 ? 64 * (wave & 3) : 64 * ((wave >> 1) & 1);
-    const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    // split-K (p.sync != nullptr): the two halves of a tile's reduction are blocks b and b + 8 -- dispatched together, on the
+    // same XCD (one L2 between the partial sums' writer and reader)
+    const bool splitk = p.sync != nullptr;
+    int t = blockIdx.x, half = 0;
+    if (splitk) {
+        t = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+        half = (blockIdx.x >> 3) & 1;
+        if (t >= p.tiles_m * p.tiles_n) return;
+    }
+    t = xcd_remap(t, p.tiles_m * p.tiles_n);
     int tile_m, tile_n;
     tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n, p.gm);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -529,7 +555,9 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
     const int srow = lane >> 3;
     const int gch = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
     const int nk1 = p.R * p.S * (p.C >> 6);
-    const int nk = DUAL ? nk1 + (p.C2 >> 6) : nk1;
+    const int nk_all = DUAL ? nk1 + (p.C2 >> 6) : nk1;
+    const int k0 = half ? (nk_all + 1) >> 1 : 0;                      // this block's k-tiles: k0 .. k0 + nk - 1
+    const int nk = splitk ? (half ? nk_all - k0 : (nk_all + 1) >> 1) : nk_all;
     const unsigned wrow_bytes = 2u * (unsigned)(p.R * p.S * p.C + (DUAL ? p.C2 : 0));
     const RowBase rb = row_base(p, m0);
     const u32x4 rx = make_rsrc((const char*)p.x - rb.padb);
@@ -615,10 +643,14 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
     TapState st = tap_first();
-    stage(st, 0, std::integral_constant<int, 0>{});
+    if (k0) {
+        if constexpr (DENSE) { st.woff = st.xoff = 128u * (unsigned)k0; }
+        else st = tap_at<DUAL>(p, k0, nk1);
+    }
+    stage(st, k0, std::integral_constant<int, 0>{});
     if (nk > 1) {
-        tap_adv(st, 1);
-        stage(st, 1, std::integral_constant<int, 1>{});
+        tap_adv(st, k0 + 1);
+        stage(st, k0 + 1, std::integral_constant<int, 1>{});
         wait_vm<6>();
     } else {
         wait_vm<0>();
@@ -628,7 +660,7 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
 
     u32x4 wf[2][4], xf[2][4];
     auto ktile = [&](int it, auto slotc) {
-        constexpr int SL = decltype(slotc)::value;          // ring slot of tile `it`
+        constexpr int SL = decltype(slotc)::value;          // ring slot of tile `it` (it counts from this block's first k-tile)
         constexpr int OFF = SL == 2 ? 0 : SL * SLOT;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -638,8 +670,8 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
             lds_read16<OFF + 32 * ROWB>(xf[1][kk], SL == 2 ? xaddr2[kk] : xaddr[kk]);
         }
         if (it + 2 < nk) {                                   // tile it+2 goes where tile it-1 was (last read a phase ago)
-            tap_adv(st, it + 2);
-            stage(st, it + 2, std::integral_constant<int, (SL + 2) % 3>{});
+            tap_adv(st, k0 + it + 2);
+            stage(st, k0 + it + 2, std::integral_constant<int, (SL + 2) % 3>{});
             wait_vm_lgkm0<6>();                              // tile it+1 has landed
         } else {
             wait_vm_lgkm0<0>();
@@ -668,6 +700,56 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
         if (it + 2 < nk) ktile(it + 2, std::integral_constant<int, 2>{});
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
+
+    if (splitk) {
+        // Two-way split-K, deterministic: whichever half of a tile finishes FIRST parks its fp32 accumulators (in register order,
+        // 16 bytes per lane: coalesced) and leaves; the other half adds them to its own -- a + b == b + a bit for bit, so the
+        // result does not depend on which one that was -- and runs the epilogue.  The second block only ever waits for a block
+        // that is already past its main loop (no dependence on dispatch order), and it leaves both words zero for the next launch.
+        // Visibility: the two blocks normally sit on one XCD (one L2; a CU's vector L1 is write-through and cannot hold a line of
+        // the partial tile, which nobody has read in this launch), so the hand-over needs no cache maintenance; the writer still
+        // publishes with ONE release (a single L2 write-back, not one per wave) and says which XCD it ran on, and a reader on a
+        // different XCD -- not seen with today's round-robin dispatch, but nothing promises it -- invalidates before it reads.
+        unsigned* sync = p.sync + 2 * t;
+        float4* part = (float4*)p.ws + (size_t)t * (BM * BN / 4) + tid;
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;                 // HW_REG_XCC_ID[3:0]
+        if (tid == 0) *(volatile unsigned*)smem = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned arrived = *(volatile unsigned*)smem;
+        __syncthreads();
+        if (arrived == 0) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        part[((a * 2 + b) * 4 + g) * 512] = make_float4(acc[a][b][4 * g + 0], acc[a][b][4 * g + 1],
+                                                                        acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
+            __syncthreads();                                 // every wave's stores have reached the L2 (s_waitcnt vmcnt(0) + barrier)
+            if (tid == 0) __hip_atomic_store(sync + 1, 1u + xcc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) {
+            int spins = 0;                                   // bounded: a stale word can cost a wrong tile, never a hung GPU
+            unsigned f;
+            while ((f = __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && ++spins < (1 << 20))
+                __builtin_amdgcn_s_sleep(2);
+            if (f != 1u + xcc) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 o = part[((a * 2 + b) * 4 + g) * 512];
+                    acc[a][b][4 * g + 0] += o.x; acc[a][b][4 * g + 1] += o.y; acc[a][b][4 * g + 2] += o.z; acc[a][b][4 * g + 3] += o.w;
+                }
+    }
 
     char* ep = smem + wave * (32 * EPITCH);
     OutT* y = (OutT*)p.y;
@@ -762,6 +844,26 @@ int igemm8_wanted(long long M, int C, int K, int R, int S) {
     return t128 >= 40 ? 2 : 0;
 }
 
+// Two-way split-K of the half-size tiles (igemm8s_kernel): a launch that leaves half of the 256 CUs idle and has a reduction long
+// enough for two main loops.  `tiles` = tiles of the 128 x 256 / 256 x 128 shape, `nk` = 64-channel k-tiles of the whole reduction.
+static bool splitk_rule(long long tiles, long long nk) {
+    if (get_flag("no_splitk")) return false;
+    // the hand-over costs ~8 us (two atomics, 128 KB out of one CU and into another): it pays from ~40 k-tiles up
+    // (tools/time_splitk.py: 72 k-tiles x1.34, 48 x1.10-1.22, 32 x1.05, 12 x0.75)
+    const int min_nk = get_flag("splitk_min_nk") ? get_flag("splitk_min_nk") : 40;
+    const int max_tiles = get_flag("splitk_max_tiles") ? get_flag("splitk_max_tiles") : 128;
+    return tiles <= max_tiles && nk >= min_nk;
+}
+constexpr size_t SPLITK_SYNC_BYTES = 4096;            // 2 words x 512 tiles
+
+size_t splitk_scratch_bytes(long long M, long long N, long long kred) {
+    if (N <= 0 || M <= 0) return 0;
+    // which of the two half-size shapes the dispatch picks is its business: room for the one with more tiles
+    const long long ta = ((M + 127) / 128) * ((N + 255) / 256), tb = ((M + 255) / 256) * ((N + 127) / 128);
+    if (!splitk_rule(ta < tb ? ta : tb, kred / 64)) return 0;
+    return SPLITK_SYNC_BYTES + (size_t)(ta > tb ? ta : tb) * 128 * 256 * 4;
+}
+
 static int igemm8_go(Igemm2P& p, bool dual, bool out_f32, int tile, hipStream_t st) {
     const int bm = tile == 1 ? 128 : 256, bn = tile == 2 ? 128 : 256;
     p.tiles_m = (p.M + bm - 1) / bm;
@@ -770,11 +872,21 @@ static int igemm8_go(Igemm2P& p, bool dual, bool out_f32, int tile, hipStream_t 
 #ifdef MV_I8_PROF
     p.skew = get_flag("i8_skew");                    // measured -3.6 % on vit_base (profiles/r04/vit_ab_i8_skew_4.6us.txt)
 #endif
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(512);
+    const int tiles = p.tiles_m * p.tiles_n;
+    p.sync = nullptr; p.ws = nullptr;
+    if (tile != 0 && splitk_rule(tiles, (long long)p.R * p.S * (p.C / 64) + (dual ? p.C2 / 64 : 0))) {
+        void* sc = take_scratch(st, SPLITK_SYNC_BYTES + (size_t)tiles * 128 * 256 * 4);      // the host's mv_set_scratch for this launch
+        if (sc) { p.sync = (unsigned*)sc; p.ws = (float*)((char*)sc + SPLITK_SYNC_BYTES); }
+    }
+    const dim3 grid((unsigned)(p.sync ? 16 * ((tiles + 7) / 8) : tiles)), block(512);
 #define GO(KERN, SMEM)                                                                                            \
     do {                                                                                                          \
         auto kern = KERN;                                                                                         \
-        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));         \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));     \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
         hipLaunchKernelGGL(kern, grid, block, SMEM, st, p);                                                       \
     } while (0)
 #define GO4(NAME, SMEM, ...)                                                  \
@@ -848,7 +960,9 @@ int igemm8_launch(const void* x, const void* w, const float* scale, const float*
                  out_dtype == MV_F32 ? "_f32out" : "");
         set_kernel_name(nm);
     }
-    return igemm8_go(p, false, out_dtype == MV_F32, tile - 1, st);
+    const int rc = igemm8_go(p, false, out_dtype == MV_F32, tile - 1, st);
+    if (p.sync) append_kernel_name("_splitk");
+    return rc;
 }
 
 // y[N,Ho,Wo,K] = act(scale[k] * (x[N,Ho,Wo,C1] . w[k, 0:C1] + x2[N, s2*ho, s2*wo, C2] . w[k, C1:C1+C2]) + shift[k] + residual)
@@ -876,7 +990,9 @@ int igemm8_dual_launch(const void* x, const void* x2, const void* w, const float
                  out_dtype == MV_F32 ? "_f32out" : "");
         set_kernel_name(nm);
     }
-    return igemm8_go(p, true, out_dtype == MV_F32, tile - 1, st);
+    const int rc = igemm8_go(p, true, out_dtype == MV_F32, tile - 1, st);
+    if (p.sync) append_kernel_name("_splitk");
+    return rc;
 }
 
 }  // namespace mv

@@ -22,6 +22,8 @@ struct Igemm2P {
     int gm;                         // igemm8: pixel tiles per group of the tile order (mfma_common.h: tile_coords)
     int skew;                       // igemm8 experiment: start delay of the first-round workgroups, (block / 8 & 3) x skew x 10 ns
     int tok;                        // > 0: head-major output y[b][n/64][t][n%64], rows m = b*tok + t (qkv projection)
+    unsigned* sync;                 // igemm8s split-K: two words per tile (arrivals, partial-is-there), zero between launches; nullptr = no split
+    float* ws;                      // igemm8s split-K: one fp32 tile of partial sums per tile
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

@@ -29,6 +29,17 @@ void set_kernel_name(const char* name) {
     strncpy(g_kernel, name, sizeof(g_kernel) - 1);
     g_kernel[sizeof(g_kernel) - 1] = 0;
 }
+void append_kernel_name(const char* suffix) {
+    strncat(g_kernel, suffix, sizeof(g_kernel) - strlen(g_kernel) - 1);
+}
+// One launch's scratch memory, handed over by the host thread that issues the launch (mv_set_scratch): the library never allocates.
+static thread_local struct { void* ptr; size_t bytes; hipStream_t stream; } g_scratch = {nullptr, 0, nullptr};
+void* take_scratch(hipStream_t stream, size_t need) {
+    if (!g_scratch.ptr || g_scratch.stream != stream || g_scratch.bytes < need) return nullptr;
+    void* p = g_scratch.ptr;
+    g_scratch.ptr = nullptr;
+    return p;
+}
 int get_flag(const char* name) {
     if (g_flags.empty()) return 0;
     auto it = g_flags.find(name);
@@ -74,6 +85,14 @@ int mv_set_flag(const char* name, int value) {
 }
 int mv_flags_epoch(void) { return mv::g_flags_epoch; }
 int mv_get_flag(const char* name) { return name ? mv::get_flag(name) : 0; }
+
+int mv_set_scratch(void* ptr, size_t bytes, mv_stream_t stream) {
+    mv::g_scratch.ptr = bytes ? ptr : nullptr;
+    mv::g_scratch.bytes = bytes;
+    mv::g_scratch.stream = (hipStream_t)stream;
+    return MV_OK;
+}
+size_t mv_splitk_scratch_bytes(int64_t M, int64_t N, int64_t K_reduction) { return mv::splitk_scratch_bytes(M, N, K_reduction); }
 
 int mv_graph_begin_capture(mv_stream_t stream) {
     if (!mv::zero_page((hipStream_t)stream)) {  // must exist before capture (hipMalloc is illegal inside)

@@ -387,6 +387,8 @@ def conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) -> A
         # convolution on zero-padded filters and compact the rows afterwards instead of dropping to the VALU kernel
         return _conv2d_padded_k(x, conv, bn, act, (w, scale, shift), (B, H, W, C, Ho, Wo))
     y = empty((B, Ho, Wo, K), TORCH_DT[dt])
+    if conv.groups == 1 and dt == "bf16":
+        _splitk_scratch(B * Ho * Wo, K, kh * kw * C)
     _lib.call("mv_conv2d_nhwc_fwd", _ptr(x.t), _ptr(w), _ptr(scale), _ptr(shift), res_ptr(), _ptr(y),
               B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, conv.groups, ACT[act], DT[dt], DT[dt], stream_ptr())
     return Act(y, "map", x.batched)
@@ -633,6 +635,7 @@ def conv1x1_dual(x: Act, conv3, bn3, xin: Act, ds_conv, ds_bn, act="relu") -> Op
         return None
     wcat, shift = _dual_weights(conv3, bn3, ds_conv, ds_bn)
     y = empty((B, Ho, Wo, K), torch.bfloat16)
+    _splitk_scratch(B * Ho * Wo, K, C1 + C2)
     _lib.call("mv_conv1x1_dual_fwd", _ptr(x.t), _ptr(xin.t), _ptr(wcat), None, _ptr(shift), _ptr(y), B, Ho, Wo, C1, H2, W2, C2,
               sd[0], K, ACT[act], DT[dt], stream_ptr())
     return Act(y, "map", x.batched)
@@ -732,6 +735,8 @@ def linear(x: Act, lin, act=None, residual: Optional[Act] = None, out_fp32: bool
         _lib.call("mv_fc_stream_fwd", _ptr(x.t), _ptr(wf), _ptr(b), _ptr(y), _ptr(ws), nbytes, M, N, K, ACT[act], DT[dt], odc, stream_ptr())
         return Act(y, x.kind, x.batched)
     w, b = prep_linear(lin, dt)
+    if dt == "bf16":
+        _splitk_scratch(M, N, K)
     _lib.call("mv_linear_fwd", _ptr(x.t), _ptr(w), None, _ptr(b), _ptr(res), _ptr(y), M, N, K, ACT[act],
               DT[dt], odc, stream_ptr())
     return Act(y, x.kind, x.batched)
@@ -753,6 +758,30 @@ def _fc_workspace(nbytes: int) -> torch.Tensor:
         ws = torch.empty(((nbytes + 3) // 4,), dtype=torch.float32, device=device())
         _FC_WS[key] = ws
     return ws
+
+
+_SPLITK_WS = {}
+
+
+def _splitk_scratch(M: int, N: int, kred: int):
+    """Hand the next launch on this stream room for split-K partial sums (include/eqxvision_amd.h: mv_set_scratch) when its shape
+    is one the library would split: [M] x [N] output, `kred` reduction elements.  Same ownership rule as `_fc_workspace`: while
+    a forward is being recorded every launch keeps its own (lanes become parallel graph branches), an eager call shares one per
+    stream.  The first 4096 bytes (the tiles' arrival words) are zeroed once; the kernel leaves them zero."""
+    nbytes = int(_lib.load().mv_splitk_scratch_bytes(M, N, kred))
+    if not nbytes:
+        return
+    from . import _act
+    if getattr(_act._tls, "keep", None) is not None:
+        ws = empty((nbytes,), torch.uint8)
+        ws[:4096].zero_()
+    else:
+        key = (stream_ptr(), torch.cuda.current_device())
+        ws = _SPLITK_WS.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.zeros((nbytes,), dtype=torch.uint8, device=device())
+            _SPLITK_WS[key] = ws
+    _lib.call("mv_set_scratch", _ptr(ws), nbytes, stream_ptr())
 
 
 def fc_fragments(lin) -> torch.Tensor:
@@ -801,6 +830,7 @@ def linear_split(x: Act, lin, out_fp32: bool = False) -> Act:
         return linear(x, lin, out_fp32=out_fp32)
     w, b = prep_linear_split(lin)
     y = empty(tuple(x.t.shape[:-1]) + (N,), torch.float32 if out_fp32 else TORCH_DT[dt])
+    _splitk_scratch(M, N, 2 * K)
     _lib.call("mv_linear_split_fwd", _ptr(x.t), _ptr(w), None, _ptr(b), None, _ptr(y), M, N, K, _lib.ACT_NONE, DT[dt],
               _lib.F32 if out_fp32 else DT[dt], stream_ptr())
     return Act(y, x.kind, x.batched)

@@ -287,6 +287,20 @@ int64_t mv_fc_stream_workspace(int64_t M, int N, int K);
 int mv_fc_stream_fwd(const void* x, const void* w_frag, const float* bias, void* y, void* workspace, int64_t workspace_bytes, int64_t M,
                      int N, int K, int act, int in_dtype, int out_dtype, mv_stream_t stream);
 
+/* Scratch memory for the NEXT launch this host thread issues on `stream`.  The library never allocates device memory; a Conv2d /
+ * Linear whose output has too few tiles to fill the 256 CUs and whose reduction is long (ResNet layer 4: resnet.py:144-162 at
+ * 7 x 7; Swin stage 3: swin.py:148-156, 280-300 at 49 tokens per image) is run as a two-way split over the reduction when the caller
+ * provides room for the fp32 partial sums: the two halves of a tile run on two CUs, the half that finishes second adds the other's
+ * partial tile to its own (a + b == b + a: the result does not depend on which one that is -- bit-reproducible) and runs the
+ * usual epilogue.  mv_splitk_scratch_bytes(M, N, K_reduction) = the bytes such a launch wants for an [M] x [N] output reduced over
+ * K_reduction = R * S * C (+ C2) elements, 0 when it would not split.  Protocol: the first 4096 bytes must be ZERO when the memory is
+ * first handed over (the kernel leaves them zero again); the memory must stay valid until the launch has completed on `stream`, and
+ * must not be shared with a launch that can run concurrently (another stream / another branch of a captured graph).  The hand-over
+ * is consumed by the launch that uses it; one that does not split ignores it; bytes = 0 / ptr = NULL withdraws it.  Without scratch
+ * every launch runs un-split (same entry points, same results to within fp32 summation order). */
+int mv_set_scratch(void* ptr, size_t bytes, mv_stream_t stream);
+size_t mv_splitk_scratch_bytes(int64_t M, int64_t N, int64_t K_reduction);
+
 /* jax.image.resize(x, shape, method="bilinear") for up-sampling (segmentation/_utils.py:52-58: logits -> input resolution;
  * deeplabv3.py:66-72: the pooled ASPP branch back to the feature size): half-pixel centres, out-of-range taps dropped and the
  * rest renormalised (== clamped taps for the 2-tap kernel).  x NHWC [N,h,w,C]; y NHWC [N,H,W,C] or, with out_nchw, NCHW

@@ -60,9 +60,32 @@ def _cmp(got, ref, tol):
 DT = {"bf16": 1, "fp32": 0}
 
 
+def _splitk_runs(L, launch, y, M, N, kred, info):
+    """Split-K protocol of include/eqxvision_amd.h (mv_set_scratch): the launch must take the scratch (kernel name ..._splitk), give
+    the same bits on every run (a + b == b + a; the arrival words are left zero), and stay within tolerance of the un-split result's
+    oracle (checked by the caller on the last run)."""
+    nb = int(L.load().mv_splitk_scratch_bytes(M, N, kred))
+    if not nb:
+        info.update(ok=False, err=f"mv_splitk_scratch_bytes({M}, {N}, {kred}) = 0: not a split shape")
+        return None
+    ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(4):
+        L.call("mv_set_scratch", ws.data_ptr(), nb, _stream())
+        launch()
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        outs.append(y.clone())
+    info["kernel"] = kern
+    info["splitk"] = kern.endswith("_splitk")
+    info["repeatable"] = all(torch.equal(outs[0], o) for o in outs[1:])
+    info["sync_clean"] = bool((ws[:4096] == 0).all().item())
+    return kern
+
+
 # --------------------------------------------------------------------------------------------
 def conv_nhwc_case(N, H, W, C, K, R, S, stride=1, pad=0, dil=1, groups=1, act=0, res=False, scale=True,
-                   dtype="bf16", out="same", generic=False, seed=0, tile=0, flags=()):
+                   dtype="bf16", out="same", generic=False, seed=0, tile=0, flags=(), splitk=False):
     def run():
         L = _lib()
         rng = _rng(seed)
@@ -98,11 +121,19 @@ def conv_nhwc_case(N, H, W, C, K, R, S, stride=1, pad=0, dil=1, groups=1, act=0,
         L.set_flag("igemm_tile", tile)
         for f in flags:
             L.set_flag(f.split("=")[0], int(f.split("=")[1]) if "=" in f else 1)
+        extra = {}
         try:
-            L.call("mv_conv2d_nhwc_fwd", xd.data_ptr(), wd.data_ptr(), None if scd is None else scd.data_ptr(),
-                   sfd.data_ptr(), None if rd is None else rd.data_ptr(), y.data_ptr(),
-                   N, H, W, C, K, R, S, stride, stride, pad, pad, dil, dil, groups, act, DT[dtype], DT[odt], _stream())
-            kern = L.last_kernel()
+            def launch():
+                L.call("mv_conv2d_nhwc_fwd", xd.data_ptr(), wd.data_ptr(), None if scd is None else scd.data_ptr(),
+                       sfd.data_ptr(), None if rd is None else rd.data_ptr(), y.data_ptr(),
+                       N, H, W, C, K, R, S, stride, stride, pad, pad, dil, dil, groups, act, DT[dtype], DT[odt], _stream())
+            if splitk:
+                kern = _splitk_runs(L, launch, y, N * Ho * Wo, K, R * S * C, extra)
+                if kern is None:
+                    return extra
+            else:
+                launch()
+                kern = L.last_kernel()
         finally:
             L.set_flag("force_generic", 0)
             L.set_flag("igemm_tile", 0)
@@ -112,6 +143,9 @@ def conv_nhwc_case(N, H, W, C, K, R, S, stride=1, pad=0, dil=1, groups=1, act=0,
         got = host(y).transpose(0, 3, 1, 2)
         info = _cmp(got, ref, TOL_BF16 if odt == "bf16" else TOL_F32)
         info["kernel"] = kern
+        info.update(extra)
+        if splitk:
+            info["ok"] = info["ok"] and extra["splitk"] and extra["repeatable"] and extra["sync_clean"]
         return info
     return run
 
@@ -512,7 +546,7 @@ def dual_chain_case(M, seed=0):
     return run
 
 
-def dual_case(N, Ho, Wo, C1, C2, K, stride, act=1, seed=0, flags=()):
+def dual_case(N, Ho, Wo, C1, C2, K, stride, act=1, seed=0, flags=(), splitk=False):
     """mv_conv1x1_dual_fwd: a dense pointwise layer on x and a strided pointwise layer on x2 accumulated in one GEMM
     (scales folded into the weight rows) vs the oracle's two convolutions with fp32 scales (resnet.py:144-162, 295-303)."""
     def run():
@@ -539,16 +573,27 @@ def dual_case(N, Ho, Wo, C1, C2, K, stride, act=1, seed=0, flags=()):
         y = torch.full((M, K), -7.0, dtype=torch.bfloat16, device="cuda")
         for f in flags:
             L.set_flag(f.split("=")[0], int(f.split("=")[1]) if "=" in f else 1)
+        extra = {}
         try:
-            L.call("mv_conv1x1_dual_fwd", xd.data_ptr(), x2d.data_ptr(), wd_.data_ptr(), None, hd.data_ptr(), y.data_ptr(), N, Ho,
-                   Wo, C1, H2, W2, C2, stride, K, act, 1, _stream())
-            kern = L.last_kernel()
+            def launch():
+                L.call("mv_conv1x1_dual_fwd", xd.data_ptr(), x2d.data_ptr(), wd_.data_ptr(), None, hd.data_ptr(), y.data_ptr(), N, Ho,
+                       Wo, C1, H2, W2, C2, stride, K, act, 1, _stream())
+            if splitk:
+                kern = _splitk_runs(L, launch, y, M, K, C1 + C2, extra)
+                if kern is None:
+                    return extra
+            else:
+                launch()
+                kern = L.last_kernel()
         finally:
             for f in flags:
                 L.set_flag(f.split("=")[0], 0)
         torch.cuda.synchronize()
         info = _cmp(host(y), ref, TOL_BF16)
         info["kernel"] = kern
+        info.update(extra)
+        if splitk:
+            info["ok"] = info["ok"] and extra["splitk"] and extra["repeatable"] and extra["sync_clean"]
         return info
     return run
 
@@ -614,7 +659,7 @@ def conv_nchw_case(N, C, H, W, K, R, S, stride, pad, act=0, xdtype="fp32", token
     return run
 
 
-def linear_case(M, K, N, act=0, res=False, dtype="bf16", out="same", generic=False, seed=0, tile=0, flags=()):
+def linear_case(M, K, N, act=0, res=False, dtype="bf16", out="same", generic=False, seed=0, tile=0, flags=(), splitk=False):
     def run():
         L = _lib()
         rng = _rng(seed)
@@ -639,10 +684,18 @@ def linear_case(M, K, N, act=0, res=False, dtype="bf16", out="same", generic=Fal
         L.set_flag("igemm_tile", tile)
         for f in flags:
             L.set_flag(f.split("=")[0], int(f.split("=")[1]) if "=" in f else 1)
+        extra = {}
         try:
-            L.call("mv_linear_fwd", xd.data_ptr(), wd.data_ptr(), None, bd.data_ptr(),
-                   None if rd is None else rd.data_ptr(), y.data_ptr(), M, N, K, act, DT[dtype], DT[odt], _stream())
-            kern = L.last_kernel()
+            def launch():
+                L.call("mv_linear_fwd", xd.data_ptr(), wd.data_ptr(), None, bd.data_ptr(),
+                       None if rd is None else rd.data_ptr(), y.data_ptr(), M, N, K, act, DT[dtype], DT[odt], _stream())
+            if splitk:
+                kern = _splitk_runs(L, launch, y, M, N, K, extra)
+                if kern is None:
+                    return extra
+            else:
+                launch()
+                kern = L.last_kernel()
         finally:
             L.set_flag("force_generic", 0)
             L.set_flag("igemm_tile", 0)
@@ -651,6 +704,9 @@ def linear_case(M, K, N, act=0, res=False, dtype="bf16", out="same", generic=Fal
         torch.cuda.synchronize()
         info = _cmp(host(y), ref, TOL_BF16 if odt == "bf16" else TOL_F32)
         info["kernel"] = kern
+        info.update(extra)
+        if splitk:
+            info["ok"] = info["ok"] and extra["splitk"] and extra["repeatable"] and extra["sync_clean"]
         return info
     return run
 
@@ -676,7 +732,7 @@ def linear_f32_head_case(M, K, N, seed=0):
     return run
 
 
-def linear_split_case(M, K, N, out="fp32", seed=0):
+def linear_split_case(M, K, N, out="fp32", seed=0, splitk=False):
     """mv_linear_split_fwd: x (bf16) . (w_hi + w_lo)^T with fp32 accumulation vs float64 on the UN-rounded fp32 weights:
     the error must be far below what bf16 weights alone would give."""
     def run():
@@ -695,12 +751,23 @@ def linear_split_case(M, K, N, out="fp32", seed=0):
         xd, bd = dev(x, "bf16"), dev(b, "fp32")
         odt = torch.float32 if out == "fp32" else torch.bfloat16
         y = torch.empty((M, N), dtype=odt, device="cuda")
-        L.call("mv_linear_split_fwd", xd.data_ptr(), wd.data_ptr(), None, bd.data_ptr(), None, y.data_ptr(), M, N, K, 0, 1,
-               0 if out == "fp32" else 1, _stream())
-        kern = L.last_kernel()
+        def launch():
+            L.call("mv_linear_split_fwd", xd.data_ptr(), wd.data_ptr(), None, bd.data_ptr(), None, y.data_ptr(), M, N, K, 0, 1,
+                   0 if out == "fp32" else 1, _stream())
+        extra = {}
+        if splitk:
+            kern = _splitk_runs(L, launch, y, M, N, 2 * K, extra)
+            if kern is None:
+                return extra
+        else:
+            launch()
+            kern = L.last_kernel()
         torch.cuda.synchronize()
         info = _cmp(host(y), ref, 2e-4 if out == "fp32" else TOL_BF16)
         info["kernel"] = kern
+        info.update(extra)
+        if splitk:
+            info["ok"] = info["ok"] and extra["splitk"] and extra["repeatable"] and extra["sync_clean"]
         info["err_if_bf16_weights"] = float(np.abs(ref_bf16w - ref).max())
         return info
     return run
@@ -1981,6 +2048,17 @@ def all_cases():
           ("igemm8/dual_layer4_entry_ragged", dual_case(86, 7, 7, 512, 1024, 2048, 2, seed=276, flags=("igemm8=2",))),
           ("igemm8/dual_s1_64_64_K200_noact", dual_case(3, 37, 41, 64, 64, 200, 1, act=0, seed=277, flags=("igemm8=2",))),
           ("igemm8/qkv_heads_vit_base", qkv_heads_case(32, 197, 12, 64, seed=278, flags=("igemm8=2",))),
+          # two-way split-K of the half-size tiles (mv_set_scratch): taken, repeatable bit for bit, arrival words left zero
+          ("splitk/3x3_7x7_512_res", conv_nhwc_case(64, 7, 7, 512, 512, 3, 3, pad=1, act=1, res=True, seed=601, splitk=True)),
+          ("splitk/1x1_2048_512_dense", conv_nhwc_case(64, 7, 7, 2048, 512, 1, 1, act=1, seed=602, splitk=True, flags=("splitk_min_nk=12",))),
+          ("splitk/3x3_s2_14_512", conv_nhwc_case(64, 14, 14, 512, 512, 3, 3, stride=2, pad=1, act=1, seed=603, splitk=True)),
+          ("splitk/256x128_3x3_256_128", conv_nhwc_case(8, 56, 56, 256, 128, 3, 3, pad=1, act=1, seed=604, splitk=True, flags=("splitk_min_nk=12",))),
+          ("splitk/linear_swin_fc2_f32res", linear_case(3136, 3072, 768, res=True, out="fp32", seed=605, splitk=True)),
+          ("splitk/linear_proj_nk12_ragged_M", linear_case(3000, 768, 768, res=True, out="fp32", seed=606, splitk=True, flags=("splitk_min_nk=12",))),
+          ("splitk/linear_odd_nk13_gelu", linear_case(3136, 832, 512, act=2, seed=607, splitk=True, flags=("splitk_min_nk=12",))),
+          ("splitk/dual_second_half_in_source2", dual_case(96, 7, 7, 512, 1024, 512, 2, seed=608, splitk=True, flags=("splitk_min_nk=12",))),
+          ("splitk/dual_crossing_inside_half", dual_case(96, 7, 7, 1024, 512, 512, 2, seed=609, splitk=True, flags=("splitk_min_nk=12",))),
+          ("splitk/linear_split_swin_merge", linear_split_case(3136, 1536, 768, seed=610, splitk=True)),
           ("igemm8s/128x256_1x1_512_256", conv_nhwc_case(8, 28, 28, 512, 256, 1, 1, act=1, seed=361, flags=("igemm8=3",))),
           ("igemm8s/128x256_3x3_128_256", conv_nhwc_case(8, 28, 28, 128, 256, 3, 3, pad=1, act=1, seed=362, flags=("igemm8=3",))),
           ("igemm8s/128x256_3x3_s2_K320", conv_nhwc_case(9, 33, 35, 128, 320, 3, 3, stride=2, pad=1, seed=363, flags=("igemm8=3",))),
