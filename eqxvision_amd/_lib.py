@@ -72,7 +72,7 @@ PROTOTYPES = {
     "mv_conv2d_nchw_f32out_fwd": [_vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_i, _i, _i, _i, _vp, _vp],
     "mv_fc_stream_supported": [_i64, _i, _i, _i, _i],
     "mv_fc_stream_workspace": [_i64, _i, _i],
-    "mv_set_scratch": [_vp, C.c_size_t, _vp],
+    "mv_set_scratch": [_vp, _i64, _vp],
     "mv_splitk_scratch_bytes": [_i64, _i64, _i64],
     "mv_fc_stream_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp],
     "mv_ln_mlp_stream_supported": [_i64, _i, _i, _i],
@@ -140,7 +140,7 @@ PROTOTYPES = {
     "mv_event_destroy": [_vp],
 }
 _RESTYPES = {"mv_last_error": C.c_char_p, "mv_last_kernel": C.c_char_p, "mv_fc_stream_workspace": _i64,
-             "mv_splitk_scratch_bytes": C.c_size_t}
+             "mv_splitk_scratch_bytes": _i64}
 
 _lib = None
 _lock = threading.Lock()

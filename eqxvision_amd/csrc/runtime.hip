@@ -86,13 +86,13 @@ int mv_set_flag(const char* name, int value) {
 int mv_flags_epoch(void) { return mv::g_flags_epoch; }
 int mv_get_flag(const char* name) { return name ? mv::get_flag(name) : 0; }
 
-int mv_set_scratch(void* ptr, size_t bytes, mv_stream_t stream) {
-    mv::g_scratch.ptr = bytes ? ptr : nullptr;
-    mv::g_scratch.bytes = bytes;
+int mv_set_scratch(void* ptr, int64_t bytes, mv_stream_t stream) {
+    mv::g_scratch.ptr = bytes > 0 ? ptr : nullptr;
+    mv::g_scratch.bytes = bytes > 0 ? (size_t)bytes : 0;
     mv::g_scratch.stream = (hipStream_t)stream;
     return MV_OK;
 }
-size_t mv_splitk_scratch_bytes(int64_t M, int64_t N, int64_t K_reduction) { return mv::splitk_scratch_bytes(M, N, K_reduction); }
+int64_t mv_splitk_scratch_bytes(int64_t M, int64_t N, int64_t K_reduction) { return (int64_t)mv::splitk_scratch_bytes(M, N, K_reduction); }
 
 int mv_graph_begin_capture(mv_stream_t stream) {
     if (!mv::zero_page((hipStream_t)stream)) {  // must exist before capture (hipMalloc is illegal inside)

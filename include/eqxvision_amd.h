@@ -298,8 +298,8 @@ int mv_fc_stream_fwd(const void* x, const void* w_frag, const float* bias, void*
  * must not be shared with a launch that can run concurrently (another stream / another branch of a captured graph).  The hand-over
  * is consumed by the launch that uses it; one that does not split ignores it; bytes = 0 / ptr = NULL withdraws it.  Without scratch
  * every launch runs un-split (same entry points, same results to within fp32 summation order). */
-int mv_set_scratch(void* ptr, size_t bytes, mv_stream_t stream);
-size_t mv_splitk_scratch_bytes(int64_t M, int64_t N, int64_t K_reduction);
+int mv_set_scratch(void* ptr, int64_t bytes, mv_stream_t stream);
+int64_t mv_splitk_scratch_bytes(int64_t M, int64_t N, int64_t K_reduction);
 
 /* jax.image.resize(x, shape, method="bilinear") for up-sampling (segmentation/_utils.py:52-58: logits -> input resolution;
  * deeplabv3.py:66-72: the pooled ASPP branch back to the feature size): half-pixel centres, out-of-range taps dropped and the
