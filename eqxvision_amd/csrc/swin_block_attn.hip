@@ -384,6 +384,290 @@ __global__ __launch_bounds__(NWV * 64) void swin_block_attn_kernel(const SwinBAP
 #undef MV_SBA_STAMP
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// C = 96 (stage 0: 3 heads, 64 windows per image): one workgroup = ONE window = two waves, and a wave OWNS a block of 32 tokens from
+// the gather to the store -- the 8-wave kernel above spends 22 of its 24 us per workgroup in dependent latencies (gather -> LDS ->
+// barrier, 8 barriers, a proj GEMM phase, an fp32 staging tile, a residual re-read) around 1.5 us of matrix work:
+//   * a lane loads its token's row straight into the B-fragment layout (lane (fr, fh): channels 16 j + 8 fh .. + 7 of token fr, as
+//     ln_mlp.hip); LayerNorm statistics are one lane^32 exchange; the normalised rows never touch LDS;
+//   * the fp32 row it just read IS the residual: one v_permlane32_swap per register pair puts it in the accumulator layout, where it
+//     seeds the proj accumulators -- no re-read in the epilogue (PMC of the 8-wave kernel: 115 MB read for 77 MB of rows);
+//   * q | k | v of ALL three heads in one pass (9 tiles x 6 k-steps, weight fragments from L2 seven ahead); q stays in registers (its
+//     accumulator layout is a valid B operand of S^T = K . Q^T once K is stored in the same channel order), k and v^T go to LDS:
+//     29 KB per window, ONE barrier per workgroup;
+//   * per head: S^T, bias + mask + softmax in registers, P . V, and the head's slice of proj straight from the P . V accumulators
+//     (y^T += Wp[:, head] . o^T; the proj fragments arrive in the standard order and are re-ordered to the accumulator's channel
+//     order by two half-wave swaps each) -- the attention output never exists in memory;
+//   * stores from the accumulator layout (16 bytes per lane, the row pair fh = 0 / 1 covers 32 contiguous bytes).
+template <int UNUSED>
+__global__ __launch_bounds__(128, 3) void swin_win96_kernel(const SwinBAP p) {
+    constexpr int C = 96, KS = 6, NH = 3, NTOK = 49, WS = 7, QROW = 80, VROW = 144;
+    constexpr int LDS_K = 0, LDS_V = NH * 64 * QROW, LDS_REG = LDS_V + NH * 32 * VROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);              // = token block of the window
+    const int fr = lane & 31, fh = lane >> 5;
+    const int b = blockIdx.x / p.nW, wloc = blockIdx.x - b * p.nW;
+#ifdef MV_I8_PROF
+    long long st_w[8];
+    int nst = 0;
+#define MV_W96_STAMP() do { if (p.prof && nst < 8) st_w[nst++] = wall_clock64(); } while (0)
+#else
+#define MV_W96_STAMP() do { } while (0)
+#endif
+    MV_W96_STAMP();                                       // 0: start
+    const int wy = wloc / p.nWw, wx = wloc - wy * p.nWw;
+    const bool shifted = (p.shh + p.shw) > 0;
+    const int tok = 32 * wave + fr;
+    const bool real = tok < NTOK;
+    long long row;
+    {
+        const int t = real ? tok : 0;
+        const int ty = t / WS, tx = t - ty * WS;
+        int oy = wy * WS + ty + p.shh, ox = wx * WS + tx + p.shw;
+        if (oy >= p.Hf) oy -= p.Hf;
+        if (ox >= p.Wf) ox -= p.Wf;
+        row = (((long long)b * p.Hf + oy) * p.Wf + ox) * C;
+    }
+    // ---- the first weight tile is on its way before anything else
+    const uint4* wq = (const uint4*)p.wqkv + lane;                       // [head][q | k | v][k-step][lane]
+    constexpr int NF = 3 * NH * KS, RING = 8, LOOK = 7;                 // 54 fragments of 1 KB, 7 in flight
+    uint4 wb[RING];
+#pragma unroll
+    for (int i = 0; i < LOOK; ++i) wb[i] = wq[i * 64];
+
+    // ---- gather + LayerNorm: B fragments of the qkv GEMM, and the residual in accumulator layout
+    float raw[KS][8];
+    {
+        const float* src = p.x + row + 8 * fh;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const float4 a = *(const float4*)(src + 16 * j), c = *(const float4*)(src + 16 * j + 4);
+            raw[j][0] = a.x; raw[j][1] = a.y; raw[j][2] = a.z; raw[j][3] = a.w;
+            raw[j][4] = c.x; raw[j][5] = c.y; raw[j][6] = c.z; raw[j][7] = c.w;
+        }
+    }
+    if (tid < 64) {                                      // shift-mask region of every token (rolled coordinates, swin.py:190-209)
+        const int t = tid < NTOK ? tid : NTOK - 1;
+        const int ty = t / WS, tx = t - ty * WS;
+        const int yy = wy * WS + ty, xx = wx * WS + tx;
+        const int rh = (yy < p.Hf - WS) ? 0 : (yy < p.Hf - p.shh ? 1 : 2);
+        const int rw = (xx < p.Wf - WS) ? 0 : (xx < p.Wf - p.shw ? 1 : 2);
+        ((int*)(smem + LDS_REG))[tid] = shifted ? rh * 3 + rw : 0;
+    }
+    uint4 xf[KS];
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += raw[j][e];
+        s += __shfl_xor(s, 32);
+        const float mean = s * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = raw[j][e] - mean;
+                q = fmaf(d, d, q);
+            }
+        q += __shfl_xor(q, 32);
+        const float rstd = real ? rsqrtf(q * (1.0f / C) + p.eps) : 0.f;                 // padded tokens: zero rows
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            xf[j].x = pack_bf2((raw[j][0] - mean) * rstd, (raw[j][1] - mean) * rstd);
+            xf[j].y = pack_bf2((raw[j][2] - mean) * rstd, (raw[j][3] - mean) * rstd);
+            xf[j].z = pack_bf2((raw[j][4] - mean) * rstd, (raw[j][5] - mean) * rstd);
+            xf[j].w = pack_bf2((raw[j][6] - mean) * rstd, (raw[j][7] - mean) * rstd);
+        }
+    }
+    // yacc[ct][4 g + i] = y^T[32 ct + 8 g + 4 fh + i][my token], seeded with the residual: the lane holds channels 16 j + 8 fh + 0..7;
+    // after the swap the first register of a pair is group g' = 2 j, the second g' = 2 j + 1 (g' = 4 ct + g), on both halves
+    f32x16 yacc[3];
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(raw[j][e]), __float_as_uint(raw[j][e + 4]), false, false);
+            const int ga = 2 * j, gb = 2 * j + 1;
+            yacc[ga >> 2][4 * (ga & 3) + e] = __uint_as_float(sw[0]);
+            yacc[gb >> 2][4 * (gb & 3) + e] = __uint_as_float(sw[1]);
+        }
+
+    MV_W96_STAMP();                                       // 1: gather + LayerNorm + residual seed
+    // ---- q | k | v of the three heads: tile u = 3 head + kind; a ring of 8 weight fragments, 7 loads in flight
+    uint4 qf[NH][2];
+#pragma unroll
+    for (int u = 0; u < 3 * NH; ++u) {
+        const int h = u / 3, kind = u - 3 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const int i = u * KS + j;
+            const uint4 a = wb[i % RING];
+            if (i + LOOK < NF) wb[(i + LOOK) % RING] = wq[(i + LOOK) * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, xf[j]), acc, 0, 0, 0);
+        }
+        const float* bb = p.bqkv + u * 32 + 4 * fh;
+        float v[16];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 bv = *(const float4*)(bb + 8 * gq);
+            v[4 * gq + 0] = acc[4 * gq + 0] + bv.x; v[4 * gq + 1] = acc[4 * gq + 1] + bv.y;
+            v[4 * gq + 2] = acc[4 * gq + 2] + bv.z; v[4 * gq + 3] = acc[4 * gq + 3] + bv.w;
+        }
+        if (kind < 2) {
+            // head channels in accumulator order: k-step j of a lane = channels 8 (2 j + (e >> 2)) + 4 fh + (e & 3) -- the same on the
+            // q side (registers) and the k side (LDS row of the token, 16 bytes at (2 fh + j) * 16), so S^T = K . Q^T is exact
+            uint4 pk[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                pk[j].x = pack_bf2(v[8 * j + 0], v[8 * j + 1]); pk[j].y = pack_bf2(v[8 * j + 2], v[8 * j + 3]);
+                pk[j].z = pack_bf2(v[8 * j + 4], v[8 * j + 5]); pk[j].w = pack_bf2(v[8 * j + 6], v[8 * j + 7]);
+            }
+            if (kind == 0) { qf[h][0] = pk[0]; qf[h][1] = pk[1]; }
+            else {
+                char* dst = smem + LDS_K + (h * 64 + tok) * QROW + fh * 32;
+                *(uint4*)dst = pk[0];
+                *(uint4*)(dst + 16) = pk[1];
+            }
+        } else {
+            // v^T[dh][slot(key)]: the 8 keys a lane feeds to one P.V step sit next to each other (same order as the 8-wave kernel)
+            const int kg = fr >> 3, khh = (fr >> 2) & 1, kr = fr & 3;
+            const int slot = ((wave * 2 + (kg >> 1)) * 2 + khh) * 8 + (kg & 1) * 4 + kr;
+            char* dst = smem + LDS_V + h * 32 * VROW + slot * 2;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) *(bf16_t*)(dst + (8 * gq + 4 * fh + e) * VROW) = f2bf(v[4 * gq + e]);
+        }
+    }
+    MV_W96_STAMP();                                       // 2: qkv of three heads + k / v stores
+    __syncthreads();
+    MV_W96_STAMP();                                       // 3: barrier
+
+    // ---- attention + the head's slice of proj
+    const int* rl = (const int*)(smem + LDS_REG);
+    const int qreg = rl[tok];
+    const float scale = rsqrtf(32.0f);
+    const uint4* wpq = (const uint4*)p.wp + lane;                        // [channel tile][k-step 0..5][lane]: k-steps 2 h, 2 h + 1 = head h
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        uint4 wpf[3][2];
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wpf[ct][j] = wpq[(ct * KS + 2 * h + j) * 64];
+        const char* kp = smem + LDS_K + (h * 64 + fr) * QROW + fh * 32;
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 kf = *(const bf16x8*)(kp + kt * 32 * QROW + j * 16);
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8, qf[h][j]), s[kt], 0, 0, 0);
+            }
+        }
+        const float* brow = p.bias + ((size_t)h * 64 + tok) * 64;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int key0 = 32 * kt + 8 * gq + 4 * fh;
+                const float4 bv = *(const float4*)(brow + key0);
+                const int4 kr = *(const int4*)(rl + key0);
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                const int rr[4] = {kr.x, kr.y, kr.z, kr.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fmaf(s[kt][4 * gq + e], scale, bb[e]);
+                    if (rr[e] != qreg) v += -100.0f;
+                    s[kt][4 * gq + e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pe = __expf(s[kt][e] - mx);
+                s[kt][e] = pe;
+                sum += pe;
+            }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.f / sum;
+        f32x16 o;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+        const char* vp = smem + LDS_V + (h * 32 + fr) * VROW + fh * 16;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                uint4 pf;
+                pf.x = pack_bf2(s[kt][8 * gp + 0], s[kt][8 * gp + 1]);
+                pf.y = pack_bf2(s[kt][8 * gp + 2], s[kt][8 * gp + 3]);
+                pf.z = pack_bf2(s[kt][8 * gp + 4], s[kt][8 * gp + 5]);
+                pf.w = pack_bf2(s[kt][8 * gp + 6], s[kt][8 * gp + 7]);
+                const bf16x8 vf = *(const bf16x8*)(vp + (kt * 2 + gp) * 32);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pf), o, 0, 0, 0);
+            }
+        // o[4 gq + i] = out[my token][32 h + 8 gq + 4 fh + i]: k-step j of proj = registers 8 j .. 8 j + 7.  The standard proj fragment
+        // of a lane holds input channels 16 jj + 8 fh + 0..7; the accumulator order wants {0..3, 8..11} below and {4..7, 12..15} above
+        uint4 of[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            of[j].x = pack_bf2(o[8 * j + 0] * inv, o[8 * j + 1] * inv); of[j].y = pack_bf2(o[8 * j + 2] * inv, o[8 * j + 3] * inv);
+            of[j].z = pack_bf2(o[8 * j + 4] * inv, o[8 * j + 5] * inv); of[j].w = pack_bf2(o[8 * j + 6] * inv, o[8 * j + 7] * inv);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint4 a = wpf[ct][j];
+                const auto s0 = __builtin_amdgcn_permlane32_swap(a.x, a.z, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(a.y, a.w, false, false);
+                a.x = s0[0]; a.z = s0[1]; a.y = s1[0]; a.w = s1[1];
+                yacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, of[j]), yacc[ct], 0, 0, 0);
+            }
+        MV_W96_STAMP();                                   // 4, 5, 6: head h (attention + proj slice)
+    }
+    // ---- epilogue: + proj bias, to the token's own position (window reverse + roll back = where it was gathered from)
+    if (real) {
+        float* yr = p.y + row + 4 * fh;
+        const float* bp = p.bp + 4 * fh;
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *(const float4*)(bp + 32 * ct + 8 * g);
+                *(float4*)(yr + 32 * ct + 8 * g) = make_float4(yacc[ct][4 * g + 0] + bv.x, yacc[ct][4 * g + 1] + bv.y,
+                                                                yacc[ct][4 * g + 2] + bv.z, yacc[ct][4 * g + 3] + bv.w);
+            }
+    }
+#ifdef MV_I8_PROF
+    if (p.prof) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const long long tend = wall_clock64();
+        if (lane == 0) {
+            long long* o = p.prof + ((size_t)blockIdx.x * 2 + wave) * 9;
+            for (int i = 0; i < 7; ++i) o[i] = st_w[i];
+            o[7] = tend;
+        }
+    }
+#endif
+#undef MV_W96_STAMP
+}
+
 }  // namespace
 
 }  // namespace mv
@@ -438,7 +722,12 @@ int mv_swin_block_attn_fwd(const void* x, const void* wqkv_f, const float* bqkv,
     } while (0)
     if (C == 384) { set_kernel_name("swin_block_attn_c384"); MV_SBA_GO(384, 1, 8); }
     else if (C == 192) { set_kernel_name("swin_block_attn_c192"); MV_SBA_GO(192, 2, 8); }
-    else { set_kernel_name("swin_block_attn_c96"); MV_SBA_GO(96, 2, 4); }
+    else if (get_flag("swin_c96_shared")) { set_kernel_name("swin_block_attn_c96"); MV_SBA_GO(96, 2, 4); }
+    else {
+        set_kernel_name("swin_win96");
+        constexpr int LDS96 = 3 * 64 * 80 + 3 * 32 * 144 + 256;
+        hipLaunchKernelGGL(swin_win96_kernel<0>, dim3((unsigned)(B * p.nW)), dim3(128), LDS96, stream, p);
+    }
 #undef MV_SBA_GO
     MV_LAUNCH_CHECK();
     return MV_OK;

@@ -1637,7 +1637,7 @@ def patch_merge_ln_case(B, H, C, out="bf16", seed=0):
     return run
 
 
-def swin_block_attn_case(B, Hf, shift, seed=0, C=384, heads=12, ws=7):
+def swin_block_attn_case(B, Hf, shift, seed=0, C=384, heads=12, ws=7, flags=()):
     """mv_swin_block_attn_fwd (LayerNorm -> qkv -> shifted-window attention -> proj -> + x, one launch, one workgroup per window;
     swin.py:572-578 first line) vs the float64 restatement (LayerNorm, Linear, `_swin_core_ref`, Linear), and vs the library's own
     four-launch sequence (which must not be closer to the reference by more than rounding noise)."""
@@ -1666,9 +1666,15 @@ def swin_block_attn_case(B, Hf, shift, seed=0, C=384, heads=12, ws=7):
         xd = dev(x, "fp32")
         d = [dev(bf(wf), "bf16"), dev(bqf, "fp32"), dev(bf(wpf), "bf16"), dev(bp, "fp32"), dev(b64, "fp32")]
         y = torch.full_like(xd, -7.0)
-        L.call("mv_swin_block_attn_fwd", xd.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
-               y.data_ptr(), B, Hf, Hf, C, heads, ws, ws, shift, shift, 1e-5, 0, _stream())
-        kern = L.last_kernel()
+        for f in flags:
+            L.set_flag(f, 1)
+        try:
+            L.call("mv_swin_block_attn_fwd", xd.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                   y.data_ptr(), B, Hf, Hf, C, heads, ws, ws, shift, shift, 1e-5, 0, _stream())
+            kern = L.last_kernel()
+        finally:
+            for f in flags:
+                L.set_flag(f, 0)
         torch.cuda.synchronize()
         info = _cmp(host(y), ref, TOL_BF16)
         info["kernel"] = kern
@@ -2198,6 +2204,7 @@ def all_cases():
           ("swin_block_attn/c96_56x56_B1_noshift", swin_block_attn_case(1, 56, 0, seed=536, C=96, heads=3)),
           ("swin_block_attn/c96_56x56_B2_shift3", swin_block_attn_case(2, 56, 3, seed=537, C=96, heads=3)),
           ("swin_block_attn/c96_14x14_B3_shift3", swin_block_attn_case(3, 14, 3, seed=538, C=96, heads=3)),
+          ("swin_block_attn/c96_56x56_B2_shift3_shared_kernel", swin_block_attn_case(2, 56, 3, seed=539, C=96, heads=3, flags=("swin_c96_shared",))),
           ("ln_mlp/stream_c384_swin_stage2_B8", ln_mlp_case(8 * 14 * 14, "fp32", seed=523, C=384, Hd=1536)),
           ("ln_mlp/stream_c384_ragged", ln_mlp_case(64 * 9 + 37, "fp32", seed=524, C=384, Hd=1536)),
           ("ln_mlp/stream_c384_many_tiles", ln_mlp_case(64 * 300 + 5, "fp32", seed=525, C=384, Hd=1536)),

@@ -7,6 +7,8 @@ from eqxvision_amd import _lib as L
 from eqxvision_amd.ops import swin_block_attn_fragments
 C = int(os.environ.get("SBA_C", "384")); heads = C // 32; Hf = {384: 14, 192: 28, 96: 56}[C]; ws, shift = 7, 3
 s = torch.cuda.current_stream().cuda_stream
+for _f in [a for a in os.environ.get("FLAGS", "").split(",") if a]:
+    L.set_flag(_f.split("=")[0], int(_f.split("=")[1]) if "=" in _f else 1)
 
 def t(fn, n=30):
     for _ in range(3): fn()
@@ -48,6 +50,9 @@ for B in [int(a) for a in sys.argv[1:]] or [64, 128]:
 
     if os.environ.get("SBA_PROF"):
         nwin = {384: 1, 192: 2, 96: 2}[C]; nwv = 4 if C == 96 else 8
+        new96 = C == 96 and not L.get_flag("swin_c96_shared")            # swin_win96_kernel: one window, two waves, its own stamp list
+        if new96:
+            nwin, nwv = 1, 2
         nwg = B * (Hf // 7) ** 2 // nwin
         prof = torch.zeros(nwg * nwv * 9, dtype=torch.int64, device="cuda")
         pp = prof.data_ptr(); lo = pp & 0xffffffff
@@ -57,6 +62,18 @@ for B in [int(a) for a in sys.argv[1:]] or [64, 128]:
         L.set_flag("sba_prof", 0); L.set_flag("prof_lo", 0); L.set_flag("prof_hi", 0)
         a = prof.cpu().numpy().reshape(nwg, nwv, 9).astype(np.float64) / 100.0
         t0 = a[:, :, 0].min()
+        if new96:
+            a = a[:, :, :8]
+            t0 = a[:, :, 0].min()
+            names = ["gather + LayerNorm + residual seed", "q | k | v of 3 heads + k / v stores", "barrier", "head 0: attention + proj slice", "head 1", "head 2",
+                     "epilogue stores (drained)"]
+            print(f"  kernel span {a[:, :, 7].max() - t0:.1f} us; {nwg} workgroups; start times: median {np.median(a[:, 0, 0]) - t0:.1f} us, last {a[:, 0, 0].max() - t0:.1f} us; per-wave mean (min..max) us")
+            for i, nm in enumerate(names):
+                d = a[:, :, i + 1] - a[:, :, i]
+                print(f"    {nm:36s} {d.mean():7.2f} ({d.min():6.2f} .. {d.max():6.2f})")
+            d = a[:, :, 7] - a[:, :, 0]
+            print(f"    {'workgroup total':36s} {d.mean():7.2f} ({d.min():6.2f} .. {d.max():6.2f})")
+            continue
         names = ["gather + LayerNorm + barrier", "qkv GEMM (group 0)", "q/k/v stores + barrier", "attention (group 0)", "barrier", "groups 1, 2", "proj + staging + barrier", "epilogue"]
         print(f"  kernel span {a[:, :, 8].max() - t0:.1f} us; {nwg} workgroups; start times: median {np.median(a[:, 0, 0]) - t0:.1f} us, last {a[:, 0, 0].max() - t0:.1f} us; per-wave mean (min..max) us")
         for i, nm in enumerate(names):
