@@ -226,6 +226,14 @@ def launch_meta(name, args):
     return flops, byts, shape
 
 
+def _symbol_name(kern, shape):
+    """One table name per kernel SYMBOL (so a rocprofv3 row and a bench row are the same launches): a split-K launch runs the same
+    igemm8s_kernel instance as the un-split one -- the suffix moves into the shape column."""
+    if kern.endswith("_splitk"):
+        return kern[:-7], shape + " split-K"
+    return kern, shape
+
+
 def layer_table(compiled, path, steps=5):
     """Replay the recorded launch list call by call with HIP events -> per-launch worksheet (every launch ALONE on the chip)."""
     from eqxvision_amd import _lib
@@ -246,6 +254,7 @@ def layer_table(compiled, path, steps=5):
             ts.append(ms.value)
         us = 1e3 * float(np.median(ts))
         flops, byts, shape = launch_meta(name, args)
+        kern, shape = _symbol_name(kern, shape)
         rows.append({"call": name, "kernel": kern, "shape": shape, "us": round(us, 2),
                      "tflops": round(flops / us / 1e6, 1) if us else 0, "gbs": round(byts / us / 1e3, 1) if us else 0,
                      "gflop": round(flops / 1e9, 3), "mb": round(byts / 1e6, 2)})
@@ -313,6 +322,7 @@ def insitu_rows(compiled, steps=6, only=None):
         for i, (cfn, args, name) in enumerate(lc):
             flops, byts, shape = launch_meta(name, args)
             us = 1e3 * tot[l][i] / steps
+            kern[l][i], shape = _symbol_name(kern[l][i], shape)
             rows.append({"call": name, "kernel": kern[l][i], "shape": shape, "us": round(us, 2), "lane": l, "index": i,
                          "tflops": round(flops / us / 1e6, 1) if us else 0, "gbs": round(byts / us / 1e3, 1) if us else 0,
                          "gflop": round(flops / 1e9, 3), "mb": round(byts / 1e6, 2)})

@@ -258,7 +258,7 @@ int dwconv_launch(const void* x, const void* w, const float* scale, const float*
         set_kernel_name(name);
         const dim3 grid((unsigned)g), block(256);
         const size_t wbytes = (size_t)R * R * C * 2;
-        if (wbytes <= 40 * 1024 && !get_flag("dwconv_no_wlds")) {        // weights in LDS (<= 40 KB: still four blocks per CU)
+        if (wbytes <= 40 * 1024) {        // weights in LDS (<= 40 KB: still four blocks per CU)
             if (R == 3 && sh == 1) hipLaunchKernelGGL((dwconv_kxk_kernel<1, 3, true>), grid, block, wbytes, st, p);
             else if (R == 3) hipLaunchKernelGGL((dwconv_kxk_kernel<2, 3, true>), grid, block, wbytes, st, p);
             else if (sh == 1) hipLaunchKernelGGL((dwconv_kxk_kernel<1, 5, true>), grid, block, wbytes, st, p);

@@ -1221,7 +1221,7 @@ int mv_adaptive_avgpool2d_nhwc_fwd(const void* x, void* y, int N, int H, int W, 
         // a block per (image, 32-channel-vector chunk): big maps always; small maps too when one thread per (image, 8 channels)
         // would leave most of the chip without a wave (squeeze-excitation on 14 x 14 / 7 x 7 maps at 128 images; Swin's last map in fp32)
         const bool wide = (long long)H * W >= 256 || ((long long)H * W >= 32 && (long long)N * (C / 8) <= 24576);
-        if (wide && N <= 65535 && !get_flag("avgpool_narrow")) {
+        if (wide && N <= 65535) {
             const int C8 = C / 8, cpb = C8 < 32 ? C8 : 32, pl = 1024 / cpb;
             set_kernel_name(in_dtype == MV_BF16 ? "global_avgpool_wide_bf16x8" : "global_avgpool_wide_f32x8");
             dim3 g((unsigned)N, (unsigned)((C8 + cpb - 1) / cpb));

@@ -371,7 +371,7 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
         set_kernel_name(dense ? "igemm_bf16_128x128_dense_act" : "igemm_bf16_128x128_conv_act");
         return launch_tile<128, 128, 4, 1>(p, dense, out_f32, st);
     }
-    const bool forced_old = get_flag("igemm_tile") || get_flag("igemm2_tile") || get_flag("no_igemm2") || get_flag("igemm2_dense_m");
+    const bool forced_old = get_flag("igemm_tile") || get_flag("igemm2_tile") || get_flag("no_igemm2");
     if (dense && !get_flag("no_skinny") && !forced_old && get_flag("igemm8") < 2 &&
         skinny_supported(M, C, K, in_dtype, residual))                   // classifier heads: one wave per 32 x 32 tile
         return skinny_launch(x, w, scale, shift, y, M, C, K, act, out_dtype, st);
@@ -415,7 +415,7 @@ int igemm_launch(const void* x, const void* w, const float* scale, const float* 
         return igemm8_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0, t8,
                              st);
     // deep-pipelined 8-wave kernel (igemm2.hip): real convolutions (taps or stride) and big Linears the rule above passed on
-    const long long dense_m = get_flag("igemm2_dense_m") ? get_flag("igemm2_dense_m") : (C >= 512 ? 4096 : 32768);
+    const long long dense_m = C >= 512 ? 4096 : 32768;
     const bool want2 = igemm2_wanted(M, C, K, R, S) && (!dense || M >= dense_m || out_f32 || get_flag("igemm2_tile"));
     if (!get_flag("no_igemm2") && !get_flag("igemm_tile") && want2)
         return igemm2_launch(x, w, scale, shift, residual, y, N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, act, out_dtype, 0, 0, st);

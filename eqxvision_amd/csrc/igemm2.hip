@@ -415,11 +415,8 @@ int igemm2_dual_launch(const void* x, const void* x2, const void* w, const float
     p.act = act;
     p.tiles_m = (p.M + 255) / 256;
     // 256 x 256 tiles measured +2% on resnet50 B=256 over 256 x 128 (the reductions are short: 6-24 k-tiles, so fewer,
-    // larger tiles amortise prologue and epilogue); "dual_tile" = 2 / 3 forces, 4 = 256 x 256 only with >= 256 tiles
-    int tile = get_flag("dual_tile");
-    const long long big = (long long)p.tiles_m * ((K + 255) / 256);
-    if (tile == 4) tile = big >= 256 ? 3 : 2;
-    if (tile != 2 && tile != 3) tile = (K % 256 == 0) ? 3 : 2;
+    // larger tiles amortise prologue and epilogue); (a forced-tile switch existed for the tuning runs of round 2)
+    const int tile = (K % 256 == 0) ? 3 : 2;
     if (tile == 3) {
         constexpr int SMEM = 2 * (256 + 256) * 128;
         p.tiles_n = (K + 255) / 256;
@@ -468,7 +465,7 @@ int igemm2_launch(const void* x, const void* w, const float* scale, const float*
     Igemm2P p;
     p.tok = tok;
     p.x2 = nullptr; p.C2 = 0; p.H2 = 0; p.W2 = 0; p.s2 = 1;
-    p.dbg = get_flag("res_early");
+    p.dbg = 0;
 #ifdef MV_I8_PROF      // debug builds only: a raw device pointer taken from flags must never reach a captured graph
     p.prof = (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo"));
 #else

@@ -851,7 +851,7 @@ static bool splitk_rule(long long tiles, long long nk) {
     // the hand-over costs ~8 us (two atomics, 128 KB out of one CU and into another): it pays from ~40 k-tiles up
     // (tools/time_splitk.py: 72 k-tiles x1.34, 48 x1.10-1.22, 32 x1.05, 12 x0.75)
     const int min_nk = get_flag("splitk_min_nk") ? get_flag("splitk_min_nk") : 40;
-    const int max_tiles = get_flag("splitk_max_tiles") ? get_flag("splitk_max_tiles") : 128;
+    const int max_tiles = 128;
     return tiles <= max_tiles && nk >= min_nk;
 }
 constexpr size_t SPLITK_SYNC_BYTES = 4096;            // 2 words x 512 tiles
@@ -868,7 +868,7 @@ static int igemm8_go(Igemm2P& p, bool dual, bool out_f32, int tile, hipStream_t 
     const int bm = tile == 1 ? 128 : 256, bn = tile == 2 ? 128 : 256;
     p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = (p.K + bn - 1) / bn;
-    p.gm = get_flag("i8_gm") ? get_flag("i8_gm") : 8;
+    p.gm = 8;
 #ifdef MV_I8_PROF
     p.skew = get_flag("i8_skew");                    // measured -3.6 % on vit_base (profiles/r04/vit_ab_i8_skew_4.6us.txt)
 #endif

@@ -276,7 +276,10 @@ int ln_mlp_launch(const void* x, const void* w1, const float* b1, const void* w2
     LnMlpP p;
     p.x = x; p.w1 = (const bf16_t*)w1; p.b1 = b1; p.w2 = (const bf16_t*)w2; p.b2 = b2; p.y = y;
     p.M = (int)M; p.tiles = (int)((M + 31) / 32); p.eps = eps;
+    p.dbg = 0;
+#ifdef MV_I8_PROF
     p.dbg = get_flag("ln_mlp_dbg");
+#endif
     set_kernel_name(x_dtype == MV_F32 ? "ln_mlp96_f32stream" : "ln_mlp96_bf16stream");
     const int wv = get_flag("ln_mlp_waves");
     if (x_dtype == MV_F32)

@@ -307,7 +307,7 @@ static int stream_go(StreamP& p, int tiles_n, hipStream_t st) {
     const size_t slab = (size_t)32 * TN * p.wpitch + (size_t)2 * 32 * TN * 4, patches = (size_t)WAVES * 32 * (64 * 4 + 16);
     int npass = (int)((160 * 1024 - 1024 - patches) / slab);
     if (npass > tiles_n) npass = tiles_n;
-    if (npass < 1 || get_flag("stream_npass1")) npass = 1;
+    if (npass < 1) npass = 1;
     p.npass = npass;
     const int gy = (tiles_n + npass - 1) / npass;
     const size_t smem = slab * npass + patches;

@@ -247,7 +247,7 @@ int swin_mfma_launch(const void* qkv, const float* bias, void* out, int B, int H
     int gx = (int)((tw + 3) / 4);
     // persistent blocks: two per CU in total (register-limited residency), so the per-block bias staging (16 KB) is
     // amortised over many windows (with 8 blocks per CU a wave saw ~1.5 windows: 66 -> 41 us on the 56x56 stage)
-    const int per_cu = get_flag("swin_blocks_per_cu") ? get_flag("swin_blocks_per_cu") : 2;
+    const int per_cu = 2;
     const int cap = (256 * per_cu) / heads > 0 ? (256 * per_cu) / heads : 1;
     if (gx > cap) gx = cap;
     if (drop_keys && (long long)p.nW * heads * p.n * p.n >= (1LL << 32)) {

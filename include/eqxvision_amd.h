@@ -39,14 +39,24 @@ enum { MV_F32 = 0, MV_BF16 = 1 };
 enum { MV_ACT_NONE = 0, MV_ACT_RELU = 1, MV_ACT_GELU_TANH = 2, MV_ACT_HARD_SWISH = 3, MV_ACT_HARD_SIGMOID = 4, MV_ACT_SIGMOID = 5,
        MV_ACT_SILU = 6 };
 enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
-/* mv_set_flag names (A/B and test switches, per calling thread; 0 = the tuned default):
- * "force_generic" (route every op to the simple VALU kernels: on-device cross-check of the MFMA kernels),
- * "igemm8" (2 / 3 / 4 = force the ping-pong GEMM with 256x256 / 128x256 / 256x128 tiles), "no_igemm8",
- * "igemm2_tile" (1 / 2 / 3 = force igemm2 with 256x64 / 256x128 / 256x256 tiles), "no_igemm2", "igemm2_dense_m",
- * "igemm_tile" (1 / 2 = force the 128x128 / 128x64 kernel), "res_early", "no_stream" (no streaming 1x1 / 3x3c64 kernels),
- * "stream_npass1", "no_stream_narrow" (reductions of 16 ... 160 channels back on the tile kernels), "stem_v0", "no_stem_pool", "no_dual", "no_chain", "no_chain_stream" (only the streamed-weights variant off), "no_dual_chain", "no_grouped64", "no_dwconv", "dwconv_generic" (one output pixel per thread for every depthwise shape), "dwconv_no_tile" (stride-1 depthwise layers back on the register-window kernel), "no_oddc" (channel counts that are not multiples of 64 back on the scalar kernel), "no_ln_mlp", "ln_mlp_waves" (8 / 12 / 16), "no_ln_stream", "ln_stream_192", "eltwise_scalar" / "affine_scalar" (the one-value-per-thread element-wise kernels for every size), "dropout_x8" / "dropout_scalar" (training-mode Dropout without the pair-sharing / vector kernels), "no_skinny", "no_tuned", and the
- * per-shape kernel choice "ov:<M>:<C>:<K>:<R>:<S>:<stride>" / "ovh:<M>:<N>:<K>:1:1:1" / "ovd:<M>:<C1>:<C2>:<K>:<stride>:1"
- * (tools/tune_tiles.py; codes in csrc/igemm.hip). */
+/* mv_set_flag names (per calling thread; 0 = the tuned default).  Policy since round 4: ONE "no_<kernel>" switch per fused / special
+ * kernel (in-process A/B with tools/ab_flag.py and the tests' cross-checks against the un-fused path), the forcing switches the tests
+ * use to reach every tile shape, and nothing else -- switches whose A/B is settled are deleted together with the losing branch.
+ *   cross-check     "force_generic" (every op on the simple VALU kernels)
+ *   GEMM core       "igemm8" (2 / 3 / 4 = force 256x256 / 128x256 / 256x128 tiles), "no_igemm8", "no_i8_lin" (generic main loop for dense
+ *                   1x1 / Linear shapes), "no_splitk", "splitk_min_nk" (tests: split short reductions too), "igemm2_tile" (1 / 2 / 3),
+ *                   "no_igemm2", "igemm_tile" (1 / 2), "no_skinny", "no_tuned", "no_dual", and the per-shape choice
+ *                   "ov:<M>:<C>:<K>:<R>:<S>:<stride>" / "ovh:<M>:<N>:<K>:1:1:1" / "ovd:<M>:<C1>:<C2>:<K>:<stride>:1" (tools/tune_tiles.py)
+ *   streaming 1x1   "no_stream", "no_stream_narrow", "no_chain", "no_chain_stream", "no_dual_chain", "no_ln_stream", "ln_stream_192"
+ *   whole blocks    "no_bneck_tail", "bneck_strip" (opt-IN: the layer-1 row-strip kernel, slower than the launches it replaces),
+ *                   "no_ln_mlp", "ln_mlp_waves" (8 / 12 / 16), "no_ln_mlp_stream", "no_swin_block_attn", "swin_c96_shared" (the
+ *                   two-windows-per-workgroup kernel at C = 96), "no_patch_merge_ln", "no_patch4_ln", "no_fc_stream"
+ *   entry / misc    "stem_v0", "no_stem_pool", "no_stem_pool11", "no_patch_f32out", "no_ln_slim", "no_grouped64", "no_dwconv",
+ *                   "dwconv_generic", "dwconv_no_tile", "dwconv_tile3", "no_oddc", "no_se_fused", "se_fused_always", "eltwise_scalar",
+ *                   "affine_scalar", "dropout_x8", "dropout_scalar"
+ * The debug build (EQV_PROF=1 python -m eqxvision_amd.build -> libeqxvision_amd_prof.so) additionally reads "prof_hi" / "prof_lo"
+ * (a device buffer for per-wave phase stamps), "*_prof", "i8_skew", "i8_ablate", "strip_skew", "ln_mlp_dbg": none of them exists in
+ * the product library. */
 
 int mv_abi_version(void);
 const char* mv_last_error(void);

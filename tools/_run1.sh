@@ -1,3 +1,3 @@
-cd $GRAFT_REPO_ROOT
-SBA_C=96 bash tools/pmc_kernel.sh gpurun_out/w96/pmc_new swin_win96 python tools/time_swin_block_attn.py 64 | tail -40
-SBA_C=96 FLAGS=swin_c96_shared bash tools/pmc_kernel.sh gpurun_out/w96/pmc_old "swin_block_attn_kernel<96" python tools/time_swin_block_attn.py 64 | tail -40
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee gpurun_out/pytest_gpu.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee gpurun_out/smoke.txt

@@ -56,7 +56,7 @@ def fam(name):
                    ("patch_embed_kernel", "patch_embed_mfma_f32in"), ("mha_mfma_kernel", "mha_mfma_dh64_hm"),
                    ("layernorm_vec_kernel", "layernorm_vec"), ("layernorm_slim_kernel", "layernorm_slim"), ("ln_mlp96_kernel", "ln_mlp96_f32stream"), ("swin_attn_mfma", "swin_attn_mfma"), ("skinny_f32_kernel", "skinny_linear_f32_mfma"),
                    ("bneck_tail_kernel", "bneck_tail_bf16_14x14_256_1024"), ("ln_mlp_stream_kernel", "ln_mlp_stream_c384_f32stream"), ("ln_mlp_stream192_kernel", "ln_mlp_stream_c192_f32stream"),
-                   ("swin_block_attn_kernel<384", "swin_block_attn_c384"), ("swin_block_attn_kernel<192", "swin_block_attn_c192"), ("swin_block_attn_kernel<96", "swin_block_attn_c96"),
+                   ("swin_win96_kernel", "swin_win96"), ("swin_block_attn_kernel<384", "swin_block_attn_c384"), ("swin_block_attn_kernel<192", "swin_block_attn_c192"), ("swin_block_attn_kernel<96", "swin_block_attn_c96"),
                    ("patch_merge_ln_kernel", "patch_merge_ln_f32in"), ("swin_stem_ln_kernel", "swin_stem_ln_k96"),
                    ("fc_stream_kernel", "fc_stream_bf16"), ("maxpool_nhwc_bf16x8_kernel", "maxpool_nhwc_bf16x8")):
         if sub in n: return f

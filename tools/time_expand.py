@@ -7,7 +7,7 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 25088
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 N = 4 * C
 by = 2.0 * (M * C + 2 * M * N + N * C)
-for flags in ((), (("stream_npass1", 1),), ((f"ov:{M}:{C}:{N}:1:1:1", 10),), ((f"ov:{M}:{C}:{N}:1:1:1", 11),), ((f"ov:{M}:{C}:{N}:1:1:1", 12),),
+for flags in ((), ((f"ov:{M}:{C}:{N}:1:1:1", 10),), ((f"ov:{M}:{C}:{N}:1:1:1", 11),), ((f"ov:{M}:{C}:{N}:1:1:1", 12),),
               ((f"ov:{M}:{C}:{N}:1:1:1", 3),), ((f"ov:{M}:{C}:{N}:1:1:1", 7),)):
     try:
         us, k = run(M, N, C, act=1, res=True, flags=flags)
