@@ -83,6 +83,51 @@ def _splitk_runs(L, launch, y, M, N, kred, info):
     return kern
 
 
+def splitk_protocol_case(seed=0):
+    """mv_set_scratch edge cases (include/eqxvision_amd.h): scratch that is too small, or handed over for ANOTHER stream, is ignored
+    (un-split kernel, the bits of the no-scratch launch); a hand-over is consumed by one launch (the next launch without a new
+    hand-over runs un-split); bytes = 0 withdraws it."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        M, K, N = 3136, 3072, 768
+        x = dev(bf(rng.standard_normal((M, K))), "bf16")
+        w = dev(bf(rng.standard_normal((N, K)) / np.sqrt(K)), "bf16")
+        b = dev((0.1 * rng.standard_normal(N)).astype(np.float32), "fp32")
+        y = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        nb = int(L.load().mv_splitk_scratch_bytes(M, N, K))
+        if not nb:
+            return {"ok": False, "err": "not a split shape"}
+        ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        other = torch.cuda.Stream()
+
+        def launch():
+            L.call("mv_linear_fwd", x.data_ptr(), w.data_ptr(), None, b.data_ptr(), None, y.data_ptr(), M, N, K, 0, 1, 1, _stream())
+            k = L.last_kernel()
+            torch.cuda.synchronize()
+            return k, y.clone()
+        k0, y0 = launch()                                                    # no scratch at all
+        L.call("mv_set_scratch", ws.data_ptr(), nb // 2, _stream())
+        k1, y1 = launch()                                                    # too small
+        L.call("mv_set_scratch", ws.data_ptr(), nb, other.cuda_stream)
+        k2, y2 = launch()                                                    # for another stream
+        L.call("mv_set_scratch", ws.data_ptr(), nb, _stream())
+        k3, y3 = launch()                                                    # taken
+        k4, y4 = launch()                                                    # consumed: not taken again
+        L.call("mv_set_scratch", ws.data_ptr(), nb, _stream())
+        L.call("mv_set_scratch", None, 0, _stream())
+        k5, y5 = launch()                                                    # withdrawn
+        unsplit = [k for k in (k0, k1, k2, k4, k5)]
+        info = {"kernels": [k0, k1, k2, k3, k4, k5],
+                "unsplit_ok": all(not k.endswith("_splitk") for k in unsplit), "split_ok": k3.endswith("_splitk"),
+                "same_bits_unsplit": all(torch.equal(y0, t) for t in (y1, y2, y4, y5)),
+                "split_close": float((y3.float() - y0.float()).abs().max().item())}
+        info["ok"] = bool(info["unsplit_ok"] and info["split_ok"] and info["same_bits_unsplit"] and info["split_close"] <= 0.05)
+        info["err"] = info["split_close"]
+        return info
+    return run
+
+
 # --------------------------------------------------------------------------------------------
 def conv_nhwc_case(N, H, W, C, K, R, S, stride=1, pad=0, dil=1, groups=1, act=0, res=False, scale=True,
                    dtype="bf16", out="same", generic=False, seed=0, tile=0, flags=(), splitk=False):
@@ -2065,6 +2110,7 @@ def all_cases():
           ("splitk/dual_second_half_in_source2", dual_case(96, 7, 7, 512, 1024, 512, 2, seed=608, splitk=True, flags=("splitk_min_nk=12",))),
           ("splitk/dual_crossing_inside_half", dual_case(96, 7, 7, 1024, 512, 512, 2, seed=609, splitk=True, flags=("splitk_min_nk=12",))),
           ("splitk/linear_split_swin_merge", linear_split_case(3136, 1536, 768, seed=610, splitk=True)),
+          ("splitk/scratch_protocol_edges", splitk_protocol_case(seed=611)),
           ("igemm8s/128x256_1x1_512_256", conv_nhwc_case(8, 28, 28, 512, 256, 1, 1, act=1, seed=361, flags=("igemm8=3",))),
           ("igemm8s/128x256_3x3_128_256", conv_nhwc_case(8, 28, 28, 128, 256, 3, 3, pad=1, act=1, seed=362, flags=("igemm8=3",))),
           ("igemm8s/128x256_3x3_s2_K320", conv_nhwc_case(9, 33, 35, 128, 320, 3, 3, stride=2, pad=1, seed=363, flags=("igemm8=3",))),
