@@ -473,3 +473,30 @@ def test_roctx_ranges_bracket_module_calls():
         assert _trace.pushed == before + 2 and _trace.depth == 0
     finally:
         _trace.enabled = old
+
+
+def test_scratch_hand_over_travels_with_the_recorded_launch():
+    """`mv_set_scratch` is not a launch: while a forward is recorded it is folded into the launch it precedes, and every replay hands the
+    scratch over again on the stream it is replayed on (eqxvision_amd/_lib.py: call, _with_scratch)."""
+    from eqxvision_amd import _lib
+    rec = []
+    old = _lib.set_recording(rec)
+    try:
+        _lib.call("mv_set_scratch", 0x1000, 8192, 7)
+        assert rec == []                                              # nothing recorded yet
+        _lib.call("mv_splitk_scratch_bytes", 1, 1, 1)                 # any recorded call that needs no GPU (returns 0 = MV_OK)
+        _lib.call("mv_splitk_scratch_bytes", 1, 1, 1)                 # the hand-over belongs to ONE launch
+    finally:
+        _lib.set_recording(old)
+    assert [r[2] for r in rec] == ["mv_splitk_scratch_bytes", "mv_splitk_scratch_bytes"]
+    assert rec[0][0].__name__ == "launch" and rec[1][0].__name__ != "launch"
+    seen = []
+    wrapped = _lib._with_scratch(lambda p, n, s: seen.append(("set", p, n, s)), (0x1000, 8192),
+                                 lambda *a: seen.append(("launch",) + a) or 0)
+    assert wrapped(1, 2, 99) == 0
+    assert seen == [("set", 0x1000, 8192, 99), ("launch", 1, 2, 99)]   # handed over first, on the replay's stream
+    # the rule behind mv_splitk_scratch_bytes: few tiles AND a long reduction
+    lib = _lib.load()
+    assert lib.mv_splitk_scratch_bytes(3136, 512, 4608) == 4096 + 52 * 128 * 256 * 4      # ResNet layer 4 3x3 at 64 images: 50 / 52 tiles
+    assert lib.mv_splitk_scratch_bytes(3136, 768, 768) == 0                                  # 12 k-tiles: not worth the hand-over
+    assert lib.mv_splitk_scratch_bytes(100352, 512, 4608) == 0                               # fills the chip un-split
