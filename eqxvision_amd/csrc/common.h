@@ -85,6 +85,7 @@ int get_flag(const char* name);
 // the scratch the host handed over with mv_set_scratch for the next launch on `stream`: returned (and forgotten) if it holds
 // at least `need` bytes, else nullptr
 void* take_scratch(hipStream_t stream, size_t need);
+void* peek_scratch(hipStream_t stream, size_t* bytes);
 size_t splitk_scratch_bytes(long long M, long long N, long long kred);       // igemm8.hip
 const void* zero_page(hipStream_t stream);  // >= 4 KiB of device zeros for the current device
 

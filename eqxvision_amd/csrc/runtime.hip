@@ -40,6 +40,11 @@ void* take_scratch(hipStream_t stream, size_t need) {
     g_scratch.ptr = nullptr;
     return p;
 }
+void* peek_scratch(hipStream_t stream, size_t* bytes) {       // what is on offer for this stream, without taking it
+    if (!g_scratch.ptr || g_scratch.stream != stream) return nullptr;
+    if (bytes) *bytes = g_scratch.bytes;
+    return g_scratch.ptr;
+}
 int get_flag(const char* name) {
     if (g_flags.empty()) return 0;
     auto it = g_flags.find(name);

@@ -10,6 +10,7 @@
 //   * LayerNorm and softmax backward, softmax cross-entropy with its gradient, the Adam update, a 2-D transpose.
 // Minimum slice: correctness first (one thread per output element, VALU); the matrix-core versions are future work.
 #include "common.h"
+#include "mfma_common.h"
 
 namespace mv {
 
@@ -145,6 +146,81 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
     part[rg][cl] = acc;
     __syncthreads();
     if (rg == 0 && c < C) out[c] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+}
+
+// the same sum with the rows split over blockIdx.y (chunk rows each): part[y][c]; colsum_finish adds the parts in a fixed order
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part,
+                                                           long long M, int C, long long chunk) {
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long long m0 = blockIdx.y * chunk, m1 = m0 + chunk < M ? m0 + chunk : M;
+    float acc = 0.f;
+    if (c < C)
+        for (long long m = m0 + rg; m < m1; m += 4) acc += b ? a[m * C + c] * b[m * C + c] : a[m * C + c];
+    sh[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < C) part[(long long)blockIdx.y * C + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+}
+// out[i] = part[0][i] + part[1][i] + ... (fixed order: bit-reproducible)
+__global__ void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, long long n, int parts) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int s = 0; s < parts; ++s) acc += part[(long long)s * n + i];
+    out[i] = acc;
+}
+
+// Weight gradient on the fp32 matrix cores: for one filter tap (r, s), dW[k][c] = sum over output positions of dy[pos][k] * x[pos @ (r, s)][c]
+// is a GEMM whose reduction runs over the positions.  One wave = one 32 (k) x 32 (c) tile of one tap over a chunk of positions,
+// v_mfma_f32_32x32x2_f32 reduces two positions per instruction: lane (fr, fh) feeds dy[pos + fh][k0 + fr] and x[..][c0 + fr] -- both
+// coalesced along the channel index, no LDS.  The chunks' partial tiles are added in a fixed order by sum_parts_kernel.
+__global__ __launch_bounds__(64) void conv_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                             int N, int H, int W, int Cfull, int K, int R, int S, int Ho, int Wo, int sh,
+                                                             int sw, int ph, int pw, int dh, int dw, int groups, long long P,
+                                                             long long chunk, int ktiles, int ctiles) {
+    const int lane = threadIdx.x, fr = lane & 31, fh = lane >> 5;
+    int t = blockIdx.x;
+    const int s = t % S; t /= S;
+    const int r = t % R; t /= R;
+    const int ct = t % ctiles; t /= ctiles;
+    const int kt = t % ktiles;
+    const int g = t / ktiles;
+    const int Kg = K / groups, Cg = Cfull / groups;
+    const int kl = kt * 32 + fr, cl = ct * 32 + fr;
+    const bool kok = kl < Kg, cok = cl < Cg;
+    const float* dyk = dy + (g * Kg + (kok ? kl : 0));
+    const float* xc = x + (g * Cg + (cok ? cl : 0));
+    const long long p0 = blockIdx.y * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
+    long long p = p0 + fh;
+    int n = (int)(p / ((long long)Ho * Wo));
+    int rem = (int)(p - (long long)n * Ho * Wo);
+    int ho = rem / Wo, wo = rem - ho * Wo;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (; p - fh < p1; p += 2) {
+        const bool in = p < p1;
+        const int hi = ho * sh - ph + r * dh, wi = wo * sw - pw + s * dw;
+        const bool inside = in && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        const float a = (in && kok) ? dyk[p * K] : 0.f;
+        const float b = (inside && cok) ? xc[(((long long)n * H + hi) * W + wi) * Cfull] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        wo += 2;
+        while (wo >= Wo) {
+            wo -= Wo;
+            if (++ho >= Ho) { ho = 0; ++n; }
+        }
+    }
+    // acc[i]: k = 8 (i / 4) + 4 fh + i % 4, c = fr
+    float* o = part + (long long)blockIdx.y * ((long long)K * R * S * Cg);
+    if (cok) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = kt * 32 + 8 * (i >> 2) + 4 * fh + (i & 3);
+            if (kk < Kg) o[(((long long)(g * Kg + kk) * R + r) * S + s) * Cg + cl] = acc[i];
+        }
+    }
 }
 
 // ds[b, c] = sum over the HW positions of image b of g[b, p, c] * x[b, p, c]  (the scale's gradient of y = x * s[b, c])
@@ -422,8 +498,38 @@ int mv_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw_krsc, in
     MV_CHECK_ARG(groups > 0 && C % groups == 0 && K % groups == 0, "conv2d_wgrad: groups = %d does not divide C = %d, K = %d", groups, C, K);
     const int Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
     MV_CHECK_ARG(Ho > 0 && Wo > 0 && (long long)K * R * S < (1LL << 31), "conv2d_wgrad: bad dims");
+    const int cg = C / groups, kg = K / groups;
+    if (cg >= 8 && kg >= 8) {
+        // matrix-core path: tiles x position chunks ~ 4096 waves; the chunks' partial sums live in the caller's scratch (mv_set_scratch),
+        // without scratch one chunk per tile writes the result directly
+        const long long P = (long long)N * Ho * Wo, out_elems = (long long)K * R * S * cg;
+        const int ktiles = (kg + 31) / 32, ctiles = (cg + 31) / 32;
+        const long long tiles = (long long)groups * ktiles * ctiles * R * S;
+        long long split = tiles >= 2048 ? 1 : (4096 + tiles - 1) / tiles;
+        if (split > (P + 127) / 128) split = (P + 127) / 128;
+        if (split > 1024) split = 1024;
+        float* part = dw_krsc;
+        if (split > 1) {
+            size_t have = 0;
+            void* sc = peek_scratch((hipStream_t)stream, &have);
+            const long long fit = sc ? (long long)(have / ((size_t)out_elems * 4)) : 0;
+            if (fit < 2) split = 1;
+            else {
+                if (split > fit) split = fit;
+                part = (float*)take_scratch((hipStream_t)stream, (size_t)split * out_elems * 4);
+            }
+        }
+        const long long chunk = ((P + split - 1) / split + 1) & ~1LL;                 // even: a pair of positions never straddles two chunks
+        set_kernel_name("conv_wgrad_mfma_f32");
+        hipLaunchKernelGGL(conv_wgrad_mfma_kernel, dim3((unsigned)tiles, (unsigned)split), dim3(64), 0, (hipStream_t)stream, x, dy, part, N, H,
+                           W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw, groups, P, chunk, ktiles, ctiles);
+        if (split > 1)
+            hipLaunchKernelGGL(sum_parts_kernel, dim3(blocks_for(out_elems, 256)), dim3(256), 0, (hipStream_t)stream, part, dw_krsc,
+                               out_elems, (int)split);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
     set_kernel_name("conv_wgrad_f32");
-    const int cg = C / groups;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(K * R * S)), dim3(cg >= 256 ? 256 : (cg > 64 ? 128 : 64)), 0,
                        (hipStream_t)stream, x, dy, dw_krsc, N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw, groups);
     MV_LAUNCH_CHECK();
@@ -462,6 +568,22 @@ int mv_avgpool_global_bwd_nhwc_f32(const float* dy, float* dx, int N, int HW, in
 
 int mv_colsum_f32(const float* a, const float* b, float* out, int64_t M, int C, mv_stream_t stream) {
     MV_CHECK_ARG(a && out && M > 0 && C > 0, "colsum: bad arguments");
+    // many rows, few columns (bias / BatchNorm gradients over a feature map): rows split over blocks, parts in the caller's scratch
+    long long split = M >= 4096 ? (M + 1023) / 1024 : 1;
+    if (split > 512) split = 512;
+    if (split > 1) {
+        float* part = (float*)take_scratch((hipStream_t)stream, (size_t)split * C * 4);
+        if (part) {
+            const long long chunk = (M + split - 1) / split;
+            set_kernel_name("colsum_split_f32");
+            hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)split), dim3(256), 0, (hipStream_t)stream, a, b,
+                               part, (long long)M, C, chunk);
+            hipLaunchKernelGGL(sum_parts_kernel, dim3(blocks_for(C, 256)), dim3(256), 0, (hipStream_t)stream, part, out, (long long)C,
+                               (int)split);
+            MV_LAUNCH_CHECK();
+            return MV_OK;
+        }
+    }
     set_kernel_name("colsum_f32");
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)M, C);
     MV_LAUNCH_CHECK();

@@ -149,8 +149,24 @@ def _acc_param(leaf, g: torch.Tensor):
     t.pgrads[id(leaf)] = g if old is None else _add(old, g)
 
 
+_BWD_SCRATCH = {}
+_BWD_SCRATCH_BYTES = 64 << 20
+
+
+def _offer_scratch():
+    """Hand the next launch on this stream the backward pass's scratch buffer (include/eqxvision_amd.h: mv_set_scratch): the column
+    sums and the weight gradients split their reduction over many blocks when they get room for the partial sums.  One buffer per
+    stream: the backward pass is eager, and launches on a stream are ordered."""
+    key = (_S(), torch.cuda.current_device())
+    ws = _BWD_SCRATCH.get(key)
+    if ws is None:
+        ws = _BWD_SCRATCH[key] = torch.empty(_BWD_SCRATCH_BYTES, dtype=torch.uint8, device=device())
+    _call("mv_set_scratch", _p(ws), _BWD_SCRATCH_BYTES, _S())
+
+
 def _colsum(a: torch.Tensor, b: Optional[torch.Tensor], C: int) -> torch.Tensor:
     out = _new((C,))
+    _offer_scratch()
     _call("mv_colsum_f32", _p(a), _p(b), _p(out), a.numel() // C, C, _S())
     return out
 
@@ -495,6 +511,7 @@ def g_conv2d(x: Act, conv, bn=None, act=None, residual: Optional[Act] = None) ->
         if conv.bias is not None:
             _acc_param(conv.bias, _colsum(dz, None, K))
         dwk = _new((K, kh, kw, C // G))
+        _offer_scratch()
         _call("mv_conv2d_wgrad_nhwc_f32", _p(xin), _p(dz), _p(dwk), B, H, W, C, K, kh, kw, sh, sw, ph, pw, dh, dw, G, _S())
         dwo = _new((K, C // G, kh, kw))
         _call("mv_nhwc_to_nchw", _p(dwk), _p(dwo), K, C // G, kh, kw, F32, F32, _S())   # KRSC -> OIHW, the leaf's layout

@@ -369,11 +369,56 @@ def conv_bwd_case(N, H, W, C, K, R, stride=1, pad=0, dil=1, seed=0, groups=1):
                dil, dil, groups, _stream())
         L.call("mv_conv2d_wgrad_nhwc_f32", d["x"].data_ptr(), d["g"].data_ptr(), dw.data_ptr(), N, H, W, C, K, R, R, stride, stride, pad, pad,
                dil, dil, groups, _stream())
+        kern = L.last_kernel()
         torch.cuda.synchronize()
         a = _cmp(host(dx).transpose(0, 3, 1, 2), dx_ref, TOL_F32)
         b = _cmp(host(dw).transpose(0, 3, 1, 2), dw_ref, TOL_F32)
-        return {"ok": a["ok"] and b["ok"], "err": max(a["err"], b["err"]) if isinstance(a["err"], float) and isinstance(b["err"], float) else (a["err"], b["err"]),
-                "dx": a, "dw": b}
+        # the same weight gradient with scratch on offer (mv_set_scratch): the positions are split over blocks and the parts added in a
+        # fixed order -- same tolerance, and the same bits on a second run
+        ws = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+        outs = []
+        for _ in range(2):
+            dw2 = torch.full((K, R, R, C // groups), -7.0, device="cuda")
+            L.call("mv_set_scratch", ws.data_ptr(), ws.numel(), _stream())
+            L.call("mv_conv2d_wgrad_nhwc_f32", d["x"].data_ptr(), d["g"].data_ptr(), dw2.data_ptr(), N, H, W, C, K, R, R, stride, stride, pad,
+                   pad, dil, dil, groups, _stream())
+            torch.cuda.synchronize()
+            outs.append(dw2)
+        L.call("mv_set_scratch", None, 0, _stream())
+        c = _cmp(host(outs[0]).transpose(0, 3, 1, 2), dw_ref, TOL_F32)
+        rep = bool(torch.equal(outs[0], outs[1]))
+        return {"ok": a["ok"] and b["ok"] and c["ok"] and rep,
+                "err": max(a["err"], b["err"], c["err"]) if all(isinstance(t["err"], float) for t in (a, b, c)) else (a["err"], b["err"], c["err"]),
+                "dx": a, "dw": b, "dw_split": c, "repeatable": rep, "kernel": kern}
+    return run
+
+
+def colsum_case(M, C, seed=0, product=False):
+    """mv_colsum_f32 (bias / BatchNorm gradients): out[c] = sum_m a[m, c] (* b[m, c]) -- the single-block-per-64-columns kernel and, with
+    scratch on offer, the row-split kernel + fixed-order finish: both vs float64, the split one repeatable bit for bit."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        a = rng.standard_normal((M, C)).astype(np.float32)
+        b = rng.standard_normal((M, C)).astype(np.float32) if product else None
+        ref = (a.astype(np.float64) * (b.astype(np.float64) if product else 1.0)).sum(0)
+        ad, bd = dev(a, "fp32"), (dev(b, "fp32") if product else None)
+        outs, kerns = [], []
+        ws = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
+        for use in (False, True, True):
+            o = torch.full((C,), -7.0, device="cuda")
+            if use:
+                L.call("mv_set_scratch", ws.data_ptr(), ws.numel(), _stream())
+            L.call("mv_colsum_f32", ad.data_ptr(), None if bd is None else bd.data_ptr(), o.data_ptr(), M, C, _stream())
+            kerns.append(L.last_kernel())
+            torch.cuda.synchronize()
+            outs.append(o)
+        L.call("mv_set_scratch", None, 0, _stream())
+        tol = 2e-5 * np.sqrt(M)
+        i0, i1 = _cmp(host(outs[0]), ref, tol), _cmp(host(outs[1]), ref, tol)
+        split_taken = kerns[1] == "colsum_split_f32" or M < 4096
+        return {"ok": bool(i0["ok"] and i1["ok"] and torch.equal(outs[1], outs[2]) and split_taken and kerns[0] == "colsum_f32"),
+                "err": max(i0["err"], i1["err"]), "kernels": kerns}
     return run
 
 
@@ -2285,6 +2330,10 @@ def all_cases():
           ("bwd/conv3x3_depthwise_s2", conv_bwd_case(2, 14, 14, 48, 48, 3, 2, 1, seed=39, groups=48)),
           ("bwd/conv3x3_groups4", conv_bwd_case(2, 12, 12, 32, 64, 3, 1, 1, seed=40, groups=4)),
           ("bwd/conv5x5_depthwise", conv_bwd_case(1, 14, 14, 40, 40, 5, 1, 2, seed=51, groups=40)),
+          ("bwd/conv3x3_c64_56_many_positions", conv_bwd_case(2, 56, 56, 64, 64, 3, 1, 1, seed=61)),
+          ("bwd/colsum_100k_x_64", colsum_case(100352, 64, seed=62)),
+          ("bwd/colsum_product_5000_x_200", colsum_case(5000, 200, seed=63, product=True)),
+          ("bwd/colsum_small", colsum_case(300, 10, seed=64)),
           ("bwd/maxpool_3x3_s2", maxpool_bwd_case(2, 27, 27, 64, 3, 2, 0, seed=41)),
           ("bwd/maxpool_3x3_s2_p1", maxpool_bwd_case(2, 28, 28, 64, 3, 2, 1, seed=42)),
           ("bwd/maxpool_2x2_s2", maxpool_bwd_case(1, 56, 56, 256, 2, 2, 0, seed=43)),

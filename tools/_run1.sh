@@ -1,8 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for i in 1 2; do
-for lib in libeqxvision_amd.so libeqxvision_amd_oldstream.so; do
-  for m in efficientnet_b0 mobilenet_v2 mobilenet_v3_large regnet_y_400mf; do
-    echo -n "$lib $m: "; EQV_LIB=$GRAFT_REPO_ROOT/eqxvision_amd/csrc/$lib timeout 300 python bench.py --model $m --batch 256 --extra none --no-cpu --steps 40 --warmup 8 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])"
-  done
-done
-done | tee gpurun_out/stream_ab.txt
+timeout 1500 python tools/gpu_check.py bwd/ grad/ > gpurun_out/bwd_check.log 2>&1; grep -c PASS gpurun_out/bwd_check.log; grep -v PASS gpurun_out/bwd_check.log | cut -c1-500 | tail -8
+for m in "alexnet 8" "resnet18 8" "resnet50 4" "vit_tiny 8" "swin_t 4"; do timeout 600 python tools/time_train_step.py $m 3 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" | tail -1; done | tee gpurun_out/train_step_times2.txt
