@@ -72,9 +72,95 @@ static int conv_generic_launch(const void* x, const void* w, const float* scale,
     return MV_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// the same contraction in fp32 on the matrix cores (v_mfma_f32_32x32x2_f32): the fp32 compute mode and the training step (both
+// passes run in fp32) spend their time here.  One wave = 32 output channels x 32 output positions; A = weights (lane: channel fr,
+// reduction element fh), B = the positions' input rows; a lane loads FOUR consecutive reduction channels at once (its half of a group
+// of eight), which feeds four MFMA steps.  Channels-last x and w only (the reduction index contiguous in both); groups = 1.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ residual, float* __restrict__ y,
+                                                            const float* __restrict__ pos, ConvP p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 31, fh = lane >> 5;
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    const long long m = ((long long)blockIdx.x * 4 + wave) * 32 + fr;
+    const int k0 = blockIdx.y * 32;
+    const bool mok = m < M;
+    const long long mm = mok ? m : 0;
+    const int wo = (int)(mm % p.Wo), ho = (int)((mm / p.Wo) % p.Ho), n = (int)(mm / ((long long)p.Wo * p.Ho));
+    const bool kok = k0 + fr < p.K;
+    const float* wk = w + (long long)(kok ? k0 + fr : 0) * p.swk;
+    const bool vec = (p.C & 3) == 0 && (p.sxn & 3) == 0 && (p.sxh & 3) == 0 && (p.sxw & 3) == 0 && (p.swk & 3) == 0 && (p.swr & 3) == 0 &&
+                     (p.sws & 3) == 0;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int r = 0; r < p.R; ++r) {
+        const int hi = ho * p.sh - p.ph + r * p.dh;
+        for (int s_ = 0; s_ < p.S; ++s_) {
+            const int wi = wo * p.sw - p.pw + s_ * p.dw;
+            const bool inside = mok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const float* xp = x + (inside ? n * p.sxn + hi * p.sxh + wi * p.sxw : 0);
+            const float* wp = wk + r * p.swr + s_ * p.sws;
+            if (vec) {
+                for (int c0 = 0; c0 < p.C; c0 += 8) {
+                    const int c = c0 + 4 * fh;
+                    const bool cin = c < p.C;                                    // C % 8 == 4: the upper half of the last group is empty
+                    const float4 a = (kok && cin) ? *(const float4*)(wp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 b = (inside && cin) ? *(const float4*)(xp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+                }
+            } else {
+                for (int c0 = 0; c0 < p.C; c0 += 2) {
+                    const int c = c0 + fh;
+                    const bool cin = c < p.C;
+                    const float a = (kok && cin) ? wp[c] : 0.f;
+                    const float b = (inside && cin) ? xp[c] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!mok) return;
+    long long row = m;
+    int pix = 0;
+    if (p.tok_stride > 0) {
+        pix = ho * p.Wo + wo;
+        row = (long long)n * p.tok_stride + p.tok_offset + pix;
+    }
+    // acc[4 q + i]: channel k0 + 8 q + 4 fh + i of position fr
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + 8 * q + 4 * fh + i;
+            if (k >= p.K) continue;
+            float v = acc[4 * q + i];
+            if (scale) v *= scale[k];
+            if (shift) v += shift[k];
+            if (p.tok_stride > 0 && pos) v += pos[(long long)(p.tok_offset + pix) * p.K + k];
+            if (residual) v += residual[row * p.K + k];
+            v = apply_act_rt(v, p.act);
+            y[row * p.K + k] = v;
+        }
+}
+
 static int conv_generic_dispatch(const void* x, const void* w, const float* scale, const float* shift,
                                  const void* residual, void* y, const float* pos, const ConvP& p, int x_dtype,
                                  int w_dtype, int y_dtype, hipStream_t st) {
+    if (x_dtype == MV_F32 && w_dtype == MV_F32 && y_dtype == MV_F32 && p.groups == 1 && p.sxc == 1 && p.swc == 1 && p.K >= 8 &&
+        !get_flag("no_f32_mfma")) {
+        const long long M = (long long)p.N * p.Ho * p.Wo;
+        set_kernel_name("conv_f32_mfma");
+        hipLaunchKernelGGL(conv_f32_mfma_kernel, dim3((unsigned)((M + 127) / 128), (unsigned)((p.K + 31) / 32)), dim3(256), 0, st,
+                           (const float*)x, (const float*)w, scale, shift, (const float*)residual, (float*)y, pos, p);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
     set_kernel_name("conv_generic");
 #define GO(TX, TW, TY) return conv_generic_launch<TX, TW, TY>(x, w, scale, shift, residual, y, pos, p, st)
     if (x_dtype == MV_F32 && w_dtype == MV_F32 && y_dtype == MV_F32) GO(float, float, float);

@@ -499,7 +499,7 @@ int mv_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw_krsc, in
     const int Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
     MV_CHECK_ARG(Ho > 0 && Wo > 0 && (long long)K * R * S < (1LL << 31), "conv2d_wgrad: bad dims");
     const int cg = C / groups, kg = K / groups;
-    if (cg >= 8 && kg >= 8) {
+    if (!get_flag("wgrad_valu")) {                  // (the one-thread-per-weight kernel below stays as the on-device cross-check)
         // matrix-core path: tiles x position chunks ~ 4096 waves; the chunks' partial sums live in the caller's scratch (mv_set_scratch),
         // without scratch one chunk per tile writes the result directly
         const long long P = (long long)N * Ho * Wo, out_elems = (long long)K * R * S * cg;
