@@ -46,6 +46,71 @@ __global__ void conv_dgrad_kernel(const float* __restrict__ dy, const float* __r
 }
 
 // one block per (k, r, s); threads over c; the block's threads walk the output positions together
+// Input gradient on the fp32 matrix cores (groups = 1): dx[pos][c] = sum over (r, s, k) of dy[out(pos, r, s)][k] * w[k][r][s][c].  One wave =
+// 32 input channels x 32 input positions; A = weights (lane: channel c0 + fr, coalesced along c; four k per step group), B = dy rows
+// (a lane loads four consecutive k of its position's output pixel); a tap contributes to a position only where the stride divides.
+__global__ __launch_bounds__(256) void conv_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                              int N, int H, int W, int C, int K, int R, int S, int Ho, int Wo, int sh,
+                                                              int sw, int ph, int pw, int dh, int dw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 31, fh = lane >> 5;
+    const long long M = (long long)N * H * W;
+    const long long m = ((long long)blockIdx.x * 4 + wave) * 32 + fr;
+    const int c0 = blockIdx.y * 32;
+    const bool mok = m < M;
+    const long long mm = mok ? m : 0;
+    const int wi = (int)(mm % W), hi = (int)((mm / W) % H), n = (int)(mm / ((long long)W * H));
+    const bool cok = c0 + fr < C;
+    const float* wc = w + (cok ? c0 + fr : 0);
+    const long long wks = (long long)R * S * C;             // stride between filters
+    const bool vec = (K & 3) == 0;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const int th = hi + ph - r * dh;
+        const int ho = th / sh;
+        const bool hok = th >= 0 && th - ho * sh == 0 && ho < Ho;
+        for (int s_ = 0; s_ < S; ++s_) {
+            const int tw = wi + pw - s_ * dw;
+            const int wo = tw / sw;
+            const bool inside = mok && hok && tw >= 0 && tw - wo * sw == 0 && wo < Wo;
+            const float* dyp = dy + (inside ? (((long long)n * Ho + ho) * Wo + wo) * K : 0);
+            const float* wp = wc + ((long long)r * S + s_) * C;
+            if (vec) {
+                for (int k0 = 0; k0 < K; k0 += 8) {
+                    const int k = k0 + 4 * fh;
+                    const bool kin = k < K;
+                    const float4 b = (inside && kin) ? *(const float4*)(dyp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float a[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = (cok && kin) ? wp[(long long)(k + e) * wks] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b.w, acc, 0, 0, 0);
+                }
+            } else {
+                for (int k0 = 0; k0 < K; k0 += 2) {
+                    const int k = k0 + fh;
+                    const bool kin = k < K;
+                    const float a = (cok && kin) ? wp[(long long)k * wks] : 0.f;
+                    const float b = (inside && kin) ? dyp[k] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!mok) return;
+    // acc[4 q + i]: channel c0 + 8 q + 4 fh + i of position fr
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + 8 * q + 4 * fh + i;
+            if (c < C) dx[m * C + c] = acc[4 * q + i];
+        }
+}
+
 __global__ void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dwt, int N, int H,
                                   int W, int Cfull, int K, int R, int S, int Ho, int Wo, int sh, int sw, int ph, int pw, int dh,
                                   int dw, int groups) {
@@ -484,6 +549,14 @@ int mv_conv2d_dgrad_nhwc_f32(const float* dy, const float* w_krsc, float* dx, in
     MV_CHECK_ARG(groups > 0 && C % groups == 0 && K % groups == 0, "conv2d_dgrad: groups = %d does not divide C = %d, K = %d", groups, C, K);
     const int Ho = (H + 2 * ph - dh * (R - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (S - 1) - 1) / sw + 1;
     MV_CHECK_ARG(Ho > 0 && Wo > 0 && (long long)N * H * W < (1LL << 31), "conv2d_dgrad: bad dims");
+    if (groups == 1 && C >= 8 && !get_flag("dgrad_valu")) {
+        const long long M = (long long)N * H * W;
+        set_kernel_name("conv_dgrad_mfma_f32");
+        hipLaunchKernelGGL(conv_dgrad_mfma_kernel, dim3((unsigned)((M + 127) / 128), (unsigned)((C + 31) / 32)), dim3(256), 0,
+                           (hipStream_t)stream, dy, w_krsc, dx, N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
     set_kernel_name("conv_dgrad_f32");
     hipLaunchKernelGGL(conv_dgrad_kernel, dim3((unsigned)((long long)N * H * W)), dim3(C >= 256 ? 256 : (C > 64 ? 128 : 64)), 0,
                        (hipStream_t)stream, dy, w_krsc, dx, N, H, W, C, K, R, S, Ho, Wo, sh, sw, ph, pw, dh, dw, groups);
@@ -569,7 +642,7 @@ int mv_avgpool_global_bwd_nhwc_f32(const float* dy, float* dx, int N, int HW, in
 int mv_colsum_f32(const float* a, const float* b, float* out, int64_t M, int C, mv_stream_t stream) {
     MV_CHECK_ARG(a && out && M > 0 && C > 0, "colsum: bad arguments");
     // many rows, few columns (bias / BatchNorm gradients over a feature map): rows split over blocks, parts in the caller's scratch
-    long long split = M >= 4096 ? (M + 1023) / 1024 : 1;
+    long long split = M >= 512 ? (M + 255) / 256 : 1;
     if (split > 512) split = 512;
     if (split > 1) {
         float* part = (float*)take_scratch((hipStream_t)stream, (size_t)split * C * 4);

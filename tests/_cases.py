@@ -416,7 +416,7 @@ def colsum_case(M, C, seed=0, product=False):
         L.call("mv_set_scratch", None, 0, _stream())
         tol = 2e-5 * np.sqrt(M)
         i0, i1 = _cmp(host(outs[0]), ref, tol), _cmp(host(outs[1]), ref, tol)
-        split_taken = kerns[1] == "colsum_split_f32" or M < 4096
+        split_taken = kerns[1] == "colsum_split_f32" or M < 512
         return {"ok": bool(i0["ok"] and i1["ok"] and torch.equal(outs[1], outs[2]) and split_taken and kerns[0] == "colsum_f32"),
                 "err": max(i0["err"], i1["err"]), "kernels": kerns}
     return run

@@ -1,3 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1500 python tools/gpu_check.py grad/ > gpurun_out/grad_check.log 2>&1; grep -c PASS gpurun_out/grad_check.log; grep -v PASS gpurun_out/grad_check.log | cut -c1-300 | tail -5; grep -o "grad/[a-z0-9_A-Z]*  {\"s\": [0-9.]*, \"err\": [0-9.e-]*, \"rel_l2\": [0-9.e-]*, \"tensors_over_lim\": [0-9]*" gpurun_out/grad_check.log
-timeout 1500 python -m pytest tests -m gpu -q --deselect "tests/test_gpu_parity.py::test_grad" 2>&1 | tail -3
+timeout 1500 python tools/gpu_check.py bwd/ grad/ > gpurun_out/bwd_check.log 2>&1; grep -c PASS gpurun_out/bwd_check.log; grep -v PASS gpurun_out/bwd_check.log | cut -c1-500 | tail -8
+for m in "alexnet 8" "resnet18 8" "resnet50 4" "vit_tiny 8" "swin_t 4"; do timeout 600 python tools/time_train_step.py $m 3 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" | tail -1; done | tee gpurun_out/train_step_times4.txt
