@@ -1,3 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1500 python tools/gpu_check.py bwd/ grad/ > gpurun_out/bwd_check.log 2>&1; grep -c PASS gpurun_out/bwd_check.log; grep -v PASS gpurun_out/bwd_check.log | cut -c1-500 | tail -8
-for m in "alexnet 8" "resnet18 8" "resnet50 4" "vit_tiny 8" "swin_t 4"; do timeout 600 python tools/time_train_step.py $m 3 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" | tail -1; done | tee gpurun_out/train_step_times4.txt
+mkdir -p gpurun_out/tune
+for m in "resnet50 256" "swin_t 128"; do
+  timeout 1500 python tools/tune_tiles.py $m 2 2>&1 | grep -v amdgpu.ids | tee gpurun_out/tune/${m%% *}.txt | tail -25
+done
