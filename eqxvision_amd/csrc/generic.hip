@@ -76,7 +76,8 @@ static int conv_generic_launch(const void* x, const void* w, const float* scale,
 // the same contraction in fp32 on the matrix cores (v_mfma_f32_32x32x2_f32): the fp32 compute mode and the training step (both
 // passes run in fp32) spend their time here.  One wave = 32 output channels x 32 output positions; A = weights (lane: channel fr,
 // reduction element fh), B = the positions' input rows; a lane loads FOUR consecutive reduction channels at once (its half of a group
-// of eight), which feeds four MFMA steps.  Channels-last x and w only (the reduction index contiguous in both); groups = 1.
+// of eight), which feeds four MFMA steps when the reduction index is contiguous in both operands (channels-last); any other layout
+// (the NCHW image + OIHW filter of the entry convolutions) takes two strided scalars per step.  groups = 1.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
@@ -91,8 +92,8 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
     const int wo = (int)(mm % p.Wo), ho = (int)((mm / p.Wo) % p.Ho), n = (int)(mm / ((long long)p.Wo * p.Ho));
     const bool kok = k0 + fr < p.K;
     const float* wk = w + (long long)(kok ? k0 + fr : 0) * p.swk;
-    const bool vec = (p.C & 3) == 0 && (p.sxn & 3) == 0 && (p.sxh & 3) == 0 && (p.sxw & 3) == 0 && (p.swk & 3) == 0 && (p.swr & 3) == 0 &&
-                     (p.sws & 3) == 0;
+    const bool vec = p.sxc == 1 && p.swc == 1 && (p.C & 3) == 0 && (p.sxn & 3) == 0 && (p.sxh & 3) == 0 && (p.sxw & 3) == 0 &&
+                     (p.swk & 3) == 0 && (p.swr & 3) == 0 && (p.sws & 3) == 0;
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -118,8 +119,8 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
                 for (int c0 = 0; c0 < p.C; c0 += 2) {
                     const int c = c0 + fh;
                     const bool cin = c < p.C;
-                    const float a = (kok && cin) ? wp[c] : 0.f;
-                    const float b = (inside && cin) ? xp[c] : 0.f;
+                    const float a = (kok && cin) ? wp[c * p.swc] : 0.f;       // any layout: NCHW images + OIHW filters (the entry convolutions)
+                    const float b = (inside && cin) ? xp[c * p.sxc] : 0.f;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
                 }
             }
@@ -149,11 +150,148 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
         }
 }
 
+// The same contraction with both operands staged through LDS: a block = 64 channels x 256 positions, a wave = 64 x 64 (2 x 2 MFMA
+// tiles); the reduction runs in chunks of 32 channels of one filter tap: 8 KB of weights + 32 KB of input rows per chunk, fetched
+// as whole 128-byte rows (eight lanes per row), double-buffered (the next chunk travels global -> registers while this one
+// multiplies, then registers -> LDS behind one barrier).  Rows are padded to 36 floats: conflict-free ds_read_b128 fragments.
+// Needs 16-byte-aligned rows (C and all strides multiples of 4); dispatched from 128 reduction channels per tap up (vit_base fp32 +23 %,
+// resnet50 +3 %; below that -- Swin stages 0-1, AlexNet -- the direct kernel's many small waves win by 3-6 %).
+__global__ __launch_bounds__(256) void conv_f32_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ residual, float* __restrict__ y,
+                                                           const float* __restrict__ pos, ConvP p) {
+    constexpr int RP = 36, WROWS = 64, XROWS = 256, STAGE = (WROWS + XROWS) * RP;       // floats per stage
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    const long long m0 = (long long)blockIdx.x * XROWS;
+    const int k0 = blockIdx.y * WROWS;
+    // loader role: thread t fetches float4 number (t & 7) of rows (t >> 3) + 32 i
+    const int lrow = tid >> 3, lq = tid & 7;
+    int xn[8], xho[8], xwo[8];
+    bool xok[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const long long m = m0 + lrow + 32 * i;
+        xok[i] = m < M;
+        const long long mm = xok[i] ? m : 0;
+        xwo[i] = (int)(mm % p.Wo); xho[i] = (int)((mm / p.Wo) % p.Ho); xn[i] = (int)(mm / ((long long)p.Wo * p.Ho));
+    }
+    const int cpt = (p.C + 31) / 32;                                   // chunks per filter tap
+    const int nchunk = p.R * p.S * cpt;
+    float4 gx[8], gw[2];
+    auto fetch = [&](int ch) {
+        const int tap = ch / cpt, c0 = (ch - tap * cpt) * 32 + 4 * lq;
+        const int r = tap / p.S, s_ = tap - r * p.S;
+        const bool cin = c0 < p.C;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int hi = xho[i] * p.sh - p.ph + r * p.dh, wi = xwo[i] * p.sw - p.pw + s_ * p.dw;
+            const bool in = xok[i] && cin && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            gx[i] = in ? *(const float4*)(x + xn[i] * p.sxn + hi * p.sxh + wi * p.sxw + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + lrow + 32 * i;
+            gw[i] = (k < p.K && cin) ? *(const float4*)(w + (long long)k * p.swk + r * p.swr + s_ * p.sws + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int buf) {
+        float* base = lds + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *(float4*)(base + (lrow + 32 * i) * RP + 4 * lq) = gw[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(float4*)(base + (WROWS + lrow + 32 * i) * RP + 4 * lq) = gx[i];
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunk) fetch(ch + 1);
+        const float* wl = lds + buf * STAGE + fr * RP + 4 * fh;
+        const float* xl = lds + buf * STAGE + (WROWS + 64 * wave + fr) * RP + 4 * fh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                   // 8 reduction channels per step: a lane holds its half of 4
+            float4 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *(const float4*)(wl + 32 * t * RP + 8 * j);
+                b[t] = *(const float4*)(xl + 32 * t * RP + 8 * j);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    acc[kt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt].x, b[pt].x, acc[kt][pt], 0, 0, 0);
+                    acc[kt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt].y, b[pt].y, acc[kt][pt], 0, 0, 0);
+                    acc[kt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt].z, b[pt].z, acc[kt][pt], 0, 0, 0);
+                    acc[kt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt].w, b[pt].w, acc[kt][pt], 0, 0, 0);
+                }
+        }
+        if (ch + 1 < nchunk) {
+            stash(buf ^ 1);                                             // its last reader finished before the previous barrier
+            __syncthreads();
+        }
+    }
+    // epilogue: acc[kt][pt][4 q + i] = channel k0 + 32 kt + 8 q + 4 fh + i of position m0 + 64 wave + 32 pt + fr
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const long long m = m0 + 64 * wave + 32 * pt + fr;
+        if (m >= M) continue;
+        long long row = m;
+        int pix = 0;
+        if (p.tok_stride > 0) {
+            const int wo = (int)(m % p.Wo), ho = (int)((m / p.Wo) % p.Ho), n = (int)(m / ((long long)p.Wo * p.Ho));
+            pix = ho * p.Wo + wo;
+            row = (long long)n * p.tok_stride + p.tok_offset + pix;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = k0 + 32 * kt + 8 * q + 4 * fh + i;
+                    if (k >= p.K) continue;
+                    float v = acc[kt][pt][4 * q + i];
+                    if (scale) v *= scale[k];
+                    if (shift) v += shift[k];
+                    if (p.tok_stride > 0 && pos) v += pos[(long long)(p.tok_offset + pix) * p.K + k];
+                    if (residual) v += residual[row * p.K + k];
+                    v = apply_act_rt(v, p.act);
+                    y[row * p.K + k] = v;
+                }
+    }
+}
+
 static int conv_generic_dispatch(const void* x, const void* w, const float* scale, const float* shift,
                                  const void* residual, void* y, const float* pos, const ConvP& p, int x_dtype,
                                  int w_dtype, int y_dtype, hipStream_t st) {
-    if (x_dtype == MV_F32 && w_dtype == MV_F32 && y_dtype == MV_F32 && p.groups == 1 && p.sxc == 1 && p.swc == 1 && p.K >= 8 &&
-        !get_flag("no_f32_mfma")) {
+    if (x_dtype == MV_F32 && w_dtype == MV_F32 && y_dtype == MV_F32 && p.groups == 1 && p.sxc == 1 && p.swc == 1 && p.K >= 32 && p.C >= 128 &&
+        (p.C & 3) == 0 && (p.sxn & 3) == 0 && (p.sxh & 3) == 0 && (p.sxw & 3) == 0 && (p.swk & 3) == 0 && (p.swr & 3) == 0 &&
+        (p.sws & 3) == 0 && (long long)p.N * p.Ho * p.Wo >= 1024 && !get_flag("no_f32_mfma") && !get_flag("no_f32_lds")) {
+        const long long M = (long long)p.N * p.Ho * p.Wo;
+        constexpr int SMEM = 2 * (64 + 256) * 36 * 4;
+        set_kernel_name("conv_f32_lds_mfma");
+        static bool attr_set = false;
+        if (!attr_set) {
+            MV_HIP(hipFuncSetAttribute((const void*)conv_f32_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(conv_f32_lds_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)((p.K + 63) / 64)), dim3(256), SMEM, st,
+                           (const float*)x, (const float*)w, scale, shift, (const float*)residual, (float*)y, pos, p);
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+    }
+    if (x_dtype == MV_F32 && w_dtype == MV_F32 && y_dtype == MV_F32 && p.groups == 1 && p.K >= 8 && !get_flag("no_f32_mfma")) {
         const long long M = (long long)p.N * p.Ho * p.Wo;
         set_kernel_name("conv_f32_mfma");
         hipLaunchKernelGGL(conv_f32_mfma_kernel, dim3((unsigned)((M + 127) / 128), (unsigned)((p.K + 31) / 32)), dim3(256), 0, st,
