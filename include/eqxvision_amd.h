@@ -433,7 +433,9 @@ int mv_cast(const void* x, void* y, int64_t n, int in_dtype, int out_dtype, mv_s
  * contraction on other operands (Linear dgrad / wgrad, the four products of attention's backward) go through mv_linear_fwd on
  * operands transposed with mv_transpose2d_f32 (eqxvision_amd/grad.py); these entries are the gradient kernels with no forward twin. */
 /* Conv2d (eqx.nn.Conv2d incl. grouped / depthwise): dx[N,H,W,C] from dy[N,Ho,Wo,K] and w [K][R][S][C/groups]; dw in the same
- * layout from x and dy. */
+ * layout from x and dy.  Both run on the fp32 matrix cores (dgrad: groups = 1).  The weight gradient's reduction runs over all
+ * N Ho Wo output positions: with scratch on offer (mv_set_scratch, any size from 2 x the gradient's bytes up) the positions are split
+ * over blocks and the parts added in a fixed order (bit-reproducible); without it one block walks all positions of its tile. */
 int mv_conv2d_dgrad_nhwc_f32(const float* dy, const float* w_krsc, float* dx, int N, int H, int W, int C, int K, int R, int S,
                              int sh, int sw, int ph, int pw, int dh, int dw, int groups, mv_stream_t stream);
 int mv_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw_krsc, int N, int H, int W, int C, int K, int R, int S,
@@ -445,7 +447,8 @@ int mv_maxpool2d_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int N,
                               int ph, int pw, mv_stream_t stream);
 /* AdaptiveAvgPool2d((1,1)) backward: dx[n,h,w,c] = dy[n,c] / (H W). */
 int mv_avgpool_global_bwd_nhwc_f32(const float* dy, float* dx, int N, int HW, int C, mv_stream_t stream);
-/* out[c] = sum over the M rows of a[m,c] * (b ? b[m,c] : 1): bias / beta gradients (b = NULL), gamma gradients (b = x_hat). */
+/* out[c] = sum over the M rows of a[m,c] * (b ? b[m,c] : 1): bias / beta gradients (b = NULL), gamma gradients (b = x_hat).  From 512
+ * rows up it takes ceil(M / 256) (<= 512) x C floats of scratch when on offer (mv_set_scratch): rows split over blocks, fixed-order finish. */
 int mv_colsum_f32(const float* a, const float* b, float* out, int64_t M, int C, mv_stream_t stream);
 /* y = x * s[b, c] (SqueezeExcitation's multiply, DropPath): ds[b, c] = sum over the image's HW positions of g * x; dx is the
  * forward multiply applied to g (mv_channel_scale_nhwc_fwd). */
