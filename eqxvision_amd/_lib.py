@@ -185,6 +185,7 @@ COMM_ID_BYTES = 128
 def set_recording(rec):
     old = getattr(_tls, "rec", None)
     _tls.rec = rec
+    _tls.pending_scratch = None        # a hand-over never outlives the recording it was made in
     return old
 
 
