@@ -124,6 +124,7 @@ PROTOTYPES = {
     "mv_bn_dgamma_f32": [_vp, _vp, _vp, _vp, _f, _vp, _i, _vp],
     "mv_layernorm_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp],
     "mv_softmax_bwd_f32": [_vp, _vp, _vp, _i64, _i, _f, _vp],
+    "mv_mha_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "mv_softmax_xent_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "mv_adam_step_f32": [_vp, _vp, _vp, _vp, _i64] + [_f] * 6 + [_vp],
     "mv_transpose2d_f32": [_vp, _vp, _i, _i, _i64, _vp],

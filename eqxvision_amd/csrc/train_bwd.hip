@@ -351,6 +351,64 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
     for (int c = lane; c < cols; c += 64) ds[row * cols + c] = scale * p[row * cols + c] * (dp[row * cols + c] - s);
 }
 
+// Attention backward (vit.py:64-73: softmax(q k^T scale) v with the probabilities kept) in two launches.
+//   query side: one wave per (image, head, query i): dP_ij = dO_i . V_j, dS_ij = scale P_ij (dP_ij - sum_j P_ij dP_ij) -> ds[b,h,i,:]
+//               (kept for the key side) and dQ_i = sum_j dS_ij K_j
+//   key side:   one wave per (image, head, key j): dK_j = sum_i dS_ij Q_i, dV_j = sum_i P_ij dO_i
+// qkv / dqkv rows are [q | k | v][head][dh] (3 D floats per token), dO rows D floats.  Every sum runs in index order: reproducible.
+__global__ __launch_bounds__(64) void mha_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
+                                                       const float* __restrict__ dout, float* __restrict__ ds, float* __restrict__ dqkv,
+                                                       int N, int H, int dh, float scale) {
+    extern __shared__ float sm[];                          // [dh] dO_i, then [N] dS_i
+    float* go = sm;
+    float* dsr = sm + dh;
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const int D = H * dh;
+    const long long tok0 = (long long)b * N;
+    for (int d = lane; d < dh; d += 64) go[d] = dout[(tok0 + i) * D + h * dh + d];
+    __syncthreads();
+    const float* prow = probs + (((long long)b * H + h) * N + i) * N;
+    float t = 0.f;
+    for (int j = lane; j < N; j += 64) {
+        const float* v = qkv + (tok0 + j) * 3 * D + 2 * D + h * dh;
+        float dp = 0.f;
+        for (int d = 0; d < dh; ++d) dp = fmaf(go[d], v[d], dp);
+        dsr[j] = dp;
+        t = fmaf(prow[j], dp, t);
+    }
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    float* dsg = ds + (((long long)b * H + h) * N + i) * N;
+    for (int j = lane; j < N; j += 64) {
+        const float v = scale * prow[j] * (dsr[j] - t);
+        dsr[j] = v;
+        dsg[j] = v;
+    }
+    __syncthreads();
+    for (int d = lane; d < dh; d += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < N; ++j) acc = fmaf(dsr[j], qkv[(tok0 + j) * 3 * D + D + h * dh + d], acc);
+        dqkv[(tok0 + i) * 3 * D + h * dh + d] = acc;
+    }
+}
+__global__ __launch_bounds__(64) void mha_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
+                                                        const float* __restrict__ dout, const float* __restrict__ ds,
+                                                        float* __restrict__ dqkv, int N, int H, int dh) {
+    const int j = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const int D = H * dh;
+    const long long tok0 = (long long)b * N;
+    const float* pcol = probs + ((long long)b * H + h) * N * N + j;
+    const float* dcol = ds + ((long long)b * H + h) * N * N + j;
+    for (int d = lane; d < dh; d += 64) {
+        float dk = 0.f, dv = 0.f;
+        for (int i = 0; i < N; ++i) {
+            dk = fmaf(dcol[(long long)i * N], qkv[(tok0 + i) * 3 * D + h * dh + d], dk);
+            dv = fmaf(pcol[(long long)i * N], dout[(tok0 + i) * D + h * dh + d], dv);
+        }
+        dqkv[(tok0 + j) * 3 * D + D + h * dh + d] = dk;
+        dqkv[(tok0 + j) * 3 * D + 2 * D + h * dh + d] = dv;
+    }
+}
+
 // optax.softmax_cross_entropy(logits, onehot).mean(): loss = mean_b (logsumexp(l_b) - sum_k t_bk l_bk); dlogits = (softmax - t) / B
 __global__ __launch_bounds__(64) void softmax_xent_kernel(const float* __restrict__ logits, const float* __restrict__ target,
                                                            float* __restrict__ loss_rows, float* __restrict__ dlogits, int B, int K) {
@@ -697,6 +755,20 @@ int mv_softmax_bwd_f32(const float* p, const float* dp, float* ds, int64_t rows,
     set_kernel_name("softmax_bwd_f32");
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, dp, ds,
                        (long long)rows, cols, scale);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_mha_bwd_f32(const float* qkv, const float* probs, const float* dout, float* ds_scratch, float* dqkv, int B, int N, int H, int dh,
+                   float scale, mv_stream_t stream) {
+    MV_CHECK_ARG(qkv && probs && dout && ds_scratch && dqkv && B > 0 && N > 0 && H > 0 && dh > 0 && B <= 65535 && H <= 65535,
+                 "mha_bwd: bad arguments");
+    MV_CHECK_ARG((size_t)(dh + N) * 4 <= 64 * 1024, "mha_bwd: N = %d tokens do not fit the row buffer", N);
+    set_kernel_name("mha_bwd_f32");
+    const dim3 grid((unsigned)N, (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL(mha_bwd_q_kernel, grid, dim3(64), (size_t)(dh + N) * 4, (hipStream_t)stream, qkv, probs, dout, ds_scratch, dqkv, N, H,
+                       dh, scale);
+    hipLaunchKernelGGL(mha_bwd_kv_kernel, grid, dim3(64), 0, (hipStream_t)stream, qkv, probs, dout, ds_scratch, dqkv, N, H, dh);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

@@ -658,8 +658,8 @@ def g_patch_embed_tokens(x: Act, conv, cls, pos, n_extra: int, out_fp32: bool = 
 
 @_op
 def g_qkv_attention(x: Act, lin, heads: int, scale: float, need_probs: bool, drop=None):
-    """qkv Linear + softmax(q k^T scale) v (vit.py:64-73) with the probabilities kept for the backward pass, whose four products
-    per (image, head) -- dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q -- run through the forward Linear entry."""
+    """qkv Linear + softmax(q k^T scale) v (vit.py:64-73) with the probabilities kept for the backward pass: dP = dO V^T, the softmax
+    gradient, dQ = dS K, dK = dS^T Q, dV = P^T dO in two launches (mv_mha_bwd_f32)."""
     if drop is not None:
         raise NotImplementedError("attention dropout has no backward yet")
     B, N, D = x.t.shape
@@ -670,28 +670,10 @@ def g_qkv_attention(x: Act, lin, heads: int, scale: float, need_probs: bool, dro
     _call("mv_mha_fwd", _p(qkv.t), _p(out), _p(probs), B, N, heads, dh, float(scale), F32, _S())
     qt = qkv.t
 
-    def piece(base: torch.Tensor, b: int, col: int, pitch: int) -> torch.Tensor:
-        """Contiguous [N, dh] copy of rows b*N .. of `base` (row pitch `pitch` floats) starting at column `col`."""
-        y = _new((N, dh))
-        _call("mv_copy_rows", base.data_ptr() + 4 * (b * N * pitch + col), _p(y), N, 4 * dh, 4 * pitch, 4 * dh, _S())
-        return y
-
     def backward(g):                                                      # g [B, N, D]
         dqkv = _new((B, N, 3 * D))
-        for b in range(B):
-            for h in range(heads):
-                q, k, v = (piece(qt, b, s * D + h * dh, 3 * D) for s in range(3))
-                do = piece(g, b, h * dh, D)
-                p = probs[b, h]                                           # [N, N] contiguous view
-                dv = _matmul_nt(_transpose(p, N, N), _transpose(do, N, dh), N, dh, N)          # P^T dO
-                dp = _matmul_nt(do, v, N, N, dh)                                               # dO V^T
-                ds = _new((N, N))
-                _call("mv_softmax_bwd_f32", _p(p), _p(dp), _p(ds), N, N, float(scale), _S())
-                dq = _matmul_nt(ds, _transpose(k, N, dh), N, dh, N)                            # dS K
-                dk = _matmul_nt(_transpose(ds, N, N), _transpose(q, N, dh), N, dh, N)          # dS^T Q
-                for s, d in enumerate((dq, dk, dv)):
-                    _call("mv_copy_rows", _p(d), dqkv.data_ptr() + 4 * (b * N * 3 * D + s * D + h * dh), N, 4 * dh, 4 * dh,
-                          4 * 3 * D, _S())
+        ds = _new((B, heads, N, N))
+        _call("mv_mha_bwd_f32", _p(qt), _p(probs), _p(g), _p(ds), _p(dqkv), B, N, heads, dh, float(scale), _S())
         return (dqkv,)
     y = _mk(out, "seq", x.batched, [_node(qkv)], backward)
     return y, (probs if need_probs else None)

@@ -447,6 +447,11 @@ int mv_maxpool2d_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int N,
                               int ph, int pw, mv_stream_t stream);
 /* AdaptiveAvgPool2d((1,1)) backward: dx[n,h,w,c] = dy[n,c] / (H W). */
 int mv_avgpool_global_bwd_nhwc_f32(const float* dy, float* dx, int N, int HW, int C, mv_stream_t stream);
+/* Attention backward (vit.py:64-73, the op of mv_mha_fwd with the probabilities kept): dqkv[B,N,3,H,dh] from qkv (same layout),
+ * probs[B,H,N,N] and dout[B,N,H*dh]; ds_scratch: B*H*N*N floats owned by the caller (the softmax gradient, written by the first of the
+ * two launches and read by the second).  Every sum runs in index order. */
+int mv_mha_bwd_f32(const float* qkv, const float* probs, const float* dout, float* ds_scratch, float* dqkv, int B, int N, int H, int dh,
+                   float scale, mv_stream_t stream);
 /* out[c] = sum over the M rows of a[m,c] * (b ? b[m,c] : 1): bias / beta gradients (b = NULL), gamma gradients (b = x_hat).  From 512
  * rows up it takes ceil(M / 256) (<= 512) x C floats of scratch when on offer (mv_set_scratch): rows split over blocks, fixed-order finish. */
 int mv_colsum_f32(const float* a, const float* b, float* out, int64_t M, int C, mv_stream_t stream);

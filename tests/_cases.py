@@ -393,6 +393,35 @@ def conv_bwd_case(N, H, W, C, K, R, stride=1, pad=0, dil=1, seed=0, groups=1):
     return run
 
 
+def mha_bwd_case(B, N, H, dh, seed=0):
+    """mv_mha_bwd_f32 (two launches) vs torch.autograd of softmax(q k^T scale) v on the same qkv rows [q | k | v][head][dh]."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        D = H * dh
+        qkv = rng.standard_normal((B, N, 3 * D)).astype(np.float32)
+        g = rng.standard_normal((B, N, D)).astype(np.float32)
+        scale = dh ** -0.5
+        t = torch.from_numpy(qkv).requires_grad_(True)
+        q, k, v = (t[:, :, i * D:(i + 1) * D].reshape(B, N, H, dh).permute(0, 2, 1, 3) for i in range(3))
+        pr = torch.softmax(q @ k.transpose(-1, -2) * scale, -1)
+        out = (pr @ v).permute(0, 2, 1, 3).reshape(B, N, D)
+        out.backward(torch.from_numpy(g))
+        ref = t.grad.numpy()
+        qd, gd = dev(qkv, "fp32"), dev(g, "fp32")
+        od = torch.empty((B, N, D), device="cuda")
+        pd = torch.empty((B, H, N, N), device="cuda")
+        L.call("mv_mha_fwd", qd.data_ptr(), od.data_ptr(), pd.data_ptr(), B, N, H, dh, float(scale), 0, _stream())
+        ds = torch.empty((B, H, N, N), device="cuda")
+        dq = torch.full((B, N, 3 * D), -7.0, device="cuda")
+        L.call("mv_mha_bwd_f32", qd.data_ptr(), pd.data_ptr(), gd.data_ptr(), ds.data_ptr(), dq.data_ptr(), B, N, H, dh, float(scale), _stream())
+        torch.cuda.synchronize()
+        a = _cmp(host(od), out.detach().numpy(), TOL_F32)
+        b = _cmp(host(dq), ref, TOL_F32)
+        return {"ok": a["ok"] and b["ok"], "err": b["err"], "fwd": a, "kernel": L.last_kernel()}
+    return run
+
+
 def colsum_case(M, C, seed=0, product=False):
     """mv_colsum_f32 (bias / BatchNorm gradients): out[c] = sum_m a[m, c] (* b[m, c]) -- the single-block-per-64-columns kernel and, with
     scratch on offer, the row-split kernel + fixed-order finish: both vs float64, the split one repeatable bit for bit."""
@@ -2334,6 +2363,9 @@ def all_cases():
           ("bwd/colsum_100k_x_64", colsum_case(100352, 64, seed=62)),
           ("bwd/colsum_product_5000_x_200", colsum_case(5000, 200, seed=63, product=True)),
           ("bwd/colsum_small", colsum_case(300, 10, seed=64)),
+          ("bwd/mha_197_dh64", mha_bwd_case(2, 197, 3, 64, seed=65)),
+          ("bwd/mha_50_dh32", mha_bwd_case(3, 50, 4, 32, seed=66)),
+          ("bwd/mha_17_dh96", mha_bwd_case(1, 17, 2, 96, seed=67)),
           ("bwd/maxpool_3x3_s2", maxpool_bwd_case(2, 27, 27, 64, 3, 2, 0, seed=41)),
           ("bwd/maxpool_3x3_s2_p1", maxpool_bwd_case(2, 28, 28, 64, 3, 2, 1, seed=42)),
           ("bwd/maxpool_2x2_s2", maxpool_bwd_case(1, 56, 56, 256, 2, 2, 0, seed=43)),

@@ -1,11 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 2500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|FAILED" | tail -3
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-( time timeout 600 python bench.py > gpurun_out/bench_default_line.json 2> gpurun_out/bench_default.err ) 2>&1 | grep real
-cut -c1-900 gpurun_out/bench_default_line.json
-python - <<'PY'
-import json
-d=json.load(open("gpurun_out/bench_default_line.json"))
-print({k:(v.get("value") if isinstance(v,dict) else v) for k,v in d.get("extra",{}).items()} if isinstance(d.get("extra"),dict) else d.get("extra"))
-print("roofline", d["roofline"]["frac"], d["roofline"].get("rocprof",{}).get("frac"), "cpu_baseline", d.get("cpu_baseline"))
-PY
+timeout 1500 python tools/gpu_check.py bwd/ grad/ > gpurun_out/bwd_check.log 2>&1; grep -c PASS gpurun_out/bwd_check.log; grep -v PASS gpurun_out/bwd_check.log | cut -c1-500 | tail -8
+for m in "vit_tiny 8" "vit_base 4" "resnet18 8"; do timeout 600 python tools/time_train_step.py $m 3 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" | tail -1; done | tee gpurun_out/train_step_times5.txt
