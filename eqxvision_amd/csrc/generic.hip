@@ -441,6 +441,109 @@ __global__ void swin_attn_generic_kernel(const T* __restrict__ qkv, const float*
 }
 
 // ------------------------------------------------------------------------------------------
+// fp32 attention with the keys and values of one (image, head [, window]) in LDS: the generic kernels above re-read every K and V row
+// from global memory for every query (one wave per query); here a block stages them once (rows padded to dh + 1 floats:
+// conflict-free column walks) and its four waves share them.  SWIN: the tokens of a window, gathered through the cyclic shift,
+// relative-position bias + region mask (swin.py:90-255); else the N tokens of an image, optional probabilities out (vit.py:64-73).
+// The fp32 compute mode and the training step's forward run here.
+// ------------------------------------------------------------------------------------------
+struct AttnF32P {
+    int n, dh, H, C;                 // tokens per group, head width, heads, channels (H * dh)
+    int Hf, Wf, wsh, wsw, shh, shw;  // SWIN only
+    float scale;
+};
+template <bool SWIN>
+__global__ __launch_bounds__(SWIN ? 256 : 1024) void attn_f32_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                           float* __restrict__ out, float* __restrict__ probs, const AttnF32P p) {
+    extern __shared__ float sm[];
+    const int n = p.n, dh = p.dh, DP = dh + 1, C = p.C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = SWIN ? 256 : 1024, NW = NT / 64;     // an image's 197 x 64 keys and values fill most of the LDS: one block per CU, so
+    float* Ks = sm;                                     // it brings 16 waves; a window's 49 x 32 leave room for several 4-wave blocks
+    float* Vs = Ks + n * DP;
+    float* sc = Vs + n * DP + wave * (n + dh);          // this wave's scores, then its query
+    float* qs = sc + n;
+    const int grp = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int nWw = SWIN ? p.Wf / p.wsw : 1;
+    const int wy = SWIN ? grp / nWw : 0, wx = SWIN ? grp - wy * nWw : 0;
+    auto tok_row = [&](int j) -> long long {           // token j of the group -> its row in qkv / out
+        if (!SWIN) return (long long)b * n + j;
+        const int ty = j / p.wsw, tx = j - ty * p.wsw;
+        const int yy = (wy * p.wsh + ty + p.shh) % p.Hf, xx = (wx * p.wsw + tx + p.shw) % p.Wf;     // np.roll(x, -s)[i] = x[(i + s) % n]
+        return ((long long)b * p.Hf + yy) * p.Wf + xx;
+    };
+    auto region = [&](int j) -> int {                  // shift-mask region of token j (rolled coordinates, swin.py:190-209)
+        const int ty = j / p.wsw, tx = j - ty * p.wsw;
+        const int y = wy * p.wsh + ty, x = wx * p.wsw + tx;
+        const int rh = (y < p.Hf - p.wsh) ? 0 : (y < p.Hf - p.shh ? 1 : 2);
+        const int rw = (x < p.Wf - p.wsw) ? 0 : (x < p.Wf - p.shw ? 1 : 2);
+        return rh * 3 + rw;
+    };
+    const long long rs = 3LL * C;
+    for (int idx = tid; idx < n * dh; idx += NT) {
+        const int j = idx / dh, d = idx - j * dh;
+        const float* r = qkv + tok_row(j) * rs + h * dh + d;
+        Ks[j * DP + d] = r[C];
+        Vs[j * DP + d] = r[2 * C];
+    }
+    __syncthreads();
+    const bool shifted = SWIN && (p.shh + p.shw) > 0;
+    for (int i = wave; i < n; i += NW) {
+        const long long qrow = tok_row(i);
+        for (int d = lane; d < dh; d += 64) qs[d] = qkv[qrow * rs + h * dh + d] * p.scale;
+        wave_lds_fence();
+        const int qreg = shifted ? region(i) : 0;
+        float mx = -INFINITY;
+        for (int j = lane; j < n; j += 64) {
+            float s = 0.f;
+            for (int d = 0; d < dh; ++d) s = fmaf(qs[d], Ks[j * DP + d], s);
+            if (SWIN) {
+                s += bias[((long long)h * n + i) * n + j];
+                if (shifted && region(j) != qreg) s += -100.0f;
+            }
+            sc[j] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < n; j += 64) {
+            const float e = __expf(sc[j] - mx);
+            sc[j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        wave_lds_fence();
+        if (!SWIN && probs)
+            for (int j = lane; j < n; j += 64) probs[(((long long)b * p.H + h) * n + i) * n + j] = sc[j] * inv;
+        for (int d = lane; d < dh; d += 64) {
+            float o = 0.f;
+            for (int j = 0; j < n; ++j) o = fmaf(sc[j], Vs[j * DP + d], o);
+            out[qrow * C + h * dh + d] = o * inv;
+        }
+        wave_lds_fence();                               // before the next query overwrites this wave's scores
+    }
+}
+template <bool SWIN>
+static int attn_f32_lds_go(const float* qkv, const float* bias, float* out, float* probs, const AttnF32P& p, int groups, int B,
+                           hipStream_t st) {
+    constexpr int NW = SWIN ? 4 : 16;
+    const size_t smem = ((size_t)2 * p.n * (p.dh + 1) + NW * (size_t)(p.n + p.dh)) * sizeof(float);
+    auto kern = attn_f32_lds_kernel<SWIN>;
+    static size_t attr = 0;
+    if (smem > attr) {
+        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = smem;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)p.H, (unsigned)B), dim3(NW * 64), smem, st, qkv, bias, out, probs, p);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+static bool attn_f32_lds_fits(int n, int dh) {
+    return ((size_t)2 * n * (dh + 1) + 16 * (size_t)(n + dh)) * sizeof(float) <= 150 * 1024 && !get_flag("no_attn_f32_lds");
+}
+
+// ------------------------------------------------------------------------------------------
 // memory-bound ops
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -1559,6 +1662,13 @@ int mv_mha_fwd(const void* qkv, void* out, float* probs, int B, int N, int H, in
     if (!get_flag("force_generic") && dtype == MV_BF16 && mha_mfma_supported(N, dh, dtype))
         return mha_mfma_launch(qkv, 0, out, probs, B, N, H, dh, scale, nullptr, 1.f, st);
     MV_CHECK_ARG(H <= 65535 && B <= 65535, "mha: H/B too large for the generic kernel");
+    if (dtype == MV_F32 && !get_flag("force_generic") && attn_f32_lds_fits(N, dh) && (long long)B * H >= 128) {   // one block per (image, head):
+        AttnF32P ap;                                                                                              // fewer do not fill the chip
+        memset(&ap, 0, sizeof(ap));
+        ap.n = N; ap.dh = dh; ap.H = H; ap.C = H * dh; ap.scale = scale;
+        set_kernel_name("mha_f32_lds");
+        return attn_f32_lds_go<false>((const float*)qkv, nullptr, (float*)out, probs, ap, 1, B, st);
+    }
     const size_t smem = (size_t)(N + dh) * sizeof(float);
     MV_CHECK_ARG(smem <= 64 * 1024, "mha: sequence too long for the generic kernel (N=%d)", N);
     set_kernel_name("mha_generic");
@@ -1645,6 +1755,13 @@ int mv_swin_window_attn_fwd(const void* qkv, const float* bias, void* out, int B
     const int n = ws_h * ws_w, dh = C / heads;
     const int tokens = Hf * Wf;
     MV_CHECK_ARG(heads <= 65535 && B <= 65535, "swin_attn: grid too large");
+    if (dtype == MV_F32 && !get_flag("force_generic") && attn_f32_lds_fits(n, dh)) {
+        AttnF32P ap;
+        ap.n = n; ap.dh = dh; ap.H = heads; ap.C = C; ap.Hf = Hf; ap.Wf = Wf; ap.wsh = ws_h; ap.wsw = ws_w; ap.shh = shift_h; ap.shw = shift_w;
+        ap.scale = 1.0f / sqrtf((float)dh);
+        set_kernel_name("swin_attn_f32_lds");
+        return attn_f32_lds_go<true>((const float*)qkv, bias, (float*)out, nullptr, ap, (Hf / ws_h) * (Wf / ws_w), B, st);
+    }
     const size_t smem = (size_t)(n + dh) * sizeof(float);
     set_kernel_name("swin_attn_generic");
     if (dtype == MV_BF16)

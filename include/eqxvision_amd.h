@@ -53,7 +53,7 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  *                   two-windows-per-workgroup kernel at C = 96), "no_patch_merge_ln", "no_patch4_ln", "no_fc_stream"
  *   entry / misc    "stem_v0", "no_stem_pool", "no_stem_pool11", "no_patch_f32out", "no_ln_slim", "no_grouped64", "no_dwconv",
  *                   "dwconv_generic", "dwconv_no_tile", "dwconv_tile3", "no_oddc", "no_se_fused", "se_fused_always", "eltwise_scalar",
- *                   "affine_scalar", "dropout_x8", "dropout_scalar", "no_f32_mfma" (fp32 contractions back on the VALU kernel), "no_f32_lds" (only the direct fp32 matrix-core kernel),
+ *                   "affine_scalar", "dropout_x8", "dropout_scalar", "no_f32_mfma" (fp32 contractions back on the VALU kernel), "no_f32_lds" (only the direct fp32 matrix-core kernel), "no_attn_f32_lds" (fp32 attention back on the one-wave-per-query kernels),
  *                   "wgrad_valu" / "dgrad_valu" (the one-thread-per-element gradient kernels: cross-check)
  * The debug build (EQV_PROF=1 python -m eqxvision_amd.build -> libeqxvision_amd_prof.so) additionally reads "prof_hi" / "prof_lo"
  * (a device buffer for per-wave phase stamps), "*_prof", "i8_skew", "i8_ablate", "strip_skew", "ln_mlp_dbg": none of them exists in
