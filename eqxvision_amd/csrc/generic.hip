@@ -150,13 +150,13 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const float* __restr
         }
 }
 
-// The same contraction with both operands staged through LDS: a block = 64 channels x 256 positions, a wave = 64 x 64 (2 x 2 MFMA
-// tiles); the reduction runs in chunks of 32 channels of one filter tap: 8 KB of weights + 32 KB of input rows per chunk, fetched
+// The same contraction with both operands staged through LDS: a block = 64 channels x 256 positions, eight waves of 64 x 32 (two MFMA
+// tiles each); the reduction runs in chunks of 32 channels of one filter tap: 8 KB of weights + 32 KB of input rows per chunk, fetched
 // as whole 128-byte rows (eight lanes per row), double-buffered (the next chunk travels global -> registers while this one
 // multiplies, then registers -> LDS behind one barrier).  Rows are padded to 36 floats: conflict-free ds_read_b128 fragments.
-// Needs 16-byte-aligned rows (C and all strides multiples of 4); dispatched from 128 reduction channels per tap up (vit_base fp32 +23 %,
-// resnet50 +3 %; below that -- Swin stages 0-1, AlexNet -- the direct kernel's many small waves win by 3-6 %).
-__global__ __launch_bounds__(256) void conv_f32_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// Needs 16-byte-aligned rows (C and all strides multiples of 4); dispatched from 64 reduction channels per tap up (with four waves per
+// block it only paid from 128; eight waves: resnet50 fp32 4291 -> 5097 img/s, vit_base 1414 -> 1585, swin_t 3214 -> 3697).
+__global__ __launch_bounds__(512) void conv_f32_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ residual, float* __restrict__ y,
                                                            const float* __restrict__ pos, ConvP p) {
@@ -166,50 +166,46 @@ __global__ __launch_bounds__(256) void conv_f32_lds_kernel(const float* __restri
     const long long M = (long long)p.N * p.Ho * p.Wo;
     const long long m0 = (long long)blockIdx.x * XROWS;
     const int k0 = blockIdx.y * WROWS;
-    // loader role: thread t fetches float4 number (t & 7) of rows (t >> 3) + 32 i
+    // loader role: thread t fetches float4 number (t & 7) of rows (t >> 3) + 64 i (eight waves: two per SIMD)
     const int lrow = tid >> 3, lq = tid & 7;
-    int xn[8], xho[8], xwo[8];
-    bool xok[8];
+    int xn[4], xho[4], xwo[4];
+    bool xok[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const long long m = m0 + lrow + 32 * i;
+    for (int i = 0; i < 4; ++i) {
+        const long long m = m0 + lrow + 64 * i;
         xok[i] = m < M;
         const long long mm = xok[i] ? m : 0;
         xwo[i] = (int)(mm % p.Wo); xho[i] = (int)((mm / p.Wo) % p.Ho); xn[i] = (int)(mm / ((long long)p.Wo * p.Ho));
     }
     const int cpt = (p.C + 31) / 32;                                   // chunks per filter tap
     const int nchunk = p.R * p.S * cpt;
-    float4 gx[8], gw[2];
+    float4 gx[4], gw;
     auto fetch = [&](int ch) {
         const int tap = ch / cpt, c0 = (ch - tap * cpt) * 32 + 4 * lq;
         const int r = tap / p.S, s_ = tap - r * p.S;
         const bool cin = c0 < p.C;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int hi = xho[i] * p.sh - p.ph + r * p.dh, wi = xwo[i] * p.sw - p.pw + s_ * p.dw;
             const bool in = xok[i] && cin && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             gx[i] = in ? *(const float4*)(x + xn[i] * p.sxn + hi * p.sxh + wi * p.sxw + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int k = k0 + lrow + 32 * i;
-            gw[i] = (k < p.K && cin) ? *(const float4*)(w + (long long)k * p.swk + r * p.swr + s_ * p.sws + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+            const int k = k0 + lrow;
+            gw = (k < p.K && cin) ? *(const float4*)(w + (long long)k * p.swk + r * p.swr + s_ * p.sws + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto stash = [&](int buf) {
         float* base = lds + buf * STAGE;
+        *(float4*)(base + lrow * RP + 4 * lq) = gw;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *(float4*)(base + (lrow + 32 * i) * RP + 4 * lq) = gw[i];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *(float4*)(base + (WROWS + lrow + 32 * i) * RP + 4 * lq) = gx[i];
+        for (int i = 0; i < 4; ++i) *(float4*)(base + (WROWS + lrow + 64 * i) * RP + 4 * lq) = gx[i];
     };
-    f32x16 acc[2][2];
+    f32x16 acc[2];                                                     // a wave: 64 channels x 32 positions
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
     fetch(0);
     stash(0);
     __syncthreads();
@@ -217,35 +213,30 @@ __global__ __launch_bounds__(256) void conv_f32_lds_kernel(const float* __restri
         const int buf = ch & 1;
         if (ch + 1 < nchunk) fetch(ch + 1);
         const float* wl = lds + buf * STAGE + fr * RP + 4 * fh;
-        const float* xl = lds + buf * STAGE + (WROWS + 64 * wave + fr) * RP + 4 * fh;
+        const float* xl = lds + buf * STAGE + (WROWS + 32 * wave + fr) * RP + 4 * fh;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                                   // 8 reduction channels per step: a lane holds its half of 4
-            float4 a[2], b[2];
+            float4 a[2];
+            const float4 b = *(const float4*)(xl + 8 * j);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t] = *(const float4*)(wl + 32 * t * RP + 8 * j);
-                b[t] = *(const float4*)(xl + 32 * t * RP + 8 * j);
+            for (int t = 0; t < 2; ++t) a[t] = *(const float4*)(wl + 32 * t * RP + 8 * j);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt].x, b.x, acc[kt], 0, 0, 0);
+                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt].y, b.y, acc[kt], 0, 0, 0);
+                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt].z, b.z, acc[kt], 0, 0, 0);
+                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt].w, b.w, acc[kt], 0, 0, 0);
             }
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt) {
-                    acc[kt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt].x, b[pt].x, acc[kt][pt], 0, 0, 0);
-                    acc[kt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt].y, b[pt].y, acc[kt][pt], 0, 0, 0);
-                    acc[kt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt].z, b[pt].z, acc[kt][pt], 0, 0, 0);
-                    acc[kt][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt].w, b[pt].w, acc[kt][pt], 0, 0, 0);
-                }
         }
         if (ch + 1 < nchunk) {
             stash(buf ^ 1);                                             // its last reader finished before the previous barrier
             __syncthreads();
         }
     }
-    // epilogue: acc[kt][pt][4 q + i] = channel k0 + 32 kt + 8 q + 4 fh + i of position m0 + 64 wave + 32 pt + fr
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-        const long long m = m0 + 64 * wave + 32 * pt + fr;
-        if (m >= M) continue;
+    // epilogue: acc[kt][4 q + i] = channel k0 + 32 kt + 8 q + 4 fh + i of position m0 + 32 wave + fr
+    {
+        const long long m = m0 + 32 * wave + fr;
+        if (m >= M) return;
         long long row = m;
         int pix = 0;
         if (p.tok_stride > 0) {
@@ -261,7 +252,7 @@ __global__ __launch_bounds__(256) void conv_f32_lds_kernel(const float* __restri
                 for (int i = 0; i < 4; ++i) {
                     const int k = k0 + 32 * kt + 8 * q + 4 * fh + i;
                     if (k >= p.K) continue;
-                    float v = acc[kt][pt][4 * q + i];
+                    float v = acc[kt][4 * q + i];
                     if (scale) v *= scale[k];
                     if (shift) v += shift[k];
                     if (p.tok_stride > 0 && pos) v += pos[(long long)(p.tok_offset + pix) * p.K + k];
@@ -275,7 +266,7 @@ __global__ __launch_bounds__(256) void conv_f32_lds_kernel(const float* __restri
 static int conv_generic_dispatch(const void* x, const void* w, const float* scale, const float* shift,
                                  const void* residual, void* y, const float* pos, const ConvP& p, int x_dtype,
                                  int w_dtype, int y_dtype, hipStream_t st) {
-    if (x_dtype == MV_F32 && w_dtype == MV_F32 && y_dtype == MV_F32 && p.groups == 1 && p.sxc == 1 && p.swc == 1 && p.K >= 32 && p.C >= 128 &&
+    if (x_dtype == MV_F32 && w_dtype == MV_F32 && y_dtype == MV_F32 && p.groups == 1 && p.sxc == 1 && p.swc == 1 && p.K >= 32 && p.C >= 64 &&
         (p.C & 3) == 0 && (p.sxn & 3) == 0 && (p.sxh & 3) == 0 && (p.sxw & 3) == 0 && (p.swk & 3) == 0 && (p.swr & 3) == 0 &&
         (p.sws & 3) == 0 && (long long)p.N * p.Ho * p.Wo >= 1024 && !get_flag("no_f32_mfma") && !get_flag("no_f32_lds")) {
         const long long M = (long long)p.N * p.Ho * p.Wo;
@@ -286,7 +277,7 @@ static int conv_generic_dispatch(const void* x, const void* w, const float* scal
             MV_HIP(hipFuncSetAttribute((const void*)conv_f32_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
             attr_set = true;
         }
-        hipLaunchKernelGGL(conv_f32_lds_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)((p.K + 63) / 64)), dim3(256), SMEM, st,
+        hipLaunchKernelGGL(conv_f32_lds_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)((p.K + 63) / 64)), dim3(512), SMEM, st,
                            (const float*)x, (const float*)w, scale, shift, (const float*)residual, (float*)y, pos, p);
         MV_LAUNCH_CHECK();
         return MV_OK;
