@@ -35,6 +35,7 @@ struct SwinBAP {
     float* y;
     int Hf, Wf, shh, shw, nWw, nW;
     float eps;
+    int ablate;            // debug build only (w96_ablate): 1 no weight streaming, 2 no bias rows, 4 no stores, 8 no gather
     long long* prof;       // experiments only (tools/time_swin_block_attn.py): per-wave wall-clock stamps at the phase boundaries
 };
 
@@ -409,8 +410,8 @@ __global__ __launch_bounds__(128, 3) void swin_win96_kernel(const SwinBAP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);              // = token block of the window
     const int fr = lane & 31, fh = lane >> 5;
     const int b = blockIdx.x / p.nW, wloc = blockIdx.x - b * p.nW;
-#ifdef MV_I8_PROF
-    long long st_w[8];
+#ifdef MV_W96_STAMPS          // per-wave phase stamps: 16 more registers, the kernel spills at three waves per SIMD -- build with -DMV_W96_STAMPS
+    long long st_w[8];       // and __launch_bounds__(128, 2) to take them (profiles/r04/swin_c96_attn_pmc_new_vs_old.txt was taken that way)
     int nst = 0;
 #define MV_W96_STAMP() do { if (p.prof && nst < 8) st_w[nst++] = wall_clock64(); } while (0)
 #else
@@ -440,7 +441,11 @@ __global__ __launch_bounds__(128, 3) void swin_win96_kernel(const SwinBAP p) {
     // ---- gather + LayerNorm: B fragments of the qkv GEMM, and the residual in accumulator layout
     float raw[KS][8];
     {
+#ifdef MV_I8_PROF
+        const float* src = p.x + ((p.ablate & 8) ? (long long)(lane * 96) : row) + 8 * fh;
+#else
         const float* src = p.x + row + 8 * fh;
+#endif
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
             const float4 a = *(const float4*)(src + 16 * j), c = *(const float4*)(src + 16 * j + 4);
@@ -509,7 +514,11 @@ __global__ __launch_bounds__(128, 3) void swin_win96_kernel(const SwinBAP p) {
         for (int j = 0; j < KS; ++j) {
             const int i = u * KS + j;
             const uint4 a = wb[i % RING];
+#ifdef MV_I8_PROF
+            if (i + LOOK < NF) wb[(i + LOOK) % RING] = wq[((p.ablate & 1) ? 0 : (i + LOOK)) * 64];
+#else
             if (i + LOOK < NF) wb[(i + LOOK) % RING] = wq[(i + LOOK) * 64];
+#endif
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, xf[j]), acc, 0, 0, 0);
         }
         const float* bb = p.bqkv + u * 32 + 4 * fh;
@@ -561,7 +570,11 @@ __global__ __launch_bounds__(128, 3) void swin_win96_kernel(const SwinBAP p) {
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
+#ifdef MV_I8_PROF
+            for (int j = 0; j < 2; ++j) wpf[ct][j] = wpq[((p.ablate & 1) ? 0 : (ct * KS + 2 * h + j)) * 64];
+#else
             for (int j = 0; j < 2; ++j) wpf[ct][j] = wpq[(ct * KS + 2 * h + j) * 64];
+#endif
         const char* kp = smem + LDS_K + (h * 64 + fr) * QROW + fh * 32;
         f32x16 s[2];
 #pragma unroll
@@ -581,7 +594,11 @@ __global__ __launch_bounds__(128, 3) void swin_win96_kernel(const SwinBAP p) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int key0 = 32 * kt + 8 * gq + 4 * fh;
+#ifdef MV_I8_PROF
+                const float4 bv = *(const float4*)(brow + ((p.ablate & 2) ? 4 * fh : key0));
+#else
                 const float4 bv = *(const float4*)(brow + key0);
+#endif
                 const int4 kr = *(const int4*)(rl + key0);
                 const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
                 const int rr[4] = {kr.x, kr.y, kr.z, kr.w};
@@ -641,20 +658,37 @@ __global__ __launch_bounds__(128, 3) void swin_win96_kernel(const SwinBAP p) {
             }
         MV_W96_STAMP();                                   // 4, 5, 6: head h (attention + proj slice)
     }
-    // ---- epilogue: + proj bias, to the token's own position (window reverse + roll back = where it was gathered from)
-    if (real) {
-        float* yr = p.y + row + 4 * fh;
+    // ---- epilogue: + proj bias, to the token's own position (window reverse + roll back = where it was gathered from).  The
+    // accumulator layout would store 32 contiguous bytes per row and instruction (partial lines: 20 % of the kernel's time in the
+    // ablation, profiles/r04/swin_win96_ablation.txt); the wave's 32 x 96 fp32 tile goes through LDS instead -- K and V are dead by
+    // now -- and leaves as whole 384-byte rows, 16 bytes per lane.
+    __syncthreads();                                     // both waves are done with K / V
+    {
+        constexpr int YP = 100;                          // floats per staged row (96 + 4: conflict-free 16-byte pieces)
+        float* yt = (float*)smem + wave * (32 * YP + 64);
+        long long* ro = (long long*)(yt + 32 * YP);      // row offset of each of the wave's 32 tokens, -1 = padding token
         const float* bp = p.bp + 4 * fh;
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 bv = *(const float4*)(bp + 32 * ct + 8 * g);
-                *(float4*)(yr + 32 * ct + 8 * g) = make_float4(yacc[ct][4 * g + 0] + bv.x, yacc[ct][4 * g + 1] + bv.y,
-                                                                yacc[ct][4 * g + 2] + bv.z, yacc[ct][4 * g + 3] + bv.w);
+                *(float4*)(yt + fr * YP + 32 * ct + 8 * g + 4 * fh) = make_float4(yacc[ct][4 * g + 0] + bv.x, yacc[ct][4 * g + 1] + bv.y,
+                                                                                    yacc[ct][4 * g + 2] + bv.z, yacc[ct][4 * g + 3] + bv.w);
             }
-    }
+        if (fh == 0) ro[fr] = real ? row : -1;
+        wave_lds_fence();
 #ifdef MV_I8_PROF
+        if ((p.ablate & 4) && yacc[0][0] != 12345.678f) return;
+#endif
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int idx = lane + 64 * i, r = idx / 24, q = idx - r * 24;
+            const long long off = ro[r];
+            if (off >= 0) *(float4*)(p.y + off + 4 * q) = *(const float4*)(yt + r * YP + 4 * q);
+        }
+    }
+#ifdef MV_W96_STAMPS
     if (p.prof) {
         __builtin_amdgcn_s_waitcnt(0);
         const long long tend = wall_clock64();
@@ -699,8 +733,9 @@ int mv_swin_block_attn_fwd(const void* x, const void* wqkv_f, const float* bqkv,
     SwinBAP p;
     p.x = (const float*)x; p.wqkv = (const bf16_t*)wqkv_f; p.bqkv = bqkv; p.wp = (const bf16_t*)wp_f; p.bp = bp; p.bias = bias64;
     p.y = (float*)y; p.Hf = Hf; p.Wf = Wf; p.shh = shh; p.shw = shw; p.nWw = Wf / 7; p.nW = (Hf / 7) * (Wf / 7); p.eps = eps;
-    p.prof = nullptr;
+    p.prof = nullptr; p.ablate = 0;
 #ifdef MV_I8_PROF              // debug build only
+    p.ablate = get_flag("w96_ablate");
     if (get_flag("sba_prof"))
         p.prof = (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo"));
 #endif
