@@ -46,6 +46,7 @@ __global__ __launch_bounds__(NWV * 64) void swin_block_attn_kernel(const SwinBAP
     constexpr int NT = NWV * 64, NSLOT = NWV / 2;            // threads; (head of group, window) slots = attention jobs / 2
     constexpr int NH = C / 32, HG = NSLOT / NWIN, NG = NH / HG, KS = C / 16, NTOK = 49, WS = 7;
     // k-loop: unrolled by U; weight fragments D steps ahead, token fragments 2 steps ahead in a ring of PB (all static indices)
+    // (8 / 6 fragments in flight per stream at C = 384: 49.7 us -- 256 VGPRs -- / 39.2 us against 39.7: not the limit)
     constexpr int U = (KS % 4 == 0) ? 4 : 6, D = (KS % 4 == 0) ? 4 : 3, PB = (KS % 4 == 0) ? 4 : 3;
     constexpr int NTB = 2 * NWIN, TR = 64 * NWIN, GT = 3 * HG, NCT = C / 32;      // token blocks / rows per workgroup; tiles per group
     static_assert(NWIN * HG == NSLOT && NH % HG == 0 && C % 48 == 0 && KS % U == 0 && U % D == 0 && U % PB == 0 && GT * NTB == 3 * NWV &&
