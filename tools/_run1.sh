@@ -1,3 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 900 python tools/gpu_check.py swin_block_attn/c384 > gpurun_out/w96_check.log 2>&1; grep -c PASS gpurun_out/w96_check.log; grep -v PASS gpurun_out/w96_check.log | cut -c1-300 | tail -4
-SBA_C=384 timeout 300 python tools/time_swin_block_attn.py 64 2>&1 | grep fused
+timeout 2500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|FAILED" | tail -3
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -c "'ok': True"
+timeout 600 python bench.py 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['frac'], d['roofline']['rocprof']['frac'], {k:v.get('value') for k,v in d.get('extra',{}).items()} if isinstance(d.get('extra'),dict) else '')"
