@@ -401,7 +401,7 @@ __global__ __launch_bounds__(NWV * 64) void swin_block_attn_kernel(const SwinBAP
 //   * per head: S^T, bias + mask + softmax in registers, P . V, and the head's slice of proj straight from the P . V accumulators
 //     (y^T += Wp[:, head] . o^T; the proj fragments arrive in the standard order and are re-ordered to the accumulator's channel
 //     order by two half-wave swaps each) -- the attention output never exists in memory;
-//   * stores from the accumulator layout (16 bytes per lane, the row pair fh = 0 / 1 covers 32 contiguous bytes).
+//   * the wave's 32 x 96 result leaves through LDS (K / V are dead by then) as whole 384-byte rows.
 template <int UNUSED>
 __global__ __launch_bounds__(128, 3) void swin_win96_kernel(const SwinBAP p) {
     constexpr int C = 96, KS = 6, NH = 3, NTOK = 49, WS = 7, QROW = 80, VROW = 144;
