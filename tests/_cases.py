@@ -83,6 +83,16 @@ def _splitk_runs(L, launch, y, M, N, kred, info):
     return kern
 
 
+def expect_kernel(case, name):
+    """The case must pass AND have been served by the kernel called `name` (dispatch regressions show up as a different name)."""
+    def run():
+        info = case()
+        info["expected_kernel"] = name
+        info["ok"] = bool(info.get("ok")) and info.get("kernel") == name
+        return info
+    return run
+
+
 def splitk_protocol_case(seed=0):
     """mv_set_scratch edge cases (include/eqxvision_amd.h): scratch that is too small, or handed over for ANOTHER stream, is ignored
     (un-split kernel, the bits of the no-scratch launch); a hand-over is consumed by one launch (the next launch without a new
@@ -2363,6 +2373,20 @@ def all_cases():
           ("bwd/colsum_100k_x_64", colsum_case(100352, 64, seed=62)),
           ("bwd/colsum_product_5000_x_200", colsum_case(5000, 200, seed=63, product=True)),
           ("bwd/colsum_small", colsum_case(300, 10, seed=64)),
+          # fp32 compute mode / training-step forward: the fp32 matrix-core contractions and the LDS attention, at op level
+          ("f32/conv3x3_c24_k40_direct", expect_kernel(conv_nhwc_case(2, 15, 13, 24, 40, 3, 3, pad=1, act=1, dtype="fp32", seed=701), "conv_f32_mfma")),
+          ("f32/conv7x7_s2_c3_stem_direct", expect_kernel(conv_nhwc_case(2, 32, 32, 3, 16, 7, 7, stride=2, pad=3, act=1, dtype="fp32", seed=702), "conv_f32_mfma")),
+          ("f32/conv3x3_s2_c128_k96_res_lds", expect_kernel(conv_nhwc_case(8, 28, 28, 128, 96, 3, 3, stride=2, pad=1, act=1, res=True, dtype="fp32", seed=703), "conv_f32_lds_mfma")),
+          ("f32/conv1x1_c68_half_empty_chunk_lds", expect_kernel(conv_nhwc_case(6, 20, 20, 68, 72, 1, 1, dtype="fp32", seed=704), "conv_f32_lds_mfma")),
+          ("f32/conv3x3_dil2_c64_lds", expect_kernel(conv_nhwc_case(3, 21, 19, 64, 64, 3, 3, pad=2, dil=2, act=2, scale=False, dtype="fp32", seed=705), "conv_f32_lds_mfma")),
+          ("f32/linear_768_3072_gelu_lds", expect_kernel(linear_case(1576, 768, 3072, act=2, dtype="fp32", seed=706), "conv_f32_lds_mfma")),
+          ("f32/linear_ragged_1500_200_k100_lds", expect_kernel(linear_case(1500, 200, 100, res=True, dtype="fp32", seed=707), "conv_f32_lds_mfma")),
+          ("f32/linear_few_rows_skinny", expect_kernel(linear_case(300, 96, 288, dtype="fp32", seed=708), "skinny_linear_f32_mfma")),
+          ("f32/linear_c48_direct", expect_kernel(linear_case(2000, 48, 96, act=1, dtype="fp32", seed=713), "conv_f32_mfma")),
+          ("f32/mha_197_dh64_lds", expect_kernel(mha_case(16, 197, 12, 64, dtype="fp32", seed=709), "mha_f32_lds")),
+          ("f32/mha_50_dh32_noprobs_lds", expect_kernel(mha_case(40, 50, 4, 32, dtype="fp32", probs=False, seed=710), "mha_f32_lds")),
+          ("f32/swin_attn_shifted_lds", expect_kernel(swin_attn_case(2, 14, 96, 3, 7, 3, dtype="fp32", seed=711), "swin_attn_f32_lds")),
+          ("f32/swin_attn_one_window_lds", expect_kernel(swin_attn_case(3, 7, 768, 24, 7, 3, dtype="fp32", seed=712), "swin_attn_f32_lds")),
           ("bwd/mha_197_dh64", mha_bwd_case(2, 197, 3, 64, seed=65)),
           ("bwd/mha_50_dh32", mha_bwd_case(3, 50, 4, 32, seed=66)),
           ("bwd/mha_17_dh96", mha_bwd_case(1, 17, 2, 96, seed=67)),
