@@ -268,7 +268,7 @@ static int conv_generic_dispatch(const void* x, const void* w, const float* scal
                                  int w_dtype, int y_dtype, hipStream_t st) {
     if (x_dtype == MV_F32 && w_dtype == MV_F32 && y_dtype == MV_F32 && p.groups == 1 && p.sxc == 1 && p.swc == 1 && p.K >= 32 && p.C >= 64 &&
         (p.C & 3) == 0 && (p.sxn & 3) == 0 && (p.sxh & 3) == 0 && (p.sxw & 3) == 0 && (p.swk & 3) == 0 && (p.swr & 3) == 0 &&
-        (p.sws & 3) == 0 && (long long)p.N * p.Ho * p.Wo >= 1024 && !get_flag("no_f32_mfma") && !get_flag("no_f32_lds")) {
+        (p.sws & 3) == 0 && (long long)p.N * p.Ho * p.Wo >= 1024 && !get_flag("no_f32_mfma") && !get_flag("force_generic") && !get_flag("no_f32_lds")) {
         const long long M = (long long)p.N * p.Ho * p.Wo;
         constexpr int SMEM = 2 * (64 + 256) * 36 * 4;
         set_kernel_name("conv_f32_lds_mfma");
@@ -282,7 +282,7 @@ static int conv_generic_dispatch(const void* x, const void* w, const float* scal
         MV_LAUNCH_CHECK();
         return MV_OK;
     }
-    if (x_dtype == MV_F32 && w_dtype == MV_F32 && y_dtype == MV_F32 && p.groups == 1 && p.K >= 8 && !get_flag("no_f32_mfma")) {
+    if (x_dtype == MV_F32 && w_dtype == MV_F32 && y_dtype == MV_F32 && p.groups == 1 && p.K >= 8 && !get_flag("no_f32_mfma") && !get_flag("force_generic")) {
         const long long M = (long long)p.N * p.Ho * p.Wo;
         set_kernel_name("conv_f32_mfma");
         hipLaunchKernelGGL(conv_f32_mfma_kernel, dim3((unsigned)((M + 127) / 128), (unsigned)((p.K + 31) / 32)), dim3(256), 0, st,
