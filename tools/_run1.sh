@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 2500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|FAILED" | tail -3
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -c "'ok': True"
-timeout 600 python bench.py 2>/dev/null | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['frac'], d['roofline']['rocprof']['frac'], {k:v.get('value') for k,v in d.get('extra',{}).items()} if isinstance(d.get('extra'),dict) else '')"
+bash tools/profile_session.sh r4prof r04 > gpurun_out/r4prof.log 2>&1
+tail -9 gpurun_out/r4prof.log | cut -c1-250
+cp gpurun_out/r4prof/traffic.json profiles/traffic.json
+timeout 400 python bench.py > gpurun_out/r4prof/bench_default_line.json 2> gpurun_out/r4prof/bench_default.err; cut -c1-400 gpurun_out/r4prof/bench_default_line.json
