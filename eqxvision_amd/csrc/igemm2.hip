@@ -310,6 +310,9 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const Igemm2P p) {
     if (p.prof) pt2 = wall_clock64();
     char* ep = smem + wave * (32 * EPITCH);
     OutT* y = (OutT*)p.y;
+    if constexpr (!RESPF && TN == 2) {    // branch-free buffer loads / stores (igemm_pipe.h), residual rows one pixel tile ahead
+        epilogue_rows<OutT, false, TM, EPITCH>(p, ep, acc, ss, res, true, m0 + xrow0, n0 + wrow0, lane);
+    } else
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
         R8<OutT> late[4];                 // no prefetch: fetch this pixel tile's 4 residual rows together

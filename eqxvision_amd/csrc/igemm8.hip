@@ -424,77 +424,8 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
     if (p.prof) pt2 = wall_clock64();
 #endif
 
-    // ---------------- epilogue (igemm2's: wave-private LDS transpose, full-line stores) --------------------
-    char* ep = smem + wave * (32 * EPITCH);
-    OutT* y = (OutT*)p.y;
-    const int xrow0 = 128 * grp, wrow0 = 64 * wc;
-    // residual rows: fetched one pixel tile AHEAD of their use (two register sets, free now that the fragments are dead), so the
-    // HBM latency of tile b+1's rows hides under tile b's transpose + stores instead of being paid four times per block
-    R8<OutT> late[2][4];
-    auto fetch_res = [&](int b, R8<OutT>(&dst)[4]) {
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int m = m0 + xrow0 + b * 32 + pass * 8 + (lane >> 3);
-            const int n = n0 + wrow0 + (lane & 7) * 8;
-            const bool ok = m < p.M && n < p.K;
-            dst[pass].load(res + (ok ? (long long)m * p.K + n : 0));
-        }
-    };
-    if (res) fetch_res(0, late[0]);
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        if (res && b + 1 < 4) fetch_res(b + 1, late[(b + 1) & 1]);
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = a * 32 + 8 * g + 4 * fh;
-                *(float4*)(ep + fr * EPITCH + nl * 4) = make_float4(acc[a][b][4 * g + 0], acc[a][b][4 * g + 1],
-                                                                     acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
-            }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int row = pass * 8 + (lane >> 3), c8 = lane & 7;
-            const int m = m0 + xrow0 + b * 32 + row;
-            const int n = n0 + wrow0 + c8 * 8;
-            const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
-            const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
-            if (m < p.M && n < p.K && do_store) {
-                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                if constexpr (LIN) ss.apply_shift(v);
-                else ss.apply(v);
-                if (res) late[b & 1][pass].add_to(v);
-                if (p.act == MV_ACT_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                } else if (p.act == MV_ACT_GELU_TANH && sizeof(OutT) != 2) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
-                }
-                long long off = (long long)m * p.K + n;
-                if (p.tok > 0) {
-                    const int bi = m / p.tok, ti = m - bi * p.tok;
-                    off = (((long long)bi * (p.K >> 6) + (n >> 6)) * p.tok + ti) * 64 + (n & 63);
-                }
-                if constexpr (sizeof(OutT) == 2) {
-                    if (p.act == MV_ACT_GELU_TANH) {  // GELU on packed fp32 pairs (v_pk_fma / v_pk_mul), straight to the bf16 store:
-                        uint4 u;                      // 14.1 -> 10.2 us of the ViT fc1 launch (148.0 -> 144.1 us, tools/gelu_ab.py)
-                        u.x = gelu_tanh_pack2(v[0], v[1]); u.y = gelu_tanh_pack2(v[2], v[3]);
-                        u.z = gelu_tanh_pack2(v[4], v[5]); u.w = gelu_tanh_pack2(v[6], v[7]);
-                        *(uint4*)(y + off) = u;
-                        continue;
-                    }
-                }
-                Out8<OutT>::st(y + off, v);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    // ---------------- epilogue (igemm2's wave-private LDS transpose; branch-free buffer loads / stores: igemm_pipe.h) ----
+    epilogue_rows<OutT, LIN, 4, EPITCH>(p, smem + wave * (32 * EPITCH), acc, ss, res, do_store, m0 + 128 * grp, n0 + 64 * wc, lane);
 #ifdef MV_I8_PROF
     if (p.prof) {
         if (tid == 0) {
@@ -751,72 +682,7 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
                 }
     }
 
-    char* ep = smem + wave * (32 * EPITCH);
-    OutT* y = (OutT*)p.y;
-    R8<OutT> late[2][4];                                     // both pixel tiles' residual rows, fetched before the first transpose
-    if (res) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int m = m0 + xrow0 + b * 32 + pass * 8 + (lane >> 3);
-                const int n = n0 + wrow0 + (lane & 7) * 8;
-                const bool ok = m < p.M && n < p.K;
-                late[b][pass].load(res + (ok ? (long long)m * p.K + n : 0));
-            }
-    }
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = a * 32 + 8 * g + 4 * fh;
-                *(float4*)(ep + fr * EPITCH + nl * 4) = make_float4(acc[a][b][4 * g + 0], acc[a][b][4 * g + 1],
-                                                                     acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
-            }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int row = pass * 8 + (lane >> 3), c8 = lane & 7;
-            const int m = m0 + xrow0 + b * 32 + row;
-            const int n = n0 + wrow0 + c8 * 8;
-            const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
-            const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
-            if (m < p.M && n < p.K) {
-                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                ss.apply(v);
-                if (res) late[b][pass].add_to(v);
-                if (p.act == MV_ACT_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                } else if (p.act == MV_ACT_GELU_TANH && sizeof(OutT) != 2) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
-                }
-                long long off = (long long)m * p.K + n;
-                if (p.tok > 0) {
-                    const int bi = m / p.tok, ti = m - bi * p.tok;
-                    off = (((long long)bi * (p.K >> 6) + (n >> 6)) * p.tok + ti) * 64 + (n & 63);
-                }
-                if constexpr (sizeof(OutT) == 2) {
-                    if (p.act == MV_ACT_GELU_TANH) {  // GELU on packed fp32 pairs (v_pk_fma / v_pk_mul), straight to the bf16 store:
-                        uint4 u;                      // 14.1 -> 10.2 us of the ViT fc1 launch (148.0 -> 144.1 us, tools/gelu_ab.py)
-                        u.x = gelu_tanh_pack2(v[0], v[1]); u.y = gelu_tanh_pack2(v[2], v[3]);
-                        u.z = gelu_tanh_pack2(v[4], v[5]); u.w = gelu_tanh_pack2(v[6], v[7]);
-                        *(uint4*)(y + off) = u;
-                        continue;
-                    }
-                }
-                Out8<OutT>::st(y + off, v);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    epilogue_rows<OutT, false, 2, EPITCH>(p, smem + wave * (32 * EPITCH), acc, ss, res, true, m0 + xrow0, n0 + wrow0, lane);
 }
 
 int igemm8_supported(long long M, int C, int K, int R, int S, long long x_bytes, long long w_bytes) {

@@ -54,4 +54,142 @@ template <> struct R8<float> {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Branch-free row-major read-back (round 5).  The first version of this epilogue wrapped every residual load and every store
+// in `if (m < M && n < K)`: hipcc turns that into an exec-masked region per pass, and because gfx9's vmcnt counts loads AND
+// stores in issue order and the waits for the (long finished) scale / shift and residual loads sat INSIDE those regions, its
+// wait-count pass fell back to `s_waitcnt vmcnt(0)` in every pass -- 16 serialised store round trips per wave and tile
+// (3.7 us of a 5.2 us bf16 epilogue, profiles/r04/vit_gemm_tile_phases.txt "no stores").  Here rows and columns outside the
+// tensor get an out-of-range offset into a raw buffer descriptor instead (the buffer unit drops the store / returns zeros), so
+// the epilogue has no divergent control flow, every wait is an exact count and the stores of a tile stream behind each other.
+
+template <typename OutT> struct Buf8;      // 8 consecutive channels of one row, through a buffer descriptor
+template <> struct Buf8<bf16_t> {
+    u32x4 u;
+    __device__ __forceinline__ void load(brsrc_t r, unsigned vo, unsigned so) { u = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0); }
+    __device__ __forceinline__ void add_to(float* v) const {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] += __uint_as_float(u[e] << 16);
+            v[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(brsrc_t r, unsigned vo, const float* v) {
+        u32x4 o;
+        o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]); o[2] = pack_bf2(v[4], v[5]); o[3] = pack_bf2(v[6], v[7]);
+        __builtin_amdgcn_raw_buffer_store_b128(o, r, vo, 0, 0);
+    }
+};
+template <> struct Buf8<float> {
+    u32x4 a, b;
+    __device__ __forceinline__ void load(brsrc_t r, unsigned vo, unsigned so) {
+        a = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
+        b = __builtin_amdgcn_raw_buffer_load_b128(r, vo + 16u, so, 0);
+    }
+    __device__ __forceinline__ void add_to(float* v) const {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(a[e]); v[4 + e] += __uint_as_float(b[e]); }
+    }
+    static __device__ __forceinline__ void store(brsrc_t r, unsigned vo, const float* v) {
+        u32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] = __float_as_uint(v[e]); hi[e] = __float_as_uint(v[4 + e]); }
+        __builtin_amdgcn_raw_buffer_store_b128(lo, r, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(hi, r, vo + 16u, 0, 0);
+    }
+};
+
+// One wave writes its (NBT x 32 pixel rows) x 64 channels: accumulator tiles acc[a][b] (a = channel half, b = pixel tile) go
+// through the wave-private LDS patch `ep` (32 rows of EPITCH bytes) and leave as full 128-byte (bf16) / 256-byte (fp32) lines.
+//   mrow0 = first pixel row of the wave, ncol0 = first channel of the wave (multiple of 64), both wave-uniform.
+template <typename OutT, bool LIN, int NBT, int EPITCH>
+__device__ __forceinline__ void epilogue_rows(const Igemm2P& p, char* ep, f32x16 (&acc)[2][NBT], const ScaleShift8& ss,
+                                              const OutT* res, bool do_store, int mrow0, int ncol0, int lane) {
+    constexpr unsigned SZ = sizeof(OutT);
+    const int fr = lane & 31, fh = lane >> 5, r0 = lane >> 3, c8 = lane & 7;
+    const int rl = ncol0 + c8 * 8 < p.K ? p.M - mrow0 : 0;           // rows of this wave's strip the lane may touch (0: its channels are past K)
+    const long long wave_elem = (long long)mrow0 * p.K + ncol0;
+    const bool has_res = res != nullptr;
+    const brsrc_t rr = make_brsrc(has_res ? res + wave_elem : (const OutT*)p.y, has_res);
+    const unsigned vrow = (unsigned)(r0 * p.K + c8 * 8) * SZ;          // lane's element of the wave's first 8 rows
+    const unsigned kstep = 8u * (unsigned)p.K * SZ;                    // 8 rows further down
+    // head-major token layout (tok > 0): y[b][n / 64][t][n % 64], rows m = b * tok + t
+    const bool hm = p.tok > 0;
+    int bi0 = 0, ti0 = 0;
+    if (hm) { bi0 = mrow0 / p.tok; ti0 = mrow0 - bi0 * p.tok; }
+    const long long y_elem = hm ? ((long long)bi0 * (p.K >> 6) + (ncol0 >> 6)) * p.tok * 64 : wave_elem;
+    const brsrc_t ry = make_brsrc((OutT*)p.y + y_elem, do_store);
+    const float inv_tok = hm ? 1.0f / (float)p.tok : 0.f;
+    const unsigned img_step = (unsigned)(p.K >> 6) * (unsigned)p.tok * 64u;   // elements from image b to b + 1 (same channel block)
+    // Residual loads: row-major offset in a VGPR (or out of range), the 8-row step in the scalar offset.
+    // Stores: the WHOLE offset in the VGPR and soffset = 0.  A buffer store of more than 64 bits reads its data registers over
+    // several cycles; hipcc's hazard recogniser only inserts the wait state before a VALU overwrite of those registers when the
+    // store's soffset is NOT a register (GCNHazardRecognizer: "this hazard only exists if the instruction is not using a register
+    // in the soffset field") -- on gfx950 the overwrite corrupted one dword of the second fp32 store of a pass in some lanes
+    // (tools/dbg_epi.py: rows 25/27/29/31 of a strip, first channel of the upper half) when soffset was an SGPR.
+    auto row_vo = [&](int row) -> unsigned { return row + r0 < rl ? vrow : BUF_OOB; };
+    auto y_vo = [&](int row, int step) -> unsigned {
+        unsigned rel = vrow + (unsigned)step * kstep;
+        if (hm) {
+            const int v = ti0 + row + r0;                            // < tok + 128
+            int q = (int)((float)v * inv_tok), t = v - q * p.tok;
+            q += t >= p.tok ? 1 : (t < 0 ? -1 : 0);
+            t -= t >= p.tok ? p.tok : (t < 0 ? -p.tok : 0);
+            rel = ((unsigned)q * img_step + (unsigned)t * 64u + (unsigned)c8 * 8u) * SZ;
+        }
+        return row + r0 < rl ? rel : BUF_OOB;
+    };
+    Buf8<OutT> late[2][4];
+    auto fetch_res = [&](int b, Buf8<OutT>(&dst)[4]) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) dst[pass].load(rr, row_vo(b * 32 + pass * 8), (unsigned)(b * 4 + pass) * kstep);
+    };
+    fetch_res(0, late[0]);
+#pragma unroll
+    for (int b = 0; b < NBT; ++b) {
+        if (b + 1 < NBT) fetch_res(b + 1, late[(b + 1) & 1]);       // one pixel tile ahead: its latency hides under this tile's stores
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = a * 32 + 8 * g + 4 * fh;
+                *(float4*)(ep + fr * EPITCH + nl * 4) = make_float4(acc[a][b][4 * g + 0], acc[a][b][4 * g + 1],
+                                                                     acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
+            }
+        wave_lds_fence();
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + r0;
+            const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
+            const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            if constexpr (LIN) ss.apply_shift(v);
+            else ss.apply(v);
+            if (has_res) late[b & 1][pass].add_to(v);
+            const unsigned voy = y_vo(b * 32 + pass * 8, b * 4 + pass);
+            if (p.act == MV_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if constexpr (sizeof(OutT) == 2) {
+                u32x4 o;
+                if (p.act == MV_ACT_GELU_TANH) {     // GELU on packed fp32 pairs (v_pk_fma / v_pk_mul), straight to the bf16 words
+                    o[0] = gelu_tanh_pack2(v[0], v[1]); o[1] = gelu_tanh_pack2(v[2], v[3]);
+                    o[2] = gelu_tanh_pack2(v[4], v[5]); o[3] = gelu_tanh_pack2(v[6], v[7]);
+                } else {
+                    o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]); o[2] = pack_bf2(v[4], v[5]); o[3] = pack_bf2(v[6], v[7]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(o, ry, voy, 0, 0);
+            } else {
+                if (p.act == MV_ACT_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                }
+                Buf8<OutT>::store(ry, voy, v);
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
 }  // namespace mv

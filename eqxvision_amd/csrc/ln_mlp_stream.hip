@@ -290,24 +290,26 @@ __global__ __launch_bounds__(512) void ln_mlp_stream_kernel(const LnMlpSP p) {
         constexpr int QPR = C / 4;                                     // float4 per row
         constexpr int NIT = TM * QPR / 512;
         static_assert(TM * QPR % 512 == 0, "whole passes");
-        float4 xr[NIT];
+        // rows past M: out-of-range buffer offsets (loads return zeros, stores are dropped) -- no branch, no load inside the store
+        // loop, so the NIT stores stream behind each other instead of one L2 round trip each (tools/scan_store_waits.py)
+        const brsrc_t rx = make_brsrc(p.x + (long long)row0 * C), ry = make_brsrc(p.y + (long long)row0 * C), rb = make_brsrc(p.b2);
+        const int rows_left = p.M - (int)row0;
+        float4 xr[NIT], b2[NIT];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int idx = tid + 512 * i;
             const int r = idx / QPR, q = idx - r * QPR;
-            long long gr = row0 + r;
-            gr = gr < p.M ? gr : p.M - 1;
-            xr[i] = *(const float4*)(p.x + gr * C + 4 * q);
+            xr[i] = buf_load_f4(rx, r < rows_left ? (unsigned)idx * 16u : BUF_OOB);
+            b2[i] = buf_load_f4(rb, (unsigned)q * 16u);
         }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int idx = tid + 512 * i;
             const int r = idx / QPR, q = idx - r * QPR;
             const float4 a = *(const float4*)(smem + r * YROW + q * 16);
-            const float4 b2 = *(const float4*)(p.b2 + 4 * q);
             float4 o;
-            o.x = a.x + b2.x + xr[i].x; o.y = a.y + b2.y + xr[i].y; o.z = a.z + b2.z + xr[i].z; o.w = a.w + b2.w + xr[i].w;
-            if (row0 + r < p.M) *(float4*)(p.y + (row0 + r) * C + 4 * q) = o;
+            o.x = a.x + b2[i].x + xr[i].x; o.y = a.y + b2[i].y + xr[i].y; o.z = a.z + b2[i].z + xr[i].z; o.w = a.w + b2[i].w + xr[i].w;
+            buf_store_f4(ry, r < rows_left ? (unsigned)idx * 16u : BUF_OOB, o);
         }
     }
     if (p.prof) {
@@ -501,24 +503,23 @@ __global__ __launch_bounds__(512) void ln_mlp_stream192_kernel(const LnMlpSP p) 
     {
         constexpr int QPR = C / 4, NIT = TM * QPR / 512;
         static_assert(TM * QPR % 512 == 0, "whole passes");
-        float4 xr[NIT];
+        const brsrc_t rx = make_brsrc(p.x + (long long)row0 * C), ry = make_brsrc(p.y + (long long)row0 * C), rb = make_brsrc(p.b2);
+        const int rows_left = p.M - (int)row0;
+        float4 xr[NIT], b2[NIT];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int idx = tid + 512 * i;
             const int r = idx / QPR, q = idx - r * QPR;
-            long long gr = row0 + r;
-            gr = gr < p.M ? gr : p.M - 1;
-            xr[i] = *(const float4*)(p.x + gr * C + 4 * q);
+            xr[i] = buf_load_f4(rx, r < rows_left ? (unsigned)idx * 16u : BUF_OOB);
+            b2[i] = buf_load_f4(rb, (unsigned)q * 16u);
         }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int idx = tid + 512 * i;
             const int r = idx / QPR, q = idx - r * QPR;
             const float4 a = *(const float4*)(smem + r * YROW + q * 16);
-            const float4 b2 = *(const float4*)(p.b2 + 4 * q);
-            if (row0 + r < p.M)
-                *(float4*)(p.y + (row0 + r) * C + 4 * q) =
-                    make_float4(a.x + b2.x + xr[i].x, a.y + b2.y + xr[i].y, a.z + b2.z + xr[i].z, a.w + b2.w + xr[i].w);
+            buf_store_f4(ry, r < rows_left ? (unsigned)idx * 16u : BUF_OOB,
+                         make_float4(a.x + b2[i].x + xr[i].x, a.y + b2[i].y + xr[i].y, a.z + b2[i].z + xr[i].z, a.w + b2[i].w + xr[i].w));
         }
     }
 }

@@ -21,6 +21,38 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Raw buffer descriptors for branch-free bounds handling (round 5): an element outside the tensor gets the offset BUF_OOB, which is
+// >= num_records, so the buffer unit drops the store / returns zeros -- no exec-masked region around the access, which is what lets
+// hipcc count vmcnt exactly instead of falling back to `s_waitcnt vmcnt(0)` between the stores of an epilogue (igemm_pipe.h).
+// Valid offsets must stay below 2^31: make the descriptor at the workgroup's / wave's first element, not at the tensor base.
+typedef __amdgpu_buffer_rsrc_t brsrc_t;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned BUF_OOB = 0x80000000u;            // == num_records of every descriptor made here
+
+__device__ __forceinline__ brsrc_t make_brsrc(const void* base, bool live = true) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, live ? (int)BUF_OOB : 0, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load_f4(brsrc_t r, unsigned vo, unsigned so = 0) {
+    const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
+    return make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
+}
+// Stores take NO scalar offset on purpose: with an SGPR soffset hipcc's hazard recogniser does not protect the data registers of a
+// > 64-bit buffer store against the next VALU write, and gfx950 does corrupt them (igemm_pipe.h: epilogue_rows).
+__device__ __forceinline__ void buf_store_f4(brsrc_t r, unsigned vo, float4 v) {
+    u32x4_t u;
+    u[0] = __float_as_uint(v.x); u[1] = __float_as_uint(v.y); u[2] = __float_as_uint(v.z); u[3] = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, vo, 0, 0);
+}
+__device__ __forceinline__ uint4 buf_load_u4(brsrc_t r, unsigned vo, unsigned so = 0) {
+    const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
+    return make_uint4(u[0], u[1], u[2], u[3]);
+}
+__device__ __forceinline__ void buf_store_u4(brsrc_t r, unsigned vo, uint4 v) {
+    u32x4_t u;
+    u[0] = v.x; u[1] = v.y; u[2] = v.z; u[3] = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, vo, 0, 0);
+}
+
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     // blocks are dispatched round-robin over the 8 XCDs; give each XCD a contiguous tile range
     const int q = nblk >> 3, r = nblk & 7;
