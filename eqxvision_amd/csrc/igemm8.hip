@@ -734,7 +734,7 @@ static int igemm8_go(Igemm2P& p, bool dual, bool out_f32, int tile, hipStream_t 
     const int bm = tile == 1 ? 128 : 256, bn = tile == 2 ? 128 : 256;
     p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = (p.K + bn - 1) / bn;
-    p.gm = 8;
+    p.gm = 8;             // 1 ... 12 are equal on the ViT shapes, 32+ lose 7 % (profiles/r05/vit_tile_order_gm_sweep.txt)
 #ifdef MV_I8_PROF
     p.skew = get_flag("i8_skew");                    // measured -3.6 % on vit_base (profiles/r04/vit_ab_i8_skew_4.6us.txt)
 #endif
