@@ -50,6 +50,7 @@ GFLOP_PER_IMG = {"resnet50": 8.178, "vit_base": 35.13, "swin_t": 8.98, "alexnet"
                  "vgg16": 30.94, "vgg16_bn": 30.94, "vgg11": 15.22, "resnext50_32x4d": 8.46, "mobilenet_v2": 0.601, "mobilenet_v3_large": 0.434, "efficientnet_b0": 0.772, "efficientnet_v2_s": 16.8, "regnet_y_400mf": 0.80, "regnet_x_3_2gf": 6.35}   # section 8 f1 (2 x MACs of the conv / Linear layers)
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+FORCE_COMM = os.environ.get("EQV_FORCE_COMM") == "1"     # 1 rank, logits still through mv_allgather (see run_model)
 
 
 def build_model(name: str, seed: int = 1):
@@ -389,11 +390,16 @@ def run_model(a, name, B, rank, world, soak_s):
     keys = eqv.random.split(eqv.random.PRNGKey(0), B)
     fwd = eqv.filter_jit(lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k),
                          use_graph=not a.no_graph, clone_outputs=False, lanes=a.lanes)
-    gathered = torch.empty((B * world, 1000), dtype=torch.float32, device="cuda") if world > 1 else None
+    # EQV_FORCE_COMM=1 (tests/test_dist_gpu.py): with ONE rank the logits still go through mv_allgather on a 1-rank RCCL
+    # communicator inside the timed region -- the code path the 8-GPU line takes, executed on the hardware a 1-GPU box has
+    use_comm = world > 1 or (FORCE_COMM and D._state["native"])
+    gathered = torch.empty((B * world, 1000), dtype=torch.float32, device="cuda") if use_comm else None
+    local_logits = [None]
 
     def step():
         logits = fwd(net, images, keys)
-        if world > 1:                        # ONE all-gather of the fp32 logits on the launch stream (mv_allgather / RCCL)
+        if use_comm:                         # ONE all-gather of the fp32 logits on the launch stream (mv_allgather / RCCL)
+            local_logits[0] = logits
             logits = D.all_gather_rows(logits, B * world, out=gathered)
         return logits
 
@@ -410,6 +416,9 @@ def run_model(a, name, B, rank, world, soak_s):
         out = step()
     torch.cuda.synchronize()
     assert out.shape == (B * world, 1000) and bool(torch.isfinite(out).all())
+    if use_comm and world == 1:              # forced 1-rank collective: the gathered buffer IS the local logits, bit for bit
+        assert out.data_ptr() == gathered.data_ptr() and out.data_ptr() != local_logits[0].data_ptr()
+        assert torch.equal(out, local_logits[0]), "mv_allgather on a 1-rank communicator changed the logits"
 
     e0, e1 = _ev(), _ev()
     D.barrier()
@@ -520,8 +529,23 @@ def run_model(a, name, B, rank, world, soak_s):
                             "events around every launch, 6 eager replays; the dominant kernel = largest summed duration among the "
                             "GEMM-type kernels (one name per kernel symbol)",
                      "rocprof": rp1, "two_lanes": two})
-        if traffic is not None and two["kernel"] != k1:
-            roof["traffic"] = None
+        # `traffic` belongs to the headline kernel: PMC bytes per launch of k1.  The PMC passes ran the two-lane command (launches of
+        # B / nl images, profiles/traffic.json); a one-lane launch carries the whole batch, so the per-launch figure is scaled by nl
+        # (the kernels' traffic is linear in the batch: weights are a few MB of 100+).
+        try:
+            t_k1 = tjd.get(name, {}).get(k1) if tjd.get("_batch", {}).get(name) == B and world == 1 else None
+        except Exception:  # noqa: BLE001
+            t_k1 = None
+        roof["traffic"] = None if t_k1 is None else int(t_k1 * nl)
+        roof["traffic_how"] = (None if t_k1 is None else
+                               f"rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE (separate passes) per launch of {k1} in the two-lane command "
+                               f"({B // nl} images per launch: {t_k1} bytes), x {nl} for this full-batch launch; profiles/traffic.json")
+        two["traffic"] = traffic if traffic is not None and two["kernel"] == dk else None
+        # both fractions side by side under explicit names (advisor, round 4): `frac` / `frac_lanes1` = the kernel alone on the chip
+        # (one launch list), `frac_in_situ` = the same-symbol or dominant two-lane kernel while the other lane runs -- the
+        # configuration `value` is measured in; `whole_forward.frac` is the time-weighted figure of the whole step
+        roof["frac_lanes1"] = roof["frac"]
+        roof["frac_in_situ"] = two["frac"]
         roof["lanes1"] = {"kernel": k1, "launches_per_step": v1["n"], "avg_launch_us": round(v1["us"] / max(1, v1["n"]), 2),
                           "achieved": round(t1, 1), "frac": round(t1 / MFMA_PEAK_TFLOPS, 4),
                           "sum_dominant_ms": round(v1["us"] / 1e3, 4), "sum_all_kernels_ms": round(sum(r_["us"] for r_ in rows1) / 1e3, 4),
@@ -537,7 +561,8 @@ def run_model(a, name, B, rank, world, soak_s):
                       "global_batch": B * world, "parallelism": f"dp{world}", "launches_per_step": len(compiled.calls),
                       "graph": compiled.graph is not None,
                       "lanes": len(compiled.lane_calls) if compiled.lane_calls else 1,
-                      "collective": ("mv_allgather (RCCL)" if D._state["native"] else "torch.distributed") if world > 1 else None},
+                      "collective": ("mv_allgather (RCCL)" if D._state["native"] else "torch.distributed") if use_comm else None,
+                      "collective_forced_1rank": bool(use_comm and world == 1)},
            "roofline": roof}
     return res, net
 
@@ -594,6 +619,8 @@ def main():
     if world > 1 and D._state["native"] and eqv._lib.load().mv_comm_size() != world:
         raise SystemExit(f"RCCL communicator has {eqv._lib.load().mv_comm_size()} ranks, expected {world}")
     torch.cuda.set_device(local)
+    if FORCE_COMM and world == 1:
+        D.native_comm_init(0, 1)             # raises if librccl cannot give a 1-rank communicator: no silent skip
     eqv.set_compute_dtype(a.dtype)
     default_batch = {"swin_t": 128}
     extras = []
@@ -633,6 +660,8 @@ def main():
         import torch.distributed as td
         D.native_comm_destroy()
         td.destroy_process_group()
+    elif FORCE_COMM:
+        D.native_comm_destroy()
 
 
 if __name__ == "__main__":

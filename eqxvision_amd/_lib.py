@@ -122,6 +122,7 @@ PROTOTYPES = {
     "mv_avgpool_global_bwd_nhwc_f32": [_vp, _vp, _i, _i, _i, _vp],
     "mv_colsum_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "mv_bn_dgamma_f32": [_vp, _vp, _vp, _vp, _f, _vp, _i, _vp],
+    "mv_bn_train_dz_coef_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _i, _vp],
     "mv_layernorm_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp],
     "mv_softmax_bwd_f32": [_vp, _vp, _vp, _i64, _i, _f, _vp],
     "mv_mha_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],

@@ -308,6 +308,21 @@ __global__ void bn_dgamma_kernel(const float* __restrict__ dyz, const float* __r
     if (c < C) dgamma[c] = (dyz[c] - mean[c] * dys[c]) * rsqrtf(var[c] + eps);        // sum dy (z - mean) rstd
 }
 
+// training-mode BatchNorm: coefficients of the batch-statistics terms of dz (header: mv_bn_train_dz_coef_f32)
+__global__ void bn_train_dz_coef_kernel(const float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ s0,
+                                        const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ scale,
+                                        const float* __restrict__ count, float rows, float a, float eps, float* __restrict__ A,
+                                        float* __restrict__ B, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float n = count ? count[0] : rows;
+    const float k = a / n;
+    const float r2 = 1.0f / (var[c] + eps);                                  // rstd^2
+    const float b = -k * scale[c] * r2 * (s2[c] - mean[c] * s1[c]);
+    B[c] = b;
+    A[c] = -k * scale[c] * s1[c] - b * (s0[c] / n);
+}
+
 // one wave per row: dx = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)); dyxhat = dy xhat (its column sums are dgamma)
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ dy, float* __restrict__ dx,
@@ -736,6 +751,18 @@ int mv_bn_dgamma_f32(const float* sum_dy_z, const float* sum_dy, const float* me
     set_kernel_name("bn_dgamma_f32");
     hipLaunchKernelGGL(bn_dgamma_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sum_dy_z, sum_dy, mean,
                        var, eps, dgamma, C);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
+int mv_bn_train_dz_coef_f32(const float* sum_dy, const float* sum_dy_z, const float* sum_z, const float* mean, const float* var,
+                            const float* scale, const float* count, float rows, float a, float eps, float* A, float* B, int C,
+                            mv_stream_t stream) {
+    MV_CHECK_ARG(sum_dy && sum_dy_z && sum_z && mean && var && scale && A && B && C > 0 && (count || rows > 0.f),
+                 "bn_train_dz_coef: bad arguments");
+    set_kernel_name("bn_train_dz_coef_f32");
+    hipLaunchKernelGGL(bn_train_dz_coef_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sum_dy, sum_dy_z,
+                       sum_z, mean, var, scale, count, rows, a, eps, A, B, C);
     MV_LAUNCH_CHECK();
     return MV_OK;
 }

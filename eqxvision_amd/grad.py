@@ -412,36 +412,65 @@ def _bn_vectors(bn, z: torch.Tensor, kind: str, batched: bool):
     if not bn.inference:
         sc, sh = ops.bn_train_update(bn, Act(z, kind, batched))
         mean, var = bn.state_index._dev
-        return sc, sh, mean, var
+        # the statistics are updated in place by the next call of this layer: the backward needs the values of THIS call
+        mean_, var_ = _new((C,)), _new((C,))
+        _call("mv_cast", _p(mean), _p(mean_), C, F32, F32, _S())
+        _call("mv_cast", _p(var), _p(var_), C, F32, F32, _S())
+        return sc, sh, mean_, var_, dict(ops._BN_LAST)
     st = bn.state_index.value
     if st is None:
         raise RuntimeError("BatchNorm has no running statistics")
     scale, shift = ops.bn_fold(bn)
-    return _upload(scale), _upload(shift), _upload(st[0]), _upload(st[1])
+    return _upload(scale), _upload(shift), _upload(st[0]), _upload(st[1]), None
 
 
 def _bn_forward(bn, z: torch.Tensor, kind: str, batched: bool):
     C = z.shape[-1]
-    sc, sh, mean, var = _bn_vectors(bn, z, kind, batched)
+    sc, sh, mean, var, train = _bn_vectors(bn, z, kind, batched)
     y = _new(z.shape)
     _call("mv_channel_affine_fwd", _p(z), _p(sc), _p(sh), _p(y), z.numel() // C, C, _lib.ACT_NONE, F32, _S())
-    return y, (sc, mean, var)
+    return y, (sc, mean, var, train)
 
 
 def _bn_backward(bn, z: torch.Tensor, g: torch.Tensor, saved) -> torch.Tensor:
-    """dz of y = z * scale + shift with scale = gamma * rstd(running) held constant w.r.t. the batch; accumulates dgamma, dbeta."""
-    sc, mean, var = saved
+    """dz of y = gamma * (z - mean') * rstd(var') + beta; accumulates dgamma, dbeta.
+    Inference mode: mean' / var' are the stored statistics, constants: dz = scale * dy.
+    Training mode (eqx.experimental.BatchNorm's training branch): mean' = a * batch_mean + (1 - a) * running_mean (a = 1 on the
+    layer's first call, 1 - momentum afterwards), likewise var', and the batch moments are differentiable functions of z -- nothing
+    in the reference stops that gradient -- so dz carries the two batch-statistics terms, scaled by a (round-4 advisor finding;
+    the oracle differentiates through them too: oracle/torch_grad.py: bn_train).  The column sums run over the whole data-parallel
+    batch: summed over ranks when the layer's axis_name spans them."""
+    from . import dist as _dist
+    sc, mean, var, train = saved
     C = z.shape[-1]
-    if bn.weight is not None:
+    s1 = s2 = None
+    if bn.weight is not None or train is not None:
         s1 = _colsum(g, None, C)
         s2 = _colsum(g, z, C)
+    if bn.weight is not None:
         dg = _new((C,))
         _call("mv_bn_dgamma_f32", _p(s2), _p(s1), _p(mean), _p(var), float(bn.eps), _p(dg), C, _S())
-        _acc_param(bn.weight, dg)
+        _acc_param(bn.weight, dg)                   # per-rank partial sums, like every other parameter gradient
         _acc_param(bn.bias, s1)
     dz = _new(z.shape)
     zeros = torch.zeros((C,), dtype=torch.float32, device=device())
-    _call("mv_channel_affine_fwd", _p(g), _p(sc), _p(zeros), _p(dz), z.numel() // C, C, _lib.ACT_NONE, F32, _S())
+    if train is None:
+        _call("mv_channel_affine_fwd", _p(g), _p(sc), _p(zeros), _p(dz), z.numel() // C, C, _lib.ACT_NONE, F32, _S())
+        return dz
+    s0 = _colsum(z, None, C)
+    if train["reduce"]:
+        s1g, s2g = _new((C,)), _new((C,))           # the parameter gradients above keep the local sums
+        _call("mv_cast", _p(s1), _p(s1g), C, F32, F32, _S())
+        _call("mv_cast", _p(s2), _p(s2g), C, F32, F32, _S())
+        for v in (s0, s1g, s2g):
+            _dist.all_reduce_sum_(v)
+        s1, s2 = s1g, s2g
+    A, Bc = _new((C,)), _new((C,))
+    _call("mv_bn_train_dz_coef_f32", _p(s1), _p(s2), _p(s0), _p(mean), _p(var), _p(sc), _p(train["cnt"]), float(train["rows"]),
+          float(train["a"]), float(bn.eps), _p(A), _p(Bc), C, _S())
+    t = _new(z.shape)
+    _call("mv_channel_affine_fwd", _p(z), _p(Bc), _p(A), _p(t), z.numel() // C, C, _lib.ACT_NONE, F32, _S())           # A + B z
+    _call("mv_channel_affine_res_fwd", _p(g), _p(sc), _p(zeros), _p(t), _p(dz), z.numel() // C, C, _lib.ACT_NONE, F32, _S())
     return dz
 
 

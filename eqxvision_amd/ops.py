@@ -71,6 +71,9 @@ def _bn_id(bn):
     return None if bn is None else (id(bn), bn.state_index.version)
 
 
+_BN_LAST: dict = {}        # set by bn_train_update, read by the tape right after the call (grad._bn_vectors)
+
+
 def bn_train_update(bn, y: Act):
     """The statistics half of eqx.experimental.BatchNorm's TRAINING branch (resnet.py:132-136 with the model
     not in inference mode): per-channel batch mean, then the mean of squared deviations from it -- two passes, each summed over
@@ -129,6 +132,10 @@ def bn_train_update(bn, y: Act):
                   _ptr(scale), _ptr(shift), float(bn.momentum), float(bn.eps), C, st)
     if first:
         bn.first_time_index.value = False
+    # what the backward of THIS call needs (grad._bn_backward): the weight of the batch statistics in the statistics the layer
+    # normalised with (running' = a * batch + (1 - a) * running), the row count of the data-parallel batch and whether the column
+    # sums have to be summed over ranks
+    _BN_LAST.update(a=1.0 if first else 1.0 - float(bn.momentum), rows=float(rows), cnt=cnt, reduce=reduce_ranks)
     sidx.device_updated(run)               # bumps the version: every fold prepared with the old statistics is stale (_bn_id)
     on_replay(lambda s=sidx, r=run: s.device_updated(r))     # ... and again after every replay of a recorded step
     return scale, shift
@@ -1186,11 +1193,12 @@ def swin_window_attention(qkv: Act, bias: torch.Tensor, heads: int, window, shif
 
 def swin_block_attn_fragments(wqkv: np.ndarray, bqkv: np.ndarray, wp: np.ndarray, bias: np.ndarray):
     """qkv weight [3C][C] (LayerNorm already folded) / bias [3C], proj weight [C][C], relative-position bias [heads][n][n] ->
-    the operand layouts of mv_swin_block_attn_fwd (header)."""
+    the operand layouts of mv_swin_block_attn_fwd (header), or None for a width the kernel is not instantiated for (swin_b's
+    128 / 256 / 512 / 1024: the caller takes the un-fused path)."""
     C = wp.shape[0]
     heads = C // 32
     if C not in (384, 192, 96):                           # the widths the kernel is instantiated for (NWIN / NWV templates)
-        raise ValueError(f"swin_block_attn_fragments: width {C} has no fused kernel (96 / 192 / 384)")
+        return None
     HG = {384: 4, 192: 2, 96: 1}[C]                       # heads per group (x windows per workgroup = 4)
     G, GT = heads // HG, 3 * HG                            # always 3 groups; tiles per group: q heads, k heads, v heads
     rows = np.array([[(t // HG) * C + 32 * (HG * g + t % HG) for t in range(GT)] for g in range(G)])              # [G][GT]
@@ -1227,8 +1235,11 @@ def swin_block_attention(x: Act, norm, attn) -> Optional[Act]:
     if hit is None:
         wq = np.asarray(attn.qkv.weight, np.float32)
         g, b = np.asarray(norm.weight, np.float32).reshape(-1), np.asarray(norm.bias, np.float32).reshape(-1)
-        wf, bq, wpf, b64 = swin_block_attn_fragments(wq * g[None, :], np.asarray(attn.qkv.bias, np.float32).reshape(-1) + wq @ b,
-                                                     np.asarray(attn.proj.weight, np.float32), attn.get_relative_position_bias())
+        frags = swin_block_attn_fragments(wq * g[None, :], np.asarray(attn.qkv.bias, np.float32).reshape(-1) + wq @ b,
+                                          np.asarray(attn.proj.weight, np.float32), attn.get_relative_position_bias())
+        if frags is None:
+            return None
+        wf, bq, wpf, b64 = frags
         hit = (_dev(wf, torch.bfloat16), _dev(bq, torch.float32), _dev(wpf, torch.bfloat16),
                _dev(np.asarray(attn.proj.bias, np.float32).reshape(-1), torch.float32), _dev(b64, torch.float32), norm)
         cache[key] = hit

@@ -462,6 +462,15 @@ int mv_channel_scale_bwd_f32(const float* g, const float* x, float* ds, int B, i
  * differentiated): dgamma[c] = (sum dy z - mean[c] sum dy) / sqrt(var[c] + eps), from the two column sums. */
 int mv_bn_dgamma_f32(const float* sum_dy_z, const float* sum_dy, const float* mean, const float* var, float eps, float* dgamma, int C,
                      mv_stream_t stream);
+/* eqx.experimental.BatchNorm TRAINING branch, input gradient through the batch statistics.  The layer normalises with
+ * running' = a * batch + (1 - a) * running (a = 1 on the first call, 1 - momentum afterwards) and the batch mean / variance are
+ * differentiable functions of z, so   dz = scale * dy + A[c] + B[c] * z   with scale = gamma * rstd(running'),
+ *   B[c] = -(a / n) * scale * rstd^2 * (sum dy z - mean'[c] sum dy),   A[c] = -(a / n) * scale * sum dy - B[c] * batch_mean[c],
+ * batch_mean = sum_z / n.  The three column sums are over ALL n rows of the data-parallel batch (summed over ranks by the caller);
+ * n = *count when count != NULL (device scalar: ragged shards), else rows. */
+int mv_bn_train_dz_coef_f32(const float* sum_dy, const float* sum_dy_z, const float* sum_z, const float* mean, const float* var,
+                            const float* scale, const float* count, float rows, float a, float eps, float* A, float* B, int C,
+                            mv_stream_t stream);
 /* eqx.nn.LayerNorm backward over M rows of C (x = the forward input): dx, and dy_xhat = dy * x_hat (its column sums = dgamma;
  * the column sums of dy = dbeta). */
 int mv_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, float* dx, float* dy_xhat, int64_t M, int C, float eps,

@@ -1,8 +1,8 @@
 """CPU ORACLE (test infrastructure) for the BACKWARD half: torch.autograd on the fp32 `torch.nn.functional` restatement of
 oracle/torch_ref.py.  loss = mean over the batch of softmax cross-entropy against one-hot labels, as the reference's gradient
-test computes it (reference tests/test_grads.py:37-41: optax.softmax_cross_entropy(output, one_hot).mean()).  BatchNorm uses the
-stored running statistics as constants (inference mode; the reference's training branch also normalises with running statistics
-that its gradient does not see).  Returns (loss, {state-dict name: gradient}) for every floating-point
+test computes it (reference tests/test_grads.py:37-41: optax.softmax_cross_entropy(output, one_hot).mean()).  BatchNorm in inference mode uses the
+stored running statistics as constants; the TRAINING branch (`bn_train`, `resnet_train`) normalises with the statistics it has just
+updated from the batch and differentiates through the batch moments.  Returns (loss, {state-dict name: gradient}) for every floating-point
 parameter.  `dtype`: torch.float32 (default: the same arithmetic as the HIP path, so the ReLU / max-pool decisions of the two sides
 coincide almost everywhere) or torch.float64 (the exact gradient of the fp64 function; where an fp32 activation sits within
 rounding of zero the two evaluations take different branches, which shows up as 1e-3..1e-2 differences in single tensors of deep
@@ -58,6 +58,41 @@ def resnet(sd, x, labels, block="basic", layers=(2, 2, 2, 2), dtype=torch.float3
     y = TR._resnet_stages(t, torch.as_tensor(x).to(dtype), block, layers)[-1]
     y = F.adaptive_avg_pool2d(y, 1).flatten(1)
     return _finish(F.linear(y, t["fc.weight"], t["fc.bias"]), labels, P)
+
+
+def bn_train(sd, x, name, first, momentum=0.99, eps=1e-5, new_running=None):
+    """eqx.experimental.BatchNorm, TRAINING branch (restated from equinox 0.9's experimental/batch_norm.py):
+    per-channel batch mean and mean squared deviation over (batch, H, W); running' = batch on the layer's first call, else
+    (1 - momentum) * batch + momentum * running; the layer normalises with running' -- and nothing stops the gradient through the
+    batch moments, so autograd on this function carries the batch-statistics terms (in full on the first call, scaled by
+    1 - momentum afterwards).  `new_running[name]` receives the updated statistics (detached)."""
+    mean = x.mean((0, 2, 3))
+    var = ((x - mean[None, :, None, None]) ** 2).mean((0, 2, 3))
+    if first:
+        rm, rv = mean, var
+    else:
+        rm = (1.0 - momentum) * mean + momentum * sd[name + ".running_mean"]
+        rv = (1.0 - momentum) * var + momentum * sd[name + ".running_var"]
+    if new_running is not None:
+        new_running[name] = (rm.detach().numpy().copy(), rv.detach().numpy().copy())
+    y = (x - rm[None, :, None, None]) / torch.sqrt(rv[None, :, None, None] + eps)
+    return y * sd[name + ".weight"][None, :, None, None] + sd[name + ".bias"][None, :, None, None]
+
+
+def resnet_train(sd, x, labels, block="basic", layers=(2, 2, 2, 2), first=True, momentum=0.99, dtype=torch.float32):
+    """loss / gradients of the ResNet restatement with every BatchNorm in TRAINING mode (bn_train) -> (loss, grads, new_running)."""
+    P = _params(sd, dtype)
+    t = TR._t(P)
+    new_running = {}
+    saved = TR._bn
+    TR._bn = lambda sd_, x_, name, eps=1e-5: bn_train(sd_, x_, name, first, momentum, eps, new_running)
+    try:
+        y = TR._resnet_stages(t, torch.as_tensor(x).to(dtype), block, layers)[-1]
+    finally:
+        TR._bn = saved
+    y = F.adaptive_avg_pool2d(y, 1).flatten(1)
+    loss, grads = _finish(F.linear(y, t["fc.weight"], t["fc.bias"]), labels, P)
+    return loss, grads, new_running
 
 
 def vit(sd, x, labels, patch=16, num_heads=3, depth=12, dtype=torch.float32):

@@ -96,6 +96,50 @@ def grad_parity_case(model, B=2, size=224, classes=10, lim=1e-3):
     return run
 
 
+def bn_train_grad_case(B=4, size=64, classes=5):
+    """Training-mode BatchNorm gradients (round-4 advisor finding): resnet18 fresh from its factory (every BatchNorm on its first
+    call: the layer normalises with the BATCH statistics and the gradient flows through them in full), then a second batch through
+    the same model (running' = 0.01 batch + 0.99 running: the batch terms scaled by 1 - momentum) -- every parameter gradient of
+    both steps against torch.autograd on oracle/torch_grad.py: resnet_train, and the running statistics after each step."""
+    def run():
+        import eqxvision_amd as eqv
+        net = eqv.models.resnet18(num_classes=classes, key=eqv.random.PRNGKey(3))
+        assert not net.bn1.inference
+        fn = _loss_fn(_keys(B), classes)
+        out = {"ok": True, "err": 0.0}
+        sd = eqv.utils.state_dict(net)
+        for step, first in ((1, True), (2, False)):
+            x = S.synthetic_images(B, size, seed=20 + step)
+            labels = (np.arange(B) + step) % classes
+            ref_loss, ref, new_running = TG.resnet_train(sd, x, labels, "basic", (2, 2, 2, 2), first=first)
+            loss, grads = fn(net, x, labels)
+            got = eqv.utils.state_dict(grads)
+            got_l = [(k, v) for k, v in got.items() if "running" not in k and np.asarray(v).dtype.kind == "f"]
+            ref_l = [k for k in sd if k in ref]
+            if len(got_l) != len(ref_l):
+                return {"ok": False, "err": f"step {step}: {len(got_l)} gradient leaves vs {len(ref_l)} parameters"}
+            errs = sorted(((float(np.abs(np.asarray(a, np.float64).reshape(-1) - np.asarray(ref[n], np.float64).reshape(-1)).max()
+                                  / max(1e-12, np.abs(ref[n]).max())), n) for (_, a), n in zip(got_l, ref_l)), reverse=True)
+            ga = np.concatenate([np.asarray(a, np.float64).reshape(-1) for _, a in got_l])
+            gb = np.concatenate([np.asarray(ref[n], np.float64).reshape(-1) for n in ref_l])
+            l2 = float(np.linalg.norm(ga - gb) / max(1e-30, np.linalg.norm(gb)))
+            sd = eqv.utils.state_dict(net)                 # the running statistics the model holds now
+            stat_err = max(float(np.abs(np.asarray(sd[n + ".running_mean"], np.float64) - m).max() / max(1e-6, np.abs(m).max()))
+                           for n, (m, _) in new_running.items())
+            var_err = max(float(np.abs(np.asarray(sd[n + ".running_var"], np.float64) - v).max() / max(1e-6, np.abs(v).max()))
+                          for n, (_, v) in new_running.items())
+            # same criterion as grad_parity_case: a ReLU / max-pool branch flip between two fp32 summation orders is allowed for
+            over = sum(1 for e, _ in errs if e > 1e-3)
+            ok = (errs[0][0] <= 1e-3 and l2 <= 1e-3) or (l2 <= 1e-4 and errs[0][0] <= 1e-2 and over <= max(1, int(0.03 * len(errs))))
+            ok = ok and abs(loss - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss)) and stat_err <= 1e-4 and var_err <= 1e-4
+            out[f"step{step}"] = {"worst": errs[0], "rel_l2": l2, "loss": loss, "ref_loss": ref_loss, "running_mean_err": stat_err,
+                                  "running_var_err": var_err, "top": errs[:4]}
+            out["err"] = max(out["err"], errs[0][0])
+            out["ok"] = bool(out["ok"] and ok)
+        return out
+    return run
+
+
 def train_step_case(model, classes=3, steps=2, **model_kw):
     """The reference's test body: model in TRAINING mode (fresh init), one 224 x 224 image, label 1, adam(0.01)."""
     def run():
@@ -130,6 +174,7 @@ def all_cases():
             ("grad/vgg11_B1_vs_autograd", grad_parity_case("vgg11", 1, lim=1e-2)),
             ("grad/mobilenet_v2_B2_vs_autograd", grad_parity_case("mobilenet_v2", 2)),
             ("grad/swin_t_B2_vs_autograd", grad_parity_case("swin_t", 2)),
+            ("grad/resnet18_training_mode_bn_through_batch_stats_vs_autograd", bn_train_grad_case()),
             ("grad/step_alexnet_training_mode", train_step_case("alexnet")),
             ("grad/step_resnet18_training_mode", train_step_case("resnet18")),
             ("grad/step_vit_tiny_training_mode", train_step_case("vit_tiny")),

@@ -1056,6 +1056,37 @@ def large_logit_case(name, target=15.0, B=2, dtype="bf16"):
     return run
 
 
+def exported_factory_case(name, B=2, size=224, dtype="bf16"):
+    """An exported factory that no other case constructs (round-4 review, weak 7): the published architecture through
+    `eqv.models.<name>(torch_weights=...)` at 224 px against the torch restatement on the same synthetic checkpoint.  swin_b's widths
+    (128 / 256 / 512 / 1024) and resnet34's basic blocks at full width take dispatch paths of their own."""
+    def run():
+        import warnings
+        import eqxvision_amd as eqv
+        kw = {}
+        if name in ("swin_s", "swin_b"):
+            embed, heads = (96, (3, 6, 12, 24)) if name == "swin_s" else (128, (4, 8, 16, 32))
+            sd = S.swin_state(1, (4, 4), embed, (2, 2, 18, 2), heads)
+            ref_fn = lambda x: TR.swin_forward(sd, x, (4, 4), (2, 2, 18, 2), heads, (7, 7)).numpy()
+        elif name in ("vit_small", "vit_tiny"):
+            dim, heads = (384, 6) if name == "vit_small" else (192, 3)
+            sd = S.vit_state(1, size, 16, dim, 12, heads)
+            ref_fn = lambda x: TR.vit_forward(sd, x, 16, heads, 12).numpy()
+            kw = {"num_classes": 1000}
+        else:
+            block, layers, wpg = {"resnet34": ("basic", (3, 4, 6, 3), 64), "resnet101": ("bottleneck", (3, 4, 23, 3), 64),
+                                  "resnet152": ("bottleneck", (3, 8, 36, 3), 64), "wide_resnet50_2": ("bottleneck", (3, 4, 6, 3), 128)}[name]
+            sd = S.resnet_state(1, block, layers, 1000, width_per_group=wpg)
+            ref_fn = lambda x: TR.resnet_forward(sd, x, block, layers).numpy()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            net = _load(getattr(eqv.models, name), sd, **kw)
+        x = S.synthetic_images(B, size, seed=0)
+        got = _run(net, x, dtype).cpu().numpy()
+        return _cmp(got, ref_fn(x), 1e-2 if dtype == "bf16" else 1e-3)
+    return run
+
+
 def all_cases(full=True):
     c = [("model/resnet_tiny_bottleneck", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2)),
          ("model/resnet18_64px", resnet_case("basic", (2, 2, 2, 2), 64, 2)),
@@ -1136,6 +1167,12 @@ def all_cases(full=True):
               ("model/fcn_resnet50_B2", segmentation_case("fcn", (3, 4, 6, 3), 224, 2, classes=21, full_ref="torch")),
               ("model/deeplabv3_resnet50_B2", segmentation_case("deeplabv3", (3, 4, 6, 3), 224, 2, classes=21, full_ref="torch")),
               ("model/swin_t_B1", swin_case(224, 96, (2, 2, 6, 2), (3, 6, 12, 24), 1, classes=1000, full_ref="torch")),
+              ("model/factory_swin_s_B2", exported_factory_case("swin_s")),
+              ("model/factory_swin_b_B2", exported_factory_case("swin_b")),
+              ("model/factory_vit_small_B2", exported_factory_case("vit_small")),
+              ("model/factory_resnet34_B2", exported_factory_case("resnet34")),
+              ("model/factory_resnet101_B2", exported_factory_case("resnet101")),
+              ("model/factory_wide_resnet50_2_B2", exported_factory_case("wide_resnet50_2")),
               ("golden/committed_alexnet_224", committed_golden_case("alexnet")),
               ("golden/committed_resnet50_224", committed_golden_case("resnet50")),
               ("golden/committed_vit_base_224", committed_golden_case("vit_base")),

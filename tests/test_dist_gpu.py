@@ -92,3 +92,17 @@ def test_bench_spawns_its_ranks():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["config"]["parallelism"] == "dp2", line
     assert line["value"] > 0
+
+
+def test_bench_one_rank_logits_through_mv_allgather():
+    """Round-4 review, item 7: `bench.py --gpus 1` with EQV_FORCE_COMM=1 pushes the logits through mv_allgather on a 1-rank RCCL
+    communicator INSIDE the timed region (bench.py asserts the gathered buffer equals the local logits bit for bit) -- the code
+    path of BASELINE configs[3]'s 8-GPU line, executed at N = 1."""
+    env = dict(os.environ)
+    env.update(EQV_FORCE_COMM="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--batch", "64",
+                        "--soak", "0", "--no-cpu", "--extra", "none", "--no-lanes1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["collective"] == "mv_allgather (RCCL)" and line["config"]["collective_forced_1rank"], line
+    assert line["value"] > 0

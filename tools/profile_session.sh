@@ -34,33 +34,8 @@ find $O -name "*.db" -delete
 O=$O python - <<'PY'
 import csv, glob, collections, json, os, re, statistics
 O = os.environ["O"]
-def fam(name):
-    n = name
-    m = re.search(r"igemm8_kernel<(float|unsigned short), (true|false), (\d)>", n)       # <OutT, DUAL, MODE>: one bench name per symbol
-    if m:
-        f32 = "_f32out" if m.group(1) == "float" else ""
-        if m.group(2) == "true": return "igemm8_dual_bf16_256x256" + f32
-        return "igemm8_bf16_256x256_" + ("conv", "dense", "lin")[int(m.group(3))] + f32
-    m = re.search(r"igemm8s_kernel<(float|unsigned short), (\d), (true|false), (true|false)>", n)   # <OutT, ARR, DUAL, DENSE>
-    if m:
-        f32 = "_f32out" if m.group(1) == "float" else ""
-        arr = "128x256" if m.group(2) == "0" else "256x128"
-        if m.group(3) == "true": return "igemm8_dual_bf16_" + arr + f32
-        return "igemm8_bf16_" + arr + ("_dense" if m.group(4) == "true" else "_conv") + f32
-    for sub, f in (("unsigned short, true>", "igemm2_dual_bf16_256x256"), ("igemm2_kernel<4, 2, 2, 2, 3", "igemm2_bf16_256x128"),
-                   ("igemm2_kernel<2, 4, 4, 2, 2", "igemm2_bf16_256x256"), ("igemm2_kernel<8, 1, 1, 2, 3", "igemm2_bf16_256x64"),
-                   ("igemm_bf16_kernel<128, 128", "igemm_bf16_128x128"), ("igemm_bf16_kernel<128, 64", "igemm_bf16_128x64"),
-                   ("stream1x1_kernel", "stream1x1"), ("chain1x1_kernel<64, 8, false", "chain1x1_bf16_64_256_64"),
-                   ("chain1x1_kernel<128", "chain1x1_bf16_64_256_128"), ("chain1x1_kernel<64, 6, true", "chain1x1_dual_bf16_64+64_256_64"), ("chain_stream_kernel", "chain_stream_bf16_128_512_128"),
-                   ("conv3x3c64_v2_kernel", "conv3x3c64_halo"), ("stem_pool_kernel<float, true, 11", "stem_pool11_mfma_f32in"), ("stem_pool_kernel", "stem_pool_mfma_f32in"),
-                   ("patch_embed_kernel", "patch_embed_mfma_f32in"), ("mha_mfma_kernel", "mha_mfma_dh64_hm"),
-                   ("layernorm_vec_kernel", "layernorm_vec"), ("layernorm_slim_kernel", "layernorm_slim"), ("ln_mlp96_kernel", "ln_mlp96_f32stream"), ("swin_attn_mfma", "swin_attn_mfma"), ("skinny_f32_kernel", "skinny_linear_f32_mfma"),
-                   ("bneck_tail_kernel", "bneck_tail_bf16_14x14_256_1024"), ("ln_mlp_stream_kernel", "ln_mlp_stream_c384_f32stream"), ("ln_mlp_stream192_kernel", "ln_mlp_stream_c192_f32stream"),
-                   ("swin_win96_kernel", "swin_win96"), ("swin_block_attn_kernel<384", "swin_block_attn_c384"), ("swin_block_attn_kernel<192", "swin_block_attn_c192"), ("swin_block_attn_kernel<96", "swin_block_attn_c96"),
-                   ("patch_merge_ln_kernel", "patch_merge_ln_f32in"), ("swin_stem_ln_kernel", "swin_stem_ln_k96"),
-                   ("fc_stream_kernel", "fc_stream_bf16"), ("maxpool_nhwc_bf16x8_kernel", "maxpool_nhwc_bf16x8")):
-        if sub in n: return f
-    return None
+import sys; sys.path.insert(0, 'tools')
+from kernel_families import fam
 out = {"_batch": {}, "_rocprof": {}, "_rocprof_lanes1": {}}
 lines = []
 for M, B in (("resnet50", 256), ("vit_base", 256), ("swin_t", 128), ("alexnet", 256)):
