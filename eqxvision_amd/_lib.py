@@ -90,8 +90,6 @@ PROTOTYPES = {
     "mv_conv1x1_chain_fwd": [_vp] * 10 + [_i64, _i, _i, _i, _i, _vp],
     "mv_bottleneck_tail_supported": [_i] * 5,
     "mv_bottleneck_tail_fwd": [_vp] * 9 + [_i] * 6 + [_vp],
-    "mv_bottleneck_strip_supported": [_i] * 7,
-    "mv_bottleneck_strip_fwd": [_vp] * 11 + [_i] * 8 + [_vp],
     "mv_conv1x1_dual_supported": [_i64, _i, _i, _i, _i],
     "mv_conv1x1_dual_fwd": [_vp] * 6 + [_i] * 11 + [_vp],
     "mv_conv1x1_dual_chain_supported": [_i64, _i, _i, _i, _i, _i],
@@ -188,7 +186,22 @@ def set_recording(rec):
     old = getattr(_tls, "rec", None)
     _tls.rec = rec
     _tls.pending_scratch = None        # a hand-over never outlives the recording it was made in
+    if rec is not None:
+        _tls.not_replayable = None
+    if _lib is not None:               # ... on the library's side of the ABI either (advisor, round 4)
+        _lib.mv_set_scratch(None, 0, None)
     return old
+
+
+def mark_not_replayable(reason: str):
+    """Called by code whose results are HOST values or whose work is not a pure list of launches (filter_value_and_grad: the loss is a
+    Python float, gradients are fetched after a synchronize): a recording in progress on this thread must not be replayed."""
+    if getattr(_tls, "rec", None) is not None:
+        _tls.not_replayable = reason
+
+
+def not_replayable():
+    return getattr(_tls, "not_replayable", None)
 
 
 _grad_guard = None      # set by eqxvision_amd.grad: refuses launches of un-differentiable ops inside filter_value_and_grad

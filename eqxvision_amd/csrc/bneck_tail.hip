@@ -353,11 +353,8 @@ int mv_bottleneck_tail_fwd(const void* t1, const void* w2f, const float* scale2,
     constexpr int SMEM = 7 * 32 * 512 + 8 * 32 * 144;        // t2 + the 8 epilogue patches (>= the zero-bordered t1 map)
     static_assert(SMEM >= (7 * 32 + 34) * 512, "t1 map must fit");
     auto kern = bneck_tail_kernel<256, 1024, 14>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        attr_set = true;
-    }
+    static LdsAttrSite attr;
+    MV_HIP(attr.ensure((const void*)kern, SMEM));
     set_kernel_name("bneck_tail_bf16_14x14_256_1024");
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(512), SMEM, stream, p);
     MV_LAUNCH_CHECK();

@@ -1,5 +1,6 @@
 // Shared device/host helpers for the gfx950 kernels.  CDNA4 only: wave = 64 lanes.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -84,6 +85,7 @@ void append_kernel_name(const char* suffix);
 int get_flag(const char* name);
 // the scratch the host handed over with mv_set_scratch for the next launch on `stream`: returned (and forgotten) if it holds
 // at least `need` bytes, else nullptr
+constexpr size_t SCRATCH_SYNC_BYTES = 4096;      // head of every scratch offer: split-K arrival words, zero between launches
 void* take_scratch(hipStream_t stream, size_t need);
 void* peek_scratch(hipStream_t stream, size_t* bytes);
 size_t splitk_scratch_bytes(long long M, long long N, long long kred);       // igemm8.hip
@@ -111,6 +113,24 @@ inline size_t dsize(int dt) { return dt == MV_BF16 ? 2 : 4; }
             return (int)e__;                                                         \
         }                                                                            \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: a launch site keeps one of these (static) and asks
+// before every launch; the attribute is set the first time the site launches on a device (and again if it needs more LDS than any
+// earlier launch asked for on that device).  Lock-free: two threads racing on the first launch both set the same value.
+struct LdsAttrSite {
+    std::atomic<int> bytes[16];                 // per device ordinal (mod 16): the largest size already granted
+    LdsAttrSite() { for (auto& b : bytes) b.store(0, std::memory_order_relaxed); }
+    hipError_t ensure(const void* kern, size_t need) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        std::atomic<int>& b = bytes[dev & 15];
+        if (b.load(std::memory_order_acquire) >= (int)need) return hipSuccess;
+        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+        if (e == hipSuccess) b.store((int)need, std::memory_order_release);
+        return e;
+    }
+};
 
 #define MV_HIP(call)                                                                 \
     do {                                                                             \

@@ -272,11 +272,8 @@ static int conv_generic_dispatch(const void* x, const void* w, const float* scal
         const long long M = (long long)p.N * p.Ho * p.Wo;
         constexpr int SMEM = 2 * (64 + 256) * 36 * 4;
         set_kernel_name("conv_f32_lds_mfma");
-        static bool attr_set = false;
-        if (!attr_set) {
-            MV_HIP(hipFuncSetAttribute((const void*)conv_f32_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-            attr_set = true;
-        }
+        static LdsAttrSite attr;
+        MV_HIP(attr.ensure((const void*)conv_f32_lds_kernel, SMEM));
         hipLaunchKernelGGL(conv_f32_lds_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)((p.K + 63) / 64)), dim3(512), SMEM, st,
                            (const float*)x, (const float*)w, scale, shift, (const float*)residual, (float*)y, pos, p);
         MV_LAUNCH_CHECK();
@@ -521,11 +518,8 @@ static int attn_f32_lds_go(const float* qkv, const float* bias, float* out, floa
     constexpr int NW = SWIN ? 4 : 16;
     const size_t smem = ((size_t)2 * p.n * (p.dh + 1) + NW * (size_t)(p.n + p.dh)) * sizeof(float);
     auto kern = attn_f32_lds_kernel<SWIN>;
-    static size_t attr = 0;
-    if (smem > attr) {
-        MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = smem;
-    }
+    static LdsAttrSite attr;
+    MV_HIP(attr.ensure((const void*)kern, smem));
     hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)p.H, (unsigned)B), dim3(NW * 64), smem, st, qkv, bias, out, probs, p);
     MV_LAUNCH_CHECK();
     return MV_OK;

@@ -662,10 +662,11 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
             return;
         }
         if (tid == 0) {
-            int spins = 0;                                   // bounded: a stale word can cost a wrong tile, never a hung GPU
-            unsigned f;
+            int spins = 0;                                   // bounded (~0.1 s): never a hung GPU -- and never a silently wrong tile:
+            unsigned f;                                      // the partner is past its main loop when this block gets here, so running
             while ((f = __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && ++spins < (1 << 20))
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(2);                 // out of spins means a broken hand-over (dirty sync words): abort the launch,
+            if (f == 0u) __builtin_trap();                   // the host sees hipErrorLaunchFailure at its next call (advisor, round 4)
             if (f != 1u + xcc) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -720,7 +721,7 @@ static bool splitk_rule(long long tiles, long long nk) {
     const int max_tiles = 128;
     return tiles <= max_tiles && nk >= min_nk;
 }
-constexpr size_t SPLITK_SYNC_BYTES = 4096;            // 2 words x 512 tiles
+constexpr size_t SPLITK_SYNC_BYTES = SCRATCH_SYNC_BYTES;            // 2 words x 512 tiles
 
 size_t splitk_scratch_bytes(long long M, long long N, long long kred) {
     if (N <= 0 || M <= 0) return 0;
@@ -748,11 +749,8 @@ static int igemm8_go(Igemm2P& p, bool dual, bool out_f32, int tile, hipStream_t 
 #define GO(KERN, SMEM)                                                                                            \
     do {                                                                                                          \
         auto kern = KERN;                                                                                         \
-        static bool attr_set = false;                                                                             \
-        if (!attr_set) {                                                                                          \
-            MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));     \
-            attr_set = true;                                                                                      \
-        }                                                                                                         \
+        static LdsAttrSite attr;                                                                                  \
+        MV_HIP(attr.ensure((const void*)kern, SMEM));                                                             \
         hipLaunchKernelGGL(kern, grid, block, SMEM, st, p);                                                       \
     } while (0)
 #define GO4(NAME, SMEM, ...)                                                  \

@@ -749,11 +749,8 @@ int mv_swin_block_attn_fwd(const void* x, const void* wqkv_f, const float* bqkv,
 #define MV_SBA_GO(CC, NW, WV)                                                                                        \
     do {                                                                                                             \
         auto kern = swin_block_attn_kernel<CC, NW, WV>;                                                              \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
-            MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
-            attr_set = true;                                                                                         \
-        }                                                                                                            \
+        static LdsAttrSite attr;                                                                                     \
+        MV_HIP(attr.ensure((const void*)kern, smem));                                                                \
         hipLaunchKernelGGL(kern, grid, dim3(WV * 64), smem, stream, p);                                              \
     } while (0)
     if (C == 384) { set_kernel_name("swin_block_attn_c384"); MV_SBA_GO(384, 1, 8); }

@@ -656,13 +656,17 @@ int mv_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw_krsc, in
         if (split > 1024) split = 1024;
         float* part = dw_krsc;
         if (split > 1) {
+            // partial sums live BEHIND the first 4096 bytes of the offer: those are the arrival words of the forward's split-K
+            // protocol (header: mv_set_scratch) and stay zero, so an offer this entry leaves unused can never hand a later
+            // split-K launch a dirty sync area
             size_t have = 0;
             void* sc = peek_scratch((hipStream_t)stream, &have);
+            have = have > SCRATCH_SYNC_BYTES ? have - SCRATCH_SYNC_BYTES : 0;
             const long long fit = sc ? (long long)(have / ((size_t)out_elems * 4)) : 0;
             if (fit < 2) split = 1;
             else {
                 if (split > fit) split = fit;
-                part = (float*)take_scratch((hipStream_t)stream, (size_t)split * out_elems * 4);
+                part = (float*)((char*)take_scratch((hipStream_t)stream, SCRATCH_SYNC_BYTES + (size_t)split * out_elems * 4) + SCRATCH_SYNC_BYTES);
             }
         }
         const long long chunk = ((P + split - 1) / split + 1) & ~1LL;                 // even: a pair of positions never straddles two chunks
@@ -718,7 +722,8 @@ int mv_colsum_f32(const float* a, const float* b, float* out, int64_t M, int C, 
     long long split = M >= 512 ? (M + 255) / 256 : 1;
     if (split > 512) split = 512;
     if (split > 1) {
-        float* part = (float*)take_scratch((hipStream_t)stream, (size_t)split * C * 4);
+        char* sc = (char*)take_scratch((hipStream_t)stream, SCRATCH_SYNC_BYTES + (size_t)split * C * 4);
+        float* part = sc ? (float*)(sc + SCRATCH_SYNC_BYTES) : nullptr;          // behind the split-K sync area (see conv wgrad)
         if (part) {
             const long long chunk = (M + split - 1) / split;
             set_kernel_name("colsum_split_f32");

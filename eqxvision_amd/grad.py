@@ -160,7 +160,9 @@ def _offer_scratch():
     key = (_S(), torch.cuda.current_device())
     ws = _BWD_SCRATCH.get(key)
     if ws is None:
-        ws = _BWD_SCRATCH[key] = torch.empty(_BWD_SCRATCH_BYTES, dtype=torch.uint8, device=device())
+        # zero-initialised: the first 4096 bytes are the split-K arrival words of the scratch protocol; the backward entries keep
+        # their partial sums behind them, so an offer that a launch leaves unused is still a valid split-K hand-over
+        ws = _BWD_SCRATCH[key] = torch.zeros(_BWD_SCRATCH_BYTES, dtype=torch.uint8, device=device())
     _call("mv_set_scratch", _p(ws), _BWD_SCRATCH_BYTES, _S())
 
 
@@ -828,7 +830,9 @@ class _Rows:
 
 
 def one_hot(labels, num_classes: int) -> np.ndarray:
-    lab = np.asarray(labels).reshape(-1).astype(np.int64)
+    if isinstance(labels, torch.Tensor):          # under filter_jit the label array arrives staged on the device
+        labels = labels.detach().cpu().numpy()
+    lab = np.rint(np.asarray(labels)).reshape(-1).astype(np.int64)
     out = np.zeros((lab.shape[0], num_classes), np.float32)
     out[np.arange(lab.shape[0]), lab] = 1.0
     return out
@@ -904,6 +908,10 @@ def filter_value_and_grad(fn: Callable) -> Callable:
     def wrapped(model, *args, **kwargs):
         if active():
             raise RuntimeError("filter_value_and_grad does not nest")
+        # under filter_jit (the reference wraps its make_step in eqx.filter_jit): the loss is a host float and the gradients are read
+        # after a synchronize -- a replay of the launches would hand back the first call's values.  The trace in progress is marked
+        # so that filter_jit runs this function eagerly on every call (transforms.jitted).
+        _lib.mark_not_replayable("filter_value_and_grad returns host values")
         if not torch.cuda.is_available():
             raise _lib.MVError("eqxvision_amd needs an MI355X (no HIP device visible); there is no CPU fallback")
         t = _tls.tape = Tape()

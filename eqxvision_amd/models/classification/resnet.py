@@ -108,12 +108,6 @@ class _ResNetBottleneck(Module):
         ds = self.downsample
         conv_ds = isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d) and \
             isinstance(ds[1], nn.BatchNorm)
-        if pre is None and (isinstance(ds, nn.Identity) or conv_ds):
-            # the whole block in one launch, t1 / t2 on the CU, the input read once as operand and identity
-            # (ops.bottleneck_strip; None when the library has no such path for the shapes: everything but the 56x56 stage)
-            y = ops.bottleneck_strip(x, self, (ds[0], ds[1]) if conv_ds else None)
-            if y is not None:
-                return y
         if pre is not None and pre[0] is self.conv1:
             out = pre[1]
         else:

@@ -518,82 +518,6 @@ def bottleneck_tail(t1: Act, conv2, bn2, conv3, bn3, identity: Act) -> Optional[
     return Act(y, "map", t1.batched)
 
 
-def _frag_rows(w: np.ndarray) -> np.ndarray:
-    """[K][C] (K % 32 == 0, C % 16 == 0) -> MFMA A-fragment order [K/32][C/16][lane = 32 (k-half) + row][8]."""
-    K, C = w.shape
-    return np.ascontiguousarray(w.reshape(K // 32, 32, C // 16, 2, 8).transpose(0, 2, 3, 1, 4))
-
-
-def prep_bneck_strip(block, ds):
-    """Weights of a whole layer-1 bottleneck in the fragment order of mv_bottleneck_strip_fwd (header), cached on conv1.
-    ds = None (identity block) or the (conv, bn) of the downsample branch."""
-    conv1, bn1, conv2, bn2, conv3, bn3 = block.conv1, block.bn1, block.conv2, block.bn2, block.conv3, block.bn3
-    dual = ds is not None
-    key = ("bneck_strip", _bn_id(bn1), id(conv2), _bn_id(bn2), id(conv3), _bn_id(bn3),
-           None if ds is None else (id(ds[0]), _bn_id(ds[1])))
-    cache = conv1._cache()
-    hit = cache.get(key)
-    if hit is None:
-        w1 = np.asarray(conv1.weight, np.float32).reshape(conv1.out_channels, conv1.in_channels)
-        s1, h1 = _fold(conv1, bn1)
-        w2 = np.ascontiguousarray(np.asarray(conv2.weight, np.float32).transpose(0, 2, 3, 1))     # [K][R][S][C]
-        K, R, S, C = w2.shape
-        w2f = w2.reshape(K // 32, 32, R * S, C // 16, 2, 8).transpose(0, 2, 3, 4, 1, 5)            # (a, tap, j, h, m, e)
-        s2, h2 = _fold(conv2, bn2)
-        if dual:
-            w3s, h3 = _scaled_rows(conv3, bn3)
-            wds, hd = _scaled_rows(ds[0], ds[1])
-            wcat = np.concatenate([w3s, wds], axis=1)
-            s3, h3 = np.ones(conv3.out_channels, np.float32), (h3 + hd).astype(np.float32)
-        else:
-            wcat = np.asarray(conv3.weight, np.float32).reshape(conv3.out_channels, conv3.in_channels)
-            s3, h3 = _fold(conv3, bn3)
-        hit = (_dev(_frag_rows(w1), torch.bfloat16), _dev(s1, torch.float32), _dev(h1, torch.float32),
-               _dev(np.ascontiguousarray(w2f), torch.bfloat16), _dev(s2, torch.float32), _dev(h2, torch.float32),
-               _dev(_frag_rows(wcat), torch.bfloat16), _dev(s3, torch.float32), _dev(h3, torch.float32),
-               (conv2, conv3, ds))                                                                # keeps the id()s in the key alive
-        cache[key] = hit
-    return hit
-
-
-def bottleneck_strip(x: Act, block, ds=None) -> Optional[Act]:
-    """A whole bottleneck (conv1 -> conv2 3x3 -> conv3 + identity, resnet.py:144-162) in ONE launch with both 64-channel
-    intermediates on the CU and the block input read once (mv_bottleneck_strip_fwd).  `block` = a _ResNetBottleneck; `ds` = None
-    when its identity is the input itself, else the (conv1x1, BatchNorm) of its downsample branch (resnet.py:295-303).  None when
-    the library has no such path for the shapes.
-
-    OPT-IN (`mv_set_flag("bneck_strip", 1)`): measured on MI355X (profiles/r04/bneck_strip_phase_stamps.txt) the launch moves 25 %
-    fewer bytes than the un-fused conv3x3c64 + chain1x1 pair (462 vs 617 MB per 128 images) but takes 181 us against their 154:
-    the one workgroup a CU can hold (157 KB of LDS, 256 VGPRs) loads, multiplies and stores in turn, and a CU's memory pipe idles
-    while it multiplies."""
-    dt = compute_dtype()
-    if dt != "bf16" or not _lib.get_flag("bneck_strip"):
-        return None
-    conv1, conv2, conv3 = block.conv1, block.conv2, block.conv3
-    if any(_bn_training(b) for b in (block.bn1, block.bn2, block.bn3)):
-        return None
-    if not (_pointwise(conv1) and _pointwise(conv3)) or tuple(conv2.kernel_size) != (3, 3) or tuple(conv2.stride) != (1, 1) \
-            or tuple(conv2.padding) != (1, 1) or tuple(conv2.dilation) != (1, 1) or conv2.groups != 1:
-        return None
-    dual = ds is not None
-    if dual and (not _pointwise(ds[0]) or _bn_training(ds[1]) or ds[0].out_channels != conv3.out_channels
-                 or ds[0].in_channels != conv1.in_channels):
-        return None
-    x = as_map(x)
-    B, H, W, C = x.t.shape
-    if x.t.dtype != torch.bfloat16 or C != conv1.in_channels or conv2.in_channels != conv1.out_channels \
-            or conv2.out_channels != conv3.in_channels or (not dual and conv3.out_channels != C):
-        return None
-    wid, K = conv1.out_channels, conv3.out_channels
-    if not _lib.load().mv_bottleneck_strip_supported(H, W, C, wid, K, int(dual), DT[dt]):
-        return None
-    w1f, s1, h1, w2f, s2, h2, w3f, s3, h3, _ = prep_bneck_strip(block, ds)
-    y = empty((B, H, W, K), torch.bfloat16)
-    _lib.call("mv_bottleneck_strip_fwd", _ptr(x.t), _ptr(w1f), _ptr(s1), _ptr(h1), _ptr(w2f), _ptr(s2), _ptr(h2), _ptr(w3f),
-              _ptr(s3), _ptr(h3), _ptr(y), B, H, W, C, wid, K, int(dual), DT[dt], stream_ptr())
-    return Act(y, "map", x.batched)
-
-
 def _scaled_rows(conv, bn) -> Tuple[np.ndarray, np.ndarray]:
     """A pointwise conv + BatchNorm(inference) as (scale[k] * W[k, :], shift[k]) in fp32."""
     w = np.asarray(conv.weight, np.float32).reshape(conv.out_channels, -1)
@@ -777,6 +701,7 @@ def _splitk_scratch(M: int, N: int, kred: int):
     stream.  The first 4096 bytes (the tiles' arrival words) are zeroed once; the kernel leaves them zero."""
     nbytes = int(_lib.load().mv_splitk_scratch_bytes(M, N, kred))
     if not nbytes:
+        _lib.call("mv_set_scratch", None, 0, stream_ptr())       # withdraw whatever an earlier entry left pending on this thread
         return
     from . import _act
     if getattr(_act._tls, "keep", None) is not None:

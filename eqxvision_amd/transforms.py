@@ -347,6 +347,8 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
         flat_all = list(args) + [v for _, v in sorted(kwargs.items())]
         ptrs = tuple(v.data_ptr() for v in flat_all if _is_array(v) and _is_resident(v))
         grp = cache.get(key)
+        if grp is not None and grp.get("eager"):
+            return fn(*args, **kwargs)             # traced once and found not replayable (host results: see below)
         if grp is None:
             grp = cache[key] = {"variants": {}, "owned": None}
             while len(cache) > MAX_CACHE_SIGNATURES:         # LRU eviction
@@ -398,6 +400,13 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
                         c.out = fn(*new_args, **new_kwargs)
                 finally:
                     _lib.set_recording(old)
+            if _lib.not_replayable():
+                # the function produced host values while it was traced (a training step: filter_value_and_grad's loss / gradients):
+                # what it returned IS this call's result; nothing is cached and every later call with this signature runs eagerly
+                grp["eager"] = True
+                out = c.out
+                _release(c)
+                return out
             if own:
                 grp["owned"] = c
             else:

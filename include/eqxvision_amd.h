@@ -48,7 +48,7 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  *                   "no_igemm2", "igemm_tile" (1 / 2), "no_skinny", "no_tuned", "no_dual", and the per-shape choice
  *                   "ov:<M>:<C>:<K>:<R>:<S>:<stride>" / "ovh:<M>:<N>:<K>:1:1:1" / "ovd:<M>:<C1>:<C2>:<K>:<stride>:1" (tools/tune_tiles.py)
  *   streaming 1x1   "no_stream", "no_stream_narrow", "no_chain", "no_chain_stream", "no_dual_chain", "no_ln_stream", "ln_stream_192"
- *   whole blocks    "no_bneck_tail", "bneck_strip" (opt-IN: the layer-1 row-strip kernel, slower than the launches it replaces),
+ *   whole blocks    "no_bneck_tail",
  *                   "no_ln_mlp", "ln_mlp_waves" (8 / 12 / 16), "no_ln_mlp_stream", "no_swin_block_attn", "swin_c96_shared" (the
  *                   two-windows-per-workgroup kernel at C = 96), "no_patch_merge_ln", "no_patch4_ln", "no_fc_stream"
  *   entry / misc    "stem_v0", "no_stem_pool", "no_stem_pool11", "no_patch_f32out", "no_ln_slim", "no_grouped64", "no_dwconv",
@@ -140,26 +140,6 @@ int mv_bottleneck_tail_supported(int H, int W, int width, int cout, int dtype);
 int mv_bottleneck_tail_fwd(const void* t1, const void* w2f, const float* scale2, const float* shift2, const void* w3f,
                            const float* scale3, const float* shift3, const void* residual, void* y, int B, int H, int W,
                            int width, int cout, int dtype, mv_stream_t stream);
-
-/* A WHOLE ResNet bottleneck of the 56x56 stage in one launch, row-strip tiled (resnet.py:144-162; first block of the stage:
- * + the downsample branch, resnet.py:295-303):
- *   t1 = relu(scale1 * conv1x1(x, w1) + shift1)            (64 channels, stays in LDS with a recomputed one-row halo, bf16)
- *   t2 = relu(scale2 * conv3x3_pad1(t1, w2) + shift2)      (64 channels, stays in registers, bf16)
- *   dual = 0:  y = relu(scale3 * (t2 . w3^T) + shift3 + x)                        x[B,56,56,256] is read ONCE: operand and identity
- *   dual = 1:  y = relu((t2 . w3s^T + x . wds^T) + shift3)                        x[B,56,56,64]; w3s = scale3 * w3, wds = scale_d * w_d
- *                                                                                   (rows folded by the caller), shift3 = shift3 + shift_d,
- *                                                                                   scale3 = ones
- * One workgroup = 8 rows x 56 columns of one image.  Weights in FRAGMENT ORDER (eqxvision_amd/ops.py:prep_bneck_strip),
- * lane = 32 * (k-half) + (output channel % 32), e = 8 consecutive input channels:
- *   w1f[a 0..1][j 0..cin/16-1][lane][e]       = w1[k = 32 a + lane%32][c = 16 j + 8 (lane/32) + e]
- *   w2f[a 0..1][tap r*3+s][j 0..3][lane][e]   = w2[k = 32 a + lane%32][r][s][c = 16 j + 8 (lane/32) + e]         (KRSC)
- *   w3f[a 0..7][j 0..3 (dual: 0..7)][lane][e] = wcat[k = 32 a + lane%32][c = 16 j + 8 (lane/32) + e],  wcat = w3 or [w3s | wds]
- * Supported: bf16, 56x56, width 64, cout 256, cin 256 (dual 0) or 64 (dual 1): ResNet-50/101/152 layer1.  y must not alias x. */
-int mv_bottleneck_strip_supported(int H, int W, int cin, int width, int cout, int dual, int dtype);
-int mv_bottleneck_strip_fwd(const void* x, const void* w1f, const float* scale1, const float* shift1, const void* w2f,
-                            const float* scale2, const float* shift2, const void* w3f, const float* scale3,
-                            const float* shift3, void* y, int B, int H, int W, int cin, int width, int cout, int dual,
-                            int dtype, mv_stream_t stream);
 
 /* conv3 + BN and the downsample conv + BN of a stage's first bottleneck (resnet.py:144-162, 295-303) as ONE GEMM over
  * the concatenated reduction: both add into the same output, so
@@ -307,8 +287,11 @@ int mv_fc_stream_fwd(const void* x, const void* w_frag, const float* bias, void*
  * K_reduction = R * S * C (+ C2) elements, 0 when it would not split.  Protocol: the first 4096 bytes must be ZERO when the memory is
  * first handed over (the kernel leaves them zero again); the memory must stay valid until the launch has completed on `stream`, and
  * must not be shared with a launch that can run concurrently (another stream / another branch of a captured graph).  The hand-over
- * is consumed by the launch that uses it; one that does not split ignores it; bytes = 0 / ptr = NULL withdraws it.  Without scratch
- * every launch runs un-split (same entry points, same results to within fp32 summation order). */
+ * is consumed by the launch that uses it; one that does not split ignores it and LEAVES IT PENDING for the next entry on this
+ * thread and stream, so a host that does not want that withdraws it (bytes = 0 / ptr = NULL).  Every consumer -- the backward
+ * entries too (mv_colsum_f32, the weight gradient) -- keeps its data behind the first 4096 bytes and those stay zero, so a pending
+ * offer is always a valid hand-over for whichever entry takes it.  Without scratch every launch runs un-split (same entry points,
+ * same results to within fp32 summation order). */
 int mv_set_scratch(void* ptr, int64_t bytes, mv_stream_t stream);
 int64_t mv_splitk_scratch_bytes(int64_t M, int64_t N, int64_t K_reduction);
 
@@ -434,7 +417,7 @@ int mv_cast(const void* x, void* y, int64_t n, int in_dtype, int out_dtype, mv_s
  * operands transposed with mv_transpose2d_f32 (eqxvision_amd/grad.py); these entries are the gradient kernels with no forward twin. */
 /* Conv2d (eqx.nn.Conv2d incl. grouped / depthwise): dx[N,H,W,C] from dy[N,Ho,Wo,K] and w [K][R][S][C/groups]; dw in the same
  * layout from x and dy.  Both run on the fp32 matrix cores (dgrad: groups = 1).  The weight gradient's reduction runs over all
- * N Ho Wo output positions: with scratch on offer (mv_set_scratch, any size from 2 x the gradient's bytes up) the positions are split
+ * N Ho Wo output positions: with scratch on offer (mv_set_scratch, any size from 4096 + 2 x the gradient's bytes up) the positions are split
  * over blocks and the parts added in a fixed order (bit-reproducible); without it one block walks all positions of its tile. */
 int mv_conv2d_dgrad_nhwc_f32(const float* dy, const float* w_krsc, float* dx, int N, int H, int W, int C, int K, int R, int S,
                              int sh, int sw, int ph, int pw, int dh, int dw, int groups, mv_stream_t stream);
@@ -453,7 +436,7 @@ int mv_avgpool_global_bwd_nhwc_f32(const float* dy, float* dx, int N, int HW, in
 int mv_mha_bwd_f32(const float* qkv, const float* probs, const float* dout, float* ds_scratch, float* dqkv, int B, int N, int H, int dh,
                    float scale, mv_stream_t stream);
 /* out[c] = sum over the M rows of a[m,c] * (b ? b[m,c] : 1): bias / beta gradients (b = NULL), gamma gradients (b = x_hat).  From 512
- * rows up it takes ceil(M / 256) (<= 512) x C floats of scratch when on offer (mv_set_scratch): rows split over blocks, fixed-order finish. */
+ * rows up it takes 4096 bytes + ceil(M / 256) (<= 512) x C floats of scratch when on offer (mv_set_scratch): rows split over blocks, fixed-order finish. */
 int mv_colsum_f32(const float* a, const float* b, float* out, int64_t M, int C, mv_stream_t stream);
 /* y = x * s[b, c] (SqueezeExcitation's multiply, DropPath): ds[b, c] = sum over the image's HW positions of g * x; dx is the
  * forward multiply applied to g (mv_channel_scale_nhwc_fwd). */

@@ -290,80 +290,6 @@ def bneck_tail_case(B, seed=0, HW=14, WID=256, COUT=1024, big=False):
     return run
 
 
-def bneck_strip_case(B, dual=False, seed=0, big=False, neg=True):
-    """mv_bottleneck_strip_fwd: a whole layer-1 bottleneck (conv1 1x1 + BN + ReLU -> conv2 3x3 + BN + ReLU -> conv3 1x1 + BN +
-    identity + ReLU, resnet.py:144-162; dual: identity = BN(conv1x1(x)), resnet.py:295-303, scales folded into the bf16 weight
-    rows as ops.prep_bneck_strip does) in one launch vs the oracle; t1 / t2 are rounded to bf16 where the un-fused launches store
-    them.  Weights are handed over in the fragment order the header documents."""
-    def run():
-        L = _lib()
-        rng = _rng(seed)
-        HW, WID, COUT = 56, 64, 256
-        CIN = 64 if dual else 256
-        amp = 4.0 if big else 1.0
-        x = bf(np.maximum(rng.standard_normal((B, CIN, HW, HW)), -0.5) * amp)
-        w1 = bf(rng.standard_normal((WID, CIN)) / np.sqrt(CIN))
-        w2 = bf(rng.standard_normal((WID, WID, 3, 3)) / np.sqrt(WID * 9))
-        w3 = rng.standard_normal((COUT, WID)) / np.sqrt(WID)
-        wd = rng.standard_normal((COUT, CIN)) / np.sqrt(CIN)
-
-        def ss(n, step):
-            s_ = rng.uniform(0.5, 1.5, n).astype(np.float32)
-            if neg:
-                s_[::step] *= -1.0
-            return s_, (0.1 * rng.standard_normal(n)).astype(np.float32)
-        s1, h1 = ss(WID, 7)
-        s2, h2 = ss(WID, 5)
-        s3, h3 = ss(COUT, 11)
-        sd, hd = ss(COUT, 13)
-        if not L.load().mv_bottleneck_strip_supported(HW, HW, CIN, WID, COUT, int(dual), 1):
-            return {"ok": False, "err": "mv_bottleneck_strip_supported says no"}
-        f64 = np.float64
-        t1 = np.einsum("bchw,kc->bkhw", x.astype(f64), w1.astype(f64))
-        t1 = bf(O.relu(t1 * s1[None, :, None, None] + h1[None, :, None, None]))
-        t2 = np.stack([O.conv2d(t1[i], w2, None, 1, 1, 1, 1) for i in range(B)])
-        t2 = bf(O.relu(t2 * s2[None, :, None, None] + h2[None, :, None, None]))
-        if dual:
-            w3s, wds = bf(w3 * s3[:, None]), bf(wd * sd[:, None])
-            wcat = np.concatenate([w3s, wds], axis=1)
-            yref = np.einsum("bchw,kc->bkhw", t2.astype(f64), w3s.astype(f64)) + np.einsum("bchw,kc->bkhw", x.astype(f64), wds.astype(f64))
-            sc3, sh3 = np.ones(COUT, np.float32), (h3 + hd).astype(np.float32)
-            yref = O.relu(yref + sh3[None, :, None, None])
-        else:
-            wcat = bf(w3)
-            sc3, sh3 = s3, h3
-            yref = np.einsum("bchw,kc->bkhw", t2.astype(f64), wcat.astype(f64))
-            yref = O.relu(yref * s3[None, :, None, None] + h3[None, :, None, None] + x)
-
-        def frag(w):
-            K, C = w.shape
-            return np.ascontiguousarray(w.reshape(K // 32, 32, C // 16, 2, 8).transpose(0, 2, 3, 1, 4))
-        w2k = np.ascontiguousarray(w2.transpose(0, 2, 3, 1))                                              # KRSC
-        w2f = w2k.reshape(WID // 32, 32, 9, WID // 16, 2, 8).transpose(0, 2, 3, 4, 1, 5)
-        d = {k: dev(v, "bf16") for k, v in dict(x=x.transpose(0, 2, 3, 1), w1f=frag(w1), w2f=w2f, w3f=frag(wcat)).items()}
-        f = {k: dev(v, "fp32") for k, v in dict(s1=s1, h1=h1, s2=s2, h2=h2, s3=sc3, h3=sh3).items()}
-        y = torch.full((B, HW, HW, COUT), -7.0, dtype=torch.bfloat16, device="cuda")
-        L.call("mv_bottleneck_strip_fwd", d["x"].data_ptr(), d["w1f"].data_ptr(), f["s1"].data_ptr(), f["h1"].data_ptr(),
-               d["w2f"].data_ptr(), f["s2"].data_ptr(), f["h2"].data_ptr(), d["w3f"].data_ptr(), f["s3"].data_ptr(), f["h3"].data_ptr(),
-               y.data_ptr(), B, HW, HW, CIN, WID, COUT, int(dual), 1, _stream())
-        kern = L.last_kernel()
-        torch.cuda.synchronize()
-        info = _cmp(host(y).transpose(0, 3, 1, 2), yref, TOL_BF16)
-        info["kernel"] = kern
-        return info
-    return run
-
-
-# ---- backward kernels (csrc/train_bwd.hip) vs torch.autograd on the CPU (fp32 both sides)
-def _ag(fn, *inputs):
-    """torch.autograd of sum(fn(*inputs) * seed) for a fixed random seed tensor -> (output, seed, grads of the inputs)."""
-    ts = [torch.from_numpy(np.ascontiguousarray(a)).clone().requires_grad_(True) for a in inputs]
-    y = fn(*ts)
-    g = torch.from_numpy(np.random.Generator(np.random.PCG64(99)).standard_normal(tuple(y.shape)).astype(np.float32))
-    (y * g).sum().backward()
-    return y.detach().numpy(), g.numpy(), [t.grad.numpy() for t in ts]
-
-
 def conv_bwd_case(N, H, W, C, K, R, stride=1, pad=0, dil=1, seed=0, groups=1):
     def run():
         import torch.nn.functional as F
@@ -2354,10 +2280,6 @@ def all_cases():
           ("bneck_tail/14x14_B1", bneck_tail_case(1, seed=11)),
           ("bneck_tail/14x14_B5", bneck_tail_case(5, seed=12)),
           ("bneck_tail/14x14_B3_big", bneck_tail_case(3, seed=13, big=True)),
-          ("bneck_strip/identity_B1", bneck_strip_case(1, seed=21)),
-          ("bneck_strip/identity_B3_big", bneck_strip_case(3, seed=22, big=True)),
-          ("bneck_strip/dual_B1", bneck_strip_case(1, dual=True, seed=23)),
-          ("bneck_strip/dual_B2_big", bneck_strip_case(2, dual=True, seed=24, big=True)),
           ("bwd/conv3x3_s1_p1", conv_bwd_case(2, 14, 14, 64, 96, 3, 1, 1, seed=31)),
           ("bwd/conv3x3_s2_p1_odd", conv_bwd_case(2, 15, 13, 24, 40, 3, 2, 1, seed=32)),
           ("bwd/conv7x7_s2_p3_stem", conv_bwd_case(1, 32, 32, 3, 16, 7, 2, 3, seed=33)),

@@ -140,6 +140,32 @@ def bn_train_grad_case(B=4, size=64, classes=5):
     return run
 
 
+def jit_train_step_case(classes=5, B=2):
+    """The reference's pattern (tests/test_grads.py:43): make_step under filter_jit.  A model without training-mode layers (vit_tiny,
+    dropout 0, inference mode) is traced instead of run eagerly; its second call -- same model object, NEW images -- must return the
+    loss and gradients of the new images, not a replay of the first call's host values (round-4 advisor finding)."""
+    def run():
+        import eqxvision_amd as eqv
+        sd = S.vit_state(1, 224, 16, 192, 12, 3, 4, classes)
+        net = _load(eqv.models.vit_tiny, sd, num_classes=classes)
+        fn = _loss_fn(_keys(B), classes)
+        jfn = eqv.filter_jit(fn)
+        labels = np.arange(B) % classes
+        x1, x2 = S.synthetic_images(B, 224, seed=31), S.synthetic_images(B, 224, seed=32)
+        l1, g1 = jfn(net, x1, labels)
+        l2, g2 = jfn(net, x2, labels)
+        e2, ge2 = fn(net, x2, labels)                                   # eager, same images as the second jitted call
+        a = np.concatenate([np.asarray(v, np.float64).reshape(-1) for v in eqv.utils.state_dict(g2).values() if np.asarray(v).dtype.kind == "f"])
+        b = np.concatenate([np.asarray(v, np.float64).reshape(-1) for v in eqv.utils.state_dict(ge2).values() if np.asarray(v).dtype.kind == "f"])
+        c = np.concatenate([np.asarray(v, np.float64).reshape(-1) for v in eqv.utils.state_dict(g1).values() if np.asarray(v).dtype.kind == "f"])
+        same_as_eager = float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+        differs_from_first = float(np.abs(a - c).max() / max(1e-30, np.abs(c).max()))
+        ok = abs(l2 - e2) <= 1e-6 * max(1.0, abs(e2)) and same_as_eager <= 1e-6 and abs(l1 - l2) > 1e-6 and differs_from_first > 1e-3
+        return {"ok": bool(ok), "err": same_as_eager, "loss_first": l1, "loss_second": l2, "loss_second_eager": e2,
+                "grad_change_first_to_second": differs_from_first}
+    return run
+
+
 def train_step_case(model, classes=3, steps=2, **model_kw):
     """The reference's test body: model in TRAINING mode (fresh init), one 224 x 224 image, label 1, adam(0.01)."""
     def run():
@@ -175,6 +201,7 @@ def all_cases():
             ("grad/mobilenet_v2_B2_vs_autograd", grad_parity_case("mobilenet_v2", 2)),
             ("grad/swin_t_B2_vs_autograd", grad_parity_case("swin_t", 2)),
             ("grad/resnet18_training_mode_bn_through_batch_stats_vs_autograd", bn_train_grad_case()),
+            ("grad/make_step_under_filter_jit_second_call_is_not_a_replay", jit_train_step_case()),
             ("grad/step_alexnet_training_mode", train_step_case("alexnet")),
             ("grad/step_resnet18_training_mode", train_step_case("resnet18")),
             ("grad/step_vit_tiny_training_mode", train_step_case("vit_tiny")),

@@ -366,21 +366,15 @@ int mv_bottleneck_strip_fwd(const void* x, const void* w1f, const float* scale1,
         p.prof = (long long*)(((unsigned long long)(unsigned)get_flag("prof_hi") << 32) | (unsigned)get_flag("prof_lo"));
 #endif
     const dim3 grid((unsigned)(B * NSTRIP)), block(512);
-    static bool attr_set[2] = {false, false};
+    static LdsAttrSite attr[2];
     if (dual) {
         auto kern = bneck_strip_kernel<64, true>;
-        if (!attr_set[1]) {
-            MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_AB));
-            attr_set[1] = true;
-        }
+        MV_HIP(attr[1].ensure((const void*)kern, LDS_AB));
         set_kernel_name("bneck_strip_dual_bf16_56x56_64_64_256");
         hipLaunchKernelGGL(kern, grid, block, LDS_AB, stream, p);
     } else {
         auto kern = bneck_strip_kernel<256, false>;
-        if (!attr_set[0]) {
-            MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_AB));
-            attr_set[0] = true;
-        }
+        MV_HIP(attr[0].ensure((const void*)kern, LDS_AB));
         set_kernel_name("bneck_strip_bf16_56x56_256_64_256");
         hipLaunchKernelGGL(kern, grid, block, LDS_AB, stream, p);
     }
