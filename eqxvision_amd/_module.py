@@ -106,6 +106,8 @@ class Module(metaclass=_ModuleMeta):
 
 
 def _short(v):
+    if isinstance(v, DevArray):
+        return repr(v)
     if isinstance(v, np.ndarray):
         return f"f{v.dtype.itemsize * 8}{list(v.shape)}"
     if isinstance(v, (list, tuple)) and len(v) > 4:
@@ -113,8 +115,71 @@ def _short(v):
     return repr(v)
 
 
+class DevArray:
+    """An fp32 array leaf that LIVES ON THE DEVICE -- what a jax.Array leaf is in the reference: gradients, optimiser updates and the
+    parameters of a model that has been through `apply_updates` (a training loop keeps its state in HBM; nothing crosses PCIe per
+    step).  `shape` / `dtype` / `ndim` / `size` like numpy; `np.asarray(x)` -- which every host-side consumer goes through
+    (state_dict, weight folding, printing) -- fetches a host copy ONCE and keeps it.  `.dev` is the device tensor."""
+    __slots__ = ("dev", "_host", "shape", "__weakref__")
+    __array_priority__ = 1000
+    dtype = np.dtype(np.float32)
+
+    def __init__(self, dev):
+        self.dev = dev.detach()
+        self.shape = tuple(int(d) for d in dev.shape)
+        self._host = None
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape)) if self.shape else 1
+
+    def __len__(self):
+        if not self.shape:
+            raise TypeError("len() of a 0-d array")
+        return self.shape[0]
+
+    def __array__(self, dtype=None, copy=None):
+        if self._host is None:
+            self._host = self.dev.cpu().numpy()
+            self._host.flags.writeable = False          # leaves are immutable, like the reference's arrays
+        return self._host if dtype is None or np.dtype(dtype) == self._host.dtype else self._host.astype(dtype)
+
+    def astype(self, dtype, copy=True):
+        return np.asarray(self).astype(dtype, copy=copy)
+
+    def reshape(self, *shape):
+        return np.asarray(self).reshape(*shape)
+
+    def __getitem__(self, i):
+        return np.asarray(self)[i]
+
+    def __iter__(self):
+        return iter(np.asarray(self))
+
+    def __repr__(self):
+        return f"DevArray(f32{list(self.shape)}, on device)"
+
+    def _np(self, other):
+        return np.asarray(other) if isinstance(other, DevArray) else other
+
+    def __add__(self, o): return np.asarray(self) + self._np(o)          # noqa: E704
+    def __radd__(self, o): return self._np(o) + np.asarray(self)         # noqa: E704
+    def __sub__(self, o): return np.asarray(self) - self._np(o)          # noqa: E704
+    def __rsub__(self, o): return self._np(o) - np.asarray(self)         # noqa: E704
+    def __mul__(self, o): return np.asarray(self) * self._np(o)          # noqa: E704
+    def __rmul__(self, o): return self._np(o) * np.asarray(self)         # noqa: E704
+    def __truediv__(self, o): return np.asarray(self) / self._np(o)      # noqa: E704
+    def __neg__(self): return -np.asarray(self)                          # noqa: E704
+    def __matmul__(self, o): return np.asarray(self) @ self._np(o)       # noqa: E704
+    def __rmatmul__(self, o): return self._np(o) @ np.asarray(self)      # noqa: E704
+
+
 def is_array(x) -> bool:
-    return isinstance(x, np.ndarray)
+    return isinstance(x, (np.ndarray, DevArray))
 
 
 def _children(node) -> List[Tuple[Any, Any]]:

@@ -260,7 +260,8 @@ def prep_f32(mod, name: str, arr) -> Optional[torch.Tensor]:
     key = ("f32", name)
     hit = cache.get(key)
     if hit is None:
-        hit = _dev(np.asarray(arr, np.float32), torch.float32)
+        from ._module import DevArray
+        hit = arr.dev.reshape(-1) if isinstance(arr, DevArray) else _dev(np.asarray(arr, np.float32), torch.float32)
         cache[key] = hit
     return hit
 

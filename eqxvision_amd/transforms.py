@@ -24,7 +24,7 @@ import torch
 from . import _lib
 from ._act import (Act, _to_device_f32, collect_replay_hooks, compute_dtype, head_fp32, keep_alive, residual_fp32, split_weights, stream_ptr,
                    wrap)
-from ._module import Module, StateIndex
+from ._module import DevArray, Module, StateIndex
 from .nn import _unwrap
 
 
@@ -118,7 +118,7 @@ def _module_sig(m: Module):
             return (type(n).__name__,) + tuple(rec(c) for c in n)
         if isinstance(n, dict):
             return ("dict",) + tuple((k, rec(c)) for k, c in n.items())
-        if isinstance(n, np.ndarray):
+        if isinstance(n, (np.ndarray, DevArray)):
             return ("a", id(n), n.shape, str(n.dtype))
         if n is None or isinstance(n, (bool, int, float, str)):
             return n

@@ -14,7 +14,7 @@ from typing import Optional
 
 import numpy as np
 
-from ._module import Module, StateIndex, tree_leaves, tree_map
+from ._module import Module, StateIndex, is_array, tree_leaves, tree_map
 
 _TEMP_DIR = "/tmp/.eqx"          # same cache dir as the reference (utils.py:17)
 
@@ -81,7 +81,7 @@ def _resolve(torch_weights: str) -> str:
 
 def _is_param_leaf(leaf) -> bool:
     # reference :192-199: every array leaf that is not a size-1 bool takes the next checkpoint tensor
-    return isinstance(leaf, np.ndarray) and not (leaf.size == 1 and leaf.dtype == np.bool_)
+    return is_array(leaf) and not (leaf.size == 1 and leaf.dtype == np.bool_)
 
 
 def load_torch_weights(model: Module, torch_weights: Optional[str] = None) -> Module:
@@ -175,8 +175,8 @@ def state_dict(model: Module) -> "OrderedDict[str, np.ndarray]":
             for i, v in enumerate(node):
                 rec(v, prefix + f"{i}.")
             return
-        if isinstance(node, np.ndarray):
-            out[prefix[:-1]] = node
+        if is_array(node):                         # a device-resident leaf (DevArray) is fetched here, once
+            out[prefix[:-1]] = np.asarray(node)
 
     rec(model, "")
     return out

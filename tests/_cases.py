@@ -290,6 +290,16 @@ def bneck_tail_case(B, seed=0, HW=14, WID=256, COUT=1024, big=False):
     return run
 
 
+# ---- backward kernels (csrc/train_bwd.hip) vs torch.autograd on the CPU (fp32 both sides)
+def _ag(fn, *inputs):
+    """torch.autograd of sum(fn(*inputs) * seed) for a fixed random seed tensor -> (output, seed, grads of the inputs)."""
+    ts = [torch.from_numpy(np.ascontiguousarray(a)).clone().requires_grad_(True) for a in inputs]
+    y = fn(*ts)
+    g = torch.from_numpy(np.random.Generator(np.random.PCG64(99)).standard_normal(tuple(y.shape)).astype(np.float32))
+    (y * g).sum().backward()
+    return y.detach().numpy(), g.numpy(), [t.grad.numpy() for t in ts]
+
+
 def conv_bwd_case(N, H, W, C, K, R, stride=1, pad=0, dil=1, seed=0, groups=1):
     def run():
         import torch.nn.functional as F
