@@ -21,13 +21,14 @@ class StateIndex:
     """Stand-in for `eqx.experimental.StateIndex`: a mutable slot holding BatchNorm running
     statistics outside the parameter leaves (reference utils.py:203-218)."""
 
-    __slots__ = ("_value", "version", "_dev", "_dev_newer")
+    __slots__ = ("_value", "version", "_dev", "_dev_newer", "_last_update")
 
     def __init__(self, value=None):
         self._value = value
         self.version = 0            # bumped by every update: weights prepared with the old statistics folded in are stale
         self._dev = None            # device copy of the statistics (training-mode steps update THIS, ops.bn_train_update)
         self._dev_newer = False     # ... and the host value is fetched when somebody asks for it
+        self._last_update = None    # what the backward of the last training-mode call needs (ops.bn_train_update -> grad._bn_vectors)
 
     @property
     def value(self):

@@ -420,7 +420,7 @@ def _bn_vectors(bn, z: torch.Tensor, kind: str, batched: bool):
         mean_, var_ = _new((C,)), _new((C,))
         _call("mv_cast", _p(mean), _p(mean_), C, F32, F32, _S())
         _call("mv_cast", _p(var), _p(var_), C, F32, F32, _S())
-        return sc, sh, mean_, var_, dict(ops._BN_LAST)
+        return sc, sh, mean_, var_, dict(bn.state_index._last_update)      # left on the layer's state slot by bn_train_update
     st = bn.state_index.value
     if st is None:
         raise RuntimeError("BatchNorm has no running statistics")

@@ -71,9 +71,6 @@ def _bn_id(bn):
     return None if bn is None else (id(bn), bn.state_index.version)
 
 
-_BN_LAST: dict = {}        # set by bn_train_update, read by the tape right after the call (grad._bn_vectors)
-
-
 def bn_train_update(bn, y: Act):
     """The statistics half of eqx.experimental.BatchNorm's TRAINING branch (resnet.py:132-136 with the model
     not in inference mode): per-channel batch mean, then the mean of squared deviations from it -- two passes, each summed over
@@ -135,7 +132,7 @@ def bn_train_update(bn, y: Act):
     # what the backward of THIS call needs (grad._bn_backward): the weight of the batch statistics in the statistics the layer
     # normalised with (running' = a * batch + (1 - a) * running), the row count of the data-parallel batch and whether the column
     # sums have to be summed over ranks
-    _BN_LAST.update(a=1.0 if first else 1.0 - float(bn.momentum), rows=float(rows), cnt=cnt, reduce=reduce_ranks)
+    sidx._last_update = dict(a=1.0 if first else 1.0 - float(bn.momentum), rows=float(rows), cnt=cnt, reduce=reduce_ranks)
     sidx.device_updated(run)               # bumps the version: every fold prepared with the old statistics is stale (_bn_id)
     on_replay(lambda s=sidx, r=run: s.device_updated(r))     # ... and again after every replay of a recorded step
     return scale, shift
