@@ -524,6 +524,7 @@ __global__ __launch_bounds__(512) void ln_mlp_stream192_kernel(const LnMlpSP p) 
     }
 }
 
+
 }  // namespace
 
 }  // namespace mv
