@@ -500,3 +500,27 @@ def test_scratch_hand_over_travels_with_the_recorded_launch():
     assert lib.mv_splitk_scratch_bytes(3136, 512, 4608) == 4096 + 52 * 128 * 256 * 4      # ResNet layer 4 3x3 at 64 images: 50 / 52 tiles
     assert lib.mv_splitk_scratch_bytes(3136, 768, 768) == 0                                  # 12 k-tiles: not worth the hand-over
     assert lib.mv_splitk_scratch_bytes(100352, 512, 4608) == 0                               # fills the chip un-split
+
+
+def test_devarray_leaf_behaves_like_an_array_leaf():
+    """A `DevArray` (gradients, updates, the parameters after apply_updates: state that stays on the device) is an array leaf to every
+    tree utility, converts through `np.asarray` ONCE (and read-only, like the reference's immutable arrays), and a model that carries
+    such leaves still yields a numpy state_dict and a stable jit signature."""
+    import torch
+    import eqxvision_amd as eqv
+    from eqxvision_amd._module import DevArray, tree_map
+    from eqxvision_amd.transforms import _module_sig
+    t = torch.arange(6, dtype=torch.float32).reshape(2, 3)
+    d = DevArray(t)
+    assert eqv.is_array(d) and d.shape == (2, 3) and d.ndim == 2 and d.size == 6 and d.dtype == np.float32 and len(d) == 2
+    a = np.asarray(d)
+    assert a is np.asarray(d) and not a.flags.writeable and np.array_equal(a, t.numpy())
+    assert np.array_equal(np.asarray(d, np.float64), t.numpy().astype(np.float64))
+    assert np.array_equal(d + 1, t.numpy() + 1) and np.array_equal(2 * d, 2 * t.numpy()) and np.array_equal(d.reshape(-1), t.numpy().reshape(-1))
+    net = eqv.models.alexnet(num_classes=3, key=eqv.random.PRNGKey(0))
+    dev = tree_map(lambda l: DevArray(torch.from_numpy(np.ascontiguousarray(l))) if isinstance(l, np.ndarray) and l.dtype.kind == "f" else l, net)
+    leaves = [l for l in eqv.tree_leaves(dev) if eqv.is_array(l)]
+    assert leaves and all(isinstance(l, DevArray) for l in leaves if l.dtype.kind == "f")
+    sd, sd0 = eqv.utils.state_dict(dev), eqv.utils.state_dict(net)
+    assert list(sd) == list(sd0) and all(isinstance(v, np.ndarray) and np.array_equal(v, sd0[k]) for k, v in sd.items())
+    assert _module_sig(dev) == _module_sig(dev) and _module_sig(dev) != _module_sig(net)
