@@ -119,13 +119,20 @@ __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
     };
 
     auto run_tile = [&](uint4* xf, int tile, int refill) {
+        // stores through buffer descriptors at the tile's first row: a row past M gets an out-of-range offset instead of an `if` --
+        // with the `if`s hipcc lost count of the in-order vmcnt queue and drained it (`vmcnt(0)`) in the middle of every tile, i.e.
+        // waited for the NEXT tiles' x rows that had just been issued to hide their latency (round 5, tools/scan_store_waits.py)
+        const int tile_u = __builtin_amdgcn_readfirstlane(tile);
+        const brsrc_t ry = make_brsrc(p.y + (long long)tile_u * 32 * K);
+        const brsrc_t rt = make_brsrc(p.t1 + (long long)tile_u * 32 * N2);
+        const int rows_left = p.M - tile_u * 32;
         f32x16 acc2[T2];
 #pragma unroll
         for (int a = 0; a < T2; ++a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc2[a][e] = 0.f;
-#pragma unroll 1
-        for (int ps = 0; ps < 2; ++ps) {                        // 128-channel slab of y
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {                        // 128-channel slab of y (unrolled: every vmcnt wait is then an exact count)
             uint4 rr[DUAL ? 1 : 2][4];                          // residual rows of the slab's two 64-channel chunks
             if constexpr (!DUAL) {
 #pragma unroll
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
                                                                      __builtin_bit_cast(bf16x8, xf[kk]), acc[a], 0, 0, 0);
                 }
-            if (ps == 1 && refill < p.tiles_m) load_x(xf, refill);
+            if (ps == 1) load_x(xf, refill);                      // unconditional (rows past M are clamped inside): a branch here costs the count
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int chunk = ps * 2 + c;                   // 64-channel chunk of y
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                     uint4 u;
                     u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
-                    if (m < p.M) *(uint4*)(p.y + (long long)m * K + nloc) = u;
+                    buf_store_u4(ry, row < rows_left ? (unsigned)(row * K + nloc) * 2u : BUF_OOB, u);
                     // the same bf16 values, row-major in the patch: the B operand of the second GEMM.  (This pass's
                     // fp32 reads of these rows are older LDS operations of the same wave: in-order, no hazard.)
                     *(uint4*)(ep + row * EPITCH + c8 * 16) = u;
@@ -236,7 +243,9 @@ __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], scv[e], shv[e]), 0.f);
-                if (m < p.M) Out8<bf16_t>::st(p.t1 + (long long)m * N2 + c2 * 64 + c8 * 8, v);
+                uint4 u;
+                u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+                buf_store_u4(rt, row < rows_left ? (unsigned)(row * N2 + c2 * 64 + c8 * 8) * 2u : BUF_OOB, u);
             }
         }
     };
