@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round 5: A/B of the branch-free igemm8 epilogue (csrc/igemm_pipe.h: epilogue_rows) against the round-4 epilogue, same box.
-# The round-4 library is csrc/libeqxvision_amd_r4epi.so (old igemm8.hip linked with today's other objects).
+# The round-4 library is csrc/libeqxvision_amd_r4epi.so: `git show 96090ca:eqxvision_amd/csrc/igemm8.hip` (+ that commit's igemm_pipe.h /
+# mfma_common.h) compiled to an object and linked with today's other objects (csrc/build/*.o); it is not kept in the tree.
+# tools/ab_lib.sh SUFFIX MODEL BATCH KERNEL is the generic form of this A/B.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5epi; mkdir -p $O
 OLD=$GRAFT_REPO_ROOT/eqxvision_amd/csrc/libeqxvision_amd_r4epi.so
