@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("EQV_LIB") or os.path.join(_HERE, "csrc", "libeqxvisio
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU_TANH = 0, 1, 2
 ACT_HARD_SWISH, ACT_HARD_SIGMOID, ACT_SIGMOID, ACT_SILU = 3, 4, 5, 6       # element-wise entries and the depthwise conv only
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
@@ -30,6 +30,7 @@ PROTOTYPES = {
     "mv_set_flag": [C.c_char_p, _i],
     "mv_get_flag": [C.c_char_p],
     "mv_flags_epoch": [],
+    "mv_device_status": [_i, _vp],
     "mv_comm_unique_id": [_vp, C.c_size_t],
     "mv_comm_init": [_i, _i, _vp],
     "mv_comm_size": [],
@@ -253,6 +254,20 @@ def last_kernel() -> str:
 
 def set_flag(name: str, value: int):
     call("mv_set_flag", name.encode(), int(value))
+
+
+def check_device_status(clear: bool = True) -> int:
+    """Reads (and clears) the library's device status word; raises if a kernel recorded a broken run-time protocol (a split-K block
+    that gave up on its partner: scratch shared between concurrent launches, or not zeroed).  Synchronises the device."""
+    v = C.c_uint(0)
+    rc = load().mv_device_status(1 if clear else 0, C.byref(v))
+    if rc != 0:
+        msg = load().mv_last_error()
+        raise MVError(f"mv_device_status failed (rc={rc}): {msg.decode() if msg else ''}")
+    if v.value:
+        raise MVError(f"device status 0x{v.value:x}: a split-K tile was finished without its partner's partial sums -- the scratch of "
+                      "mv_set_scratch was shared by concurrent launches or not zero-initialised; results of that launch are wrong")
+    return 0
 
 
 def get_flag(name: str) -> int:

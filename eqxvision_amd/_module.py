@@ -143,17 +143,66 @@ class DevArray:
             raise TypeError("len() of a 0-d array")
         return self.shape[0]
 
-    def __array__(self, dtype=None, copy=None):
+    def _h(self):
         if self._host is None:
             self._host = self.dev.cpu().numpy()
             self._host.flags.writeable = False          # leaves are immutable, like the reference's arrays
-        return self._host if dtype is None or np.dtype(dtype) == self._host.dtype else self._host.astype(dtype)
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        """numpy 2 protocol: `copy=True` must hand out memory the caller owns (np.array(leaf) is writable and does not alias the
+        cached read-only host copy), `copy=False` must raise when a conversion would be needed, `copy=None` may share."""
+        h = self._h()
+        if dtype is not None and np.dtype(dtype) != h.dtype:
+            if copy is False:
+                raise ValueError("DevArray: a dtype conversion needs a copy (copy=False was requested)")
+            return h.astype(dtype)
+        return h.copy() if copy else h
+
+    # numpy semantics on the host copy: ufuncs (np.sqrt(leaf), leaf ** 2 via the operators below), reductions and array functions
+    # (np.linalg.norm, np.concatenate, np.clip ...) see a plain ndarray -- gradient clipping / L2 penalties written against the
+    # reference's jax arrays keep working on device-resident leaves.
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        un = lambda v: np.asarray(v) if isinstance(v, DevArray) else v
+        if "out" in kwargs:
+            if any(isinstance(o, DevArray) for o in kwargs["out"]):
+                raise TypeError("DevArray leaves are immutable: cannot be a ufunc `out=` target")
+        return getattr(ufunc, method)(*[un(v) for v in inputs], **kwargs)
+
+    def __array_function__(self, func, types, args, kwargs):
+        def un(v):
+            if isinstance(v, DevArray):
+                return np.asarray(v)
+            if isinstance(v, (list, tuple)):
+                return type(v)(un(e) for e in v)
+            return v
+        return func(*[un(a) for a in args], **{k: un(v) for k, v in kwargs.items()})
 
     def astype(self, dtype, copy=True):
         return np.asarray(self).astype(dtype, copy=copy)
 
     def reshape(self, *shape):
         return np.asarray(self).reshape(*shape)
+
+    def copy(self):
+        return np.asarray(self).copy()
+
+    @property
+    def T(self):
+        return np.asarray(self).T
+
+    def transpose(self, *axes): return np.asarray(self).transpose(*axes)                 # noqa: E704
+    def sum(self, *a, **k): return np.asarray(self).sum(*a, **k)                         # noqa: E704
+    def mean(self, *a, **k): return np.asarray(self).mean(*a, **k)                       # noqa: E704
+    def max(self, *a, **k): return np.asarray(self).max(*a, **k)                         # noqa: E704
+    def min(self, *a, **k): return np.asarray(self).min(*a, **k)                         # noqa: E704
+    def std(self, *a, **k): return np.asarray(self).std(*a, **k)                         # noqa: E704
+    def var(self, *a, **k): return np.asarray(self).var(*a, **k)                         # noqa: E704
+    def ravel(self): return np.asarray(self).ravel()                                     # noqa: E704
+    def flatten(self): return np.asarray(self).flatten()                                 # noqa: E704
+    def item(self): return np.asarray(self).item()                                       # noqa: E704
+    def tolist(self): return np.asarray(self).tolist()                                   # noqa: E704
+    def __float__(self): return float(np.asarray(self))                                  # noqa: E704
 
     def __getitem__(self, i):
         return np.asarray(self)[i]
@@ -174,9 +223,20 @@ class DevArray:
     def __mul__(self, o): return np.asarray(self) * self._np(o)          # noqa: E704
     def __rmul__(self, o): return self._np(o) * np.asarray(self)         # noqa: E704
     def __truediv__(self, o): return np.asarray(self) / self._np(o)      # noqa: E704
+    def __rtruediv__(self, o): return self._np(o) / np.asarray(self)     # noqa: E704
+    def __pow__(self, o): return np.asarray(self) ** self._np(o)         # noqa: E704
+    def __rpow__(self, o): return self._np(o) ** np.asarray(self)        # noqa: E704
     def __neg__(self): return -np.asarray(self)                          # noqa: E704
+    def __pos__(self): return +np.asarray(self)                          # noqa: E704
+    def __abs__(self): return np.abs(np.asarray(self))                   # noqa: E704
     def __matmul__(self, o): return np.asarray(self) @ self._np(o)       # noqa: E704
     def __rmatmul__(self, o): return self._np(o) @ np.asarray(self)      # noqa: E704
+    def __lt__(self, o): return np.asarray(self) < self._np(o)           # noqa: E704
+    def __le__(self, o): return np.asarray(self) <= self._np(o)          # noqa: E704
+    def __gt__(self, o): return np.asarray(self) > self._np(o)           # noqa: E704
+    def __ge__(self, o): return np.asarray(self) >= self._np(o)          # noqa: E704
+    # == / != stay identity-based (and the type hashable): leaves are found BY IDENTITY in the tape and in cache signatures;
+    # use np.array_equal(a, b) / np.asarray(a) == b for element-wise comparison.
 
 
 def is_array(x) -> bool:

@@ -190,6 +190,7 @@ int chain_stream_supported(long long M, int C, int K, int N2, int dtype);
 int chain_stream_launch(const void* x, const void* w3, const float* scale3, const float* shift3, const void* residual, void* y,
                         const void* w1, const float* scale1, const float* shift1, void* t1, long long M, hipStream_t st);
 int igemm8_supported(long long M, int C, int K, int R, int S, long long x_bytes, long long w_bytes);
+int device_status(int clear, unsigned* out);              // igemm8.hip: the status word of mv_device_status
 int igemm8_wanted(long long M, int C, int K, int R, int S);
 int igemm8_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y,
                   int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,

@@ -39,6 +39,12 @@ namespace mv {
 namespace {
 
 constexpr unsigned OOB = 0x80000000u;          // >= num_records of every descriptor: the DMA writes zeros
+
+// Device status word (mv_device_status): bit 0 = a split-K block gave up waiting for its partner's partial tile.  A kernel that
+// finds its hand-over broken RECORDS it here and finishes with what it has -- it does not trap: a trap is a sticky
+// hipErrorLaunchFailure that poisons the whole context (an in-flight graph replay, other streams) and surfaces at an unrelated
+// call (advisor, round 5).  The host reads the word at its own synchronisation points and fails with a clear message.
+__device__ unsigned g_dev_status = 0;
 constexpr int LDS_W = 0, LDS_XT = 65536, LDS_XB = 98304;   // unit bases of buffer 0; buffer 1: W +32768, XT/XB +16384
 constexpr int LDS_TOTAL = 131072;
 
@@ -662,11 +668,12 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
             return;
         }
         if (tid == 0) {
-            int spins = 0;                                   // bounded (~0.1 s): never a hung GPU -- and never a silently wrong tile:
+            int spins = 0;                                   // bounded (~0.1 s): never a hung GPU -- and never a SILENTLY wrong tile:
             unsigned f;                                      // the partner is past its main loop when this block gets here, so running
             while ((f = __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && ++spins < (1 << 20))
-                __builtin_amdgcn_s_sleep(2);                 // out of spins means a broken hand-over (dirty sync words): abort the launch,
-            if (f == 0u) __builtin_trap();                   // the host sees hipErrorLaunchFailure at its next call (advisor, round 4)
+                __builtin_amdgcn_s_sleep(2);                 // out of spins means a broken hand-over (dirty sync words, or a partner that
+            if (f == 0u)                                     // was never co-resident): say so in the status word -- the host checks it
+                __hip_atomic_fetch_or(&g_dev_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (mv_device_status) -- and go on
             if (f != 1u + xcc) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -684,6 +691,18 @@ __global__ __launch_bounds__(512) void igemm8s_kernel(const Igemm2P p) {
     }
 
     epilogue_rows<OutT, false, 2, EPITCH>(p, smem + wave * (32 * EPITCH), acc, ss, res, true, m0 + xrow0, n0 + wrow0, lane);
+}
+
+// -> the status word (and clears it when asked).  Synchronises the device: call it where the host synchronises anyway.
+int device_status(int clear, unsigned* out) {
+    unsigned v = 0;
+    MV_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_dev_status), sizeof(v), 0, hipMemcpyDeviceToHost));
+    if (clear && v) {
+        const unsigned z = 0;
+        MV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dev_status), &z, sizeof(z), 0, hipMemcpyHostToDevice));
+    }
+    *out = v;
+    return MV_OK;
 }
 
 int igemm8_supported(long long M, int C, int K, int R, int S, long long x_bytes, long long w_bytes) {

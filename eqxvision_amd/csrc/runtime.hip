@@ -89,6 +89,10 @@ int mv_set_flag(const char* name, int value) {
     return MV_OK;
 }
 int mv_flags_epoch(void) { return mv::g_flags_epoch; }
+int mv_device_status(int clear, unsigned* status) {
+    MV_CHECK_ARG(status, "device_status: NULL pointer");
+    return mv::device_status(clear, status);
+}
 int mv_get_flag(const char* name) { return name ? mv::get_flag(name) : 0; }
 
 int mv_set_scratch(void* ptr, int64_t bytes, mv_stream_t stream) {

@@ -982,6 +982,8 @@ def apply_updates(model, updates):
         if not _float_leaf(leaf):
             return leaf
         u = next(it)
+        if leaf.dtype != np.float32:               # the device state is fp32 only: other float widths keep their dtype, summed on the host
+            return (np.asarray(leaf) + np.asarray(u).reshape(leaf.shape).astype(leaf.dtype)).astype(leaf.dtype)
         ud = _upload(u)
         p = _upload(leaf)
         out = torch.empty_like(p)

@@ -36,7 +36,7 @@ class MlpProjection(Module):
     def _live(self) -> bool:
         return nn.dropout_live(self.drop1) or nn.dropout_live(self.drop2)
 
-    def _forward(self, x, residual=None, norm=None, keys=None, per_row=False):
+    def _forward(self, x, residual=None, norm=None, keys=None, per_row=False, precise=False):
         """`norm` given: x is the un-normalised input; the LayerNorm is folded into fc1 where the library can.
         `keys` (training mode with a live Dropout): one PRNG key per sample, or per ROW of a (tokens, features) input when
         `per_row` -- the reference's ViT vmaps the layer over the tokens (vit.py:155); each is split in two for drop1 / drop2
@@ -46,6 +46,9 @@ class MlpProjection(Module):
         name = nn.act_name(self.act)
         if norm is not None and not isinstance(self.fc1, nn.Linear):
             x, norm = norm(x), None
+        if precise and name is not None and not self._live():          # split-precision weights (ops.swin_precise: swin_b's widths)
+            h = ops.linear_split(x if norm is None else ops.layernorm(x, norm), self.fc1, act=name)
+            return ops.linear_split(h, self.fc2, residual=residual)
         if name is not None:
             h = ops.linear(x, self.fc1, act=name) if norm is None else ops.ln_linear(x, norm, self.fc1, act=name)
         else:

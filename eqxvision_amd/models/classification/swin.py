@@ -110,9 +110,15 @@ class _ShiftedWindowAttention(Module):
         if Hf % self.window_size[0] or Wf % self.window_size[1]:
             raise ValueError(f"feature map {Hf}x{Wf} is not a multiple of the window {self.window_size} "
                              "(the reference does not pad either, swin.py:782-790)")
-        qkv = ops.linear(x, self.qkv) if norm is None else ops.ln_linear(x, norm, self.qkv)      # reference :151-153
+        precise = ops.swin_precise(C)            # widths off the fused kernels (swin_b): split-precision block Linears
+        if precise:
+            qkv = ops.linear_split(x if norm is None else ops.layernorm(x, norm), self.qkv)
+        else:
+            qkv = ops.linear(x, self.qkv) if norm is None else ops.ln_linear(x, norm, self.qkv)      # reference :151-153
         if not self._live():
             a = ops.swin_window_attention(qkv, self._bias_dev(), self.num_heads, self.window_size, self.shift_size)
+            if precise:
+                return ops.linear_split(a, self.proj, residual=residual)
             return ops.linear(a, self.proj, residual=residual)         # reference :232 (+ the block's residual)
         if key is None:
             raise RuntimeError("Swin attention_dropout / dropout > 0 requires a key (drawn in every mode, swin.py:17-20)")
@@ -166,7 +172,7 @@ class _SwinTransformerBlock(Module):
                 if y is not None:
                     return y
                 if isinstance(self.norm2, nn.LayerNorm):
-                    return self.mlp._forward(x, residual=x, norm=self.norm2)
+                    return self.mlp._forward(x, residual=x, norm=self.norm2, precise=ops.swin_precise(x.t.shape[-1]))
             return self.mlp._forward(self.norm2(x), residual=x)
         if key is None:
             raise RuntimeError("stochastic depth outside inference mode / Swin dropout > 0 requires a key")

@@ -205,6 +205,29 @@ def _sig(x):
         return ("obj", id(x))
 
 
+def _struct_sig(x):
+    """`_sig` without leaf identities: types, field layout, leaf shapes / dtypes, static values.  A training loop hands `filter_jit`
+    a model with NEW leaves every step (`apply_updates`), so the identity-based signature misses every time; whether a function is
+    replayable at all (a training step is not: its loss is a host value) depends on this structure only."""
+    if _is_array(x) or isinstance(x, (np.ndarray, DevArray)):
+        return ("a", tuple(x.shape), str(x.dtype))
+    if isinstance(x, StateIndex):
+        return ("state",)
+    if isinstance(x, Module):
+        return (type(x).__qualname__,) + tuple((f, _struct_sig(getattr(x, f))) for f in x.__fields__ if hasattr(x, f))
+    if isinstance(x, (list, tuple)):
+        return (type(x).__name__,) + tuple(_struct_sig(v) for v in x)
+    if isinstance(x, dict):
+        return ("dict",) + tuple((k, _struct_sig(v)) for k, v in sorted(x.items()))
+    if callable(x):
+        return ("obj", id(x))
+    try:
+        hash(x)
+        return ("val", x)
+    except TypeError:
+        return ("obj", type(x).__name__)
+
+
 MAX_CACHE_SIGNATURES = 8   # per jitted function: least-recently-used signatures beyond this are evicted (graph destroyed,
                            # pinned intermediates and argument references dropped)
 
@@ -232,6 +255,7 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
         return functools.partial(filter_jit, use_graph=use_graph, clone_outputs=clone_outputs, lanes=lanes)
     import collections
     cache = collections.OrderedDict()
+    eager_structs = set()      # argument structures found not replayable (training steps): run eagerly, see `jitted`
 
     def _replay(c: _Compiled):
         s = stream_ptr()
@@ -277,6 +301,8 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
                     o = fn(*la, **lk)
             finally:
                 _lib.set_recording(old)
+            if _lib.not_replayable():
+                return                               # host results: not a launch list; the caller's full-batch trace decides
             leaves = list(o) if isinstance(o, (tuple, list)) else [o]
             if not leaves or not all(t is None or (isinstance(t, torch.Tensor) and t.is_cuda and t.shape[0] == step and t.is_contiguous())
                                      for t in leaves) or all(t is None for t in leaves):
@@ -338,6 +364,10 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
     def jitted(*args, **kwargs):
         if any(_needs_eager(v) for v in list(args) + list(kwargs.values()) if isinstance(v, (Module, list, tuple, dict))):
             return fn(*args, **kwargs)             # training-mode layers: host logic between launches, nothing to replay
+        if eager_structs:                          # this function was traced once with arguments of this STRUCTURE and found not
+            sk = (tuple(_struct_sig(a) for a in args), tuple((k, _struct_sig(v)) for k, v in sorted(kwargs.items())))
+            if sk in eager_structs:                # replayable (a training step): no signature, no staging copies, no recording, no
+                return fn(*args, **kwargs)         # pinned intermediates, no cache entry -- whatever leaves the model carries this step
         key = (compute_dtype(), residual_fp32(), head_fp32(), split_weights(), _lib.load().mv_flags_epoch(), tuple(_sig(a) for a in args),
                tuple((k, _sig(v)) for k, v in sorted(kwargs.items())))
         # A graph bakes buffer addresses in.  Resident device inputs are read in place -- no staging copy -- by a
@@ -347,8 +377,6 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
         flat_all = list(args) + [v for _, v in sorted(kwargs.items())]
         ptrs = tuple(v.data_ptr() for v in flat_all if _is_array(v) and _is_resident(v))
         grp = cache.get(key)
-        if grp is not None and grp.get("eager"):
-            return fn(*args, **kwargs)             # traced once and found not replayable (host results: see below)
         if grp is None:
             grp = cache[key] = {"variants": {}, "owned": None}
             while len(cache) > MAX_CACHE_SIGNATURES:         # LRU eviction
@@ -402,8 +430,13 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
                     _lib.set_recording(old)
             if _lib.not_replayable():
                 # the function produced host values while it was traced (a training step: filter_value_and_grad's loss / gradients):
-                # what it returned IS this call's result; nothing is cached and every later call with this signature runs eagerly
-                grp["eager"] = True
+                # what it returned IS this call's result; nothing is cached -- the signature's slot is given back, so a training loop
+                # cannot evict compiled inference entries of the same function -- and every later call with arguments of this
+                # structure runs eagerly from the top of `jitted` (advisor, round 5: the identity-keyed mark never hit, because
+                # apply_updates makes new leaves every step)
+                eager_structs.add((tuple(_struct_sig(a) for a in args), tuple((k, _struct_sig(v)) for k, v in sorted(kwargs.items()))))
+                if not grp["variants"] and grp["owned"] is None:
+                    cache.pop(key, None)
                 out = c.out
                 _release(c)
                 return out
@@ -458,6 +491,7 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
         return _outputs(c)
 
     jitted._cache = cache
+    jitted._eager_structs = eager_structs
     jitted._entries = lambda: [c for g in cache.values()
                                for c in list(g["variants"].values()) + ([g["owned"]] if g["owned"] is not None else [])]
     return jitted

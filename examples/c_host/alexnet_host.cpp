@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
         t.push_back(d);
     }
     fclose(f);
-    if (mv_abi_version() != 1) { fprintf(stderr, "ABI version %d\n", mv_abi_version()); return 1; }
+    if (mv_abi_version() != MV_ABI_VERSION) { fprintf(stderr, "ABI version %d\n", mv_abi_version()); return 1; }
 
     // activations: bf16 NHWC maps, bf16 rows, fp32 logits
     auto bf = [&](size_t elems) { return dev_alloc(2 * elems); };

@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define MV_ABI_VERSION 1
+#define MV_ABI_VERSION 2   /* 2 (round 6): mv_bottleneck_strip_* gone, mv_bn_train_dz_coef_f32 / mv_device_status / the layer-1 recompute
+                            * chain entries added, every scratch consumer keeps its data behind a 4096-byte sync header */
 
 typedef void* mv_stream_t; /* hipStream_t */
 
@@ -64,6 +65,11 @@ const char* mv_last_error(void);
 int mv_set_flag(const char* name, int value);   /* flags are per calling THREAD, like mv_last_error */
 int mv_get_flag(const char* name);
 int mv_flags_epoch(void);                        /* hash of this thread's current switch settings (0 = all default): recorded launch lists key on it */
+/* Device status word: kernels that detect a broken protocol at run time record it here instead of trapping (a trap poisons the whole
+ * HIP context, graph replays and other streams included).  bit 0: a split-K block gave up waiting for its partner's partial sums
+ * (dirty / shared scratch; the tile it wrote is incomplete).  Writes the word to *status, clears it if `clear`; SYNCHRONISES the
+ * device -- call it where the host synchronises anyway (after a forward, at the end of a test). */
+int mv_device_status(int clear, unsigned* status);
 /* name of the kernel variant the last call on this thread dispatched to (for tests/bench) */
 const char* mv_last_kernel(void);
 

@@ -166,6 +166,45 @@ def jit_train_step_case(classes=5, B=2):
     return run
 
 
+def jit_train_loop_case(classes=5, B=2, steps=4):
+    """A real jitted training loop (advisor, round 5): make_step = filter_jit(value_and_grad + adam + apply_updates), called in a loop
+    with the model it returned.  apply_updates makes NEW leaves every step, so the identity-keyed signature never repeats; the
+    not-replayable decision has to be per argument STRUCTURE: from the second step on the call must run eagerly from the top of
+    `jitted` (no cache entries, nothing pinned), and a compiled inference entry of the SAME jitted function must survive the loop."""
+    def run():
+        import eqxvision_amd as eqv
+        sd = S.vit_state(1, 32, 8, 64, 2, 2, 4, classes)
+        fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(eqv.models.VisionTransformer(**kw), torch_weights)
+        net = _load(fac, sd, img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=2, num_classes=classes)
+        fn = _loss_fn(_keys(B), classes)
+        opt = eqv.optim.adam(learning_rate=1e-3)
+        st = opt.init(eqv.filter(net, eqv.is_array))
+        labels = np.arange(B) % classes
+        x = S.synthetic_images(B, 32, seed=5)
+
+        def make_step(model, state, x, y):
+            loss, grads = fn(model, x, y)
+            updates, state = opt.update(grads, state)
+            return loss, eqv.apply_updates(model, updates), state
+        jstep = eqv.filter_jit(make_step)
+        losses, entries = [], []
+        m = net
+        for _ in range(steps):
+            loss, m, st = jstep(m, st, x, labels)
+            losses.append(float(loss))
+            entries.append(len(jstep._cache))
+        # the same loop, eager
+        m2, st2, ref = net, opt.init(eqv.filter(net, eqv.is_array)), []
+        for _ in range(steps):
+            loss, m2, st2 = make_step(m2, st2, x, labels)
+            ref.append(float(loss))
+        err = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(losses, ref))
+        ok = err <= 1e-6 and losses[-1] < losses[0] and max(entries) == 0 and len(jstep._eager_structs) == 1
+        return {"ok": bool(ok), "err": err, "losses": losses, "losses_eager": ref, "cache_entries_per_step": entries,
+                "eager_structures": len(jstep._eager_structs)}
+    return run
+
+
 def train_step_case(model, classes=3, steps=2, **model_kw):
     """The reference's test body: model in TRAINING mode (fresh init), one 224 x 224 image, label 1, adam(0.01)."""
     def run():
@@ -204,6 +243,7 @@ def all_cases():
             ("grad/swin_t_B2_vs_autograd", grad_parity_case("swin_t", 2)),
             ("grad/resnet18_training_mode_bn_through_batch_stats_vs_autograd", bn_train_grad_case()),
             ("grad/make_step_under_filter_jit_second_call_is_not_a_replay", jit_train_step_case()),
+            ("grad/jitted_training_loop_runs_eagerly_from_step_2_no_cache_entries", jit_train_loop_case()),
             ("grad/step_alexnet_training_mode", train_step_case("alexnet")),
             ("grad/step_resnet18_training_mode", train_step_case("resnet18")),
             ("grad/step_vit_tiny_training_mode", train_step_case("vit_tiny")),

@@ -1027,7 +1027,7 @@ def large_logit_case(name, target=15.0, B=2, dtype="bf16"):
     return run
 
 
-def exported_factory_case(name, B=2, size=224, dtype="bf16", scaled=False):
+def exported_factory_case(name, B=2, size=224, dtype="bf16"):
     """An exported factory that no other case constructs (round-4 review, weak 7): the published architecture through
     `eqv.models.<name>(torch_weights=...)` at 224 px against the torch restatement on the same synthetic checkpoint.  swin_b's widths
     (128 / 256 / 512 / 1024) and resnet34's basic blocks at full width take dispatch paths of their own."""
@@ -1054,9 +1054,10 @@ def exported_factory_case(name, B=2, size=224, dtype="bf16", scaled=False):
             net = _load(getattr(eqv.models, name), sd, **kw)
         x = S.synthetic_images(B, size, seed=0)
         got = _run(net, x, dtype).cpu().numpy()
-        # `scaled`: the bound is 1e-2 of the logit scale (max |ref|) instead of absolute -- swin_b only: 24 blocks at twice swin_t's
-        # width put its bf16 error at 1.15e-2 absolute on logits of +-2.2 (0.5 % of the scale; swin_s, half as wide, passes absolute)
-        return _cmp(got, ref_fn(x), 1e-2 if dtype == "bf16" else 1e-3, scaled=scaled)
+        # every factory is held to the ABSOLUTE bound.  swin_b (widths 128 .. 1024: the un-fused Swin path) sat at 1.15e-2 in round 5
+        # and was passed on a relative bound; its block Linears now carry split-precision weights (ops.swin_precise,
+        # tests/attrib_swin_bf16.py: weight rounding alone was 1.16e-2); the relative bound is gone from this case.
+        return _cmp(got, ref_fn(x), 1e-2 if dtype == "bf16" else 1e-3)
     return run
 
 
@@ -1140,7 +1141,7 @@ def all_cases(full=True):
               ("model/deeplabv3_resnet50_B2", segmentation_case("deeplabv3", (3, 4, 6, 3), 224, 2, classes=21, full_ref="torch")),
               ("model/swin_t_B1", swin_case(224, 96, (2, 2, 6, 2), (3, 6, 12, 24), 1, classes=1000, full_ref="torch")),
               ("model/factory_swin_s_B2", exported_factory_case("swin_s")),
-              ("model/factory_swin_b_B2", exported_factory_case("swin_b", scaled=True)),
+              ("model/factory_swin_b_B2", exported_factory_case("swin_b")),
               ("model/factory_vit_small_B2", exported_factory_case("vit_small")),
               ("model/factory_resnet34_B2", exported_factory_case("resnet34")),
               ("model/factory_resnet101_B2", exported_factory_case("resnet101")),
@@ -1149,6 +1150,11 @@ def all_cases(full=True):
               ("golden/committed_resnet50_224", committed_golden_case("resnet50")),
               ("golden/committed_vit_base_224", committed_golden_case("vit_base")),
               ("golden/committed_swin_t_224", committed_golden_case("swin_t")),
+              ("golden/committed_resnet50_224_fp32", committed_golden_case("resnet50", "fp32")),
+              ("golden/committed_vit_base_224_fp32", committed_golden_case("vit_base", "fp32")),
+              ("golden/committed_swin_t_224_fp32", committed_golden_case("swin_t", "fp32")),
+              ("model/resnet50_B2_fp32", resnet_case("bottleneck", (3, 4, 6, 3), 224, 2, classes=1000, full_ref="torch", dtype="fp32")),
+              ("model/vit_base_B2_fp32", vit_case(224, 16, 768, 12, 12, 2, classes=1000, full_ref="torch", dtype="fp32")),
               ("golden/committed_small_models", committed_small_golden_case()),
               ("golden/committed_small_models_fp32", committed_small_golden_case("fp32")),
               ("model/resnet50_logits_at_trained_scale", large_logit_case("resnet50")),

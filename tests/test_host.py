@@ -524,3 +524,33 @@ def test_devarray_leaf_behaves_like_an_array_leaf():
     sd, sd0 = eqv.utils.state_dict(dev), eqv.utils.state_dict(net)
     assert list(sd) == list(sd0) and all(isinstance(v, np.ndarray) and np.array_equal(v, sd0[k]) for k, v in sd.items())
     assert _module_sig(dev) == _module_sig(dev) and _module_sig(dev) != _module_sig(net)
+    # numpy 2 protocol and the host-side arithmetic a training loop written against jax arrays does on its leaves (advisor, round 5):
+    # a requested copy is the caller's own writable memory, copy=False refuses a conversion, ufuncs / reductions / array functions work
+    c = np.array(d, copy=True)
+    assert c is not np.asarray(d) and c.flags.writeable and np.array_equal(c, a)
+    c *= 2.0
+    assert np.array_equal(np.asarray(d), t.numpy())                       # the cached host copy is untouched
+    assert np.array(d) is not np.asarray(d)
+    with pytest.raises(ValueError):
+        np.asarray(d, dtype=np.float64, copy=False)
+    assert np.asarray(d, copy=False) is np.asarray(d)
+    assert np.array_equal(d ** 2, t.numpy() ** 2) and np.array_equal(abs(-d), t.numpy()) and d.T.shape == (3, 2)
+    assert float(d.sum()) == 15.0 and float(d.mean()) == 2.5 and float((d * d).sum()) == 55.0 and int((d > 2).sum()) == 3
+    assert np.isclose(np.linalg.norm(d), np.sqrt(55.0)) and np.array_equal(np.sqrt(d), np.sqrt(t.numpy()))
+    assert np.concatenate([d, d]).shape == (4, 3) and float(np.clip(d, 0, 1).max()) == 1.0 and hash(d) == hash(d)
+    gnorm = np.sqrt(sum(float(np.sum(np.square(l))) for l in leaves if l.dtype.kind == "f"))        # global-norm clipping on device leaves
+    assert np.isfinite(gnorm) and gnorm > 0
+
+
+def test_filter_jit_structure_signature_ignores_leaf_identity():
+    """The eager-fast-path key of `filter_jit` (transforms._struct_sig): equal for a model and a copy with NEW leaf objects of the same
+    shapes (what apply_updates returns every step), different when a shape or a static field changes."""
+    import eqxvision_amd as eqv
+    from eqxvision_amd._module import tree_map
+    from eqxvision_amd.transforms import _module_sig, _struct_sig
+    net = eqv.models.alexnet(num_classes=3, key=eqv.random.PRNGKey(0))
+    new = tree_map(lambda l: l.copy() if isinstance(l, np.ndarray) else l, net)
+    assert _module_sig(new) != _module_sig(net) and _struct_sig(new) == _struct_sig(net)
+    other = eqv.models.alexnet(num_classes=4, key=eqv.random.PRNGKey(0))
+    assert _struct_sig(other) != _struct_sig(net)
+    assert _struct_sig(eqv.tree_inference(net, True)) != _struct_sig(eqv.tree_inference(net, False))
