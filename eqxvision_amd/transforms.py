@@ -221,6 +221,8 @@ def _struct_sig(x):
         return ("dict",) + tuple((k, _struct_sig(v)) for k, v in sorted(x.items()))
     if callable(x):
         return ("obj", id(x))
+    if isinstance(x, (int, float)) and not isinstance(x, bool):
+        return ("num", type(x).__name__)       # an optimiser's step counter changes every call; flags (bool / str / None) stay values
     try:
         hash(x)
         return ("val", x)
