@@ -134,7 +134,7 @@ def on_replay(fn) -> None:
 
 
 class Act:
-    __slots__ = ("t", "kind", "batched", "pre", "node")
+    __slots__ = ("t", "kind", "batched", "pre", "node", "sub")
 
     def __init__(self, t: torch.Tensor, kind: str, batched: bool):
         self.t = t
@@ -143,6 +143,8 @@ class Act:
         self.pre = None     # (module, Act): the result of applying `module` (+ its norm + relu) to this activation was
                             # already produced by the launch that produced it (ops.conv1x1_chain)
         self.node = None    # under filter_value_and_grad: the autograd node that produced this activation (grad.py)
+        self.sub = None     # s: `t` holds only the pixels (s i, s j) of the logical map -- written that way because the one consumer
+                            # left is a stride-s pointwise convolution (ops.conv1x1_chain(..., sub=), ops.conv1x1_dual)
 
     @property
     def B(self) -> int:

@@ -93,6 +93,10 @@ PROTOTYPES = {
     "mv_bottleneck_tail_fwd": [_vp] * 9 + [_i] * 6 + [_vp],
     "mv_conv1x1_dual_supported": [_i64, _i, _i, _i, _i],
     "mv_conv1x1_dual_fwd": [_vp] * 6 + [_i] * 11 + [_vp],
+    "mv_conv1x1_chain_rc_supported": [_i64, _i, _i, _i, _i],
+    "mv_conv1x1_chain_rc_fwd": [_vp] * 7 + [_i64, _i, _i, _i, _i, _vp],
+    "mv_conv1x1_chain_sub_supported": [_i] * 7,
+    "mv_conv1x1_chain_sub_fwd": [_vp] * 10 + [_i] * 7 + [_vp],
     "mv_conv1x1_dual_chain_supported": [_i64, _i, _i, _i, _i, _i],
     "mv_conv1x1_dual_chain_fwd": [_vp] * 10 + [_i64, _i, _i, _i, _i, _i, _vp],
     "mv_linear_heads_supported": [_i64, _i, _i, _i, _i, _i],

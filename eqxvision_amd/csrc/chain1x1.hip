@@ -33,6 +33,7 @@ struct ChainP {
     const float* shift1;
     bf16_t* t1;             // [M][64]
     int M, tiles_m;
+    int subH, subW;         // SUB: the map is [.., subH, subW] and y is its stride-2 sub-sampling [.., subH / 2, subW / 2, 256]
 };
 
 // N2 = 64: the next block of the same stage (8 waves).  N2 = 128: the first block of the next stage, whose conv1 is
@@ -41,7 +42,11 @@ struct ChainP {
 // resnet.py:295-303).  conv3 and the downsample conv write the same output, so they are ONE GEMM over the concatenated
 // reduction [t2 | x] with the two BatchNorm scales folded into the bf16 weight rows (shifts summed): the 256-channel
 // identity map is neither written nor read (-411 MB at batch 256) and its launch disappears.
-template <int N2, int WAVES, bool DUAL>
+// SUB (round 6): the ONLY consumer of y besides the fused conv1 is a stride-2 pointwise convolution (the downsample branch of the next
+// stage's first block, resnet.py:295-303; the 3x3 of ResNet v1.5 strides on t1, not on y): only the pixels with even (h, w) are
+// stored, compactly -- a quarter of the 256-channel map's bytes -- and the strided consumer reads that tensor with stride 1.
+// y == NULL (DUAL, round 6): nobody reads this block's output map (the next block recomputes it, chain_rc.hip): no store.
+template <int N2, int WAVES, bool DUAL, bool SUB = false>
 __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
     constexpr int C = DUAL ? 128 : 64, K = 256;
     constexpr int T2 = N2 / 32;                                 // 32-channel tiles of the second GEMM
@@ -123,9 +128,21 @@ __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
         // with the `if`s hipcc lost count of the in-order vmcnt queue and drained it (`vmcnt(0)`) in the middle of every tile, i.e.
         // waited for the NEXT tiles' x rows that had just been issued to hide their latency (round 5, tools/scan_store_waits.py)
         const int tile_u = __builtin_amdgcn_readfirstlane(tile);
-        const brsrc_t ry = make_brsrc(p.y + (long long)tile_u * 32 * K);
+        const brsrc_t ry = SUB ? make_brsrc(p.y) : make_brsrc(p.y + (long long)tile_u * 32 * K, p.y != nullptr);
         const brsrc_t rt = make_brsrc(p.t1 + (long long)tile_u * 32 * N2);
         const int rows_left = p.M - tile_u * 32;
+        unsigned ysub[4] = {0, 0, 0, 0};                        // SUB: byte offset of the lane's row of pass i in the compact y, or OOB
+        if constexpr (SUB) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = tile * 32 + pass * 8 + (lane >> 3);
+                const int hw = p.subH * p.subW;
+                const int b = m / hw, rem = m - b * hw;
+                const int h = rem / p.subW, w = rem - h * p.subW;
+                const bool keep = m < p.M && !((h | w) & 1);
+                ysub[pass] = keep ? (unsigned)(((b * (p.subH >> 1) + (h >> 1)) * (p.subW >> 1) + (w >> 1)) * K) * 2u : BUF_OOB;
+            }
+        }
         f32x16 acc2[T2];
 #pragma unroll
         for (int a = 0; a < T2; ++a)
@@ -199,7 +216,8 @@ __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                     uint4 u;
                     u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
-                    buf_store_u4(ry, row < rows_left ? (unsigned)(row * K + nloc) * 2u : BUF_OOB, u);
+                    if constexpr (SUB) buf_store_u4(ry, ysub[pass] == BUF_OOB ? BUF_OOB : ysub[pass] + (unsigned)nloc * 2u, u);
+                    else buf_store_u4(ry, row < rows_left ? (unsigned)(row * K + nloc) * 2u : BUF_OOB, u);
                     // the same bf16 values, row-major in the patch: the B operand of the second GEMM.  (This pass's
                     // fp32 reads of these rows are older LDS operations of the same wave: in-order, no hazard.)
                     *(uint4*)(ep + row * EPITCH + c8 * 16) = u;
@@ -252,6 +270,10 @@ __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
 
     uint4 xa[KC], xb[KC];                                       // two pixel tiles in flight per wave
     int tile = gw;
+    // (Round 6 tried running both tiles of an iteration unconditionally -- rows clamped, stores out of range -- so that hipcc's
+    // waits at the loop head become exact counts instead of vmcnt(11) .. vmcnt(0): 7 -> 3-4 drains per kernel in the ISA, and the
+    // kernels got 4-8 % SLOWER alone, because a wave with an odd number of tiles then computes a whole tile for nothing
+    // (12 544 tiles over 2 048 waves = 6.1 each: 8 instead of 7); profiles/r06/chain_loop_unconditional_second_tile_ab.txt.)
     if (tile < p.tiles_m) load_x(xa, tile);
     if (tile + nw < p.tiles_m) load_x(xb, tile + nw);
     for (; tile < p.tiles_m; tile += 2 * nw) {
@@ -261,23 +283,24 @@ __global__ __launch_bounds__(WAVES * 64) void chain1x1_kernel(const ChainP p) {
 }
 
 int chain1x1_supported(long long M, int C, int K, int N2, int dtype) {
-    return dtype == MV_BF16 && C == 64 && K == 256 && (N2 == 64 || N2 == 128) && M >= 8192 && M < (1LL << 31) - 64 &&
+    return dtype == MV_BF16 && C == 64 && K == 256 && (N2 == 64 || N2 == 128) && M >= 8192 && M < (1LL << 31) - (1 << 20) &&
            !get_flag("no_chain");
 }
 int chain1x1_dual_supported(long long M, int C1, int C2, int K, int N2, int dtype) {
-    return dtype == MV_BF16 && C1 == 64 && C2 == 64 && K == 256 && N2 == 64 && M >= 8192 && M < (1LL << 31) - 64 &&
+    return dtype == MV_BF16 && C1 == 64 && C2 == 64 && K == 256 && N2 == 64 && M >= 8192 && M < (1LL << 31) - (1 << 20) &&
            !get_flag("no_chain") && !get_flag("no_dual_chain");
 }
 
-template <int N2, int WAVES, bool DUAL>
+template <int N2, int WAVES, bool DUAL, bool SUB = false>
 static int chain_go(ChainP& p, hipStream_t st) {
     constexpr int SMEM = 256 * ((DUAL ? 128 : 64) * 2 + 16) + N2 * 528 + (2 * 256 + 2 * N2) * 4 + WAVES * 32 * (64 * 4 + 16);
     static_assert(SMEM <= 160 * 1024, "LDS");
     int gx = 256;
     const int need = (p.tiles_m + WAVES - 1) / WAVES;
     if (gx > need) gx = need;
-    auto kern = chain1x1_kernel<N2, WAVES, DUAL>;
-    MV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    auto kern = chain1x1_kernel<N2, WAVES, DUAL, SUB>;
+    static LdsAttrSite attr;
+    MV_HIP(attr.ensure((const void*)kern, SMEM));
     hipLaunchKernelGGL(kern, dim3(gx), dim3(WAVES * 64), SMEM, st, p);
     MV_LAUNCH_CHECK();
     return MV_OK;
@@ -291,12 +314,33 @@ int chain1x1_launch(const void* x, const void* w3, const float* scale3, const fl
     p.w1 = (const bf16_t*)w1; p.scale1 = scale1; p.shift1 = shift1; p.t1 = (bf16_t*)t1;
     p.M = (int)M;
     p.tiles_m = (int)((M + 31) / 32);
+    p.subH = p.subW = 0;
     if (N2 == 64) {
         set_kernel_name("chain1x1_bf16_64_256_64");
         return chain_go<64, 8, false>(p, st);
     }
     set_kernel_name("chain1x1_bf16_64_256_128");
     return chain_go<128, 6, false>(p, st);
+}
+
+int chain1x1_sub_supported(long long N, int H, int W, int C, int K, int N2, int dtype) {
+    return chain1x1_supported(N * H * W, C, K, N2, dtype) && N2 == 128 && H % 2 == 0 && W % 2 == 0 &&
+           N * (H / 2) * (W / 2) * K * 2 < (1LL << 31) && !get_flag("no_chain_sub");
+}
+
+// as chain1x1_launch with N2 = 128, y = the stride-2 sub-sampling [N][H/2][W/2][256] of the block output
+int chain1x1_sub_launch(const void* x, const void* w3, const float* scale3, const float* shift3, const void* residual, void* y_sub,
+                        const void* w1, const float* scale1, const float* shift1, void* t1, int N, int H, int W, hipStream_t st) {
+    ChainP p;
+    p.x = (const bf16_t*)x; p.x2 = nullptr; p.w3 = (const bf16_t*)w3; p.scale3 = scale3; p.shift3 = shift3;
+    p.residual = (const bf16_t*)residual; p.y = (bf16_t*)y_sub;
+    p.w1 = (const bf16_t*)w1; p.scale1 = scale1; p.shift1 = shift1; p.t1 = (bf16_t*)t1;
+    const long long M = (long long)N * H * W;
+    p.M = (int)M;
+    p.tiles_m = (int)((M + 31) / 32);
+    p.subH = H; p.subW = W;
+    set_kernel_name("chain1x1_bf16_64_256_128_ysub2");
+    return chain_go<128, 6, false, true>(p, st);
 }
 
 // x [M][64] and x2 [M][64] are the two K-sources, wcat [256][128] = [rows of W3 scaled | rows of W_d scaled], shift3 = the
@@ -309,7 +353,8 @@ int chain1x1_dual_launch(const void* x, const void* x2, const void* wcat, const 
     p.w1 = (const bf16_t*)w1; p.scale1 = scale1; p.shift1 = shift1; p.t1 = (bf16_t*)t1;
     p.M = (int)M;
     p.tiles_m = (int)((M + 31) / 32);
-    set_kernel_name("chain1x1_dual_bf16_64+64_256_64");
+    p.subH = p.subW = 0;
+    set_kernel_name(y ? "chain1x1_dual_bf16_64+64_256_64" : "chain1x1_dual_bf16_64+64_256_64_noy");
     return chain_go<64, 6, true>(p, st);
 }
 

@@ -134,7 +134,9 @@ __global__ __launch_bounds__(512) void conv3x3c64_v2_kernel(const C3V2P p) {
             f32x16 acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-            u32x4 bf[2][4];
+            u32x4 bf[2][4];     // B fragments one tap ahead.  (Two taps ahead -- a tap is only 4 MFMAs = 128 cycles of matrix work -- was
+                                // built in round 6 and is 7 % SLOWER, 44.8 vs 41.8 us alone, resnet50 -0.9 %: 256 instead of 247 VGPRs
+                                // and three taps of reads in the LDS queue; profiles/r06/conv3x3c64_prefetch_two_taps_ab.txt)
             auto read_tap = [&](int set, int tap) {
                 const int r = tap / 3, sx = tap - 3 * r;
 #pragma unroll

@@ -1329,6 +1329,40 @@ int mv_conv1x1_chain_fwd(const void* x, const void* w3, const float* scale3, con
     return chain1x1_launch(x, w3, scale3, shift3, residual, y, w1, scale1, shift1, t1, M, N2, (hipStream_t)stream);
 }
 
+int mv_conv1x1_chain_sub_supported(int N, int H, int W, int C, int K, int N2, int dtype) {
+    return !get_flag("force_generic") && !get_flag("no_stream") && N > 0 && H > 0 && W > 0 && chain1x1_sub_supported(N, H, W, C, K, N2, dtype);
+}
+
+int mv_conv1x1_chain_sub_fwd(const void* x, const void* w3, const float* scale3, const float* shift3, const void* residual,
+                             void* y_sub, const void* w1, const float* scale1, const float* shift1, void* t1, int N, int H, int W,
+                             int C, int K, int N2, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && w3 && residual && y_sub && w1 && t1, "conv1x1_chain_sub: NULL pointer");
+    if (!mv_conv1x1_chain_sub_supported(N, H, W, C, K, N2, dtype)) {
+        set_error("conv1x1_chain_sub: unsupported shape N=%d H=%d W=%d C=%d K=%d N2=%d (ask mv_conv1x1_chain_sub_supported first)", N, H,
+                  W, C, K, N2);
+        return MV_E_UNSUPPORTED;
+    }
+    MV_CHECK_ARG(y_sub != residual && y_sub != x && t1 != y_sub, "conv1x1_chain_sub: y_sub must not alias x / residual / t1");
+    return chain1x1_sub_launch(x, w3, scale3, shift3, residual, y_sub, w1, scale1, shift1, t1, N, H, W, (hipStream_t)stream);
+}
+
+int mv_conv1x1_chain_rc_supported(int64_t M, int C, int K, int N2, int dtype) {
+    return !get_flag("force_generic") && !get_flag("no_stream") && chain_rc_supported(M, C, K, N2, dtype);
+}
+
+int mv_conv1x1_chain_rc_fwd(const void* t2, const void* t2_prev, const void* x0, const void* wfrag, const float* tab, void* y,
+                            void* t1, int64_t M, int C, int K, int N2, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(t2 && t2_prev && x0 && wfrag && tab && y && t1, "conv1x1_chain_rc: NULL pointer");
+    if (!mv_conv1x1_chain_rc_supported(M, C, K, N2, dtype)) {
+        set_error("conv1x1_chain_rc: unsupported shape M=%lld C=%d K=%d N2=%d (ask mv_conv1x1_chain_rc_supported first)", (long long)M, C,
+                  K, N2);
+        return MV_E_UNSUPPORTED;
+    }
+    MV_CHECK_ARG(y != t2 && y != t2_prev && y != x0 && t1 != y && t1 != t2 && t1 != t2_prev && t1 != x0,
+                 "conv1x1_chain_rc: outputs must not alias inputs");
+    return chain_rc_launch(t2, t2_prev, x0, wfrag, tab, y, t1, M, (hipStream_t)stream);
+}
+
 int mv_conv1x1_dual_supported(int64_t M, int C1, int C2, int K, int dtype) {
     return !get_flag("force_generic") && !get_flag("no_igemm2") && igemm2_dual_supported(M, C1, C2, K, dtype);
 }
@@ -1366,7 +1400,7 @@ int mv_conv1x1_dual_chain_supported(int64_t M, int C1, int C2, int K, int N2, in
 int mv_conv1x1_dual_chain_fwd(const void* x, const void* x2, const void* wcat, const float* scale, const float* shift, void* y,
                               const void* w1, const float* scale1, const float* shift1, void* t1, int64_t M, int C1, int C2,
                               int K, int N2, int dtype, mv_stream_t stream) {
-    MV_CHECK_ARG(x && x2 && wcat && y && w1 && t1, "conv1x1_dual_chain: NULL pointer");
+    MV_CHECK_ARG(x && x2 && wcat && w1 && t1, "conv1x1_dual_chain: NULL pointer");       // y may be NULL: the block output is not stored
     if (!mv_conv1x1_dual_chain_supported(M, C1, C2, K, N2, dtype)) {
         set_error("conv1x1_dual_chain: unsupported shape M=%lld C1=%d C2=%d K=%d N2=%d (ask mv_conv1x1_dual_chain_supported)",
                   (long long)M, C1, C2, K, N2);

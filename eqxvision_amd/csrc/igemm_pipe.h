@@ -144,6 +144,9 @@ __device__ __forceinline__ void epilogue_rows(const Igemm2P& p, char* ep, f32x16
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) dst[pass].load(rr, row_vo(b * 32 + pass * 8), (unsigned)(b * 4 + pass) * kstep);
     };
+    // (Fetching the first tile's rows BEFORE the main loop -- 32 more live registers, 255 VGPRs in the lin / fp32 kernel, no spills --
+    // was built in round 6: proj 61.4 -> 62.2 us, fc2 160.0 -> 157.4 us alone, vit_base 22 784 vs 22 805 img/s: nothing.
+    // profiles/r06/vit_residual_rows_before_main_loop_ab.txt)
     fetch_res(0, late[0]);
 #pragma unroll
     for (int b = 0; b < NBT; ++b) {

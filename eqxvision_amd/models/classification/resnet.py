@@ -129,12 +129,65 @@ class _ResNetBottleneck(Module):
             y = ops.conv1x1_dual(out, self.conv3, self.bn3, x, ds[0], ds[1], "relu")
             if y is not None:
                 return y
+        if x.sub is not None:
+            raise RuntimeError("bottleneck: the input map was written sub-sampled for a downsample branch that did not run")
         identity = _shortcut(self, x)
         if isinstance(nxt, _ResNetBottleneck):
-            y = ops.conv1x1_chain(out, self.conv3, self.bn3, identity, nxt.conv1, nxt.bn1)
+            # `nxt` opening the next stage with a stride-2 pointwise downsample branch is -- besides its conv1, which this launch
+            # computes -- the only consumer of this block's output: then only the pixels that branch reads are written
+            y = ops.conv1x1_chain(out, self.conv3, self.bn3, identity, nxt.conv1, nxt.bn1, sub=2 if _reads_strided_only(nxt, out) else 0)
             if y is not None:
                 return y
         return ops.conv2d(out, self.conv3, self.bn3, "relu", residual=identity)
+
+
+def _conv_downsample(block):
+    ds = block.downsample
+    if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d) and isinstance(ds[1], nn.BatchNorm):
+        return ds[0], ds[1]
+    return None
+
+
+def _reads_strided_only(nxt, out) -> bool:
+    """True when bottleneck `nxt` reads its input map ONLY through a 1x1 stride-2 downsample convolution that ops.conv1x1_dual
+    will run (its conv1 is pointwise and fused into the producer; ResNet v1.5 strides the 3x3, resnet.py:119-127, 295-303)."""
+    cd = _conv_downsample(nxt)
+    if cd is None or not ops._pointwise(nxt.conv1):
+        return False
+    conv, bn = cd
+    if tuple(conv.kernel_size) != (1, 1) or tuple(conv.stride) != (2, 2) or tuple(conv.padding) != (0, 0) \
+            or tuple(conv.dilation) != (1, 1) or conv.groups != 1:
+        return False
+    B, H, W, _ = out.t.shape
+    if H % 2 or W % 2 or tuple(nxt.conv2.stride) != (2, 2):
+        return False
+    return ops.conv1x1_dual_available(B * (H // 2) * (W // 2), nxt.conv3, nxt.bn3, conv, bn)
+
+
+def _stage_rc(stage, x, nxt):
+    """A stage of exactly three bottlenecks (layer1 of ResNet-50 / 101 / 152) with the first block's output never written: block 0
+    stores only the next conv1's result, block 1's boundary recomputes y0 from its two 64-channel sources (ops.conv1x1_chain_rc),
+    block 2 runs as usual (and writes its output sub-sampled when `nxt` only reads it strided).  None when any piece has no path."""
+    L = list(stage.layers) if isinstance(stage, nn.Sequential) else []
+    if len(L) != 3 or not all(type(b) is _ResNetBottleneck for b in L) or not ops.is_act(x) or x.pre is not None:
+        return None
+    b0, b1, b2 = L
+    cd = _conv_downsample(b0)
+    if cd is None or not isinstance(b1.downsample, nn.Identity) or not isinstance(b2.downsample, nn.Identity):
+        return None
+    if not ops.chain_rc_available(x, b0, cd, b1, b2):
+        return None
+    x = ops.as_map(x)
+    t1 = ops.conv2d(x, b0.conv1, b0.bn1, "relu")
+    t2_0 = ops.conv2d(t1, b0.conv2, b0.bn2, "relu")
+    t1 = ops.conv1x1_dual_chain(t2_0, b0.conv3, b0.bn3, x, cd[0], cd[1], b1.conv1, b1.bn1, store_y=False)
+    if t1 is None:
+        raise RuntimeError("stage_rc: the dual chain refused shapes ops.chain_rc_available accepted")
+    t2_1 = ops.conv2d(t1, b1.conv2, b1.bn2, "relu")
+    y1 = ops.conv1x1_chain_rc(t2_1, t2_0, x, b0.conv3, b0.bn3, cd[0], cd[1], b1.conv3, b1.bn3, b2.conv1, b2.bn1)
+    if y1 is None:
+        raise RuntimeError("stage_rc: the recompute chain refused shapes ops.chain_rc_available accepted")
+    return b2.call_chained(y1, nxt)
 
 
 EXPANSIONS = {_ResNetBasicBlock: 1, _ResNetBottleneck: 4}
@@ -225,6 +278,10 @@ class ResNet(Module):
             # the last block of a stage may fuse its tail with the head of the next stage's first block
             nxt = stages[i + 1][0] if i + 1 < len(stages) and isinstance(stages[i + 1], nn.Sequential) and \
                 len(stages[i + 1]) > 0 else None
+            y = _stage_rc(stage, x, nxt)
+            if y is not None:
+                x = y
+                continue
             x = stage.call_chained(x, nxt) if isinstance(stage, nn.Sequential) else stage(x)
         if type(self.avgpool) is nn.AdaptiveAvgPool2d and head_fp32():     # reference :354-356, pooled features kept fp32
             x = ops.adaptive_avgpool2d(x, self.avgpool.target_shape, out_fp32=True)

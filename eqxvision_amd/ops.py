@@ -430,10 +430,13 @@ def _pointwise(conv) -> bool:
             and tuple(conv.dilation) == (1, 1) and conv.groups == 1)
 
 
-def conv1x1_chain(x: Act, conv3, bn3, residual: Act, conv1n, bn1n) -> Optional[Act]:
+def conv1x1_chain(x: Act, conv3, bn3, residual: Act, conv1n, bn1n, sub: int = 0) -> Optional[Act]:
     """relu(bn3(conv3(x)) + residual), and in the same launch relu(bn1n(conv1n(.))) of that result: the tail of one
     ResNet bottleneck and the head of the next (resnet.py:144-162).  Returns the first result with the second attached
-    as `.pre = (conv1n, Act)`, or None when the library has no fused path for the shapes (caller falls back to conv2d)."""
+    as `.pre = (conv1n, Act)`, or None when the library has no fused path for the shapes (caller falls back to conv2d).
+    `sub` = 2: the caller guarantees that the only other consumer of the first result is a stride-2 pointwise convolution
+    (the next stage's downsample branch); where the library can, only the pixels that convolution reads are written
+    (`.sub = 2`, a quarter of the map); otherwise the full map is written as usual."""
     dt = compute_dtype()
     if dt != "bf16" or not (_pointwise(conv3) and _pointwise(conv1n)) or conv3.out_channels != conv1n.in_channels:
         return None
@@ -450,12 +453,85 @@ def conv1x1_chain(x: Act, conv3, bn3, residual: Act, conv1n, bn1n) -> Optional[A
         return None
     w3, s3, h3 = prep_conv(conv3, bn3, "krsc", dt)
     w1, s1, h1 = prep_conv(conv1n, bn1n, "krsc", dt)
+    t1 = empty((B, H, W, N2), torch.bfloat16)
+    if sub == 2 and _lib.load().mv_conv1x1_chain_sub_supported(B, H, W, C, K, N2, DT[dt]):
+        y = empty((B, H // 2, W // 2, K), torch.bfloat16)
+        _lib.call("mv_conv1x1_chain_sub_fwd", _ptr(x.t), _ptr(w3), _ptr(s3), _ptr(h3), _ptr(residual.t), _ptr(y), _ptr(w1), _ptr(s1),
+                  _ptr(h1), _ptr(t1), B, H, W, C, K, N2, DT[dt], stream_ptr())
+        out = Act(y, "map", x.batched)
+        out.sub = 2
+    else:
+        y = empty((B, H, W, K), torch.bfloat16)
+        _lib.call("mv_conv1x1_chain_fwd", _ptr(x.t), _ptr(w3), _ptr(s3), _ptr(h3), _ptr(residual.t), _ptr(y), _ptr(w1), _ptr(s1),
+                  _ptr(h1), _ptr(t1), M, C, K, N2, DT[dt], stream_ptr())
+        out = Act(y, "map", x.batched)
+    out.pre = (conv1n, Act(t1, "map", x.batched))
+    return out
+
+
+def chain_rc_fragments(conv3_0, bn3_0, ds_conv, ds_bn, conv3_1, bn3_1, conv1n, bn1n):
+    """Weights and epilogue constants of mv_conv1x1_chain_rc_fwd (header): per 32-channel chunk c of the block output, 16 MFMA A
+    fragments [lane = 32 fh + r][8] -- 8 of [scale3 W3_0 | scale_d W_d][32 c + r, 16 kk + 8 fh ..], 4 of W3_1[32 c + r, ...], 4 of
+    the next conv1 (k-step s, row tile a2) with the reduction index in accumulator order -- and the table
+    shift0 | scale1 | shift1 | scaleN | shiftN (cached on conv3_1)."""
+    cache = conv3_1._cache()
+    key = ("chain_rc", _bn_id(bn3_1), id(conv3_0), _bn_id(bn3_0), id(ds_conv), _bn_id(ds_bn), id(conv1n), _bn_id(bn1n))
+    hit = cache.get(key)
+    if hit is None:
+        w30, h30 = _scaled_rows(conv3_0, bn3_0)
+        wd, hd = _scaled_rows(ds_conv, ds_bn)
+        wcat = np.concatenate([w30, wd], axis=1)                                  # [256][128], as ops._dual_weights
+        w31 = np.asarray(conv3_1.weight, np.float32).reshape(conv3_1.out_channels, -1)      # [256][64]
+        s1, h1 = _fold(conv3_1, bn3_1)
+        w1n = np.asarray(conv1n.weight, np.float32).reshape(conv1n.out_channels, -1)        # [64][256]
+        sn, hn = _fold(conv1n, bn1n)
+        K, N2 = wcat.shape[0], w1n.shape[0]
+        frags = np.empty((K // 32, 16, 2, 32, 8), np.float32)                      # (chunk, fragment, fh, r, e)
+        e8 = np.arange(8)
+        for c in range(K // 32):
+            rows = slice(32 * c, 32 * c + 32)
+            for fh in range(2):
+                for kk in range(8):
+                    frags[c, kk, fh] = wcat[rows][:, 16 * kk + 8 * fh + e8]
+                for kk in range(4):
+                    frags[c, 8 + kk, fh] = w31[rows][:, 16 * kk + 8 * fh + e8]
+                for s_ in range(2):
+                    cols = 32 * c + 16 * s_ + 4 * fh + np.array([0, 1, 2, 3, 8, 9, 10, 11])
+                    for a2 in range(N2 // 32):
+                        frags[c, 12 + 2 * s_ + a2, fh] = w1n[32 * a2:32 * a2 + 32][:, cols]
+        tab = np.concatenate([(h30 + hd).astype(np.float32), s1, h1, sn, hn]).astype(np.float32)
+        hit = (_dev(frags.reshape(-1), torch.bfloat16), _dev(tab, torch.float32), (conv3_0, ds_conv, conv1n))   # modules: keep ids alive
+        cache[key] = hit
+    return hit
+
+
+def conv1x1_chain_rc(t2: Act, t2_prev: Act, x0: Act, conv3_0, bn3_0, ds_conv, ds_bn, conv3_1, bn3_1, conv1n, bn1n) -> Optional[Act]:
+    """The boundary between the second and the third bottleneck of a stage whose FIRST block output was not written
+    (ops.conv1x1_dual_chain(..., store_y=False)): y0 = relu(bn3_0(conv3_0(t2_prev)) + ds_bn(ds_conv(x0))) is recomputed from its
+    two 64-channel sources, then y1 = relu(bn3_1(conv3_1(t2)) + y0) and relu(bn1n(conv1n(y1))) as ops.conv1x1_chain
+    (resnet.py:144-162, 295-303).  Returns y1 with the next conv1's result attached as `.pre`, or None if unsupported."""
+    dt = compute_dtype()
+    if dt != "bf16" or not all(_pointwise(c) for c in (conv3_0, ds_conv, conv3_1, conv1n)):
+        return None
+    if any(_bn_training(b) for b in (bn3_0, ds_bn, bn3_1, bn1n)):
+        return None
+    t2, t2_prev, x0 = as_map(t2), as_map(t2_prev), as_map(x0)
+    B, H, W, C = t2.t.shape
+    K, N2 = conv3_1.out_channels, conv1n.out_channels
+    M = B * H * W
+    if tuple(t2_prev.t.shape) != (B, H, W, C) or tuple(x0.t.shape) != (B, H, W, C) or conv3_0.in_channels != C \
+            or ds_conv.in_channels != C or conv3_1.in_channels != C or conv3_0.out_channels != K or ds_conv.out_channels != K \
+            or conv1n.in_channels != K or any(a.t.dtype != torch.bfloat16 for a in (t2, t2_prev, x0)):
+        return None
+    if not _lib.load().mv_conv1x1_chain_rc_supported(M, C, K, N2, DT[dt]):
+        return None
+    wf, tab, _ = chain_rc_fragments(conv3_0, bn3_0, ds_conv, ds_bn, conv3_1, bn3_1, conv1n, bn1n)
     y = empty((B, H, W, K), torch.bfloat16)
     t1 = empty((B, H, W, N2), torch.bfloat16)
-    _lib.call("mv_conv1x1_chain_fwd", _ptr(x.t), _ptr(w3), _ptr(s3), _ptr(h3), _ptr(residual.t), _ptr(y), _ptr(w1), _ptr(s1),
-              _ptr(h1), _ptr(t1), M, C, K, N2, DT[dt], stream_ptr())
-    out = Act(y, "map", x.batched)
-    out.pre = (conv1n, Act(t1, "map", x.batched))
+    _lib.call("mv_conv1x1_chain_rc_fwd", _ptr(t2.t), _ptr(t2_prev.t), _ptr(x0.t), _ptr(wf), _ptr(tab), _ptr(y), _ptr(t1), M, C, K, N2,
+              DT[dt], stream_ptr())
+    out = Act(y, "map", t2.batched)
+    out.pre = (conv1n, Act(t1, "map", t2.batched))
     return out
 
 
@@ -557,6 +633,10 @@ def conv1x1_dual(x: Act, conv3, bn3, xin: Act, ds_conv, ds_bn, act="relu") -> Op
     B, Ho, Wo, C1 = x.t.shape
     B2, H2, W2, C2 = xin.t.shape
     K = conv3.out_channels
+    if xin.sub is not None:             # the producer wrote only the pixels this convolution reads (ops.conv1x1_chain(..., sub=))
+        if xin.sub != sd[0]:
+            raise RuntimeError(f"conv1x1_dual: source sub-sampled by {xin.sub}, convolution stride {sd[0]}")
+        sd = (1, 1)
     if B2 != B or (H2 - 1) // sd[0] + 1 != Ho or (W2 - 1) // sd[0] + 1 != Wo or C1 != conv3.in_channels \
             or C2 != ds_conv.in_channels or x.t.dtype != torch.bfloat16 or xin.t.dtype != torch.bfloat16:
         return None
@@ -570,7 +650,36 @@ def conv1x1_dual(x: Act, conv3, bn3, xin: Act, ds_conv, ds_bn, act="relu") -> Op
     return Act(y, "map", x.batched)
 
 
-def conv1x1_dual_chain(x: Act, conv3, bn3, xin: Act, ds_conv, ds_bn, conv1n, bn1n) -> Optional[Act]:
+def conv1x1_dual_available(M: int, conv3, bn3, ds_conv, ds_bn) -> bool:
+    """Would ops.conv1x1_dual run for M output pixels of these layers?  (Asked BEFORE a producer decides to write only the pixels
+    a strided downsample branch reads.)"""
+    if compute_dtype() != "bf16" or not _pointwise(conv3) or _bn_training(bn3) or _bn_training(ds_bn) \
+            or conv3.out_channels != ds_conv.out_channels or _lib.get_flag("no_chain_sub"):
+        return False
+    return bool(_lib.load().mv_conv1x1_dual_supported(M, conv3.in_channels, ds_conv.in_channels, conv3.out_channels, DT["bf16"]))
+
+
+def chain_rc_available(x: Act, b0, cd, b1, b2) -> bool:
+    """Can a three-bottleneck stage run with its first block output un-written (models/classification/resnet.py: _stage_rc)?"""
+    if compute_dtype() != "bf16" or _lib.get_flag("no_chain_rc"):
+        return False
+    convs = (b0.conv3, cd[0], b1.conv1, b1.conv3, b2.conv1)
+    if not all(_pointwise(c) for c in convs) or any(_bn_training(b) for b in (b0.bn1, b0.bn2, b0.bn3, cd[1], b1.bn1, b1.bn2, b1.bn3, b2.bn1)):
+        return False
+    if x.kind != "map" or x.t.dtype != torch.bfloat16:
+        return False
+    B, H, W, C = x.t.shape
+    M, K = B * H * W, b0.conv3.out_channels
+    if b0.conv3.in_channels != C or cd[0].in_channels != C or b1.conv3.in_channels != C or cd[0].out_channels != K \
+            or b1.conv3.out_channels != K or b1.conv1.in_channels != K or b2.conv1.in_channels != K \
+            or tuple(b0.conv2.stride) != (1, 1) or tuple(b1.conv2.stride) != (1, 1) or b0.conv2.out_channels != C or b1.conv2.out_channels != C:
+        return False
+    lib = _lib.load()
+    return bool(lib.mv_conv1x1_dual_chain_supported(M, C, C, K, b1.conv1.out_channels, DT["bf16"])
+                and lib.mv_conv1x1_chain_rc_supported(M, C, K, b2.conv1.out_channels, DT["bf16"]))
+
+
+def conv1x1_dual_chain(x: Act, conv3, bn3, xin: Act, ds_conv, ds_bn, conv1n, bn1n, store_y: bool = True) -> Optional[Act]:
     """relu(bn3(conv3(x)) + ds_bn(ds_conv(xin))) -- a bottleneck whose identity is a pointwise conv of the block input
     (resnet.py:295-303) -- and relu(bn1n(conv1n(.))) of that result, in ONE launch: the two convolutions that add into
     the same output run as one GEMM over the concatenated reduction [x | xin], the BatchNorm scales folded into the bf16
@@ -593,10 +702,12 @@ def conv1x1_dual_chain(x: Act, conv3, bn3, xin: Act, ds_conv, ds_bn, conv1n, bn1
         return None
     wcat, shift = _dual_weights(conv3, bn3, ds_conv, ds_bn)
     w1, s1, h1 = prep_conv(conv1n, bn1n, "krsc", dt)
-    y = empty((B, H, W, K), torch.bfloat16)
+    y = empty((B, H, W, K), torch.bfloat16) if store_y else None
     t1 = empty((B, H, W, N2), torch.bfloat16)
     _lib.call("mv_conv1x1_dual_chain_fwd", _ptr(x.t), _ptr(xin.t), _ptr(wcat), None, _ptr(shift), _ptr(y), _ptr(w1), _ptr(s1),
               _ptr(h1), _ptr(t1), M, C1, C2, K, N2, DT[dt], stream_ptr())
+    if not store_y:                     # the block output stays un-written (the next boundary recomputes it: ops.conv1x1_chain_rc):
+        return Act(t1, "map", x.batched)        # the caller gets the next block's conv1 output itself
     out = Act(y, "map", x.batched)
     out.pre = (conv1n, Act(t1, "map", x.batched))
     return out

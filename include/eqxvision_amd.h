@@ -169,6 +169,29 @@ int mv_conv1x1_dual_chain_fwd(const void* x, const void* x2, const void* wcat, c
                               const float* shift1, void* t1, int64_t M, int C1, int C2, int K, int N2,
                               int dtype, mv_stream_t stream);
 
+/* ---- a bottleneck stage whose block outputs are not all written (round 6; resnet.py:144-162, 295-303, 330-333).  Between the fused
+ * boundaries above the 256-channel block output y_i is still written once and read once; in a stage of three bottlenecks
+ * (ResNet-50 / 101 / 152 layer1) most of that traffic can go:
+ *   (1) mv_conv1x1_dual_chain_fwd with y = NULL: block 0 stores only t1 of block 1 -- y0 is recomputed by (2);
+ *   (2) mv_conv1x1_chain_rc_fwd: block 1's boundary WITHOUT y0 in memory.  It reads t2 (block 1's conv2 output), t2_prev (block 0's)
+ *       and x0 (the stage input), recomputes  y0 = relu([t2_prev | x0] . wcat0^T + shift0)  exactly as (1) computed it (bf16-rounded),
+ *       then  y = relu(scale1 * (t2 . w3^T) + shift1 + y0)  and  t1 = relu(scaleN * (y . w1n^T) + shiftN)  as mv_conv1x1_chain_fwd.
+ *       wfrag: the three weight matrices in MFMA fragment order, 128 fragments of 1 KB -- per 32-channel chunk c of y: 8 of
+ *       wcat0[32c.., :] (k16-steps of [t2_prev | x0]), 4 of w3[32c.., :], 4 of w1n[:, 32c..] as (k-step s, 32-row tile a2) with the
+ *       reduction index in accumulator order (slot 8 fh + i <-> channel 32 c + 8 (2 s + i / 4) + 4 fh + i % 4); a fragment is
+ *       [lane = 32 fh + r][8 bf16] = W[row0 + r][k0 + 8 fh ..].  tab: shift0[K] scale1[K] shift1[K] scaleN[N2] shiftN[N2] fp32.
+ *       C = 64, K = 256, N2 = 64, M >= 8192;
+ *   (3) mv_conv1x1_chain_sub_fwd: the LAST block's boundary when the only other consumer of y is a stride-2 pointwise convolution
+ *       (the next stage's downsample branch): as mv_conv1x1_chain_fwd with N2 = 128, but y_sub = [N][H/2][W/2][K] holds only the
+ *       pixels with even (h, w) -- the strided consumer reads it with stride 1 (mv_conv1x1_dual_fwd, stride2 = 1). */
+int mv_conv1x1_chain_rc_supported(int64_t M, int C, int K, int N2, int dtype);
+int mv_conv1x1_chain_rc_fwd(const void* t2, const void* t2_prev, const void* x0, const void* wfrag, const float* tab, void* y,
+                            void* t1, int64_t M, int C, int K, int N2, int dtype, mv_stream_t stream);
+int mv_conv1x1_chain_sub_supported(int N, int H, int W, int C, int K, int N2, int dtype);
+int mv_conv1x1_chain_sub_fwd(const void* x, const void* w3, const float* scale3, const float* shift3, const void* residual,
+                             void* y_sub, const void* w1, const float* scale1, const float* shift1, void* t1, int N, int H, int W,
+                             int C, int K, int N2, int dtype, mv_stream_t stream);
+
 /* eqx.nn.Linear under vmap / Linear2d (vit.py:64,74; mlps.py:60-64; resnet.py:356;
  * extensions_2d.py:31-50):  y[M,N] = act(scale[n]*(x[M,K] . w[N,K]^T) + shift[n] + residual[M,N]).
  * in_dtype = out_dtype = MV_F32 with M <= 1024 (the classifier heads: resnet.py:356, vit.py:273, swin.py:771) runs on the

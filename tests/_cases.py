@@ -611,6 +611,133 @@ def dual_chain_case(M, seed=0):
     return run
 
 
+def _rc_fragments(wcat, w31, w1n):
+    """The fragment order mv_conv1x1_chain_rc_fwd documents (include/eqxvision_amd.h), written out independently of ops.py."""
+    K, N2 = wcat.shape[0], w1n.shape[0]
+    out = np.zeros((K // 32, 16, 64, 8), np.float32)
+    for c in range(K // 32):
+        for lane in range(64):
+            fh, r = lane // 32, lane % 32
+            for kk in range(8):
+                out[c, kk, lane] = wcat[32 * c + r, 16 * kk + 8 * fh:16 * kk + 8 * fh + 8]
+            for kk in range(4):
+                out[c, 8 + kk, lane] = w31[32 * c + r, 16 * kk + 8 * fh:16 * kk + 8 * fh + 8]
+            for s_ in range(2):
+                for a2 in range(N2 // 32):
+                    for i in range(8):
+                        out[c, 12 + 2 * s_ + a2, lane, i] = w1n[32 * a2 + r, 32 * c + 8 * (2 * s_ + i // 4) + 4 * fh + i % 4]
+    return out.reshape(-1)
+
+
+def chain_rc_case(M, seed=0):
+    """mv_conv1x1_chain_rc_fwd (the second bottleneck boundary of a stage whose first block output is NOT in memory: y0 recomputed
+    from [t2_0 | x0], then conv3 + BN + y0 + ReLU and the next conv1 + BN + ReLU; resnet.py:144-162, 295-303) vs the oracle, and
+    bit for bit vs the library's own pair mv_conv1x1_dual_chain_fwd (y0 written) -> mv_conv1x1_chain_fwd (y0 read back);
+    mv_conv1x1_dual_chain_fwd with y = NULL must produce the same t1 as with y."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        C, K, N2 = 64, 256, 64
+        f64 = np.float64
+        x0, t20, t21 = (bf(np.maximum(rng.standard_normal((M, C)), -0.5)) for _ in range(3))
+        w30 = bf(rng.standard_normal((K, C)) / np.sqrt(C))
+        wd = bf(rng.standard_normal((K, C)) / np.sqrt(C))
+        s30 = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        sd = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        sd[::7] *= -1.0
+        h0 = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        w31 = bf(rng.standard_normal((K, C)) / np.sqrt(C))
+        s31 = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        s31[::5] *= -1.0
+        h31 = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        w1a = bf(rng.standard_normal((N2, K)) / np.sqrt(K))            # conv1 of block 1 (block 0's launch computes it)
+        w1n = bf(rng.standard_normal((N2, K)) / np.sqrt(K))            # conv1 of block 2
+        s1a, s1n = (rng.uniform(0.5, 1.5, N2).astype(np.float32) for _ in range(2))
+        h1a, h1n = ((0.1 * rng.standard_normal(N2)).astype(np.float32) for _ in range(2))
+        lib = L.load()
+        if not (lib.mv_conv1x1_chain_rc_supported(M, C, K, N2, 1) and lib.mv_conv1x1_dual_chain_supported(M, C, C, K, N2, 1)):
+            return {"ok": False, "err": "mv_conv1x1_chain_rc_supported / dual_chain_supported says no"}
+        wcat = bf(np.concatenate([w30.astype(np.float32) * s30[:, None], wd.astype(np.float32) * sd[:, None]], axis=1))
+        y0ref = O.relu(np.concatenate([t20, x0], 1).astype(f64) @ wcat.astype(f64).T + h0)
+        y1ref = O.relu((t21.astype(f64) @ w31.astype(f64).T) * s31 + h31 + bf(y0ref))
+        t1ref = O.relu((bf(y1ref).astype(f64) @ w1n.astype(f64).T) * s1n + h1n)
+        d = {k: dev(v, "bf16") for k, v in dict(x0=x0, t20=t20, t21=t21, wcat=wcat, w31=w31, w1a=w1a, w1n=w1n,
+                                               wf=bf(_rc_fragments(wcat.astype(np.float32), w31.astype(np.float32), w1n.astype(np.float32)))).items()}
+        f = {k: dev(v, "fp32") for k, v in dict(h0=h0, s31=s31, h31=h31, s1a=s1a, h1a=h1a, s1n=s1n, h1n=h1n,
+                                               tab=np.concatenate([h0, s31, h31, s1n, h1n]).astype(np.float32)).items()}
+        y1 = torch.full((M, K), -7.0, dtype=torch.bfloat16, device="cuda")
+        t1 = torch.full((M, N2), -7.0, dtype=torch.bfloat16, device="cuda")
+        L.call("mv_conv1x1_chain_rc_fwd", d["t21"].data_ptr(), d["t20"].data_ptr(), d["x0"].data_ptr(), d["wf"].data_ptr(),
+               f["tab"].data_ptr(), y1.data_ptr(), t1.data_ptr(), M, C, K, N2, 1, _stream())
+        kern = L.last_kernel()
+        # the pair it replaces: y0 written by the dual chain, read back as the residual of the plain chain
+        y0 = torch.empty((M, K), dtype=torch.bfloat16, device="cuda")
+        ta, tb = (torch.full((M, N2), -7.0, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+        L.call("mv_conv1x1_dual_chain_fwd", d["t20"].data_ptr(), d["x0"].data_ptr(), d["wcat"].data_ptr(), None, f["h0"].data_ptr(),
+               y0.data_ptr(), d["w1a"].data_ptr(), f["s1a"].data_ptr(), f["h1a"].data_ptr(), ta.data_ptr(), M, C, C, K, N2, 1, _stream())
+        L.call("mv_conv1x1_dual_chain_fwd", d["t20"].data_ptr(), d["x0"].data_ptr(), d["wcat"].data_ptr(), None, f["h0"].data_ptr(),
+               None, d["w1a"].data_ptr(), f["s1a"].data_ptr(), f["h1a"].data_ptr(), tb.data_ptr(), M, C, C, K, N2, 1, _stream())
+        kern_noy = L.last_kernel()
+        y1p = torch.empty_like(y1)
+        t1p = torch.empty_like(t1)
+        L.call("mv_conv1x1_chain_fwd", d["t21"].data_ptr(), d["w31"].data_ptr(), f["s31"].data_ptr(), f["h31"].data_ptr(),
+               y0.data_ptr(), y1p.data_ptr(), d["w1n"].data_ptr(), f["s1n"].data_ptr(), f["h1n"].data_ptr(), t1p.data_ptr(),
+               M, C, K, N2, 1, _stream())
+        torch.cuda.synchronize()
+        a = _cmp(host(y1), y1ref, TOL_BF16)
+        b = _cmp(host(t1), t1ref, TOL_BF16)
+        same_y = bool(torch.equal(y1, y1p))
+        dt1 = float((t1.float() - t1p.float()).abs().max())
+        noy_same = bool(torch.equal(ta, tb))
+        return {"ok": a["ok"] and b["ok"] and same_y and dt1 <= b["lim"] and noy_same, "err": max(a["err"], b["err"]), "lim": a["lim"],
+                "y1_bit_identical_to_pair": same_y, "t1_vs_pair": dt1, "dual_chain_without_y_same_t1": noy_same, "kernel": kern,
+                "kernel_noy": kern_noy}
+    return run
+
+
+def chain_sub_case(N, H, W, seed=0):
+    """mv_conv1x1_chain_sub_fwd: as mv_conv1x1_chain_fwd (N2 = 128) but only the pixels with even (h, w) of y are written, compactly
+    -- against the full launch: y_sub must equal y[:, ::2, ::2] bit for bit, t1 must be identical, and nothing beyond y_sub's
+    extent may be touched."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        C, K, N2 = 64, 256, 128
+        M = N * H * W
+        x = bf(rng.standard_normal((M, C)))
+        w3 = bf(rng.standard_normal((K, C)) / np.sqrt(C))
+        s3 = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        h3 = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        r = bf(rng.standard_normal((M, K)))
+        w1 = bf(rng.standard_normal((N2, K)) / np.sqrt(K))
+        s1 = rng.uniform(0.5, 1.5, N2).astype(np.float32)
+        h1 = (0.1 * rng.standard_normal(N2)).astype(np.float32)
+        if not L.load().mv_conv1x1_chain_sub_supported(N, H, W, C, K, N2, 1):
+            return {"ok": False, "err": "mv_conv1x1_chain_sub_supported says no"}
+        d = {k: dev(v, "bf16") for k, v in dict(x=x, w3=w3, r=r, w1=w1).items()}
+        f = {k: dev(v, "fp32") for k, v in dict(s3=s3, h3=h3, s1=s1, h1=h1).items()}
+        y = torch.empty((N, H, W, K), dtype=torch.bfloat16, device="cuda")
+        t1 = torch.empty((M, N2), dtype=torch.bfloat16, device="cuda")
+        L.call("mv_conv1x1_chain_fwd", d["x"].data_ptr(), d["w3"].data_ptr(), f["s3"].data_ptr(), f["h3"].data_ptr(), d["r"].data_ptr(),
+               y.data_ptr(), d["w1"].data_ptr(), f["s1"].data_ptr(), f["h1"].data_ptr(), t1.data_ptr(), M, C, K, N2, 1, _stream())
+        nsub = N * (H // 2) * (W // 2) * K
+        ybuf = torch.full((nsub + 4096,), -7.0, dtype=torch.bfloat16, device="cuda")        # guard band behind the compact map
+        t1s = torch.full((M, N2), -7.0, dtype=torch.bfloat16, device="cuda")
+        L.call("mv_conv1x1_chain_sub_fwd", d["x"].data_ptr(), d["w3"].data_ptr(), f["s3"].data_ptr(), f["h3"].data_ptr(), d["r"].data_ptr(),
+               ybuf.data_ptr(), d["w1"].data_ptr(), f["s1"].data_ptr(), f["h1"].data_ptr(), t1s.data_ptr(), N, H, W, C, K, N2, 1, _stream())
+        kern = L.last_kernel()
+        torch.cuda.synchronize()
+        ysub = ybuf[:nsub].view(N, H // 2, W // 2, K)
+        same_y = bool(torch.equal(ysub, y[:, ::2, ::2].contiguous()))
+        same_t = bool(torch.equal(t1, t1s))
+        guard = bool((ybuf[nsub:] == -7.0).all())
+        yref = O.relu((x.astype(np.float64) @ w3.astype(np.float64).T) * s3 + h3 + r).reshape(N, H, W, K)[:, ::2, ::2]
+        a = _cmp(host(ysub), yref, TOL_BF16)
+        return {"ok": a["ok"] and same_y and same_t and guard, "err": a["err"], "lim": a["lim"], "y_sub_equals_strided_full": same_y,
+                "t1_identical": same_t, "guard_band_untouched": guard, "kernel": kern}
+    return run
+
+
 def dual_case(N, Ho, Wo, C1, C2, K, stride, act=1, seed=0, flags=(), splitk=False):
     """mv_conv1x1_dual_fwd: a dense pointwise layer on x and a strided pointwise layer on x2 accumulated in one GEMM
     (scales folded into the weight rows) vs the oracle's two convolutions with fp32 scales (resnet.py:144-162, 295-303)."""
@@ -2343,6 +2470,11 @@ def all_cases():
           ("bwd/patch_merge", patch_merge_bwd_case(2, 14, 96, seed=60)),
           ("chain/dual_56x56_B4", dual_chain_case(4 * 56 * 56, seed=6)),
           ("chain/dual_ragged_many", dual_chain_case(29 * 56 * 56 + 13, seed=7)),
+          ("chain/rc_56x56_B4", chain_rc_case(4 * 56 * 56, seed=21)),
+          ("chain/rc_ragged_many_tiles", chain_rc_case(31 * 56 * 56 + 19, seed=22)),
+          ("chain/rc_min_rows", chain_rc_case(8192, seed=23)),
+          ("chain/ysub2_56x56_B4", chain_sub_case(4, 56, 56, seed=24)),
+          ("chain/ysub2_ragged_B37_28x30", chain_sub_case(37, 28, 30, seed=25)),
           ("chain/n128_56x56_B4", chain_case(4 * 56 * 56, seed=4, N2=128)),
           ("chain/n128_ragged_many", chain_case(33 * 56 * 56 + 21, seed=5, N2=128)),
           ("chain/stream_28x28_B32", chain_case(32 * 28 * 28, seed=8, N2=128, C=128, K=512)),

@@ -1061,6 +1061,52 @@ def exported_factory_case(name, B=2, size=224, dtype="bf16"):
     return run
 
 
+def resnet50_rc_case(B=3, size=224):
+    """ResNet-50 with the round-6 layer-1 plan (first block output never written, second boundary recomputes it, third block output
+    written sub-sampled for the next stage's strided downsample branch; models/classification/resnet.py: _stage_rc) against the same
+    network with the plan switched off ("no_chain_rc", "no_chain_sub"): both within the bound of the oracle, the two within 2e-3 of
+    each other (the recompute changes no rounding point; the next conv1 sums its 256 products in another order), and the launch list
+    must show that the plan actually ran."""
+    def run():
+        import eqxvision_amd as eqv
+        from eqxvision_amd import _lib
+        sd = S.resnet_state(1)
+        net = _load(eqv.models.resnet50, sd)
+        x = S.synthetic_images(B, size, seed=0)
+        ref = TR.resnet_forward(sd, x).numpy()
+        rec = []
+        old = _lib.set_recording(rec)
+        try:
+            got = _run(net, x, "bf16").cpu().numpy()
+        finally:
+            _lib.set_recording(old)
+        names = [n for _, _, n in rec]
+        for f in ("no_chain_rc", "no_chain_sub"):
+            _lib.set_flag(f, 1)
+        try:
+            net2 = _load(eqv.models.resnet50, sd)            # fresh module: no cached decisions
+            rec2 = []
+            old = _lib.set_recording(rec2)
+            try:
+                plain = _run(net2, x, "bf16").cpu().numpy()
+            finally:
+                _lib.set_recording(old)
+        finally:
+            for f in ("no_chain_rc", "no_chain_sub"):
+                _lib.set_flag(f, 0)
+        names2 = [n for _, _, n in rec2]
+        info = _cmp(got, ref, 1e-2)
+        info2 = _cmp(plain, ref, 1e-2)
+        d = float(np.abs(got - plain).max())
+        sub_possible = bool(_lib.load().mv_conv1x1_dual_supported(B * (size // 8) ** 2, 128, 256, 512, 1))     # small batches: no dual kernel
+        ran = "mv_conv1x1_chain_rc_fwd" in names and ("mv_conv1x1_chain_sub_fwd" in names) == sub_possible
+        off = "mv_conv1x1_chain_rc_fwd" not in names2 and "mv_conv1x1_chain_sub_fwd" not in names2
+        info.update({"ok": bool(info["ok"] and info2["ok"] and d <= 2e-3 and ran and off), "err_plan_off": info2["err"], "plan_vs_off": d,
+                     "plan_ran": ran, "sub_sampled_output_possible": sub_possible, "plan_off_honoured": off, "launches": len(names), "launches_plan_off": len(names2)})
+        return info
+    return run
+
+
 def all_cases(full=True):
     c = [("model/resnet_tiny_bottleneck", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2)),
          ("model/resnet18_64px", resnet_case("basic", (2, 2, 2, 2), 64, 2)),
@@ -1121,6 +1167,8 @@ def all_cases(full=True):
               ("model/resnet50_B2", resnet_case("bottleneck", (3, 4, 6, 3), 224, 2, classes=1000, full_ref="torch")),
               ("model/resnet50_B3_chained_tail_head", resnet_case("bottleneck", (3, 4, 6, 3), 224, 3, classes=1000, full_ref="torch")),
               ("model/resnet50_B5_odd_200px", resnet_case("bottleneck", (3, 4, 6, 3), 200, 5, classes=1000, full_ref="torch")),
+              ("model/resnet50_B3_layer1_recompute_plan_vs_plan_off", resnet50_rc_case()),
+              ("model/resnet50_B16_layer1_recompute_plan_vs_plan_off", resnet50_rc_case(B=16)),
               ("model/resnet_2111_160px_B7_mixed_paths", resnet_case("bottleneck", (2, 1, 1, 1), 160, 7, classes=10, full_ref="torch")),
               ("model/resnet_1211_128px_B16_mixed_paths", resnet_case("bottleneck", (1, 2, 1, 1), 128, 16, classes=10, full_ref="torch")),
               ("model/resnext50_32x4d_B2", resnet_case("bottleneck", (3, 4, 6, 3), 224, 2, classes=1000, full_ref="torch",
