@@ -95,6 +95,7 @@ PROTOTYPES = {
     "mv_conv1x1_dual_fwd": [_vp] * 6 + [_i] * 11 + [_vp],
     "mv_conv1x1_chain_rc_supported": [_i64, _i, _i, _i, _i],
     "mv_conv1x1_chain_rc_fwd": [_vp] * 7 + [_i64, _i, _i, _i, _i, _vp],
+    "mv_conv1x1_chain_rc0_fwd": [_vp] * 5 + [_i64, _i, _i, _i, _i, _vp],
     "mv_conv1x1_chain_sub_supported": [_i] * 7,
     "mv_conv1x1_chain_sub_fwd": [_vp] * 10 + [_i] * 7 + [_vp],
     "mv_conv1x1_dual_chain_supported": [_i64, _i, _i, _i, _i, _i],

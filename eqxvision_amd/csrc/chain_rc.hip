@@ -37,9 +37,18 @@ struct ChainRcP {
     int M, tiles_m;
 };
 
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void chain_rc1_kernel(const ChainRcP p) {
-    constexpr int K = 256, N2 = 64, NFRAG = 128, PITCH = 144, TABN = 3 * K + 2 * N2, NT = WAVES * 64;
+// NPREV = 1: the kernel described above.  NPREV = 0 (round 6): the FIRST boundary of the stage when its output map is not wanted --
+//   t1[m] = relu( scaleN * (W1_1 . bf16(relu([s3 W3_0 | sd Wd] . [t2_0[m] | x0[m]] + shift0))) + shiftN )
+// i.e. mv_conv1x1_dual_chain_fwd without y, rebuilt in this file's style: 96 KB of fragments, nothing staged for a store, 138 VGPRs
+// -- so TWELVE waves per CU (three per SIMD) instead of six hide the LDS / HBM round trips of each other's tiles: 50.6 us per 128
+// images against 88.2 for chain1x1_dual with y = NULL (profiles/r06/resnet50_layer1_recompute_plan_ab.txt).
+// (NPREV = 1 with eight waves -- 32-channel store patches, 64-byte row pieces -- was built and is slower: 126 vs 118 us.  That
+//  kernel is not short of waves: per tile its 128 MFMAs, ~1 200 VALU instructions and ~250 KB of LDS reads -- 128 KB of fragments,
+//  96 KB of broadcast table reads -- each cost 30-50 us per launch, and they add up.)
+template <int NPREV, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void chain_rc_kernel(const ChainRcP p) {
+    constexpr int K = 256, N2 = 64, FPC = 12 + 4 * NPREV, NFRAG = 8 * FPC, PITCH = 144, TABN = (1 + 2 * NPREV) * K + 2 * N2,
+                  NT = WAVES * 64, NX = 8 + 4 * NPREV, TN = (1 + 2 * NPREV) * K;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wl = smem;
     float* tab = (float*)(smem + NFRAG * 1024);
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(WAVES * 64) void chain_rc1_kernel(const ChainRcP p)
     // materialised one address register per table read -- 96 of them -- and spilled them; scratch reloads count in vmcnt and put
     // `s_waitcnt vmcnt(0)` between the MFMAs.)
     unsigned wbase0 = (unsigned)(uintptr_t)(lds_cp)wl + lane * 16;             // fragments 0 .. 63
-    unsigned wbase1 = wbase0 + 65536u;                                            // fragments 64 .. 127
+    unsigned wbase1 = wbase0 + 65536u;                                            // fragments 64 .. 127 (NPREV = 1)
     unsigned tbase = (unsigned)(uintptr_t)(lds_cp)(const char*)tab + fh * 16;   // lane's 4 channels of a quad: + (32 c + 8 g) * 4
     asm volatile("" : "+v"(wbase0), "+v"(wbase1), "+v"(tbase));
     auto afrag = [&](int f) -> bf16x8 {
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(WAVES * 64) void chain_rc1_kernel(const ChainRcP p)
         return make_float4(v[0], v[1], v[2], v[3]);
     };
 
-    // xf[0..3] = t2_0, xf[4..7] = x0 (the two K-sources of block 0's GEMM, in Wcat's column order), xf[8..11] = t2_1
+    // xf[0..3] = t2_0, xf[4..7] = x0 (the two K-sources of block 0's GEMM, in Wcat's column order), xf[8..11] = t2_1 (NPREV = 1)
     auto load_x = [&](uint4* xf, int tile) {
         int m = tile * 32 + fr;
         m = m < p.M ? m : p.M - 1;                               // clamp: rows past the end are never stored
@@ -93,13 +102,15 @@ __global__ __launch_bounds__(WAVES * 64) void chain_rc1_kernel(const ChainRcP p)
         for (int kk = 0; kk < 4; ++kk) xf[kk] = *(const uint4*)(p.t2p + off + kk * 16);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) xf[4 + kk] = *(const uint4*)(p.x0 + off + kk * 16);
+        if constexpr (NPREV == 1) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) xf[8 + kk] = *(const uint4*)(p.t2 + off + kk * 16);
+            for (int kk = 0; kk < 4; ++kk) xf[8 + kk] = *(const uint4*)(p.t2 + off + kk * 16);
+        }
     };
 
     auto run_tile = [&](uint4* xf, int tile, int refill) {
         const int tile_u = __builtin_amdgcn_readfirstlane(tile);
-        const brsrc_t ry = make_brsrc(p.y + (long long)tile_u * 32 * K);
+        const brsrc_t ry = make_brsrc(p.y + (long long)tile_u * 32 * K, NPREV == 1);
         const brsrc_t rt = make_brsrc(p.t1 + (long long)tile_u * 32 * N2);
         const int rows_left = p.M - tile_u * 32;
         f32x16 acc2[2];
@@ -117,47 +128,58 @@ __global__ __launch_bounds__(WAVES * 64) void chain_rc1_kernel(const ChainRcP p)
                 for (int e = 0; e < 16; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {                 // the two independent accumulators interleaved
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * 16 + kk), __builtin_bit_cast(bf16x8, xf[kk]), a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * 16 + 8 + kk), __builtin_bit_cast(bf16x8, xf[8 + kk]), a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * FPC + kk), __builtin_bit_cast(bf16x8, xf[kk]), a0, 0, 0, 0);
+                    if constexpr (NPREV == 1)
+                        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * FPC + 8 + kk), __builtin_bit_cast(bf16x8, xf[8 + kk]), a1, 0, 0, 0);
                 }
 #pragma unroll
                 for (int kk = 4; kk < 8; ++kk)
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * 16 + kk), __builtin_bit_cast(bf16x8, xf[kk]), a0, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * FPC + kk), __builtin_bit_cast(bf16x8, xf[kk]), a0, 0, 0, 0);
                 if (c == 7) load_x(xf, refill);                  // unconditional (rows clamped): a branch here costs the vmcnt count
                 uint32_t pk[8];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 h0 = tabq(c * 32 + 8 * g), s1 = tabq(K + c * 32 + 8 * g), h1 = tabq(2 * K + c * 32 + 8 * g);
-                    const float h0v[4] = {h0.x, h0.y, h0.z, h0.w}, s1v[4] = {s1.x, s1.y, s1.z, s1.w}, h1v[4] = {h1.x, h1.y, h1.z, h1.w};
-                    float r[4], v[4];
+                    const float4 h0 = tabq(c * 32 + 8 * g);
+                    const float h0v[4] = {h0.x, h0.y, h0.z, h0.w};
+                    float r[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) r[j] = fmaxf(a0[4 * g + j] + h0v[j], 0.f);
                     const uint32_t w0 = pack_bf2(r[0], r[1]), w1 = pack_bf2(r[2], r[3]);      // y0 as block 0 would have stored it
-                    r[0] = __uint_as_float(w0 << 16); r[1] = __uint_as_float(w0 & 0xffff0000u);
-                    r[2] = __uint_as_float(w1 << 16); r[3] = __uint_as_float(w1 & 0xffff0000u);
+                    if constexpr (NPREV == 0) {
+                        pk[2 * g] = w0;
+                        pk[2 * g + 1] = w1;
+                    } else {
+                        const float4 s1 = tabq(K + c * 32 + 8 * g), h1 = tabq(2 * K + c * 32 + 8 * g);
+                        const float s1v[4] = {s1.x, s1.y, s1.z, s1.w}, h1v[4] = {h1.x, h1.y, h1.z, h1.w};
+                        float v[4];
+                        r[0] = __uint_as_float(w0 << 16); r[1] = __uint_as_float(w0 & 0xffff0000u);
+                        r[2] = __uint_as_float(w1 << 16); r[3] = __uint_as_float(w1 & 0xffff0000u);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(a1[4 * g + j], s1v[j], h1v[j]) + r[j], 0.f);
-                    pk[2 * g] = pack_bf2(v[0], v[1]);
-                    pk[2 * g + 1] = pack_bf2(v[2], v[3]);
-                    // row-major staging for the store: row = pixel fr, 4 consecutive channels = 8 bytes
-                    *(uint2*)(ep + fr * PITCH + (cc * 32 + 8 * g + 4 * fh) * 2) = make_uint2(pk[2 * g], pk[2 * g + 1]);
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(a1[4 * g + j], s1v[j], h1v[j]) + r[j], 0.f);
+                        pk[2 * g] = pack_bf2(v[0], v[1]);
+                        pk[2 * g + 1] = pack_bf2(v[2], v[3]);
+                        // row-major staging for the store: row = pixel fr, 4 consecutive channels = 8 bytes
+                        *(uint2*)(ep + fr * PITCH + (cc * 32 + 8 * g + 4 * fh) * 2) = make_uint2(pk[2 * g], pk[2 * g + 1]);
+                    }
                 }
                 // next block's conv1 on this chunk: the packed accumulator entries 8 s .. 8 s + 7 ARE the B operand of k-step s
                 const uint4 b0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), b1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
 #pragma unroll
                 for (int a2 = 0; a2 < 2; ++a2) {
-                    acc2[a2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * 16 + 12 + a2), __builtin_bit_cast(bf16x8, b0), acc2[a2], 0, 0, 0);
-                    acc2[a2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * 16 + 14 + a2), __builtin_bit_cast(bf16x8, b1), acc2[a2], 0, 0, 0);
+                    acc2[a2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * FPC + FPC - 4 + a2), __builtin_bit_cast(bf16x8, b0), acc2[a2], 0, 0, 0);
+                    acc2[a2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * FPC + FPC - 2 + a2), __builtin_bit_cast(bf16x8, b1), acc2[a2], 0, 0, 0);
                 }
             }
-            wave_lds_fence();
+            if constexpr (NPREV == 1) {
+                wave_lds_fence();
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int row = pass * 8 + (lane >> 3);
-                const uint4 u = *(const uint4*)(ep + row * PITCH + (lane & 7) * 16);
-                buf_store_u4(ry, row < rows_left ? (unsigned)(row * K + ps * 64 + (lane & 7) * 8) * 2u : BUF_OOB, u);
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int row = pass * 8 + (lane >> 3);
+                    const uint4 u = *(const uint4*)(ep + row * PITCH + (lane & 7) * 16);
+                    buf_store_u4(ry, row < rows_left ? (unsigned)(row * K + ps * 64 + (lane & 7) * 8) * 2u : BUF_OOB, u);
+                }
+                wave_lds_fence();
             }
-            wave_lds_fence();
         }
         // ---- conv1 of the next block: 32 pixels x 64 channels
 #pragma unroll
@@ -165,7 +187,7 @@ __global__ __launch_bounds__(WAVES * 64) void chain_rc1_kernel(const ChainRcP p)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ch = a2 * 32 + 8 * g + 4 * fh;
-                const float4 sn = tabq(3 * K + a2 * 32 + 8 * g), hn = tabq(3 * K + N2 + a2 * 32 + 8 * g);
+                const float4 sn = tabq(TN + a2 * 32 + 8 * g), hn = tabq(TN + N2 + a2 * 32 + 8 * g);
                 const float snv[4] = {sn.x, sn.y, sn.z, sn.w}, hnv[4] = {hn.x, hn.y, hn.z, hn.w};
                 float v[4];
 #pragma unroll
@@ -182,7 +204,7 @@ __global__ __launch_bounds__(WAVES * 64) void chain_rc1_kernel(const ChainRcP p)
         wave_lds_fence();
     };
 
-    uint4 xa[12], xb[12];                                       // two pixel tiles in flight per wave
+    uint4 xa[NX], xb[NX];                                       // two pixel tiles in flight per wave
     const int gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
     int tile = gw;
     if (tile < p.tiles_m) load_x(xa, tile);
@@ -198,26 +220,41 @@ int chain_rc_supported(long long M, int C, int K, int N2, int dtype) {
            !get_flag("no_chain_rc");
 }
 
+template <int NPREV, int WAVES>
+static int chain_rc_go(ChainRcP& p, hipStream_t st) {
+    constexpr int SMEM = 8 * (12 + 4 * NPREV) * 1024 + ((1 + 2 * NPREV) * 256 + 2 * 64) * 4 + WAVES * 32 * 144;
+    static_assert(SMEM <= 160 * 1024, "LDS");
+    int gx = 256;
+    const int need = (p.tiles_m + WAVES - 1) / WAVES;
+    if (gx > need) gx = need;
+    auto kern = chain_rc_kernel<NPREV, WAVES>;
+    static LdsAttrSite attr;
+    MV_HIP(attr.ensure((const void*)kern, SMEM));
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(WAVES * 64), SMEM, st, p);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
 int chain_rc_launch(const void* t2, const void* t2_prev, const void* x0, const void* wfrag, const float* tab, void* y, void* t1,
                     long long M, hipStream_t st) {
-    constexpr int WAVES = 6;
-    constexpr int SMEM = 128 * 1024 + (3 * 256 + 2 * 64) * 4 + WAVES * 32 * 144;
-    static_assert(SMEM <= 160 * 1024, "LDS");
     ChainRcP p;
     p.t2 = (const bf16_t*)t2; p.t2p = (const bf16_t*)t2_prev; p.x0 = (const bf16_t*)x0; p.wf = (const bf16_t*)wfrag; p.tab = tab;
     p.y = (bf16_t*)y; p.t1 = (bf16_t*)t1;
     p.M = (int)M;
     p.tiles_m = (int)((M + 31) / 32);
-    int gx = 256;
-    const int need = (p.tiles_m + WAVES - 1) / WAVES;
-    if (gx > need) gx = need;
-    auto kern = chain_rc1_kernel<WAVES>;
-    static LdsAttrSite attr;
-    MV_HIP(attr.ensure((const void*)kern, SMEM));
     set_kernel_name("chain_rc1_bf16_64x3_256_64");
-    hipLaunchKernelGGL(kern, dim3(gx), dim3(WAVES * 64), SMEM, st, p);
-    MV_LAUNCH_CHECK();
-    return MV_OK;
+    return chain_rc_go<1, 6>(p, st);
+}
+
+// the first boundary without its output map: t2 = the first block's conv2 output, x0 = the stage input
+int chain_rc0_launch(const void* t2, const void* x0, const void* wfrag, const float* tab, void* t1, long long M, hipStream_t st) {
+    ChainRcP p;
+    p.t2 = nullptr; p.t2p = (const bf16_t*)t2; p.x0 = (const bf16_t*)x0; p.wf = (const bf16_t*)wfrag; p.tab = tab;
+    p.y = nullptr; p.t1 = (bf16_t*)t1;
+    p.M = (int)M;
+    p.tiles_m = (int)((M + 31) / 32);
+    set_kernel_name("chain_rc0_bf16_64x2_256_64");
+    return chain_rc_go<0, 12>(p, st);      // 8 waves: the same on the model (87.1 vs 87.0 k img/s, tools/ab_flag.py chain_rc0_waves, round 6)
 }
 
 }  // namespace mv

@@ -505,6 +505,36 @@ def chain_rc_fragments(conv3_0, bn3_0, ds_conv, ds_bn, conv3_1, bn3_1, conv1n, b
     return hit
 
 
+def chain_rc0_fragments(conv3_0, bn3_0, ds_conv, ds_bn, conv1n, bn1n):
+    """mv_conv1x1_chain_rc0_fwd's operands: 12 fragments per 32-channel chunk (the 8 of [scale3 W3_0 | scale_d W_d], the 4 of the next
+    conv1 in accumulator order) and the table shift0 | scaleN | shiftN (cached on conv3_0)."""
+    cache = conv3_0._cache()
+    key = ("chain_rc0", _bn_id(bn3_0), id(ds_conv), _bn_id(ds_bn), id(conv1n), _bn_id(bn1n))
+    hit = cache.get(key)
+    if hit is None:
+        w30, h30 = _scaled_rows(conv3_0, bn3_0)
+        wd, hd = _scaled_rows(ds_conv, ds_bn)
+        wcat = np.concatenate([w30, wd], axis=1)
+        w1n = np.asarray(conv1n.weight, np.float32).reshape(conv1n.out_channels, -1)
+        sn, hn = _fold(conv1n, bn1n)
+        K, N2 = wcat.shape[0], w1n.shape[0]
+        frags = np.empty((K // 32, 12, 2, 32, 8), np.float32)
+        e8 = np.arange(8)
+        for c in range(K // 32):
+            rows = slice(32 * c, 32 * c + 32)
+            for fh in range(2):
+                for kk in range(8):
+                    frags[c, kk, fh] = wcat[rows][:, 16 * kk + 8 * fh + e8]
+                for s_ in range(2):
+                    cols = 32 * c + 16 * s_ + 4 * fh + np.array([0, 1, 2, 3, 8, 9, 10, 11])
+                    for a2 in range(N2 // 32):
+                        frags[c, 8 + 2 * s_ + a2, fh] = w1n[32 * a2:32 * a2 + 32][:, cols]
+        tab = np.concatenate([(h30 + hd).astype(np.float32), sn, hn]).astype(np.float32)
+        hit = (_dev(frags.reshape(-1), torch.bfloat16), _dev(tab, torch.float32), (ds_conv, conv1n))
+        cache[key] = hit
+    return hit
+
+
 def conv1x1_chain_rc(t2: Act, t2_prev: Act, x0: Act, conv3_0, bn3_0, ds_conv, ds_bn, conv3_1, bn3_1, conv1n, bn1n) -> Optional[Act]:
     """The boundary between the second and the third bottleneck of a stage whose FIRST block output was not written
     (ops.conv1x1_dual_chain(..., store_y=False)): y0 = relu(bn3_0(conv3_0(t2_prev)) + ds_bn(ds_conv(x0))) is recomputed from its
@@ -700,6 +730,11 @@ def conv1x1_dual_chain(x: Act, conv3, bn3, xin: Act, ds_conv, ds_bn, conv1n, bn1
         return None
     if not _lib.load().mv_conv1x1_dual_chain_supported(M, C1, C2, K, N2, DT[dt]):
         return None
+    if not store_y and not _lib.get_flag("no_chain_rc0") and _lib.load().mv_conv1x1_chain_rc_supported(M, C1, K, N2, DT[dt]):
+        wf, tab, _ = chain_rc0_fragments(conv3, bn3, ds_conv, ds_bn, conv1n, bn1n)      # the same function without its output map
+        t1 = empty((B, H, W, N2), torch.bfloat16)
+        _lib.call("mv_conv1x1_chain_rc0_fwd", _ptr(x.t), _ptr(xin.t), _ptr(wf), _ptr(tab), _ptr(t1), M, C1, K, N2, DT[dt], stream_ptr())
+        return Act(t1, "map", x.batched)
     wcat, shift = _dual_weights(conv3, bn3, ds_conv, ds_bn)
     w1, s1, h1 = prep_conv(conv1n, bn1n, "krsc", dt)
     y = empty((B, H, W, K), torch.bfloat16) if store_y else None

@@ -183,8 +183,13 @@ int mv_conv1x1_dual_chain_fwd(const void* x, const void* x2, const void* wcat, c
  *       C = 64, K = 256, N2 = 64, M >= 8192;
  *   (3) mv_conv1x1_chain_sub_fwd: the LAST block's boundary when the only other consumer of y is a stride-2 pointwise convolution
  *       (the next stage's downsample branch): as mv_conv1x1_chain_fwd with N2 = 128, but y_sub = [N][H/2][W/2][K] holds only the
- *       pixels with even (h, w) -- the strided consumer reads it with stride 1 (mv_conv1x1_dual_fwd, stride2 = 1). */
+ *       pixels with even (h, w) -- the strided consumer reads it with stride 1 (mv_conv1x1_dual_fwd, stride2 = 1).
+ *   (1') mv_conv1x1_chain_rc0_fwd: (1) rebuilt in (2)'s style -- t1 = relu(scaleN * (w1n . relu([t2 | x0] . wcat0^T + shift0)) + shiftN),
+ *       wfrag = 96 fragments (per chunk: the 8 of wcat0, the 4 of w1n, as in (2)), tab = shift0[K] scaleN[N2] shiftN[N2]; nothing is
+ *       staged for a store, so twelve waves per CU fit instead of six.  Same shapes as (2). */
 int mv_conv1x1_chain_rc_supported(int64_t M, int C, int K, int N2, int dtype);
+int mv_conv1x1_chain_rc0_fwd(const void* t2, const void* x0, const void* wfrag, const float* tab, void* t1, int64_t M, int C, int K,
+                             int N2, int dtype, mv_stream_t stream);
 int mv_conv1x1_chain_rc_fwd(const void* t2, const void* t2_prev, const void* x0, const void* wfrag, const float* tab, void* y,
                             void* t1, int64_t M, int C, int K, int N2, int dtype, mv_stream_t stream);
 int mv_conv1x1_chain_sub_supported(int N, int H, int W, int C, int K, int N2, int dtype);

@@ -678,6 +678,15 @@ def chain_rc_case(M, seed=0):
         L.call("mv_conv1x1_dual_chain_fwd", d["t20"].data_ptr(), d["x0"].data_ptr(), d["wcat"].data_ptr(), None, f["h0"].data_ptr(),
                None, d["w1a"].data_ptr(), f["s1a"].data_ptr(), f["h1a"].data_ptr(), tb.data_ptr(), M, C, C, K, N2, 1, _stream())
         kern_noy = L.last_kernel()
+        # (1'): the first boundary without its output map in this file's style -- against the dual chain's t1
+        wf0 = np.zeros((K // 32, 12, 64, 8), np.float32)
+        full = _rc_fragments(wcat.astype(np.float32), w31.astype(np.float32), w1a.astype(np.float32)).reshape(K // 32, 16, 64, 8)
+        wf0[:, :8], wf0[:, 8:] = full[:, :8], full[:, 12:]
+        wf0d, tab0 = dev(bf(wf0.reshape(-1)), "bf16"), dev(np.concatenate([h0, s1a, h1a]).astype(np.float32), "fp32")
+        tc = torch.full((M, N2), -7.0, dtype=torch.bfloat16, device="cuda")
+        L.call("mv_conv1x1_chain_rc0_fwd", d["t20"].data_ptr(), d["x0"].data_ptr(), wf0d.data_ptr(), tab0.data_ptr(), tc.data_ptr(),
+               M, C, K, N2, 1, _stream())
+        kern_rc0 = L.last_kernel()
         y1p = torch.empty_like(y1)
         t1p = torch.empty_like(t1)
         L.call("mv_conv1x1_chain_fwd", d["t21"].data_ptr(), d["w31"].data_ptr(), f["s31"].data_ptr(), f["h31"].data_ptr(),
@@ -689,9 +698,13 @@ def chain_rc_case(M, seed=0):
         same_y = bool(torch.equal(y1, y1p))
         dt1 = float((t1.float() - t1p.float()).abs().max())
         noy_same = bool(torch.equal(ta, tb))
-        return {"ok": a["ok"] and b["ok"] and same_y and dt1 <= b["lim"] and noy_same, "err": max(a["err"], b["err"]), "lim": a["lim"],
-                "y1_bit_identical_to_pair": same_y, "t1_vs_pair": dt1, "dual_chain_without_y_same_t1": noy_same, "kernel": kern,
-                "kernel_noy": kern_noy}
+        t1aref = O.relu((bf(y0ref).astype(f64) @ w1a.astype(f64).T) * s1a + h1a)
+        c0 = _cmp(host(tc), t1aref, TOL_BF16)
+        d0 = float((tc.float() - ta.float()).abs().max())
+        return {"ok": a["ok"] and b["ok"] and same_y and dt1 <= b["lim"] and noy_same and c0["ok"] and d0 <= c0["lim"],
+                "err": max(a["err"], b["err"], c0["err"]), "lim": a["lim"], "y1_bit_identical_to_pair": same_y, "t1_vs_pair": dt1,
+                "dual_chain_without_y_same_t1": noy_same, "rc0_t1_vs_dual_chain": d0, "kernel": kern, "kernel_noy": kern_noy,
+                "kernel_rc0": kern_rc0}
     return run
 
 
