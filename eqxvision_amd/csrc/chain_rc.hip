@@ -1,4 +1,4 @@
-// ResNet-50 layer 1, second bottleneck boundary, WITHOUT the first block's output in HBM (round 6).
+// ResNet-50 layer 1: the first two bottleneck boundaries WITHOUT the first block's output map in HBM (round 6).
 //
 // chain1x1.hip fuses the last convolution of bottleneck i with the first one of bottleneck i+1, so the 256-channel block output y_i
 // is written once and read once (as block i+1's identity).  Those two passes over y are still 40 % of layer 1's bytes -- and y_0 is
@@ -6,56 +6,74 @@
 // resnet.py:144-162, 295-303):
 //
 //   y0[m] = relu( [s3 W3_0 | sd Wd] . [t2_0[m] | x0[m]] + shift0 )                  (block 0: conv3 + downsample conv, one GEMM)
-//   y1[m] = relu( scale1 * (W3_1 . t2_1[m]) + shift1 + bf16(y0[m]) )                -> HBM (block 2's identity)
-//   t1[m] = relu( scaleN * (W1_2 . bf16(y1[m])) + shiftN )                          -> HBM (block 2's conv2 input)
+//   y1[m] = relu( (s1 W3_1) . t2_1[m] + shift1 + bf16(y0[m]) )                      -> HBM (block 2's identity)
+//   t1[m] = relu( (sN W1_2) . bf16(y1[m]) + shiftN )                                -> HBM (block 2's conv2 input)
 //
-// Block 0's kernel (chain1x1_dual with y = NULL) then stores only its t1, and this kernel reads t2_1, t2_0, x0 (3 x 64 channels)
-// instead of t2_1 + y0 (64 + 256): -205 MB written and -103 MB read per 128 images.  The price is matrix work the HBM-bound chain
-// kernels have to spare (their matrix pipes are 11-15 % busy): 16 MFMAs per 32 x 32 output chunk instead of 8.
+// NPREV = 0 (chain_rc0): block 0's boundary, storing only t1 = relu((sN W1_1) . bf16(y0) + shiftN).
+// NPREV = 1 (chain_rc1): block 1's boundary as above: reads t2_1, t2_0, x0 (3 x 64 channels) instead of t2_1 + y0 (64 + 256).
+// Together: -205 MB written and -103 MB read per 128 images.  The price is matrix work that these kernels have to spare.
 //
-// Structure: chain1x1's free-running waves over 32-pixel tiles (x fragments straight from HBM, two tiles in flight per wave, no block
-// barrier in steady state), with three differences that keep LDS for the 128 KB of weights:
+// These kernels are not HBM-bound -- block 0's boundary took the same 90 us with and without its 205 MB store -- they are bound by
+// what ONE WAVE has to issue per 32-pixel tile: the matrix, vector and LDS instructions of a tile add up (profiles/r06/
+// resnet50_layer1_recompute_plan_ab.txt).  So everything here is about a short instruction stream per tile:
 //   * weights sit in LDS in MFMA FRAGMENT ORDER (host: ops.chain_rc_fragments): fragment f = 64 lanes x 16 bytes, so the copy in is
-//     linear and every A operand is one conflict-free ds_read_b128 at a compile-time offset;
-//   * the whole chain stays in the ACCUMULATOR layout: y0's chunk, the residual add and y1's chunk are lane-local (a lane holds 4
-//     consecutive channels of one pixel per accumulator quad in all three), and y1's bf16 chunk IS the B operand of the next conv1
-//     once the host has permuted that layer's reduction index to the accumulator's channel order
-//     (k-slot 8 fh + i  <->  channel 8 (2 s + i / 4) + 4 fh + i % 4): no LDS transpose between the GEMMs;
-//   * LDS patches are bf16 and only serve the row-major stores (32 rows x 128 bytes): 4.5 KB per wave instead of 8.5.
+//     linear and every A operand is one conflict-free ds_read_b128 at a compile-time offset from an opaque base register;
+//   * the whole chain stays in the ACCUMULATOR layout (a lane holds 4 consecutive channels of one pixel per accumulator quad): a
+//     bf16 chunk of y IS the B operand of the next conv1 once the host has permuted that layer's reduction index to the
+//     accumulator's channel order (k-slot 8 fh + i  <->  channel 8 (2 s + i / 4) + 4 fh + i % 4): no LDS transpose between the GEMMs;
+//   * NO per-channel vector arithmetic: every BatchNorm scale is folded into the bf16 weight rows (as chain1x1's DUAL form always
+//     did), every shift enters through the matrix pipe as one more k-step -- A = [hi(shift) lo(shift) 0 ...] (two bf16 terms: 16
+//     mantissa bits), B = [1 1 0 ...], 4 bytes per lane out of a 256-byte LDS row instead of four 1 KB table reads and 16 adds --
+//     and the identity is the C operand that STARTS the next accumulation (y1's chain begins at bf16(y0), not at zero);
+//   * ReLU on PACKED bf16 pairs (v_pk_max_i16 against 0: bf16 is sign-magnitude, round(relu(x)) == relu(round(x))): half a
+//     conversion + half a max per value is all the vector work a y value costs (this file's first version: 7 instructions);
+//   * the weight fragments are fetched SIX matrix instructions ahead into a rolling register ring, and the two 32-channel chunks of
+//     a 64-channel slab run INTERLEAVED (independent accumulators sharing every B operand): a wave's consecutive MFMAs wait neither
+//     for an LDS round trip nor for each other;
+//   * LDS patches are bf16 and only serve the row-major stores (32 rows x 128 bytes): NPREV = 0 stages nothing for y (eight waves
+//     per CU), NPREV = 1 runs six (the 128 KB of fragments leave room for six patches; an eight-wave form with 32-channel patches
+//     was measured slower).
+// Measured alone, 128 images (profiles/r06/resnet50_layer1_recompute_plan_ab.txt): NPREV = 0 41-44 us (chain1x1_dual: 94 with y, 88
+// without), NPREV = 1 102-114 us (chain1x1: 109) -- of which ~35 us are its 205 MB of y stores, which do not overlap its 65 us of
+// instruction stream (debug-build ablations, same file); resnet50 B = 256: +2.5 ... 3.1 % with the plan on, same box.
 #include "mfma_common.h"
 
 namespace mv {
 
 struct ChainRcP {
-    const bf16_t* t2;      // [M][64] conv2 output of THIS block
-    const bf16_t* t2p;     // [M][64] conv2 output of the previous (first) block
+    const bf16_t* t2;      // NPREV = 1: [M][64] conv2 output of THIS block
+    const bf16_t* t2p;     // [M][64] conv2 output of the first block
     const bf16_t* x0;      // [M][64] the stage input (the first block's input)
-    const bf16_t* wf;      // 128 fragments of 1 KB (ops.chain_rc_fragments)
-    const float* tab;      // shift0[256] scale1[256] shift1[256] scaleN[64] shiftN[64]
-    bf16_t* y;             // [M][256]
+    const bf16_t* wf;      // 8 * (12 + 4 NPREV) fragments of 1 KB
+    const unsigned* sh;    // 8 (1 + NPREV) + 2 shift rows of 64 words: word r < 32 = [hi(shift[row r]) | lo << 16], words 32 .. 63 zero
+    bf16_t* y;             // NPREV = 1: [M][256]
     bf16_t* t1;            // [M][64]
     int M, tiles_m;
+    int dbg;               // ablations, debug build only ("rc_dbg", results wrong): 1 = y stores dropped, 2 = every tile reads the same 32 rows, 4 = t1 stores dropped
 };
 
-// NPREV = 1: the kernel described above.  NPREV = 0 (round 6): the FIRST boundary of the stage when its output map is not wanted --
-//   t1[m] = relu( scaleN * (W1_1 . bf16(relu([s3 W3_0 | sd Wd] . [t2_0[m] | x0[m]] + shift0))) + shiftN )
-// i.e. mv_conv1x1_dual_chain_fwd without y, rebuilt in this file's style: 96 KB of fragments, nothing staged for a store, 138 VGPRs
-// -- so TWELVE waves per CU (three per SIMD) instead of six hide the LDS / HBM round trips of each other's tiles: 50.6 us per 128
-// images against 88.2 for chain1x1_dual with y = NULL (profiles/r06/resnet50_layer1_recompute_plan_ab.txt).
-// (NPREV = 1 with eight waves -- 32-channel store patches, 64-byte row pieces -- was built and is slower: 126 vs 118 us.  That
-//  kernel is not short of waves: per tile its 128 MFMAs, ~1 200 VALU instructions and ~250 KB of LDS reads -- 128 KB of fragments,
-//  96 KB of broadcast table reads -- each cost 30-50 us per launch, and they add up.)
-template <int NPREV, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void chain_rc_kernel(const ChainRcP p) {
-    constexpr int K = 256, N2 = 64, FPC = 12 + 4 * NPREV, NFRAG = 8 * FPC, PITCH = 144, TABN = (1 + 2 * NPREV) * K + 2 * N2,
-                  NT = WAVES * 64, NX = 8 + 4 * NPREV, TN = (1 + 2 * NPREV) * K;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* wl = smem;
-    float* tab = (float*)(smem + NFRAG * 1024);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    char* ep = (char*)(tab + TABN) + wave * (32 * PITCH);
+// the bf16 pair (relu(a), relu(b)): ONE v_cvt_pk_bf16_f32 + ONE v_pk_max_i16 (bf16 is sign-magnitude: max against 0 as int16 is ReLU).
+// The empty asm keeps the packed word a value of its own: without it hipcc turned conversion + vector max into two single conversions
+// and a v_perm_b32 per pair.  (Not an asm instruction on purpose: the hazard recogniser does not see into inline asm, and these
+// values come straight out of the matrix pipe.)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t relu_pack_bf2(float a, float b) {
+    uint32_t w = pack_bf2(a, b);
+    asm volatile("" : "+v"(w));
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), z));
+}
 
-    {   // weights -> LDS: a straight copy, several loads in flight per thread
+template <int NPREV, int WAVES, int RD>
+__global__ __launch_bounds__(WAVES * 64) void chain_rc_kernel(const ChainRcP p) {
+    constexpr int K = 256, N2 = 64, FPC = 12 + 4 * NPREV, NFRAG = 8 * FPC, PITCH = 144, NSH = 8 * (1 + NPREV) + 2, NT = WAVES * 64,
+                  NX = 8 + 4 * NPREV;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wl = smem;                                             // NFRAG KB of fragments, then NSH shift rows of 256 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* ep = smem + NFRAG * 1024 + NSH * 256 + wave * (32 * PITCH);
+
+    {   // fragments + shift rows -> LDS: straight copies, several loads in flight per thread
         constexpr int N16 = NFRAG * 64, U = 4;
         for (int base = 0; base < N16; base += U * NT) {
             uint4 v[U];
@@ -70,33 +88,39 @@ __global__ __launch_bounds__(WAVES * 64) void chain_rc_kernel(const ChainRcP p) 
                 if (i < N16) ((uint4*)wl)[i] = v[u];
             }
         }
-        for (int i = tid; i < TABN; i += NT) tab[i] = p.tab[i];
+        for (int i = tid; i < NSH * 64; i += NT) ((unsigned*)(wl + NFRAG * 1024))[i] = p.sh[i];
     }
     __syncthreads();
 
     const int fr = lane & 31, fh = lane >> 5;
     typedef __attribute__((address_space(3))) const char* lds_cp;
     // LDS bases as OPAQUE 32-bit addresses: every read below is then base + compile-time immediate.  (Left to itself hipcc
-    // materialised one address register per table read -- 96 of them -- and spilled them; scratch reloads count in vmcnt and put
+    // materialised one address register per table read and spilled them; scratch reloads count in vmcnt and put
     // `s_waitcnt vmcnt(0)` between the MFMAs.)
     unsigned wbase0 = (unsigned)(uintptr_t)(lds_cp)wl + lane * 16;             // fragments 0 .. 63
     unsigned wbase1 = wbase0 + 65536u;                                            // fragments 64 .. 127 (NPREV = 1)
-    unsigned tbase = (unsigned)(uintptr_t)(lds_cp)(const char*)tab + fh * 16;   // lane's 4 channels of a quad: + (32 c + 8 g) * 4
-    asm volatile("" : "+v"(wbase0), "+v"(wbase1), "+v"(tbase));
+    unsigned sbase = (unsigned)(uintptr_t)(lds_cp)wl + NFRAG * 1024 + lane * 4;  // shift row r: + 256 r
+    asm volatile("" : "+v"(wbase0), "+v"(wbase1), "+v"(sbase));
     auto afrag = [&](int f) -> bf16x8 {
         const lds_cp b = (lds_cp)(uintptr_t)(f < 64 ? wbase0 : wbase1);
         return __builtin_bit_cast(bf16x8, *(const __attribute__((address_space(3))) u32x4_t*)(b + (f & 63) * 1024));
     };
-    typedef float f32x4v __attribute__((ext_vector_type(4)));
-    auto tabq = [&](int word) -> float4 {                        // 4 floats at table word `word` + 4 fh
-        const f32x4v v = *(const __attribute__((address_space(3))) f32x4v*)((lds_cp)(uintptr_t)tbase + word * 4);
-        return make_float4(v[0], v[1], v[2], v[3]);
+    // the A operand of a shift step: lane r < 32 holds [hi(shift[row r]), lo(shift[row r]), 0 x 6], lanes 32 .. 63 zeros
+    auto sfrag = [&](int row) -> bf16x8 {
+        u32x4_t v;
+        v[0] = *(const __attribute__((address_space(3))) unsigned*)((lds_cp)(uintptr_t)sbase + row * 256);
+        v[1] = 0u; v[2] = 0u; v[3] = 0u;
+        return __builtin_bit_cast(bf16x8, v);
     };
+    u32x4_t onesv;                                               // its B operand: k-slots 0 and 1 (lanes fh = 0) are 1.0
+    onesv[0] = fh ? 0u : 0x3f803f80u; onesv[1] = 0u; onesv[2] = 0u; onesv[3] = 0u;
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, onesv);
 
     // xf[0..3] = t2_0, xf[4..7] = x0 (the two K-sources of block 0's GEMM, in Wcat's column order), xf[8..11] = t2_1 (NPREV = 1)
     auto load_x = [&](uint4* xf, int tile) {
         int m = tile * 32 + fr;
         m = m < p.M ? m : p.M - 1;                               // clamp: rows past the end are never stored
+        m = (p.dbg & 2) ? fr : m;
         const long long off = (long long)m * 64 + fh * 8;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) xf[kk] = *(const uint4*)(p.t2p + off + kk * 16);
@@ -115,60 +139,98 @@ __global__ __launch_bounds__(WAVES * 64) void chain_rc_kernel(const ChainRcP p) 
         const int rows_left = p.M - tile_u * 32;
         f32x16 acc2[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a2 = 0; a2 < 2; ++a2) {                         // the next conv1's accumulators start at its shift
+            f32x16 z;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc2[a][e] = 0.f;
+            for (int e = 0; e < 16; ++e) z[e] = 0.f;
+            acc2[a2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sfrag(NSH - 2 + a2), ones, z, 0, 0, 0);
+        }
+        // The tile's weight fragments are consumed in ONE fixed order (step i -> fragment fid(i)) and fetched RD steps ahead into a
+        // rolling register ring; `sched_barrier` pins [take fragment, refill slot, MFMA].  Left to hipcc every fragment was read
+        // right before its MFMA: one LDS round trip (~100 cycles) per 32-cycle matrix instruction, ~15k cycles per tile -- the
+        // kernel's floor with all memory traffic removed was 77 us (rc_dbg = 7) for 30 us of matrix work.  Per 64-channel slab the
+        // two 32-channel chunks' accumulation chains are INTERLEAVED (they are independent and share every B operand), so a wave's
+        // consecutive matrix instructions never wait on each other either.
+        constexpr int SL = 16 + 8 * NPREV + 8, NSTEP = 4 * SL;
+        auto fid = [&](int i) -> int {
+            const int ps = i / SL, r = i - ps * SL;
+            if (r < 16) return (2 * ps + (r & 1)) * FPC + (r >> 1);
+            if (r < 16 + 8 * NPREV) return (2 * ps + ((r - 16) & 1)) * FPC + 8 + ((r - 16) >> 1);
+            const int q = r - 16 - 8 * NPREV;
+            return (2 * ps + (q >> 2)) * FPC + FPC - 4 + (q & 3);
+        };
+        bf16x8 ring[RD > 0 ? RD : 1];                            // RD = 0: no ring (hipcc places the reads), for the register-tight form
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {                         // 64-channel slab of y1 = two 32-channel chunks
+        for (int d = 0; d < RD; ++d) ring[d] = afrag(fid(d));
+        auto take = [&](int i) -> bf16x8 {                       // fragment of step i; its slot is refilled for step i + RD
+            if constexpr (RD == 0) return afrag(fid(i));
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 a = ring[i % (RD > 0 ? RD : 1)];
+            if (i + RD < NSTEP) ring[i % (RD > 0 ? RD : 1)] = afrag(fid(i + RD));
+            return a;
+        };
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int s0 = ps * SL;
+            f32x16 a0[2];
+            uint32_t pk[2][8];
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
-                const int c = ps * 2 + cc;
-                f32x16 a0, a1;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+                for (int e = 0; e < 16; ++e) a0[cc][e] = 0.f;
+                a0[cc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sfrag(ps * 2 + cc), ones, a0[cc], 0, 0, 0);
+            }
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {                 // the two independent accumulators interleaved
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * FPC + kk), __builtin_bit_cast(bf16x8, xf[kk]), a0, 0, 0, 0);
-                    if constexpr (NPREV == 1)
-                        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * FPC + 8 + kk), __builtin_bit_cast(bf16x8, xf[8 + kk]), a1, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) {
+                const bf16x8 a = take(s0 + r);
+                a0[r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, xf[r >> 1]), a0[r & 1], 0, 0, 0);
+                if constexpr (RD > 0) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {                    // y0 = bf16(relu(.)), as block 0 would have stored it
+                    pk[cc][2 * g] = relu_pack_bf2(a0[cc][4 * g], a0[cc][4 * g + 1]);
+                    pk[cc][2 * g + 1] = relu_pack_bf2(a0[cc][4 * g + 2], a0[cc][4 * g + 3]);
                 }
+            if constexpr (NPREV == 1) {
+                f32x16 a1[2];                                    // y1's accumulation STARTS at y0 (the identity), then shift1, then W3_1 . t2_1
 #pragma unroll
-                for (int kk = 4; kk < 8; ++kk)
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * FPC + kk), __builtin_bit_cast(bf16x8, xf[kk]), a0, 0, 0, 0);
-                if (c == 7) load_x(xf, refill);                  // unconditional (rows clamped): a branch here costs the vmcnt count
-                uint32_t pk[8];
+                for (int cc = 0; cc < 2; ++cc) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 h0 = tabq(c * 32 + 8 * g);
-                    const float h0v[4] = {h0.x, h0.y, h0.z, h0.w};
-                    float r[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) r[j] = fmaxf(a0[4 * g + j] + h0v[j], 0.f);
-                    const uint32_t w0 = pack_bf2(r[0], r[1]), w1 = pack_bf2(r[2], r[3]);      // y0 as block 0 would have stored it
-                    if constexpr (NPREV == 0) {
-                        pk[2 * g] = w0;
-                        pk[2 * g + 1] = w1;
-                    } else {
-                        const float4 s1 = tabq(K + c * 32 + 8 * g), h1 = tabq(2 * K + c * 32 + 8 * g);
-                        const float s1v[4] = {s1.x, s1.y, s1.z, s1.w}, h1v[4] = {h1.x, h1.y, h1.z, h1.w};
-                        float v[4];
-                        r[0] = __uint_as_float(w0 << 16); r[1] = __uint_as_float(w0 & 0xffff0000u);
-                        r[2] = __uint_as_float(w1 << 16); r[3] = __uint_as_float(w1 & 0xffff0000u);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(a1[4 * g + j], s1v[j], h1v[j]) + r[j], 0.f);
-                        pk[2 * g] = pack_bf2(v[0], v[1]);
-                        pk[2 * g + 1] = pack_bf2(v[2], v[3]);
-                        // row-major staging for the store: row = pixel fr, 4 consecutive channels = 8 bytes
-                        *(uint2*)(ep + fr * PITCH + (cc * 32 + 8 * g + 4 * fh) * 2) = make_uint2(pk[2 * g], pk[2 * g + 1]);
+                    for (int g = 0; g < 4; ++g) {
+                        a1[cc][4 * g] = __uint_as_float(pk[cc][2 * g] << 16);
+                        a1[cc][4 * g + 1] = __uint_as_float(pk[cc][2 * g] & 0xffff0000u);
+                        a1[cc][4 * g + 2] = __uint_as_float(pk[cc][2 * g + 1] << 16);
+                        a1[cc][4 * g + 3] = __uint_as_float(pk[cc][2 * g + 1] & 0xffff0000u);
                     }
+                    a1[cc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sfrag(8 + ps * 2 + cc), ones, a1[cc], 0, 0, 0);
                 }
-                // next block's conv1 on this chunk: the packed accumulator entries 8 s .. 8 s + 7 ARE the B operand of k-step s
-                const uint4 b0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), b1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
 #pragma unroll
-                for (int a2 = 0; a2 < 2; ++a2) {
-                    acc2[a2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * FPC + FPC - 4 + a2), __builtin_bit_cast(bf16x8, b0), acc2[a2], 0, 0, 0);
-                    acc2[a2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(c * FPC + FPC - 2 + a2), __builtin_bit_cast(bf16x8, b1), acc2[a2], 0, 0, 0);
+                for (int r = 0; r < 8; ++r) {
+                    const bf16x8 a = take(s0 + 16 + r);
+                    a1[r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, xf[8 + (r >> 1)]), a1[r & 1], 0, 0, 0);
+                    if constexpr (RD > 0) __builtin_amdgcn_sched_barrier(0);
                 }
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        pk[cc][2 * g] = relu_pack_bf2(a1[cc][4 * g], a1[cc][4 * g + 1]);
+                        pk[cc][2 * g + 1] = relu_pack_bf2(a1[cc][4 * g + 2], a1[cc][4 * g + 3]);
+                        // row-major staging for the store: row = pixel fr, 4 consecutive channels = 8 bytes
+                        *(uint2*)(ep + fr * PITCH + (cc * 32 + 8 * g + 4 * fh) * 2) = make_uint2(pk[cc][2 * g], pk[cc][2 * g + 1]);
+                    }
+            }
+            if (ps == 3) load_x(xf, refill);                     // unconditional (rows clamped): a branch here costs the vmcnt count
+            // next block's conv1 on this slab: the packed accumulator entries 8 s .. 8 s + 7 of a chunk ARE the B operand of k-step s
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bf16x8 a = take(s0 + 16 + 8 * NPREV + q);
+                const int cc = q >> 2, sstep = (q >> 1) & 1;
+                const uint4 b = make_uint4(pk[cc][4 * sstep], pk[cc][4 * sstep + 1], pk[cc][4 * sstep + 2], pk[cc][4 * sstep + 3]);
+                acc2[q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b), acc2[q & 1], 0, 0, 0);
+                if constexpr (RD > 0) __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (NPREV == 1) {
                 wave_lds_fence();
@@ -176,7 +238,7 @@ __global__ __launch_bounds__(WAVES * 64) void chain_rc_kernel(const ChainRcP p) 
                 for (int pass = 0; pass < 4; ++pass) {
                     const int row = pass * 8 + (lane >> 3);
                     const uint4 u = *(const uint4*)(ep + row * PITCH + (lane & 7) * 16);
-                    buf_store_u4(ry, row < rows_left ? (unsigned)(row * K + ps * 64 + (lane & 7) * 8) * 2u : BUF_OOB, u);
+                    buf_store_u4(ry, row < rows_left && !(p.dbg & 1) ? (unsigned)(row * K + ps * 64 + (lane & 7) * 8) * 2u : BUF_OOB, u);
                 }
                 wave_lds_fence();
             }
@@ -185,21 +247,15 @@ __global__ __launch_bounds__(WAVES * 64) void chain_rc_kernel(const ChainRcP p) 
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch = a2 * 32 + 8 * g + 4 * fh;
-                const float4 sn = tabq(TN + a2 * 32 + 8 * g), hn = tabq(TN + N2 + a2 * 32 + 8 * g);
-                const float snv[4] = {sn.x, sn.y, sn.z, sn.w}, hnv[4] = {hn.x, hn.y, hn.z, hn.w};
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(acc2[a2][4 * g + j], snv[j], hnv[j]), 0.f);
-                *(uint2*)(ep + fr * PITCH + ch * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            }
+            for (int g = 0; g < 4; ++g)
+                *(uint2*)(ep + fr * PITCH + (a2 * 32 + 8 * g + 4 * fh) * 2) =
+                    make_uint2(relu_pack_bf2(acc2[a2][4 * g], acc2[a2][4 * g + 1]), relu_pack_bf2(acc2[a2][4 * g + 2], acc2[a2][4 * g + 3]));
         wave_lds_fence();
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             const int row = pass * 8 + (lane >> 3);
             const uint4 u = *(const uint4*)(ep + row * PITCH + (lane & 7) * 16);
-            buf_store_u4(rt, row < rows_left ? (unsigned)(row * N2 + (lane & 7) * 8) * 2u : BUF_OOB, u);
+            buf_store_u4(rt, row < rows_left && !(p.dbg & 4) ? (unsigned)(row * N2 + (lane & 7) * 8) * 2u : BUF_OOB, u);
         }
         wave_lds_fence();
     };
@@ -207,12 +263,16 @@ __global__ __launch_bounds__(WAVES * 64) void chain_rc_kernel(const ChainRcP p) 
     uint4 xa[NX], xb[NX];                                       // two pixel tiles in flight per wave
     const int gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
     int tile = gw;
-    if (tile < p.tiles_m) load_x(xa, tile);
-    if (tile + nw < p.tiles_m) load_x(xb, tile + nw);
-    for (; tile < p.tiles_m; tile += 2 * nw) {
+    // The loop body is ALWAYS both tiles (a wave's odd last tile runs behind the loop): with `if (second tile exists)` inside, the
+    // two paths into the loop head disagree about what is in flight and hipcc's wait for the first tile's rows becomes
+    // vmcnt(11) .. vmcnt(0) -- a drain of the second tile's stores and of its prefetch at the start of every pair.
+    load_x(xa, tile);                                           // (rows clamped: harmless for a wave without tiles)
+    load_x(xb, tile + nw);
+    for (; tile + nw < p.tiles_m; tile += 2 * nw) {
         run_tile(xa, tile, tile + 2 * nw);
-        if (tile + nw < p.tiles_m) run_tile(xb, tile + nw, tile + 3 * nw);
+        run_tile(xb, tile + nw, tile + 3 * nw);
     }
+    if (tile < p.tiles_m) run_tile(xa, tile, tile);
 }
 
 int chain_rc_supported(long long M, int C, int K, int N2, int dtype) {
@@ -220,14 +280,14 @@ int chain_rc_supported(long long M, int C, int K, int N2, int dtype) {
            !get_flag("no_chain_rc");
 }
 
-template <int NPREV, int WAVES>
+template <int NPREV, int WAVES, int RD>
 static int chain_rc_go(ChainRcP& p, hipStream_t st) {
-    constexpr int SMEM = 8 * (12 + 4 * NPREV) * 1024 + ((1 + 2 * NPREV) * 256 + 2 * 64) * 4 + WAVES * 32 * 144;
+    constexpr int SMEM = 8 * (12 + 4 * NPREV) * 1024 + (8 * (1 + NPREV) + 2) * 256 + WAVES * 32 * 144;
     static_assert(SMEM <= 160 * 1024, "LDS");
     int gx = 256;
     const int need = (p.tiles_m + WAVES - 1) / WAVES;
     if (gx > need) gx = need;
-    auto kern = chain_rc_kernel<NPREV, WAVES>;
+    auto kern = chain_rc_kernel<NPREV, WAVES, RD>;
     static LdsAttrSite attr;
     MV_HIP(attr.ensure((const void*)kern, SMEM));
     hipLaunchKernelGGL(kern, dim3(gx), dim3(WAVES * 64), SMEM, st, p);
@@ -235,26 +295,36 @@ static int chain_rc_go(ChainRcP& p, hipStream_t st) {
     return MV_OK;
 }
 
-int chain_rc_launch(const void* t2, const void* t2_prev, const void* x0, const void* wfrag, const float* tab, void* y, void* t1,
+int chain_rc_launch(const void* t2, const void* t2_prev, const void* x0, const void* wfrag, const void* shifts, void* y, void* t1,
                     long long M, hipStream_t st) {
     ChainRcP p;
-    p.t2 = (const bf16_t*)t2; p.t2p = (const bf16_t*)t2_prev; p.x0 = (const bf16_t*)x0; p.wf = (const bf16_t*)wfrag; p.tab = tab;
+    p.t2 = (const bf16_t*)t2; p.t2p = (const bf16_t*)t2_prev; p.x0 = (const bf16_t*)x0; p.wf = (const bf16_t*)wfrag;
+    p.sh = (const unsigned*)shifts;
     p.y = (bf16_t*)y; p.t1 = (bf16_t*)t1;
     p.M = (int)M;
     p.tiles_m = (int)((M + 31) / 32);
+    p.dbg = 0;
+#ifdef MV_I8_PROF
+    p.dbg = get_flag("rc_dbg");
+#endif
     set_kernel_name("chain_rc1_bf16_64x3_256_64");
-    return chain_rc_go<1, 6>(p, st);
+    return chain_rc_go<1, 6, 6>(p, st);
 }
 
 // the first boundary without its output map: t2 = the first block's conv2 output, x0 = the stage input
-int chain_rc0_launch(const void* t2, const void* x0, const void* wfrag, const float* tab, void* t1, long long M, hipStream_t st) {
+int chain_rc0_launch(const void* t2, const void* x0, const void* wfrag, const void* shifts, void* t1, long long M, hipStream_t st) {
     ChainRcP p;
-    p.t2 = nullptr; p.t2p = (const bf16_t*)t2; p.x0 = (const bf16_t*)x0; p.wf = (const bf16_t*)wfrag; p.tab = tab;
+    p.t2 = nullptr; p.t2p = (const bf16_t*)t2; p.x0 = (const bf16_t*)x0; p.wf = (const bf16_t*)wfrag; p.sh = (const unsigned*)shifts;
     p.y = nullptr; p.t1 = (bf16_t*)t1;
     p.M = (int)M;
     p.tiles_m = (int)((M + 31) / 32);
+    p.dbg = 0;
+#ifdef MV_I8_PROF
+    p.dbg = get_flag("rc_dbg");
+#endif
     set_kernel_name("chain_rc0_bf16_64x2_256_64");
-    return chain_rc_go<0, 12>(p, st);      // 8 waves: the same on the model (87.1 vs 87.0 k img/s, tools/ab_flag.py chain_rc0_waves, round 6)
+    // eight waves with the fragment ring; twelve (three per SIMD: 168 VGPRs, no room for a ring) measured 45.8 vs 41.2 us
+    return chain_rc_go<0, 8, 6>(p, st);
 }
 
 }  // namespace mv

@@ -1350,9 +1350,9 @@ int mv_conv1x1_chain_rc_supported(int64_t M, int C, int K, int N2, int dtype) {
     return !get_flag("force_generic") && !get_flag("no_stream") && chain_rc_supported(M, C, K, N2, dtype);
 }
 
-int mv_conv1x1_chain_rc_fwd(const void* t2, const void* t2_prev, const void* x0, const void* wfrag, const float* tab, void* y,
+int mv_conv1x1_chain_rc_fwd(const void* t2, const void* t2_prev, const void* x0, const void* wfrag, const void* shifts, void* y,
                             void* t1, int64_t M, int C, int K, int N2, int dtype, mv_stream_t stream) {
-    MV_CHECK_ARG(t2 && t2_prev && x0 && wfrag && tab && y && t1, "conv1x1_chain_rc: NULL pointer");
+    MV_CHECK_ARG(t2 && t2_prev && x0 && wfrag && shifts && y && t1, "conv1x1_chain_rc: NULL pointer");
     if (!mv_conv1x1_chain_rc_supported(M, C, K, N2, dtype)) {
         set_error("conv1x1_chain_rc: unsupported shape M=%lld C=%d K=%d N2=%d (ask mv_conv1x1_chain_rc_supported first)", (long long)M, C,
                   K, N2);
@@ -1360,19 +1360,19 @@ int mv_conv1x1_chain_rc_fwd(const void* t2, const void* t2_prev, const void* x0,
     }
     MV_CHECK_ARG(y != t2 && y != t2_prev && y != x0 && t1 != y && t1 != t2 && t1 != t2_prev && t1 != x0,
                  "conv1x1_chain_rc: outputs must not alias inputs");
-    return chain_rc_launch(t2, t2_prev, x0, wfrag, tab, y, t1, M, (hipStream_t)stream);
+    return chain_rc_launch(t2, t2_prev, x0, wfrag, shifts, y, t1, M, (hipStream_t)stream);
 }
 
-int mv_conv1x1_chain_rc0_fwd(const void* t2, const void* x0, const void* wfrag, const float* tab, void* t1, int64_t M, int C, int K,
+int mv_conv1x1_chain_rc0_fwd(const void* t2, const void* x0, const void* wfrag, const void* shifts, void* t1, int64_t M, int C, int K,
                              int N2, int dtype, mv_stream_t stream) {
-    MV_CHECK_ARG(t2 && x0 && wfrag && tab && t1, "conv1x1_chain_rc0: NULL pointer");
+    MV_CHECK_ARG(t2 && x0 && wfrag && shifts && t1, "conv1x1_chain_rc0: NULL pointer");
     if (!mv_conv1x1_chain_rc_supported(M, C, K, N2, dtype)) {
         set_error("conv1x1_chain_rc0: unsupported shape M=%lld C=%d K=%d N2=%d (ask mv_conv1x1_chain_rc_supported first)", (long long)M, C,
                   K, N2);
         return MV_E_UNSUPPORTED;
     }
     MV_CHECK_ARG(t1 != t2 && t1 != x0, "conv1x1_chain_rc0: t1 must not alias an input");
-    return chain_rc0_launch(t2, x0, wfrag, tab, t1, M, (hipStream_t)stream);
+    return chain_rc0_launch(t2, x0, wfrag, shifts, t1, M, (hipStream_t)stream);
 }
 
 int mv_conv1x1_dual_supported(int64_t M, int C1, int C2, int K, int dtype) {

@@ -469,11 +469,33 @@ def conv1x1_chain(x: Act, conv3, bn3, residual: Act, conv1n, bn1n, sub: int = 0)
     return out
 
 
+def _rc_shift_rows(*vecs) -> np.ndarray:
+    """The shift rows of mv_conv1x1_chain_rc*_fwd: per 32 values one row of 64 uint32 words, word r < 32 = bf16 hi(v) | bf16 lo(v) << 16
+    (two bf16 terms: the shift goes through the matrix pipe as one more k-step), words 32 .. 63 zero."""
+    rows = []
+    for v in vecs:
+        v = np.asarray(v, np.float32).reshape(-1, 32)
+        hi = torch.from_numpy(v).to(torch.bfloat16)
+        lo = (torch.from_numpy(v) - hi.to(torch.float32)).to(torch.bfloat16)
+        w = hi.view(torch.int16).numpy().astype(np.uint16).astype(np.uint32) | (lo.view(torch.int16).numpy().astype(np.uint16).astype(np.uint32) << 16)
+        out = np.zeros((v.shape[0], 64), np.uint32)
+        out[:, :32] = w
+        rows.append(out)
+    return np.concatenate(rows, 0)
+
+
+def _rc_conv1n_frags(frags, base, w1n, c):
+    for fh in range(2):
+        for s_ in range(2):
+            cols = 32 * c + 16 * s_ + 4 * fh + np.array([0, 1, 2, 3, 8, 9, 10, 11])
+            for a2 in range(w1n.shape[0] // 32):
+                frags[c, base + 2 * s_ + a2, fh] = w1n[32 * a2:32 * a2 + 32][:, cols]
+
+
 def chain_rc_fragments(conv3_0, bn3_0, ds_conv, ds_bn, conv3_1, bn3_1, conv1n, bn1n):
-    """Weights and epilogue constants of mv_conv1x1_chain_rc_fwd (header): per 32-channel chunk c of the block output, 16 MFMA A
-    fragments [lane = 32 fh + r][8] -- 8 of [scale3 W3_0 | scale_d W_d][32 c + r, 16 kk + 8 fh ..], 4 of W3_1[32 c + r, ...], 4 of
-    the next conv1 (k-step s, row tile a2) with the reduction index in accumulator order -- and the table
-    shift0 | scale1 | shift1 | scaleN | shiftN (cached on conv3_1)."""
+    """Operands of mv_conv1x1_chain_rc_fwd (header): per 32-channel chunk c of the block output, 16 MFMA A fragments
+    [lane = 32 fh + r][8] -- 8 of [scale3 W3_0 | scale_d W_d][32 c + r, 16 kk + 8 fh ..], 4 of scale1 W3_1[32 c + r, ...], 4 of the
+    scaled next conv1 (k-step s, row tile a2) with the reduction index in accumulator order -- and the 18 shift rows (cached on conv3_1)."""
     cache = conv3_1._cache()
     key = ("chain_rc", _bn_id(bn3_1), id(conv3_0), _bn_id(bn3_0), id(ds_conv), _bn_id(ds_bn), id(conv1n), _bn_id(bn1n))
     hit = cache.get(key)
@@ -481,11 +503,9 @@ def chain_rc_fragments(conv3_0, bn3_0, ds_conv, ds_bn, conv3_1, bn3_1, conv1n, b
         w30, h30 = _scaled_rows(conv3_0, bn3_0)
         wd, hd = _scaled_rows(ds_conv, ds_bn)
         wcat = np.concatenate([w30, wd], axis=1)                                  # [256][128], as ops._dual_weights
-        w31 = np.asarray(conv3_1.weight, np.float32).reshape(conv3_1.out_channels, -1)      # [256][64]
-        s1, h1 = _fold(conv3_1, bn3_1)
-        w1n = np.asarray(conv1n.weight, np.float32).reshape(conv1n.out_channels, -1)        # [64][256]
-        sn, hn = _fold(conv1n, bn1n)
-        K, N2 = wcat.shape[0], w1n.shape[0]
+        w31, h1 = _scaled_rows(conv3_1, bn3_1)                                    # [256][64]
+        w1n, hn = _scaled_rows(conv1n, bn1n)                                      # [64][256]
+        K = wcat.shape[0]
         frags = np.empty((K // 32, 16, 2, 32, 8), np.float32)                      # (chunk, fragment, fh, r, e)
         e8 = np.arange(8)
         for c in range(K // 32):
@@ -495,19 +515,16 @@ def chain_rc_fragments(conv3_0, bn3_0, ds_conv, ds_bn, conv3_1, bn3_1, conv1n, b
                     frags[c, kk, fh] = wcat[rows][:, 16 * kk + 8 * fh + e8]
                 for kk in range(4):
                     frags[c, 8 + kk, fh] = w31[rows][:, 16 * kk + 8 * fh + e8]
-                for s_ in range(2):
-                    cols = 32 * c + 16 * s_ + 4 * fh + np.array([0, 1, 2, 3, 8, 9, 10, 11])
-                    for a2 in range(N2 // 32):
-                        frags[c, 12 + 2 * s_ + a2, fh] = w1n[32 * a2:32 * a2 + 32][:, cols]
-        tab = np.concatenate([(h30 + hd).astype(np.float32), s1, h1, sn, hn]).astype(np.float32)
-        hit = (_dev(frags.reshape(-1), torch.bfloat16), _dev(tab, torch.float32), (conv3_0, ds_conv, conv1n))   # modules: keep ids alive
+            _rc_conv1n_frags(frags, 12, w1n, c)
+        sh = _rc_shift_rows(h30 + hd, h1, hn)
+        hit = (_dev(frags.reshape(-1), torch.bfloat16), torch.from_numpy(sh.view(np.int32)).to(device()), (conv3_0, ds_conv, conv1n))
         cache[key] = hit
     return hit
 
 
 def chain_rc0_fragments(conv3_0, bn3_0, ds_conv, ds_bn, conv1n, bn1n):
-    """mv_conv1x1_chain_rc0_fwd's operands: 12 fragments per 32-channel chunk (the 8 of [scale3 W3_0 | scale_d W_d], the 4 of the next
-    conv1 in accumulator order) and the table shift0 | scaleN | shiftN (cached on conv3_0)."""
+    """mv_conv1x1_chain_rc0_fwd's operands: 12 fragments per 32-channel chunk (the 8 of [scale3 W3_0 | scale_d W_d], the 4 of the scaled
+    next conv1 in accumulator order) and the 10 shift rows (cached on conv3_0)."""
     cache = conv3_0._cache()
     key = ("chain_rc0", _bn_id(bn3_0), id(ds_conv), _bn_id(ds_bn), id(conv1n), _bn_id(bn1n))
     hit = cache.get(key)
@@ -515,9 +532,8 @@ def chain_rc0_fragments(conv3_0, bn3_0, ds_conv, ds_bn, conv1n, bn1n):
         w30, h30 = _scaled_rows(conv3_0, bn3_0)
         wd, hd = _scaled_rows(ds_conv, ds_bn)
         wcat = np.concatenate([w30, wd], axis=1)
-        w1n = np.asarray(conv1n.weight, np.float32).reshape(conv1n.out_channels, -1)
-        sn, hn = _fold(conv1n, bn1n)
-        K, N2 = wcat.shape[0], w1n.shape[0]
+        w1n, hn = _scaled_rows(conv1n, bn1n)
+        K = wcat.shape[0]
         frags = np.empty((K // 32, 12, 2, 32, 8), np.float32)
         e8 = np.arange(8)
         for c in range(K // 32):
@@ -525,12 +541,9 @@ def chain_rc0_fragments(conv3_0, bn3_0, ds_conv, ds_bn, conv1n, bn1n):
             for fh in range(2):
                 for kk in range(8):
                     frags[c, kk, fh] = wcat[rows][:, 16 * kk + 8 * fh + e8]
-                for s_ in range(2):
-                    cols = 32 * c + 16 * s_ + 4 * fh + np.array([0, 1, 2, 3, 8, 9, 10, 11])
-                    for a2 in range(N2 // 32):
-                        frags[c, 8 + 2 * s_ + a2, fh] = w1n[32 * a2:32 * a2 + 32][:, cols]
-        tab = np.concatenate([(h30 + hd).astype(np.float32), sn, hn]).astype(np.float32)
-        hit = (_dev(frags.reshape(-1), torch.bfloat16), _dev(tab, torch.float32), (ds_conv, conv1n))
+            _rc_conv1n_frags(frags, 8, w1n, c)
+        sh = _rc_shift_rows(h30 + hd, hn)
+        hit = (_dev(frags.reshape(-1), torch.bfloat16), torch.from_numpy(sh.view(np.int32)).to(device()), (ds_conv, conv1n))
         cache[key] = hit
     return hit
 

@@ -175,22 +175,24 @@ int mv_conv1x1_dual_chain_fwd(const void* x, const void* x2, const void* wcat, c
  *   (1) mv_conv1x1_dual_chain_fwd with y = NULL: block 0 stores only t1 of block 1 -- y0 is recomputed by (2);
  *   (2) mv_conv1x1_chain_rc_fwd: block 1's boundary WITHOUT y0 in memory.  It reads t2 (block 1's conv2 output), t2_prev (block 0's)
  *       and x0 (the stage input), recomputes  y0 = relu([t2_prev | x0] . wcat0^T + shift0)  exactly as (1) computed it (bf16-rounded),
- *       then  y = relu(scale1 * (t2 . w3^T) + shift1 + y0)  and  t1 = relu(scaleN * (y . w1n^T) + shiftN)  as mv_conv1x1_chain_fwd.
- *       wfrag: the three weight matrices in MFMA fragment order, 128 fragments of 1 KB -- per 32-channel chunk c of y: 8 of
- *       wcat0[32c.., :] (k16-steps of [t2_prev | x0]), 4 of w3[32c.., :], 4 of w1n[:, 32c..] as (k-step s, 32-row tile a2) with the
- *       reduction index in accumulator order (slot 8 fh + i <-> channel 32 c + 8 (2 s + i / 4) + 4 fh + i % 4); a fragment is
- *       [lane = 32 fh + r][8 bf16] = W[row0 + r][k0 + 8 fh ..].  tab: shift0[K] scale1[K] shift1[K] scaleN[N2] shiftN[N2] fp32.
- *       C = 64, K = 256, N2 = 64, M >= 8192;
+ *       then  y = relu(t2 . (scale1 w3)^T + shift1 + y0)  and  t1 = relu(y . (scaleN w1n)^T + shiftN).  Every BatchNorm scale is folded
+ *       into the bf16 weight rows by the caller (as wcat of (1) always was); the shifts enter through the matrix pipe.
+ *       wfrag: the three (scaled) weight matrices in MFMA fragment order, 128 fragments of 1 KB -- per 32-channel chunk c of y: 8 of
+ *       wcat0[32c.., :] (k16-steps of [t2_prev | x0]), 4 of scale1 w3[32c.., :], 4 of scaleN w1n[:, 32c..] as (k-step s, 32-row
+ *       tile a2) with the reduction index in accumulator order (slot 8 fh + i <-> channel 32 c + 8 (2 s + i / 4) + 4 fh + i % 4); a
+ *       fragment is [lane = 32 fh + r][8 bf16] = W[row0 + r][k0 + 8 fh ..].  shifts: 18 rows of 64 32-bit words -- rows 0-7 shift0
+ *       of chunk c, 8-15 shift1 of chunk c, 16-17 shiftN of tile a2 -- word r < 32 = bf16 hi(v) | bf16 lo(v) << 16 of v = shift[row r]
+ *       (hi + lo = v to 16 mantissa bits), words 32-63 zero.  C = 64, K = 256, N2 = 64, M >= 8192;
  *   (3) mv_conv1x1_chain_sub_fwd: the LAST block's boundary when the only other consumer of y is a stride-2 pointwise convolution
  *       (the next stage's downsample branch): as mv_conv1x1_chain_fwd with N2 = 128, but y_sub = [N][H/2][W/2][K] holds only the
  *       pixels with even (h, w) -- the strided consumer reads it with stride 1 (mv_conv1x1_dual_fwd, stride2 = 1).
- *   (1') mv_conv1x1_chain_rc0_fwd: (1) rebuilt in (2)'s style -- t1 = relu(scaleN * (w1n . relu([t2 | x0] . wcat0^T + shift0)) + shiftN),
- *       wfrag = 96 fragments (per chunk: the 8 of wcat0, the 4 of w1n, as in (2)), tab = shift0[K] scaleN[N2] shiftN[N2]; nothing is
- *       staged for a store, so twelve waves per CU fit instead of six.  Same shapes as (2). */
+ *   (1') mv_conv1x1_chain_rc0_fwd: (1) rebuilt in (2)'s style -- t1 = relu(relu([t2 | x0] . wcat0^T + shift0) . (scaleN w1n)^T + shiftN),
+ *       wfrag = 96 fragments (per chunk: the 8 of wcat0, the 4 of scaleN w1n, as in (2)), shifts = 10 rows (0-7 shift0, 8-9 shiftN);
+ *       nothing is staged for a store, so twelve waves per CU fit instead of six.  Same shapes as (2). */
 int mv_conv1x1_chain_rc_supported(int64_t M, int C, int K, int N2, int dtype);
-int mv_conv1x1_chain_rc0_fwd(const void* t2, const void* x0, const void* wfrag, const float* tab, void* t1, int64_t M, int C, int K,
+int mv_conv1x1_chain_rc0_fwd(const void* t2, const void* x0, const void* wfrag, const void* shifts, void* t1, int64_t M, int C, int K,
                              int N2, int dtype, mv_stream_t stream);
-int mv_conv1x1_chain_rc_fwd(const void* t2, const void* t2_prev, const void* x0, const void* wfrag, const float* tab, void* y,
+int mv_conv1x1_chain_rc_fwd(const void* t2, const void* t2_prev, const void* x0, const void* wfrag, const void* shifts, void* y,
                             void* t1, int64_t M, int C, int K, int N2, int dtype, mv_stream_t stream);
 int mv_conv1x1_chain_sub_supported(int N, int H, int W, int C, int K, int N2, int dtype);
 int mv_conv1x1_chain_sub_fwd(const void* x, const void* w3, const float* scale3, const float* shift3, const void* residual,

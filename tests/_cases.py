@@ -629,10 +629,25 @@ def _rc_fragments(wcat, w31, w1n):
     return out.reshape(-1)
 
 
+def _rc_shifts(*vecs):
+    """Shift rows as include/eqxvision_amd.h documents them (independent of ops.py): 64 words per 32 values, hi | lo << 16."""
+    rows = []
+    for v in vecs:
+        v = np.asarray(v, np.float32)
+        hi = bf(v)
+        lo = bf(v - hi)
+        w = (hi.view(np.uint32) >> 16) | (lo.view(np.uint32) & 0xffff0000)
+        out = np.zeros((v.size // 32, 64), np.uint32)
+        out[:, :32] = w.reshape(-1, 32)
+        rows.append(out)
+    return np.concatenate(rows, 0)
+
+
 def chain_rc_case(M, seed=0):
     """mv_conv1x1_chain_rc_fwd (the second bottleneck boundary of a stage whose first block output is NOT in memory: y0 recomputed
-    from [t2_0 | x0], then conv3 + BN + y0 + ReLU and the next conv1 + BN + ReLU; resnet.py:144-162, 295-303) vs the oracle, and
-    bit for bit vs the library's own pair mv_conv1x1_dual_chain_fwd (y0 written) -> mv_conv1x1_chain_fwd (y0 read back);
+    from [t2_0 | x0], then conv3 + BN + y0 + ReLU and the next conv1 + BN + ReLU; resnet.py:144-162, 295-303) and
+    mv_conv1x1_chain_rc0_fwd (the first boundary without its output map) vs the oracle with fp32 scales, and within the same bound of
+    the library's own pair mv_conv1x1_dual_chain_fwd (y0 written) -> mv_conv1x1_chain_fwd (y0 read back);
     mv_conv1x1_dual_chain_fwd with y = NULL must produce the same t1 as with y."""
     def run():
         L = _lib()
@@ -661,14 +676,16 @@ def chain_rc_case(M, seed=0):
         y0ref = O.relu(np.concatenate([t20, x0], 1).astype(f64) @ wcat.astype(f64).T + h0)
         y1ref = O.relu((t21.astype(f64) @ w31.astype(f64).T) * s31 + h31 + bf(y0ref))
         t1ref = O.relu((bf(y1ref).astype(f64) @ w1n.astype(f64).T) * s1n + h1n)
+        # the recompute kernels take every BatchNorm scale folded into the bf16 weight rows and the shifts as two-term bf16 rows
+        w31s, w1ns, w1as = (bf(w.astype(np.float32) * sc[:, None]) for w, sc in ((w31, s31), (w1n, s1n), (w1a, s1a)))
         d = {k: dev(v, "bf16") for k, v in dict(x0=x0, t20=t20, t21=t21, wcat=wcat, w31=w31, w1a=w1a, w1n=w1n,
-                                               wf=bf(_rc_fragments(wcat.astype(np.float32), w31.astype(np.float32), w1n.astype(np.float32)))).items()}
-        f = {k: dev(v, "fp32") for k, v in dict(h0=h0, s31=s31, h31=h31, s1a=s1a, h1a=h1a, s1n=s1n, h1n=h1n,
-                                               tab=np.concatenate([h0, s31, h31, s1n, h1n]).astype(np.float32)).items()}
+                                               wf=bf(_rc_fragments(wcat.astype(np.float32), w31s.astype(np.float32), w1ns.astype(np.float32)))).items()}
+        f = {k: dev(v, "fp32") for k, v in dict(h0=h0, s31=s31, h31=h31, s1a=s1a, h1a=h1a, s1n=s1n, h1n=h1n).items()}
+        sh = torch.from_numpy(_rc_shifts(h0, h31, h1n).view(np.int32)).cuda()
         y1 = torch.full((M, K), -7.0, dtype=torch.bfloat16, device="cuda")
         t1 = torch.full((M, N2), -7.0, dtype=torch.bfloat16, device="cuda")
         L.call("mv_conv1x1_chain_rc_fwd", d["t21"].data_ptr(), d["t20"].data_ptr(), d["x0"].data_ptr(), d["wf"].data_ptr(),
-               f["tab"].data_ptr(), y1.data_ptr(), t1.data_ptr(), M, C, K, N2, 1, _stream())
+               sh.data_ptr(), y1.data_ptr(), t1.data_ptr(), M, C, K, N2, 1, _stream())
         kern = L.last_kernel()
         # the pair it replaces: y0 written by the dual chain, read back as the residual of the plain chain
         y0 = torch.empty((M, K), dtype=torch.bfloat16, device="cuda")
@@ -680,11 +697,11 @@ def chain_rc_case(M, seed=0):
         kern_noy = L.last_kernel()
         # (1'): the first boundary without its output map in this file's style -- against the dual chain's t1
         wf0 = np.zeros((K // 32, 12, 64, 8), np.float32)
-        full = _rc_fragments(wcat.astype(np.float32), w31.astype(np.float32), w1a.astype(np.float32)).reshape(K // 32, 16, 64, 8)
+        full = _rc_fragments(wcat.astype(np.float32), w31s.astype(np.float32), w1as.astype(np.float32)).reshape(K // 32, 16, 64, 8)
         wf0[:, :8], wf0[:, 8:] = full[:, :8], full[:, 12:]
-        wf0d, tab0 = dev(bf(wf0.reshape(-1)), "bf16"), dev(np.concatenate([h0, s1a, h1a]).astype(np.float32), "fp32")
+        wf0d, sh0 = dev(bf(wf0.reshape(-1)), "bf16"), torch.from_numpy(_rc_shifts(h0, h1a).view(np.int32)).cuda()
         tc = torch.full((M, N2), -7.0, dtype=torch.bfloat16, device="cuda")
-        L.call("mv_conv1x1_chain_rc0_fwd", d["t20"].data_ptr(), d["x0"].data_ptr(), wf0d.data_ptr(), tab0.data_ptr(), tc.data_ptr(),
+        L.call("mv_conv1x1_chain_rc0_fwd", d["t20"].data_ptr(), d["x0"].data_ptr(), wf0d.data_ptr(), sh0.data_ptr(), tc.data_ptr(),
                M, C, K, N2, 1, _stream())
         kern_rc0 = L.last_kernel()
         y1p = torch.empty_like(y1)
@@ -695,14 +712,15 @@ def chain_rc_case(M, seed=0):
         torch.cuda.synchronize()
         a = _cmp(host(y1), y1ref, TOL_BF16)
         b = _cmp(host(t1), t1ref, TOL_BF16)
-        same_y = bool(torch.equal(y1, y1p))
+        dy1 = float((y1.float() - y1p.float()).abs().max())             # scales folded into bf16 rows: close to the pair, not identical
+        same_y = dy1 <= a["lim"]
         dt1 = float((t1.float() - t1p.float()).abs().max())
         noy_same = bool(torch.equal(ta, tb))
         t1aref = O.relu((bf(y0ref).astype(f64) @ w1a.astype(f64).T) * s1a + h1a)
         c0 = _cmp(host(tc), t1aref, TOL_BF16)
         d0 = float((tc.float() - ta.float()).abs().max())
         return {"ok": a["ok"] and b["ok"] and same_y and dt1 <= b["lim"] and noy_same and c0["ok"] and d0 <= c0["lim"],
-                "err": max(a["err"], b["err"], c0["err"]), "lim": a["lim"], "y1_bit_identical_to_pair": same_y, "t1_vs_pair": dt1,
+                "err": max(a["err"], b["err"], c0["err"]), "lim": a["lim"], "y1_vs_pair": dy1, "t1_vs_pair": dt1,
                 "dual_chain_without_y_same_t1": noy_same, "rc0_t1_vs_dual_chain": d0, "kernel": kern, "kernel_noy": kern_noy,
                 "kernel_rc0": kern_rc0}
     return run

@@ -27,23 +27,24 @@ w1c = (torch.randn(128, K, device="cuda") / K ** 0.5).bfloat16()
 sK, hK = torch.rand(K, device="cuda") + 0.5, torch.rand(K, device="cuda")
 s64, h64, s128, h128 = (torch.rand(n, device="cuda") + 0.5 for n in (64, 64, 128, 128))
 wf = torch.from_numpy(_rc_fragments(wcat.float().cpu().numpy(), w3.float().cpu().numpy(), w1.float().cpu().numpy())).bfloat16().cuda()
-tab = torch.cat([hK, sK, hK, s64, h64]).contiguous()
+from tests._cases import _rc_shifts
+tab = torch.from_numpy(_rc_shifts(hK.cpu().numpy(), hK.cpu().numpy(), h64.cpu().numpy()).view(np.int32)).cuda()
 _f = _rc_fragments(wcat.float().cpu().numpy(), w3.float().cpu().numpy(), w1.float().cpu().numpy()).reshape(8, 16, 64, 8)
 wf0 = torch.from_numpy(np.ascontiguousarray(np.concatenate([_f[:, :8], _f[:, 12:]], 1)).reshape(-1)).bfloat16().cuda()
-tab0 = torch.cat([hK, s64, h64]).contiguous()
+tab0 = torch.from_numpy(_rc_shifts(hK.cpu().numpy(), h64.cpu().numpy()).view(np.int32)).cuda()
 P = lambda t: t.data_ptr() if t is not None else None
 
 launches = {
     "dual chain, y0 written (round 5)": lambda: L.call("mv_conv1x1_dual_chain_fwd", P(t20), P(x0), P(wcat), None, P(hK), P(y0), P(w1), P(s64), P(h64), P(t1a), M, C, C, K, 64, 1, s),
     "dual chain, y0 NOT written": lambda: L.call("mv_conv1x1_dual_chain_fwd", P(t20), P(x0), P(wcat), None, P(hK), None, P(w1), P(s64), P(h64), P(t1a), M, C, C, K, 64, 1, s),
-    "chain_rc0 (12 waves), y0 NOT written": lambda: L.call("mv_conv1x1_chain_rc0_fwd", P(t20), P(x0), P(wf0), P(tab0), P(t1a), M, C, K, 64, 1, s),
+    "chain_rc0, y0 NOT written": lambda: L.call("mv_conv1x1_chain_rc0_fwd", P(t20), P(x0), P(wf0), P(tab0), P(t1a), M, C, K, 64, 1, s),
     "chain, residual y0 read (round 5)": lambda: L.call("mv_conv1x1_chain_fwd", P(t21), P(w3), P(sK), P(hK), P(y0), P(y1), P(w1), P(s64), P(h64), P(t1b), M, C, K, 64, 1, s),
     "chain_rc, y0 recomputed": lambda: L.call("mv_conv1x1_chain_rc_fwd", P(t21), P(t20), P(x0), P(wf), P(tab), P(y1), P(t1b), M, C, K, 64, 1, s),
     "chain -> 128, y2 full (round 5)": lambda: L.call("mv_conv1x1_chain_fwd", P(t22), P(w3), P(sK), P(hK), P(y1), P(y2), P(w1c), P(s128), P(h128), P(t1c), M, C, K, 128, 1, s),
     "chain -> 128, y2 sub-sampled": lambda: L.call("mv_conv1x1_chain_sub_fwd", P(t22), P(w3), P(sK), P(hK), P(y1), P(y2s), P(w1c), P(s128), P(h128), P(t1c), N, H, W, C, K, 128, 1, s),
 }
 mb = {"dual chain, y0 written (round 5)": 2 * M * (2 * C + K + 64), "dual chain, y0 NOT written": 2 * M * (2 * C + 64),
-      "chain_rc0 (12 waves), y0 NOT written": 2 * M * (2 * C + 64),
+      "chain_rc0, y0 NOT written": 2 * M * (2 * C + 64),
       "chain, residual y0 read (round 5)": 2 * M * (C + 2 * K + 64), "chain_rc, y0 recomputed": 2 * M * (3 * C + K + 64),
       "chain -> 128, y2 full (round 5)": 2 * M * (C + 2 * K + 128), "chain -> 128, y2 sub-sampled": 2 * M * (C + K + K // 4 + 128)}
 
@@ -69,3 +70,10 @@ for name, fn in launches.items():
         tot["round 5" if "round 5" in name else "round 6"] += us
     print(f"{name:36s} [{L.last_kernel():40s}] {us:7.1f} us  {mb[name] / 1e6:6.1f} MB algorithmic  {mb[name] / us / 1e6:5.2f} TB/s")
 print(f"sum of the three boundaries: round 5 {tot['round 5']:.1f} us, round 6 {tot['round 6']:.1f} us")
+
+if os.environ.get("EQV_LIB", "").endswith("_prof.so"):          # the ablation switch exists in the debug build only
+    for dbg, what in ((1, "y stores dropped"), (2, "every tile reads the same 32 rows (cache hits)"), (4, "t1 stores dropped"),
+                      (3, "no y stores + cached reads"), (7, "no stores at all + cached reads")):
+        L.set_flag("rc_dbg", dbg)
+        print(f"ablation rc_dbg={dbg} ({what}): chain_rc0 {t(launches['chain_rc0, y0 NOT written']):.1f} us, chain_rc1 {t(launches['chain_rc, y0 recomputed']):.1f} us")
+    L.set_flag("rc_dbg", 0)
