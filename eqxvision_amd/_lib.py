@@ -93,6 +93,8 @@ PROTOTYPES = {
     "mv_bottleneck_tail_fwd": [_vp] * 9 + [_i] * 6 + [_vp],
     "mv_conv1x1_dual_supported": [_i64, _i, _i, _i, _i],
     "mv_conv1x1_dual_fwd": [_vp] * 6 + [_i] * 11 + [_vp],
+    "mv_conv1x1_chain_res_supported": [_i] * 8,
+    "mv_conv1x1_chain_res_fwd": [_vp] * 6 + [_i] * 8 + [_vp],
     "mv_conv1x1_chain_rc_supported": [_i64, _i, _i, _i, _i],
     "mv_conv1x1_chain_rc_fwd": [_vp] * 7 + [_i64, _i, _i, _i, _i, _vp],
     "mv_conv1x1_chain_rc0_fwd": [_vp] * 5 + [_i64, _i, _i, _i, _i, _vp],

@@ -327,4 +327,263 @@ int chain_rc0_launch(const void* t2, const void* x0, const void* wfrag, const vo
     return chain_rc_go<0, 8, 6>(p, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same style for a boundary whose identity DOES come from memory (the stage's last block: its predecessor's output was written):
+//   y [m] = relu( (s3 W3) . t2[m] + shift3 + res[m] )             -> HBM, all pixels or (SUB) only those with even (h, w), compactly
+//   t1[m] = relu( (sN W1n) . bf16(y[m]) + shiftN ),  N2 = 128     -> HBM
+// = chain1x1_kernel<128, 6, false, SUB> (chain1x1.hip) with this file's instruction stream.  The identity reaches the accumulator
+// layout through the wave's LDS patch (row-major 16-byte loads, one slab ahead; 8-byte reads back) and STARTS the accumulation.
+struct ChainResP {
+    const bf16_t* t2;      // [M][64]
+    const bf16_t* res;     // [M][256]
+    const bf16_t* wf;      // 8 * (4 + 2 N2 / 32) fragments
+    const unsigned* sh;    // 8 + N2 / 32 shift rows
+    bf16_t* y;             // [M][256], or SUB: [N][H/2][W/2][256]
+    bf16_t* t1;            // [M][N2]
+    int M, tiles_m, subH, subW;
+};
+
+template <int N2, bool SUB, int WAVES, int RD>
+__global__ __launch_bounds__(WAVES * 64) void chain_res_kernel(const ChainResP p) {
+    constexpr int K = 256, T2 = N2 / 32, FPC = 4 + 2 * T2, NFRAG = 8 * FPC, PITCH = 144, NSH = 8 + T2, NT = WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wl = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* ep = smem + NFRAG * 1024 + NSH * 256 + wave * (32 * PITCH);
+    {
+        constexpr int N16 = NFRAG * 64, U = 4;
+        for (int base = 0; base < N16; base += U * NT) {
+            uint4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * NT + tid;
+                v[u] = ((const uint4*)p.wf)[i < N16 ? i : N16 - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * NT + tid;
+                if (i < N16) ((uint4*)wl)[i] = v[u];
+            }
+        }
+        for (int i = tid; i < NSH * 64; i += NT) ((unsigned*)(wl + NFRAG * 1024))[i] = p.sh[i];
+    }
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    typedef __attribute__((address_space(3))) const char* lds_cp;
+    unsigned wbase0 = (unsigned)(uintptr_t)(lds_cp)wl + lane * 16;
+    unsigned wbase1 = wbase0 + 65536u;
+    unsigned sbase = (unsigned)(uintptr_t)(lds_cp)wl + NFRAG * 1024 + lane * 4;
+    asm volatile("" : "+v"(wbase0), "+v"(wbase1), "+v"(sbase));
+    auto afrag = [&](int f) -> bf16x8 {
+        const lds_cp b = (lds_cp)(uintptr_t)(f < 64 ? wbase0 : wbase1);
+        return __builtin_bit_cast(bf16x8, *(const __attribute__((address_space(3))) u32x4_t*)(b + (f & 63) * 1024));
+    };
+    auto sfrag = [&](int row) -> bf16x8 {
+        u32x4_t v;
+        v[0] = *(const __attribute__((address_space(3))) unsigned*)((lds_cp)(uintptr_t)sbase + row * 256);
+        v[1] = 0u; v[2] = 0u; v[3] = 0u;
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    u32x4_t onesv;
+    onesv[0] = fh ? 0u : 0x3f803f80u; onesv[1] = 0u; onesv[2] = 0u; onesv[3] = 0u;
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, onesv);
+
+    auto load_x = [&](uint4* xf, int tile) {
+        int m = tile * 32 + fr;
+        m = m < p.M ? m : p.M - 1;
+        const long long off = (long long)m * 64 + fh * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xf[kk] = *(const uint4*)(p.t2 + off + kk * 16);
+    };
+    // identity rows of 64-channel slab `ps` of a tile, row-major: field i = rows 8 i .. 8 i + 7, 16 bytes per lane.  (A struct of four
+    // values handed around BY VALUE: as a `uint4[4]` behind a pointer the rows stayed in scratch memory.)
+    struct Rows4 { uint4 r0, r1, r2, r3; };
+    auto load_res = [&](int tile, int ps) -> Rows4 {
+        auto row = [&](int pass) -> uint4 {
+            int m = tile * 32 + pass * 8 + (lane >> 3);
+            m = m < p.M ? m : p.M - 1;
+            return *(const uint4*)(p.res + (long long)m * K + ps * 64 + (lane & 7) * 8);
+        };
+        Rows4 o;
+        o.r0 = row(0); o.r1 = row(1); o.r2 = row(2); o.r3 = row(3);
+        return o;
+    };
+
+    // rr: the identity rows of this tile's first slab; returns those of `next_tile`'s
+    auto run_tile = [&](uint4* xf, Rows4 rr, int tile, int refill, int next_tile) -> Rows4 {
+        const int tile_u = __builtin_amdgcn_readfirstlane(tile);
+        const brsrc_t ry = SUB ? make_brsrc(p.y) : make_brsrc(p.y + (long long)tile_u * 32 * K);
+        const brsrc_t rt = make_brsrc(p.t1 + (long long)tile_u * 32 * N2);
+        const int rows_left = p.M - tile_u * 32;
+        unsigned ysub[4] = {0, 0, 0, 0};
+        if constexpr (SUB) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = tile * 32 + pass * 8 + (lane >> 3);
+                const int hw = p.subH * p.subW;
+                const int b = m / hw, rem = m - b * hw;
+                const int h = rem / p.subW, w = rem - h * p.subW;
+                const bool keep = m < p.M && !((h | w) & 1);
+                ysub[pass] = keep ? (unsigned)(((b * (p.subH >> 1) + (h >> 1)) * (p.subW >> 1) + (w >> 1)) * K) * 2u : BUF_OOB;
+            }
+        }
+        constexpr int SL = 8 + 4 * T2, NSTEP = 4 * SL;
+        auto fid = [&](int i) -> int {
+            const int ps = i / SL, r = i - ps * SL;
+            if (r < 8) return (2 * ps + (r & 1)) * FPC + (r >> 1);
+            const int q = r - 8;
+            return (2 * ps + q / (2 * T2)) * FPC + 4 + q % (2 * T2);
+        };
+        bf16x8 ring[RD];
+#pragma unroll
+        for (int d = 0; d < RD; ++d) ring[d] = afrag(fid(d));
+        auto take = [&](int i) -> bf16x8 {
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 a = ring[i % RD];
+            if (i + RD < NSTEP) ring[i % RD] = afrag(fid(i + RD));
+            return a;
+        };
+        f32x16 acc2[T2];
+#pragma unroll
+        for (int a2 = 0; a2 < T2; ++a2) {
+            f32x16 z;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0.f;
+            acc2[a2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sfrag(8 + a2), ones, z, 0, 0, 0);
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int s0 = ps * SL;
+            // ---- identity of this slab: row-major registers -> patch -> accumulator layout; the next slab's rows are requested
+            {
+                char* w = ep + (lane >> 3) * PITCH + (lane & 7) * 16;
+                *(uint4*)(w) = rr.r0; *(uint4*)(w + 8 * PITCH) = rr.r1; *(uint4*)(w + 16 * PITCH) = rr.r2; *(uint4*)(w + 24 * PITCH) = rr.r3;
+            }
+            wave_lds_fence();
+            rr = ps < 3 ? load_res(tile, ps + 1) : load_res(next_tile, 0);      // (rows clamped: harmless behind the last tile)
+            f32x16 a[2];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint2 u = *(const uint2*)(ep + fr * PITCH + (cc * 32 + 8 * g + 4 * fh) * 2);
+                    a[cc][4 * g] = __uint_as_float(u.x << 16);
+                    a[cc][4 * g + 1] = __uint_as_float(u.x & 0xffff0000u);
+                    a[cc][4 * g + 2] = __uint_as_float(u.y << 16);
+                    a[cc][4 * g + 3] = __uint_as_float(u.y & 0xffff0000u);
+                }
+                a[cc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sfrag(ps * 2 + cc), ones, a[cc], 0, 0, 0);
+            }
+            wave_lds_fence();                                    // the patch is free again (y staging below)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const bf16x8 af = take(s0 + r);
+                a[r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, xf[r >> 1]), a[r & 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            uint32_t pk[2][8];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    pk[cc][2 * g] = relu_pack_bf2(a[cc][4 * g], a[cc][4 * g + 1]);
+                    pk[cc][2 * g + 1] = relu_pack_bf2(a[cc][4 * g + 2], a[cc][4 * g + 3]);
+                    *(uint2*)(ep + fr * PITCH + (cc * 32 + 8 * g + 4 * fh) * 2) = make_uint2(pk[cc][2 * g], pk[cc][2 * g + 1]);
+                }
+            if (ps == 3) load_x(xf, refill);
+#pragma unroll
+            for (int q = 0; q < 4 * T2; ++q) {
+                const bf16x8 af = take(s0 + 8 + q);
+                const int cc = q / (2 * T2), sstep = (q / T2) & 1, a2 = q % T2;
+                const uint4 b = make_uint4(pk[cc][4 * sstep], pk[cc][4 * sstep + 1], pk[cc][4 * sstep + 2], pk[cc][4 * sstep + 3]);
+                acc2[a2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b), acc2[a2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = pass * 8 + (lane >> 3);
+                const uint4 u = *(const uint4*)(ep + row * PITCH + (lane & 7) * 16);
+                if constexpr (SUB) buf_store_u4(ry, ysub[pass] == BUF_OOB ? BUF_OOB : ysub[pass] + (unsigned)(ps * 64 + (lane & 7) * 8) * 2u, u);
+                else buf_store_u4(ry, row < rows_left ? (unsigned)(row * K + ps * 64 + (lane & 7) * 8) * 2u : BUF_OOB, u);
+            }
+            wave_lds_fence();
+        }
+        // ---- conv1 of the next block: 32 pixels x N2 channels, 64 channels per round through the patch
+#pragma unroll
+        for (int rd = 0; rd < T2 / 2; ++rd) {
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(uint2*)(ep + fr * PITCH + (a2 * 32 + 8 * g + 4 * fh) * 2) =
+                        make_uint2(relu_pack_bf2(acc2[2 * rd + a2][4 * g], acc2[2 * rd + a2][4 * g + 1]),
+                                   relu_pack_bf2(acc2[2 * rd + a2][4 * g + 2], acc2[2 * rd + a2][4 * g + 3]));
+            wave_lds_fence();
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = pass * 8 + (lane >> 3);
+                const uint4 u = *(const uint4*)(ep + row * PITCH + (lane & 7) * 16);
+                buf_store_u4(rt, row < rows_left ? (unsigned)(row * N2 + rd * 64 + (lane & 7) * 8) * 2u : BUF_OOB, u);
+            }
+            wave_lds_fence();
+        }
+        return rr;
+    };
+
+    uint4 xa[4], xb[4];
+    const int gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
+    int tile = gw;
+    load_x(xa, tile);
+    load_x(xb, tile + nw);
+    Rows4 rr = load_res(tile, 0);
+    for (; tile + nw < p.tiles_m; tile += 2 * nw) {
+        rr = run_tile(xa, rr, tile, tile + 2 * nw, tile + nw);
+        rr = run_tile(xb, rr, tile + nw, tile + 3 * nw, tile + 2 * nw);
+    }
+    if (tile < p.tiles_m) run_tile(xa, rr, tile, tile, tile);
+}
+
+int chain_res_supported(long long N, int H, int W, int C, int K, int N2, int sub, int dtype) {
+    const long long M = N * H * W;
+    if (!(dtype == MV_BF16 && C == 64 && K == 256 && N2 == 128 && M >= 8192 && M < (1LL << 31) - (1 << 20)) || get_flag("no_chain") ||
+        get_flag("no_chain_res"))
+        return 0;
+    if (sub == 0) return 1;
+    return sub == 2 && H % 2 == 0 && W % 2 == 0 && N * (H / 2) * (W / 2) * K * 2 < (1LL << 31) && !get_flag("no_chain_sub");
+}
+
+int chain_res_launch(const void* t2, const void* residual, const void* wfrag, const void* shifts, void* y, void* t1, int N, int H, int W,
+                     int sub, hipStream_t st) {
+    constexpr int WAVES = 8, N2 = 128, RD = 6;
+    constexpr int SMEM = 8 * (4 + 2 * N2 / 32) * 1024 + (8 + N2 / 32) * 256 + WAVES * 32 * 144;
+    static_assert(SMEM <= 160 * 1024, "LDS");
+    ChainResP p;
+    p.t2 = (const bf16_t*)t2; p.res = (const bf16_t*)residual; p.wf = (const bf16_t*)wfrag; p.sh = (const unsigned*)shifts;
+    p.y = (bf16_t*)y; p.t1 = (bf16_t*)t1;
+    const long long M = (long long)N * H * W;
+    p.M = (int)M;
+    p.tiles_m = (int)((M + 31) / 32);
+    p.subH = H; p.subW = W;
+    int gx = 256;
+    const int need = (p.tiles_m + WAVES - 1) / WAVES;
+    if (gx > need) gx = need;
+    if (sub) {
+        auto kern = chain_res_kernel<N2, true, WAVES, RD>;
+        static LdsAttrSite attr;
+        MV_HIP(attr.ensure((const void*)kern, SMEM));
+        set_kernel_name("chain_res_bf16_64_256_128_ysub2");
+        hipLaunchKernelGGL(kern, dim3(gx), dim3(WAVES * 64), SMEM, st, p);
+    } else {
+        auto kern = chain_res_kernel<N2, false, WAVES, RD>;
+        static LdsAttrSite attr;
+        MV_HIP(attr.ensure((const void*)kern, SMEM));
+        set_kernel_name("chain_res_bf16_64_256_128");
+        hipLaunchKernelGGL(kern, dim3(gx), dim3(WAVES * 64), SMEM, st, p);
+    }
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+}
+
 }  // namespace mv

@@ -193,6 +193,9 @@ int chain_rc_supported(long long M, int C, int K, int N2, int dtype);
 int chain_rc_launch(const void* t2, const void* t2_prev, const void* x0, const void* wfrag, const void* shifts, void* y, void* t1,
                     long long M, hipStream_t st);
 int chain_rc0_launch(const void* t2, const void* x0, const void* wfrag, const void* shifts, void* t1, long long M, hipStream_t st);
+int chain_res_supported(long long N, int H, int W, int C, int K, int N2, int sub, int dtype);
+int chain_res_launch(const void* t2, const void* residual, const void* wfrag, const void* shifts, void* y, void* t1, int N, int H, int W,
+                     int sub, hipStream_t st);
 int chain_stream_supported(long long M, int C, int K, int N2, int dtype);
 int chain_stream_launch(const void* x, const void* w3, const float* scale3, const float* shift3, const void* residual, void* y,
                         const void* w1, const float* scale1, const float* shift1, void* t1, long long M, hipStream_t st);

@@ -1346,6 +1346,22 @@ int mv_conv1x1_chain_sub_fwd(const void* x, const void* w3, const float* scale3,
     return chain1x1_sub_launch(x, w3, scale3, shift3, residual, y_sub, w1, scale1, shift1, t1, N, H, W, (hipStream_t)stream);
 }
 
+int mv_conv1x1_chain_res_supported(int N, int H, int W, int C, int K, int N2, int sub, int dtype) {
+    return !get_flag("force_generic") && !get_flag("no_stream") && N > 0 && H > 0 && W > 0 && chain_res_supported(N, H, W, C, K, N2, sub, dtype);
+}
+
+int mv_conv1x1_chain_res_fwd(const void* t2, const void* residual, const void* wfrag, const void* shifts, void* y, void* t1, int N, int H,
+                             int W, int C, int K, int N2, int sub, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(t2 && residual && wfrag && shifts && y && t1, "conv1x1_chain_res: NULL pointer");
+    if (!mv_conv1x1_chain_res_supported(N, H, W, C, K, N2, sub, dtype)) {
+        set_error("conv1x1_chain_res: unsupported shape N=%d H=%d W=%d C=%d K=%d N2=%d sub=%d (ask mv_conv1x1_chain_res_supported first)", N,
+                  H, W, C, K, N2, sub);
+        return MV_E_UNSUPPORTED;
+    }
+    MV_CHECK_ARG(y != residual && y != t2 && t1 != y && t1 != residual && t1 != t2, "conv1x1_chain_res: outputs must not alias inputs");
+    return chain_res_launch(t2, residual, wfrag, shifts, y, t1, N, H, W, sub, (hipStream_t)stream);
+}
+
 int mv_conv1x1_chain_rc_supported(int64_t M, int C, int K, int N2, int dtype) {
     return !get_flag("force_generic") && !get_flag("no_stream") && chain_rc_supported(M, C, K, N2, dtype);
 }

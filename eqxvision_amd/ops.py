@@ -451,6 +451,18 @@ def conv1x1_chain(x: Act, conv3, bn3, residual: Act, conv1n, bn1n, sub: int = 0)
         return None
     if not _lib.load().mv_conv1x1_chain_supported(M, C, K, N2, DT[dt]):
         return None
+    lib = _lib.load()
+    for sb in ((2, 0) if sub == 2 else (0,)):      # the accumulator-layout kernel (csrc/chain_rc.hip: chain_res) where it has the shape
+        if lib.mv_conv1x1_chain_res_supported(B, H, W, C, K, N2, sb, DT[dt]):
+            wf, shf, _ = chain_res_fragments(conv3, bn3, conv1n, bn1n)
+            y = empty((B, H // 2, W // 2, K) if sb else (B, H, W, K), torch.bfloat16)
+            t1 = empty((B, H, W, N2), torch.bfloat16)
+            _lib.call("mv_conv1x1_chain_res_fwd", _ptr(x.t), _ptr(residual.t), _ptr(wf), _ptr(shf), _ptr(y), _ptr(t1), B, H, W, C, K, N2,
+                      sb, DT[dt], stream_ptr())
+            out = Act(y, "map", x.batched)
+            out.sub = 2 if sb else None
+            out.pre = (conv1n, Act(t1, "map", x.batched))
+            return out
     w3, s3, h3 = prep_conv(conv3, bn3, "krsc", dt)
     w1, s1, h1 = prep_conv(conv1n, bn1n, "krsc", dt)
     t1 = empty((B, H, W, N2), torch.bfloat16)
@@ -518,6 +530,33 @@ def chain_rc_fragments(conv3_0, bn3_0, ds_conv, ds_bn, conv3_1, bn3_1, conv1n, b
             _rc_conv1n_frags(frags, 12, w1n, c)
         sh = _rc_shift_rows(h30 + hd, h1, hn)
         hit = (_dev(frags.reshape(-1), torch.bfloat16), torch.from_numpy(sh.view(np.int32)).to(device()), (conv3_0, ds_conv, conv1n))
+        cache[key] = hit
+    return hit
+
+
+def chain_res_fragments(conv3, bn3, conv1n, bn1n):
+    """mv_conv1x1_chain_res_fwd's operands: per 32-channel chunk 4 fragments of scale3 W3 and 2 N2 / 32 of the scaled next conv1
+    (k-step s, row tile a2; accumulator order), then the shift rows shift3 | shiftN (cached on conv3)."""
+    cache = conv3._cache()
+    key = ("chain_res", _bn_id(bn3), id(conv1n), _bn_id(bn1n))
+    hit = cache.get(key)
+    if hit is None:
+        w3, h3 = _scaled_rows(conv3, bn3)
+        w1n, hn = _scaled_rows(conv1n, bn1n)
+        K, T2 = w3.shape[0], w1n.shape[0] // 32
+        frags = np.empty((K // 32, 4 + 2 * T2, 2, 32, 8), np.float32)
+        e8 = np.arange(8)
+        for c in range(K // 32):
+            rows = slice(32 * c, 32 * c + 32)
+            for fh in range(2):
+                for kk in range(4):
+                    frags[c, kk, fh] = w3[rows][:, 16 * kk + 8 * fh + e8]
+                for s_ in range(2):
+                    cols = 32 * c + 16 * s_ + 4 * fh + np.array([0, 1, 2, 3, 8, 9, 10, 11])
+                    for a2 in range(T2):
+                        frags[c, 4 + T2 * s_ + a2, fh] = w1n[32 * a2:32 * a2 + 32][:, cols]
+        sh = _rc_shift_rows(h3, hn)
+        hit = (_dev(frags.reshape(-1), torch.bfloat16), torch.from_numpy(sh.view(np.int32)).to(device()), conv1n)
         cache[key] = hit
     return hit
 

@@ -188,7 +188,15 @@ int mv_conv1x1_dual_chain_fwd(const void* x, const void* x2, const void* wcat, c
  *       pixels with even (h, w) -- the strided consumer reads it with stride 1 (mv_conv1x1_dual_fwd, stride2 = 1).
  *   (1') mv_conv1x1_chain_rc0_fwd: (1) rebuilt in (2)'s style -- t1 = relu(relu([t2 | x0] . wcat0^T + shift0) . (scaleN w1n)^T + shiftN),
  *       wfrag = 96 fragments (per chunk: the 8 of wcat0, the 4 of scaleN w1n, as in (2)), shifts = 10 rows (0-7 shift0, 8-9 shiftN);
- *       nothing is staged for a store, so twelve waves per CU fit instead of six.  Same shapes as (2). */
+ *       nothing is staged for a store, so twelve waves per CU fit instead of six.  Same shapes as (2).
+ *   (3') mv_conv1x1_chain_res_fwd: mv_conv1x1_chain_fwd / (3) in (2)'s style, for the boundary whose identity comes from memory:
+ *       y = relu(t2 . (scale3 w3)^T + shift3 + residual)  (all pixels, or with sub = 2 only those with even (h, w), compactly),
+ *       t1 = relu(y . (scaleN w1n)^T + shiftN).  wfrag = 8 x (4 + 2 N2 / 32) fragments (per chunk c: 4 of scale3 w3[32c.., :], then the
+ *       scaled w1n fragments as (k-step s, 32-row tile a2) in accumulator order), shifts = 8 rows of shift3 + N2 / 32 rows of shiftN,
+ *       both as in (2).  C = 64, K = 256, N2 = 128, N H W >= 8192. */
+int mv_conv1x1_chain_res_supported(int N, int H, int W, int C, int K, int N2, int sub, int dtype);
+int mv_conv1x1_chain_res_fwd(const void* t2, const void* residual, const void* wfrag, const void* shifts, void* y, void* t1, int N, int H,
+                             int W, int C, int K, int N2, int sub, int dtype, mv_stream_t stream);
 int mv_conv1x1_chain_rc_supported(int64_t M, int C, int K, int N2, int dtype);
 int mv_conv1x1_chain_rc0_fwd(const void* t2, const void* x0, const void* wfrag, const void* shifts, void* t1, int64_t M, int C, int K,
                              int N2, int dtype, mv_stream_t stream);

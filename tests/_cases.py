@@ -769,6 +769,71 @@ def chain_sub_case(N, H, W, seed=0):
     return run
 
 
+def chain_res_case(N, H, W, sub, seed=0):
+    """mv_conv1x1_chain_res_fwd (a bottleneck boundary with the identity read from memory, in the accumulator-layout style of
+    csrc/chain_rc.hip; N2 = 128; sub = 2: y written only at even (h, w)) vs the oracle with fp32 scales, and within the same bound of
+    mv_conv1x1_chain_fwd on the same operands; nothing behind the (compact) y may be touched."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        C, K, N2 = 64, 256, 128
+        M = N * H * W
+        f64 = np.float64
+        x = bf(rng.standard_normal((M, C)))
+        w3 = bf(rng.standard_normal((K, C)) / np.sqrt(C))
+        s3 = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        s3[::5] *= -1.0
+        h3 = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        r = bf(rng.standard_normal((M, K)))
+        w1 = bf(rng.standard_normal((N2, K)) / np.sqrt(K))
+        s1 = rng.uniform(0.5, 1.5, N2).astype(np.float32)
+        h1 = (0.1 * rng.standard_normal(N2)).astype(np.float32)
+        if not L.load().mv_conv1x1_chain_res_supported(N, H, W, C, K, N2, sub, 1):
+            return {"ok": False, "err": "mv_conv1x1_chain_res_supported says no"}
+        yref = O.relu((x.astype(f64) @ w3.astype(f64).T) * s3 + h3 + r)
+        t1ref = O.relu((bf(yref).astype(f64) @ w1.astype(f64).T) * s1 + h1)
+        w3s, w1s = bf(w3.astype(np.float32) * s3[:, None]), bf(w1.astype(np.float32) * s1[:, None])
+        T2 = N2 // 32
+        fr = np.zeros((K // 32, 4 + 2 * T2, 64, 8), np.float32)
+        for c in range(K // 32):
+            for lane in range(64):
+                fh, rr = lane // 32, lane % 32
+                for kk in range(4):
+                    fr[c, kk, lane] = w3s[32 * c + rr, 16 * kk + 8 * fh:16 * kk + 8 * fh + 8]
+                for s_ in range(2):
+                    for a2 in range(T2):
+                        for i in range(8):
+                            fr[c, 4 + T2 * s_ + a2, lane, i] = w1s[32 * a2 + rr, 32 * c + 8 * (2 * s_ + i // 4) + 4 * fh + i % 4]
+        d = {k: dev(v, "bf16") for k, v in dict(x=x, w3=w3, r=r, w1=w1, wf=bf(fr.reshape(-1))).items()}
+        f = {k: dev(v, "fp32") for k, v in dict(s3=s3, h3=h3, s1=s1, h1=h1).items()}
+        sh = torch.from_numpy(_rc_shifts(h3, h1).view(np.int32)).cuda()
+        ny = N * (H // 2) * (W // 2) * K if sub else M * K
+        ybuf = torch.full((ny + 4096,), -7.0, dtype=torch.bfloat16, device="cuda")
+        t1 = torch.full((M, N2), -7.0, dtype=torch.bfloat16, device="cuda")
+        L.call("mv_conv1x1_chain_res_fwd", d["x"].data_ptr(), d["r"].data_ptr(), d["wf"].data_ptr(), sh.data_ptr(), ybuf.data_ptr(),
+               t1.data_ptr(), N, H, W, C, K, N2, sub, 1, _stream())
+        kern = L.last_kernel()
+        y2 = torch.empty((M, K), dtype=torch.bfloat16, device="cuda")
+        t2 = torch.empty((M, N2), dtype=torch.bfloat16, device="cuda")
+        L.call("mv_conv1x1_chain_fwd", d["x"].data_ptr(), d["w3"].data_ptr(), f["s3"].data_ptr(), f["h3"].data_ptr(), d["r"].data_ptr(),
+               y2.data_ptr(), d["w1"].data_ptr(), f["s1"].data_ptr(), f["h1"].data_ptr(), t2.data_ptr(), M, C, K, N2, 1, _stream())
+        torch.cuda.synchronize()
+        if sub:
+            got_y = ybuf[:ny].view(N, H // 2, W // 2, K)
+            ref_y = yref.reshape(N, H, W, K)[:, ::2, ::2]
+            pair_y = y2.view(N, H, W, K)[:, ::2, ::2]
+        else:
+            got_y, ref_y, pair_y = ybuf[:ny].view(M, K), yref, y2
+        a = _cmp(host(got_y), ref_y, TOL_BF16)
+        b = _cmp(host(t1), t1ref, TOL_BF16)
+        dy = float((got_y.float() - pair_y.float()).abs().max())
+        dt = float((t1.float() - t2.float()).abs().max())
+        guard = bool((ybuf[ny:] == -7.0).all())
+        return {"ok": a["ok"] and b["ok"] and dy <= a["lim"] and dt <= b["lim"] and guard, "err": max(a["err"], b["err"]), "lim": a["lim"],
+                "y_vs_chain1x1": dy, "t1_vs_chain1x1": dt, "guard_band_untouched": guard, "kernel": kern}
+    return run
+
+
 def dual_case(N, Ho, Wo, C1, C2, K, stride, act=1, seed=0, flags=(), splitk=False):
     """mv_conv1x1_dual_fwd: a dense pointwise layer on x and a strided pointwise layer on x2 accumulated in one GEMM
     (scales folded into the weight rows) vs the oracle's two convolutions with fp32 scales (resnet.py:144-162, 295-303)."""
@@ -2504,6 +2569,10 @@ def all_cases():
           ("chain/rc_56x56_B4", chain_rc_case(4 * 56 * 56, seed=21)),
           ("chain/rc_ragged_many_tiles", chain_rc_case(31 * 56 * 56 + 19, seed=22)),
           ("chain/rc_min_rows", chain_rc_case(8192, seed=23)),
+          ("chain/res_56x56_B4_ysub2", chain_res_case(4, 56, 56, 2, seed=26)),
+          ("chain/res_56x56_B4_full_y", chain_res_case(4, 56, 56, 0, seed=27)),
+          ("chain/res_ragged_B37_28x30_ysub2", chain_res_case(37, 28, 30, 2, seed=28)),
+          ("chain/res_ragged_B33_full_y_many_tiles", chain_res_case(33, 57, 55, 0, seed=29)),
           ("chain/ysub2_56x56_B4", chain_sub_case(4, 56, 56, seed=24)),
           ("chain/ysub2_ragged_B37_28x30", chain_sub_case(37, 28, 30, seed=25)),
           ("chain/n128_56x56_B4", chain_case(4 * 56 * 56, seed=4, N2=128)),

@@ -1064,7 +1064,7 @@ def exported_factory_case(name, B=2, size=224, dtype="bf16"):
 def resnet50_rc_case(B=3, size=224):
     """ResNet-50 with the round-6 layer-1 plan (first block output never written, second boundary recomputes it, third block output
     written sub-sampled for the next stage's strided downsample branch; models/classification/resnet.py: _stage_rc) against the same
-    network with the plan switched off ("no_chain_rc", "no_chain_sub"): both within the bound of the oracle, the two within 2e-3 of
+    network with the plan switched off ("no_chain_rc", "no_chain_sub", "no_chain_res": round 5's launches): both within the bound of the oracle, the two within 2e-3 of
     each other (the recompute changes no rounding point; the next conv1 sums its 256 products in another order), and the launch list
     must show that the plan actually ran."""
     def run():
@@ -1081,7 +1081,7 @@ def resnet50_rc_case(B=3, size=224):
         finally:
             _lib.set_recording(old)
         names = [n for _, _, n in rec]
-        for f in ("no_chain_rc", "no_chain_sub"):
+        for f in ("no_chain_rc", "no_chain_sub", "no_chain_res"):
             _lib.set_flag(f, 1)
         try:
             net2 = _load(eqv.models.resnet50, sd)            # fresh module: no cached decisions
@@ -1092,15 +1092,16 @@ def resnet50_rc_case(B=3, size=224):
             finally:
                 _lib.set_recording(old)
         finally:
-            for f in ("no_chain_rc", "no_chain_sub"):
+            for f in ("no_chain_rc", "no_chain_sub", "no_chain_res"):
                 _lib.set_flag(f, 0)
         names2 = [n for _, _, n in rec2]
         info = _cmp(got, ref, 1e-2)
         info2 = _cmp(plain, ref, 1e-2)
         d = float(np.abs(got - plain).max())
         sub_possible = bool(_lib.load().mv_conv1x1_dual_supported(B * (size // 8) ** 2, 128, 256, 512, 1))     # small batches: no dual kernel
-        ran = "mv_conv1x1_chain_rc_fwd" in names and ("mv_conv1x1_chain_sub_fwd" in names) == sub_possible
-        off = "mv_conv1x1_chain_rc_fwd" not in names2 and "mv_conv1x1_chain_sub_fwd" not in names2
+        new = ("mv_conv1x1_chain_rc0_fwd", "mv_conv1x1_chain_rc_fwd", "mv_conv1x1_chain_res_fwd", "mv_conv1x1_chain_sub_fwd")
+        ran = all(n in names for n in new[:3])
+        off = not any(n in names2 for n in new)
         info.update({"ok": bool(info["ok"] and info2["ok"] and d <= 2e-3 and ran and off), "err_plan_off": info2["err"], "plan_vs_off": d,
                      "plan_ran": ran, "sub_sampled_output_possible": sub_possible, "plan_off_honoured": off, "launches": len(names), "launches_plan_off": len(names2)})
         return info

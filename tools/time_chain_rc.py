@@ -32,6 +32,21 @@ tab = torch.from_numpy(_rc_shifts(hK.cpu().numpy(), hK.cpu().numpy(), h64.cpu().
 _f = _rc_fragments(wcat.float().cpu().numpy(), w3.float().cpu().numpy(), w1.float().cpu().numpy()).reshape(8, 16, 64, 8)
 wf0 = torch.from_numpy(np.ascontiguousarray(np.concatenate([_f[:, :8], _f[:, 12:]], 1)).reshape(-1)).bfloat16().cuda()
 tab0 = torch.from_numpy(_rc_shifts(hK.cpu().numpy(), h64.cpu().numpy()).view(np.int32)).cuda()
+def _res_frags(w3s, w1s):
+    K, T2 = w3s.shape[0], w1s.shape[0] // 32
+    fr = np.zeros((K // 32, 4 + 2 * T2, 2, 32, 8), np.float32)
+    e8 = np.arange(8)
+    for c in range(K // 32):
+        for fh in range(2):
+            for kk in range(4):
+                fr[c, kk, fh] = w3s[32 * c:32 * c + 32][:, 16 * kk + 8 * fh + e8]
+            for s_ in range(2):
+                cols = 32 * c + 16 * s_ + 4 * fh + np.array([0, 1, 2, 3, 8, 9, 10, 11])
+                for a2 in range(T2):
+                    fr[c, 4 + T2 * s_ + a2, fh] = w1s[32 * a2:32 * a2 + 32][:, cols]
+    return fr.reshape(-1)
+wfr = torch.from_numpy(_res_frags(w3.float().cpu().numpy(), w1c.float().cpu().numpy())).bfloat16().cuda()
+shr = torch.from_numpy(_rc_shifts(hK.cpu().numpy(), h128.cpu().numpy()).view(np.int32)).cuda()
 P = lambda t: t.data_ptr() if t is not None else None
 
 launches = {
@@ -42,8 +57,11 @@ launches = {
     "chain_rc, y0 recomputed": lambda: L.call("mv_conv1x1_chain_rc_fwd", P(t21), P(t20), P(x0), P(wf), P(tab), P(y1), P(t1b), M, C, K, 64, 1, s),
     "chain -> 128, y2 full (round 5)": lambda: L.call("mv_conv1x1_chain_fwd", P(t22), P(w3), P(sK), P(hK), P(y1), P(y2), P(w1c), P(s128), P(h128), P(t1c), M, C, K, 128, 1, s),
     "chain -> 128, y2 sub-sampled": lambda: L.call("mv_conv1x1_chain_sub_fwd", P(t22), P(w3), P(sK), P(hK), P(y1), P(y2s), P(w1c), P(s128), P(h128), P(t1c), N, H, W, C, K, 128, 1, s),
+    "chain_res -> 128, y2 sub-sampled": lambda: L.call("mv_conv1x1_chain_res_fwd", P(t22), P(y1), P(wfr), P(shr), P(y2s), P(t1c), N, H, W, C, K, 128, 2, 1, s),
+    "chain_res -> 128, y2 full": lambda: L.call("mv_conv1x1_chain_res_fwd", P(t22), P(y1), P(wfr), P(shr), P(y2), P(t1c), N, H, W, C, K, 128, 0, 1, s),
 }
-mb = {"dual chain, y0 written (round 5)": 2 * M * (2 * C + K + 64), "dual chain, y0 NOT written": 2 * M * (2 * C + 64),
+mb = {"chain_res -> 128, y2 sub-sampled": 2 * M * (C + K + K // 4 + 128), "chain_res -> 128, y2 full": 2 * M * (C + 2 * K + 128),
+      "dual chain, y0 written (round 5)": 2 * M * (2 * C + K + 64), "dual chain, y0 NOT written": 2 * M * (2 * C + 64),
       "chain_rc0, y0 NOT written": 2 * M * (2 * C + 64),
       "chain, residual y0 read (round 5)": 2 * M * (C + 2 * K + 64), "chain_rc, y0 recomputed": 2 * M * (3 * C + K + 64),
       "chain -> 128, y2 full (round 5)": 2 * M * (C + 2 * K + 128), "chain -> 128, y2 sub-sampled": 2 * M * (C + K + K // 4 + 128)}
@@ -66,7 +84,7 @@ print(f"# ResNet-50 layer-1 boundaries, {N} images ({M} pixels), each launch alo
 tot = {"round 5": 0.0, "round 6": 0.0}
 for name, fn in launches.items():
     us = t(fn)
-    if name != "dual chain, y0 NOT written":
+    if name not in ("dual chain, y0 NOT written", "chain -> 128, y2 sub-sampled", "chain_res -> 128, y2 full"):
         tot["round 5" if "round 5" in name else "round 6"] += us
     print(f"{name:36s} [{L.last_kernel():40s}] {us:7.1f} us  {mb[name] / 1e6:6.1f} MB algorithmic  {mb[name] / us / 1e6:5.2f} TB/s")
 print(f"sum of the three boundaries: round 5 {tot['round 5']:.1f} us, round 6 {tot['round 6']:.1f} us")
