@@ -16,11 +16,11 @@ Extra objects in the line:
                events and rocprofv3 agree to 1-3 %).  `achieved` = its algorithmic FLOPs per launch (2 x MACs, `flop_per_launch`) /
                its average launch duration (`avg_launch_us`), measured live with HIP events on the launch stream right after the
                timed region; `rocprof` = the same kernel's `avg_us_warm` in the committed summary of `bench.py --lanes 1`
-               (profiles/r04/<model>_lanes1_rocprofv3_warm_stats.txt) and the fraction that follows from it.  `two_lanes`: the same
+               (profiles/<round>/<model>_lanes1_rocprofv3_warm_stats.txt: the directory profiles/traffic.json names) and the fraction that follows from it.  `two_lanes`: the same
                measurement IN SITU in the two-lane graph's launch lists (eager two-stream replay; a launch then shares the chip with
-               the other lane's kernel, and a profiler changes that overlap: profiles/r04/README.md);
+               the other lane's kernel, and a profiler changes that overlap: profiles/r04/README.md, round 4's measurement);
                `frac` = achieved / 2.5 PFLOP/s (dense bf16 MFMA peak).  `rocprof`: the same kernel's warm average in the committed
-               rocprofv3 summary (profiles/traffic.json -> profiles/r04/<model>_rocprofv3_warm_stats.txt) and the fraction that
+               rocprofv3 summary (profiles/traffic.json -> profiles/<round>/<model>_rocprofv3_warm_stats.txt) and the fraction that
                follows from it.  `alone_frac` / `lanes1`: the same model as ONE launch list (lanes
                overlap in time, so only there does the sum over the dominant kernel's launches compare with a step);
                `isolated` (with --layers): every launch alone on the chip.  `whole_forward`: SURVEY section 8d's FLOPs per
@@ -40,6 +40,20 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _profile_dir() -> str:
+    """The profiles/<round> directory that profiles/traffic.json (written by tools/collect_profiles.sh together with the files it
+    cites) points at."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        for sect in ("_rocprof_lanes1", "_rocprof"):
+            for mod in tj.get(sect, {}).values():
+                for ent in mod.values():
+                    return os.path.dirname(ent["file"])
+    except Exception:  # noqa: BLE001
+        pass
+    return "profiles"
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -185,6 +199,28 @@ def launch_meta(name, args):
         flops = 2.0 * M * (C * K + K * N2)
         byts = 2.0 * M * (C + 2 * K + N2)
         shape = f"M{M} {C}->{K}(+res)->{N2}"
+    elif name == "mv_conv1x1_chain_rc0_fwd":        # the reference's work of this boundary (conv3 + downsample conv + next conv1); y is not stored
+        M, C, K, N2 = args[5:9]
+        flops = 2.0 * M * (2 * C * K + K * N2)
+        byts = 2.0 * M * (2 * C + N2)
+        shape = f"M{M} {C}+{C}->{K}(not stored)->{N2}"
+    elif name == "mv_conv1x1_chain_rc_fwd":         # algorithmic FLOPs = conv3 + next conv1; the recomputed identity (2 M 2C K) is not counted
+        M, C, K, N2 = args[7:11]
+        flops = 2.0 * M * (C * K + K * N2)
+        byts = 2.0 * M * (3 * C + K + N2)
+        shape = f"M{M} {C}->{K}(+recomputed identity from {C}+{C})->{N2}"
+    elif name == "mv_conv1x1_chain_res_fwd":
+        N, H, W, C, K, N2, sub = args[6:13]
+        M = N * H * W
+        flops = 2.0 * M * (C * K + K * N2)
+        byts = 2.0 * M * (C + K + (K // 4 if sub else K) + N2)
+        shape = f"M{M} {C}->{K}(+res{', stored at even pixels' if sub else ''})->{N2}"
+    elif name == "mv_conv1x1_chain_sub_fwd":
+        N, H, W, C, K, N2 = args[10:16]
+        M = N * H * W
+        flops = 2.0 * M * (C * K + K * N2)
+        byts = 2.0 * M * (C + K + K // 4 + N2)
+        shape = f"M{M} {C}->{K}(+res, stored at even pixels)->{N2}"
     elif name == "mv_conv1x1_dual_chain_fwd":
         M, C1, C2, K, N2 = args[10:15]
         flops = 2.0 * M * ((C1 + C2) * K + K * N2)
@@ -471,7 +507,7 @@ def run_model(a, name, B, rank, world, soak_s):
             "avg_launch_us": round(dv["us"] / max(1, dv["n"]), 2),
             "how": f"in situ: eager replay of the {nl}-lane launch lists on {nl} stream(s), two HIP events around every launch on "
                    "its own stream, 6 steps (the LAST 6 x launches_per_step rows of a rocprofv3 --kernel-trace of this command are "
-                   "this pass: profiles/r04/roofline_vs_rocprof.txt compares the two clocks)",
+                   f"this pass: {_profile_dir()}/roofline_vs_rocprof.txt compares the two clocks)",
             "share_of_kernel_time": round(dv["us"] / max(1e-9, sum(r_["us"] for r_ in rows)), 3),
             "flop_per_launch": round(dv["gflop"] * 1e9 / max(1, dv["n"])),
             "kernel_hbm_gbs": round(dv["mb"] / dv["us"] * 1e3, 1) if dv["us"] else 0.0,
@@ -508,7 +544,7 @@ def run_model(a, name, B, rank, world, soak_s):
         # THE headline figure: the dominant kernel of the ONE-lane list.  Only there do the per-kernel durations add up to a step
         # (sum_all_kernels_ms ~ ms_per_step_eager) and only there do HIP events and a rocprofv3 trace of `bench.py --lanes 1` agree
         # (1-3 %): with two lanes a launch shares the chip with the other lane's kernel, and rocprofv3 itself changes how much the
-        # lanes overlap (profiles/r04/README.md), so the two-lane in-situ figure (`roofline.two_lanes`) has no second clock.
+        # lanes overlap (round 4's measurement: profiles/r04/README.md), so the two-lane in-situ figure (`roofline.two_lanes`) has no second clock.
         rp1 = None
         try:
             tjd = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))

@@ -21,7 +21,9 @@ def fam(name):
                    ("igemm2_kernel<2, 4, 4, 2, 2", "igemm2_bf16_256x256"), ("igemm2_kernel<8, 1, 1, 2, 3", "igemm2_bf16_256x64"),
                    ("igemm_bf16_kernel<128, 128", "igemm_bf16_128x128"), ("igemm_bf16_kernel<128, 64", "igemm_bf16_128x64"),
                    ("stream1x1_kernel", "stream1x1"), ("chain1x1_kernel<64, 8, false", "chain1x1_bf16_64_256_64"),
-                   ("chain1x1_kernel<128", "chain1x1_bf16_64_256_128"), ("chain1x1_kernel<64, 6, true", "chain1x1_dual_bf16_64+64_256_64"), ("chain_stream_kernel", "chain_stream_bf16_128_512_128"),
+                   ("chain1x1_kernel<128, 6, false, true", "chain1x1_bf16_64_256_128_ysub2"), ("chain1x1_kernel<128", "chain1x1_bf16_64_256_128"), ("chain1x1_kernel<64, 6, true", "chain1x1_dual_bf16_64+64_256_64"), ("chain_stream_kernel", "chain_stream_bf16_128_512_128"),
+                   ("chain_rc_kernel<0", "chain_rc0_bf16_64x2_256_64"), ("chain_rc_kernel<1", "chain_rc1_bf16_64x3_256_64"),
+                   ("chain_res_kernel<128, true", "chain_res_bf16_64_256_128_ysub2"), ("chain_res_kernel<128, false", "chain_res_bf16_64_256_128"),
                    ("conv3x3c64_v2_kernel", "conv3x3c64_halo"), ("stem_pool_kernel<float, true, 11", "stem_pool11_mfma_f32in"), ("stem_pool_kernel", "stem_pool_mfma_f32in"),
                    ("patch_embed_kernel", "patch_embed_mfma_f32in"), ("mha_mfma_kernel", "mha_mfma_dh64_hm"),
                    ("layernorm_vec_kernel", "layernorm_vec"), ("layernorm_slim_kernel", "layernorm_slim"), ("ln_mlp96_kernel", "ln_mlp96_f32stream"), ("swin_attn_mfma", "swin_attn_mfma"), ("skinny_f32_kernel", "skinny_linear_f32_mfma"),
