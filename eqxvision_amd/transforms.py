@@ -64,7 +64,7 @@ MAX_INPLACE_VARIANTS = 2   # per signature: graphs that read resident device inp
 
 
 class _Compiled:
-    __slots__ = ("static_in", "calls", "keep", "out", "graph", "replays", "refs", "lane_calls", "own_resident", "hooks")
+    __slots__ = ("static_in", "calls", "keep", "out", "graph", "replays", "refs", "lane_calls", "own_resident", "hooks", "lane_graphs", "done")
 
     def __init__(self):
         self.own_resident = False      # True: resident device inputs are copied into owned buffers before each replay
@@ -77,6 +77,8 @@ class _Compiled:
         self.replays = 0
         self.refs = None
         self.hooks = []                # run after every replay (ops register them while recording: _act.on_replay)
+        self.lane_graphs = None        # join="stream": one hipGraph per lane, launched on the jitted function's lane streams
+        self.done = None               # join="stream": the event each lane records behind its last launch of the latest call
 
 
 def _is_key_array(x) -> bool:
@@ -244,17 +246,40 @@ def _release(c: "_Compiled"):
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
         c.graph = None
+    if c.lane_graphs:
+        try:
+            torch.cuda.synchronize()
+            for g in c.lane_graphs:
+                _lib.call("mv_graph_destroy", g)
+        except Exception:  # noqa: BLE001
+            pass
+        c.lane_graphs, c.done = None, None
     c.calls, c.lane_calls, c.keep, c.static_in, c.refs, c.out = [], None, [], [], None, None
 
 
-def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bool = True, lanes: int = 1) -> Callable:
+def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bool = True, lanes: int = 1, join: str = "call") -> Callable:
     """`lanes` > 1 (an extension; the reference has no counterpart): the batch is cut into `lanes` contiguous
     sub-batches whose launch lists are captured as PARALLEL branches of the hipGraph (one stream each).  The
     kernels are the same, so are the results; what changes is that the mostly empty last round of CUs of one
     sub-batch's kernel is filled by the other sub-batch's next kernel instead of idling (tile quantisation:
-    e.g. 784 / 392 / 196 tiles on 256 CUs for the ResNet-50 3x3 layers at batch 256)."""
+    e.g. 784 / 392 / 196 tiles on 256 CUs for the ResNet-50 3x3 layers at batch 256).
+
+    `join` (with lanes > 1): "call" (default) -- the lanes join inside the call: when it returns, the result is complete in
+    stream order on the caller's stream, `jax.jit`'s contract as a torch user reads it.  "stream" (opt-in, round 6) -- each lane has
+    its own stream and its own graph and the call returns WITHOUT joining: the next call's first lane starts while this call's last
+    lane is still finishing (the tail of a forward -- pooling, classifier -- runs at half occupancy otherwise: resnet50 +2 %, alexnet
+    +12 % in tools/lane_offset.py).  That is jax's ASYNCHRONOUS dispatch made explicit: the returned tensors are futures until
+    `jitted.ready()` (makes the current stream wait for the latest call; `jitted.block_until_ready()` also synchronises the host).
+    Results alternate between TWO sets of buffers, so one stays valid until the second next call; inputs are read in place and must
+    not be overwritten before `ready()`.  Requires clone_outputs=False and device-resident inputs."""
     if fn is None:
-        return functools.partial(filter_jit, use_graph=use_graph, clone_outputs=clone_outputs, lanes=lanes)
+        return functools.partial(filter_jit, use_graph=use_graph, clone_outputs=clone_outputs, lanes=lanes, join=join)
+    if join not in ("call", "stream"):
+        raise ValueError(f"filter_jit: join must be 'call' or 'stream', got {join!r}")
+    if join == "stream" and (clone_outputs or not use_graph or lanes < 2):
+        raise ValueError("filter_jit(join='stream') needs lanes >= 2, use_graph=True and clone_outputs=False (a clone would read the "
+                         "result on the caller's stream before the lanes have produced it)")
+    pipe = {"streams": None, "last": None}      # join="stream": the lane streams of this function, the entry of the latest call
     import collections
     cache = collections.OrderedDict()
     eager_structs = set()      # argument structures found not replayable (training steps): run eagerly, see `jitted`
@@ -387,9 +412,14 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
                     _release(oc)
         else:
             cache.move_to_end(key)
+        if join == "stream":                       # two buffer sets per input-address tuple, used in turn
+            if len(ptrs) != sum(1 for v in flat_all if _is_array(v) and not _is_key_array(v)):
+                raise ValueError("filter_jit(join='stream'): every array argument must be a device-resident tensor (read in place)")
+            grp["turn"] = 1 - grp.get("turn", 1)
+            ptrs = ptrs + (("turn", grp["turn"]),)
         c = grp["variants"].get(ptrs)
         own = False
-        if c is None and ptrs and len(grp["variants"]) >= MAX_INPLACE_VARIANTS:
+        if c is None and ptrs and join != "stream" and len(grp["variants"]) >= MAX_INPLACE_VARIANTS:
             c, own = grp["owned"], True
         elif c is not None:
             own = c.own_resident
@@ -446,11 +476,45 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
                 grp["owned"] = c
             else:
                 grp["variants"][ptrs] = c
+            if join == "stream":
+                if c.lane_calls is None:
+                    raise ValueError("filter_jit(join='stream'): the function could not be split into lanes (batch not divisible, or "
+                                     "outputs that are not batched tensors)")
+                pipe["last"] = None                # the trace ran on the caller's stream: complete in stream order
             return _outputs(c)
         # refresh the static input buffers, then replay
         for dst, src in zip(c.static_in, flat_arrays):
             dst.copy_(src if isinstance(src, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(src)),
                       non_blocking=True)
+        if join == "stream":
+            import ctypes
+            cur = torch.cuda.current_stream()
+            if pipe["streams"] is None:
+                pipe["streams"] = [torch.cuda.Stream() for _ in c.lane_calls]
+            if c.lane_graphs is None:              # one graph per lane, captured on that lane's stream
+                gs = []
+                for st_l, calls in zip(pipe["streams"], c.lane_calls):
+                    st_l.wait_stream(cur)
+                    with torch.cuda.stream(st_l):
+                        _lib.call("mv_graph_begin_capture", stream_ptr())
+                        g = ctypes.c_void_p()
+                        try:
+                            _replay_list(calls)
+                        finally:
+                            _lib.call("mv_graph_end_capture", stream_ptr(), ctypes.byref(g))
+                    gs.append(g)
+                c.lane_graphs = gs
+                c.done = [torch.cuda.Event() for _ in gs]
+            ready = torch.cuda.Event()
+            ready.record(cur)                      # everything the caller queued (its writes to the inputs) comes first
+            for st_l, g, ev in zip(pipe["streams"], c.lane_graphs, c.done):
+                st_l.wait_event(ready)
+                with torch.cuda.stream(st_l):
+                    _lib.call("mv_graph_launch", g, stream_ptr())
+                    ev.record(st_l)
+            pipe["last"] = c
+            c.replays += 1
+            return c.out
         if use_graph and c.graph is None and c.calls:
             # capture on a private stream (the legacy default stream cannot be captured); it first waits
             # for everything already queued on the caller's stream
@@ -492,6 +556,20 @@ def filter_jit(fn: Callable = None, *, use_graph: bool = True, clone_outputs: bo
         c.replays += 1
         return _outputs(c)
 
+    def ready(stream=None):
+        """join="stream": make `stream` (default: the current one) wait for the latest call's lanes."""
+        c = pipe["last"]
+        if c is not None and c.done:
+            st = stream if stream is not None else torch.cuda.current_stream()
+            for ev in c.done:
+                st.wait_event(ev)
+
+    def block_until_ready():
+        ready()
+        torch.cuda.current_stream().synchronize()
+
+    jitted.ready = ready
+    jitted.block_until_ready = block_until_ready
     jitted._cache = cache
     jitted._eager_structs = eager_structs
     jitted._entries = lambda: [c for g in cache.values()

@@ -48,7 +48,11 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  *                   1x1 / Linear shapes), "no_splitk", "splitk_min_nk" (tests: split short reductions too), "igemm2_tile" (1 / 2 / 3),
  *                   "no_igemm2", "igemm_tile" (1 / 2), "no_skinny", "no_tuned", "no_dual", and the per-shape choice
  *                   "ov:<M>:<C>:<K>:<R>:<S>:<stride>" / "ovh:<M>:<N>:<K>:1:1:1" / "ovd:<M>:<C1>:<C2>:<K>:<stride>:1" (tools/tune_tiles.py)
- *   streaming 1x1   "no_stream", "no_stream_narrow", "no_chain", "no_chain_stream", "no_dual_chain", "no_ln_stream", "ln_stream_192"
+ *   streaming 1x1   "no_stream", "no_stream_narrow", "no_chain", "no_chain_stream", "no_dual_chain", "no_ln_stream", "ln_stream_192",
+ *                   "no_chain_rc" (the layer-1 plan that leaves the first block output un-written: mv_conv1x1_chain_rc*_supported say no),
+ *                   "no_chain_rc0" (host: first boundary on mv_conv1x1_dual_chain_fwd with y = NULL instead of mv_conv1x1_chain_rc0_fwd),
+ *                   "no_chain_res" (last boundary on chain1x1's form), "no_chain_sub" (block output written whole, not sub-sampled),
+ *                   "no_swin_precise" (host: plain bf16 block Linears for Swin widths off the fused kernels)
  *   whole blocks    "no_bneck_tail",
  *                   "no_ln_mlp", "ln_mlp_waves" (8 / 12 / 16), "no_ln_mlp_stream", "no_swin_block_attn", "swin_c96_shared" (the
  *                   two-windows-per-workgroup kernel at C = 96), "no_patch_merge_ln", "no_patch4_ln", "no_fc_stream"
@@ -57,7 +61,7 @@ enum { MV_OK = 0, MV_E_INVALID = -1, MV_E_UNSUPPORTED = -2, MV_E_OOM = -3 };
  *                   "affine_scalar", "dropout_x8", "dropout_scalar", "no_f32_mfma" (fp32 contractions back on the VALU kernel), "no_f32_lds" (only the direct fp32 matrix-core kernel), "no_attn_f32_lds" (fp32 attention back on the one-wave-per-query kernels),
  *                   "wgrad_valu" / "dgrad_valu" (the one-thread-per-element gradient kernels: cross-check)
  * The debug build (EQV_PROF=1 python -m eqxvision_amd.build -> libeqxvision_amd_prof.so) additionally reads "prof_hi" / "prof_lo"
- * (a device buffer for per-wave phase stamps), "*_prof", "i8_skew", "i8_ablate", "strip_skew", "ln_mlp_dbg": none of them exists in
+ * (a device buffer for per-wave phase stamps), "*_prof", "i8_skew", "i8_ablate", "strip_skew", "ln_mlp_dbg", "rc_dbg" (chain_rc ablations): none of them exists in
  * the product library. */
 
 int mv_abi_version(void);

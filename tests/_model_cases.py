@@ -1061,6 +1061,50 @@ def exported_factory_case(name, B=2, size=224, dtype="bf16"):
     return run
 
 
+def join_stream_case(B=8, lanes=2):
+    """filter_jit(lanes=2, join="stream") (the lanes are not joined per call: results are futures until `ready()`): five calls with
+    the input rewritten in place between `ready()`s must give, bit for bit, what the default (joined) forward gives for the same
+    images; the two latest results live in different buffers; misuse raises."""
+    def run():
+        import eqxvision_amd as eqv
+        sd = S.resnet_state(1, "bottleneck", (1, 1, 1, 1), 10)
+        blk = eqv.models.classification.resnet._ResNetBottleneck
+        fac = lambda torch_weights=None, **kw: eqv.models.classification.resnet._resnet(blk, [1, 1, 1, 1], torch_weights, **kw)
+        net = _load(fac, sd, num_classes=10)
+        body = lambda n, im, k: eqv.vmap(n, axis_name="batch")(im, key=k)
+        with eqv.precision("bf16"):
+            fj = eqv.filter_jit(body, clone_outputs=False, lanes=lanes)
+            fp = eqv.filter_jit(body, clone_outputs=False, lanes=lanes, join="stream")
+            x = torch.from_numpy(S.synthetic_images(B, 64, seed=0)).cuda()
+            errs, ptrs = [], []
+            for seed in range(1, 7):
+                x.copy_(torch.from_numpy(S.synthetic_images(B, 64, seed=seed)).cuda())
+                got = fp(net, x, _keys(B))
+                fp.ready()
+                ref = fj(net, x, _keys(B)).clone()
+                torch.cuda.synchronize()
+                errs.append(float((got - ref).abs().max()))
+                ptrs.append(got.data_ptr())
+            # back-to-back calls without ready() in between (the pipelined use), same input: the last result must still be right
+            for _ in range(5):
+                got = fp(net, x, _keys(B))
+            fp.block_until_ready()
+            errs.append(float((got - ref).abs().max()))
+            refused = 0
+            for kw in (dict(lanes=1, join="stream", clone_outputs=False), dict(lanes=2, join="stream"), dict(lanes=2, join="bogus")):
+                try:
+                    eqv.filter_jit(body, **kw)
+                except ValueError:
+                    refused += 1
+            try:
+                fp(net, S.synthetic_images(B, 64, seed=0), _keys(B))       # a host array: not read in place
+            except ValueError:
+                refused += 1
+        ok = max(errs) == 0.0 and len(set(ptrs[-2:])) == 2 and refused == 4
+        return {"ok": bool(ok), "err": max(errs), "errs": errs, "two_buffer_sets": len(set(ptrs)) == 2, "misuse_refused": refused}
+    return run
+
+
 def resnet50_rc_case(B=3, size=224):
     """ResNet-50 with the round-6 layer-1 plan (first block output never written, second boundary recomputes it, third block output
     written sub-sampled for the next stage's strided downsample branch; models/classification/resnet.py: _stage_rc) against the same
@@ -1160,7 +1204,8 @@ def all_cases(full=True):
          ("model/filter_jit_replay", jit_case()),
          ("model/filter_jit_lanes2_resnet", lanes_case("resnet", 2, 6)),
          ("model/filter_jit_lanes3_resnet", lanes_case("resnet", 3, 6)),
-         ("model/filter_jit_fresh_device_inputs", fresh_inputs_case())]
+         ("model/filter_jit_fresh_device_inputs", fresh_inputs_case()),
+         ("model/filter_jit_lanes2_join_stream_futures", join_stream_case())]
     if full:
         c += [("model/alexnet_features_B2", alexnet_case(2, features_only=True)),
               ("model/alexnet_B4_bf16", alexnet_case(4)),

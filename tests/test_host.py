@@ -554,3 +554,20 @@ def test_filter_jit_structure_signature_ignores_leaf_identity():
     other = eqv.models.alexnet(num_classes=4, key=eqv.random.PRNGKey(0))
     assert _struct_sig(other) != _struct_sig(net)
     assert _struct_sig(eqv.tree_inference(net, True)) != _struct_sig(eqv.tree_inference(net, False))
+
+
+def test_shift_rows_of_the_recompute_chain_kernels():
+    """ops._rc_shift_rows (the host side of mv_conv1x1_chain_rc*_fwd / chain_res_fwd's `shifts` operand) against the layout the header
+    documents, written out independently in tests/_cases.py: 64 words per 32 values, word r < 32 = bf16 hi | bf16 lo << 16 with
+    hi + lo equal to the fp32 value to 16 mantissa bits, words 32 .. 63 zero."""
+    from eqxvision_amd.ops import _rc_shift_rows
+    from tests._cases import _rc_shifts
+    rng = np.random.Generator(np.random.PCG64(3))
+    a, b = rng.standard_normal(256).astype(np.float32), (10.0 * rng.standard_normal(64)).astype(np.float32)
+    got, ref = _rc_shift_rows(a, b), _rc_shifts(a, b)
+    assert got.shape == (10, 64) and got.dtype == np.uint32 and np.array_equal(got, ref)
+    assert not got[:, 32:].any()
+    hi = ((got[:, :32] & 0xffff) << 16).astype(np.uint32).view(np.float32).reshape(-1)
+    lo = (got[:, :32] & 0xffff0000).astype(np.uint32).view(np.float32).reshape(-1)
+    v = np.concatenate([a, b])
+    assert np.abs(hi + lo - v).max() <= 2.0 ** -16 * np.abs(v).max()

@@ -2,7 +2,7 @@
 # Round profiles: rocprofv3 kernel statistics of the bench command per model (in-situ durations, two graph lanes), HBM traffic
 # per launch from separate --pmc passes (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE), and an SQ pass with the
 # matrix-pipe busy counter.  usage: tools/profile_session.sh TAG [ROUND]  ->  gpurun_out/TAG/{MODEL}_*  (copy what matters to profiles/ROUND)
-TAG=${1:-prof}; export ROUND=${2:-r04}
+TAG=${1:-prof}; export ROUND=${2:-r06}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
 for spec in resnet50:256 vit_base:256 swin_t:128 alexnet:256; do
