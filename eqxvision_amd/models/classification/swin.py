@@ -103,14 +103,15 @@ class _ShiftedWindowAttention(Module):
         """The reference's `_func_dropout` (swin.py:17-20, 227, 233) has no inference switch: a non-zero rate drops in EVERY mode."""
         return self.attention_dropout > 0 or self.dropout > 0
 
-    def _forward(self, x: Act, residual: Optional[Act] = None, norm=None, key=None) -> Act:
+    def _forward(self, x: Act, residual: Optional[Act] = None, norm=None, key=None, precise: Optional[bool] = None) -> Act:
         """`norm` given: x is the UN-normalised input and the LayerNorm is folded into the qkv Linear where possible."""
         x = ops.as_map(x)
         B, Hf, Wf, C = x.t.shape
         if Hf % self.window_size[0] or Wf % self.window_size[1]:
             raise ValueError(f"feature map {Hf}x{Wf} is not a multiple of the window {self.window_size} "
                              "(the reference does not pad either, swin.py:782-790)")
-        precise = ops.swin_precise(C)            # widths off the fused kernels (swin_b): split-precision block Linears
+        if precise is None:
+            precise = ops.swin_precise(C)        # widths off the fused kernels (swin_b): split-precision block Linears
         if precise:
             qkv = ops.linear_split(x if norm is None else ops.layernorm(x, norm), self.qkv)
         else:
@@ -162,17 +163,21 @@ class _SwinTransformerBlock(Module):
         attn_live = bool(getattr(self.attn, "_live", lambda: False)())
         mlp_live = isinstance(self.mlp, MlpProjection) and self.mlp._live()
         if (sd.inference or sd.p == 0.0) and not attn_live and not mlp_live:
+            # `_deep_stage` (set by SwinTransformer on the blocks of a stage deeper than 6: swin_s / swin_b's 18-block stage 2): the bf16
+            # rounding of the block Linears' weights adds up over the blocks -- swin_s sat at 9.97e-3 of the 1e-2 bound on the fused
+            # kernels -- so those blocks take the split-precision path (ops.swin_precise) like the widths without fused kernels
+            precise = ops.swin_precise(x.t.shape[-1]) or (getattr(self, "_deep_stage", False) and ops.swin_precise(0))
             if type(self.attn) is _ShiftedWindowAttention and isinstance(self.norm1, nn.LayerNorm):
-                y = ops.swin_block_attention(x, self.norm1, self.attn)     # the whole attention half, one workgroup per window
-                x = y if y is not None else self.attn._forward(x, residual=x, norm=self.norm1)
+                y = None if precise else ops.swin_block_attention(x, self.norm1, self.attn)     # the whole attention half, one workgroup per window
+                x = y if y is not None else self.attn._forward(x, residual=x, norm=self.norm1, precise=precise)
             else:
                 x = self.attn._forward(self.norm1(x), residual=x)
             if isinstance(self.mlp, MlpProjection):
-                y = ops.ln_mlp(x, self.norm2, self.mlp)              # one launch where the weights fit in LDS (stage 0)
+                y = None if precise else ops.ln_mlp(x, self.norm2, self.mlp)   # one launch where the weights fit in LDS (stage 0)
                 if y is not None:
                     return y
                 if isinstance(self.norm2, nn.LayerNorm):
-                    return self.mlp._forward(x, residual=x, norm=self.norm2, precise=ops.swin_precise(x.t.shape[-1]))
+                    return self.mlp._forward(x, residual=x, norm=self.norm2, precise=precise)
             return self.mlp._forward(self.norm2(x), residual=x)
         if key is None:
             raise RuntimeError("stochastic depth outside inference mode / Swin dropout > 0 requires a key")
@@ -219,6 +224,9 @@ class SwinTransformer(Module):
                                    mlp_ratio=mlp_ratio, dropout=dropout, attention_dropout=attention_dropout,
                                    stochastic_depth_prob=sd_prob, norm_layer=norm_layer, key=keys[0]))
                 bid += 1
+            if depths[i_stage] > 6:                # a non-field attribute: travels with tree copies, invisible to the leaf order
+                for blk in stage:
+                    object.__setattr__(blk, "_deep_stage", True)
             stack.append(nn.Sequential(stage))
             if i_stage < len(depths) - 1:
                 keys = jr.split(keys[1], 2)
