@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MV_ABI_VERSION 2   /* 2 (round 6): mv_bottleneck_strip_* gone, mv_bn_train_dz_coef_f32 / mv_device_status / the layer-1 recompute
+#define MV_ABI_VERSION 2   /* 2 (round 6): mv_bottleneck_strip_* gone, mv_bn_train_dz_coef_f32 / mv_device_status / the layer-1 plan (rc0, rc, res, sub)
                             * chain entries added, every scratch consumer keeps its data behind a 4096-byte sync header */
 
 typedef void* mv_stream_t; /* hipStream_t */
