@@ -571,3 +571,68 @@ def test_shift_rows_of_the_recompute_chain_kernels():
     lo = (got[:, :32] & 0xffff0000).astype(np.uint32).view(np.float32).reshape(-1)
     v = np.concatenate([a, b])
     assert np.abs(hi + lo - v).max() <= 2.0 ** -16 * np.abs(v).max()
+
+
+def _launch_list(monkeypatch, factory, sd_fn, B, size=224, flags=()):
+    """The C-ABI entries a forward would call, in order, WITHOUT a GPU: every launch is replaced by a recorder and every device
+    allocation by a CPU tensor (the host-side dispatch -- which kernel serves which layer -- is pure Python + the library's
+    `_supported` entries, which need no device)."""
+    import torch
+    import eqxvision_amd as eqv
+    from eqxvision_amd import _act, _lib, ops
+    names = []
+
+    def fake_call(name, *a):
+        names.append(name)
+        return 0
+    monkeypatch.setattr(_lib, "call", fake_call)
+    monkeypatch.setattr(_act, "device", lambda: torch.device("cpu"))
+    monkeypatch.setattr(ops, "device", lambda: torch.device("cpu"))
+    monkeypatch.setattr(ops, "empty", lambda shape, dtype: torch.zeros(shape, dtype=dtype))
+    monkeypatch.setattr(_act, "empty", lambda shape, dtype: torch.zeros(shape, dtype=dtype))
+    monkeypatch.setattr(ops, "stream_ptr", lambda: 0)
+    monkeypatch.setattr(ops, "_dev", lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt))
+    monkeypatch.setattr(ops, "_splitk_scratch", lambda *a, **k: None)
+    for f in flags:                                      # (the real entry: _lib.call is the recorder now)
+        _lib.load().mv_set_flag(f.encode(), 1)
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            p = os.path.join(td, "w.pth")
+            S.save_pth(sd_fn(), p)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                net = eqv.tree_inference(factory(torch_weights=p), True)
+        with eqv.precision("bf16"):
+            eqv.vmap(net, axis_name="batch")(torch.zeros(B, 3, size, size), key=eqv.random.split(eqv.random.PRNGKey(0), B))
+    finally:
+        for f in flags:
+            _lib.load().mv_set_flag(f.encode(), 0)
+    return [n for n in names if n != "mv_set_scratch"]
+
+
+def test_resnet50_layer1_plan_launch_list(monkeypatch, built_lib):
+    """Round 6's layer-1 plan, host side: at B >= 3 (>= 8192 pixels at 56 x 56) the three block boundaries of ResNet-50's first stage
+    are mv_conv1x1_chain_rc0_fwd (block 0's output never written) -> mv_conv1x1_chain_rc_fwd (it is recomputed) ->
+    mv_conv1x1_chain_res_fwd; below that, and with the plan switched off, the round-5 entries; the launch COUNT is the same either way."""
+    import eqxvision_amd as eqv
+    new = ("mv_conv1x1_chain_rc0_fwd", "mv_conv1x1_chain_rc_fwd", "mv_conv1x1_chain_res_fwd")
+    on = _launch_list(monkeypatch, eqv.models.resnet50, lambda: S.resnet_state(1), 4)
+    assert [n for n in on if n in new] == list(new)
+    assert on.index("mv_conv1x1_chain_rc0_fwd") < on.index("mv_conv1x1_chain_rc_fwd") < on.index("mv_conv1x1_chain_res_fwd")
+    assert "mv_conv1x1_dual_chain_fwd" not in on and "mv_conv1x1_chain_fwd" not in on          # (layer 2 chains from 16 384 pixels up: not at B = 4)
+    off = _launch_list(monkeypatch, eqv.models.resnet50, lambda: S.resnet_state(1), 4, flags=("no_chain_rc", "no_chain_res", "no_chain_sub"))
+    assert not any(n in off for n in new) and "mv_conv1x1_dual_chain_fwd" in off and off.count("mv_conv1x1_chain_fwd") == 2
+    assert len(on) == len(off)
+    small = _launch_list(monkeypatch, eqv.models.resnet50, lambda: S.resnet_state(1), 2)           # 6272 pixels: below every chain kernel
+    assert not any(n in small for n in new) and "mv_conv1x1_chain_fwd" not in small
+
+
+def test_layer1_plan_only_where_the_stage_matches(monkeypatch, built_lib):
+    """A stage that is not three 64 -> 256 bottlenecks never sees the plan: basic blocks (resnet34), width 128 (wide_resnet50_2)."""
+    import eqxvision_amd as eqv
+    new = ("mv_conv1x1_chain_rc0_fwd", "mv_conv1x1_chain_rc_fwd", "mv_conv1x1_chain_res_fwd")
+    r34 = _launch_list(monkeypatch, eqv.models.resnet34, lambda: S.resnet_state(1, "basic", (3, 4, 6, 3), 1000), 4)
+    wide = _launch_list(monkeypatch, eqv.models.wide_resnet50_2, lambda: S.resnet_state(1, "bottleneck", (3, 4, 6, 3), 1000, width_per_group=128), 4)
+    assert not any(n in r34 for n in new) and not any(n in wide for n in new)
+    r101 = _launch_list(monkeypatch, eqv.models.resnet101, lambda: S.resnet_state(1, "bottleneck", (3, 4, 23, 3), 1000), 4)
+    assert [n for n in r101 if n in new] == list(new)
