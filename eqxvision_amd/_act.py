@@ -134,7 +134,7 @@ def on_replay(fn) -> None:
 
 
 class Act:
-    __slots__ = ("t", "kind", "batched", "pre", "node", "sub")
+    __slots__ = ("t", "kind", "batched", "pre", "node", "sub", "ln")
 
     def __init__(self, t: torch.Tensor, kind: str, batched: bool):
         self.t = t
@@ -143,6 +143,9 @@ class Act:
         self.pre = None     # (module, Act): the result of applying `module` (+ its norm + relu) to this activation was
                             # already produced by the launch that produced it (ops.conv1x1_chain)
         self.node = None    # under filter_value_and_grad: the autograd node that produced this activation (grad.py)
+        self.ln = None      # (low plane, per-row statistics pieces): `t` is the HIGH bf16 plane of a residual stream kept as two planes
+                            # (hi = bf16(y), lo = bf16(y - hi)) -- what a LayerNorm + Linear pair behind these rows needs instead of
+                            # a LayerNorm launch (ops.linear_lnout -> ops.linear_lnin; ops.stream_f32 gives fp32 rows back)
         self.sub = None     # s: `t` holds only the pixels (s i, s j) of the logical map -- written that way because the one consumer
                             # left is a stride-s pointwise convolution (ops.conv1x1_chain(..., sub=), ops.conv1x1_dual)
 

@@ -103,6 +103,10 @@ PROTOTYPES = {
     "mv_conv1x1_dual_chain_supported": [_i64, _i, _i, _i, _i, _i],
     "mv_conv1x1_dual_chain_fwd": [_vp] * 10 + [_i64, _i, _i, _i, _i, _i, _vp],
     "mv_linear_heads_supported": [_i64, _i, _i, _i, _i, _i],
+    "mv_linear_lnout_supported": [_i64, _i, _i, _i],
+    "mv_linear_lnout_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "mv_linear_lnin_supported": [_i64, _i, _i, _i, _i, _i],
+    "mv_linear_lnin_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _i, _i, _i, _vp],
     "mv_linear_heads_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp],
     "mv_mha_heads_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "mv_mha_dropout_fwd": [_vp, _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _f, _i, _vp],

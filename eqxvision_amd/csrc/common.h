@@ -205,6 +205,11 @@ int igemm8_wanted(long long M, int C, int K, int R, int S);
 int igemm8_launch(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y,
                   int N, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, int dh, int dw,
                   int act, int out_dtype, int tok, int tile, hipStream_t st);   // tile: 1 = 256x256, 2 = 128x256, 3 = 256x128
+bool igemm8_ln_supported(long long M, int N, int K);
+int igemm8_lnout_launch(const void* x, const void* w, const float* shift, const void* res, const void* res_lo, void* y, void* y_lo,
+                        float* stats, long long M, int N, int K, hipStream_t st);
+int igemm8_lnin_launch(const void* x, const float* stats, const void* w, const float* colsum, const float* shift, void* y, long long M,
+                       int N, int K, float eps, int act, int tok, hipStream_t st);
 int igemm8_dual_launch(const void* x, const void* x2, const void* w, const float* scale, const float* shift,
                        const void* residual, void* y, int N, int Ho, int Wo, int C1, int H2, int W2, int C2, int s2, int K,
                        int act, int out_dtype, int tile, hipStream_t st);

@@ -1764,6 +1764,46 @@ int mv_linear_heads_fwd(const void* x, const void* w, const float* scale, const 
                          tokens, (hipStream_t)stream);
 }
 
+// ---- the LayerNorm between two Linears folded into their epilogues (ViT: norm1 -> qkv, norm2 -> fc1) ----
+// The pair is only worth it on the 256 x 256 tiles both GEMMs would take anyway (igemm8_wanted == 1 for BOTH shapes is the
+// caller's business: ask _supported for each Linear of the pair).
+int mv_linear_lnout_supported(int64_t M, int N, int K, int dtype) {
+    return dtype == MV_BF16 && !get_flag("force_generic") && !get_flag("no_igemm8") && !get_flag("no_ln_fold") && igemm8_ln_supported(M, N, K) &&
+           igemm8_wanted(M, K, N, 1, 1) == 1;
+}
+
+int mv_linear_lnout_fwd(const void* x, const void* w, const float* shift, const void* res, const void* res_lo, void* y, void* y_lo,
+                        float* stats, int64_t M, int N, int K, int dtype, mv_stream_t stream) {
+    MV_CHECK_ARG(x && w && res && y, "linear_lnout: NULL pointer");
+    MV_CHECK_ARG((y_lo != nullptr) == (stats != nullptr), "linear_lnout: y_lo and stats go together (planes out) or are both NULL (fp32 rows out)");
+    MV_CHECK_ARG(y_lo || res_lo, "linear_lnout: fp32 rows in and out is mv_linear_fwd");
+    MV_CHECK_ARG(y != x && y_lo != x, "linear_lnout: an output aliases the operand rows");
+    if (!mv_linear_lnout_supported(M, N, K, dtype)) {
+        set_error("linear_lnout: unsupported shape M=%lld N=%d K=%d (ask mv_linear_lnout_supported first)", (long long)M, N, K);
+        return MV_E_UNSUPPORTED;
+    }
+    return igemm8_lnout_launch(x, w, shift, res, res_lo, y, y_lo, stats, M, N, K, (hipStream_t)stream);
+}
+
+int mv_linear_lnin_supported(int64_t M, int N, int K, int tokens, int dh, int dtype) {
+    if (tokens > 0 && !(dh == 64 && M % tokens == 0 && mha_mfma_supported(tokens, dh, dtype))) return 0;
+    return dtype == MV_BF16 && !get_flag("force_generic") && !get_flag("no_igemm8") && !get_flag("no_ln_fold") && K <= 768 &&
+           igemm8_ln_supported(M, N, K) && igemm8_wanted(M, K, N, 1, 1) == 1;
+}
+
+int mv_linear_lnin_fwd(const void* x, const float* stats, const void* w_folded, const float* colsum, const float* shift, void* y,
+                       int64_t M, int N, int K, float eps, int act, int tokens, int dh, int dtype, mv_stream_t stream) {
+    MV_CHECK_FUSED_ACT(act, "linear_lnin");
+    MV_CHECK_ARG(x && stats && w_folded && colsum && y, "linear_lnin: NULL pointer");
+    MV_CHECK_ARG(eps > 0.f, "linear_lnin: eps %g", (double)eps);
+    if (!mv_linear_lnin_supported(M, N, K, tokens, dh, dtype)) {
+        set_error("linear_lnin: unsupported shape M=%lld N=%d K=%d tokens=%d dh=%d (ask mv_linear_lnin_supported first)", (long long)M, N,
+                  K, tokens, dh);
+        return MV_E_UNSUPPORTED;
+    }
+    return igemm8_lnin_launch(x, stats, w_folded, colsum, shift, y, M, N, K, eps, act, tokens, (hipStream_t)stream);
+}
+
 int mv_mha_heads_fwd(const void* qkv, void* out, float* probs, int B, int N, int H, int dh, float scale, int dtype,
                      mv_stream_t stream) {
     MV_CHECK_ARG(qkv && out && B > 0 && N > 0 && H > 0 && dh > 0, "mha_heads: bad args");

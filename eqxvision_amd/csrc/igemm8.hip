@@ -47,10 +47,21 @@ constexpr unsigned OOB = 0x80000000u;          // >= num_records of every descri
 __device__ unsigned g_dev_status = 0;
 constexpr int LDS_W = 0, LDS_XT = 65536, LDS_XB = 98304;   // unit bases of buffer 0; buffer 1: W +32768, XT/XB +16384
 constexpr int LDS_TOTAL = 131072;
+// LayerNorm fold, consumer side (LNF 2): behind the operand buffers the 256 rows' statistics pieces as the producers wrote them
+// (up to 12 pieces of 256 x (sum, m2) = 2 KB each) and the finalised 256 x (-mean * rstd, rstd)
+constexpr int LDS_LNP = LDS_TOTAL, LN_MAXP = 12, LDS_LNS = LDS_LNP + LN_MAXP * 2048, LDS_TOTAL_LN = LDS_LNS + 2048;
 
 template <int LOFF>
 __device__ __forceinline__ void dma16(unsigned ldsw, unsigned voff, const u32x4& rsrc, unsigned soff) {
     asm volatile("s_add_u32 m0, %0, %4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(ldsw), "v"(voff), "s"(rsrc), "s"(soff), "n"(LOFF)
+                 : "memory", "scc");
+}
+
+template <int LOFF>
+__device__ __forceinline__ void dma4(unsigned ldsw, unsigned voff, const u32x4& rsrc, unsigned soff) {      // one dword per lane
+    asm volatile("s_add_u32 m0, %0, %4\n\tbuffer_load_dword %1, %2, %3 offen lds"
                  :
                  : "s"(ldsw), "v"(voff), "s"(rsrc), "s"(soff), "n"(LOFF)
                  : "memory", "scc");
@@ -181,10 +192,17 @@ __device__ __forceinline__ void row_setup(const Igemm2P& p, const RowBase& rb, i
 // MODE 0: any convolution.  MODE 1 (DENSE): a dense 1x1 layer, one source -- no tap masks, the k-tile advance is two additions
 // (measured on the ViT qkv shape: 114.6 -> 101.4 us, the DMA issue path loses its per-piece mask test).  MODE 2 (LIN) = DENSE
 // without the per-channel scale (Linear layers).
-template <typename OutT, bool DUAL, int MODE = 0>
+//
+// LNF (igemm_pipe.h: epilogue_rows_ln): 1 / 3 / 4 = a Linear that adds to the residual stream in front of a LayerNorm + Linear pair
+// (MODE 2; 1: fp32 rows in, bf16 planes + row-statistics pieces out; 3: planes in, planes + pieces out; 4: planes in, fp32 rows out);
+// 2 = the Linear behind that LayerNorm, on the un-normalised high plane (MODE 1: scale = colsum(W'), shift = b'): the pieces of its 256
+// rows are DMA'd into LDS ahead of the first k-tile (older than every operand piece, so the counted waits of the main loop stand),
+// finalised by 256 threads after the main loop.
+template <typename OutT, bool DUAL, int MODE = 0, int LNF = 0>
 __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
     constexpr bool DENSE = MODE >= 1, LIN = MODE == 2;
     static_assert(!(DUAL && DENSE), "DENSE is single-source");
+    static_assert(LNF == 0 || (LNF != 2 && MODE == 2) || (LNF == 2 && MODE == 1), "LayerNorm fold: producer = LIN, consumer = DENSE");
     constexpr int BM = 256, BN = 256;
     constexpr int ROWB = 128;
     constexpr int EPITCH = 64 * 4 + 16;
@@ -198,7 +216,7 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
                        // prologue / main loop / epilogue boundaries, and for block 0 the shader-clock of every barrier exit
     long long pt0 = 0, pt1 = 0, pt2 = 0;
     int nstamp = 0;
-    unsigned* stamps = (unsigned*)(smem + LDS_TOTAL) + wave * 128;
+    unsigned* stamps = (unsigned*)(smem + (LNF == 2 ? LDS_TOTAL_LN : LDS_TOTAL)) + wave * 128;
     if (p.prof) pt0 = wall_clock64();
 #define MV_I8_STAMP()                                                                                      \
     do {                                                                                                   \
@@ -315,6 +333,17 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
     // ---------------- prologue: all of k-tile 0, and the phase-2 share (W, Xtop rows of group 0) of k-tile 1 ----
     TapState sa = tap_first();      // state of the tile whose W / Xtop(0) pieces are issued next (phase-2 issue)
     TapState sb = tap_first();      // state of the tile whose Xtop(1) / Xbot pieces are issued next (phase-1 issue)
+    if constexpr (LNF == 2) {       // piece j of rows m0 .. m0 + 255 = 512 consecutive dwords of the table: one per thread
+        const u32x4 rs = make_rsrc(p.stats_in);
+        const unsigned ldsw4 = __builtin_amdgcn_readfirstlane(lds0 + wave * 256);
+        const unsigned svo = m0 + (tid >> 1) < p.M ? 4u * (unsigned)(2 * m0 + tid) : OOB;
+        const unsigned pstep = 8u * (unsigned)p.M;
+        const int P = p.C >> 6;
+#define MV_I8_LNP(j) if ((j) < P) dma4<LDS_LNP + (j) * 2048>(ldsw4, svo, rs, (unsigned)(j) * pstep)
+        MV_I8_LNP(0); MV_I8_LNP(1); MV_I8_LNP(2); MV_I8_LNP(3); MV_I8_LNP(4); MV_I8_LNP(5);
+        MV_I8_LNP(6); MV_I8_LNP(7); MV_I8_LNP(8); MV_I8_LNP(9); MV_I8_LNP(10); MV_I8_LNP(11);
+#undef MV_I8_LNP
+    }
     MV_I8_W(0, sa);
     MV_I8_X(0, 0, sa, 0);
     MV_I8_X(0, 1, sb, 0);
@@ -431,7 +460,41 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
 #endif
 
     // ---------------- epilogue (igemm2's wave-private LDS transpose; branch-free buffer loads / stores: igemm_pipe.h) ----
-    epilogue_rows<OutT, LIN, 4, EPITCH>(p, smem + wave * (32 * EPITCH), acc, ss, res, do_store, m0 + 128 * grp, n0 + 64 * wc, lane);
+    if constexpr (LNF == 2) {
+        // Chan's merge of P equal-sized pieces (64 values each): mean = sum(s_j) / 64P, M2 = sum(q_j) + 64 sum((s_j / 64 - mean)^2).
+        // All LN_MAXP reads are issued unconditionally and back to back (pieces >= P: whatever the LDS holds, dropped by a select):
+        // guarded reads were 24 dependent LDS round trips, 1.1 us per tile.
+        if (tid < 256) {
+            const int P = p.C >> 6;
+            const unsigned a0 = lds0 + LDS_LNP + 8u * (unsigned)tid;
+            u32x2 pc[LN_MAXP];
+#define MV_I8_RD(j) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(pc[j]) : "v"(a0), "n"((j) * 2048) : "memory")
+            MV_I8_RD(0); MV_I8_RD(1); MV_I8_RD(2); MV_I8_RD(3); MV_I8_RD(4); MV_I8_RD(5);
+            MV_I8_RD(6); MV_I8_RD(7); MV_I8_RD(8); MV_I8_RD(9); MV_I8_RD(10); MV_I8_RD(11);
+#undef MV_I8_RD
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < LN_MAXP; ++j) asm volatile("" : "+v"(pc[j]));
+            float tot = 0.f;
+#pragma unroll
+            for (int j = 0; j < LN_MAXP; ++j) tot += j < P ? __uint_as_float(pc[j][0]) : 0.f;
+            const float inv_n = 1.0f / (float)(64 * P), mean = tot * inv_n;
+            float m2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < LN_MAXP; ++j) {
+                const float d = __uint_as_float(pc[j][0]) * (1.0f / 64.0f) - mean;
+                m2 += j < P ? __uint_as_float(pc[j][1]) + 64.0f * d * d : 0.f;
+            }
+            const float rstd = 1.0f / sqrtf(m2 * inv_n + p.ln_eps);
+            *(float2*)(smem + LDS_LNS + 8 * tid) = make_float2(-mean * rstd, rstd);
+        }
+        __syncthreads();
+    }
+    if constexpr (LNF == 0 || LNF == 2)
+        epilogue_rows<OutT, LIN, 4, EPITCH, LNF>(p, smem + wave * (32 * EPITCH), acc, ss, res, do_store, m0 + 128 * grp, n0 + 64 * wc, lane,
+                                                 smem + LDS_LNS + 1024 * grp);
+    else
+        epilogue_rows_ln<LNF != 1, LNF != 4, 4, EPITCH>(p, smem + wave * (32 * EPITCH), acc, ss, do_store, m0 + 128 * grp, n0 + 64 * wc, lane);
 #ifdef MV_I8_PROF
     if (p.prof) {
         if (tid == 0) {
@@ -783,7 +846,16 @@ static int igemm8_go(Igemm2P& p, bool dual, bool out_f32, int tile, hipStream_t 
         }                                                                     \
     } while (0)
     const bool dense1 = !dual && p.R == 1 && p.S == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0 && !get_flag("no_i8_lin");
-    if (tile == 1 && dense1) {
+#ifdef MV_I8_PROF
+    constexpr int PROF_PAD = 4096;
+#else
+    constexpr int PROF_PAD = 0;
+#endif
+    if (p.stats_out && !p.residual2) GO((igemm8_kernel<float, false, 2, 1>), LDS_TOTAL + PROF_PAD);   // igemm8_ln*_launch: tile 0, dense, checked there
+    else if (p.stats_out) GO((igemm8_kernel<float, false, 2, 3>), LDS_TOTAL + PROF_PAD);
+    else if (p.residual2) GO((igemm8_kernel<float, false, 2, 4>), LDS_TOTAL + PROF_PAD);
+    else if (p.stats_in) GO((igemm8_kernel<bf16_t, false, 1, 2>), LDS_TOTAL_LN + PROF_PAD);
+    else if (tile == 1 && dense1) {
         if (out_f32) GO((igemm8s_kernel<float, 0, false, true>), 3 * 384 * 128);
         else GO((igemm8s_kernel<bf16_t, 0, false, true>), 3 * 384 * 128);
     } else if (tile == 2 && dense1) {
@@ -846,6 +918,50 @@ int igemm8_launch(const void* x, const void* w, const float* scale, const float*
     const int rc = igemm8_go(p, false, out_dtype == MV_F32, tile - 1, st);
     if (p.sync) append_kernel_name("_splitk");
     return rc;
+}
+
+// The LayerNorm between two Linears folded into their epilogues (256 x 256 tiles; igemm_pipe.h: epilogue_rows_ln / epilogue_rows LNF 2).
+//   producer: y[M][N] = residual + x[M][K] . w[N][K]^T + shift.  residual: fp32 rows (res_lo == nullptr) or two bf16 planes (res, res_lo);
+//             y: two bf16 planes (y, y_lo) + stats[N / 64][M][2], or fp32 rows (y_lo == stats == nullptr; needs res_lo)
+//   consumer: y[M][N] bf16 (or head-major, tok > 0) = act(rstd[m] * (x[M][K] . w'[N][K]^T - mean[m] * colsum[n]) + shift'[n]),
+//             x = the producer's high plane, (mean, rstd)[m] from its stats[K / 64][M][2]
+bool igemm8_ln_supported(long long M, int N, int K) {
+    return M >= 256 && M < (1LL << 24) && N % 64 == 0 && N >= 256 && K % 64 == 0 && K >= 256 &&
+           igemm8_supported(M, K, N, 1, 1, 2LL * M * K, 2LL * N * K);
+}
+
+static void ln_params(Igemm2P& p, const void* x, const void* w, const float* shift, void* y, long long M, int N, int K) {
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.shift = shift; p.y = y;
+    p.N = 1; p.H = (int)M; p.W = 1; p.C = K; p.K = N; p.R = 1; p.S = 1; p.Ho = (int)M; p.Wo = 1;
+    p.sh = 1; p.sw = 1; p.dh = 1; p.dw = 1; p.s2 = 1;
+    p.M = (int)M;
+}
+
+int igemm8_lnout_launch(const void* x, const void* w, const float* shift, const void* res, const void* res_lo, void* y, void* y_lo,
+                        float* stats, long long M, int N, int K, hipStream_t st) {
+    if (!igemm8_ln_supported(M, N, K) || !res || (!y_lo) != (!stats) || (!y_lo && !res_lo)) {
+        set_error("igemm8 lnout: unsupported shape M=%lld N=%d K=%d or stream form", M, N, K);
+        return MV_E_UNSUPPORTED;
+    }
+    Igemm2P p;
+    ln_params(p, x, w, shift, y, M, N, K);
+    p.residual = res; p.residual2 = res_lo; p.y2 = y_lo; p.stats_out = stats;
+    set_kernel_name(!res_lo ? "igemm8_bf16_256x256_lin_lnout_f32res" : (y_lo ? "igemm8_bf16_256x256_lin_lnout" : "igemm8_bf16_256x256_lin_f32out_splitres"));
+    return igemm8_go(p, false, true, 0, st);
+}
+
+int igemm8_lnin_launch(const void* x, const float* stats, const void* w, const float* colsum, const float* shift, void* y, long long M,
+                       int N, int K, float eps, int act, int tok, hipStream_t st) {
+    if (!igemm8_ln_supported(M, N, K) || K > 64 * LN_MAXP) {
+        set_error("igemm8 lnin: unsupported shape M=%lld N=%d K=%d", M, N, K);
+        return MV_E_UNSUPPORTED;
+    }
+    Igemm2P p;
+    ln_params(p, x, w, shift, y, M, N, K);
+    p.scale = colsum; p.stats_in = stats; p.ln_eps = eps; p.act = act; p.tok = tok;
+    set_kernel_name("igemm8_bf16_256x256_dense_lnin");
+    return igemm8_go(p, false, false, 0, st);
 }
 
 // y[N,Ho,Wo,K] = act(scale[k] * (x[N,Ho,Wo,C1] . w[k, 0:C1] + x2[N, s2*ho, s2*wo, C2] . w[k, C1:C1+C2]) + shift[k] + residual)

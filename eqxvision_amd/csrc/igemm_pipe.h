@@ -24,9 +24,16 @@ struct Igemm2P {
     int tok;                        // > 0: head-major output y[b][n/64][t][n%64], rows m = b*tok + t (qkv projection)
     unsigned* sync;                 // igemm8s split-K: two words per tile (arrivals, partial-is-there), zero between launches; nullptr = no split
     float* ws;                      // igemm8s split-K: one fp32 tile of partial sums per tile
+    // LayerNorm folded across two Linears (igemm8, 256 x 256 tiles only; see epilogue_rows):
+    void* y2;                       // producer: low plane of the rows y (y = the high plane = the next Linear's operand)
+    const void* residual2;          // producer: low plane of the residual rows (residual = their high plane); nullptr: residual is fp32 rows
+    float* stats_out;               // producer: [K / 64][M][2] = per row and 64-column piece (sum, sum of squares about the piece's mean)
+    const float* stats_in;          // consumer: the same table for THIS launch's operand rows, [C / 64][M][2]
+    float ln_eps;                   // consumer
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 template <int IMM> __device__ __forceinline__ void lds_read16(u32x4& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM) : "memory");
@@ -102,9 +109,25 @@ template <> struct Buf8<float> {
 // One wave writes its (NBT x 32 pixel rows) x 64 channels: accumulator tiles acc[a][b] (a = channel half, b = pixel tile) go
 // through the wave-private LDS patch `ep` (32 rows of EPITCH bytes) and leave as full 128-byte (bf16) / 256-byte (fp32) lines.
 //   mrow0 = first pixel row of the wave, ncol0 = first channel of the wave (multiple of 64), both wave-uniform.
-template <typename OutT, bool LIN, int NBT, int EPITCH>
+//
+// LNF 2: the consumer side of a LayerNorm folded across two Linears (epilogue_rows_ln below):
+//   v = rstd[row] * acc + (-mean * rstd)[row] * colsum[n] + b'[n]; `lnst` = the wave group's 128 x (-mean * rstd, rstd) table in LDS
+//   (finalised by the kernel from the producers' pieces), ss.sc = colsum, ss.sh = b'.
+__device__ __forceinline__ float dpp_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)); }
+__device__ __forceinline__ float dpp_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)); }
+__device__ __forceinline__ float dpp_half_mirror(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)); }
+__device__ __forceinline__ float sum8_lanes(float v) {       // sum over the 8 consecutive lanes (lane & ~7) .. (lane | 7), in every lane
+    v += dpp_xor1(v);
+    v += dpp_xor2(v);
+    v += dpp_half_mirror(v);
+    return v;
+}
+
+template <typename OutT, bool LIN, int NBT, int EPITCH, int LNF = 0>
 __device__ __forceinline__ void epilogue_rows(const Igemm2P& p, char* ep, f32x16 (&acc)[2][NBT], const ScaleShift8& ss,
-                                              const OutT* res, bool do_store, int mrow0, int ncol0, int lane) {
+                                              const OutT* res, bool do_store, int mrow0, int ncol0, int lane,
+                                              const char* lnst = nullptr) {
+    static_assert(LNF == 0 || (LNF == 2 && sizeof(OutT) == 2 && !LIN), "LayerNorm fold, consumer form");
     constexpr unsigned SZ = sizeof(OutT);
     const int fr = lane & 31, fh = lane >> 5, r0 = lane >> 3, c8 = lane & 7;
     const int rl = ncol0 + c8 * 8 < p.K ? p.M - mrow0 : 0;           // rows of this wave's strip the lane may touch (0: its channels are past K)
@@ -166,7 +189,11 @@ __device__ __forceinline__ void epilogue_rows(const Igemm2P& p, char* ep, f32x16
             const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
             const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            if constexpr (LIN) ss.apply_shift(v);
+            if constexpr (LNF == 2) {
+                const float2 st = *(const float2*)(lnst + (b * 32 + row) * 8);          // (-mean * rstd, rstd) of this row
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaf(st.y, v[e], fmaf(st.x, ss.sc[e], ss.sh[e]));
+            } else if constexpr (LIN) ss.apply_shift(v);
             else ss.apply(v);
             if (has_res) late[b & 1][pass].add_to(v);
             const unsigned voy = y_vo(b * 32 + pass * 8, b * 4 + pass);
@@ -189,6 +216,108 @@ __device__ __forceinline__ void epilogue_rows(const Igemm2P& p, char* ep, f32x16
                     for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
                 }
                 Buf8<OutT>::store(ry, voy, v);
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The LayerNorm between two Linears folded into their epilogues (ViT: norm1 -> qkv, norm2 -> fc1; vit.py:139-157):
+//   LN(y) . W^T + b  =  rstd * (y . W'^T - mean * colsum(W')) + b',   W' = W . diag(gamma),  b' = b + W . beta
+// so the consumer's MAIN LOOP runs on the un-normalised rows (rounded to bf16 once) and only its epilogue needs the row statistics.
+// This is the PRODUCER: y = residual + acc + shift.  The residual stream is kept as TWO bf16 planes, hi = bf16(y) and
+// lo = bf16(y - hi) (the same four bytes per value as fp32, ~16 mantissa bits: 2^-17 relative per store against the 2^-9 of the
+// operands) -- the high plane IS the consumer's operand, so folding the LayerNorm costs no extra copy of the rows:
+//   RES_SPLIT  the residual rows arrive as planes (p.residual, p.residual2), else as fp32 rows (the first block: the token rows);
+//   OUT_SPLIT  y leaves as planes (p.y, p.y2) + per row and 64-column piece -- a wave's 64 channels -- the pair (sum, sum of squared
+//              deviations from the piece's own mean) in p.stats_out (Chan's parallel form: no E[x^2] - mean^2 cancellation
+//              whatever the row's offset is; the 8 lanes of a row meet through three DPP adds); else as fp32 rows (the last block).
+template <bool RES_SPLIT, bool OUT_SPLIT, int NBT, int EPITCH>
+__device__ __forceinline__ void epilogue_rows_ln(const Igemm2P& p, char* ep, f32x16 (&acc)[2][NBT], const ScaleShift8& ss, bool do_store,
+                                                 int mrow0, int ncol0, int lane) {
+    static_assert(RES_SPLIT || OUT_SPLIT, "fp32 in, fp32 out is the plain epilogue");
+    const int fr = lane & 31, fh = lane >> 5, r0 = lane >> 3, c8 = lane & 7;
+    const int rl = ncol0 + c8 * 8 < p.K ? p.M - mrow0 : 0;
+    const long long wave_elem = (long long)mrow0 * p.K + ncol0;
+    const unsigned vrow2 = (unsigned)(r0 * p.K + c8 * 8) * 2u, kstep2 = 16u * (unsigned)p.K;       // bf16 planes
+    const brsrc_t rra = make_brsrc(RES_SPLIT ? (const void*)((const bf16_t*)p.residual + wave_elem) : (const void*)((const float*)p.residual + wave_elem));
+    const brsrc_t rrb = make_brsrc(RES_SPLIT ? (const void*)((const bf16_t*)p.residual2 + wave_elem) : (const void*)p.y, RES_SPLIT);
+    const brsrc_t rya = make_brsrc(OUT_SPLIT ? (void*)((bf16_t*)p.y + wave_elem) : (void*)((float*)p.y + wave_elem), do_store);
+    const brsrc_t ryb = make_brsrc(OUT_SPLIT ? (void*)((bf16_t*)p.y2 + wave_elem) : p.y, OUT_SPLIT && do_store);
+    const brsrc_t rst = make_brsrc(OUT_SPLIT ? (const void*)(p.stats_out + 2 * ((long long)(ncol0 >> 6) * p.M + mrow0)) : (const void*)p.y,
+                                   OUT_SPLIT && do_store);
+    auto row_ok = [&](int row) -> bool { return row + r0 < rl; };
+    u32x4 la[2][4], lb[2][4];
+    auto fetch_res = [&](int b, u32x4 (&da)[4], u32x4 (&db)[4]) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const bool ok = row_ok(b * 32 + pass * 8);
+            const unsigned step = (unsigned)(b * 4 + pass);
+            if constexpr (RES_SPLIT) {
+                da[pass] = __builtin_amdgcn_raw_buffer_load_b128(rra, ok ? vrow2 : BUF_OOB, step * kstep2, 0);
+                db[pass] = __builtin_amdgcn_raw_buffer_load_b128(rrb, ok ? vrow2 : BUF_OOB, step * kstep2, 0);
+            } else {
+                da[pass] = __builtin_amdgcn_raw_buffer_load_b128(rra, ok ? 2u * vrow2 : BUF_OOB, step * 2u * kstep2, 0);
+                db[pass] = __builtin_amdgcn_raw_buffer_load_b128(rra, ok ? 2u * vrow2 + 16u : BUF_OOB, step * 2u * kstep2, 0);
+            }
+        }
+    };
+    fetch_res(0, la[0], lb[0]);
+#pragma unroll
+    for (int b = 0; b < NBT; ++b) {
+        if (b + 1 < NBT) fetch_res(b + 1, la[(b + 1) & 1], lb[(b + 1) & 1]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = a * 32 + 8 * g + 4 * fh;
+                *(float4*)(ep + fr * EPITCH + nl * 4) = make_float4(acc[a][b][4 * g + 0], acc[a][b][4 * g + 1],
+                                                                     acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
+            }
+        wave_lds_fence();
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + r0;
+            const float4 lo = *(const float4*)(ep + row * EPITCH + c8 * 32);
+            const float4 hi = *(const float4*)(ep + row * EPITCH + c8 * 32 + 16);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            ss.apply_shift(v);
+            const u32x4 ra = la[b & 1][pass], rb = lb[b & 1][pass];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (RES_SPLIT) {
+                    v[2 * e] += __uint_as_float(ra[e] << 16) + __uint_as_float(rb[e] << 16);
+                    v[2 * e + 1] += __uint_as_float(ra[e] & 0xffff0000u) + __uint_as_float(rb[e] & 0xffff0000u);
+                } else {
+                    v[e] += __uint_as_float(ra[e]);
+                    v[4 + e] += __uint_as_float(rb[e]);
+                }
+            }
+            const bool ok = row_ok(b * 32 + pass * 8);
+            const unsigned step = (unsigned)(b * 4 + pass);
+            if constexpr (OUT_SPLIT) {
+                const float s = sum8_lanes(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+                const float mu = s * (1.0f / 64.0f);
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[e] - mu; q = fmaf(d, d, q); }
+                q = sum8_lanes(q);
+                u32x2 st;
+                st[0] = __float_as_uint(s); st[1] = __float_as_uint(q);
+                __builtin_amdgcn_raw_buffer_store_b64(st, rst, ok && c8 == 0 ? (unsigned)(b * 32 + pass * 8 + r0) * 8u : BUF_OOB, 0, 0);
+                u32x4 oh, ol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    oh[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                    ol[e] = pack_bf2(v[2 * e] - __uint_as_float(oh[e] << 16), v[2 * e + 1] - __uint_as_float(oh[e] & 0xffff0000u));
+                }
+                const unsigned vo = ok ? vrow2 + step * kstep2 : BUF_OOB;       // whole offset in the VGPR (see epilogue_rows)
+                __builtin_amdgcn_raw_buffer_store_b128(oh, rya, vo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ol, ryb, vo, 0, 0);
+            } else {
+                Buf8<float>::store(rya, ok ? 2u * (vrow2 + step * kstep2) : BUF_OOB, v);
             }
         }
         wave_lds_fence();

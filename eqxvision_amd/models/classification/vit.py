@@ -4,12 +4,15 @@ Same classes / fields / constructors / `__call__` signatures.  Device lowering o
 (`_VitBlock.__call__`, reference :139-157) = 7 launches:
   LayerNorm | qkv GEMM(+bias) | fused attention (QK^T, softmax, PV) | proj GEMM(+bias,+residual)
   LayerNorm | fc1 GEMM(+bias,+gelu) | fc2 GEMM(+bias,+residual)
+and 5 in inference where the rows fill the 256 x 256 GEMM tiles (round 6): the two LayerNorms become per-row factors in the
+epilogues of the GEMMs on either side of them (`_VitBlock._ln_fold`, ops.linear_lnout / linear_lnin).
 """
 from __future__ import annotations
 
 from typing import Optional, Sequence, Tuple, Union
 
 import numpy as np
+import torch
 
 from ... import nn, ops
 from ... import random as jr
@@ -96,9 +99,46 @@ class _VitBlock(Module):
         return ((isinstance(dp, nn.Identity) or dp.inference or dp.p == 0.0)
                 and not self.attn._live() and not self.mlp._live())
 
+    def _ln_fold(self, x: Act):
+        """The inference form without LayerNorm launches, where the library has it for this many rows: proj and fc2 keep the
+        residual stream as two bf16 planes (+ row statistics), fc1 and qkv take the LayerNorm in their epilogue (ops.linear_lnout /
+        linear_lnin).  -> (fold norm2 -> fc1, fold norm1 -> qkv) for rows x."""
+        split = ops.is_split_stream(x)
+        if x.kind != "seq" or x.t.dim() != 3 or not (split or (x.t.dtype == torch.float32 and x.ln is None)):
+            return False, False
+        mlp, at = self.mlp, self.attn
+        if not (type(mlp) is MlpProjection and type(mlp.fc1) is nn.Linear and type(mlp.fc2) is nn.Linear
+                and nn.act_name(mlp.act) in ("gelu", "relu") and type(at.qkv) is nn.Linear and type(at.proj) is nn.Linear):
+            return False, False
+        B, N, D = x.t.shape
+        M = B * N
+        if not (at.proj.out_features == D and mlp.fc2.out_features == D and mlp.fc1.in_features == D and D % at.num_heads == 0):
+            return False, False
+        inner = (ops.linear_lnout_available(M, at.proj) and ops.linear_lnout_available(M, mlp.fc2)
+                 and ops.linear_lnin_available(M, self.norm2, mlp.fc1))
+        first = inner and split and ops.linear_lnin_available(M, self.norm1, at.qkv, N, D // at.num_heads)
+        return inner, first
+
     @boundary
     def __call__(self, x, return_attention=False, *, key=None):        # reference :139-157
+        return self._forward(x, return_attention, key=key)
+
+    def _forward(self, x, return_attention=False, key=None, feeds_block=False):
+        """`feeds_block`: the rows returned go into another _VitBlock (VisionTransformer.__call__) -- they may then stay a split
+        stream (what its norm1 -> qkv pair takes)."""
         x = ops.as_rows(x, keep_fp32=True)      # the residual stream may be fp32 (see _act.residual_fp32)
+        if self._deterministic() and not return_attention:
+            inner, first = self._ln_fold(x)
+            if inner:
+                at = self.attn
+                if first:
+                    a = ops.qkv_attention_ln(x, self.norm1, at.qkv, at.num_heads, at.scale)
+                else:
+                    a, _ = ops.qkv_attention(ops.as_rows(self.norm1(ops.stream_f32(x))), at.qkv, at.num_heads, at.scale, False)
+                x = ops.linear_lnout(a, at.proj, residual=x)                               # reference :74 + :150
+                h = ops.linear_lnin(x, self.norm2, self.mlp.fc1, act=nn.act_name(self.mlp.act))
+                return ops.linear_lnout(h, self.mlp.fc2, residual=x, out_split=feeds_block)
+        x = ops.stream_f32(x)
         y = self.norm1(x)
         if self._deterministic():          # x + Identity(y): fold the adds into the GEMM epilogues
             if return_attention:
@@ -183,8 +223,11 @@ class VisionTransformer(Module):
     def __call__(self, x, *, key=None):                                # reference :261-273
         x = self._tokens(x)
         keys = [None] * len(self.blocks) if key is None else jr.split(key, len(self.blocks))     # reference :267
-        for blk, k in zip(self.blocks, keys):
-            x = blk(x, key=k)
+        for i, (blk, k) in enumerate(zip(self.blocks, keys)):
+            if type(blk) is _VitBlock:
+                x = blk._forward(x, key=k, feeds_block=i + 1 < len(self.blocks) and type(self.blocks[i + 1]) is _VitBlock)
+            else:
+                x = blk(x, key=k)
         return self._head(x)
 
     @boundary

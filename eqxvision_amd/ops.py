@@ -1092,6 +1092,103 @@ def _ln_folded(lin, ln):
     return hit
 
 
+def _ln_folded_cs(lin, ln):
+    """For mv_linear_lnin_fwd: (W' = bf16(W . diag(gamma)), colsum[n] = sum_k W'[n][k] of the ROUNDED values, b' = b + W . beta),
+    on the device, cached on the Linear."""
+    cache = lin._cache()
+    key = ("ln_fold_cs", id(ln.weight), id(ln.bias))
+    hit = cache.get(key)
+    if hit is None:
+        w = np.asarray(lin.weight, np.float32)
+        g, b = np.asarray(ln.weight, np.float32).reshape(-1), np.asarray(ln.bias, np.float32).reshape(-1)
+        b0 = np.zeros(w.shape[0], np.float32) if lin.bias is None else np.asarray(lin.bias, np.float32).reshape(-1)
+        wf = torch.from_numpy(np.ascontiguousarray(w * g[None, :])).to(torch.bfloat16)
+        cs = wf.to(torch.float64).sum(dim=1).to(torch.float32).numpy()
+        bf = (b0.astype(np.float64) + w.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+        hit = (wf.to(device()), _dev(cs, torch.float32), _dev(bf, torch.float32), ln)      # ln: keeps the ids alive
+        cache[key] = hit
+    return hit
+
+
+def _ln_foldable(ln, C: int) -> bool:
+    from . import nn
+    return (type(ln) is nn.LayerNorm and ln.weight is not None and ln.bias is not None and int(np.prod(ln.shape)) == C)
+
+
+def linear_lnout_available(M: int, lin) -> bool:
+    return (compute_dtype() == "bf16" and residual_fp32()
+            and bool(_lib.load().mv_linear_lnout_supported(M, lin.out_features, lin.in_features, _lib.BF16)))
+
+
+def linear_lnin_available(M: int, ln, lin, tokens: int = 0, dh: int = 0) -> bool:
+    return (compute_dtype() == "bf16" and _ln_foldable(ln, lin.in_features)
+            and bool(_lib.load().mv_linear_lnin_supported(M, lin.out_features, lin.in_features, tokens, dh, _lib.BF16)))
+
+
+def is_split_stream(x: Act) -> bool:
+    """The residual stream as two bf16 planes: `x.t` = hi = bf16(y), `x.ln` = (lo = bf16(y - hi), row-statistics pieces)."""
+    return x.ln is not None and x.t.dtype == torch.bfloat16
+
+
+def stream_f32(x: Act) -> Act:
+    """Split stream -> fp32 rows (hi + lo), for a consumer that has no folded form (three element-wise launches: not the hot path)."""
+    if not is_split_stream(x):
+        return x
+    hi = Act(x.t, x.kind, x.batched)
+    lo = Act(x.ln[0], x.kind, x.batched)
+    return add(cast(hi, "fp32"), cast(lo, "fp32"))
+
+
+def linear_lnout(x: Act, lin, residual: Act, out_split: bool = True) -> Act:
+    """residual + lin(x) on the residual STREAM of a block whose LayerNorms are folded into the GEMM epilogues (header:
+    mv_linear_lnout_fwd).  `residual`: fp32 rows or a split stream; result: a split stream (`Act.t` = the high plane = the operand of
+    the LayerNorm + Linear pair behind it, `Act.ln` = (low plane, statistics pieces) -> `linear_lnin`), or fp32 rows
+    (`out_split=False`, from a split residual).  Ask `linear_lnout_available` first."""
+    x = as_rows(x)
+    if x.t.dtype != torch.bfloat16:
+        x = cast(x, "bf16")
+    N, K = lin.out_features, lin.in_features
+    M = x.t.numel() // K
+    split_in = is_split_stream(residual)
+    if tuple(residual.t.shape) != tuple(x.t.shape[:-1]) + (N,) or not (split_in or residual.t.dtype == torch.float32):
+        raise ValueError(f"linear_lnout: residual {residual} does not match {tuple(x.t.shape[:-1]) + (N,)} (fp32 rows or a split stream)")
+    if not out_split and not split_in:
+        raise ValueError("linear_lnout: fp32 rows in and out is ops.linear")
+    w, b = prep_linear(lin, "bf16")
+    res_lo = residual.ln[0] if split_in else None
+    if out_split:
+        y = empty(tuple(residual.t.shape), torch.bfloat16)
+        y_lo = empty(tuple(residual.t.shape), torch.bfloat16)
+        st = empty((N // 64, M, 2), torch.float32)
+    else:
+        y, y_lo, st = empty(tuple(residual.t.shape), torch.float32), None, None
+    _lib.call("mv_linear_lnout_fwd", _ptr(x.t), _ptr(w), _ptr(b), _ptr(residual.t), _ptr(res_lo), _ptr(y), _ptr(y_lo), _ptr(st), M, N, K,
+              _lib.BF16, stream_ptr())
+    out = Act(y, x.kind, x.batched)
+    if out_split:
+        out.ln = (y_lo, st)
+    return out
+
+
+def linear_lnin(x: Act, ln, lin, act=None, heads: int = 0):
+    """lin(ln(x)) (+ activation) for a split stream x (header: mv_linear_lnin_fwd).  heads > 0: the qkv projection, written
+    head-major [B, 3*heads, N, dh] (as `qkv_attention` does).  Ask `linear_lnin_available` first."""
+    hi, st = x.t, x.ln[1]
+    N, K = lin.out_features, lin.in_features
+    M = hi.numel() // K
+    w, cs, b = _ln_folded_cs(lin, ln)[:3]
+    if heads:
+        B, T, D = hi.shape
+        y = empty((B, 3 * heads, T, D // heads), torch.bfloat16)
+        tok, dh = T, D // heads
+    else:
+        y = empty(tuple(hi.shape[:-1]) + (N,), torch.bfloat16)
+        tok, dh = 0, 0
+    _lib.call("mv_linear_lnin_fwd", _ptr(hi), _ptr(st), _ptr(w), _ptr(cs), _ptr(b), _ptr(y), M, N, K, float(ln.eps), ACT[act], tok, dh,
+              _lib.BF16, stream_ptr())
+    return y if heads else Act(y, x.kind, x.batched)
+
+
 def ln_linear(x: Act, ln, lin, act=None) -> Act:
     """lin(ln(x)) (+ activation): ONE launch where the library folds the LayerNorm into the Linear's operand path (short rows:
     Swin stages 0-1), else LayerNorm launch + Linear launch."""
@@ -1275,6 +1372,16 @@ def mha(qkv: Act, heads: int, scale: float, need_probs: bool, drop=None):
     probs = empty((B, heads, N, N), torch.float32) if need_probs else None
     _mha_call(qkv.t, False, out, probs, B, N, heads, dh, scale, qkv.dt, drop)
     return Act(out, "seq", qkv.batched), probs
+
+
+def qkv_attention_ln(x: Act, ln, lin, heads: int, scale: float):
+    """`qkv_attention(ln(x), lin, ...)` for a split stream x (inference, no probabilities): the LayerNorm is folded into the qkv
+    projection's epilogue (vit.py:142 norm1 -> :64 qkv)."""
+    B, N, D = x.t.shape
+    qkv = linear_lnin(x, ln, lin, heads=heads)
+    out = empty((B, N, D), torch.bfloat16)
+    _mha_call(qkv, True, out, None, B, N, heads, D // heads, scale, _lib.BF16, None)
+    return Act(out, "seq", x.batched)
 
 
 def qkv_attention(x: Act, lin, heads: int, scale: float, need_probs: bool, drop=None):

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define MV_ABI_VERSION 2   /* 2 (round 6): mv_bottleneck_strip_* gone, mv_bn_train_dz_coef_f32 / mv_device_status / the layer-1 plan (rc0, rc, res, sub)
-                            * chain entries added, every scratch consumer keeps its data behind a 4096-byte sync header */
+                            * chain entries and the LayerNorm-fold Linear pair (lnout / lnin) added, every scratch consumer keeps its data behind a 4096-byte sync header */
 
 typedef void* mv_stream_t; /* hipStream_t */
 
@@ -390,6 +390,34 @@ int mv_linear_heads_fwd(const void* x, const void* w, const float* scale, const 
                         int64_t M, int N, int K, int tokens, int dh, int dtype, mv_stream_t stream);
 int mv_mha_heads_fwd(const void* qkv_head_major, void* out, float* probs, int B, int N, int H, int dh,
                      float scale, int dtype, mv_stream_t stream);
+
+/* _VitBlock (vit.py:139-157) in inference: x = x + proj(attn(norm1(x))); x = x + fc2(gelu(fc1(norm2(x)))).  The LayerNorm
+ * between a residual-producing Linear (proj, fc2) and the next Linear (fc1, the next block's qkv) is folded into the two
+ * GEMM epilogues -- no LayerNorm launch, no second read of the fp32 rows:
+ *     LN(y) . W^T + b  =  rstd * (y . W'^T - mean * colsum(W')) + b',     W' = W . diag(gamma),  b' = b + W . beta
+ *   mv_linear_lnout_fwd   y[M][N] = residual + x[M][K] . w[N][K]^T + shift, the residual STREAM kept as two bf16 planes:
+ *                         hi = bf16(y), lo = bf16(y - hi) -- the four bytes per value of fp32, ~16 mantissa bits (2^-17 relative per
+ *                         store, against the 2^-9 of the operands); the high plane IS the next Linear's operand, so the fold
+ *                         costs no extra copy of the rows.  Forms:
+ *                           res fp32 rows (res_lo NULL)      -> planes (y, y_lo) + stats     the first block (token rows are fp32)
+ *                           res planes (res, res_lo)         -> planes (y, y_lo) + stats
+ *                           res planes (res, res_lo)         -> fp32 rows y (y_lo, stats NULL)   the stream leaves the split form
+ *                         stats[N/64][M][2] fp32 = per row and 64-column piece (sum, sum of squared deviations from the piece's own
+ *                         mean) -- merged by the consumer with Chan's formula, so no E[x^2] - mean^2 cancellation.
+ *   mv_linear_lnin_fwd    y[M][N] bf16 = act(rstd[m] * (x[M][K] . w_folded[N][K]^T - mean[m] * colsum[n]) + shift[n]), x = the
+ *                         producer's HIGH plane (un-normalised rows), stats = its table ([K/64][M][2]), (mean, rstd) with the
+ *                         biased variance and `eps` as eqx.nn.LayerNorm; colsum[n] = sum_k float(w_folded[n][k]) (of the
+ *                         bf16-ROUNDED values), shift = b'.  tokens > 0: head-major output as mv_linear_heads_fwd.  K <= 768.
+ * The operand is rounded to bf16 BEFORE the mean is removed (the un-fused path rounds LN(y)): the relative error of the two is
+ * the same while |mean| <~ std of a row, and grows with |mean| / std beyond -- the host uses the pair for the ViT blocks'
+ * residual stream only (switch: no_ln_fold).  Both need the 256 x 256 GEMM tile to be the dispatch's choice for the shape. */
+int mv_linear_lnout_supported(int64_t M, int N, int K, int dtype);
+int mv_linear_lnout_fwd(const void* x, const void* w, const float* shift, const void* res, const void* res_lo, void* y,
+                        void* y_lo, float* stats, int64_t M, int N, int K, int dtype, mv_stream_t stream);
+int mv_linear_lnin_supported(int64_t M, int N, int K, int tokens, int dh, int dtype);
+int mv_linear_lnin_fwd(const void* x, const float* stats, const void* w_folded, const float* colsum, const float* shift,
+                       void* y, int64_t M, int N, int K, float eps, int act, int tokens, int dh, int dtype,
+                       mv_stream_t stream);
 
 /* The same attention core with the reference's LIVE attention dropout (vit.py:71, training mode: attn =
  * attn_drop(softmax(...), key)): every probability is kept (and divided by keep_prob) or zeroed by word

@@ -1281,6 +1281,107 @@ def ln_linear_case(M, K, N, stream="fp32", act=0, seed=0, flags=()):
     return run
 
 
+def ln_fold_case(M, D, Kp, N2, act=0, tokens=0, seed=0, row_mean=0.0, eps=1e-6):
+    """The LayerNorm between two Linears folded into their epilogues (include/eqxvision_amd.h: mv_linear_lnout_fwd ->
+    mv_linear_lnin_fwd; vit.py:139-157) vs float64, all three producer forms chained as a ViT does:
+      1. fp32 residual rows -> planes:  y1 = res + x . w^T + b as hi = bf16(y1), lo = bf16(y1 - hi) (hi + lo within 3e-5 of float64, hi
+         a correct bf16 rounding, |lo| below half an ulp of hi) + the statistics pieces (merged here with Chan's formula, against the
+         float64 mean / variance of the rows);
+      2. consumer: act(LayerNorm(y1) . w2^T + b2) as the oracle computes it (O.layernorm_rows on the rows hi + lo), row-major or
+         head-major (tokens > 0);
+      3. planes -> planes:  y2 = y1 + x . w^T + b, checked the same way;   4. planes -> fp32 rows:  y3 = y2 + x . w^T + b.
+    `row_mean`: per-row offsets of that many row standard deviations in the residual rows -- the fold rounds y, not y - mean, to bf16."""
+    def run():
+        L = _lib()
+        rng = _rng(seed)
+        x = bf(rng.standard_normal((M, Kp)).astype(np.float32))
+        w = bf((rng.standard_normal((D, Kp)) / np.sqrt(Kp)).astype(np.float32))
+        b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+        res = (rng.standard_normal((M, D)) * rng.uniform(0.5, 2.0, (M, 1))).astype(np.float32)
+        res += (row_mean * np.sqrt(2.0) * rng.uniform(-1, 1, (M, 1))).astype(np.float32) + rng.uniform(-0.3, 0.3, (M, 1)).astype(np.float32)
+        g = rng.uniform(0.5, 1.5, D).astype(np.float32)
+        be = (0.1 * rng.standard_normal(D)).astype(np.float32)
+        w2 = (rng.standard_normal((N2, D)) / np.sqrt(D)).astype(np.float32)
+        b2 = (0.1 * rng.standard_normal(N2)).astype(np.float32)
+        dh = 64
+        if not L.load().mv_linear_lnout_supported(M, D, Kp, 1):
+            return {"ok": False, "err": "mv_linear_lnout_supported says no"}
+        if not L.load().mv_linear_lnin_supported(M, N2, D, tokens, dh if tokens else 0, 1):
+            return {"ok": False, "err": "mv_linear_lnin_supported says no"}
+        delta = x.astype(np.float64) @ w.astype(np.float64).T + b
+        xd, wd, bd, rd = dev(x, "bf16"), dev(w, "bf16"), dev(b, "fp32"), dev(res, "fp32")
+        P = D // 64
+
+        def planes_out(res_hi, res_lo):
+            hi = torch.empty((M, D), dtype=torch.bfloat16, device="cuda")
+            lo = torch.empty((M, D), dtype=torch.bfloat16, device="cuda")
+            st = torch.full((P, M, 2), float("nan"), dtype=torch.float32, device="cuda")
+            L.call("mv_linear_lnout_fwd", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), res_hi.data_ptr(), None if res_lo is None else res_lo.data_ptr(),
+                   hi.data_ptr(), lo.data_ptr(), st.data_ptr(), M, D, Kp, 1, _stream())
+            k = L.last_kernel()
+            torch.cuda.synchronize()
+            return hi, lo, st, k
+
+        def check_planes(hi, lo, st, y_ref):
+            hh, ll = host(hi).astype(np.float64), host(lo).astype(np.float64)
+            i = _cmp(hh + ll, y_ref, 3e-5)
+            slack = i["lim"]            # the fp32 accumulation may land on the other side of a rounding boundary; values near zero
+            hi_ok = bool((np.abs(hh - y_ref) <= np.abs(y_ref) * 2.0 ** -8 + slack).all() and (np.abs(ll) <= np.abs(hh) * 2.0 ** -8 + slack).all())
+            sth = st.cpu().numpy().astype(np.float64)                     # [P][M][2]
+            mean = sth[:, :, 0].sum(0) / D
+            m2 = (sth[:, :, 1] + 64.0 * (sth[:, :, 0] / 64.0 - mean[None, :]) ** 2).sum(0)
+            e_mean = float(np.abs(mean - y_ref.mean(1)).max())
+            e_var = float((np.abs(m2 / D - y_ref.var(1)) / y_ref.var(1)).max())
+            ok = bool(i["ok"] and hi_ok and np.isfinite(sth).all() and e_mean < 1e-5 * max(1.0, np.abs(y_ref).max()) and e_var < 2e-5)
+            return ok, {"err": i.get("err"), "lim": i.get("lim"), "hi_is_a_bf16_rounding": hi_ok, "stats_mean_err": e_mean, "stats_var_relerr": e_var}
+
+        # ---- 1. fp32 rows -> planes
+        y1_ref = res.astype(np.float64) + delta
+        hi1, lo1, st1, k1 = planes_out(rd, None)
+        ok1, info = check_planes(hi1, lo1, st1, y1_ref)
+        info["ok"] = ok1 and "lnout_f32res" in k1
+        # ---- 2. consumer on (hi1, st1)
+        y1 = host(hi1).astype(np.float64) + host(lo1).astype(np.float64)
+        ref = O.layernorm_rows(y1, g, be, eps).astype(np.float64) @ w2.astype(np.float64).T + b2
+        if act == 2:
+            ref = O.gelu_tanh(ref).astype(np.float64)
+        wf = bf(w2 * g[None, :])
+        cs = wf.astype(np.float64).sum(1).astype(np.float32)
+        bfold = (b2.astype(np.float64) + w2.astype(np.float64) @ be.astype(np.float64)).astype(np.float32)
+        wfd, csd, bfd = dev(wf, "bf16"), dev(cs, "fp32"), dev(bfold, "fp32")
+        if tokens:
+            B, H = M // tokens, N2 // 3 // dh
+            out = torch.empty((B, 3 * H, tokens, dh), dtype=torch.bfloat16, device="cuda")
+            ref = ref.reshape(B, tokens, 3 * H, dh).transpose(0, 2, 1, 3)
+        else:
+            out = torch.empty((M, N2), dtype=torch.bfloat16, device="cuda")
+        L.call("mv_linear_lnin_fwd", hi1.data_ptr(), st1.data_ptr(), wfd.data_ptr(), csd.data_ptr(), bfd.data_ptr(), out.data_ptr(), M, N2, D,
+               float(eps), act, tokens, dh if tokens else 0, 1, _stream())
+        k2 = L.last_kernel()
+        torch.cuda.synchronize()
+        i2 = _cmp(host(out), ref, TOL_BF16)
+        info["lnin_err"], info["lnin_lim"] = i2.get("err"), i2.get("lim")
+        info["ok"] = bool(info["ok"] and i2["ok"] and "lnin" in k2)
+        # ---- 3. planes -> planes
+        hi2, lo2, st2, k3 = planes_out(hi1, lo1)
+        ok3, i3 = check_planes(hi2, lo2, st2, y1 + delta)
+        info["planes_to_planes"] = i3
+        info["ok"] = bool(info["ok"] and ok3 and k3.endswith("lin_lnout"))
+        # ---- 4. planes -> fp32 rows
+        y2 = host(hi2).astype(np.float64) + host(lo2).astype(np.float64)
+        y3 = torch.empty((M, D), dtype=torch.float32, device="cuda")
+        L.call("mv_linear_lnout_fwd", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), hi2.data_ptr(), lo2.data_ptr(), y3.data_ptr(), None, None,
+               M, D, Kp, 1, _stream())
+        k4 = L.last_kernel()
+        torch.cuda.synchronize()
+        i4 = _cmp(y3.cpu().numpy(), y2 + delta, 2e-5)
+        info["planes_to_f32_err"] = i4.get("err")
+        info["kernel"] = "+".join((k1, k2, k3, k4))
+        info["ok"] = bool(info["ok"] and i4["ok"] and "splitres" in k4)
+        return info
+    return run
+
+
 def se_scale_case(N, H, W, C, S, act1=1, act2=5, seed=0):
     """mv_se_scale_fwd (SqueezeExcitation's scale vector in one launch, layers/squeeze.py:47-60) vs float64:
     act2(b2 + w2 . act1(b1 + w1 . mean_hw x))."""
@@ -2453,6 +2554,10 @@ def all_cases():
           ("ln_linear/swin_qkv_192_576_bf16stream_ragged", ln_linear_case(8192 + 45, 192, 576, "bf16", seed=532, flags=(("ln_stream_192", 1),))),
           ("ln_linear/swin_fc1_96_384_gelu_bf16stream", ln_linear_case(8192 + 45, 96, 384, "bf16", act=2, seed=534)),
           ("ln_linear/k96_N200_tail", ln_linear_case(9000, 96, 200, "fp32", seed=533)),
+          ("ln_fold/vit_base_proj_fc1_gelu", ln_fold_case(64 * 197, 768, 768, 3072, act=2, seed=540)),
+          ("ln_fold/vit_base_fc2_qkv_heads_ragged", ln_fold_case(65 * 197, 768, 3072, 2304, tokens=197, seed=541)),
+          ("ln_fold/vit_small_width_384", ln_fold_case(98 * 197, 384, 384, 1536, act=2, seed=542)),
+          ("ln_fold/row_means_of_2_sigma", ln_fold_case(64 * 197 + 31, 768, 768, 768, seed=543, row_mean=2.0)),
           ("se_scale/effnet_32_8_silu_sigmoid_112", se_scale_case(3, 112, 112, 32, 8, act1=6, act2=5, seed=590)),
           ("se_scale/effnet_1152_48_7x7", se_scale_case(5, 7, 7, 1152, 48, act1=6, act2=5, seed=591)),
           ("se_scale/mbv3_72_24_relu_hsigmoid", se_scale_case(4, 28, 28, 72, 24, act1=1, act2=4, seed=592)),

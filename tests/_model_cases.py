@@ -1152,6 +1152,50 @@ def resnet50_rc_case(B=3, size=224):
     return run
 
 
+def vit_ln_fold_case(B=64, depth=12):
+    """ViT-B/16 with the LayerNorms of its blocks folded into the GEMM epilogues on either side (round 6: _VitBlock._ln_fold,
+    ops.linear_lnout / linear_lnin) against the same network with the fold switched off ("no_ln_fold": LayerNorm launches): both
+    within the bound of the fp32 restatement on the 8 distinct images of the batch, the two within 8e-3 of each other (two different sets of bf16 rounding points), and the
+    launch list must show the fold where it applies (every norm2 -> fc1, every norm1 -> qkv but the first) and none with the switch."""
+    def run():
+        import eqxvision_amd as eqv
+        from eqxvision_amd import _lib
+        sd = S.vit_state(1, 224, 16, 768, depth, 12, 4, 1000)
+        fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(eqv.models.VisionTransformer(**kw), torch_weights)
+        kw = dict(img_size=224, patch_size=16, embed_dim=768, depth=depth, num_heads=12, num_classes=1000)
+        x8 = S.synthetic_images(8, 224, seed=3)
+        ref = TR.vit_forward(sd, x8, 16, 12, depth).numpy()
+        x = np.tile(np.asarray(x8), (B // 8, 1, 1, 1))
+
+        def go(flag):
+            _lib.set_flag("no_ln_fold", flag)
+            try:
+                net = _load(fac, sd, **kw)            # fresh module: no cached decisions
+                rec = []
+                old = _lib.set_recording(rec)
+                try:
+                    out = _run(net, x, "bf16").cpu().numpy()
+                finally:
+                    _lib.set_recording(old)
+                return out, [n for _, _, n in rec]
+            finally:
+                _lib.set_flag("no_ln_fold", 0)
+        got, names = go(0)
+        plain, names2 = go(1)
+        info = _cmp(got[:8], ref, 1e-2)
+        info2 = _cmp(plain[:8], ref, 1e-2)
+        d = float(np.abs(got - plain).max())
+        rep = float(np.abs(got.reshape(B // 8, 8, -1) - got[None, :8]).max())
+        n_out, n_in, n_ln = names.count("mv_linear_lnout_fwd"), names.count("mv_linear_lnin_fwd"), names.count("mv_layernorm_fwd")
+        ran = n_out == 2 * depth and n_in == 2 * depth - 1
+        off = not any(n in names2 for n in ("mv_linear_lnout_fwd", "mv_linear_lnin_fwd")) and names2.count("mv_layernorm_fwd") == n_ln + 2 * depth - 1
+        info.update({"ok": bool(info["ok"] and info2["ok"] and d <= 8e-3 and rep <= info["lim"] and ran and off), "err_fold_off": info2["err"],
+                     "fold_vs_off": d, "replica_max_diff": rep, "fold_ran": ran, "fold_off_honoured": off, "launches": len(names),
+                     "launches_fold_off": len(names2)})
+        return info
+    return run
+
+
 def all_cases(full=True):
     c = [("model/resnet_tiny_bottleneck", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2)),
          ("model/resnet18_64px", resnet_case("basic", (2, 2, 2, 2), 64, 2)),
@@ -1215,6 +1259,7 @@ def all_cases(full=True):
               ("model/resnet50_B5_odd_200px", resnet_case("bottleneck", (3, 4, 6, 3), 200, 5, classes=1000, full_ref="torch")),
               ("model/resnet50_B3_layer1_recompute_plan_vs_plan_off", resnet50_rc_case()),
               ("model/resnet50_B16_layer1_recompute_plan_vs_plan_off", resnet50_rc_case(B=16)),
+              ("model/vit_base_B64_layernorm_fold_vs_fold_off", vit_ln_fold_case()),
               ("model/resnet_2111_160px_B7_mixed_paths", resnet_case("bottleneck", (2, 1, 1, 1), 160, 7, classes=10, full_ref="torch")),
               ("model/resnet_1211_128px_B16_mixed_paths", resnet_case("bottleneck", (1, 2, 1, 1), 128, 16, classes=10, full_ref="torch")),
               ("model/resnext50_32x4d_B2", resnet_case("bottleneck", (3, 4, 6, 3), 224, 2, classes=1000, full_ref="torch",
