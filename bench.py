@@ -177,6 +177,16 @@ def launch_meta(name, args):
         flops = 2.0 * M * 16 * C * K * (2 if args[2] else 1)
         byts = 4.0 * B_ * C * H * W + 4.0 * M * K
         shape = f"B{B_} {C}x{H}x{W} -> {H // 4}x{W // 4}x{K} conv4s4+LN" + (" hi+lo" if args[2] else "")
+    elif name == "mv_linear_lnout_fwd":      # residual stream as two bf16 planes (4 bytes per value, as fp32) + the row-statistics pieces
+        M, N, K = args[8:11]
+        flops = 2.0 * M * N * K
+        byts = 2.0 * (M * K + N * K) + 8.0 * M * N + (8.0 * ((N + 255) // 256) * M if args[7] else 0.0)
+        shape = f"M{M} K{K} N{N} +res " + ("f32 rows" if not args[4] else "planes") + " -> " + ("planes + row stats" if args[7] else "f32 rows")
+    elif name == "mv_linear_lnin_fwd":
+        M, N, K = args[6:9]
+        flops = 2.0 * M * N * K
+        byts = 2.0 * (M * K + N * K + M * N) + 8.0 * ((K + 255) // 256) * M
+        shape = f"M{M} K{K} N{N} LN in the epilogue" + (" head-major" if args[11] else "")
     elif name == "mv_linear_heads_fwd":
         M, N, K = args[5:8]
         flops = 2.0 * M * N * K

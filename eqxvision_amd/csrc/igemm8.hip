@@ -48,8 +48,11 @@ __device__ unsigned g_dev_status = 0;
 constexpr int LDS_W = 0, LDS_XT = 65536, LDS_XB = 98304;   // unit bases of buffer 0; buffer 1: W +32768, XT/XB +16384
 constexpr int LDS_TOTAL = 131072;
 // LayerNorm fold, consumer side (LNF 2): behind the operand buffers the 256 rows' statistics pieces as the producers wrote them
-// (up to 12 pieces of 256 x (sum, m2) = 2 KB each) and the finalised 256 x (-mean * rstd, rstd)
-constexpr int LDS_LNP = LDS_TOTAL, LN_MAXP = 12, LDS_LNS = LDS_LNP + LN_MAXP * 2048, LDS_TOTAL_LN = LDS_LNS + 2048;
+// (one piece of 256 x (sum, m2) = 2 KB per 256 columns of the row, up to 3) and the finalised 256 x (-mean * rstd, rstd);
+// producer side: behind the epilogue patches 256 rows x 4 waves x (sum, m2) and 512 dummy bytes per wave
+constexpr int LDS_LNP = LDS_TOTAL, LN_MAXP = 3, LDS_LNS = LDS_LNP + LN_MAXP * 2048, LDS_TOTAL_LN = LDS_LNS + 2048;
+constexpr int LDS_LN_SLOTS = 8 * 32 * (64 * 4 + 16), LDS_LN_DUMMY = LDS_LN_SLOTS + 256 * 32;
+static_assert(LDS_LN_DUMMY + 8 * 512 <= LDS_TOTAL, "producer statistics slots");
 
 template <int LOFF>
 __device__ __forceinline__ void dma16(unsigned ldsw, unsigned voff, const u32x4& rsrc, unsigned soff) {
@@ -338,10 +341,9 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
         const unsigned ldsw4 = __builtin_amdgcn_readfirstlane(lds0 + wave * 256);
         const unsigned svo = m0 + (tid >> 1) < p.M ? 4u * (unsigned)(2 * m0 + tid) : OOB;
         const unsigned pstep = 8u * (unsigned)p.M;
-        const int P = p.C >> 6;
+        const int P = (p.C + 255) >> 8;
 #define MV_I8_LNP(j) if ((j) < P) dma4<LDS_LNP + (j) * 2048>(ldsw4, svo, rs, (unsigned)(j) * pstep)
-        MV_I8_LNP(0); MV_I8_LNP(1); MV_I8_LNP(2); MV_I8_LNP(3); MV_I8_LNP(4); MV_I8_LNP(5);
-        MV_I8_LNP(6); MV_I8_LNP(7); MV_I8_LNP(8); MV_I8_LNP(9); MV_I8_LNP(10); MV_I8_LNP(11);
+        MV_I8_LNP(0); MV_I8_LNP(1); MV_I8_LNP(2);
 #undef MV_I8_LNP
     }
     MV_I8_W(0, sa);
@@ -461,16 +463,15 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
 
     // ---------------- epilogue (igemm2's wave-private LDS transpose; branch-free buffer loads / stores: igemm_pipe.h) ----
     if constexpr (LNF == 2) {
-        // Chan's merge of P equal-sized pieces (64 values each): mean = sum(s_j) / 64P, M2 = sum(q_j) + 64 sum((s_j / 64 - mean)^2).
-        // All LN_MAXP reads are issued unconditionally and back to back (pieces >= P: whatever the LDS holds, dropped by a select):
-        // guarded reads were 24 dependent LDS round trips, 1.1 us per tile.
+        // Chan's merge of the P pieces (n_j = 256 values, the last one what is left of C): mean = sum(s_j) / C,
+        // M2 = sum(q_j) + sum(n_j (s_j / n_j - mean)^2).  The reads are issued unconditionally and back to back (pieces >= P: whatever
+        // the LDS holds, dropped by a select): guarded reads were dependent LDS round trips, 1.1 us per tile with twelve pieces.
         if (tid < 256) {
-            const int P = p.C >> 6;
+            const int P = (p.C + 255) >> 8;
             const unsigned a0 = lds0 + LDS_LNP + 8u * (unsigned)tid;
             u32x2 pc[LN_MAXP];
 #define MV_I8_RD(j) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(pc[j]) : "v"(a0), "n"((j) * 2048) : "memory")
-            MV_I8_RD(0); MV_I8_RD(1); MV_I8_RD(2); MV_I8_RD(3); MV_I8_RD(4); MV_I8_RD(5);
-            MV_I8_RD(6); MV_I8_RD(7); MV_I8_RD(8); MV_I8_RD(9); MV_I8_RD(10); MV_I8_RD(11);
+            MV_I8_RD(0); MV_I8_RD(1); MV_I8_RD(2);
 #undef MV_I8_RD
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -478,12 +479,13 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
             float tot = 0.f;
 #pragma unroll
             for (int j = 0; j < LN_MAXP; ++j) tot += j < P ? __uint_as_float(pc[j][0]) : 0.f;
-            const float inv_n = 1.0f / (float)(64 * P), mean = tot * inv_n;
+            const float inv_n = 1.0f / (float)p.C, mean = tot * inv_n;
             float m2 = 0.f;
 #pragma unroll
             for (int j = 0; j < LN_MAXP; ++j) {
-                const float d = __uint_as_float(pc[j][0]) * (1.0f / 64.0f) - mean;
-                m2 += j < P ? __uint_as_float(pc[j][1]) + 64.0f * d * d : 0.f;
+                const float nj = (float)min(256, p.C - 256 * j);
+                const float d = __uint_as_float(pc[j][0]) / nj - mean;
+                m2 += j < P ? __uint_as_float(pc[j][1]) + nj * d * d : 0.f;
             }
             const float rstd = 1.0f / sqrtf(m2 * inv_n + p.ln_eps);
             *(float2*)(smem + LDS_LNS + 8 * tid) = make_float2(-mean * rstd, rstd);
@@ -494,7 +496,14 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
         epilogue_rows<OutT, LIN, 4, EPITCH, LNF>(p, smem + wave * (32 * EPITCH), acc, ss, res, do_store, m0 + 128 * grp, n0 + 64 * wc, lane,
                                                  smem + LDS_LNS + 1024 * grp);
     else
-        epilogue_rows_ln<LNF != 1, LNF != 4, 4, EPITCH>(p, smem + wave * (32 * EPITCH), acc, ss, do_store, m0 + 128 * grp, n0 + 64 * wc, lane);
+    {
+        epilogue_rows_ln<LNF != 1, LNF != 4, 4, EPITCH>(p, smem + wave * (32 * EPITCH), acc, ss, do_store, m0 + 128 * grp, n0 + 64 * wc, lane,
+                                                        smem + LDS_LN_SLOTS + 128 * 32 * grp, wc, smem + LDS_LN_DUMMY + 512 * wave);
+        if constexpr (LNF != 4) {
+            __syncthreads();
+            if (tid < 256 && do_store) merge_row_stats(p, smem + LDS_LN_SLOTS, tid, m0, tile_n, min(4, (p.K - n0) >> 6));
+        }
+    }
 #ifdef MV_I8_PROF
     if (p.prof) {
         if (tid == 0) {
@@ -922,9 +931,9 @@ int igemm8_launch(const void* x, const void* w, const float* scale, const float*
 
 // The LayerNorm between two Linears folded into their epilogues (256 x 256 tiles; igemm_pipe.h: epilogue_rows_ln / epilogue_rows LNF 2).
 //   producer: y[M][N] = residual + x[M][K] . w[N][K]^T + shift.  residual: fp32 rows (res_lo == nullptr) or two bf16 planes (res, res_lo);
-//             y: two bf16 planes (y, y_lo) + stats[N / 64][M][2], or fp32 rows (y_lo == stats == nullptr; needs res_lo)
+//             y: two bf16 planes (y, y_lo) + stats[ceil(N / 256)][M][2], or fp32 rows (y_lo == stats == nullptr; needs res_lo)
 //   consumer: y[M][N] bf16 (or head-major, tok > 0) = act(rstd[m] * (x[M][K] . w'[N][K]^T - mean[m] * colsum[n]) + shift'[n]),
-//             x = the producer's high plane, (mean, rstd)[m] from its stats[K / 64][M][2]
+//             x = the producer's high plane, (mean, rstd)[m] from its stats[ceil(K / 256)][M][2]
 bool igemm8_ln_supported(long long M, int N, int K) {
     return M >= 256 && M < (1LL << 24) && N % 64 == 0 && N >= 256 && K % 64 == 0 && K >= 256 &&
            igemm8_supported(M, K, N, 1, 1, 2LL * M * K, 2LL * N * K);
@@ -953,7 +962,7 @@ int igemm8_lnout_launch(const void* x, const void* w, const float* shift, const 
 
 int igemm8_lnin_launch(const void* x, const float* stats, const void* w, const float* colsum, const float* shift, void* y, long long M,
                        int N, int K, float eps, int act, int tok, hipStream_t st) {
-    if (!igemm8_ln_supported(M, N, K) || K > 64 * LN_MAXP) {
+    if (!igemm8_ln_supported(M, N, K) || K > 256 * LN_MAXP) {
         set_error("igemm8 lnin: unsupported shape M=%lld N=%d K=%d", M, N, K);
         return MV_E_UNSUPPORTED;
     }

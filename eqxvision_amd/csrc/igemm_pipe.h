@@ -27,8 +27,8 @@ struct Igemm2P {
     // LayerNorm folded across two Linears (igemm8, 256 x 256 tiles only; see epilogue_rows):
     void* y2;                       // producer: low plane of the rows y (y = the high plane = the next Linear's operand)
     const void* residual2;          // producer: low plane of the residual rows (residual = their high plane); nullptr: residual is fp32 rows
-    float* stats_out;               // producer: [K / 64][M][2] = per row and 64-column piece (sum, sum of squares about the piece's mean)
-    const float* stats_in;          // consumer: the same table for THIS launch's operand rows, [C / 64][M][2]
+    float* stats_out;               // producer: [ceil(K / 256)][M][2] = per row and 256-column tile (sum, sum of squares about the tile's own mean)
+    const float* stats_in;          // consumer: the same table for THIS launch's operand rows, [ceil(C / 256)][M][2]
     float ln_eps;                   // consumer
 };
 
@@ -231,12 +231,15 @@ __device__ __forceinline__ void epilogue_rows(const Igemm2P& p, char* ep, f32x16
 // lo = bf16(y - hi) (the same four bytes per value as fp32, ~16 mantissa bits: 2^-17 relative per store against the 2^-9 of the
 // operands) -- the high plane IS the consumer's operand, so folding the LayerNorm costs no extra copy of the rows:
 //   RES_SPLIT  the residual rows arrive as planes (p.residual, p.residual2), else as fp32 rows (the first block: the token rows);
-//   OUT_SPLIT  y leaves as planes (p.y, p.y2) + per row and 64-column piece -- a wave's 64 channels -- the pair (sum, sum of squared
-//              deviations from the piece's own mean) in p.stats_out (Chan's parallel form: no E[x^2] - mean^2 cancellation
-//              whatever the row's offset is; the 8 lanes of a row meet through three DPP adds); else as fp32 rows (the last block).
+//   OUT_SPLIT  y leaves as planes (p.y, p.y2), and per row and 64-column piece -- a wave's 64 channels -- the pair (sum, sum of squared
+//              deviations from the piece's own mean) goes to `slots` (LDS: [row of the wave group][4 waves] float2; the 8 lanes of a
+//              row meet through three DPP adds); the kernel merges the four waves of a row in a fixed order behind a barrier
+//              (merge_row_stats) and stores ONE pair per row and 256-column tile.  Chan's parallel form throughout: no
+//              E[x^2] - mean^2 cancellation whatever the row's offset is.  Else y leaves as fp32 rows (the last block).
+//   `slots` = the wave group's first row, `wc` = the wave's 64-column piece of the tile, `dummy` = 512 bytes per wave nobody reads.
 template <bool RES_SPLIT, bool OUT_SPLIT, int NBT, int EPITCH>
 __device__ __forceinline__ void epilogue_rows_ln(const Igemm2P& p, char* ep, f32x16 (&acc)[2][NBT], const ScaleShift8& ss, bool do_store,
-                                                 int mrow0, int ncol0, int lane) {
+                                                 int mrow0, int ncol0, int lane, char* slots, int wc, char* dummy) {
     static_assert(RES_SPLIT || OUT_SPLIT, "fp32 in, fp32 out is the plain epilogue");
     const int fr = lane & 31, fh = lane >> 5, r0 = lane >> 3, c8 = lane & 7;
     const int rl = ncol0 + c8 * 8 < p.K ? p.M - mrow0 : 0;
@@ -246,8 +249,6 @@ __device__ __forceinline__ void epilogue_rows_ln(const Igemm2P& p, char* ep, f32
     const brsrc_t rrb = make_brsrc(RES_SPLIT ? (const void*)((const bf16_t*)p.residual2 + wave_elem) : (const void*)p.y, RES_SPLIT);
     const brsrc_t rya = make_brsrc(OUT_SPLIT ? (void*)((bf16_t*)p.y + wave_elem) : (void*)((float*)p.y + wave_elem), do_store);
     const brsrc_t ryb = make_brsrc(OUT_SPLIT ? (void*)((bf16_t*)p.y2 + wave_elem) : p.y, OUT_SPLIT && do_store);
-    const brsrc_t rst = make_brsrc(OUT_SPLIT ? (const void*)(p.stats_out + 2 * ((long long)(ncol0 >> 6) * p.M + mrow0)) : (const void*)p.y,
-                                   OUT_SPLIT && do_store);
     auto row_ok = [&](int row) -> bool { return row + r0 < rl; };
     u32x4 la[2][4], lb[2][4];
     auto fetch_res = [&](int b, u32x4 (&da)[4], u32x4 (&db)[4]) {
@@ -304,9 +305,8 @@ __device__ __forceinline__ void epilogue_rows_ln(const Igemm2P& p, char* ep, f32
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float d = v[e] - mu; q = fmaf(d, d, q); }
                 q = sum8_lanes(q);
-                u32x2 st;
-                st[0] = __float_as_uint(s); st[1] = __float_as_uint(q);
-                __builtin_amdgcn_raw_buffer_store_b64(st, rst, ok && c8 == 0 ? (unsigned)(b * 32 + pass * 8 + r0) * 8u : BUF_OOB, 0, 0);
+                // lane c8 == 0 of a row files the pair; the other seven write it to the wave's dummy words (no divergent region)
+                *(float2*)(c8 == 0 ? slots + ((b * 32 + row) * 4 + wc) * 8 : dummy + lane * 8) = make_float2(s, q);
                 u32x4 oh, ol;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -322,6 +322,28 @@ __device__ __forceinline__ void epilogue_rows_ln(const Igemm2P& p, char* ep, f32
         }
         wave_lds_fence();
     }
+}
+
+
+// One thread per row of the 256-row tile: the four waves' (sum, m2) of the row -> one pair for the tile's `nw` valid 64-column pieces
+// (Chan's merge in a fixed order), stored to stats_out[tile_n][m0 + row].
+__device__ __forceinline__ void merge_row_stats(const Igemm2P& p, const char* slots, int tid, int m0, int tile_n, int nw) {
+    const float4 a = *(const float4*)(slots + tid * 32), b = *(const float4*)(slots + tid * 32 + 16);
+    const float s[4] = {a.x, a.z, b.x, b.z}, q[4] = {a.y, a.w, b.y, b.w};
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tot += j < nw ? s[j] : 0.f;
+    const float mean = tot / (float)(64 * nw);
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float d = s[j] * (1.0f / 64.0f) - mean;
+        m2 += j < nw ? q[j] + 64.0f * d * d : 0.f;
+    }
+    const brsrc_t rst = make_brsrc(p.stats_out + 2 * ((long long)tile_n * p.M + m0));
+    u32x2 st;
+    st[0] = __float_as_uint(tot); st[1] = __float_as_uint(m2);
+    __builtin_amdgcn_raw_buffer_store_b64(st, rst, m0 + tid < p.M ? 8u * (unsigned)tid : BUF_OOB, 0, 0);
 }
 
 }  // namespace mv

@@ -1159,7 +1159,7 @@ def linear_lnout(x: Act, lin, residual: Act, out_split: bool = True) -> Act:
     if out_split:
         y = empty(tuple(residual.t.shape), torch.bfloat16)
         y_lo = empty(tuple(residual.t.shape), torch.bfloat16)
-        st = empty((N // 64, M, 2), torch.float32)
+        st = empty(((N + 255) // 256, M, 2), torch.float32)
     else:
         y, y_lo, st = empty(tuple(residual.t.shape), torch.float32), None, None
     _lib.call("mv_linear_lnout_fwd", _ptr(x.t), _ptr(w), _ptr(b), _ptr(residual.t), _ptr(res_lo), _ptr(y), _ptr(y_lo), _ptr(st), M, N, K,

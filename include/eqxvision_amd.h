@@ -402,10 +402,11 @@ int mv_mha_heads_fwd(const void* qkv_head_major, void* out, float* probs, int B,
  *                           res fp32 rows (res_lo NULL)      -> planes (y, y_lo) + stats     the first block (token rows are fp32)
  *                           res planes (res, res_lo)         -> planes (y, y_lo) + stats
  *                           res planes (res, res_lo)         -> fp32 rows y (y_lo, stats NULL)   the stream leaves the split form
- *                         stats[N/64][M][2] fp32 = per row and 64-column piece (sum, sum of squared deviations from the piece's own
- *                         mean) -- merged by the consumer with Chan's formula, so no E[x^2] - mean^2 cancellation.
+ *                         stats[ceil(N/256)][M][2] fp32 = per row and 256-column piece j (its last one: what is left of N) the pair
+ *                         (sum, sum of squared deviations from the piece's own mean) -- merged by the consumer with Chan's
+ *                         formula, so no E[x^2] - mean^2 cancellation.
  *   mv_linear_lnin_fwd    y[M][N] bf16 = act(rstd[m] * (x[M][K] . w_folded[N][K]^T - mean[m] * colsum[n]) + shift[n]), x = the
- *                         producer's HIGH plane (un-normalised rows), stats = its table ([K/64][M][2]), (mean, rstd) with the
+ *                         producer's HIGH plane (un-normalised rows), stats = its table ([ceil(K/256)][M][2]), (mean, rstd) with the
  *                         biased variance and `eps` as eqx.nn.LayerNorm; colsum[n] = sum_k float(w_folded[n][k]) (of the
  *                         bf16-ROUNDED values), shift = b'.  tokens > 0: head-major output as mv_linear_heads_fwd.  K <= 768.
  * The operand is rounded to bf16 BEFORE the mean is removed (the un-fused path rounds LN(y)): the relative error of the two is

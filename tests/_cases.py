@@ -1310,7 +1310,8 @@ def ln_fold_case(M, D, Kp, N2, act=0, tokens=0, seed=0, row_mean=0.0, eps=1e-6):
             return {"ok": False, "err": "mv_linear_lnin_supported says no"}
         delta = x.astype(np.float64) @ w.astype(np.float64).T + b
         xd, wd, bd, rd = dev(x, "bf16"), dev(w, "bf16"), dev(b, "fp32"), dev(res, "fp32")
-        P = D // 64
+        P = (D + 255) // 256
+        npc = np.array([min(256, D - 256 * j) for j in range(P)], np.float64)[:, None]
 
         def planes_out(res_hi, res_lo):
             hi = torch.empty((M, D), dtype=torch.bfloat16, device="cuda")
@@ -1329,7 +1330,7 @@ def ln_fold_case(M, D, Kp, N2, act=0, tokens=0, seed=0, row_mean=0.0, eps=1e-6):
             hi_ok = bool((np.abs(hh - y_ref) <= np.abs(y_ref) * 2.0 ** -8 + slack).all() and (np.abs(ll) <= np.abs(hh) * 2.0 ** -8 + slack).all())
             sth = st.cpu().numpy().astype(np.float64)                     # [P][M][2]
             mean = sth[:, :, 0].sum(0) / D
-            m2 = (sth[:, :, 1] + 64.0 * (sth[:, :, 0] / 64.0 - mean[None, :]) ** 2).sum(0)
+            m2 = (sth[:, :, 1] + npc * (sth[:, :, 0] / npc - mean[None, :]) ** 2).sum(0)
             e_mean = float(np.abs(mean - y_ref.mean(1)).max())
             e_var = float((np.abs(m2 / D - y_ref.var(1)) / y_ref.var(1)).max())
             ok = bool(i["ok"] and hi_ok and np.isfinite(sth).all() and e_mean < 1e-5 * max(1.0, np.abs(y_ref).max()) and e_var < 2e-5)

@@ -6,9 +6,11 @@ import re
 
 def fam(name):
     n = name
-    m = re.search(r"igemm8_kernel<(float|unsigned short), (true|false), (\d)>", n)       # <OutT, DUAL, MODE>: one bench name per symbol
+    m = re.search(r"igemm8_kernel<(float|unsigned short), (true|false), (\d)(?:, (\d))?>", n)   # <OutT, DUAL, MODE[, LNF]>: one bench name per symbol
     if m:
         f32 = "_f32out" if m.group(1) == "float" else ""
+        lnf = int(m.group(4) or 0)              # the LayerNorm-fold forms (round 6; profiles older than that print three arguments)
+        if lnf: return "igemm8_bf16_256x256_" + {1: "lin_lnout_f32res", 2: "dense_lnin", 3: "lin_lnout", 4: "lin_f32out_splitres"}[lnf]
         if m.group(2) == "true": return "igemm8_dual_bf16_256x256" + f32
         return "igemm8_bf16_256x256_" + ("conv", "dense", "lin")[int(m.group(3))] + f32
     m = re.search(r"igemm8s_kernel<(float|unsigned short), (\d), (true|false), (true|false)>", n)   # <OutT, ARR, DUAL, DENSE>

@@ -21,7 +21,7 @@ xb, hb = rnd(M, D), rnd(M, H)
 res = rnd(M, D, dt=torch.float32, sc=2.0)
 y, yb, ylo = torch.empty(M, D, device="cuda"), torch.empty(M, D, device="cuda", dtype=torch.bfloat16), torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
 rhi, rlo = res.to(torch.bfloat16), (res - res.to(torch.bfloat16).float()).to(torch.bfloat16)
-stats = torch.empty(D // 64, M, 2, device="cuda")
+stats = torch.empty((D + 255) // 256, M, 2, device="cuda")
 for name, x, K in (("proj", xb, D), ("fc2", hb, H)):
     w, b = rnd(D, K, sc=K ** -0.5), rnd(D, dt=torch.float32, sc=0.1)
     plain = timeit(lambda: L.call("mv_linear_fwd", x.data_ptr(), w.data_ptr(), None, b.data_ptr(), res.data_ptr(), y.data_ptr(), M, D, K, 0, 1, 0, st))
