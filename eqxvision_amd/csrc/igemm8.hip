@@ -200,7 +200,7 @@ __device__ __forceinline__ void row_setup(const Igemm2P& p, const RowBase& rb, i
 // (MODE 2; 1: fp32 rows in, bf16 planes + row-statistics pieces out; 3: planes in, planes + pieces out; 4: planes in, fp32 rows out);
 // 2 = the Linear behind that LayerNorm, on the un-normalised high plane (MODE 1: scale = colsum(W'), shift = b'): the pieces of its 256
 // rows are DMA'd into LDS ahead of the first k-tile (older than every operand piece, so the counted waits of the main loop stand),
-// finalised by 256 threads after the main loop.
+// finalised by 256 threads while the first k-tile is in flight.
 template <typename OutT, bool DUAL, int MODE = 0, int LNF = 0>
 __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
     constexpr bool DENSE = MODE >= 1, LIN = MODE == 2;
@@ -351,12 +351,46 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
     MV_I8_X(0, 1, sb, 0);
     MV_I8_X(0, 2, sb, 0);
     MV_I8_X(0, 3, sb, 0);
+    // LNF 2: the rows' (-mean * rstd, rstd) from the producers' pieces, while the first k-tile is still on its way (every wave's pieces
+    // have landed once all waves are past their counted wait: one barrier); the epilogue reads the table many barriers later.
+    auto ln_finalize = [&]() {
+        __builtin_amdgcn_s_barrier();
+        // Chan's merge of the P pieces (n_j = 256 values, the last one what is left of C): mean = sum(s_j) / C,
+        // M2 = sum(q_j) + sum(n_j (s_j / n_j - mean)^2).  The reads are issued unconditionally and back to back (pieces >= P: whatever
+        // the LDS holds, dropped by a select): guarded reads were dependent LDS round trips, 1.1 us per tile with twelve pieces.
+        if (tid < 256) {
+            const int P = (p.C + 255) >> 8;
+            const unsigned a0 = lds0 + LDS_LNP + 8u * (unsigned)tid;
+            u32x2 pc[LN_MAXP];
+#define MV_I8_RD(j) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(pc[j]) : "v"(a0), "n"((j) * 2048) : "memory")
+            MV_I8_RD(0); MV_I8_RD(1); MV_I8_RD(2);
+#undef MV_I8_RD
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < LN_MAXP; ++j) asm volatile("" : "+v"(pc[j]));
+            float tot = 0.f;
+#pragma unroll
+            for (int j = 0; j < LN_MAXP; ++j) tot += j < P ? __uint_as_float(pc[j][0]) : 0.f;
+            const float inv_n = 1.0f / (float)p.C, mean = tot * inv_n;
+            float m2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < LN_MAXP; ++j) {
+                const float nj = (float)min(256, p.C - 256 * j);
+                const float d = __uint_as_float(pc[j][0]) / nj - mean;
+                m2 += j < P ? __uint_as_float(pc[j][1]) + nj * d * d : 0.f;
+            }
+            const float rstd = 1.0f / sqrtf(m2 * inv_n + p.ln_eps);
+            *(float2*)(smem + LDS_LNS + 8 * tid) = make_float2(-mean * rstd, rstd);
+        }
+    };
     if (nk > 1) {
         tap_adv(sa, 1);
         MV_I8_W(1, sa);
         MV_I8_X(1, 0, sa, 1);
+        if constexpr (LNF == 2) { wait_vm<13>(); ln_finalize(); }      // the statistics pieces are older than the 13 operand pieces
         wait_vm<7>();
     } else {
+        if constexpr (LNF == 2) { wait_vm<8>(); ln_finalize(); }
         wait_vm<2>();
     }
     __builtin_amdgcn_s_barrier();
@@ -462,36 +496,6 @@ __global__ __launch_bounds__(512) void igemm8_kernel(const Igemm2P p) {
 #endif
 
     // ---------------- epilogue (igemm2's wave-private LDS transpose; branch-free buffer loads / stores: igemm_pipe.h) ----
-    if constexpr (LNF == 2) {
-        // Chan's merge of the P pieces (n_j = 256 values, the last one what is left of C): mean = sum(s_j) / C,
-        // M2 = sum(q_j) + sum(n_j (s_j / n_j - mean)^2).  The reads are issued unconditionally and back to back (pieces >= P: whatever
-        // the LDS holds, dropped by a select): guarded reads were dependent LDS round trips, 1.1 us per tile with twelve pieces.
-        if (tid < 256) {
-            const int P = (p.C + 255) >> 8;
-            const unsigned a0 = lds0 + LDS_LNP + 8u * (unsigned)tid;
-            u32x2 pc[LN_MAXP];
-#define MV_I8_RD(j) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(pc[j]) : "v"(a0), "n"((j) * 2048) : "memory")
-            MV_I8_RD(0); MV_I8_RD(1); MV_I8_RD(2);
-#undef MV_I8_RD
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < LN_MAXP; ++j) asm volatile("" : "+v"(pc[j]));
-            float tot = 0.f;
-#pragma unroll
-            for (int j = 0; j < LN_MAXP; ++j) tot += j < P ? __uint_as_float(pc[j][0]) : 0.f;
-            const float inv_n = 1.0f / (float)p.C, mean = tot * inv_n;
-            float m2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < LN_MAXP; ++j) {
-                const float nj = (float)min(256, p.C - 256 * j);
-                const float d = __uint_as_float(pc[j][0]) / nj - mean;
-                m2 += j < P ? __uint_as_float(pc[j][1]) + nj * d * d : 0.f;
-            }
-            const float rstd = 1.0f / sqrtf(m2 * inv_n + p.ln_eps);
-            *(float2*)(smem + LDS_LNS + 8 * tid) = make_float2(-mean * rstd, rstd);
-        }
-        __syncthreads();
-    }
     if constexpr (LNF == 0 || LNF == 2)
         epilogue_rows<OutT, LIN, 4, EPITCH, LNF>(p, smem + wave * (32 * EPITCH), acc, ss, res, do_store, m0 + 128 * grp, n0 + 64 * wc, lane,
                                                  smem + LDS_LNS + 1024 * grp);

@@ -1196,6 +1196,41 @@ def vit_ln_fold_case(B=64, depth=12):
     return run
 
 
+def vit_split_stream_handover_case(B=64):
+    """A folded _VitBlock hands its rows to the next one as two bf16 planes; a block that has no folded form (here: norm2 without an
+    affine) must get fp32 rows back (ops.stream_f32: hi + lo) and run the plain launches -- same logits as with the fold switched off."""
+    def run():
+        import eqxvision_amd as eqv
+        from eqxvision_amd import _lib, nn
+        sd = S.vit_state(1, 224, 16, 768, 2, 12, 4, 10)
+        fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(eqv.models.VisionTransformer(**kw), torch_weights)
+        kw = dict(img_size=224, patch_size=16, embed_dim=768, depth=2, num_heads=12, num_classes=10)
+        x = np.tile(np.asarray(S.synthetic_images(8, 224, seed=5)), (B // 8, 1, 1, 1))
+
+        def go(flag):
+            _lib.set_flag("no_ln_fold", flag)
+            try:
+                net = _load(fac, sd, **kw)
+                object.__setattr__(net.blocks[1], "norm2", nn.LayerNorm(768, eps=net.blocks[1].norm2.eps, elementwise_affine=False))
+                rec = []
+                old = _lib.set_recording(rec)
+                try:
+                    out = _run(net, x, "bf16").cpu().numpy()
+                finally:
+                    _lib.set_recording(old)
+                return out, [n for _, _, n in rec]
+            finally:
+                _lib.set_flag("no_ln_fold", 0)
+        got, names = go(0)
+        plain, names2 = go(1)
+        d = float(np.abs(got - plain).max())
+        handed = names.count("mv_linear_lnout_fwd") == 2 and names.count("mv_linear_lnin_fwd") == 1 and "mv_add_fwd" in names
+        off = "mv_linear_lnout_fwd" not in names2 and "mv_add_fwd" not in names2
+        return {"ok": bool(np.isfinite(got).all() and d <= 8e-3 * max(1.0, float(np.abs(plain).max())) and handed and off), "err": d,
+                "refmax": float(np.abs(plain).max()), "split_stream_handed_back_as_fp32": handed, "fold_off_honoured": off}
+    return run
+
+
 def all_cases(full=True):
     c = [("model/resnet_tiny_bottleneck", resnet_case("bottleneck", (1, 1, 1, 1), 64, 2)),
          ("model/resnet18_64px", resnet_case("basic", (2, 2, 2, 2), 64, 2)),
@@ -1260,6 +1295,7 @@ def all_cases(full=True):
               ("model/resnet50_B3_layer1_recompute_plan_vs_plan_off", resnet50_rc_case()),
               ("model/resnet50_B16_layer1_recompute_plan_vs_plan_off", resnet50_rc_case(B=16)),
               ("model/vit_base_B64_layernorm_fold_vs_fold_off", vit_ln_fold_case()),
+              ("model/vit_split_stream_handed_to_a_block_without_the_fold", vit_split_stream_handover_case()),
               ("model/resnet_2111_160px_B7_mixed_paths", resnet_case("bottleneck", (2, 1, 1, 1), 160, 7, classes=10, full_ref="torch")),
               ("model/resnet_1211_128px_B16_mixed_paths", resnet_case("bottleneck", (1, 2, 1, 1), 128, 16, classes=10, full_ref="torch")),
               ("model/resnext50_32x4d_B2", resnet_case("bottleneck", (3, 4, 6, 3), 224, 2, classes=1000, full_ref="torch",

@@ -636,3 +636,26 @@ def test_layer1_plan_only_where_the_stage_matches(monkeypatch, built_lib):
     assert not any(n in r34 for n in new) and not any(n in wide for n in new)
     r101 = _launch_list(monkeypatch, eqv.models.resnet101, lambda: S.resnet_state(1, "bottleneck", (3, 4, 23, 3), 1000), 4)
     assert [n for n in r101 if n in new] == list(new)
+
+
+def test_vit_layernorm_fold_launch_list(monkeypatch, built_lib):
+    """Round 6's ViT block without LayerNorm launches, host side: where the 256 x 256 GEMM tile is the dispatch's choice for the block's
+    Linears (64 images of 197 tokens and up) proj / fc2 are mv_linear_lnout_fwd (the residual stream as two bf16 planes) and fc1 / every
+    qkv but the first are mv_linear_lnin_fwd; the LayerNorms left are the first block's norm1 and the head's.  Below that size, and with
+    the switch, the LayerNorm launches."""
+    import eqxvision_amd as eqv
+    depth = 3
+    fac = lambda torch_weights=None: eqv.utils.load_torch_weights(
+        eqv.models.VisionTransformer(img_size=224, patch_size=16, embed_dim=768, depth=depth, num_heads=12, num_classes=10), torch_weights)
+    sd = lambda: S.vit_state(1, 224, 16, 768, depth, 12, 4, 10)
+    on = _launch_list(monkeypatch, fac, sd, 64)
+    assert on.count("mv_linear_lnout_fwd") == 2 * depth and on.count("mv_linear_lnin_fwd") == 2 * depth - 1
+    assert on.count("mv_layernorm_fwd") == 2 and on.count("mv_linear_heads_fwd") == 1 and on.count("mv_mha_heads_fwd") == depth   # norm1 of block 0, the head's
+    first_out = on.index("mv_linear_lnout_fwd")
+    assert on.index("mv_layernorm_fwd") < on.index("mv_linear_heads_fwd") < first_out < on.index("mv_linear_lnin_fwd")
+    off = _launch_list(monkeypatch, fac, sd, 64, flags=("no_ln_fold",))
+    assert "mv_linear_lnout_fwd" not in off and "mv_linear_lnin_fwd" not in off
+    assert off.count("mv_layernorm_fwd") == 2 * depth + 1 and off.count("mv_linear_heads_fwd") == depth
+    assert len(off) == len(on) + 2 * depth - 1
+    small = _launch_list(monkeypatch, fac, sd, 8)
+    assert "mv_linear_lnout_fwd" not in small and small.count("mv_layernorm_fwd") == 2 * depth + 1
