@@ -1346,6 +1346,8 @@ def ln_fold_case(M, D, Kp, N2, act=0, tokens=0, seed=0, row_mean=0.0, eps=1e-6):
         ref = O.layernorm_rows(y1, g, be, eps).astype(np.float64) @ w2.astype(np.float64).T + b2
         if act == 2:
             ref = O.gelu_tanh(ref).astype(np.float64)
+        elif act == 1:
+            ref = np.maximum(ref, 0.0)
         wf = bf(w2 * g[None, :])
         cs = wf.astype(np.float64).sum(1).astype(np.float32)
         bfold = (b2.astype(np.float64) + w2.astype(np.float64) @ be.astype(np.float64)).astype(np.float32)
@@ -2559,6 +2561,8 @@ def all_cases():
           ("ln_fold/vit_base_fc2_qkv_heads_ragged", ln_fold_case(65 * 197, 768, 3072, 2304, tokens=197, seed=541)),
           ("ln_fold/vit_small_width_384", ln_fold_case(98 * 197, 384, 384, 1536, act=2, seed=542)),
           ("ln_fold/row_means_of_2_sigma", ln_fold_case(64 * 197 + 31, 768, 768, 768, seed=543, row_mean=2.0)),
+          ("ln_fold/width_512_two_pieces_M_multiple_of_256", ln_fold_case(75 * 256, 512, 512, 1024, act=1, seed=544)),
+          ("ln_fold/width_320_last_tile_one_wave_wide", ln_fold_case(75 * 256 + 1, 320, 256, 640, seed=545, eps=1e-5)),
           ("se_scale/effnet_32_8_silu_sigmoid_112", se_scale_case(3, 112, 112, 32, 8, act1=6, act2=5, seed=590)),
           ("se_scale/effnet_1152_48_7x7", se_scale_case(5, 7, 7, 1152, 48, act1=6, act2=5, seed=591)),
           ("se_scale/mbv3_72_24_relu_hsigmoid", se_scale_case(4, 28, 28, 72, 24, act1=1, act2=4, seed=592)),
