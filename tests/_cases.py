@@ -2365,6 +2365,33 @@ def fuzz_family_cases(n, seed=0):
     return out
 
 
+def fuzz_ln_fold_cases(n, seed=0):
+    """Random shapes for the LayerNorm-fold pair where the library offers it (the 256 x 256 tile is the dispatch's choice for both
+    Linears): stream widths 256 ... 768 in steps of 64 (1 - 3 statistics pieces, last tile 1 - 4 waves wide), ragged row counts,
+    all three activations, row-major and head-major consumers."""
+    L = _lib().load()
+    rng = _rng(seed)
+    out = []
+    tries = 0
+    while len(out) < n and tries < 400:
+        tries += 1
+        D = int(rng.choice([256, 320, 384, 448, 512, 576, 640, 704, 768]))
+        Kp = int(rng.choice([256, 384, 512, 768, 1024]))
+        tokens = int(rng.choice([0, 0, 50, 197]))
+        N2 = 3 * D if tokens else int(rng.choice([256, 512, 768, 1024, 1536]))
+        if tokens and D % 64:
+            continue
+        M = int(rng.integers(150 * 256 // ((D + 255) // 256), 150 * 256 // ((D + 255) // 256) + 3000))
+        if tokens:
+            M = (M // tokens + 1) * tokens
+        if not (L.mv_linear_lnout_supported(M, D, Kp, 1) and L.mv_linear_lnin_supported(M, N2, D, tokens, 64 if tokens else 0, 1)):
+            continue
+        act = int(rng.integers(0, 3)) if not tokens else 0
+        out.append((f"fuzz/ln_fold_{len(out)}_M{M}_D{D}_K{Kp}_N{N2}_act{act}_tok{tokens}",
+                    ln_fold_case(M, D, Kp, N2, act=act, tokens=tokens, seed=900 + len(out), eps=float(rng.choice([1e-5, 1e-6])))))
+    return out
+
+
 def fuzz_stochastic_cases(n, seed=0):
     """Random shapes for the in-kernel / window-layout / per-token draws of the training-mode transformers: attention dropout
     (both qkv layouts, with and without the probabilities), Dropout in window layout, key splits."""
@@ -2835,4 +2862,5 @@ def all_cases():
     c += fuzz_misc_cases(24, seed=5)
     c += fuzz_family_cases(42, seed=6)
     c += fuzz_stochastic_cases(18, seed=7)
+    c += fuzz_ln_fold_cases(6, seed=8)
     return c
