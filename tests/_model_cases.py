@@ -1152,7 +1152,7 @@ def resnet50_rc_case(B=3, size=224):
     return run
 
 
-def vit_ln_fold_case(B=64, depth=12):
+def vit_ln_fold_case(B=64, depth=12, stress=False):
     """ViT-B/16 with the LayerNorms of its blocks folded into the GEMM epilogues on either side (round 6: _VitBlock._ln_fold,
     ops.linear_lnout / linear_lnin) against the same network with the fold switched off ("no_ln_fold": LayerNorm launches): both
     within the bound of the fp32 restatement on the 8 distinct images of the batch, the two within 8e-3 of each other (two different sets of bf16 rounding points), and the
@@ -1161,6 +1161,12 @@ def vit_ln_fold_case(B=64, depth=12):
         import eqxvision_amd as eqv
         from eqxvision_amd import _lib
         sd = S.vit_state(1, 224, 16, 768, depth, 12, 4, 1000)
+        if stress:      # a residual stream shaped like a trained one: every row offset by ~0.4 of its standard deviation and three
+                        # "massive activation" channels at 20 (the fold rounds y, not y - mean, to bf16; the un-fused path rounds LN(y))
+            pe = np.array(sd["pos_embed"], np.float32, copy=True)
+            pe += np.float32(0.7)
+            pe[..., [5, 301, 640]] += np.float32(20.0)
+            sd = type(sd)((k, pe if k == "pos_embed" else v) for k, v in sd.items())
         fac = lambda torch_weights=None, **kw: eqv.utils.load_torch_weights(eqv.models.VisionTransformer(**kw), torch_weights)
         kw = dict(img_size=224, patch_size=16, embed_dim=768, depth=depth, num_heads=12, num_classes=1000)
         x8 = S.synthetic_images(8, 224, seed=3)
@@ -1295,6 +1301,7 @@ def all_cases(full=True):
               ("model/resnet50_B3_layer1_recompute_plan_vs_plan_off", resnet50_rc_case()),
               ("model/resnet50_B16_layer1_recompute_plan_vs_plan_off", resnet50_rc_case(B=16)),
               ("model/vit_base_B64_layernorm_fold_vs_fold_off", vit_ln_fold_case()),
+              ("model/vit_B64_depth4_layernorm_fold_row_means_and_massive_channels", vit_ln_fold_case(depth=4, stress=True)),
               ("model/vit_split_stream_handed_to_a_block_without_the_fold", vit_split_stream_handover_case()),
               ("model/resnet_2111_160px_B7_mixed_paths", resnet_case("bottleneck", (2, 1, 1, 1), 160, 7, classes=10, full_ref="torch")),
               ("model/resnet_1211_128px_B16_mixed_paths", resnet_case("bottleneck", (1, 2, 1, 1), 128, 16, classes=10, full_ref="torch")),
