@@ -289,6 +289,8 @@ def as_rows(x: Act, keep_fp32: bool = False) -> Act:
 
 def to_user(x: Act) -> torch.Tensor:
     """Act -> fp32 torch tensor in the reference's logical layout (batch axis kept iff batched)."""
+    if x.ln is not None:            # a residual stream kept as two bf16 planes never leaves as its high plane alone
+        x = stream_f32(x)
     if x.kind == "map":
         B, H, W, C = x.t.shape
         y = empty((B, C, H, W), torch.float32)
