@@ -3,7 +3,7 @@
 (any tap count / stride / padding / dilation / residual / activation / output dtype) and linears.  Finds the shapes
 where a specialised kernel is chosen but mishandles an edge (ragged rows, channel tails, tiny reductions).
 usage: fuzz_ops.py [N_CASES] [SEED]   (MISC=1: attention / pools / fused entries; FAMILY=1: depthwise, grouped, resize, training-mode
-moments and dropout; STOCHASTIC=1: attention dropout, window-layout dropout, key splits)"""
+moments and dropout; STOCHASTIC=1: attention dropout, window-layout dropout, key splits; LNFOLD=1: the LayerNorm-fold Linear pair)"""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import _cases as T
@@ -13,7 +13,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 fails = 0
 kernels = {}
 flags = tuple(f for f in os.environ.get("FUZZ_FLAGS", "").split(",") if f)      # e.g. FUZZ_FLAGS=igemm8=3 forces a kernel family
-cases = T.fuzz_stochastic_cases(n, seed) if os.environ.get("STOCHASTIC") else T.fuzz_family_cases(n, seed) if os.environ.get("FAMILY") else T.fuzz_misc_cases(n, seed) if os.environ.get("MISC") else T.fuzz_cases(n, seed, mfma_only=bool(os.environ.get("MFMA_ONLY")),
+cases = T.fuzz_ln_fold_cases(n, seed) if os.environ.get("LNFOLD") else T.fuzz_stochastic_cases(n, seed) if os.environ.get("STOCHASTIC") else T.fuzz_family_cases(n, seed) if os.environ.get("FAMILY") else T.fuzz_misc_cases(n, seed) if os.environ.get("MISC") else T.fuzz_cases(n, seed, mfma_only=bool(os.environ.get("MFMA_ONLY")),
                                                                                flags=flags)
 for name, fn in cases:
     try:
